@@ -1,0 +1,555 @@
+"""CPU oracle for the GP-posterior + acquisition hot path of `bayes_optim` (NumPy/SciPy restatement).
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import it; the product path (`bayesian-optimization_amd/`) never
+does and fails loudly when `libbogp.so` is missing.
+
+Parity status: PINNED BY IMPORT.  The reference's own tests hold no numeric vectors for this path
+(every GP assertion is "runs without raising"), so the oracle is pinned against outputs
+of the reference itself: `oracle/make_golden.py` imports `/root/reference/bayes_optim` in the build
+container, runs it on seeded inputs and commits inputs + outputs under `tests/golden/*.npz`;
+`tests/test_oracle_golden.py` checks every function below against those vectors (≤1e-12 relative).
+
+Every function cites the reference lines it restates (paths relative to /root/reference/bayes_optim).
+All arithmetic is float64.  The third-party numerics the reference leans on (unpinned there,
+`setup.py:24-40` gives lower bounds only) are NumPy/SciPy: versions used to make the goldens are recorded
+inside each .npz.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+from scipy.linalg import cho_solve, cholesky, qr, solve_triangular
+from scipy.special import ndtr
+
+# kernel ids shared with include/bogp.h
+KERNEL_SE = 0
+KERNEL_MATERN12 = 1
+KERNEL_MATERN32 = 2
+KERNEL_MATERN52 = 3
+KERNEL_NAMES = {"squared_exponential": KERNEL_SE, "matern": KERNEL_MATERN32}
+
+# estimation modes (surrogate/gaussian_process/gpr.py:252-263)
+MODE_NOISELESS = 0
+MODE_NOISY = 1
+MODE_NOISE_ESTIM = 2
+
+# acquisition ids shared with include/bogp.h
+ACQ_EI = 0
+ACQ_EPSILON_PI = 1
+ACQ_UCB = 2
+ACQ_MGFI = 3
+
+_SQRT3 = math.sqrt(3)
+_SQRT5 = math.sqrt(5)
+_NORM_PDF_C = np.sqrt(2 * np.pi)  # scipy.stats._continuous_distns._norm_pdf_C
+
+
+# ----------------------------------------------------------------------------------------------
+# a1 / a2: componentwise distances and correlation functions
+# ----------------------------------------------------------------------------------------------
+def l1_cross_distances(X: np.ndarray, Y: np.ndarray) -> np.ndarray:
+    """|X[:,None,:] - Y[None,:,:]| flattened to (M*N, d).  gpr.py:42-47."""
+    D = X[:, np.newaxis, :] - Y[np.newaxis, :, :]
+    D = np.abs(D, D)
+    return D.reshape((-1, X.shape[1]))
+
+
+def l1_pair_distances(X: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Strict-upper-triangle pair list D (N(N-1)/2, d) and index pairs ij.  gpr.py:48-61 (vectorised:
+    same rows in the same order as the reference's Python loop)."""
+    n = X.shape[0]
+    i, j = np.triu_indices(n, 1)
+    return np.abs(X[i] - X[j]), np.c_[i, j]
+
+
+def corr(kernel: int, theta: np.ndarray, d: np.ndarray) -> np.ndarray:
+    """Stationary correlation of componentwise distances d (rows) with weights theta.
+
+    SE: kernel.py:289-329  exp(-sum_k theta_k d_k^2)   (isotropic if theta.size == 1)
+    Matern: kernel.py:159-207  dists = sqrt(sum_k theta_k d_k^2);
+        nu=1/2 exp(-dists) (:190); nu=3/2 K=dists*sqrt(3); (1+K)exp(-K) (:193-196);
+        nu=5/2 K=dists*sqrt(5); (1+K+K^2/3)exp(-K) (:198-200).
+    """
+    theta = np.asarray(theta, dtype=np.float64)
+    d = np.asarray(d, dtype=np.float64)
+    n_features = d.shape[1] if d.ndim > 1 else 1
+    if theta.size == 1:
+        s = theta[0] * np.sum(d**2, axis=1)
+    else:
+        if theta.size != n_features:
+            raise ValueError("Length of theta must be 1 or %s" % n_features)
+        s = np.sum(theta.reshape(1, n_features) * d**2, axis=1)
+    if kernel == KERNEL_SE:
+        return np.exp(-s)
+    dists = np.sqrt(s)
+    if kernel == KERNEL_MATERN12:
+        return np.exp(-dists)
+    if kernel == KERNEL_MATERN32:
+        K = dists * _SQRT3
+        return (1.0 + K) * np.exp(-K)
+    if kernel == KERNEL_MATERN52:
+        K = dists * _SQRT5
+        return (1.0 + K + K**2 / 3.0) * np.exp(-K)
+    raise ValueError("unknown kernel id %r" % kernel)
+
+
+def corr_grad_theta(kernel: int, theta: np.ndarray, X: np.ndarray, R0: np.ndarray) -> np.ndarray:
+    """dR0/dtheta_k as an (N, N, d) tensor.  gpr.py:736-770.
+
+    SE: -diff * R0 (:747-748); Matern-3/2: -3 exp(-sqrt(3) D) diff / 2 (:750-757).
+    The reference leaves Matern-5/2 unimplemented (`pass`, :758-759); the formula used here for it,
+    -(5/6)(1 + sqrt(5) D) exp(-sqrt(5) D) diff, is the analytic derivative of kernel.py:198-200 and is an
+    extension (flagged `extension` wherever it is tested; not covered by reference goldens).
+    Matern-1/2 in the reference divides by D (nan on the diagonal, :754-755); restated as-is off-diagonal
+    with the diagonal set to 0 (its limit), also an extension.
+    """
+    diff = (X[:, np.newaxis, :] - X[np.newaxis, :, :]) ** 2.0
+    if kernel == KERNEL_SE:
+        return -diff * R0[..., np.newaxis]
+    D = np.sqrt(np.sum(theta * diff, axis=-1))
+    if kernel == KERNEL_MATERN32:
+        return -3 * np.exp(-_SQRT3 * D)[..., np.newaxis] * diff / 2.0
+    if kernel == KERNEL_MATERN52:
+        return (-(5.0 / 6.0) * (1.0 + _SQRT5 * D) * np.exp(-_SQRT5 * D))[..., np.newaxis] * diff
+    if kernel == KERNEL_MATERN12:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            g = -0.5 * (R0 / D)[..., np.newaxis] * diff
+        g[~np.isfinite(g)] = 0.0
+        return g
+    raise ValueError("unknown kernel id %r" % kernel)
+
+
+def correlation_matrix(kernel: int, theta: np.ndarray, X: np.ndarray) -> np.ndarray:
+    """Symmetric R0 with unit diagonal scattered from the pair list.  gpr.py:772-782."""
+    n = X.shape[0]
+    D, ij = l1_pair_distances(X)
+    r = corr(kernel, theta, D)
+    R = np.eye(n)
+    R[ij[:, 0], ij[:, 1]] = r
+    R[ij[:, 1], ij[:, 0]] = r
+    return R
+
+
+# ----------------------------------------------------------------------------------------------
+# a3 trend bases (surrogate/gaussian_process/trend.py)
+# ----------------------------------------------------------------------------------------------
+TREND_CONSTANT = 0
+TREND_LINEAR = 1
+TREND_QUADRATIC = 2
+
+
+def trend_F(trend: int, X: np.ndarray) -> np.ndarray:
+    """Basis matrix F(X).  constant trend.py:79-82, linear :104-107, quadratic :130-136 (all x_i x_j, j >= i)."""
+    X = np.atleast_2d(X)
+    n = X.shape[0]
+    if trend == TREND_CONSTANT:
+        return np.ones((n, 1))
+    if trend == TREND_LINEAR:
+        return np.c_[np.ones(n), X]
+    if trend == TREND_QUADRATIC:
+        f = np.c_[np.ones(n), X]
+        for k in range(X.shape[1]):
+            f = np.c_[f, X[:, k, np.newaxis] * X[:, k:]]
+        return f
+    raise ValueError("unknown trend id %r" % trend)
+
+
+def trend_jacobian(trend: int, x: np.ndarray) -> np.ndarray:
+    """Jacobian of the basis at ONE point, (p, d) numerator layout.  trend.py:83-85, 109-112, 135-138."""
+    x = np.atleast_2d(x)
+    d = x.shape[1]
+    if trend == TREND_CONSTANT:
+        return np.zeros((1, d))
+    if trend == TREND_LINEAR:
+        return np.r_[np.zeros((1, d)), np.eye(d)]
+    if trend == TREND_QUADRATIC:
+        raise NotImplementedError("quadratic_trend.Jacobian raises in the reference (trend.py:138-139)")
+    raise ValueError("unknown trend id %r" % trend)
+
+
+# ----------------------------------------------------------------------------------------------
+# fitted state
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class GPState:
+    """Everything `predict`/`gradient`/acquisitions read.  Mirrors the attributes `fit` sets,
+    gpr.py:402-415 (+ compute_beta_gamma :784-788)."""
+
+    kernel: int
+    mode: int
+    X: np.ndarray  # (N, d)
+    y: np.ndarray  # (N, n_t)
+    theta: np.ndarray  # (d,) or (1,)
+    sigma2: np.ndarray  # (n_t,)
+    noise_var: object
+    C: np.ndarray  # (N, N) lower Cholesky factor L of the (normalised) R
+    rho: np.ndarray
+    Yt: np.ndarray
+    gamma: np.ndarray  # (N, n_t)
+    trend: int = TREND_CONSTANT
+    estimate_trend: bool = False
+    beta: Optional[np.ndarray] = None  # (p, n_t): fixed (simple kriging) or GLS estimate
+    Ft: Optional[np.ndarray] = None
+    G: Optional[np.ndarray] = None
+    Q: Optional[np.ndarray] = None
+    llf: float = float("nan")
+    extra: Dict = field(default_factory=dict)
+
+
+def compute_aux_var(R, y, F=None, mean_vec=None):
+    """L=chol(R); Yt=L^-1 y; OK/UK: Ft=L^-1 F, Q,G=qr(Ft), rho=Yt-QQ^T Yt; SK: rho=Yt-L^-1 mean(X).
+    gpr.py:790-811."""
+    L = cholesky(R, lower=True)
+    Yt = solve_triangular(L, y, lower=True)
+    if F is not None:
+        Ft = solve_triangular(L, F, lower=True)
+        Q, G = qr(Ft, mode="economic")
+        rho = Yt - Q.dot(Q.T).dot(Yt)
+    else:
+        rho = Yt - solve_triangular(L, mean_vec, lower=True)
+        Ft, Q, G = None, None, None
+    return L, Ft, Yt, Q, G, rho
+
+
+def log_likelihood_concentrated(
+    par: np.ndarray,
+    X: np.ndarray,
+    y: np.ndarray,
+    kernel: int,
+    mode: int,
+    noise_var=0.0,
+    trend: int = TREND_CONSTANT,
+    estimate_trend: bool = False,
+    beta=None,
+    eval_grad: bool = False,
+    env: Optional[dict] = None,
+):
+    """Concentrated log-likelihood (+ gradient w.r.t. `par`, NOT log10 par).  gpr.py:920-1040.
+
+    Parameter layouts (gpr.py:1073-1086): noiseless [theta]; noisy [theta, sigma2]; noise_estim [theta, alpha].
+    Returns llf (summed over targets) or (llf, grad (n_par,)); -inf (and zeros((n_par,1))) on Cholesky
+    failure or llf > 0 (:981-982).
+    """
+    par = np.asarray(par, dtype=np.float64)
+    y = y.reshape(len(y), -1)
+    n, n_par, n_t = X.shape[0], len(par), y.shape[1]
+    F = trend_F(trend, X) if estimate_trend else None
+    mean_vec = None
+    if not estimate_trend:
+        b = np.asarray(beta if beta is not None else 0.0, dtype=np.float64)
+        Fx = trend_F(trend, X)
+        b = np.full((Fx.shape[1], 1), float(b)) if b.ndim == 0 else b.reshape(Fx.shape[1], -1)
+        mean_vec = Fx.dot(b)  # trend.py:34-37
+
+    llf = None
+    try:
+        if mode == MODE_NOISELESS:  # :931-947
+            theta = par
+            nv = 0
+            R0 = correlation_matrix(kernel, theta, X)
+            with np.errstate(all="raise"):
+                L, Ft, Yt, Q, G, rho = compute_aux_var(R0, y, F, mean_vec)
+                k = np.linalg.matrix_rank(Q.dot(Q.T)) if Q is not None else 0
+                sigma2 = (rho**2.0).sum(axis=0) / (n - k)
+                llf = -0.5 * (n * np.log(2.0 * np.pi * sigma2) + 2.0 * np.log(np.diag(L)).sum() + n)
+            sigma2_total = sigma2
+        elif mode == MODE_NOISE_ESTIM:  # :949-961
+            theta, alpha = par[:-1], par[-1]
+            R0 = correlation_matrix(kernel, theta, X)
+            R = alpha * R0 + (1 - alpha) * np.eye(n)
+            L, Ft, Yt, Q, G, rho = compute_aux_var(R, y, F, mean_vec)
+            sigma2_total = (rho**2.0).sum(axis=0) / n
+            sigma2, nv = alpha * sigma2_total, (1 - alpha) * sigma2_total
+            llf = -0.5 * (n * np.log(2.0 * np.pi * sigma2_total) + 2.0 * np.log(np.diag(L)).sum() + n)
+        elif mode == MODE_NOISY:  # :963-979
+            theta, sigma2 = par[:-1], par[-1]
+            nv = noise_var
+            sigma2_total = sigma2 + nv
+            R0 = correlation_matrix(kernel, theta, X)
+            C = sigma2 * R0 + nv * np.eye(n)
+            R = C / sigma2_total
+            sigma2 = np.repeat(sigma2, n_t)
+            L, Ft, Yt, Q, G, rho = compute_aux_var(R, y, F, mean_vec)
+            llf = -0.5 * (
+                n * np.log(2.0 * np.pi * sigma2_total)
+                + 2.0 * np.log(np.diag(L)).sum()
+                + np.diag(np.dot(rho.T, rho)) / sigma2_total
+            )
+        else:
+            raise ValueError("unknown mode")
+    except (np.linalg.LinAlgError, ValueError, FloatingPointError):
+        llf = None
+
+    if llf is None or np.any(np.asarray(llf) > 0) or not np.all(np.isfinite(np.asarray(llf))):
+        # :981-982 (non-finite llf cannot pass `any(llf > 0)` in the reference either way; a NaN llf
+        # there comes from a LinAlgError-free but broken factorisation and is treated as failure here)
+        return (-np.inf, np.zeros((n_par, 1))) if eval_grad else -np.inf
+
+    if env is not None:  # :984-992
+        env.update(sigma2=np.atleast_1d(sigma2), noise_var=nv, rho=rho, Yt=Yt, C=L, Ft=Ft, G=G, Q=Q, R0=R0)
+
+    llf = np.atleast_1d(llf)
+    if not eval_grad:
+        return llf.sum()
+
+    # gradient :994-1038
+    gamma = solve_triangular(L.T, rho).reshape(-1, n_t)
+    Rinv = cho_solve((L, True), np.eye(n))
+    iu = np.triu_indices(n, 1)
+    Rinv_upper = Rinv[iu]
+    _upper = gamma.dot(gamma.T)[iu]
+    g = np.zeros((n_par, n_t))
+    if mode == MODE_NOISELESS:
+        T = corr_grad_theta(kernel, theta, X, R0)
+        for i in range(n_par):
+            Gu = T[:, :, i][iu]
+            g[i, :] = np.sum(_upper * Gu) / sigma2 - np.sum(Rinv_upper * Gu)
+    elif mode == MODE_NOISE_ESTIM:
+        T = alpha * corr_grad_theta(kernel, theta, X, R0)
+        for i in range(n_par - 1):
+            Gu = T[:, :, i][iu]
+            g[i, :] = np.sum(_upper * Gu) / sigma2_total - np.sum(Rinv_upper * Gu)
+        R_dv = R0 - np.eye(n)
+        g[n_par - 1, :] = -0.5 * (np.sum(Rinv * R_dv) - np.diag(gamma.T.dot(R_dv.dot(gamma))) / sigma2_total)
+    else:
+        gamma_ = gamma / sigma2_total
+        Cinv = Rinv / sigma2_total
+        T = sigma2_total * corr_grad_theta(kernel, theta, X, R0)
+        T = np.concatenate([T, R0[..., np.newaxis]], axis=2)
+        for i in range(n_par):
+            Cg = T[:, :, i]
+            g[i, :] = -0.5 * (np.sum(Cinv * Cg) - np.diag(gamma_.T.dot(Cg).dot(gamma_)))
+    return llf.sum(), g.sum(axis=1)
+
+
+def make_state(
+    par, X, y, kernel, mode, noise_var=0.0, trend=TREND_CONSTANT, estimate_trend=False, beta=None
+) -> GPState:
+    """Pin a fitted state at given hyper-parameters without running the MLE: one likelihood call with an
+    env dict, then copy env as `fit` does (gpr.py:402-415) and `compute_beta_gamma` (:784-788)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64).reshape(len(X), -1)
+    env: dict = {}
+    llf = log_likelihood_concentrated(
+        par, X, y, kernel, mode, noise_var, trend, estimate_trend, beta, eval_grad=False, env=env
+    )
+    if not np.isfinite(llf):
+        raise np.linalg.LinAlgError("likelihood is -inf at the requested parameters")
+    n_theta = len(par) if mode == MODE_NOISELESS else len(par) - 1
+    theta = np.asarray(par[:n_theta], dtype=np.float64)
+    L, rho, Yt = env["C"], env["rho"], env["Yt"]
+    p = trend_F(trend, X[:1]).shape[1]
+    if estimate_trend:
+        b = solve_triangular(env["G"], env["Q"].T.dot(Yt))  # :785-787
+    else:
+        b0 = np.asarray(beta if beta is not None else 0.0, dtype=np.float64)
+        b = np.full((p, 1), float(b0)) if b0.ndim == 0 else b0.reshape(p, -1)
+    gamma = solve_triangular(L.T, rho).reshape(-1, y.shape[1])  # :788
+    return GPState(
+        kernel=kernel, mode=mode, X=X, y=y, theta=theta, sigma2=np.atleast_1d(env["sigma2"]).astype(float),
+        noise_var=env["noise_var"], C=L, rho=rho, Yt=Yt, gamma=gamma, trend=trend,
+        estimate_trend=estimate_trend, beta=b, Ft=env["Ft"], G=env["G"], Q=env["Q"], llf=float(llf),
+    )  # fmt: skip
+
+
+# ----------------------------------------------------------------------------------------------
+# a3 / a4: posterior mean and MSE
+# ----------------------------------------------------------------------------------------------
+def predict(st: GPState, Xs: np.ndarray, eval_MSE: bool = True):
+    """mu (M, n_t) and MSE (M, n_t) at candidates Xs.  gpr.py:486-510 operation for operation:
+    materialised |dx| temporary -> corr -> r.gamma -> solve_triangular -> (1 - sum rt^2 + sum u^2) sigma2,
+    negatives clipped to 0.  The caller chunks (the reference's batch_size branch is dead, :513-535)."""
+    Xs = np.ascontiguousarray(Xs, dtype=np.float64)
+    M, N = Xs.shape[0], st.X.shape[0]
+    dx = l1_cross_distances(Xs, st.X)
+    r = corr(st.kernel, st.theta, dx).reshape(M, N)
+    mean = trend_F(st.trend, Xs).dot(st.beta)
+    mu = (mean + r.dot(st.gamma)).reshape(M, -1)
+    if not eval_MSE:
+        return mu
+    rt = solve_triangular(st.C, r.T, lower=True)
+    if st.estimate_trend:
+        f = trend_F(st.trend, Xs)
+        u = solve_triangular(st.G.T, np.dot(st.Ft.T, rt) - f.T, lower=True)
+    else:
+        u = np.zeros((1, M))
+    MSE = np.dot((1.0 - (rt**2.0).sum(axis=0) + (u**2.0).sum(axis=0)).reshape(M, -1), st.sigma2.reshape(1, -1))
+    MSE[MSE < 0.0] = 0.0
+    return mu, MSE
+
+
+def predict_chunked(st: GPState, Xs: np.ndarray, chunk: int = 1024):
+    mus, mses = [], []
+    for a in range(0, len(Xs), chunk):
+        m, s = predict(st, Xs[a : a + chunk])
+        mus.append(m)
+        mses.append(s)
+    return np.concatenate(mus), np.concatenate(mses)
+
+
+# ----------------------------------------------------------------------------------------------
+# a11: input-gradient of the posterior at ONE point
+# ----------------------------------------------------------------------------------------------
+def corr_dx(st: GPState, x: np.ndarray, r: np.ndarray) -> np.ndarray:
+    """dr/dx as (d, N).  gpr.py:600-661: SE -2 r theta diff (:635-636); Matern-3/2
+    diff theta / D * (-3 D exp(-sqrt3 D)) (:638-646) -- the 0/0 at diff = 0 raises a warning that the
+    reference converts to an all-zero gradient (:658-659).  Matern-5/2 is `pass` in the reference
+    (:647-648, UnboundLocalError); the analytic form -(5/3)(1+sqrt5 D) exp(-sqrt5 D) theta diff is an extension."""
+    x = np.atleast_2d(x)
+    diff = (x - st.X).T
+    theta = st.theta.reshape(-1, 1)
+    if st.kernel == KERNEL_SE:
+        return -2 * r * (theta * diff)
+    D = np.sqrt(np.sum(theta * diff**2.0, axis=0))
+    if st.kernel == KERNEL_MATERN32:
+        with np.errstate(all="raise"):
+            try:
+                grad = diff * theta / D
+                grad *= -3.0 * D * np.exp(-_SQRT3 * D)
+            except FloatingPointError:
+                grad = np.zeros(diff.shape)
+        return grad
+    if st.kernel == KERNEL_MATERN52:
+        return (-(5.0 / 3.0) * (1.0 + _SQRT5 * D) * np.exp(-_SQRT5 * D)) * (theta * diff)
+    if st.kernel == KERNEL_MATERN12:
+        with np.errstate(all="raise"):
+            try:
+                grad = -diff * theta / D * r
+            except FloatingPointError:
+                grad = np.zeros(diff.shape)
+        return grad
+    raise ValueError
+
+
+def gradient(st: GPState, x: np.ndarray):
+    """(d mu/dx (d, n_t), d MSE/dx (d, 1)) at a single row x.  gpr.py:537-576."""
+    x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+    N = st.X.shape[0]
+    f = trend_F(st.trend, x).reshape(-1, 1)
+    f_dx = trend_jacobian(st.trend, x)
+    d_ = l1_cross_distances(x, st.X)
+    r = corr(st.kernel, st.theta, d_).reshape(1, N)
+    r_dx = corr_dx(st, x, r).T  # (N, d)
+    y_dx = np.dot(st.beta.T, f_dx) + st.gamma.T.dot(r_dx)
+    rt = solve_triangular(st.C, r.T, lower=True)
+    rt_dx = solve_triangular(st.C, r_dx, lower=True)
+    mse_dx = -1.0 * np.dot(rt.T, rt_dx)
+    if st.estimate_trend:
+        u = np.dot(st.Ft.T, rt) - f
+        u_dx = np.dot(st.Ft.T, rt_dx) - f_dx
+        Ft2inv = np.linalg.inv(np.dot(st.Ft.T, st.Ft))
+        mse_dx += u.T.dot(Ft2inv).dot(u_dx)
+    mse_dx = 2.0 * st.sigma2 * mse_dx
+    return y_dx.T, mse_dx.T
+
+
+# ----------------------------------------------------------------------------------------------
+# a5-a10: acquisition functions, batched = "row i is what the single-point call returns for row i"
+# (the reference's EI/EpsilonPI/MGFI raise on >1 row, so the batched semantics
+# are the per-row map with the guards turned into per-row selects).
+# ----------------------------------------------------------------------------------------------
+def _yhat_sd(mu, mse, minimize):
+    """acquisition_fun.py:52-64: y_hat negated iff maximising; sd = sqrt(MSE)."""
+    y_hat = mu if minimize else -1 * mu
+    return y_hat, np.sqrt(mse)
+
+
+def plugin_value(y_train: np.ndarray, minimize: bool, plugin=None) -> float:
+    """acquisition_fun.py:96-104."""
+    if plugin is None:
+        return float(np.min(y_train) if minimize else -1.0 * np.max(y_train))
+    return float(plugin if minimize else -1.0 * plugin)
+
+
+def _pdf(z):
+    return np.exp(-(z**2) / 2.0) / _NORM_PDF_C  # scipy.stats.norm.pdf (_norm_pdf)
+
+
+def ei(mu, mse, plugin, sigma2, minimize=True):
+    """Expected improvement per row.  acquisition_fun.py:153-176: guard sd/sqrt(sigma2) < 1e-6 -> 0;
+    (plugin - y)Phi(z) + sd phi(z)."""
+    y_hat, sd = _yhat_sd(np.asarray(mu, float).ravel(), np.asarray(mse, float).ravel(), minimize)
+    out = np.zeros_like(sd)
+    ok = ~(sd / np.sqrt(sigma2) < 1e-6)
+    xcr_ = plugin - y_hat[ok]
+    xcr = xcr_ / sd[ok]
+    out[ok] = xcr_ * ndtr(xcr) + sd[ok] * _pdf(xcr)
+    return out
+
+
+def epsilon_pi(mu, mse, plugin, epsilon=1e-10, minimize=True):
+    """acquisition_fun.py:208-217: coef = 1-eps if y>0 else 1+eps; Phi((plugin - coef*y)/sd).  No guard:
+    sd = 0 gives Phi(+-inf) in {0, 1} (and nan for 0/0), reproduced as IEEE division does."""
+    y_hat, sd = _yhat_sd(np.asarray(mu, float).ravel(), np.asarray(mse, float).ravel(), minimize)
+    coef = np.where(y_hat > 0, 1 - epsilon, 1 + epsilon)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        xcr = (plugin - coef * y_hat) / sd
+    return ndtr(xcr)
+
+
+def ucb(mu, mse, alpha=0.5, minimize=True):
+    """acquisition_fun.py:127-135: y_hat + alpha*sd (no sign flip for minimisation; maximised as-is)."""
+    y_hat, sd = _yhat_sd(np.asarray(mu, float).ravel(), np.asarray(mse, float).ravel(), minimize)
+    return y_hat + alpha * sd
+
+
+def mgfi(mu, mse, plugin, t=1.0, minimize=True):
+    """acquisition_fun.py:265-290: t clamped to 22.36 (:260-263); guard np.isclose(sd, 0) -> 0;
+    Phi(beta') exp(t (plugin - y - 1) + t^2 sd^2 / 2); overflow/invalid (warnings-as-errors) -> 0; inf -> 0."""
+    t = min(t, 22.36)
+    y_hat, sd = _yhat_sd(np.asarray(mu, float).ravel(), np.asarray(mse, float).ravel(), minimize)
+    out = np.zeros_like(sd)
+    ok = ~np.isclose(sd, 0)
+    yh, s = y_hat[ok], sd[ok]
+    with np.errstate(over="ignore", invalid="ignore", under="ignore"):
+        y_hat_p = yh - t * s**2.0
+        beta_p = (plugin - y_hat_p) / s
+        term = t * (plugin - yh - 1)
+        e = np.exp(term + t**2.0 * s**2.0 / 2.0)
+        f_ = ndtr(beta_p) * e
+    f_[~np.isfinite(e)] = 0.0  # exp overflow raises under warnings-as-errors -> 0.0 (:286-290)
+    f_[~np.isfinite(f_)] = 0.0
+    out[ok] = f_
+    return out
+
+
+def acquisition(acq_id: int, par: float, mu, mse, plugin, sigma2, minimize=True):
+    if acq_id == ACQ_EI:
+        return ei(mu, mse, plugin, sigma2, minimize)
+    if acq_id == ACQ_EPSILON_PI:
+        return epsilon_pi(mu, mse, plugin, par, minimize)
+    if acq_id == ACQ_UCB:
+        return ucb(mu, mse, par, minimize)
+    if acq_id == ACQ_MGFI:
+        return mgfi(mu, mse, plugin, par, minimize)
+    raise ValueError("unknown acquisition id %r" % acq_id)
+
+
+def nan_first_argmax(v: np.ndarray) -> int:
+    """np.argmax semantics (first maximal element; a NaN, if any, wins at its first position)."""
+    return int(np.argmax(v))
+
+
+def sweep(
+    st: GPState,
+    Xs: np.ndarray,
+    acq: Sequence[Tuple[int, float]],
+    plugin: Optional[float] = None,
+    minimize: bool = True,
+    chunk: int = 1024,
+    return_values: bool = False,
+):
+    """The M-candidate argmax sweep: posterior (chunked like the reference caller must) ->
+    q acquisition criteria sharing (mu, MSE) -> np.argmax per criterion.  Returns (best_val (q,), best_idx (q,))."""
+    mu, mse = predict_chunked(st, Xs, chunk)
+    pl = plugin_value(st.y, minimize, plugin)
+    vals = [acquisition(a, p, mu[:, 0], mse[:, 0], pl, st.sigma2[0], minimize) for a, p in acq]
+    idx = np.array([nan_first_argmax(v) for v in vals], dtype=np.int64)
+    best = np.array([v[i] for v, i in zip(vals, idx)])
+    if return_values:
+        return best, idx, vals, mu, mse
+    return best, idx

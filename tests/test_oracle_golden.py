@@ -1,0 +1,177 @@
+"""The oracle (oracle/gp_oracle.py) against golden vectors produced by importing the reference
+(oracle/make_golden.py).  CPU only.  Tolerances: 1e-12 relative on values the reference computes with the
+same LAPACK/NumPy calls (they are in practice bit-identical); argmax indices exact."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, state_from_golden
+from oracle import gp_oracle as O
+
+RT = 1e-12
+STATE_FILES = ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G3_m52_sk_noisy", "G4_se_ok_noiseless", "G5_se_sk_noise_estim", "G7_edges"]
+
+
+def close(a, b, rtol=RT, atol=0.0):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    np.testing.assert_allclose(a.reshape(b.shape), b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("name", STATE_FILES)
+def test_state_matches_reference(name):
+    g = load_golden(name)
+    st = state_from_golden(g)
+    close(st.llf, g["llf"])
+    close(st.C, g["C"])
+    close(st.gamma, g["gamma"], rtol=1e-10)
+    close(st.rho, g["rho"], rtol=1e-10, atol=1e-13)
+    close(st.Yt, g["Yt"], rtol=1e-10, atol=1e-13)
+    close(st.sigma2, g["sigma2"])
+    close(st.beta, g["beta"], rtol=1e-10)
+    if st.estimate_trend:
+        close(st.Ft, g["Ft"])
+        close(st.G, g["G"])
+        close(st.Q, g["Q"])
+
+
+@pytest.mark.parametrize("name", STATE_FILES)
+def test_predict_matches_reference(name):
+    g = load_golden(name)
+    st = state_from_golden(g)
+    mu, mse = O.predict(st, g["Xs"])
+    close(mu, g["mu"], rtol=1e-10, atol=1e-13)
+    close(mse, g["mse"], rtol=1e-9, atol=1e-13)
+    # chunked evaluation is the same function row by row
+    mu2, mse2 = O.predict_chunked(st, g["Xs"], chunk=37)
+    close(mu2, g["mu"], rtol=1e-10, atol=1e-13)
+    close(mse2, g["mse"], rtol=1e-9, atol=1e-13)
+
+
+def _acq_cases(g, prefix=""):
+    for k in g:
+        if not k.startswith(prefix) or k.startswith(prefix + "argmax_") or k.startswith("dx_"):
+            continue
+        base = k[len(prefix):]
+        if base == "EI":
+            yield k, O.ACQ_EI, 0.0
+        elif base.startswith("EpsilonPI_"):
+            yield k, O.ACQ_EPSILON_PI, float(base.split("_")[1])
+        elif base.startswith("UCB_"):
+            yield k, O.ACQ_UCB, float(base.split("_")[1])
+        elif base.startswith("MGFI_"):
+            yield k, O.ACQ_MGFI, float(base.split("_")[1])
+
+
+@pytest.mark.parametrize("name", STATE_FILES)
+def test_acquisitions_match_reference_row_by_row(name):
+    g = load_golden(name)
+    st = state_from_golden(g)
+    # acquisition values from the REFERENCE's stored (mu, mse): isolates the closed forms + guards
+    mu, mse = g["mu"][:, 0], g["mse"][:, 0]
+    variants = [("", True, None)]
+    if name == "G7_edges":
+        variants += [("max_", False, None), ("plg_", True, -0.3)]
+    for prefix, minimize, plugin in variants:
+        pl = O.plugin_value(st.y, minimize, plugin)
+        close(pl, g[prefix + "plugin_eff"])
+        n = 0
+        for key, acq, par in _acq_cases(g, prefix):
+            if prefix == "" and (key.startswith("max_") or key.startswith("plg_")):
+                continue
+            v = O.acquisition(acq, par, mu, mse, pl, st.sigma2[0], minimize)
+            ref = g[key]
+            # the stored rows come from single-row predict() calls, the stored (mu, mse) from one batched
+            # call: BLAS rounds the two differently in the last bits, and deep-tail EI/MGFI amplify that by
+            # ~z^3 (cancellation), hence 1e-9 rather than 1e-12 here
+            ok = np.ones(len(v), bool)
+            if acq in (O.ACQ_EPSILON_PI, O.ACQ_MGFI):
+                # EpsilonPI has no small-variance guard (acquisition_fun.py:208-217) and MGFI's guard is
+                # sd <= 1e-8 (:274): on rows whose MSE is rounding noise around 0 (a training point in a
+                # noiseless model) the value is Phi(noise/noise) -- not a reproducible number even between two
+                # calls of the reference; only its range is checked there
+                ok = mse > 1e-12 * st.sigma2[0]
+                assert np.all((v[~ok] >= 0) | np.isnan(v[~ok]))
+            np.testing.assert_allclose(v[ok], ref[ok], rtol=1e-9, atol=1e-300, equal_nan=True, err_msg=key)
+            if not ok.all():
+                continue
+            assert O.nan_first_argmax(v) == int(g[prefix + "argmax_" + key[len(prefix):]][0]), key
+            n += 1
+        assert n >= 2
+
+
+@pytest.mark.parametrize("name", STATE_FILES)
+def test_sweep_argmax_matches_reference(name):
+    """End to end through the oracle's own posterior: same argmax index as the reference row loop."""
+    g = load_golden(name)
+    st = state_from_golden(g)
+    acq = [(a, p) for _, a, p in _acq_cases(g, "") if True]
+    keys = [k for k, _, _ in _acq_cases(g, "")]
+    keep = [i for i, k in enumerate(keys) if not (k.startswith("max_") or k.startswith("plg_"))]
+    acq, keys = [acq[i] for i in keep], [keys[i] for i in keep]
+    best, idx = O.sweep(st, g["Xs"], acq, chunk=64)
+    for k, b, i in zip(keys, best, idx):
+        assert i == int(g["argmax_" + k][0]), k
+        np.testing.assert_allclose(b, g[k][i], rtol=1e-8, atol=1e-300)
+
+
+def test_edge_semantics():
+    """candidate == training point in a noiseless model -> MSE exactly 0 -> EI 0,
+    MGFI 0, EpsilonPI in {0,1}, UCB = mu; t clamps at 22.36."""
+    g = load_golden("G7_edges")
+    assert np.all(g["mse"][:6, 0] <= 1e-15) and np.any(g["mse"][:6, 0] == 0.0)  # clipped to 0 or rounding noise
+    assert np.all(g["EI"][:6] == 0.0) and np.all(g["MGFI_1"][:6] == 0.0)
+    assert set(np.unique(g["EpsilonPI_1e-10"][:6])) <= {0.0, 1.0}
+    np.testing.assert_allclose(g["UCB_0.5"][:6], g["mu"][:6, 0], atol=2e-8)
+    np.testing.assert_array_equal(g["MGFI_100"], O.mgfi(g["mu"][:, 0], g["mse"][:, 0], float(g["plugin_eff"][0]), 22.36))
+
+
+@pytest.mark.parametrize("name", ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G4_se_ok_noiseless"])
+def test_gradient_matches_reference(name):
+    g = load_golden(name)
+    st = state_from_golden(g)
+    for i in range(len(g["grad_mu"])):
+        dmu, dmse = O.gradient(st, g["Xs"][i])
+        close(dmu, g["grad_mu"][i], rtol=1e-9, atol=1e-13)
+        close(dmse, g["grad_mse"][i], rtol=1e-8, atol=1e-13)
+
+
+def test_llf_tables():
+    g = load_golden("G6_llf_tables")
+    X, y = g["X"], g["y"]
+    n = 0
+    for kid in (0, 2):
+        for mid in (0, 1, 2):
+            for tname in ("sk", "ok"):
+                key = "k%d_m%d_%s" % (kid, mid, tname)
+                for p, v, gr in zip(g[key + "_par"], g[key + "_llf"], g[key + "_grad"]):
+                    out = O.log_likelihood_concentrated(
+                        p, X, y, kid, mid, noise_var=1e-6 if mid == 1 else 0.0,
+                        estimate_trend=(tname == "ok"), beta=0.0, eval_grad=True)  # fmt: skip
+                    if np.isneginf(v):
+                        assert np.isneginf(out[0])
+                        continue
+                    close(out[0], v, rtol=1e-11)
+                    close(out[1], gr, rtol=1e-8, atol=1e-9)
+                    n += 1
+    assert n >= 30
+
+
+def test_mid_size():
+    g = load_golden("G8_mid")
+    rng = np.random.default_rng(8)
+    X = rng.uniform(-5, 5, size=(512, 10))
+    y = np.sum(X**2, axis=1)
+    y = ((y - y.mean()) / y.std()).reshape(-1, 1)
+    st = O.make_state(g["par"], X, y, O.KERNEL_SE, O.MODE_NOISY, noise_var=1e-6)
+    close(st.llf, g["llf"], rtol=1e-11)
+    close(st.gamma, g["gamma"], rtol=1e-7, atol=1e-9)
+    mu, mse = O.predict_chunked(st, g["Xs"], 512)
+    close(mu, g["mu"], rtol=1e-8, atol=1e-11)
+    close(mse, g["mse"], rtol=1e-8, atol=1e-12)
+    v = O.ei(mu[:, 0], mse[:, 0], O.plugin_value(y, True), st.sigma2[0])
+    np.testing.assert_allclose(v, g["EI"], rtol=1e-7, atol=1e-300)
+    assert int(np.argmax(v)) == int(g["argmax_EI"][0])
+
+
+def test_fmin_plumbing_invariants_recorded():
+    g = load_golden("G9_fmin_plumbing")
+    assert int(g["n_ret"]) == 5 and int(g["n_x"]) == 2 and int(g["n_iter"]) == 21 and int(g["n_eval"]) == 30
