@@ -1,0 +1,214 @@
+"""ctypes binding of libbogp.so (include/bogp.h).  There is no fallback: if the library is missing or no
+gfx950 device is usable, every entry point raises -- the product path never computes on the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbogp.so")
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_NOT_POSDEF, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_LLF_POSITIVE = -1, -2, -3, -4, -5, -6
+KERNEL_SE, KERNEL_MATERN12, KERNEL_MATERN32, KERNEL_MATERN52 = 0, 1, 2, 3
+MODE_NOISELESS, MODE_NOISY, MODE_NOISE_ESTIM = 0, 1, 2
+ACQ_EI, ACQ_EPSILON_PI, ACQ_UCB, ACQ_MGFI = 0, 1, 2, 3
+TREND_CONSTANT = 0
+MAX_Q = 64
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_lp = C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes); must list every symbol include/bogp.h declares (tests/test_abi.py checks it)
+SIGNATURES = {
+    "bogp_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "bogp_destroy": (None, [C.c_void_p]),
+    "bogp_last_error": (C.c_char_p, [C.c_void_p]),
+    "bogp_abi_version": (C.c_int, []),
+    "bogp_set_train": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_int]),
+    "bogp_nll": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp, _dp]),
+    "bogp_commit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp]),
+    "bogp_get_state": (C.c_int, [C.c_void_p] + [_dp] * 10),
+    "bogp_candidates_upload": (C.c_int, [C.c_void_p, _dp, C.c_int64]),
+    "bogp_candidates_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "bogp_predict": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "bogp_sweep": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, C.c_double, C.c_int, _dp, _lp, _dp]),
+    "bogp_gradient": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
+    "bogp_last_timing": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip]),
+    "bogp_flops_per_candidate": (C.c_double, [C.c_void_p]),
+}
+
+_lib = None
+
+
+class BogpError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("libbogp error %d: %s" % (code, msg))
+        self.code = code
+
+
+class NotPositiveDefinite(BogpError, np.linalg.LinAlgError):
+    """rocSOLVER potrf info > 0 (or llf > 0, which the reference also rejects): the host maps it to llf = -inf."""
+
+
+def load():
+    """dlopen libbogp.so and bind every symbol.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libbogp.so not found at %s -- build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH
+        )
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and this table drift apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _f64(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+class Engine:
+    """One handle = one GPU.  Thin, stateful wrapper over the C ABI; raises BogpError on any non-zero code."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        h = C.c_void_p()
+        rc = self._lib.bogp_create(int(device), C.byref(h))
+        if rc != OK:
+            raise BogpError(rc, (self._lib.bogp_last_error(None) or b"").decode())
+        self._h = h
+        self.device = int(device)
+        self.N = self.d = 0
+        self.M = 0
+        self._keep = None  # keeps bound device memory owners alive
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bogp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc == OK:
+            return
+        msg = (self._lib.bogp_last_error(self._h) or b"").decode()
+        if rc in (ERR_NOT_POSDEF, ERR_LLF_POSITIVE):
+            raise NotPositiveDefinite(rc, msg)
+        raise BogpError(rc, msg)
+
+    # -- training set / likelihood / commit ---------------------------------------------------------
+    def set_train(self, X, y):
+        X = _f64(X)
+        y = _f64(y).reshape(len(X), -1)
+        self._check(self._lib.bogp_set_train(self._h, _ptr(X), _ptr(y), X.shape[0], X.shape[1], y.shape[1]))
+        self.N, self.d = X.shape
+
+    def nll(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False):
+        """log-likelihood (and d llf / d par) at `par`; raises NotPositiveDefinite where the reference returns -inf."""
+        par = _f64(par).ravel()
+        llf = C.c_double()
+        grad = np.zeros(len(par)) if eval_grad else None
+        self._check(
+            self._lib.bogp_nll(self._h, kernel, mode, _ptr(par), len(par), float(noise_var), TREND_CONSTANT,
+                               int(bool(estimate_trend)), float(beta), C.byref(llf), _ptr(grad))
+        )  # fmt: skip
+        return (llf.value, grad) if eval_grad else llf.value
+
+    def commit(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0) -> float:
+        par = _f64(par).ravel()
+        llf = C.c_double()
+        self._check(
+            self._lib.bogp_commit(self._h, kernel, mode, _ptr(par), len(par), float(noise_var), TREND_CONSTANT,
+                                  int(bool(estimate_trend)), float(beta), C.byref(llf))
+        )  # fmt: skip
+        return llf.value
+
+    def get_state(self, with_C=True) -> dict:
+        N = self.N
+        Cm = np.empty((N, N)) if with_C else None
+        v = {k: np.zeros(N) for k in ("gamma", "rho", "Yt", "Ft", "Q")}
+        s = [C.c_double() for _ in range(4)]
+        self._check(
+            self._lib.bogp_get_state(self._h, _ptr(Cm), _ptr(v["gamma"]), _ptr(v["rho"]), _ptr(v["Yt"]), _ptr(v["Ft"]),
+                                     _ptr(v["Q"]), *[C.cast(C.byref(x), _dp) for x in s])
+        )  # fmt: skip
+        out = dict(v, G=s[0].value, beta=s[1].value, sigma2=s[2].value, noise_var=s[3].value)
+        if with_C:
+            out["C"] = Cm
+        return out
+
+    # -- candidates ---------------------------------------------------------------------------------
+    def upload_candidates(self, Xs):
+        Xs = _f64(Xs)
+        if Xs.ndim != 2 or Xs.shape[1] != self.d:
+            raise ValueError("candidates must have shape (M, %d)" % self.d)
+        self._check(self._lib.bogp_candidates_upload(self._h, _ptr(Xs), Xs.shape[0]))
+        self.M = Xs.shape[0]
+        self._keep = None
+
+    def bind_candidates(self, device_ptr: int, M: int, owner=None):
+        """Adopt caller-owned device memory (M x d float64 row-major), e.g. a torch tensor's data_ptr()."""
+        self._check(self._lib.bogp_candidates_bind(self._h, C.c_void_p(int(device_ptr)), int(M)))
+        self.M = int(M)
+        self._keep = owner
+
+    # -- posterior / sweep ----------------------------------------------------------------------------
+    def predict(self, eval_MSE=True) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        mu = np.empty(self.M)
+        mse = np.empty(self.M) if eval_MSE else None
+        self._check(self._lib.bogp_predict(self._h, _ptr(mu), _ptr(mse)))
+        return mu, mse
+
+    def sweep(self, acq: Sequence[Tuple[int, float]], plugin: float, minimize=True, return_values=False):
+        q = len(acq)
+        ids = np.ascontiguousarray([a for a, _ in acq], dtype=np.int32)
+        pars = _f64([float(p) if p is not None else 0.0 for _, p in acq])
+        best = np.empty(q)
+        idx = np.empty(q, dtype=np.int64)
+        vals = np.empty((q, self.M)) if return_values else None
+        self._check(
+            self._lib.bogp_sweep(self._h, q, ids.ctypes.data_as(_ip), _ptr(pars), float(plugin), int(bool(minimize)),
+                                 _ptr(best), idx.ctypes.data_as(_lp), _ptr(vals))
+        )  # fmt: skip
+        return (best, idx, vals) if return_values else (best, idx)
+
+    def gradient(self, x):
+        x = _f64(x).ravel()
+        if len(x) != self.d:
+            raise Exception("x does not have the right size!")
+        dmu, dmse = np.empty(self.d), np.empty(self.d)
+        self._check(self._lib.bogp_gradient(self._h, _ptr(x), _ptr(dmu), _ptr(dmse)))
+        return dmu, dmse
+
+    def last_timing(self) -> dict:
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        n = C.c_int()
+        cast = lambda x: C.cast(C.byref(x), _dp)  # noqa: E731
+        self._check(self._lib.bogp_last_timing(self._h, cast(a), cast(b), cast(c), C.cast(C.byref(n), _ip)))
+        return dict(corr_ms=a.value, contract_ms=b.value, acquisition_ms=c.value, n_chunks=n.value)
+
+    def flops_per_candidate(self) -> float:
+        return float(self._lib.bogp_flops_per_candidate(self._h))

@@ -1,0 +1,639 @@
+// bogp_api.hip -- the C ABI of libbogp.so (include/bogp.h): device state, rocSOLVER/rocBLAS orchestration of the
+// fit path, and the chunked posterior/acquisition sweep.  No host fallback exists: every numerical step runs on
+// the gfx950 device, and every failure is reported as an error code + message.
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bogp.h"
+#include "bogp_internal.h"
+
+using namespace bogp;
+
+static std::string g_create_error;
+
+struct bogp_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  rocblas_handle blas = nullptr;
+  std::string err;
+
+  // training set
+  int N = 0, d = 0, Np = 0;
+  double *dX = nullptr, *dy = nullptr;
+
+  // factorisation workspace (column-major N x N, ld = N)
+  double *dR = nullptr, *dV = nullptr, *dRinv = nullptr;
+  double *dyt = nullptr, *dft = nullptr, *drho = nullptr, *dtmp = nullptr;  // N each
+  double *dgamma = nullptr, *dw = nullptr;                                  // Np each (zero padded)
+  double *dtheta = nullptr, *dsqrt_theta = nullptr;                         // d each
+  double* dscal = nullptr;                                                  // small scalar scratch
+  rocblas_int* dinfo = nullptr;
+  double* dgrad_partial = nullptr;
+  size_t grad_partial_cap = 0;
+
+  // committed state
+  bool committed = false;
+  int kernel = 0, mode = 0, estimate_trend = 0;
+  double beta = 0, G = 0, sigma2 = 0, noise_var = 0, llf = 0, ftft = 0;
+  double* dXthT = nullptr;  // [d][Np]
+  double2* dVp = nullptr;   // [Np/16][Np/8][64]
+
+  // candidates
+  const double* dXs = nullptr;
+  double* dXs_owned = nullptr;
+  size_t xs_cap = 0;
+  int64_t M = 0;
+
+  // sweep scratch
+  double *drT = nullptr, *dmu_part = nullptr, *dw_part = nullptr, *dss_part = nullptr;
+  size_t rT_cap = 0, mu_part_cap = 0, w_part_cap = 0, ss_part_cap = 0;
+  double *dblk_val = nullptr, *dmu_out = nullptr, *dmse_out = nullptr, *dacq_out = nullptr, *dbest_val = nullptr;
+  int64_t *dblk_idx = nullptr, *dbest_idx = nullptr;
+  size_t blk_val_cap = 0, blk_idx_cap = 0, mu_out_cap = 0, mse_out_cap = 0, acq_out_cap = 0;
+
+  // timing of the last sweep/predict
+  std::vector<hipEvent_t> ev;
+  double t_corr_ms = 0, t_contract_ms = 0, t_acq_ms = 0;
+  int n_chunks = 0;
+};
+
+#define FAIL(h, code, ...)                              \
+  do {                                                  \
+    char _b[512];                                       \
+    snprintf(_b, sizeof(_b), __VA_ARGS__);              \
+    (h)->err = _b;                                      \
+    return (code);                                      \
+  } while (0)
+#define HIPCHK(h, expr)                                                                                  \
+  do {                                                                                                   \
+    hipError_t _e = (expr);                                                                              \
+    if (_e != hipSuccess) FAIL(h, BOGP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define BLASCHK(h, expr)                                                                          \
+  do {                                                                                            \
+    rocblas_status _s = (expr);                                                                   \
+    if (_s != rocblas_status_success)                                                             \
+      FAIL(h, BOGP_ERR_HIP, "%s failed: rocblas_status %d (%s:%d)", #expr, (int)_s, __FILE__, __LINE__); \
+  } while (0)
+
+template <typename T>
+static int ensure(bogp_handle* h, T** p, size_t* cap, size_t n) {
+  if (*cap >= n && *p) return BOGP_OK;
+  if (*p) HIPCHK(h, hipFree(*p));
+  *p = nullptr;
+  *cap = 0;
+  HIPCHK(h, hipMalloc((void**)p, n * sizeof(T)));
+  *cap = n;
+  return BOGP_OK;
+}
+template <typename T>
+static void dfree(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+extern "C" int bogp_abi_version(void) { return 1; }
+
+extern "C" const char* bogp_last_error(const bogp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int bogp_create(int device, bogp_handle** out) {
+  if (!out) return BOGP_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_error = std::string("no HIP device: ") + hipGetErrorString(e);
+    return BOGP_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) {
+    g_create_error = "device index out of range";
+    return BOGP_ERR_INVALID;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    g_create_error = "hipGetDeviceProperties failed";
+    return BOGP_ERR_HIP;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("libbogp is built for gfx950 only; device is ") + prop.gcnArchName;
+    return BOGP_ERR_NO_DEVICE;
+  }
+  bogp_handle* h = new bogp_handle();
+  h->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      rocblas_create_handle(&h->blas) != rocblas_status_success ||
+      rocblas_set_stream(h->blas, h->stream) != rocblas_status_success ||
+      hipMalloc((void**)&h->dinfo, sizeof(rocblas_int)) != hipSuccess ||
+      hipMalloc((void**)&h->dscal, 64 * sizeof(double)) != hipSuccess) {
+    g_create_error = "stream / rocBLAS handle creation failed";
+    delete h;
+    return BOGP_ERR_HIP;
+  }
+  rocblas_set_pointer_mode(h->blas, rocblas_pointer_mode_host);
+  *out = h;
+  return BOGP_OK;
+}
+
+static void free_train(bogp_handle* h) {
+  dfree(h->dX); dfree(h->dy); dfree(h->dR); dfree(h->dV); dfree(h->dRinv);
+  dfree(h->dyt); dfree(h->dft); dfree(h->drho); dfree(h->dtmp); dfree(h->dgamma); dfree(h->dw);
+  dfree(h->dtheta); dfree(h->dsqrt_theta); dfree(h->dXthT); dfree(h->dVp);
+  h->committed = false;
+}
+
+extern "C" void bogp_destroy(bogp_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  free_train(h);
+  dfree(h->dXs_owned); dfree(h->drT); dfree(h->dmu_part); dfree(h->dw_part); dfree(h->dss_part);
+  dfree(h->dblk_val); dfree(h->dblk_idx); dfree(h->dmu_out); dfree(h->dmse_out); dfree(h->dacq_out);
+  dfree(h->dbest_val); dfree(h->dbest_idx); dfree(h->dinfo); dfree(h->dscal); dfree(h->dgrad_partial);
+  for (auto e : h->ev) (void)hipEventDestroy(e);
+  if (h->blas) rocblas_destroy_handle(h->blas);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, int N, int d, int n_targets) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!X || !y || N <= 0 || d <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_set_train: X, y must be non-null and N, d > 0");
+  if (n_targets != 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_set_train: n_targets = %d; only single-target GPs are built (multi-target y is MOBO-only)", n_targets);
+  if (d > 1024) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_set_train: d = %d > 1024 exceeds the LDS tile of the sweep producer", d);
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_train(h);
+  h->N = N;
+  h->d = d;
+  h->Np = ((N + 31) / 32) * 32;
+  const size_t NN = (size_t)N * N;
+  HIPCHK(h, hipMalloc((void**)&h->dX, (size_t)N * d * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->dy, N * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->dR, NN * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->dyt, N * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->dft, N * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->drho, N * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->dtmp, N * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->dgamma, h->Np * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->dw, h->Np * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->dtheta, d * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->dsqrt_theta, d * sizeof(double)));
+  HIPCHK(h, hipMemcpyAsync(h->dX, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->dy, y, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return BOGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// factorise at `par` (shared by bogp_nll and bogp_commit)
+// ------------------------------------------------------------------------------------------------------
+struct FitOut {
+  double llf = 0, sigma2 = 0, noise_var = 0, s2t = 0, G = 0, beta = 0, ftyt = 0, ftft = 0;
+};
+
+static int factorize(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
+                     int estimate_trend, double beta, bool want_gamma, FitOut* o, std::vector<double>* theta_out) {
+  if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "no training set: call bogp_set_train first");
+  if (kernel < 0 || kernel > 3) FAIL(h, BOGP_ERR_INVALID, "unknown kernel id %d", kernel);
+  if (mode < 0 || mode > 2) FAIL(h, BOGP_ERR_INVALID, "unknown estimation mode %d", mode);
+  if (trend != BOGP_TREND_CONSTANT) FAIL(h, BOGP_ERR_UNSUPPORTED, "only the constant trend basis is built (trend id %d)", trend);
+  const int N = h->N, d = h->d;
+  const int n_theta = n_par - (mode == BOGP_MODE_NOISELESS ? 0 : 1);
+  if (n_theta != d && n_theta != 1) FAIL(h, BOGP_ERR_INVALID, "len(theta) = %d must be 1 or d = %d", n_theta, d);
+  std::vector<double> th(d), sth(d);
+  for (int k = 0; k < d; ++k) {
+    th[k] = par[n_theta == 1 ? 0 : k];
+    if (!(th[k] > 0) || !std::isfinite(th[k])) FAIL(h, BOGP_ERR_INVALID, "theta[%d] = %g must be finite and > 0", k, th[k]);
+    sth[k] = std::sqrt(th[k]);
+  }
+  if (theta_out) *theta_out = th;
+  hipStream_t st = h->stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(h->dtheta, th.data(), d * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(h->dsqrt_theta, sth.data(), d * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipStreamSynchronize(st));  // th/sth are stack vectors
+
+  // correlation matrix with the per-mode normalisation (gpr.py:931-969)
+  double s2t = 0, alpha = 0, sigma2_par = 0;
+  if (mode == BOGP_MODE_NOISELESS) {
+    HIPCHK(h, launch_build_R(kernel, h->dX, N, d, h->dtheta, 1.0, 1.0, h->dR, N, st));
+  } else if (mode == BOGP_MODE_NOISE_ESTIM) {
+    alpha = par[n_par - 1];
+    HIPCHK(h, launch_build_R(kernel, h->dX, N, d, h->dtheta, alpha, alpha * 1.0 + (1 - alpha) * 1.0, h->dR, N, st));
+  } else {
+    sigma2_par = par[n_par - 1];
+    s2t = sigma2_par + noise_var;
+    HIPCHK(h, launch_build_R_div(kernel, h->dX, N, d, h->dtheta, sigma2_par, s2t, (sigma2_par * 1.0 + noise_var * 1.0) / s2t,
+                                 h->dR, N, st));
+  }
+  // L = chol(R) (gpr.py:795)
+  BLASCHK(h, rocsolver_dpotrf(h->blas, rocblas_fill_lower, N, h->dR, N, h->dinfo));
+  rocblas_int info = 0;
+  HIPCHK(h, hipMemcpyAsync(&info, h->dinfo, sizeof(info), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, launch_logdet(h->dR, N, N, h->dscal, st));
+  // Yt = L^-1 y (:799)
+  HIPCHK(h, hipMemcpyAsync(h->dyt, h->dy, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+  BLASCHK(h, rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, h->dR, N, h->dyt, 1));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (info != 0) FAIL(h, BOGP_ERR_NOT_POSDEF, "correlation matrix is not positive definite (potrf info = %d)", (int)info);
+
+  const double one = 1.0;
+  double ftyt = 0, ftft = 0, G = 0, beta_eff = beta;
+  if (estimate_trend) {
+    // Ft = L^-1 F, F = ones (constant trend); economic QR of a single column: G = -sign(Ft[0]) |Ft|, Q = Ft / G (:803-806)
+    std::vector<double> ones(N, 1.0);
+    HIPCHK(h, hipMemcpyAsync(h->dft, ones.data(), N * sizeof(double), hipMemcpyHostToDevice, st));
+    BLASCHK(h, rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, h->dR, N, h->dft, 1));
+    double nrm = 0;
+    BLASCHK(h, rocblas_dnrm2(h->blas, N, h->dft, 1, &nrm));
+    BLASCHK(h, rocblas_ddot(h->blas, N, h->dft, 1, h->dyt, 1, &ftyt));
+    HIPCHK(h, hipStreamSynchronize(st));
+    G = -nrm;  // Ft[0] = 1 / L[0][0] > 0
+    ftft = nrm * nrm;
+    const double qty = ftyt / G;  // Q^T Yt
+    // rho = Yt - Q (Q^T Yt)
+    HIPCHK(h, hipMemcpyAsync(h->drho, h->dyt, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    const double coef = -(qty / G);
+    BLASCHK(h, rocblas_daxpy(h->blas, N, &coef, h->dft, 1, h->drho, 1));
+    beta_eff = qty / G;  // beta = G^-1 Q^T Yt (:785-787)
+  } else {
+    HIPCHK(h, hipMemcpyAsync(h->drho, h->dyt, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (beta != 0.0) {  // rho = Yt - L^-1 (beta * 1) (:808)
+      std::vector<double> bv(N, beta);
+      HIPCHK(h, hipMemcpyAsync(h->dtmp, bv.data(), N * sizeof(double), hipMemcpyHostToDevice, st));
+      BLASCHK(h, rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, h->dR, N, h->dtmp, 1));
+      const double m1 = -1.0;
+      BLASCHK(h, rocblas_daxpy(h->blas, N, &m1, h->dtmp, 1, h->drho, 1));
+      HIPCHK(h, hipStreamSynchronize(st));
+    }
+  }
+  (void)one;
+  double rho_ss = 0, logdet = 0;
+  BLASCHK(h, rocblas_ddot(h->blas, N, h->drho, 1, h->drho, 1, &rho_ss));
+  HIPCHK(h, hipMemcpyAsync(&logdet, h->dscal, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+
+  const double TWO_PI = 2.0 * 3.141592653589793;
+  double llf, sigma2, nv;
+  if (mode == BOGP_MODE_NOISELESS) {  // :941-945
+    const int k = estimate_trend ? 1 : 0;
+    sigma2 = rho_ss / (N - k);
+    nv = 0;
+    s2t = sigma2;
+    llf = -0.5 * (N * std::log(TWO_PI * sigma2) + 2.0 * logdet + N);
+  } else if (mode == BOGP_MODE_NOISE_ESTIM) {  // :954-958
+    s2t = rho_ss / N;
+    sigma2 = alpha * s2t;
+    nv = (1 - alpha) * s2t;
+    llf = -0.5 * (N * std::log(TWO_PI * s2t) + 2.0 * logdet + N);
+  } else {  // :973-977
+    sigma2 = sigma2_par;
+    nv = noise_var;
+    llf = -0.5 * (N * std::log(TWO_PI * s2t) + 2.0 * logdet + rho_ss / s2t);
+  }
+  if (!std::isfinite(llf)) FAIL(h, BOGP_ERR_NOT_POSDEF, "log-likelihood is not finite (%g): degenerate factorisation", llf);
+  o->llf = llf; o->sigma2 = sigma2; o->noise_var = nv; o->s2t = s2t; o->G = G; o->beta = beta_eff; o->ftyt = ftyt; o->ftft = ftft;
+  if (llf > 0) FAIL(h, BOGP_ERR_LLF_POSITIVE, "log-likelihood %g > 0 is rejected by the reference (gpr.py:981-982)", llf);
+
+  if (want_gamma) {  // gamma = L^-T rho (:788 / :996)
+    HIPCHK(h, hipMemsetAsync(h->dgamma, 0, h->Np * sizeof(double), st));
+    HIPCHK(h, hipMemcpyAsync(h->dgamma, h->drho, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    BLASCHK(h, rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, h->dR, N, h->dgamma, 1));
+  }
+  return BOGP_OK;
+}
+
+extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
+                        int estimate_trend, double beta, double* llf, double* grad) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!par || !llf || n_par <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_nll: par/llf must be non-null");
+  h->committed = false;  // the factor buffers are about to be overwritten
+  FitOut o;
+  int rc = factorize(h, kernel, mode, par, n_par, noise_var, trend, estimate_trend, beta, grad != nullptr, &o, nullptr);
+  *llf = o.llf;
+  if (rc != BOGP_OK) return rc;
+  if (!grad) return BOGP_OK;
+
+  const int N = h->N, d = h->d;
+  const int n_theta = n_par - (mode == BOGP_MODE_NOISELESS ? 0 : 1);
+  if (n_theta != d) FAIL(h, BOGP_ERR_UNSUPPORTED, "gradient with isotropic theta (len 1, d = %d) is not built: the reference's own gradient is inconsistent there (gpr.py:1001-1037 index the (N,N,d) tensor by parameter)", d);
+  hipStream_t st = h->stream;
+  // R^-1 = cho_solve(L, I) (:997) via potri on a copy of L
+  if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)N * N * sizeof(double)));
+  HIPCHK(h, hipMemcpyAsync(h->dRinv, h->dR, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, st));
+  BLASCHK(h, rocsolver_dpotri(h->blas, rocblas_fill_lower, N, h->dRinv, N, h->dinfo));
+  const int nblk = grad_contract_blocks(N);
+  int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)nblk * (d + 1) + (d + 1));
+  if (e) return e;
+  const double c1 = 1.0 / (mode == BOGP_MODE_NOISELESS ? o.sigma2 : o.s2t);
+  HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, h->dgamma, c1, h->dRinv, N, h->dgrad_partial, nblk, st));
+  double* dS = h->dgrad_partial + (size_t)nblk * (d + 1);
+  HIPCHK(h, launch_grad_reduce(h->dgrad_partial, nblk, d + 1, dS, st));
+  std::vector<double> S(d + 1);
+  HIPCHK(h, hipMemcpyAsync(S.data(), dS, (d + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+  double tr = 0, gg = 0;
+  if (mode == BOGP_MODE_NOISY) {
+    BLASCHK(h, rocblas_dasum(h->blas, N, h->dRinv, N + 1, &tr));  // trace: the diagonal of an SPD inverse is positive
+    BLASCHK(h, rocblas_ddot(h->blas, N, h->dgamma, 1, h->dgamma, 1, &gg));
+  }
+  HIPCHK(h, hipStreamSynchronize(st));
+  rocblas_int info = 0;
+  HIPCHK(h, hipMemcpy(&info, h->dinfo, sizeof(info), hipMemcpyDeviceToHost));
+  if (info != 0) FAIL(h, BOGP_ERR_NOT_POSDEF, "potri failed (info = %d)", (int)info);
+  if (mode == BOGP_MODE_NOISELESS) {
+    for (int k = 0; k < d; ++k) grad[k] = S[k];
+  } else if (mode == BOGP_MODE_NOISE_ESTIM) {
+    const double alpha = par[n_par - 1];
+    for (int k = 0; k < d; ++k) grad[k] = alpha * S[k];
+    grad[d] = S[d];
+  } else {
+    for (int k = 0; k < d; ++k) grad[k] = S[k];
+    grad[d] = -0.5 * (tr / o.s2t - gg / (o.s2t * o.s2t)) + S[d] / o.s2t;
+  }
+  return BOGP_OK;
+}
+
+extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
+                           int estimate_trend, double beta, double* llf) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!par || n_par <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_commit: par must be non-null");
+  h->committed = false;
+  FitOut o;
+  std::vector<double> th;
+  int rc = factorize(h, kernel, mode, par, n_par, noise_var, trend, estimate_trend, beta, true, &o, &th);
+  if (llf) *llf = o.llf;
+  if (rc != BOGP_OK) return rc;
+  const int N = h->N, d = h->d, Np = h->Np;
+  hipStream_t st = h->stream;
+  // V = L^-1 (the triangular solve of gpr.py:494 becomes a triangular GEMM against V)
+  if (!h->dV) HIPCHK(h, hipMalloc((void**)&h->dV, (size_t)N * N * sizeof(double)));
+  HIPCHK(h, hipMemcpyAsync(h->dV, h->dR, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, st));
+  BLASCHK(h, rocsolver_dtrtri(h->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, N, h->dV, N, h->dinfo));
+  if (!h->dVp) HIPCHK(h, hipMalloc((void**)&h->dVp, (size_t)Np * Np * sizeof(double)));
+  HIPCHK(h, launch_pack_V(h->dV, N, N, Np, h->dVp, st));
+  // w = L^-T Ft  (so that Ft^T L^-1 r = w . r, gpr.py:496-498)
+  HIPCHK(h, hipMemsetAsync(h->dw, 0, Np * sizeof(double), st));
+  if (estimate_trend) {
+    HIPCHK(h, hipMemcpyAsync(h->dw, h->dft, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    BLASCHK(h, rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, h->dR, N, h->dw, 1));
+  }
+  if (!h->dXthT) HIPCHK(h, hipMalloc((void**)&h->dXthT, (size_t)d * Np * sizeof(double)));
+  HIPCHK(h, launch_scale_transpose(h->dX, N, d, Np, h->dsqrt_theta, h->dXthT, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  rocblas_int info = 0;
+  HIPCHK(h, hipMemcpy(&info, h->dinfo, sizeof(info), hipMemcpyDeviceToHost));
+  if (info != 0) FAIL(h, BOGP_ERR_NOT_POSDEF, "trtri failed (info = %d)", (int)info);
+  h->kernel = kernel; h->mode = mode; h->estimate_trend = estimate_trend;
+  h->beta = o.beta; h->G = o.G; h->sigma2 = o.sigma2; h->noise_var = o.noise_var; h->llf = o.llf; h->ftft = o.ftft;
+  h->committed = true;
+  return BOGP_OK;
+}
+
+extern "C" int bogp_get_state(bogp_handle* h, double* C, double* gamma, double* rho, double* Yt, double* Ft, double* Q,
+                              double* G, double* beta, double* sigma2, double* noise_var) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "bogp_get_state: no committed state");
+  const int N = h->N;
+  hipStream_t st = h->stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (C) {
+    if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)N * N * sizeof(double)));
+    HIPCHK(h, launch_copy_lower(h->dR, N, N, h->dRinv, st));
+    HIPCHK(h, hipMemcpyAsync(C, h->dRinv, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  if (gamma) HIPCHK(h, hipMemcpyAsync(gamma, h->dgamma, N * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (rho) HIPCHK(h, hipMemcpyAsync(rho, h->drho, N * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (Yt) HIPCHK(h, hipMemcpyAsync(Yt, h->dyt, N * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (h->estimate_trend) {
+    if (Ft) HIPCHK(h, hipMemcpyAsync(Ft, h->dft, N * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (Q) HIPCHK(h, hipMemcpyAsync(Q, h->dft, N * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (h->estimate_trend && Q)
+    for (int i = 0; i < N; ++i) Q[i] /= h->G;
+  if (G) *G = h->G;
+  if (beta) *beta = h->beta;
+  if (sigma2) *sigma2 = h->sigma2;
+  if (noise_var) *noise_var = h->noise_var;
+  return BOGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// candidates
+// ------------------------------------------------------------------------------------------------------
+extern "C" int bogp_candidates_upload(bogp_handle* h, const double* Xs, int64_t M) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_upload: call bogp_set_train first (d is unknown)");
+  if (!Xs || M <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_upload: Xs must be non-null and M > 0");
+  HIPCHK(h, hipSetDevice(h->device));
+  int e = ensure(h, &h->dXs_owned, &h->xs_cap, (size_t)M * h->d);
+  if (e) return e;
+  HIPCHK(h, hipMemcpyAsync(h->dXs_owned, Xs, (size_t)M * h->d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->dXs = h->dXs_owned;
+  h->M = M;
+  return BOGP_OK;
+}
+
+extern "C" int bogp_candidates_bind(bogp_handle* h, const void* d_Xs, int64_t M) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!d_Xs || M <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_bind: pointer must be non-null and M > 0");
+  h->dXs = (const double*)d_Xs;
+  h->M = M;
+  return BOGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// posterior + acquisition sweep
+// ------------------------------------------------------------------------------------------------------
+static hipEvent_t get_event(bogp_handle* h, size_t i) {
+  while (h->ev.size() <= i) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    h->ev.push_back(e);
+  }
+  return h->ev[i];
+}
+
+static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, const double* acq_par, double plugin,
+                     int minimize, bool want_acq_out) {
+  if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "no committed model: call bogp_commit first");
+  if (!h->dXs || h->M <= 0) FAIL(h, BOGP_ERR_INVALID, "no candidates: call bogp_candidates_upload/bind first");
+  if (q < 0 || q > BOGP_MAX_Q) FAIL(h, BOGP_ERR_INVALID, "q = %d outside [0, %d]", q, BOGP_MAX_Q);
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = h->stream;
+  const int Np = h->Np, d = h->d;
+  const int64_t M = h->M;
+  const int64_t Mpad = ((M + 63) / 64) * 64;
+  size_t chunk_bytes = (size_t)1 << 30;
+  if (const char* env = getenv("BOGP_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, atoi(env)) << 20;
+  int64_t Mc = (int64_t)(chunk_bytes / ((size_t)Np * sizeof(double)) / 64) * 64;
+  Mc = std::max<int64_t>(64, std::min<int64_t>(Mc, Mpad));
+  const int nblk32 = Np / 32;
+  int S = (int)std::min<int64_t>(nblk32, std::max<int64_t>(1, (2048 + Mc / 64 - 1) / (Mc / 64)));
+  const int nblk_per_split = (nblk32 + S - 1) / S;
+  S = (nblk32 + nblk_per_split - 1) / nblk_per_split;
+  const int NJ16 = Np / 16;
+  const int cols = contract_cols_per_group();
+  const int nJ = (Np + cols - 1) / cols;
+  const int64_t nchunk = (M + Mc - 1) / Mc;
+  const int64_t nblk_total = (M + 255) / 256 + nchunk;  // per-chunk block counts are rounded up
+
+  int e;
+  if ((e = ensure(h, &h->drT, &h->rT_cap, (size_t)Np * Mc))) return e;
+  if ((e = ensure(h, &h->dmu_part, &h->mu_part_cap, (size_t)S * Mc))) return e;
+  if ((e = ensure(h, &h->dw_part, &h->w_part_cap, (size_t)S * Mc))) return e;
+  if ((e = ensure(h, &h->dss_part, &h->ss_part_cap, (size_t)nJ * Mc))) return e;
+  if (q > 0) {
+    if ((e = ensure(h, &h->dblk_val, &h->blk_val_cap, (size_t)q * nblk_total))) return e;
+    if ((e = ensure(h, &h->dblk_idx, &h->blk_idx_cap, (size_t)q * nblk_total))) return e;
+    if (!h->dbest_val) HIPCHK(h, hipMalloc((void**)&h->dbest_val, BOGP_MAX_Q * sizeof(double)));
+    if (!h->dbest_idx) HIPCHK(h, hipMalloc((void**)&h->dbest_idx, BOGP_MAX_Q * sizeof(int64_t)));
+  }
+  if (want_out) {
+    if ((e = ensure(h, &h->dmu_out, &h->mu_out_cap, (size_t)M))) return e;
+    if ((e = ensure(h, &h->dmse_out, &h->mse_out_cap, (size_t)M))) return e;
+  }
+  if (want_acq_out)
+    if ((e = ensure(h, &h->dacq_out, &h->acq_out_cap, (size_t)q * M))) return e;
+
+  int64_t blk_offset = 0;
+  size_t nev = 0;
+  for (int64_t c = 0; c < nchunk; ++c) {
+    const int64_t m0 = c * Mc;
+    const int64_t mcount = std::min<int64_t>(Mc, M - m0);
+    const int64_t Mc_eff = ((mcount + 63) / 64) * 64;  // rows actually launched; array stride stays Mc
+    CorrArgs ca;
+    ca.Xs = h->dXs; ca.M = M; ca.m0 = m0; ca.Mc = Mc; ca.d = d; ca.Np = Np; ca.nblk_per_split = nblk_per_split;
+    ca.sqrt_theta = h->dsqrt_theta; ca.XthT = h->dXthT; ca.gamma = h->dgamma; ca.wvec = h->dw;
+    ca.rT = h->drT; ca.mu_part = h->dmu_part; ca.w_part = h->dw_part;
+    ContractArgs ka;
+    ka.rT = h->drT; ka.Vp = h->dVp; ka.ss_part = h->dss_part; ka.Mc = Mc; ka.nMt = (int)(Mc_eff / 64); ka.nJ = nJ;
+    ka.NJ16 = NJ16; ka.NKP = Np / 8;
+    hipEvent_t e0 = get_event(h, nev++), e1 = get_event(h, nev++), e2 = get_event(h, nev++), e3 = get_event(h, nev++);
+    if (!e0 || !e1 || !e2 || !e3) FAIL(h, BOGP_ERR_HIP, "hipEventCreate failed");
+    HIPCHK(h, hipEventRecord(e0, st));
+    HIPCHK(h, launch_corr_chunk(h->kernel, ca, (int)(Mc_eff / 64), S, st));
+    HIPCHK(h, hipEventRecord(e1, st));
+    HIPCHK(h, launch_contract(ka, st));
+    HIPCHK(h, hipEventRecord(e2, st));
+    AcqArgs aa;
+    memset(&aa, 0, sizeof(aa));
+    aa.mu_part = h->dmu_part; aa.w_part = h->dw_part; aa.ss_part = h->dss_part; aa.S = S; aa.nJ = nJ; aa.Mc = Mc;
+    aa.mcount = mcount; aa.m0 = m0; aa.beta = h->beta; aa.G = h->G; aa.estimate_trend = h->estimate_trend;
+    aa.sigma2 = h->sigma2; aa.mu_out = want_out ? h->dmu_out : nullptr; aa.mse_out = want_out ? h->dmse_out : nullptr;
+    aa.q = q;
+    for (int i = 0; i < q; ++i) { aa.acq_id[i] = acq_id[i]; aa.acq_par[i] = acq_par ? acq_par[i] : 0.0; }
+    aa.plugin = plugin; aa.minimize = minimize; aa.acq_out = want_acq_out ? h->dacq_out : nullptr; aa.M = M;
+    aa.blk_val = h->dblk_val; aa.blk_idx = h->dblk_idx; aa.blk_offset = blk_offset; aa.nblk_total = nblk_total;
+    HIPCHK(h, launch_acquisition(aa, st));
+    HIPCHK(h, hipEventRecord(e3, st));
+    blk_offset += (mcount + 255) / 256;
+  }
+  if (q > 0) HIPCHK(h, launch_argmax_final(h->dblk_val, h->dblk_idx, blk_offset, nblk_total, q, h->dbest_val, h->dbest_idx, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  h->t_corr_ms = h->t_contract_ms = h->t_acq_ms = 0;
+  for (size_t i = 0; i + 3 < nev; i += 4) {
+    float a = 0, b = 0, c2 = 0;
+    (void)hipEventElapsedTime(&a, h->ev[i], h->ev[i + 1]);
+    (void)hipEventElapsedTime(&b, h->ev[i + 1], h->ev[i + 2]);
+    (void)hipEventElapsedTime(&c2, h->ev[i + 2], h->ev[i + 3]);
+    h->t_corr_ms += a; h->t_contract_ms += b; h->t_acq_ms += c2;
+  }
+  h->n_chunks = (int)nchunk;
+  return BOGP_OK;
+}
+
+extern "C" int bogp_predict(bogp_handle* h, double* mu, double* mse) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!mu) FAIL(h, BOGP_ERR_INVALID, "bogp_predict: mu must be non-null");
+  int rc = run_sweep(h, true, 0, nullptr, nullptr, 0.0, 1, false);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpy(mu, h->dmu_out, (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost));
+  if (mse) HIPCHK(h, hipMemcpy(mse, h->dmse_out, (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost));
+  return BOGP_OK;
+}
+
+extern "C" int bogp_sweep(bogp_handle* h, int q, const int* acq_id, const double* acq_par, double plugin, int minimize,
+                          double* best_val, int64_t* best_idx, double* acq_out) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (q <= 0 || !acq_id || !best_val || !best_idx) FAIL(h, BOGP_ERR_INVALID, "bogp_sweep: q > 0 and non-null acq_id/best_val/best_idx required");
+  for (int i = 0; i < q; ++i) {
+    if (acq_id[i] < 0 || acq_id[i] > 3) FAIL(h, BOGP_ERR_INVALID, "unknown acquisition id %d", acq_id[i]);
+    if (acq_id[i] != BOGP_ACQ_EI && (!acq_par || !(acq_par[i] > 0)))
+      FAIL(h, BOGP_ERR_INVALID, "acquisition parameter %d must be > 0 (the reference asserts alpha/epsilon/t > 0)", i);
+  }
+  int rc = run_sweep(h, false, q, acq_id, acq_par, plugin, minimize, acq_out != nullptr);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpy(best_val, h->dbest_val, q * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(best_idx, h->dbest_idx, q * sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (acq_out) HIPCHK(h, hipMemcpy(acq_out, h->dacq_out, (size_t)q * h->M * sizeof(double), hipMemcpyDeviceToHost));
+  return BOGP_OK;
+}
+
+extern "C" int bogp_last_timing(bogp_handle* h, double* corr_ms, double* contract_ms, double* acquisition_ms, int* n_chunks) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (corr_ms) *corr_ms = h->t_corr_ms;
+  if (contract_ms) *contract_ms = h->t_contract_ms;
+  if (acquisition_ms) *acquisition_ms = h->t_acq_ms;
+  if (n_chunks) *n_chunks = h->n_chunks;
+  return BOGP_OK;
+}
+
+extern "C" double bogp_flops_per_candidate(const bogp_handle* h) {
+  if (!h || !h->committed) return 0.0;
+  const double N = h->N, d = h->d, p = h->estimate_trend ? 1 : 0;
+  return N * N + N * (3 * d + 5 + 2 * p);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// gradient of the posterior at one point (gpr.py:537-576)
+// ------------------------------------------------------------------------------------------------------
+extern "C" int bogp_gradient(bogp_handle* h, const double* x, double* dmu, double* dmse) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "bogp_gradient: no committed model");
+  if (!x || !dmu || !dmse) FAIL(h, BOGP_ERR_INVALID, "bogp_gradient: null pointer");
+  const int N = h->N, d = h->d;
+  hipStream_t st = h->stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)N * (d + 2) + 4 * d + 8);
+  if (e) return e;
+  double* dr = h->dgrad_partial;            // N
+  double* drdx = dr + N;                    // d x N (column k = dr/dx_k)
+  double* dz = drdx + (size_t)N * d;        // N
+  double* dx = dz + N;                      // d
+  double* dout = dx + d;                    // 3 d
+  HIPCHK(h, hipMemcpyAsync(dx, x, d * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(h, launch_point_corr(h->kernel, h->dX, N, d, h->dtheta, dx, dr, drdx, st));
+  // z = L^-T L^-1 r
+  HIPCHK(h, hipMemcpyAsync(dz, dr, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+  BLASCHK(h, rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, h->dR, N, dz, 1));
+  BLASCHK(h, rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, h->dR, N, dz, 1));
+  const double one = 1.0, zero = 0.0;
+  BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, h->dgamma, 1, &zero, dout, 1));
+  BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, dz, 1, &zero, dout + d, 1));
+  double wr = 0;
+  if (h->estimate_trend) {
+    BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, h->dw, 1, &zero, dout + 2 * d, 1));
+    BLASCHK(h, rocblas_ddot(h->blas, N, h->dw, 1, dr, 1, &wr));
+  }
+  std::vector<double> out(3 * d, 0.0);
+  HIPCHK(h, hipMemcpyAsync(out.data(), dout, (h->estimate_trend ? 3 : 2) * d * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  for (int k = 0; k < d; ++k) {
+    dmu[k] = out[k];  // beta^T f_dx = 0 for the constant basis
+    double m = -1.0 * out[d + k];
+    if (h->estimate_trend) m += (wr - 1.0) * (1.0 / h->ftft) * out[2 * d + k];
+    dmse[k] = 2.0 * h->sigma2 * m;
+  }
+  return BOGP_OK;
+}

@@ -1,0 +1,80 @@
+// bogp_device.h -- device-side helpers shared by the gfx950 kernels of libbogp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bogp.h"
+
+namespace bogp {
+
+// ---------------------------------------------------------------------------------------------------
+// Radial profile of the correlation functions (surrogate/gaussian_process/kernel.py, see bogp.h).
+// s2 = sum_k theta_k (x_k - y_k)^2 computed by the caller.  Operation order follows the reference:
+//   matern: dists = sqrt(s2); K = dists * sqrt(nu2); (1 + K [+ K^2/3]) * exp(-K)      (kernel.py:186-200)
+// ---------------------------------------------------------------------------------------------------
+template <int KERNEL>
+__device__ __forceinline__ double corr_profile(double s2) {
+  if (KERNEL == BOGP_KERNEL_SE) return exp(-s2);
+  const double dists = sqrt(s2);
+  if (KERNEL == BOGP_KERNEL_MATERN12) return exp(-dists);
+  if (KERNEL == BOGP_KERNEL_MATERN32) {
+    const double K = dists * 1.7320508075688772;  // math.sqrt(3)
+    return (1.0 + K) * exp(-K);
+  }
+  const double K = dists * 2.23606797749979;  // math.sqrt(5)
+  // K**2 / 3.0 in the reference; a multiply by the rounded reciprocal differs by <= 1 ulp of that term and saves
+  // an FP64 division sequence (~20 DP ops) per pair
+  return (1.0 + K + (K * K) * 0.3333333333333333) * exp(-K);
+}
+
+// -h(D) such that dR0/dtheta_k = -(x_ik - x_jk)^2 * h  (gpr.py:736-770 corr_grad_theta):
+//   SE r; Matern-3/2 1.5 exp(-sqrt3 D); [extensions: Matern-5/2 (5/6)(1+sqrt5 D)exp(-sqrt5 D); Matern-1/2 r/(2D)]
+template <int KERNEL>
+__device__ __forceinline__ double corr_dtheta_profile(double s2, double r) {
+  if (KERNEL == BOGP_KERNEL_SE) return r;
+  const double D = sqrt(s2);
+  if (KERNEL == BOGP_KERNEL_MATERN32) return 1.5 * exp(-1.7320508075688772 * D);
+  if (KERNEL == BOGP_KERNEL_MATERN52) return (5.0 / 6.0) * (1.0 + 2.23606797749979 * D) * exp(-2.23606797749979 * D);
+  return D > 0.0 ? 0.5 * r / D : 0.0;
+}
+
+// scipy.special.ndtr (cephes ndtr.c) branch structure on top of the device erf/erfc:
+//   x = a * sqrt(1/2); z = |x|; z < sqrt(1/2): .5 + .5 erf(x); else y = .5 erfc(z), x > 0 -> 1 - y
+__device__ __forceinline__ double ndtr(double a) {
+  if (isnan(a)) return a;
+  const double x = a * 0.70710678118654752440;
+  const double z = fabs(x);
+  if (z < 0.70710678118654752440) return 0.5 + 0.5 * erf(x);
+  double y = 0.5 * erfc(z);
+  if (x > 0) y = 1.0 - y;
+  return y;
+}
+
+// scipy.stats.norm.pdf: exp(-x**2/2.0) / sqrt(2*pi)
+__device__ __forceinline__ double norm_pdf(double x) { return exp(-(x * x) / 2.0) / 2.5066282746310002; }
+
+// argmax ordering identical to np.argmax over a 1-D float64 array: first maximal element, where a NaN
+// (if any) is maximal.  (value, index) pairs; `better(a,b)` == a should replace b.
+struct ArgMax {
+  double v;
+  int64_t i;
+};
+__device__ __forceinline__ bool better(double av, int64_t ai, double bv, int64_t bi) {
+  const bool an = isnan(av), bn = isnan(bv);
+  if (an != bn) return an;
+  if (!an && av != bv) return av > bv;
+  return ai < bi;
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  int lo = __shfl_xor(__double2loint(v), mask, 64);
+  int hi = __shfl_xor(__double2hiint(v), mask, 64);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int mask) {
+  int lo = __shfl_xor((int)(v & 0xffffffffll), mask, 64);
+  int hi = __shfl_xor((int)(v >> 32), mask, 64);
+  return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+}  // namespace bogp

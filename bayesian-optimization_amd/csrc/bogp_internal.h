@@ -1,0 +1,90 @@
+// bogp_internal.h -- host-side declarations shared by the translation units of libbogp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+namespace bogp {
+
+// ---- kernel argument blocks (passed by value) -------------------------------------------------------
+struct CorrArgs {
+  const double* Xs;          // candidates, M x d row-major (device)
+  int64_t M;                 // total candidates
+  int64_t m0;                // first candidate of this chunk
+  int64_t Mc;                // chunk size padded to a multiple of 64
+  int d;
+  int Np;                    // training points padded to a multiple of 32
+  int nblk_per_split;        // 32-blocks of n per workgroup (grid.y slices the training set)
+  const double* sqrt_theta;  // d
+  const double* XthT;        // [d][Np] theta-scaled training points, transposed
+  const double* gamma;       // Np (zero padded)
+  const double* wvec;        // Np (zero padded): L^-T Ft, or zeros for simple kriging
+  double* rT;                // [Np][Mc] correlation chunk, n-major
+  double* mu_part;           // [S][Mc]
+  double* w_part;            // [S][Mc]
+};
+
+struct ContractArgs {
+  const double* rT;   // [Np][Mc]
+  const double2* Vp;  // packed L^-1: [NJ16][NKP][64] double2
+  double* ss_part;    // [nJ][Mc]
+  int64_t Mc;
+  int nMt;   // Mc / 64
+  int nJ;    // column groups
+  int NJ16;  // Np / 16
+  int NKP;   // Np / 8
+};
+
+struct AcqArgs {
+  const double* mu_part;  // [S][Mc]
+  const double* w_part;   // [S][Mc]
+  const double* ss_part;  // [nJ][Mc]
+  int S, nJ;
+  int64_t Mc;      // chunk stride of the partial arrays
+  int64_t mcount;  // valid candidates in this chunk
+  int64_t m0;      // global index of the chunk's first candidate
+  double beta;     // trend coefficient (constant basis)
+  double G;        // QR factor of Ft (ordinary kriging), unused otherwise
+  int estimate_trend;
+  double sigma2;
+  double* mu_out;   // [M] or null (global arrays, indexed by m0 + i)
+  double* mse_out;  // [M] or null
+  int q;
+  int acq_id[64];
+  double acq_par[64];
+  double plugin;
+  int minimize;
+  double* acq_out;     // [q][M] or null
+  int64_t M;           // row stride of acq_out
+  double* blk_val;     // [q][nblk_total] per-block partial argmax
+  int64_t* blk_idx;    // [q][nblk_total]
+  int64_t blk_offset;  // first block slot of this chunk
+  int64_t nblk_total;
+};
+
+hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipStream_t st);
+hipError_t launch_contract(const ContractArgs& a, hipStream_t st);
+int contract_cols_per_group();
+hipError_t launch_acquisition(const AcqArgs& a, hipStream_t st);
+hipError_t launch_argmax_final(const double* blk_val, const int64_t* blk_idx, int64_t nblk, int64_t stride, int q,
+                               double* out_val, int64_t* out_idx, hipStream_t st);
+
+// fit-path kernels (kernels_fit.hip)
+hipError_t launch_build_R(int kernel, const double* X, int N, int d, const double* theta, double off_scale, double diag,
+                          double* R, int ld, hipStream_t st);
+hipError_t launch_build_R_div(int kernel, const double* X, int N, int d, const double* theta, double mul, double div,
+                              double diag, double* R, int ld, hipStream_t st);
+hipError_t launch_scale_transpose(const double* X, int N, int d, int Np, const double* sqrt_theta, double* XthT,
+                                  hipStream_t st);
+hipError_t launch_pack_V(const double* Vcm, int N, int ld, int Np, double2* Vp, hipStream_t st);
+hipError_t launch_logdet(const double* L, int N, int ld, double* out, hipStream_t st);
+hipError_t launch_copy_lower(const double* L, int N, int ld, double* dst, hipStream_t st);
+hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const double* theta, const double* gamma,
+                                double c1, const double* Rinv, int ld, double* partial, int nblk, hipStream_t st);
+hipError_t launch_grad_reduce(const double* partial, int nblk, int nout, double* out, hipStream_t st);
+int grad_contract_blocks(int N);
+hipError_t launch_point_corr(int kernel, const double* X, int N, int d, const double* theta, const double* x,
+                             double* r, double* rdx, hipStream_t st);
+
+}  // namespace bogp

@@ -1,0 +1,273 @@
+// kernels_fit.hip -- fit-side kernels of libbogp (gfx950): everything around the rocSOLVER factorisation.
+//
+//   k_build_R        correlation_matrix (gpr.py:772-782) + the per-mode normalisation (:949-969) without the
+//                    N(N-1)/2 x d pair list of l1_cross_distances (:48-61)
+//   k_scale_transpose theta-scaled, transposed copy of X that the sweep's producer reads with scalar loads
+//   k_pack_V         L^-1 -> MFMA B-fragment order for k_contract
+//   k_logdet         sum(log(diag(L)))  (gpr.py:943-945)
+//   k_grad_contract  the d trace-contractions of the llf gradient (gpr.py:994-1038) formed on the fly from X:
+//                    sum_{i<j} (gamma_i gamma_j c1 - Rinv_ij) dR0_ij/dtheta_k -- no (N,N,d) tensor (:736-770)
+//   k_point_corr     r and dr/dx at ONE point for GaussianProcess.gradient (gpr.py:537-576, corr_dx :600-661)
+#include "bogp_device.h"
+#include "bogp_internal.h"
+
+namespace bogp {
+
+template <int KERNEL>
+__global__ __launch_bounds__(256) void k_build_R(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
+                                                 double off_scale, double diag, double* __restrict__ R, int ld) {
+  // 16x16 tile per workgroup; both triangles are written (exactly symmetric: (a-b)^2 == (b-a)^2)
+  const int i = blockIdx.y * 16 + (threadIdx.x >> 4);
+  const int j = blockIdx.x * 16 + (threadIdx.x & 15);
+  if (i >= N || j >= N) return;
+  double v;
+  if (i == j) {
+    v = diag;
+  } else {
+    double s2 = 0.0;
+    for (int k = 0; k < d; ++k) {
+      const double df = fabs(X[(size_t)i * d + k] - X[(size_t)j * d + k]);
+      s2 += theta[k] * (df * df);
+    }
+    v = off_scale * corr_profile<KERNEL>(s2);
+  }
+  R[(size_t)j * ld + i] = v;  // column-major (symmetric anyway)
+}
+
+// NOISY mode divides after the multiply (C = sigma2 R0 + tau2 I; R = C / sigma2_total, gpr.py:966-967)
+template <int KERNEL>
+__global__ __launch_bounds__(256) void k_build_R_div(const double* __restrict__ X, int N, int d,
+                                                     const double* __restrict__ theta, double mul, double div,
+                                                     double diag, double* __restrict__ R, int ld) {
+  const int i = blockIdx.y * 16 + (threadIdx.x >> 4);
+  const int j = blockIdx.x * 16 + (threadIdx.x & 15);
+  if (i >= N || j >= N) return;
+  double v;
+  if (i == j) {
+    v = diag;
+  } else {
+    double s2 = 0.0;
+    for (int k = 0; k < d; ++k) {
+      const double df = fabs(X[(size_t)i * d + k] - X[(size_t)j * d + k]);
+      s2 += theta[k] * (df * df);
+    }
+    v = (mul * corr_profile<KERNEL>(s2)) / div;
+  }
+  R[(size_t)j * ld + i] = v;
+}
+
+hipError_t launch_build_R(int kernel, const double* X, int N, int d, const double* theta, double off_scale, double diag,
+                          double* R, int ld, hipStream_t st) {
+  // multiply-only form (NOISELESS: off_scale = 1; NOISE_ESTIM: off_scale = alpha); NOISY uses launch_build_R_div
+  dim3 grid((N + 15) / 16, (N + 15) / 16);
+  switch (kernel) {
+    case BOGP_KERNEL_SE: hipLaunchKernelGGL(k_build_R<BOGP_KERNEL_SE>, grid, 256, 0, st, X, N, d, theta, off_scale, diag, R, ld); break;
+    case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL(k_build_R<BOGP_KERNEL_MATERN12>, grid, 256, 0, st, X, N, d, theta, off_scale, diag, R, ld); break;
+    case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL(k_build_R<BOGP_KERNEL_MATERN32>, grid, 256, 0, st, X, N, d, theta, off_scale, diag, R, ld); break;
+    default: hipLaunchKernelGGL(k_build_R<BOGP_KERNEL_MATERN52>, grid, 256, 0, st, X, N, d, theta, off_scale, diag, R, ld); break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_build_R_div(int kernel, const double* X, int N, int d, const double* theta, double mul, double div,
+                              double diag, double* R, int ld, hipStream_t st) {
+  dim3 grid((N + 15) / 16, (N + 15) / 16);
+  switch (kernel) {
+    case BOGP_KERNEL_SE: hipLaunchKernelGGL(k_build_R_div<BOGP_KERNEL_SE>, grid, 256, 0, st, X, N, d, theta, mul, div, diag, R, ld); break;
+    case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL(k_build_R_div<BOGP_KERNEL_MATERN12>, grid, 256, 0, st, X, N, d, theta, mul, div, diag, R, ld); break;
+    case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL(k_build_R_div<BOGP_KERNEL_MATERN32>, grid, 256, 0, st, X, N, d, theta, mul, div, diag, R, ld); break;
+    default: hipLaunchKernelGGL(k_build_R_div<BOGP_KERNEL_MATERN52>, grid, 256, 0, st, X, N, d, theta, mul, div, diag, R, ld); break;
+  }
+  return hipGetLastError();
+}
+
+__global__ void k_scale_transpose(const double* __restrict__ X, int N, int d, int Np, const double* __restrict__ sth,
+                                  double* __restrict__ XthT) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= Np) return;
+  for (int k = 0; k < d; ++k) XthT[(size_t)k * Np + n] = n < N ? X[(size_t)n * d + k] * sth[k] : 0.0;
+}
+hipError_t launch_scale_transpose(const double* X, int N, int d, int Np, const double* sqrt_theta, double* XthT,
+                                  hipStream_t st) {
+  hipLaunchKernelGGL(k_scale_transpose, dim3((Np + 255) / 256), 256, 0, st, X, N, d, Np, sqrt_theta, XthT);
+  return hipGetLastError();
+}
+
+// Vp[(jt*NKP + kp)*64 + lane] = ( V[j][8kp + k], V[j][8kp + 4 + k] ),  j = 16 jt + (lane & 15), k = lane >> 4,
+// zero above the diagonal and in the padding.  Vcm is column-major: V(j, n) = Vcm[j + n*ld].
+__global__ __launch_bounds__(64) void k_pack_V(const double* __restrict__ Vcm, int N, int ld, int NKP, double2* __restrict__ Vp) {
+  const int jt = blockIdx.y, kp = blockIdx.x, lane = threadIdx.x;
+  const int j = 16 * jt + (lane & 15);
+  const int n0 = 8 * kp + (lane >> 4), n1 = n0 + 4;
+  double2 v;
+  v.x = (j < N && n0 <= j) ? Vcm[(size_t)n0 * ld + j] : 0.0;
+  v.y = (j < N && n1 <= j) ? Vcm[(size_t)n1 * ld + j] : 0.0;
+  Vp[((size_t)jt * NKP + kp) * 64 + lane] = v;
+}
+hipError_t launch_pack_V(const double* Vcm, int N, int ld, int Np, double2* Vp, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_V, dim3(Np / 8, Np / 16), 64, 0, st, Vcm, N, ld, Np / 8, Vp);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_logdet(const double* __restrict__ L, int N, int ld, double* out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < N; i += 256) s += log(L[(size_t)i * ld + i]);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+hipError_t launch_logdet(const double* L, int N, int ld, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_logdet, dim3(1), 256, 0, st, L, N, ld, out);
+  return hipGetLastError();
+}
+
+// dst (row-major N x N, strict upper = 0)  <-  lower triangle of column-major L
+__global__ void k_copy_lower(const double* __restrict__ L, int N, int ld, double* __restrict__ dst) {
+  const int j = blockIdx.x * 16 + (threadIdx.x & 15);  // column
+  const int i = blockIdx.y * 16 + (threadIdx.x >> 4);  // row
+  if (i >= N || j >= N) return;
+  dst[(size_t)i * N + j] = j <= i ? L[(size_t)j * ld + i] : 0.0;
+}
+hipError_t launch_copy_lower(const double* L, int N, int ld, double* dst, hipStream_t st) {
+  hipLaunchKernelGGL(k_copy_lower, dim3((N + 15) / 16, (N + 15) / 16), 256, 0, st, L, N, ld, dst);
+  return hipGetLastError();
+}
+
+// ---- likelihood-gradient contraction ------------------------------------------------------------------
+// One workgroup per 16x16 tile on or above the diagonal; thread (ti, tj) owns pair (i, j), i < j only.
+// partial[blk][0..d-1] = sum A_ij * (-(x_ik - x_jk)^2 h_ij),  partial[blk][d] = sum A_ij R0_ij,
+// with A_ij = gamma_i gamma_j c1 - Rinv_ij.  MAXD bounds d for the per-thread accumulators via chunking over k.
+template <int KERNEL>
+__global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict__ X, int N, int d,
+                                                       const double* __restrict__ theta,
+                                                       const double* __restrict__ gamma, double c1,
+                                                       const double* __restrict__ Rinv, int ld,
+                                                       double* __restrict__ partial, int ntile) {
+  __shared__ double red[256];
+  // linear tile id -> (bi <= bj)
+  int t = blockIdx.x, bi = 0;
+  while (t >= ntile - bi) {
+    t -= ntile - bi;
+    ++bi;
+  }
+  const int bj = bi + t;
+  const int i = bi * 16 + (threadIdx.x >> 4);
+  const int j = bj * 16 + (threadIdx.x & 15);
+  const bool ok = i < N && j < N && i < j;
+  double A = 0.0, h = 0.0, r0 = 0.0;
+  if (ok) {
+    double s2 = 0.0;
+    for (int k = 0; k < d; ++k) {
+      const double df = X[(size_t)i * d + k] - X[(size_t)j * d + k];
+      s2 += theta[k] * (df * df);
+    }
+    r0 = corr_profile<KERNEL>(s2);
+    h = corr_dtheta_profile<KERNEL>(s2, r0);
+    A = gamma[i] * gamma[j] * c1 - Rinv[(size_t)i * ld + j];  // element (j, i) of the lower triangle, column-major
+  }
+  double* out = partial + (size_t)blockIdx.x * (d + 1);
+  for (int k = 0; k <= d; ++k) {
+    double v = 0.0;
+    if (ok) {
+      if (k < d) {
+        const double df = X[(size_t)i * d + k] - X[(size_t)j * d + k];
+        v = A * (-(df * df) * h);
+      } else {
+        v = A * r0;
+      }
+    }
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[k] = red[0];
+    __syncthreads();
+  }
+}
+int grad_contract_blocks(int N) {
+  const int nt = (N + 15) / 16;
+  return nt * (nt + 1) / 2;
+}
+hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const double* theta, const double* gamma,
+                                double c1, const double* Rinv, int ld, double* partial, int nblk, hipStream_t st) {
+  const int nt = (N + 15) / 16;
+  switch (kernel) {
+    case BOGP_KERNEL_SE: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_SE>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, partial, nt); break;
+    case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN12>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, partial, nt); break;
+    case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN32>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, partial, nt); break;
+    default: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN52>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, partial, nt); break;
+  }
+  return hipGetLastError();
+}
+
+// out[k] = sum_blk partial[blk][k]  (fixed order: deterministic)
+__global__ __launch_bounds__(256) void k_grad_reduce(const double* __restrict__ partial, int nblk, int nout, double* out) {
+  __shared__ double red[256];
+  const int k = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(size_t)b * nout + k];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[k] = red[0];
+}
+hipError_t launch_grad_reduce(const double* partial, int nblk, int nout, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_grad_reduce, dim3(nout), 256, 0, st, partial, nblk, nout, out);
+  return hipGetLastError();
+}
+
+// r[n] = corr(theta, |x - X_n|), rdx[k*N + n] = d r[n] / d x_k     (corr_dx, gpr.py:600-661)
+//   SE: -2 r theta_k diff_k (:635-636);  Matern-3/2: diff theta / D * (-3 D exp(-sqrt3 D)) (:642-644), the 0/0
+//   at D = 0 is a warning the reference turns into an all-zero gradient (:658-659) -- here the affected
+//   entries are 0 (their limit);  Matern-5/2 / 1/2: analytic forms (extensions, the reference has `pass`).
+template <int KERNEL>
+__global__ void k_point_corr(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
+                             const double* __restrict__ x, double* __restrict__ r, double* __restrict__ rdx) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double s2 = 0.0;
+  for (int k = 0; k < d; ++k) {
+    const double df = fabs(x[k] - X[(size_t)n * d + k]);
+    s2 += theta[k] * (df * df);
+  }
+  const double rv = corr_profile<KERNEL>(s2);
+  r[n] = rv;
+  const double D = sqrt(s2);
+  for (int k = 0; k < d; ++k) {
+    const double diff = x[k] - X[(size_t)n * d + k];
+    double g;
+    if (KERNEL == BOGP_KERNEL_SE) {
+      g = -2 * rv * (theta[k] * diff);
+    } else if (KERNEL == BOGP_KERNEL_MATERN32) {
+      g = D > 0.0 ? (diff * theta[k] / D) * (-3.0 * D * exp(-1.7320508075688772 * D)) : 0.0;
+    } else if (KERNEL == BOGP_KERNEL_MATERN52) {
+      g = (-(5.0 / 3.0) * (1.0 + 2.23606797749979 * D) * exp(-2.23606797749979 * D)) * (theta[k] * diff);
+    } else {
+      g = D > 0.0 ? -diff * theta[k] / D * rv : 0.0;
+    }
+    rdx[(size_t)k * N + n] = g;
+  }
+}
+hipError_t launch_point_corr(int kernel, const double* X, int N, int d, const double* theta, const double* x,
+                             double* r, double* rdx, hipStream_t st) {
+  dim3 grid((N + 255) / 256);
+  switch (kernel) {
+    case BOGP_KERNEL_SE: hipLaunchKernelGGL(k_point_corr<BOGP_KERNEL_SE>, grid, 256, 0, st, X, N, d, theta, x, r, rdx); break;
+    case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL(k_point_corr<BOGP_KERNEL_MATERN12>, grid, 256, 0, st, X, N, d, theta, x, r, rdx); break;
+    case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL(k_point_corr<BOGP_KERNEL_MATERN32>, grid, 256, 0, st, X, N, d, theta, x, r, rdx); break;
+    default: hipLaunchKernelGGL(k_point_corr<BOGP_KERNEL_MATERN52>, grid, 256, 0, st, X, N, d, theta, x, r, rdx); break;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace bogp

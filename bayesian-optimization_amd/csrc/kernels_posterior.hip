@@ -1,0 +1,311 @@
+// kernels_posterior.hip -- the candidates/sec hot path of libbogp on gfx950 (MI355X).
+//
+// Replaces GaussianProcess.predict (surrogate/gaussian_process/gpr.py:486-510):
+//     dx = |X*_i - X_j|                  (M*N, d) temporary          -> never materialised
+//     r  = corr(theta, dx)               (M, N)                      -> k_corr_chunk   (FP64 VALU)
+//     mu = mean + r @ gamma                                          -> k_corr_chunk   (fused)
+//     rt = solve_triangular(L, r.T)      N^2 flops per candidate     -> k_contract     (FP64 MFMA)
+//     1 - sum(rt^2) [+ sum(u^2)]                                     -> k_contract epilogue (+ acquisition kernel)
+//
+// Design constants come from measurements on the target (tools/ubench_f64*.hip, profiles/ubench_r01.txt):
+//   * v_mfma_f64_4x4x4_4b_f64 issues every 16 cycles (512 flop) = 32 flop/clk/SIMD = the 78.6 TF/s FP64 peak;
+//     v_mfma_f64_16x16x4_f64 needs ~137 cycles (2048 flop) = HALF that rate on gfx950 -> not used.
+//   * FP64 VALU work does not hide beside FP64 MFMA (same DP pipe: times add), so the kernel-matrix
+//     producer must run ONCE per (candidate, training point) -- it is split into its own kernel and r is
+//     staged through HBM/L2 in candidate chunks instead of being recomputed per column tile.
+//   * lane layout of v_mfma_f64_4x4x4_4b_f64 (tools/probe_mfma_layout.hip): A lane = 16k+4b+i,
+//     B lane = 16k+4b+j, D lane = 16i+4b+j  (b = block 0..3).
+//
+// Triangular contraction.  With V = L^-1 (lower triangular, packed once per fit into B-fragment order),
+// rt = V r and sum(rt^2) = sum_j (sum_{n<=j} V[j][n] r[n])^2.  A workgroup owns 64 candidates x 256 columns j
+// (4 waves x 4 sixteen-wide column tiles, interleaved so every wave meets the diagonal equally) and walks n in
+// blocks of 32; 16x16 blocks above the diagonal are skipped (executed flops ~= N^2 (1 + 16/N) per candidate).
+// A 16x16 output tile is 4 instructions: instruction t pairs A row-block (b+t)%4 with B column-block b, so ONE
+// B register and four rotated A reads (LDS) feed 2048 flop.
+#include <cstdlib>
+
+#include "bogp_device.h"
+#include "bogp_internal.h"
+
+namespace bogp {
+
+// ---------------------------------------------------------------------------------------------------
+// Kernel A: correlation chunk  rT[n][m] = corr(theta, |x*_m - x_n|), + partial mean / trend dot products
+//   grid (Mc/64, S): 64 candidates x one slice of the training set per workgroup; 256 threads.
+//   thread (m = tid&63, g = tid>>6) produces r for 8 consecutive n per 32-block; the training rows are
+//   wave-uniform => scalar loads from the theta-scaled transposed copy XthT[d][Np].
+// ---------------------------------------------------------------------------------------------------
+struct CorrDims {
+  int64_t M, m0, Mc;
+  int d, Np, nblk_per_split;
+};
+// pointers are separate __restrict__ kernel arguments (not struct members) so that the wave-uniform reads of
+// XthT / gamma / wvec are provably read-only and become scalar (SMEM) loads
+template <int KERNEL>
+__global__ __launch_bounds__(256) void k_corr_chunk(const double* __restrict__ Xs, const double* __restrict__ sqrt_theta,
+                                                    const double* __restrict__ XthT, const double* __restrict__ gamma,
+                                                    const double* __restrict__ wvec, double* __restrict__ rT,
+                                                    double* __restrict__ mu_part, double* __restrict__ w_part,
+                                                    CorrDims a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* xs = smem;  // [d][64] theta-scaled candidate tile, k-major
+  const int tid = threadIdx.x;
+  const int m = tid & 63;
+  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t mc0 = (int64_t)blockIdx.x * 64;  // offset inside the chunk
+  const int64_t mg0 = a.m0 + mc0;                // global candidate index of row 0
+  const int d = a.d;
+
+  for (int idx = tid; idx < 64 * d; idx += 256) {
+    const int row = idx / d, k = idx - row * d;
+    const int64_t gm = mg0 + row;
+    const double v = gm < a.M ? Xs[gm * d + k] : 0.0;
+    xs[k * 64 + row] = v * sqrt_theta[k];
+  }
+  __syncthreads();
+
+  const int nb0 = blockIdx.y * a.nblk_per_split * 32;
+  const int nb1 = min(a.Np, nb0 + a.nblk_per_split * 32);
+  double mu = 0.0, wd = 0.0;
+  for (int nb = nb0; nb < nb1; nb += 32) {
+    const int n0 = nb + g * 8;
+    double acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+#pragma unroll 2
+    for (int k = 0; k < d; ++k) {
+      const double xk = xs[k * 64 + m];
+      const double* __restrict__ xr = XthT + (size_t)k * a.Np + n0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const double diff = xk - xr[i];
+        acc[i] = __builtin_fma(diff, diff, acc[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const double r = corr_profile<KERNEL>(acc[i]);
+      rT[(size_t)(n0 + i) * a.Mc + mc0 + m] = r;
+      mu = __builtin_fma(r, gamma[n0 + i], mu);
+      wd = __builtin_fma(r, wvec[n0 + i], wd);
+    }
+  }
+  // reduce the 4 n-groups (fixed order) -> partial sums of this training-set slice
+  __syncthreads();
+  double* red = smem;  // reuse: [2][4][64]
+  red[g * 64 + m] = mu;
+  red[256 + g * 64 + m] = wd;
+  __syncthreads();
+  if (tid < 64) {
+    const double s0 = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+    const double s1 = ((red[256 + tid] + red[320 + tid]) + red[384 + tid]) + red[448 + tid];
+    mu_part[(size_t)blockIdx.y * a.Mc + mc0 + tid] = s0;
+    w_part[(size_t)blockIdx.y * a.Mc + mc0 + tid] = s1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Kernel B: triangular contraction  ss_part[jg][m] = sum_{j in group jg} (sum_{n<=j} V[j][n] r[m][n])^2
+// ---------------------------------------------------------------------------------------------------
+constexpr int MR = 4;                // 16-row fragments per wave  (64 candidates)
+constexpr int NWJ = 4;               // waves per workgroup (along j)
+// NR = 16-column fragments per wave (template parameter): NR = 4 -> 256 columns per workgroup, 128 accumulator
+// VGPRs, one workgroup per CU (512-register budget); NR = 2 -> 128 columns, two workgroups per CU.
+constexpr int KB = 32;               // training points per staged block
+constexpr int PITCH = 64 + 16;       // LDS row pitch in doubles: 640 B == 128 (mod 256) -> conflict-free A reads
+
+__device__ __forceinline__ double mfma4(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+// One 32-row block of n: 4 k-pairs x 2 k-steps x (MR x NR x 4) MFMAs.  GUARDED = this block touches the diagonal
+// (16x16 tiles above it are skipped, wave-uniform predicates).  All global loads are unconditional (addresses
+// clamped) so that the compiler can keep counted vmcnt waits and the B prefetch stays one k-pair ahead.
+template <bool GUARDED, int NR>
+__device__ __forceinline__ void contract_block(const double* __restrict__ tile, const double2* __restrict__ vp,
+                                               const size_t (&boff)[NR], const int (&jt)[NR], const int (&aoff)[4],
+                                               int kb, int kp_last, double2 (&bq)[2][NR], double (&acc)[MR][NR][4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int kp = kb * 4 + s;
+    const int kb16 = kp >> 1;
+    {  // prefetch the next k-pair of B fragments (clamped at the end of this group's range)
+      const int kpn = min(kp + 1, kp_last);
+#pragma unroll
+      for (int ni = 0; ni < NR; ++ni) bq[(s + 1) & 1][ni] = vp[boff[ni] + (size_t)kpn * 64];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const double* trow = tile + (4 * (2 * s + h)) * PITCH;
+      double af[MR][4];
+#pragma unroll
+      for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[mi][t] = trow[aoff[t] + 16 * mi];
+#pragma unroll
+      for (int ni = 0; ni < NR; ++ni) {
+        if (!GUARDED || kb16 <= jt[ni]) {
+          const double bv = h == 0 ? bq[s & 1][ni].x : bq[s & 1][ni].y;
+#pragma unroll
+          for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[mi][ni][t] = mfma4(af[mi][t], bv, acc[mi][ni][t]);
+        }
+      }
+    }
+  }
+}
+
+template <int NR>
+__global__ __launch_bounds__(256, NR == 4 ? 1 : 2) void k_contract(ContractArgs a) {
+  constexpr int JT16 = NWJ * NR;  // sixteen-wide column tiles per workgroup
+  __shared__ __attribute__((aligned(16))) double lds[2 * KB * PITCH];  // 40 KB: two r tiles [32][80]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // heavy (long-K) column groups first
+  const int nMt = a.nMt;
+  const int jg = a.nJ - 1 - (int)(blockIdx.x / nMt);
+  const int mt = blockIdx.x % nMt;
+  const int64_t mc0 = (int64_t)mt * 64;
+  const int NJ16 = a.NJ16, NKP = a.NKP;
+  const int kmax16 = min((jg + 1) * JT16, NJ16);  // sixteen-blocks of n this group needs (even: Np % 32 == 0)
+  const int nkb = kmax16 >> 1;
+  const int nkb_full = jg * (JT16 / 2);  // blocks entirely below this group's diagonal: every tile is active
+  const int kp_last = 2 * kmax16 - 1;
+
+  // column tiles of this wave, interleaved across the 4 waves; tiles past the matrix edge are computed on
+  // clamped (valid) addresses and dropped in the epilogue
+  int jt[NR];
+  size_t boff[NR];
+  bool valid[NR];
+#pragma unroll
+  for (int ni = 0; ni < NR; ++ni) {
+    const int j = jg * JT16 + w + NWJ * ni;
+    valid[ni] = j < NJ16;
+    jt[ni] = valid[ni] ? j : -1;  // -1: never active in the guarded phase
+    boff[ni] = (size_t)min(j, NJ16 - 1) * NKP * 64;
+  }
+
+  double acc[MR][NR][4];
+#pragma unroll
+  for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[mi][ni][t] = 0.0;
+
+  // ---- staging of the r tile: 32 rows x 512 B, 4 x 16 B per thread --------------------------------
+  const int srow = tid >> 5;        // 0..7 (+8c)
+  const int scol = (tid & 31) * 2;  // double index inside the 64-wide row
+  const double* __restrict__ rbase = a.rT + mc0 + scol;
+  const size_t Mc = (size_t)a.Mc;
+  double2 st0, st1, st2, st3;  // named registers: an indexed array here ends up in scratch
+#define BOGP_STAGE_LOAD(kb_)                                                                         \
+  do {                                                                                               \
+    const double* p_ = rbase + (size_t)((kb_)*KB + srow) * Mc;                                       \
+    st0 = *reinterpret_cast<const double2*>(p_);                                                     \
+    st1 = *reinterpret_cast<const double2*>(p_ + 8 * Mc);                                            \
+    st2 = *reinterpret_cast<const double2*>(p_ + 16 * Mc);                                           \
+    st3 = *reinterpret_cast<const double2*>(p_ + 24 * Mc);                                           \
+  } while (0)
+#define BOGP_STAGE_STORE(buf_)                                                                       \
+  do {                                                                                               \
+    double* q_ = &lds[(buf_)*KB * PITCH + srow * PITCH + scol];                                      \
+    *reinterpret_cast<double2*>(q_) = st0;                                                           \
+    *reinterpret_cast<double2*>(q_ + 8 * PITCH) = st1;                                               \
+    *reinterpret_cast<double2*>(q_ + 16 * PITCH) = st2;                                              \
+    *reinterpret_cast<double2*>(q_ + 24 * PITCH) = st3;                                              \
+  } while (0)
+
+  // ---- B fragments: Vp[jt][kp][lane] = (V[j][8kp + k], V[j][8kp + 4 + k]),  j = 16 jt + (lane&15), k = lane>>4
+  const double2* __restrict__ vp = a.Vp + lane;
+  double2 bq[2][NR];
+#pragma unroll
+  for (int ni = 0; ni < NR; ++ni) bq[0][ni] = vp[boff[ni]];
+
+  // A-fragment read offsets (doubles) for this lane: A lane = 16k + 4b + i reads row k, column 4*((b+t)&3) + i
+  const int lk = lane >> 4, lb = (lane >> 2) & 3, li = lane & 3;
+  int aoff[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) aoff[t] = lk * PITCH + 4 * ((lb + t) & 3) + li;
+
+  BOGP_STAGE_LOAD(0);
+  BOGP_STAGE_STORE(0);
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();                       // tile kb is in lds[kb & 1]; every wave is done with the other buffer
+    BOGP_STAGE_LOAD(min(kb + 1, nkb - 1));  // next tile -> registers, in flight during the MFMAs
+    const double* tile = &lds[(kb & 1) * KB * PITCH];
+    if (kb < nkb_full)
+      contract_block<false, NR>(tile, vp, boff, jt, aoff, kb, kp_last, bq, acc);
+    else
+      contract_block<true, NR>(tile, vp, boff, jt, aoff, kb, kp_last, bq, acc);
+    BOGP_STAGE_STORE((kb + 1) & 1);
+  }
+#undef BOGP_STAGE_LOAD
+#undef BOGP_STAGE_STORE
+
+  // ---- epilogue: sum of squares over this group's columns, per candidate row -----------------------
+  __syncthreads();
+  double* red = lds;  // [NWJ][64 rows][16 slots]
+#pragma unroll
+  for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      double s = 0.0;
+#pragma unroll
+      for (int ni = 0; ni < NR; ++ni)
+        if (valid[ni]) s = __builtin_fma(acc[mi][ni][t], acc[mi][ni][t], s);
+      const int row = 16 * mi + 4 * ((lb + t) & 3) + lk;  // D lane = 16 i + 4 b + j  ->  i = lane>>4
+      red[(w * 64 + row) * 16 + 4 * t + li] = s;
+    }
+  __syncthreads();
+  if (tid < 64) {
+    double s = 0.0;
+    for (int ww = 0; ww < NWJ; ++ww)
+#pragma unroll
+      for (int sl = 0; sl < 16; ++sl) s += red[(ww * 64 + tid) * 16 + sl];
+    a.ss_part[(size_t)jg * a.Mc + mc0 + tid] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------------
+hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipStream_t st) {
+  dim3 grid((unsigned)nMt, (unsigned)S);
+  size_t shm = (size_t)max(64 * a.d, 512) * sizeof(double);
+  CorrDims dm{a.M, a.m0, a.Mc, a.d, a.Np, a.nblk_per_split};
+#define BOGP_LAUNCH_CORR(K) \
+  hipLaunchKernelGGL(k_corr_chunk<K>, grid, 256, shm, st, a.Xs, a.sqrt_theta, a.XthT, a.gamma, a.wvec, a.rT, a.mu_part, a.w_part, dm)
+  switch (kernel) {
+    case BOGP_KERNEL_SE: BOGP_LAUNCH_CORR(BOGP_KERNEL_SE); break;
+    case BOGP_KERNEL_MATERN12: BOGP_LAUNCH_CORR(BOGP_KERNEL_MATERN12); break;
+    case BOGP_KERNEL_MATERN32: BOGP_LAUNCH_CORR(BOGP_KERNEL_MATERN32); break;
+    default: BOGP_LAUNCH_CORR(BOGP_KERNEL_MATERN52); break;
+  }
+#undef BOGP_LAUNCH_CORR
+  return hipGetLastError();
+}
+
+static int contract_nr() {
+  static int nr = [] {
+    const char* e = getenv("BOGP_CONTRACT_NR");
+    return (e && atoi(e) == 2) ? 2 : 4;
+  }();
+  return nr;
+}
+
+hipError_t launch_contract(const ContractArgs& a, hipStream_t st) {
+  if (contract_nr() == 4)
+    hipLaunchKernelGGL(k_contract<4>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
+  else
+    hipLaunchKernelGGL(k_contract<2>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
+  return hipGetLastError();
+}
+
+int contract_cols_per_group() { return NWJ * contract_nr() * 16; }
+
+}  // namespace bogp

@@ -1,0 +1,150 @@
+/* bogp.h -- C ABI of libbogp.so: the MI355X (gfx950) GP-surrogate + batch-acquisition engine.
+ *
+ * The reference (wangronin/Bayesian-Optimization, `bayes_optim` 0.3.0) is pure Python: it has no FFI for
+ * this path.  The drop-in boundary is three Python duck-typed protocols; the entry
+ * points below are what a binding for those protocols needs, and each one names the reference code it
+ * replaces (paths relative to bayes_optim/).  `INTEGRATION.md` shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every host array is C-contiguous float64 / int32 / int64
+ *   - return value: 0 = BOGP_OK, < 0 = error code (never throws across the ABI);
+ *     `bogp_last_error(h)` gives a human-readable message for the last failing call on that handle
+ *   - BOGP_ERR_NOT_POSDEF is the "Cholesky failed" outcome (rocSOLVER info > 0); the Python host maps it to
+ *     llf = -inf exactly like the reference maps LinAlgError (surrogate/gaussian_process/gpr.py:946-947,
+ *     960-961, 978-979)
+ *   - the library owns all device memory; the caller owns all host buffers
+ *   - one handle per device; calls on one handle must be serialised by the caller (ctypes releases the GIL)
+ *   - all arithmetic is IEEE float64 on the device; there is NO host/CPU fallback path
+ */
+#ifndef BOGP_H
+#define BOGP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bogp_handle bogp_handle;
+
+/* error codes */
+#define BOGP_OK 0
+#define BOGP_ERR_INVALID (-1)      /* bad argument / call order                                           */
+#define BOGP_ERR_HIP (-2)          /* HIP runtime / rocBLAS / rocSOLVER failure                            */
+#define BOGP_ERR_NOT_POSDEF (-3)   /* correlation matrix not positive definite (potrf info > 0)            */
+#define BOGP_ERR_UNSUPPORTED (-4)  /* valid in the reference but not built yet (see DESIGN.md "out of scope") */
+#define BOGP_ERR_NO_DEVICE (-5)    /* no usable gfx950 device                                              */
+#define BOGP_ERR_LLF_POSITIVE (-6) /* llf > 0: the reference rejects it as -inf (gpr.py:981-982)           */
+
+/* correlation functions: surrogate/gaussian_process/kernel.py
+ *   SE        squared_exponential :289-329   exp(-sum_k theta_k d_k^2)
+ *   MATERN12  matern nu=0.5       :190       exp(-s),                     s = sqrt(sum_k theta_k d_k^2)
+ *   MATERN32  matern nu=1.5       :193-196   (1+t) exp(-t),               t = sqrt(3) s   [corr="matern"]
+ *   MATERN52  matern nu=2.5       :198-200   (1+t+t^2/3) exp(-t),         t = sqrt(5) s                    */
+#define BOGP_KERNEL_SE 0
+#define BOGP_KERNEL_MATERN12 1
+#define BOGP_KERNEL_MATERN32 2
+#define BOGP_KERNEL_MATERN52 3
+
+/* estimation modes: gpr.py:252-263; parameter layouts gpr.py:1073-1086
+ *   NOISELESS   par = [theta]          sigma2 = sum(rho^2)/(N-k)
+ *   NOISY       par = [theta, sigma2]  R = (sigma2 R0 + noise_var I)/(sigma2 + noise_var)
+ *   NOISE_ESTIM par = [theta, alpha]   R = alpha R0 + (1-alpha) I                                        */
+#define BOGP_MODE_NOISELESS 0
+#define BOGP_MODE_NOISY 1
+#define BOGP_MODE_NOISE_ESTIM 2
+
+/* acquisition functions: acquisition/acquisition_fun.py (EI :150-189, EpsilonPI/PI :192-235, UCB :107-147,
+ * MGFI :238-310).  `acq_par` is unused for EI, epsilon for EPSILON_PI, alpha for UCB, t for MGFI.          */
+#define BOGP_ACQ_EI 0
+#define BOGP_ACQ_EPSILON_PI 1
+#define BOGP_ACQ_UCB 2
+#define BOGP_ACQ_MGFI 3
+
+/* trend (prior mean) bases: surrogate/gaussian_process/trend.py.  Only the constant basis (p = 1) is built. */
+#define BOGP_TREND_CONSTANT 0
+
+#define BOGP_MAX_Q 64 /* criteria evaluated in one sweep (ParallelBO batch size q) */
+
+/* ---- lifetime ------------------------------------------------------------------------------------- */
+int bogp_create(int device, bogp_handle** out);
+void bogp_destroy(bogp_handle* h);
+const char* bogp_last_error(const bogp_handle* h); /* h may be NULL: message of the last failed bogp_create */
+int bogp_abi_version(void);                        /* bumps whenever a signature below changes            */
+
+/* ---- training set --------------------------------------------------------------------------------
+ * Replaces GaussianProcess._check_data (gpr.py:279-310): X (N x d, row-major), y (N x n_targets).
+ * The pair-distance list D of the reference (gpr.py:48-61, 13.4 GB at N=8192,d=50) is never built.
+ * n_targets must be 1 (multi-target y is used only by MOBO, out of scope).                              */
+int bogp_set_train(bogp_handle* h, const double* X, const double* y, int N, int d, int n_targets);
+
+/* ---- likelihood -----------------------------------------------------------------------------------
+ * Replaces GaussianProcess.log_likelihood_concentrated(par, eval_grad) (gpr.py:920-1040):
+ * correlation_matrix (:772-782) -> _compute_aux_var (:790-811: potrf, L^-1 y, trend QR, rho) -> llf ->
+ * gradient (:994-1038: gamma, R^-1 via potri, corr_grad_theta contraction without the (N,N,d) tensor).
+ *   par           [theta (n_theta = d or 1), then sigma2 | alpha per mode], NOT log10
+ *   noise_var     nugget tau^2 (NOISY mode); ignored otherwise
+ *   estimate_trend 1: beta is GLS-estimated (ordinary kriging);  0: fixed `beta` (simple kriging)
+ *   llf           out, scalar
+ *   grad          out, n_par doubles, d llf / d par (the un-scaled gradient the reference hands L-BFGS-B,
+ *                 SURVEY 8a quirks); NULL to skip the gradient (saves potri + contraction)
+ * Returns BOGP_ERR_NOT_POSDEF / BOGP_ERR_LLF_POSITIVE where the reference returns -inf.                 */
+int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
+             int estimate_trend, double beta, double* llf, double* grad);
+
+/* ---- commit a fitted state ------------------------------------------------------------------------
+ * Replaces the tail of GaussianProcess.fit (gpr.py:402-415) + compute_beta_gamma (:784-788): factorise at
+ * the final parameters and keep L, V = L^-1 (packed for the MFMA sweep), gamma, beta, w = L^-T Ft on the
+ * device.  Same arguments as bogp_nll.                                                                  */
+int bogp_commit(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
+                int estimate_trend, double beta, double* llf);
+
+/* Read the committed state back (so the Python attributes C, gamma, rho, Yt, Ft, G, Q, beta, sigma2 stay
+ * populated and the object stays picklable, base.py:499-540).  Any pointer may be NULL.
+ *   C (N x N row-major lower Cholesky factor, strict upper = 0), gamma/rho/Yt/Ft/Q (N), G, beta, sigma2,
+ *   noise_var (scalars).                                                                                */
+int bogp_get_state(bogp_handle* h, double* C, double* gamma, double* rho, double* Yt, double* Ft, double* Q,
+                   double* G, double* beta, double* sigma2, double* noise_var);
+
+/* ---- candidates -----------------------------------------------------------------------------------
+ * M x d row-major float64.  `upload` copies from host (PCIe); `bind` adopts caller-owned DEVICE memory
+ * (e.g. a torch tensor's data_ptr()) without copying -- it must stay alive until the next upload/bind.   */
+int bogp_candidates_upload(bogp_handle* h, const double* Xs, int64_t M);
+int bogp_candidates_bind(bogp_handle* h, const void* d_Xs, int64_t M);
+
+/* ---- posterior ------------------------------------------------------------------------------------
+ * Replaces GaussianProcess.predict(X, eval_MSE) (gpr.py:486-510) on the current candidates:
+ * mu (M) and mse (M, may be NULL) are HOST buffers.                                                     */
+int bogp_predict(bogp_handle* h, double* mu, double* mse);
+
+/* ---- sweep: posterior + q acquisition criteria + argmax ---------------------------------------------
+ * Replaces the inner maximiser behind acquisition/optim/__init__.py:55-153 (argmax_restart) for
+ * optimizer="sweep", evaluating AcquisitionFunction.__call__ row by row (acquisition_fun.py:127-135,
+ * 153-176, 208-217, 265-290; _predict :52-64; plugin :96-104) for q criteria that share (mu, MSE)
+ * (ParallelBO._batch_arg_max_acquisition, bayes_opt.py:100-115).
+ *   plugin    effective plugin as stored by ImprovementBased.plugin (already negated when maximising)
+ *   minimize  0/1 as AcquisitionFunction.minimize
+ *   best_val  out (q): acquisition value at the argmax;  best_idx out (q): np.argmax index (first
+ *             maximum; a NaN, if present, wins at its first position) -- local to these M candidates
+ *   acq_out   optional HOST buffer (q x M row-major) receiving every acquisition value; NULL to skip     */
+int bogp_sweep(bogp_handle* h, int q, const int* acq_id, const double* acq_par, double plugin, int minimize,
+               double* best_val, int64_t* best_idx, double* acq_out);
+
+/* ---- input-gradient of the posterior at ONE point ---------------------------------------------------
+ * Replaces GaussianProcess.gradient(x) (gpr.py:537-576, corr_dx :600-661): dmu (d), dmse (d).            */
+int bogp_gradient(bogp_handle* h, const double* x, double* dmu, double* dmse);
+
+/* ---- measurement ----------------------------------------------------------------------------------
+ * HIP-event durations (ms, summed over candidate chunks) of the kernels of the LAST bogp_predict /
+ * bogp_sweep call, recorded on the library's own stream: corr (k_corr_chunk, the K* producer), contract
+ * (k_contract, the dominant L^-1 MFMA contraction) and acquisition/argmax.  n_chunks = launches of each.  */
+int bogp_last_timing(bogp_handle* h, double* corr_ms, double* contract_ms, double* acquisition_ms, int* n_chunks);
+
+/* Algorithmic FP64 flops per candidate of the posterior for the committed model:
+ * N^2 + N (3d + 5 + 2p)  (SURVEY.md section 8d).                                                        */
+double bogp_flops_per_candidate(const bogp_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOGP_H */
