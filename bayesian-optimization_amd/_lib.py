@@ -65,6 +65,14 @@ def load():
             "libbogp.so not found at %s -- build it with `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH
         )
+    # Load order matters: the PyTorch wheel bundles its own libamdhip64 / librocblas / librocsolver with the SAME
+    # sonames as /opt/rocm's.  The dynamic loader keeps whichever copy comes first, and torch crashes when it is
+    # handed the system copies; the other way round (libbogp on torch's copies) works.  So torch goes first
+    # whenever it is installed (it provides torch.distributed for the multi-GPU exchange anyway).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI and this table drift apart

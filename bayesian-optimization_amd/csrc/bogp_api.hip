@@ -569,7 +569,8 @@ extern "C" int bogp_sweep(bogp_handle* h, int q, const int* acq_id, const double
   if (q <= 0 || !acq_id || !best_val || !best_idx) FAIL(h, BOGP_ERR_INVALID, "bogp_sweep: q > 0 and non-null acq_id/best_val/best_idx required");
   for (int i = 0; i < q; ++i) {
     if (acq_id[i] < 0 || acq_id[i] > 3) FAIL(h, BOGP_ERR_INVALID, "unknown acquisition id %d", acq_id[i]);
-    if (acq_id[i] != BOGP_ACQ_EI && (!acq_par || !(acq_par[i] > 0)))
+    const bool zero_ok = acq_id[i] == BOGP_ACQ_EPSILON_PI;  // epsilon = 0 is plain PI
+    if (acq_id[i] != BOGP_ACQ_EI && (!acq_par || !(acq_par[i] > 0 || (zero_ok && acq_par[i] == 0))))
       FAIL(h, BOGP_ERR_INVALID, "acquisition parameter %d must be > 0 (the reference asserts alpha/epsilon/t > 0)", i);
   }
   int rc = run_sweep(h, false, q, acq_id, acq_par, plugin, minimize, acq_out != nullptr);

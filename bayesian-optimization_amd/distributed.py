@@ -1,0 +1,77 @@
+"""One exchange step per sweep: all-gather of q x (value, global index [, point]) + identical deterministic reduce.
+
+RCCL has no MAXLOC and an (f64, i64) pair does not pack into one max-reducible 64-bit key, hence gather-then-reduce
+(SURVEY.md section 8e).  Over xGMI this is latency-bound (q * 16 B per rank); it is issued once per `ask()`, never
+per tile.  Works on any initialised `torch.distributed` backend: "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests.
+Without an initialised process group it is the identity (single GPU).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+    except Exception:  # torch absent: single-process use only
+        return None
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def reduce_pairs(vals: np.ndarray, idxs: np.ndarray) -> np.ndarray:
+    """vals, idxs: (R, q).  Per criterion pick the winning rank with np.argmax semantics over the concatenated
+    global array: the maximum value, a NaN (if any) beats every number, ties -> lowest global index."""
+    vals = np.asarray(vals, dtype=np.float64)
+    idxs = np.asarray(idxs, dtype=np.int64)
+    R, q = vals.shape
+    win = np.zeros(q, dtype=np.int64)
+    for c in range(q):
+        b = 0
+        for r in range(1, R):
+            av, bv = vals[r, c], vals[b, c]
+            an, bn = np.isnan(av), np.isnan(bv)
+            if an != bn:
+                better = an
+            elif not an and av != bv:
+                better = av > bv
+            else:
+                better = idxs[r, c] < idxs[b, c]
+            if better:
+                b = r
+        win[c] = b
+    return win
+
+
+def exchange_argmax(best_val: np.ndarray, best_gidx: np.ndarray, best_x: Optional[np.ndarray] = None, group=None):
+    """All ranks call this with their local winners; all ranks return the same global winners
+    (best_val (q,), best_gidx (q,), best_x (q, d) or None)."""
+    best_val = np.ascontiguousarray(best_val, dtype=np.float64)
+    best_gidx = np.ascontiguousarray(best_gidx, dtype=np.int64)
+    dist = _dist()
+    if dist is None or dist.get_world_size(group) == 1:
+        return best_val, best_gidx, best_x
+    import torch
+
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    q = len(best_val)
+    d = 0 if best_x is None else best_x.shape[1]
+    # one buffer: [val | idx (bit pattern) | x] per criterion, all float64-sized words -> ONE collective
+    pack = np.empty((q, 2 + d), dtype=np.float64)
+    pack[:, 0] = best_val
+    pack[:, 1] = best_gidx.view(np.float64)
+    if d:
+        pack[:, 2:] = best_x
+    mine = torch.from_numpy(pack).to(dev)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine, group=group)
+    allp = torch.stack(gathered).cpu().numpy()  # (R, q, 2 + d)
+    vals = allp[:, :, 0]
+    idxs = np.ascontiguousarray(allp[:, :, 1]).view(np.int64)
+    win = reduce_pairs(vals, idxs)
+    ar = np.arange(q)
+    out_x = allp[win, ar, 2:] if d else None
+    return vals[win, ar].copy(), idxs[win, ar].copy(), out_x

@@ -1,0 +1,126 @@
+"""Inner maximiser of the acquisition function: the M-candidate GPU sweep behind `argmax_restart`'s signature.
+
+The reference maximises one criterion with multi-restart L-BFGS-B / (1+1)-CMA-ES / MIES, ONE point per call
+(`bayes_optim/acquisition/optim/__init__.py:55-153`; <= 100 d points per `ask()`).  The sweep is a new option
+behind the same signature (`optimizer="sweep"`): sample `eval_budget` candidates in the box, evaluate posterior +
+criterion for all of them in one device pass, return the argmax as `(xopt: list, fopt: float)`.
+q criteria that differ only in their parameter (ParallelBO's t / alpha draws, `bayes_opt.py:100-115`) share one
+posterior pass: `sweep_argmax(criteria=[...])`.
+
+Candidates shard across ranks (one process per GPU): every rank sweeps its own block and ONE exchange of
+q x (value, global index) decides the winner (`distributed.exchange_argmax`).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+from scipy.optimize import fmin_l_bfgs_b
+
+from . import distributed
+
+
+class Box:
+    """Minimal continuous search space with the three members of `RealSpace` the maximiser touches
+    (`search_space.py:724-769`: `bounds`, `dim`, `sample(N, method)`)."""
+
+    def __init__(self, bounds, random_seed=None):
+        self.bounds = [tuple(map(float, b)) for b in bounds]
+        self.dim = len(self.bounds)
+        self._rng = np.random.default_rng(random_seed)
+
+    def sample(self, N=1, method="uniform"):
+        lo = np.array([b[0] for b in self.bounds])
+        hi = np.array([b[1] for b in self.bounds])
+        return self._rng.uniform(lo, hi, size=(int(N), self.dim))
+
+
+def shard_bounds(M: int, rank: int, world: int):
+    """Contiguous block of rank r: rows [r M / R, (r+1) M / R)."""
+    return (rank * M) // world, ((rank + 1) * M) // world
+
+
+def candidate_block(bounds, M: int, seed: int, rank: int = 0, world: int = 1) -> np.ndarray:
+    """This rank's block of M uniform candidates in the box: a deterministic function of (seed, rank, world)."""
+    lo = np.array([b[0] for b in bounds], dtype=float)
+    hi = np.array([b[1] for b in bounds], dtype=float)
+    a, b_ = shard_bounds(M, rank, world)
+    rng = np.random.default_rng([int(seed), int(rank), int(world)])
+    return rng.uniform(lo, hi, size=(b_ - a, len(lo)))
+
+
+def sweep_argmax(criteria: Sequence, Xs: np.ndarray, index_offset: int = 0, group=None, return_points: bool = True):
+    """Evaluate q criteria (same model, same minimize / plugin) on this rank's candidates `Xs` and reduce across
+    ranks.  Returns (best_val (q,), best_global_idx (q,), best_x (q, d) or None)."""
+    c0 = criteria[0]
+    model = c0.model
+    eng = model.engine
+    if getattr(model, "_committed_par", None) is None:
+        raise Exception("The model is not fitted yet!")
+    for c in criteria[1:]:
+        if c.model is not model or c.minimize != c0.minimize or c.effective_plugin() != c0.effective_plugin():
+            raise ValueError("criteria sharing one sweep must share model, minimize and plugin")
+    Xs = model._check_X(Xs)
+    eng.upload_candidates(Xs)
+    acq = [(c.acq_id, c.acq_par()) for c in criteria]
+    best, idx = eng.sweep(acq, c0.effective_plugin(), c0.minimize)
+    gidx = idx + int(index_offset)
+    xbest = Xs[idx] if return_points else None
+    return distributed.exchange_argmax(best, gidx, xbest, group=group)
+
+
+def argmax_restart(
+    obj_func: Callable,
+    search_space,
+    h: Callable = None,
+    g: Callable = None,
+    eval_budget: int = 100,
+    n_restart: int = 10,
+    wait_iter: int = 3,
+    optimizer: str = "BFGS",
+    logger=None,
+):
+    """Same signature and return convention as the reference's `argmax_restart` (optim/__init__.py:55-153).
+
+    optimizer="sweep": `obj_func` must be one of this package's acquisition objects; `eval_budget` candidates are
+    drawn with `search_space.sample(N, "uniform")` and swept on the GPU.
+    optimizer="BFGS": the reference's multi-restart L-BFGS-B loop on `obj_func(x) -> (value, dx)` (host; every
+    evaluation is one device call through the acquisition object).
+    """
+    if optimizer == "sweep":
+        if h is not None or g is not None:
+            raise NotImplementedError("constraints are handled by the reference's penalised optimisers, not the sweep")
+        Xs = np.asarray(search_space.sample(int(eval_budget), method="uniform"), dtype=float)
+        best, _, xb = sweep_argmax([obj_func], Xs)
+        return xb[0].tolist(), float(best[0])
+    if optimizer != "BFGS":
+        raise NotImplementedError("optimizer %r is out of scope here (SURVEY.md 2 rows 6-7); use 'BFGS' or 'sweep'" % optimizer)
+
+    xopt, fopt = [], []
+    best = -np.inf
+    wait_count = 0
+    bounds = np.array(search_space.bounds)
+
+    def neg(x):  # Penalized without constraints (optim/__init__.py:45-52)
+        f, fg = obj_func(np.asarray(x, dtype=float).reshape(1, -1), return_dx=True)
+        return -1.0 * float(np.asarray(f, float).ravel()[0]), -1.0 * np.asarray(fg, float).ravel()
+
+    for iteration in range(n_restart):
+        x0 = np.asarray(search_space.sample(N=1, method="uniform")[0], dtype=float)
+        xopt_, fopt_, stop_dict = fmin_l_bfgs_b(neg, x0, pgtol=1e-8, factr=1e6, bounds=bounds, maxfun=eval_budget)
+        xopt_ = xopt_.flatten().tolist()
+        fopt_ = -float(fopt_)
+        if fopt_ > best:
+            best = fopt_
+            wait_count = 0
+        else:
+            wait_count += 1
+        eval_budget -= stop_dict["funcalls"]
+        xopt.append(xopt_)
+        fopt.append(fopt_)
+        if eval_budget <= 0 or wait_count >= wait_iter:
+            break
+    if len(xopt) == 0:
+        return [], []
+    idx = np.argsort(fopt)[::-1]
+    return xopt[idx[0]], fopt[idx[0]]

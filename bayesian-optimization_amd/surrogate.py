@@ -1,0 +1,403 @@
+"""GPU GaussianProcess: drop-in for `bayes_optim.surrogate.GaussianProcess` on one MI355X.
+
+Satisfies the surrogate protocol of SURVEY.md section 8b (who calls what: `base.py:423-446` fit/predict,
+`acquisition_fun.py:52-80` predict/gradient, attributes `sigma2`, `y`, `is_fitted`) with the same constructor
+keywords as the reference (`surrogate/gaussian_process/gpr.py:211-228`).  All O(N^2)+ arithmetic runs in libbogp
+(HIP kernels + rocSOLVER); the host keeps only what the reference keeps on the host: the L-BFGS-B restart loop of
+the MLE (`gpr.py:1058-1197`) and input validation.  There is no CPU fallback.
+
+Differences from the reference, all deliberate and listed in DESIGN.md:
+  * `optimizer="CMA"`, `likelihood="restricted"`, multi-target y, non-constant trends: NotImplementedError
+    (out of scope / "next" rows) instead of running on the CPU.
+  * Matern-5/2 (`corr=functools.partial(matern, nu=2.5)` or `"matern52"`) can be FITTED: the device has its
+    theta- and x-derivatives, which the reference leaves as `pass` (gpr.py:647-648, 758-759).
+  * `predict(batch_size=...)` works (the reference's branch is dead code on Python 3, gpr.py:513-535); chunking
+    is done inside the library anyway.
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+from scipy.optimize import fmin_l_bfgs_b
+
+from . import _lib
+from .prior_mean import constant_trend, device_trend_of
+
+_KERNEL_IDS = {
+    "squared_exponential": _lib.KERNEL_SE,
+    "matern": _lib.KERNEL_MATERN32,  # the reference passes only (theta, d): nu defaults to 1.5 (kernel.py:159)
+    "matern12": _lib.KERNEL_MATERN12,
+    "matern32": _lib.KERNEL_MATERN32,
+    "matern52": _lib.KERNEL_MATERN52,
+}
+_UNBUILT_KERNELS = ("absolute_exponential", "generalized_exponential", "cubic", "linear")
+_NU_IDS = {0.5: _lib.KERNEL_MATERN12, 1.5: _lib.KERNEL_MATERN32, 2.5: _lib.KERNEL_MATERN52}
+
+
+def kernel_id_of(corr) -> int:
+    """Map the reference's `corr` argument (a name, or a callable such as functools.partial(matern, nu=2.5))."""
+    if isinstance(corr, str):
+        if corr in _KERNEL_IDS:
+            return _KERNEL_IDS[corr]
+        if corr in _UNBUILT_KERNELS:
+            raise NotImplementedError("correlation %r is not built on the device yet (SURVEY.md 8 f4)" % corr)
+        raise ValueError("corr should be one of %s or callable, %s was given." % (list(_KERNEL_IDS), corr))
+    func = getattr(corr, "func", corr)
+    name = getattr(func, "__name__", "")
+    if name == "squared_exponential":
+        return _lib.KERNEL_SE
+    if name == "matern":
+        nu = (getattr(corr, "keywords", None) or {}).get("nu", 1.5)
+        if nu in _NU_IDS:
+            return _NU_IDS[nu]
+        raise NotImplementedError("general-nu Matern (Bessel kv) is not built on the device")
+    raise NotImplementedError("callable correlation %r is not built on the device" % (corr,))
+
+
+class GaussianProcess:
+    """The Gaussian Process model class (GPU engine).  Constructor keywords as gpr.py:211-228, plus `device`."""
+
+    _optimizer_types = ["BFGS", "CMA"]
+    _likelihood_functions = ["concentrated", "restricted"]
+
+    def __init__(
+        self,
+        mean=None,
+        corr="squared_exponential",
+        theta0=None,
+        thetaL=None,
+        thetaU=None,
+        sigma2=None,
+        nugget=1e-6,
+        noise_estim=False,
+        optimizer="BFGS",
+        likelihood="concentrated",
+        random_start=1,
+        wait_iter=5,
+        eval_budget=None,
+        random_state=None,
+        verbose=False,
+        device=0,
+    ):
+        self.mean = mean
+        self.corr = corr
+        self.sigma2 = sigma2
+        self.verbose = bool(verbose)
+        self.corr_type = corr
+        self.kernel_id = kernel_id_of(corr)
+        self.is_fitted = False
+        self.device = int(device)
+
+        self.theta0 = np.array(theta0, dtype=float).flatten() if theta0 is not None else None
+        if thetaL is None or thetaU is None:
+            # np.array(None) makes np.isfinite raise TypeError in the reference (gpr.py:238-242): bounds are mandatory
+            raise TypeError("thetaL and thetaU are required (finite bounds of the MLE search box)")
+        self.thetaL = np.array(thetaL, dtype=float).flatten()
+        self.thetaU = np.array(thetaU, dtype=float).flatten()
+        if not (np.isfinite(self.thetaL).all() and np.isfinite(self.thetaU).all()):
+            raise ValueError("all bounds are required finite.")
+
+        self.optimizer = optimizer
+        self.random_start = int(random_start)
+        self.random_state = random_state
+        self.wait_iter = wait_iter
+        self.eval_budget = eval_budget
+
+        self.nugget = nugget
+        self.noise_var = np.atleast_1d(nugget) if nugget else 0
+        self.noise_estim = noise_estim
+        self.noisy = bool(self.noise_var) or bool(self.noise_estim)
+        if not self.noisy:
+            self.estimation_mode = "noiseless"
+        elif self.noise_estim:
+            self.estimation_mode = "noise_estim"
+        else:
+            self.estimation_mode = "noisy"
+
+        assert likelihood in self._likelihood_functions
+        self.likelihood = likelihood
+        if self.mean is None:
+            self.mean = constant_trend(len(self.thetaU), beta=0)  # simple Kriging (gpr.py:269-270)
+        self.mean_type = "basis_expansion"
+        self.estimate_trend = self.mean.beta is None
+        self._engine = None
+        self._committed_par = None
+        self._check_params()
+
+    # ------------------------------------------------------------------------------------------------
+    # engine plumbing (the object stays picklable: base.py:499-540 dills the whole optimiser)
+    # ------------------------------------------------------------------------------------------------
+    _MODE = {"noiseless": _lib.MODE_NOISELESS, "noisy": _lib.MODE_NOISY, "noise_estim": _lib.MODE_NOISE_ESTIM}
+
+    @property
+    def engine(self) -> "_lib.Engine":
+        if self._engine is None:
+            self._engine = _lib.Engine(self.device)
+            if hasattr(self, "X"):
+                self._engine.set_train(self.X, self.y)
+                if self._committed_par is not None:
+                    self._commit(self._committed_par, refresh_attributes=False)
+        return self._engine
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_engine"] = None  # device handles never travel; re-created lazily from (X, y, par)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+
+    def _trend_args(self):
+        _, beta = device_trend_of(self.mean)  # raises for bases the device does not evaluate
+        # the estimation mode is fixed at construction (gpr.py:273-275); fit() later fills mean.beta with the GLS value
+        return self.estimate_trend, (0.0 if self.estimate_trend else beta)
+
+    def _nv(self) -> float:
+        return float(np.atleast_1d(self.noise_var)[0]) if self.estimation_mode == "noisy" else 0.0
+
+    # ------------------------------------------------------------------------------------------------
+    def _check_params(self):
+        """gpr.py:1199-1248 (the parts that apply)."""
+        if self.thetaL.size != self.thetaU.size:
+            raise ValueError("thetaL and thetaU must have the same length.")
+        if self.theta0 is not None and self.theta0.size != self.thetaL.size:
+            raise ValueError("theta0, thetaL, and thetaU must have the same length.")
+        if np.any(self.thetaL <= 0) or np.any(self.thetaU < self.thetaL):
+            raise ValueError("The bounds must satisfy O < thetaL <= thetaU.")
+        if self.optimizer not in self._optimizer_types:
+            raise ValueError("optimizer should be one of %s" % self._optimizer_types)
+        if self.optimizer == "CMA":
+            raise NotImplementedError("optimizer='CMA' is out of scope (SURVEY.md 2 row 8); use 'BFGS'")
+        if self.likelihood == "restricted":
+            raise NotImplementedError("likelihood='restricted' (REML, gpr.py:813-918) is a 'next' row; use 'concentrated'")
+
+    def _check_data(self, X, y):
+        """gpr.py:279-310 without the pair-distance list (never built on the device)."""
+        X = np.asarray(X, dtype=np.float64)  # also coerces a `Solution` (object dtype), like check_X_y
+        y = np.asarray(y, dtype=np.float64)
+        if X.ndim != 2:
+            raise ValueError("Expected 2D array, got %dD array instead" % X.ndim)
+        if y.ndim == 1:
+            y = y.reshape(-1, 1)
+        if X.shape[0] != y.shape[0]:
+            raise ValueError("Found input variables with inconsistent numbers of samples: [%d, %d]" % (X.shape[0], y.shape[0]))
+        if not (np.isfinite(X).all() and np.isfinite(y).all()):
+            raise ValueError("Input contains NaN, infinity or a value too large for dtype('float64').")
+        if y.shape[1] != 1:
+            raise NotImplementedError("multi-target y is only used by MOBO and is not built on the device (SURVEY.md 8 f3)")
+        if self.thetaL.size not in (1, X.shape[1]):
+            raise ValueError("Length of theta must be 1 or %s" % X.shape[1])
+        self.X, self.y = np.ascontiguousarray(X), np.ascontiguousarray(y)
+        self._committed_par = None
+        self.engine.set_train(self.X, self.y)
+
+    # ------------------------------------------------------------------------------------------------
+    # likelihood (gpr.py:920-1040) -- evaluated on the device
+    # ------------------------------------------------------------------------------------------------
+    def log_likelihood_concentrated(self, par, env=None, eval_grad=False):
+        par = np.asarray(par, dtype=np.float64).ravel()
+        est, beta = self._trend_args()
+        mode = self._MODE[self.estimation_mode]
+        try:
+            if env is not None:
+                llf = self._commit(par, refresh_attributes=False)
+                st = self.engine.get_state()
+                env.update(
+                    sigma2=np.atleast_1d(st["sigma2"]), noise_var=st["noise_var"], rho=st["rho"].reshape(-1, 1),
+                    Yt=st["Yt"].reshape(-1, 1), C=st["C"], Ft=st["Ft"].reshape(-1, 1) if est else None,
+                    G=np.array([[st["G"]]]) if est else None, Q=st["Q"].reshape(-1, 1) if est else None,
+                    beta=st["beta"], gamma=st["gamma"].reshape(-1, 1),
+                )  # fmt: skip
+                if not eval_grad:
+                    return llf
+            out = self.engine.nll(self.kernel_id, mode, par, self._nv(), est, beta, eval_grad=eval_grad)
+            if env is not None and eval_grad:
+                self._committed_par = None  # nll overwrote the factor buffers
+            return out
+        except _lib.NotPositiveDefinite:
+            # Cholesky failure or llf > 0: the reference's -inf convention (gpr.py:946-947, 981-982)
+            return (-np.inf, np.zeros((len(par), 1))) if eval_grad else -np.inf
+
+    def _commit(self, par, refresh_attributes=True) -> float:
+        est, beta = self._trend_args()
+        llf = self.engine.commit(self.kernel_id, self._MODE[self.estimation_mode], par, self._nv(), est, beta)
+        self._committed_par = np.array(par, dtype=float)
+        if refresh_attributes:
+            self._pull_state(par)
+        return llf
+
+    def _pull_state(self, par):
+        """The tail of fit(): gpr.py:402-415 + compute_beta_gamma (:784-788)."""
+        st = self.engine.get_state()
+        n_theta = len(self.thetaL)
+        self.theta_ = np.array(par[:n_theta], dtype=float)
+        self.noise_var = st["noise_var"]
+        self.sigma2 = np.atleast_1d(st["sigma2"]).astype(float)
+        self.rho = st["rho"].reshape(-1, 1)
+        self.Yt = st["Yt"].reshape(-1, 1)
+        self.C = st["C"]
+        self.gamma = st["gamma"].reshape(-1, 1)
+        if self.estimate_trend:
+            self.Ft = st["Ft"].reshape(-1, 1)
+            self.G = np.array([[st["G"]]])
+            self.Q = st["Q"].reshape(-1, 1)
+            self.mean.beta = st["beta"]
+
+    # ------------------------------------------------------------------------------------------------
+    # MLE (gpr.py:1042-1197): the host loop is the reference's; every objective evaluation is a device call
+    # ------------------------------------------------------------------------------------------------
+    def _hyperparameter_bound(self, par_list):
+        bounds = []
+        for name in par_list:
+            if name == "theta":
+                bounds.append(np.c_[self.thetaL, self.thetaU])
+            elif name == "sigma2":
+                bounds.append(np.atleast_2d([1e-5, max(1e-3, self.y.std() ** 2)]))
+            elif name == "alpha":
+                bounds.append(np.atleast_2d([1e-10, 1.0 - 1e-10]))
+        return np.concatenate(bounds, axis=0)
+
+    def _optimize_hyperparameter(self):
+        par_list, par_len = ["theta"], [len(self.thetaL)]
+        if self.estimation_mode == "noisy":
+            par_list.append("sigma2")
+            par_len.append(1)
+        if self.estimation_mode == "noise_estim":
+            par_list.append("alpha")
+            par_len.append(1)
+        bounds = self._hyperparameter_bound(par_list)
+        log10bounds = np.log10(bounds)
+        n_theta = len(self.thetaL)
+        # warm start from the previous optimum when refitting (:1095-1107); draws use the GLOBAL np.random, as there
+        if hasattr(self, "theta_"):
+            log10theta0 = np.log10(self.theta_)
+        else:
+            log10theta0 = (
+                np.log10(self.theta0)
+                if self.theta0 is not None
+                else np.random.uniform(np.log10(self.thetaL), np.log10(self.thetaU))
+            )
+        if self.estimation_mode == "noiseless":
+            log10param = log10theta0
+        else:
+            log10param = np.r_[log10theta0, np.random.uniform(log10bounds[n_theta:, 0], log10bounds[n_theta:, 1])]
+        n_par = len(log10param)
+        eval_budget = 200 * n_par if self.eval_budget is None else self.eval_budget
+        llf_opt = np.inf
+        self.eval_count = 0
+
+        def obj_func(log10param):
+            # NB: the gradient handed to L-BFGS-B is d llf / d param, NOT d / d log10 param (SURVEY.md 8a quirk,
+            # gpr.py:1113-1123); reproduced so that the optimiser walks the reference's trajectory
+            self.eval_count += 1
+            param = 10.0 ** np.array(log10param)
+            llf, grad = self.log_likelihood_concentrated(param, eval_grad=True)
+            return -1.0 * llf, -1.0 * np.asarray(grad, dtype=float).ravel()
+
+        wait_count = 0
+        for iteration in range(self.random_start):
+            if iteration != 0:
+                log10param = np.random.uniform(log10bounds[:, 0], log10bounds[:, 1])
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                param_opt_, llf_opt_, info = fmin_l_bfgs_b(obj_func, log10param, bounds=log10bounds, maxfun=eval_budget)
+            if iteration == 0:
+                param_opt, llf_opt = param_opt_, llf_opt_
+            elif llf_opt_ <= llf_opt:
+                param_opt, llf_opt = param_opt_, llf_opt_
+                wait_count = 0
+            else:
+                wait_count += 1
+            if self.verbose:
+                print("restart {} takes {} evals".format(iteration + 1, info["funcalls"]))
+                print("best log likekihood value: {}".format(-llf_opt))
+            eval_budget -= info["funcalls"]
+            if eval_budget <= 0 or wait_count >= self.wait_iter:
+                break
+
+        optimal_param = 10.0**param_opt
+        env = {}
+        optimal_llf_value = self.log_likelihood_concentrated(optimal_param, env)
+        param, i = {}, 0
+        for name, len_ in zip(par_list, par_len):
+            param[name] = optimal_param[i : i + len_]
+            i += len_
+        return param, optimal_llf_value, env, optimal_param
+
+    def fit(self, X, y):
+        """gpr.py:355-417.  Returns self; sets `is_fitted`."""
+        self._check_data(X, y)
+        n_retry = 0
+        while True:
+            self.par, self.log_likelihood_, env, optimal_param = self._optimize_hyperparameter()
+            if np.isinf(self.log_likelihood_):
+                print("Invalid likelihood value. Increasing nugget...")  # gpr.py:384-399
+                if self.estimation_mode == "noiseless":
+                    self.estimation_mode = "noisy"
+                    self.noise_var = 1e-5
+                else:
+                    self.noise_var = np.atleast_1d(self.noise_var) * 10
+                n_retry += 1
+                if n_retry > 12:  # the reference loops forever; bound it (noise_var would exceed 1e7)
+                    raise np.linalg.LinAlgError("likelihood stays -inf after %d nugget increases" % n_retry)
+            else:
+                break
+        # `log_likelihood_concentrated(par, env)` committed the model at the optimum: pull the attributes
+        self._pull_state(optimal_param)
+        self.is_fitted = True
+        return self
+
+    def update(self, X, y):
+        self.fit(X, y)
+        return self
+
+    def set_state(self, par, X=None, y=None):
+        """Pin a fitted state at given hyper-parameters without running the MLE (what SURVEY.md Appendix A does to
+        the reference with `_check_data` + one likelihood call + attribute copy).  Returns the log-likelihood."""
+        if X is not None:
+            self._check_data(X, y)
+        par = np.asarray(par, dtype=float).ravel()
+        llf = self._commit(par)
+        self.log_likelihood_ = llf
+        self.is_fitted = True
+        return llf
+
+    # ------------------------------------------------------------------------------------------------
+    # posterior (gpr.py:424-535) and its input-gradient (gpr.py:537-576)
+    # ------------------------------------------------------------------------------------------------
+    def _check_X(self, X):
+        X = np.asarray(X, dtype=np.float64)
+        if X.ndim == 1:
+            X = X.reshape(1, -1)
+        if X.shape[1] != self.X.shape[1]:
+            raise ValueError(
+                "The number of features in X (X.shape[1] = %d) should match the number of features used for fit() which is %d."
+                % (X.shape[1], self.X.shape[1])
+            )
+        if not np.isfinite(X).all():
+            raise ValueError("Input contains NaN, infinity or a value too large for dtype('float64').")
+        return np.ascontiguousarray(X)
+
+    def predict(self, X, eval_MSE=False, batch_size=None):
+        assert hasattr(self, "X")
+        if self._committed_par is None:
+            raise Exception("The model is not fitted yet!")
+        X = self._check_X(X)
+        if batch_size is not None and (type(batch_size) is not int or batch_size <= 0):
+            raise Exception("batch_size must be a positive integer")
+        eng = self.engine
+        eng.upload_candidates(X)
+        mu, mse = eng.predict(eval_MSE=eval_MSE)
+        if eval_MSE:
+            return mu.reshape(-1, 1), mse.reshape(-1, 1)
+        return mu.reshape(-1, 1)
+
+    def gradient(self, x):
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        if x.shape[1] != self.X.shape[1]:
+            raise Exception("x does not have the right size!")
+        if x.shape[0] != 1:
+            raise Exception("x must be a vector!")
+        dmu, dmse = self.engine.gradient(x[0])
+        return dmu.reshape(-1, 1), dmse.reshape(-1, 1)

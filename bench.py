@@ -1,0 +1,192 @@
+"""bench.py -- candidates/sec of the GP posterior + acquisition + argmax sweep on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]                      (N = 1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic candidates already resident in HBM: posterior
+(mu, MSE) of M candidates per GPU + q = 2 criteria (MGFI t=2, EI) + argmax, then the one cross-rank exchange of the
+per-shard winners.  Workload = BASELINE.json configs[2] ("C3", the configuration the metric is quoted on):
+N = 2048 training points, d = 20, Matern-5/2, M = 1e6 candidates per GPU (weak scaling: configs[3] is 8 x 1e6).
+Hyper-parameters are pinned (theta = 0.01, sigma2 = 0.9, nugget 1e-6, simple kriging), not fitted, as SURVEY.md
+section 8d prescribes; X ~ U[-5,5], y = sum x^2 standardised; seeds fixed.
+
+Prints ONE JSON line (rank 0) with the driver's fields + "roofline" (dominant kernel k_contract: algorithmic FP64
+flops / HIP-event duration on the library's stream) + "cpu_baseline" (the NumPy oracle timed on this box's host
+cores on a bounded sample of the same workload; also used as a parity check of the timed run).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+PEAK_FP64_TFLOPS = 78.6  # MI355X FP64 vector = matrix peak (AMD spec; 256 CU x 128 flop/clk x 2.4 GHz)
+WORKLOADS = {
+    "C2": dict(N=512, d=10, M=100_000, kernel=0, theta=0.02, acq=[(0, 0.0)], name="C2: N=512 d=10 M=1e5 SE EI"),
+    "C3": dict(N=2048, d=20, M=1_000_000, kernel=3, theta=0.01, acq=[(3, 2.0), (0, 0.0)],
+               name="C3: N=2048 d=20 M=1e6/GPU Matern-5/2 MGFI(t=2)+EI"),  # fmt: skip
+    "C5": dict(N=8192, d=50, M=500_000, kernel=0, theta=0.004, acq=[(2, 0.5)], name="C5: N=8192 d=50 M=5e5/GPU SE UCB"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample", type=int, default=16384, help="candidates timed through the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from bogp import _lib, distributed
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs a %d-rank torch.distributed.run launch (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    w = WORKLOADS[args.workload]
+    N, d, M = w["N"], w["d"], w["M"]
+    rng = np.random.default_rng(0)  # the model is replicated: every rank builds and factorises the same one
+    X = rng.uniform(-5, 5, size=(N, d))
+    y = np.sum(X**2, axis=1)
+    y = ((y - y.mean()) / y.std()).reshape(-1, 1)
+    par = np.r_[np.full(d, w["theta"]), 0.9]
+    plugin = float(y.min())
+
+    eng = _lib.Engine(local)
+    eng.set_train(X, y)
+    t0 = time.perf_counter()
+    llf = eng.commit(w["kernel"], _lib.MODE_NOISY, par, 1e-6, False, 0.0)
+    commit_s = time.perf_counter() - t0
+
+    # this rank's candidate shard, generated on the device and adopted without a copy
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234 + rank)
+    Xs = (torch.rand((M, d), dtype=torch.float64, device="cuda", generator=g) * 10.0 - 5.0).contiguous()
+    torch.cuda.synchronize()
+    eng.bind_candidates(Xs.data_ptr(), M, owner=Xs)
+    offset = rank * M
+
+    def step():
+        best, idx = eng.sweep(w["acq"], plugin, True)
+        return distributed.exchange_argmax(best, idx + offset, None)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    tim = dict(corr_ms=0.0, contract_ms=0.0, acquisition_ms=0.0, n_chunks=0)
+    for _ in range(args.steps):
+        out = step()
+        lt = eng.last_timing()
+        for k in tim:
+            tim[k] += lt[k]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # PCIe-inclusive ask(): H2D of the shard + one step (noted, never `value`)
+    h2d_ms = None
+    if rank == 0:
+        Xh = Xs.cpu().numpy()
+        t1 = time.perf_counter()
+        eng.upload_candidates(Xh)
+        eng.sweep(w["acq"], plugin, True)
+        h2d_ms = (time.perf_counter() - t1) * 1e3
+        eng.bind_candidates(Xs.data_ptr(), M, owner=Xs)
+
+    if rank == 0:
+        total = float(M) * world * args.steps
+        value = total / elapsed
+        flops_contract = (float(N) * N + 3.0 * N) * M * args.steps  # k_contract: forward substitution + sum of squares
+        achieved = flops_contract / (tim["contract_ms"] * 1e-3) / 1e12
+        res = {
+            "metric": "candidates/sec (GP posterior+EI) at N=2048,d=20 and ask() wall-time, 1/2/4/8 GPU",
+            "value": value,
+            "unit": "candidates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": w["name"], "N": N, "d": d, "M_per_gpu": M, "q": len(w["acq"]),
+                       "parallelism": "candidate shards x%d, 1 all-gather of q*(val,idx) per step" % world},
+            "roofline": {
+                "bound": "mfma", "kernel": "k_contract (v_mfma_f64_4x4x4_4b_f64)", "achieved": achieved, "peak": PEAK_FP64_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS, "traffic": None,
+                "avg_launch_ms": tim["contract_ms"] / max(1, tim["n_chunks"]), "launches": tim["n_chunks"],
+                "flops_per_candidate": float(N) * N + 3.0 * N,
+            },
+            "kernels_ms_per_step": {k: tim[k] / args.steps for k in ("corr_ms", "contract_ms", "acquisition_ms")},
+            "whole_step_tflops": eng.flops_per_candidate() * M / (elapsed / args.steps) / 1e12,
+            "ask_ms": elapsed / args.steps * 1e3,
+            "ask_ms_with_h2d": h2d_ms,
+            "commit_s": commit_s,
+            "llf": llf,
+            "argmax": [int(i) for i in out[1]],
+        }
+        if world == 1 and not args.no_cpu:
+            res["cpu_baseline"] = cpu_baseline(w, X, y, par, plugin, Xh, args.cpu_sample, eng)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(w, X, y, par, plugin, Xh, n_sample, eng):
+    """The oracle ('port' of gpr.py:486-510 + the vectorised acquisition closed forms) on a bounded sample of the
+    same candidates, 1024-row chunks, BLAS threads = all host cores.  Doubles as a parity check of the GPU run."""
+    from oracle import gp_oracle as O
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    n = min(n_sample, len(Xh))
+    st = O.make_state(par, X, y, w["kernel"], O.MODE_NOISY, 1e-6)
+    O.sweep(st, Xh[:1024], w["acq"], plugin, True)  # warm-up
+    t0 = time.perf_counter()
+    obest, oidx, ovals, omu, omse = O.sweep(st, Xh[:n], w["acq"], plugin, True, return_values=True)
+    dt = time.perf_counter() - t0
+    # parity of the very run that was timed: same rows through the GPU path
+    eng.upload_candidates(Xh[:n])
+    mu, mse = eng.predict()
+    best, idx = eng.sweep(w["acq"], plugin, True)
+    np.testing.assert_allclose(mu, omu.ravel(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(mse, omse.ravel(), rtol=1e-6, atol=1e-12)
+    np.testing.assert_array_equal(idx, oidx)
+    return {"value": n / dt, "unit": "candidates/s", "cores": threads, "kind": "port",
+            "sample": "%d of the timed run's candidates, 1024-row chunks, NumPy/SciPy oracle; parity vs GPU checked (1e-6, argmax exact)" % n,
+            "seconds": dt}  # fmt: skip
+
+
+if __name__ == "__main__":
+    main()

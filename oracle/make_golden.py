@@ -269,6 +269,34 @@ def main():
     res = bayes_optim.fmin(lambda x: float(np.sum(np.asarray(x) ** 2)), [-5.0, -5.0], [5.0, 5.0], max_FEs=30, seed=42, verbose=False)
     save("G9_fmin_plumbing", n_ret=np.array(len(res)), n_x=np.array(len(res[0])), n_iter=np.array(res[2]),
          n_eval=np.array(res[3]))  # fmt: skip
+    golden_fit()
+
+
+def golden_fit():
+    """G10: full GaussianProcess.fit (MLE through L-BFGS-B restarts) by the reference on seeded data; the GPU
+    class replays the same host loop (same global np.random stream) and must land on the same optimum."""
+    out = {}
+    for tag, kw, d, N in (
+        ("se_sk_noisy", dict(corr="squared_exponential", nugget=1e-6), 3, 40),
+        ("m32_ok_noisy", dict(corr="matern", nugget=1e-6, mean="ok"), 2, 30),
+        ("se_sk_noise_estim", dict(corr="squared_exponential", nugget=1e-6, noise_estim=True), 3, 40),
+    ):
+        X, y = make_data(10 + d + N, N, d)
+        y = y + 0.05 * np.random.default_rng(5).standard_normal(y.shape)  # a little noise keeps llf <= 0
+        kw = dict(kw)
+        mean = trend.constant_trend(d) if kw.pop("mean", None) == "ok" else None
+        gp = GaussianProcess(mean=mean, thetaL=[1e-3] * d, thetaU=[1e2] * d, optimizer="BFGS", wait_iter=3,
+                             random_start=5, eval_budget=100 * d, **kw)  # fmt: skip
+        np.random.seed(123)
+        gp.fit(X, y)
+        Xs = np.random.default_rng(6).uniform(-5, 5, size=(64, d))
+        mu, mse = gp.predict(Xs, eval_MSE=True)
+        out.update({
+            tag + "_X": X, tag + "_y": y, tag + "_theta": gp.theta_, tag + "_sigma2": gp.sigma2,
+            tag + "_noise_var": np.atleast_1d(gp.noise_var).astype(float), tag + "_llf": np.array(gp.log_likelihood_),
+            tag + "_Xs": Xs, tag + "_mu": mu, tag + "_mse": mse, tag + "_beta": np.asarray(gp.mean.beta, float),
+        })  # fmt: skip
+    save("G10_fit", **out)
 
 
 def _g8_outputs(gp, Xs):

@@ -1,0 +1,68 @@
+"""world_size-2 `gloo` test of the one exchange step of the sharded sweep (runs on CPU: the local winners are
+synthetic, the collective + deterministic reduce are the product code)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q_out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from bogp import distributed, optim
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        M, d, q = 1001, 3, 4
+        rng = np.random.default_rng(7)  # every rank builds the SAME global table, then takes its shard
+        table = rng.standard_normal((q, M)).round(2)
+        table[1, :] = 0.25  # plateau -> global index 0 must win
+        table[2, 700] = np.nan  # NaN is maximal for np.argmax
+        table[3, [10, 900]] = 9.0  # cross-rank tie -> lower global index
+        X = rng.uniform(-1, 1, size=(M, d))
+        a, b = optim.shard_bounds(M, rank, world)
+        loc = table[:, a:b]
+        li = np.array([int(np.argmax(loc[c])) for c in range(q)])
+        lv = loc[np.arange(q), li]
+        v, gi, x = distributed.exchange_argmax(lv, li + a, X[a:b][li])
+        q_out.put((rank, v, gi, x, table, X))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_exchange_matches_global_argmax():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q_out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q_out.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, v, gi, x, table, X in res:
+        for c in range(table.shape[0]):
+            ref = int(np.argmax(table[c]))
+            assert gi[c] == ref, (rank, c, gi[c], ref)
+            np.testing.assert_array_equal(v[c], table[c, ref])
+            np.testing.assert_array_equal(x[c], X[ref])
+    # both ranks hold identical results
+    np.testing.assert_array_equal(res[0][2], res[1][2])

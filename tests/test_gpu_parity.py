@@ -1,0 +1,390 @@
+"""Parity tests proper: the HIP path (through the C ABI / ctypes) against the oracle and the committed goldens.
+
+Tolerances (north_star: mu / sigma / acquisition within 1e-6 rtol, argmax index bit-exact):
+  * mu:   |d| <= 1e-6 |ref| + 1e-9        (mu crosses 0; 1e-9 is ~1e-9 of the unit-variance fitness scale)
+  * MSE:  |d| <= 1e-6 |ref| + 1e-12 sigma2 (MSE is a cancellation 1 - |L^-1 r|^2; near training points only the
+          absolute error is meaningful)
+  * acquisition: 1e-6 relative, except rows whose MSE is rounding noise (see tests/test_oracle_golden.py)
+  * argmax index: exact
+All of it needs a real MI355X: `pytest -m gpu`.
+"""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, state_from_golden
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+import bogp  # noqa: E402
+from bogp import _lib  # noqa: E402
+
+STATE_FILES = ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G3_m52_sk_noisy", "G4_se_ok_noiseless", "G5_se_sk_noise_estim", "G7_edges"]
+ACQ_KEYS = [("EI", O.ACQ_EI, 0.0), ("EpsilonPI_1e-10", O.ACQ_EPSILON_PI, 1e-10), ("UCB_0.5", O.ACQ_UCB, 0.5),
+            ("MGFI_1", O.ACQ_MGFI, 1.0), ("MGFI_2", O.ACQ_MGFI, 2.0), ("MGFI_100", O.ACQ_MGFI, 100.0)]  # fmt: skip
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = _lib.Engine(0)
+    yield e
+    e.close()
+
+
+def close_mu(a, ref):
+    np.testing.assert_allclose(np.ravel(a), np.ravel(ref), rtol=1e-6, atol=1e-9)
+
+
+def close_mse(a, ref, sigma2):
+    np.testing.assert_allclose(np.ravel(a), np.ravel(ref), rtol=1e-6, atol=1e-12 * float(sigma2))
+
+
+def commit_golden(eng, g):
+    mode, kernel = int(g["mode"]), int(g["kernel"])
+    est = bool(g["estimate_trend"])
+    nv = float(g["noise_var"][0]) if mode == O.MODE_NOISY else 0.0
+    eng.set_train(g["X"], g["y"])
+    return eng.commit(kernel, mode, g["par"], nv, est, 0.0)
+
+
+@pytest.mark.parametrize("name", STATE_FILES)
+def test_committed_state_matches_reference(eng, name):
+    g = load_golden(name)
+    llf = commit_golden(eng, g)
+    np.testing.assert_allclose(llf, g["llf"], rtol=1e-10)
+    s = eng.get_state()
+    scale = np.abs(g["C"]).max()
+    np.testing.assert_allclose(s["C"], g["C"], rtol=0, atol=1e-11 * scale)
+    assert np.all(np.triu(s["C"], 1) == 0)
+    np.testing.assert_allclose(s["gamma"], g["gamma"].ravel(), rtol=1e-6, atol=1e-9 * np.abs(g["gamma"]).max())
+    np.testing.assert_allclose(s["rho"], g["rho"].ravel(), rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(s["Yt"], g["Yt"].ravel(), rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(s["sigma2"], g["sigma2"][0], rtol=1e-10)
+    np.testing.assert_allclose(s["beta"], g["beta"].ravel()[0], rtol=1e-8, atol=1e-12)
+    if bool(g["estimate_trend"]):
+        np.testing.assert_allclose(s["Ft"], g["Ft"].ravel(), rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(s["G"], g["G"].ravel()[0], rtol=1e-10)  # sign convention of LAPACK's QR included
+        np.testing.assert_allclose(s["Q"], g["Q"].ravel(), rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", STATE_FILES)
+def test_posterior_matches_reference(eng, name):
+    g = load_golden(name)
+    commit_golden(eng, g)
+    eng.upload_candidates(g["Xs"])
+    mu, mse = eng.predict()
+    close_mu(mu, g["mu"])
+    close_mse(mse, g["mse"], g["sigma2"][0])
+    mu_only, none = eng.predict(eval_MSE=False)
+    assert none is None
+    np.testing.assert_array_equal(mu_only, mu)
+
+
+@pytest.mark.parametrize("name", STATE_FILES)
+def test_acquisitions_and_argmax_match_reference(eng, name):
+    g = load_golden(name)
+    st = state_from_golden(g)
+    commit_golden(eng, g)
+    eng.upload_candidates(g["Xs"])
+    variants = [("", True, None)]
+    if name == "G7_edges":
+        variants += [("max_", False, None), ("plg_", True, -0.3)]
+    mse_ref = g["mse"][:, 0]
+    noise_rows = mse_ref <= 1e-12 * st.sigma2[0]
+    for prefix, minimize, plugin in variants:
+        pl = O.plugin_value(st.y, minimize, plugin)
+        acq = [(a, p) for _, a, p in ACQ_KEYS]
+        best, idx, vals = eng.sweep(acq, pl, minimize, return_values=True)
+        for (key, a, p), b, i, v in zip(ACQ_KEYS, best, idx, vals):
+            ref = g[prefix + key]
+            ok = ~noise_rows if a in (O.ACQ_EPSILON_PI, O.ACQ_MGFI) else np.ones(len(ref), bool)
+            np.testing.assert_allclose(v[ok], ref[ok], rtol=1e-6, atol=1e-300, equal_nan=True, err_msg=prefix + key)
+            if ok.all():
+                assert i == int(g[prefix + "argmax_" + key][0]), (prefix + key, i)
+            assert i == int(np.argmax(v))  # the device argmax is np.argmax of the device values, always
+            np.testing.assert_array_equal(b, v[i])
+
+
+def test_edge_rows_are_the_reference_quirks(eng):
+    """candidate == training point in a noiseless model: MSE exactly 0 (or noise) -> EI 0, MGFI 0, UCB = mu."""
+    g = load_golden("G7_edges")
+    st = state_from_golden(g)
+    commit_golden(eng, g)
+    eng.upload_candidates(g["Xs"])
+    mu, mse = eng.predict()
+    assert np.all(mse[:6] <= 1e-14) and np.all(mse >= 0)
+    pl = O.plugin_value(st.y, True)
+    _, _, vals = eng.sweep([(O.ACQ_EI, 0), (O.ACQ_MGFI, 1.0), (O.ACQ_UCB, 0.5)], pl, True, return_values=True)
+    assert np.all(vals[0][:6] == 0.0)
+    np.testing.assert_allclose(vals[2][:6], mu[:6], atol=2e-7)
+    # far away: r -> 0, posterior reverts to the prior
+    np.testing.assert_allclose(mu[6:8], 0.0, atol=1e-12)
+    np.testing.assert_allclose(mse[6:8], g["sigma2"][0], rtol=1e-12)
+
+
+def test_llf_and_gradient_tables(eng):
+    g = load_golden("G6_llf_tables")
+    eng.set_train(g["X"], g["y"])
+    n = 0
+    for kid in (0, 2):
+        for mid in (0, 1, 2):
+            for tname in ("sk", "ok"):
+                key = "k%d_m%d_%s" % (kid, mid, tname)
+                for p, v, gr in zip(g[key + "_par"], g[key + "_llf"], g[key + "_grad"]):
+                    nv = 1e-6 if mid == 1 else 0.0
+                    if np.isneginf(v):
+                        with pytest.raises(_lib.NotPositiveDefinite):
+                            eng.nll(kid, mid, p, nv, tname == "ok", 0.0, eval_grad=True)
+                        continue
+                    llf, grad = eng.nll(kid, mid, p, nv, tname == "ok", 0.0, eval_grad=True)
+                    np.testing.assert_allclose(llf, v, rtol=1e-9)
+                    np.testing.assert_allclose(grad, gr, rtol=1e-6, atol=1e-8 * np.abs(gr).max())
+                    assert eng.nll(kid, mid, p, nv, tname == "ok", 0.0) == llf
+                    n += 1
+    assert n >= 30
+
+
+@pytest.mark.parametrize("name", ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G4_se_ok_noiseless"])
+def test_input_gradient_matches_reference(eng, name):
+    g = load_golden(name)
+    commit_golden(eng, g)
+    for i in range(len(g["grad_mu"])):
+        dmu, dmse = eng.gradient(g["Xs"][i])
+        np.testing.assert_allclose(dmu, g["grad_mu"][i].ravel(), rtol=1e-6, atol=1e-10)
+        np.testing.assert_allclose(dmse, g["grad_mse"][i].ravel(), rtol=1e-6, atol=1e-10)
+
+
+def test_mid_size_golden(eng):
+    g = load_golden("G8_mid")
+    rng = np.random.default_rng(8)
+    X = rng.uniform(-5, 5, size=(512, 10))
+    y = np.sum(X**2, axis=1)
+    y = ((y - y.mean()) / y.std()).reshape(-1, 1)
+    eng.set_train(X, y)
+    llf = eng.commit(O.KERNEL_SE, O.MODE_NOISY, g["par"], 1e-6, False, 0.0)
+    np.testing.assert_allclose(llf, g["llf"], rtol=1e-10)
+    eng.upload_candidates(g["Xs"])
+    mu, mse = eng.predict()
+    close_mu(mu, g["mu"])
+    close_mse(mse, g["mse"], 0.9)
+    best, idx, vals = eng.sweep([(O.ACQ_EI, 0)], O.plugin_value(y, True), True, return_values=True)
+    np.testing.assert_allclose(vals[0], g["EI"], rtol=1e-6, atol=1e-300)
+    assert idx[0] == int(g["argmax_EI"][0])
+
+
+# ---- seeded random cases against the oracle, incl. ragged sizes -----------------------------------------
+def _problem(seed, N, d, lo=-5.0, hi=5.0):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(lo, hi, size=(N, d))
+    y = np.sum(X**2, axis=1)
+    y = ((y - y.mean()) / y.std()).reshape(-1, 1)
+    return rng, X, y
+
+
+@pytest.mark.parametrize(
+    "N,d,M,kernel,mode,est",
+    [
+        (33, 1, 1, O.KERNEL_SE, O.MODE_NOISY, False),  # single candidate, d = 1, N just over one 32-block
+        (31, 2, 63, O.KERNEL_MATERN32, O.MODE_NOISY, True),  # everything ragged
+        (64, 3, 65, O.KERNEL_MATERN52, O.MODE_NOISY, False),
+        (257, 6, 1000, O.KERNEL_MATERN12, O.MODE_NOISY, True),  # crosses one 256-column group boundary
+        (300, 5, 777, O.KERNEL_SE, O.MODE_NOISE_ESTIM, True),
+        (520, 12, 3000, O.KERNEL_MATERN32, O.MODE_NOISELESS, True),
+        (1000, 50, 2048, O.KERNEL_SE, O.MODE_NOISY, False),  # d = 50 (config C5's dimension)
+    ],
+)
+def test_random_problem_matches_oracle(eng, N, d, M, kernel, mode, est):
+    rng, X, y = _problem(1000 + N, N, d)
+    theta = np.full(d, 0.4 / d) * rng.uniform(0.7, 1.3, size=d)
+    if mode == O.MODE_NOISELESS:
+        theta = theta * 6  # keep the noiseless matrix well conditioned
+    par = {O.MODE_NOISELESS: theta, O.MODE_NOISY: np.r_[theta, 0.9], O.MODE_NOISE_ESTIM: np.r_[theta, 0.98]}[mode]
+    nv = 1e-6 if mode == O.MODE_NOISY else 0.0
+    st = O.make_state(par, X, y, kernel, mode, nv, estimate_trend=est, beta=0.0)
+    eng.set_train(X, y)
+    llf = eng.commit(kernel, mode, par, nv, est, 0.0)
+    np.testing.assert_allclose(llf, st.llf, rtol=1e-9)
+    Xs = rng.uniform(-5, 5, size=(M, d))
+    eng.upload_candidates(Xs)
+    mu, mse = eng.predict()
+    rmu, rmse = O.predict_chunked(st, Xs, 1024)
+    close_mu(mu, rmu)
+    close_mse(mse, rmse, st.sigma2[0])
+    pl = O.plugin_value(y, True)
+    acq = [(O.ACQ_EI, 0.0), (O.ACQ_MGFI, 2.0), (O.ACQ_UCB, 0.5), (O.ACQ_EPSILON_PI, 1e-10)]
+    best, idx = eng.sweep(acq, pl, True)
+    obest, oidx = O.sweep(st, Xs, acq, pl, True)
+    np.testing.assert_array_equal(idx, oidx)
+    np.testing.assert_allclose(best, obest, rtol=1e-6, atol=1e-300)
+
+
+def test_isotropic_theta_and_fixed_beta(eng):
+    rng, X, y = _problem(5, 90, 4)
+    par = np.r_[0.07, 0.9]  # len(theta) = 1 (kernel.py:319-320)
+    st = O.make_state(par, X, y, O.KERNEL_SE, O.MODE_NOISY, 1e-6, estimate_trend=False, beta=0.3)
+    eng.set_train(X, y)
+    llf = eng.commit(O.KERNEL_SE, O.MODE_NOISY, par, 1e-6, False, 0.3)
+    np.testing.assert_allclose(llf, st.llf, rtol=1e-10)
+    Xs = rng.uniform(-5, 5, size=(200, 4))
+    eng.upload_candidates(Xs)
+    mu, mse = eng.predict()
+    rmu, rmse = O.predict(st, Xs)
+    close_mu(mu, rmu)
+    close_mse(mse, rmse, 0.9)
+
+
+def test_error_codes(eng):
+    e2 = _lib.Engine(0)
+    with pytest.raises(_lib.BogpError):
+        e2.predict()
+    with pytest.raises(_lib.BogpError):
+        e2.commit(0, 1, [0.1, 0.9], 1e-6)
+    X = np.zeros((5, 2))
+    X[:, 0] = np.arange(5)
+    e2.set_train(X, np.arange(5.0))
+    with pytest.raises(_lib.BogpError):
+        e2.commit(0, 1, [0.1, 0.2, 0.3, 0.9], 1e-6)  # wrong len(theta)
+    with pytest.raises(_lib.BogpError):
+        e2.set_train(X, np.zeros((5, 2)))  # multi-target
+    # duplicated rows, no nugget -> singular correlation matrix -> the -inf convention
+    Xd = np.vstack([X, X[:1]])
+    e2.set_train(Xd, np.arange(6.0))
+    with pytest.raises(_lib.NotPositiveDefinite):
+        e2.commit(0, 0, [0.1, 0.2])
+    e2.close()
+
+
+# ---- size-independent properties at BASELINE.json's full sizes ------------------------------------------
+def _bench_problem(N, d, kernel, theta):
+    rng, X, y = _problem(0, N, d)
+    par = np.r_[np.full(d, theta), 0.9]
+    return rng, X, y, par, kernel
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3"])
+def test_full_size_properties(eng, cfg):
+    N, d, M, kernel, theta, acq = {
+        "C2": (512, 10, 100_000, O.KERNEL_SE, 0.02, [(O.ACQ_EI, 0.0)]),
+        "C3": (2048, 20, 1_000_000, O.KERNEL_MATERN52, 0.01, [(O.ACQ_MGFI, 2.0), (O.ACQ_EI, 0.0)]),
+    }[cfg]
+    rng, X, y, par, kernel = _bench_problem(N, d, kernel, theta)
+    eng.set_train(X, y)
+    eng.commit(kernel, O.MODE_NOISY, par, 1e-6, False, 0.0)
+    Xs = rng.uniform(-5, 5, size=(M, d))
+    eng.upload_candidates(Xs)
+    mu, mse = eng.predict()
+    pl = O.plugin_value(y, True)
+    best, idx = eng.sweep(acq, pl, True)
+    # (1) the device argmax is np.argmax of the oracle's closed forms applied to the device posterior
+    for (a, p), b, i in zip(acq, best, idx):
+        v = O.acquisition(a, p, mu, mse, pl, 0.9, True)
+        assert i == int(np.argmax(v))
+        np.testing.assert_allclose(b, v[i], rtol=1e-9)
+    # (2) oracle parity on a random sub-sample of rows (the oracle needs seconds for 2048 rows)
+    st = O.make_state(par, X, y, kernel, O.MODE_NOISY, 1e-6)
+    rows = np.sort(rng.choice(M, size=2048, replace=False))
+    rows[0] = idx[0]  # include the winner
+    rmu, rmse = O.predict_chunked(st, Xs[rows], 512)
+    close_mu(mu[rows], rmu)
+    close_mse(mse[rows], rmse, 0.9)
+    # (3) chunking is invisible: a different chunk size gives bit-identical outputs
+    os.environ["BOGP_CHUNK_MB"] = "96"
+    try:
+        mu2, mse2 = eng.predict()
+        best2, idx2 = eng.sweep(acq, pl, True)
+    finally:
+        del os.environ["BOGP_CHUNK_MB"]
+    np.testing.assert_array_equal(mu, mu2)
+    np.testing.assert_array_equal(mse, mse2)
+    np.testing.assert_array_equal(idx, idx2)
+    np.testing.assert_array_equal(best, best2)
+    # (4) a row's result does not depend on where it sits: reversing the candidates reverses the outputs bit for bit
+    eng.upload_candidates(Xs[::-1].copy())
+    mu3, mse3 = eng.predict()
+    np.testing.assert_array_equal(mu3[::-1], mu)
+    np.testing.assert_array_equal(mse3[::-1], mse)
+    # (5) interpolation: at the training points the posterior mean returns y and the MSE collapses to nugget level
+    eng.upload_candidates(X)
+    mut, mset = eng.predict()
+    np.testing.assert_allclose(mut, y.ravel(), atol=1e-4)
+    assert np.all(mset < 1e-4) and np.all(mset >= 0)
+
+
+# ---- the drop-in classes ----------------------------------------------------------------------------
+def test_fit_replays_the_reference_mle():
+    g = load_golden("G10_fit")
+    for tag, kw, d in (
+        ("se_sk_noisy", dict(corr="squared_exponential", nugget=1e-6), 3),
+        ("m32_ok_noisy", dict(corr="matern", nugget=1e-6, mean="ok"), 2),
+        ("se_sk_noise_estim", dict(corr="squared_exponential", nugget=1e-6, noise_estim=True), 3),
+    ):
+        kw = dict(kw)
+        mean = bogp.trend.constant_trend(d) if kw.pop("mean", None) == "ok" else None
+        gp = bogp.GaussianProcess(mean=mean, thetaL=[1e-3] * d, thetaU=[1e2] * d, optimizer="BFGS", wait_iter=3,
+                                  random_start=5, eval_budget=100 * d, **kw)  # fmt: skip
+        np.random.seed(123)
+        assert gp.fit(g[tag + "_X"], g[tag + "_y"]) is gp and gp.is_fitted
+        # same host loop + same random stream + a likelihood that agrees to ~1e-13 -> the same optimum
+        np.testing.assert_allclose(gp.log_likelihood_, g[tag + "_llf"], rtol=1e-6)
+        np.testing.assert_allclose(gp.theta_, g[tag + "_theta"], rtol=1e-3)
+        np.testing.assert_allclose(gp.sigma2, g[tag + "_sigma2"], rtol=1e-3)
+        mu, mse = gp.predict(g[tag + "_Xs"], eval_MSE=True)
+        assert mu.shape == (64, 1) and mse.shape == (64, 1)
+        np.testing.assert_allclose(mu, g[tag + "_mu"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(mse, g[tag + "_mse"], rtol=1e-2, atol=1e-6)
+
+
+def test_classes_follow_the_protocols():
+    g = load_golden("G1_se_sk_noisy")
+    d = g["X"].shape[1]
+    gp = bogp.GaussianProcess(corr="squared_exponential", thetaL=[1e-4] * d, thetaU=[1e2] * d, nugget=1e-6)
+    gp.set_state(g["par"], g["X"], g["y"])
+    np.testing.assert_allclose(gp.C, g["C"], atol=1e-11)
+    np.testing.assert_allclose(gp.gamma, g["gamma"], rtol=1e-6, atol=1e-9 * np.abs(g["gamma"]).max())
+    mu = gp.predict(g["Xs"])
+    mu2, mse = gp.predict(g["Xs"], eval_MSE=True)
+    assert mu.shape == (256, 1) and mse.shape == (256, 1)
+    close_mu(mu2, g["mu"])
+    with pytest.raises(ValueError):
+        gp.predict(np.zeros((3, d + 1)))
+    # acquisition objects: values row by row, shapes as the reference returns them
+    x1 = g["Xs"][:1]
+    for cls, key, kw in ((bogp.EI, "EI", {}), (bogp.MGFI, "MGFI_2", {"t": 2}), (bogp.UCB, "UCB_0.5", {}), (bogp.EpsilonPI, "EpsilonPI_1e-10", {})):
+        c = cls(model=gp, minimize=True, **kw)
+        v1 = c(x1)
+        assert np.shape(v1) == ((1, 1) if cls is bogp.EpsilonPI else (1,))
+        np.testing.assert_allclose(np.ravel(v1)[0], g[key][0], rtol=1e-6)
+        vall = c(g["Xs"])
+        assert vall.shape == (256, 1)
+        np.testing.assert_allclose(vall.ravel(), g[key], rtol=1e-6, atol=1e-300)
+    # return_dx against the reference's chain rule (8 stored points)
+    for cls, key, kw in ((bogp.EI, "EI", {}), (bogp.MGFI, "MGFI_2", {"t": 2}), (bogp.UCB, "UCB", {}), (bogp.EpsilonPI, "EpsilonPI", {})):
+        c = cls(model=gp, minimize=True, **kw)
+        for i in range(8):
+            v, dx = c(g["Xs"][i : i + 1], return_dx=True)
+            np.testing.assert_allclose(np.ravel(v)[0], g["dx_val_" + key][i], rtol=1e-6)
+            np.testing.assert_allclose(np.ravel(dx), g["dx_" + key][i], rtol=1e-5, atol=1e-12)
+    pi = bogp.PI(model=gp)(x1)
+    np.testing.assert_allclose(np.ravel(pi)[0], g["EpsilonPI_1e-10"][0], rtol=1e-6)
+    # pickling: no device handles travel, predictions are reproduced after a lazy re-commit
+    gp2 = pickle.loads(pickle.dumps(gp))
+    assert gp2._engine is None
+    np.testing.assert_array_equal(gp2.predict(g["Xs"]), mu)
+    # inner maximisers behind the reference's signature
+    box = bogp.optim.Box([(-5, 5)] * d, random_seed=1)
+    xopt, fopt = bogp.argmax_restart(bogp.EI(model=gp), box, eval_budget=20000, optimizer="sweep")
+    assert isinstance(xopt, list) and len(xopt) == d and isinstance(fopt, float)
+    xb, fb = bogp.argmax_restart(bogp.EI(model=gp), box, eval_budget=100 * d, n_restart=4, optimizer="BFGS")
+    assert len(xb) == d and fb > 0
+    np.testing.assert_allclose(float(np.ravel(bogp.EI(model=gp)(np.array(xopt).reshape(1, -1)))[0]), fopt, rtol=1e-9)
+    # q criteria share one posterior pass
+    crit = [bogp.MGFI(model=gp, t=t) for t in (0.5, 1.0, 2.0, 4.0)]
+    Xs = box.sample(5000)
+    best, gidx, xbest = bogp.sweep_argmax(crit, Xs)
+    for c, b, i, xb_ in zip(crit, best, gidx, xbest):
+        v = c(Xs).ravel()
+        assert i == int(np.argmax(v)) and b == v[i]
+        np.testing.assert_array_equal(xb_, Xs[i])

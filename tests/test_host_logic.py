@@ -1,0 +1,145 @@
+"""Host-side logic of the drop-in layer that needs no GPU: protocol surface, validation, argmax reduction rules."""
+import functools
+import pickle
+
+import numpy as np
+import pytest
+
+import bogp
+from bogp import _lib, distributed, optim
+from bogp.surrogate import kernel_id_of
+
+
+def test_kernel_name_mapping_follows_the_reference():
+    assert kernel_id_of("squared_exponential") == _lib.KERNEL_SE
+    assert kernel_id_of("matern") == _lib.KERNEL_MATERN32  # nu defaults to 1.5 (kernel.py:159)
+
+    def matern(theta, X, nu=1.5):  # stands for bayes_optim's function: only __name__/keywords are inspected
+        raise AssertionError
+
+    assert kernel_id_of(functools.partial(matern, nu=2.5)) == _lib.KERNEL_MATERN52
+    assert kernel_id_of(functools.partial(matern, nu=0.5)) == _lib.KERNEL_MATERN12
+    assert kernel_id_of(matern) == _lib.KERNEL_MATERN32
+    with pytest.raises(NotImplementedError):
+        kernel_id_of("cubic")
+    with pytest.raises(ValueError):
+        kernel_id_of("no_such_kernel")
+
+
+def test_constructor_contract():
+    gp = bogp.GaussianProcess(thetaL=[1e-3] * 4, thetaU=[1e2] * 4, nugget=1e-6)
+    assert gp.estimation_mode == "noisy" and not gp.estimate_trend and not gp.is_fitted
+    assert float(gp.mean.beta) == 0.0  # simple kriging default (gpr.py:269-270)
+    assert bogp.GaussianProcess(thetaL=[1e-3], thetaU=[1e2], nugget=0).estimation_mode == "noiseless"
+    assert bogp.GaussianProcess(thetaL=[1e-3], thetaU=[1e2], noise_estim=True).estimation_mode == "noise_estim"
+    ok = bogp.GaussianProcess(mean=bogp.trend.constant_trend(2), thetaL=[1e-3] * 2, thetaU=[1e2] * 2)
+    assert ok.estimate_trend  # beta=None -> ordinary kriging (what fmin builds, __init__.py:147-160)
+    with pytest.raises(TypeError):
+        bogp.GaussianProcess()  # bounds are mandatory in practice (gpr.py:238-242)
+    with pytest.raises(ValueError):
+        bogp.GaussianProcess(thetaL=[1e-3], thetaU=[np.inf])
+    with pytest.raises(ValueError):
+        bogp.GaussianProcess(thetaL=[1.0], thetaU=[0.5])
+    with pytest.raises(NotImplementedError):
+        bogp.GaussianProcess(thetaL=[1e-3], thetaU=[1e2], optimizer="CMA")
+    with pytest.raises(NotImplementedError):
+        bogp.GaussianProcess(thetaL=[1e-3], thetaU=[1e2], likelihood="restricted")
+    assert hasattr(gp, "gradient")  # its presence selects the BFGS inner optimiser (base.py:201)
+
+
+def test_model_is_picklable_without_device_state():
+    gp = bogp.GaussianProcess(mean=bogp.trend.constant_trend(3), corr="matern", thetaL=[1e-3] * 3, thetaU=[1e2] * 3)
+    gp.X = np.zeros((4, 3))
+    gp.y = np.zeros((4, 1))
+    gp2 = pickle.loads(pickle.dumps(gp))
+    assert gp2._engine is None and gp2.kernel_id == _lib.KERNEL_MATERN32 and gp2.estimate_trend
+
+
+def test_trend_objects():
+    t = bogp.trend.constant_trend(3, beta=2.0)
+    X = np.arange(12.0).reshape(4, 3)
+    np.testing.assert_array_equal(t(X), np.full((4, 1), 2.0))
+    np.testing.assert_array_equal(t.Jacobian(X[:1]), np.zeros((1, 3)))
+    q = bogp.trend.quadratic_trend(3)
+    assert q.n_dim == 10 and q.F(X).shape == (4, 10)
+    np.testing.assert_array_equal(q.F(X)[:, 4], X[:, 0] * X[:, 0])
+    np.testing.assert_array_equal(q.F(X)[:, 5], X[:, 0] * X[:, 1])
+    lin = bogp.trend.linear_trend(3)
+    assert lin.F(X).shape == (4, 4)
+    with pytest.raises(NotImplementedError):
+        bogp.trend.device_trend_of(lin)
+    with pytest.raises(Exception):
+        bogp.trend.constant_trend(3)(X)  # beta not set
+    pickle.loads(pickle.dumps(q))
+
+
+class _Model:  # the minimum an acquisition constructor touches
+    y = np.array([[0.3], [-1.2], [0.8]])
+
+    def predict(self, X, eval_MSE=False):
+        raise AssertionError
+
+
+def test_acquisition_constructor_contract():
+    m = _Model()
+    assert bogp.EI(model=m).plugin == -1.2
+    assert bogp.EI(model=m, minimize=False).plugin == -0.8
+    assert bogp.EI(model=m, minimize=False, plugin=3.0).plugin == -3.0  # stored negated (acquisition_fun.py:104)
+    assert bogp.MGFI(model=m, t=100).t == 22.36  # clamp (acquisition_fun.py:260-263)
+    assert bogp.UCB(model=m).alpha == 0.5 and bogp.EpsilonPI(model=m).epsilon == 1e-10
+    for bad in (lambda: bogp.UCB(model=m, alpha=0), lambda: bogp.MGFI(model=m, t=-1), lambda: bogp.EpsilonPI(model=m, epsilon=0)):
+        with pytest.raises(AssertionError):
+            bad()
+    assert bogp.PI(model=m).epsilon == 0  # constructible here, unlike the reference
+    with pytest.raises(ValueError):
+        bogp.EI(model=None)
+    assert hasattr(bogp.acquisition.EI, "plugin") and not hasattr(bogp.acquisition.UCB, "plugin")  # bayes_opt.py:21-23
+    for name in ("EI", "PI", "EpsilonPI", "UCB", "MGFI"):
+        assert hasattr(bogp.acquisition, name)  # looked up by name (base.py:485-488)
+
+
+def test_reduce_pairs_is_np_argmax_over_the_concatenation():
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        R, q, m = rng.integers(1, 6), rng.integers(1, 4), 7
+        blocks = rng.standard_normal((R, q, m)).round(1)  # rounding creates ties
+        if trial % 3 == 0:
+            blocks[rng.integers(R), rng.integers(q), rng.integers(m)] = np.nan
+        if trial % 5 == 0:
+            blocks[:] = 0.0  # plateau: first index must win
+        vals = np.empty((R, q))
+        idxs = np.empty((R, q), dtype=np.int64)
+        for r in range(R):
+            for c in range(q):
+                i = int(np.argmax(blocks[r, c]))
+                vals[r, c], idxs[r, c] = blocks[r, c, i], r * m + i
+        win = distributed.reduce_pairs(vals, idxs)
+        for c in range(q):
+            flat = blocks[:, c, :].reshape(-1)
+            assert idxs[win[c], c] == int(np.argmax(flat))
+
+
+def test_exchange_is_identity_without_process_group():
+    v, i = np.array([1.0, 2.0]), np.array([5, 7], dtype=np.int64)
+    v2, i2, x2 = distributed.exchange_argmax(v, i, None)
+    np.testing.assert_array_equal(v, v2)
+    np.testing.assert_array_equal(i, i2)
+    assert x2 is None
+
+
+def test_shards_tile_the_candidate_range():
+    for M in (10, 1000, 10**6 + 3):
+        for world in (1, 2, 4, 8):
+            edges = [optim.shard_bounds(M, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == M
+            assert all(edges[r][1] == edges[r + 1][0] for r in range(world - 1))
+    a = optim.candidate_block([(-5, 5)] * 3, 1000, seed=1, rank=1, world=4)
+    b = optim.candidate_block([(-5, 5)] * 3, 1000, seed=1, rank=1, world=4)
+    np.testing.assert_array_equal(a, b)
+    assert a.shape == (250, 3) and a.min() >= -5 and a.max() <= 5
+
+
+def test_box_space_protocol():
+    box = optim.Box([(-1, 1), (0, 2)], random_seed=3)
+    s = box.sample(5, method="uniform")
+    assert box.dim == 2 and s.shape == (5, 2) and (s[:, 1] >= 0).all()
