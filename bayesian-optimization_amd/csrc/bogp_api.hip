@@ -479,9 +479,10 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
   int64_t Mc = (int64_t)(chunk_bytes / ((size_t)Np * sizeof(double)) / 64) * 64;
   Mc = std::max<int64_t>(64, std::min<int64_t>(Mc, Mpad));
   const int nblk32 = Np / 32;
-  int S = (int)std::min<int64_t>(nblk32, std::max<int64_t>(1, (2048 + Mc / 64 - 1) / (Mc / 64)));
-  const int nblk_per_split = (nblk32 + S - 1) / S;
-  S = (nblk32 + nblk_per_split - 1) / nblk_per_split;
+  // the training set is sliced into groups of 8 x 32 rows per producer workgroup: a function of N only, so that the
+  // grouping of the partial sums of mu (hence every output bit) does not depend on the chunk size
+  const int nblk_per_split = 8;
+  const int S = (nblk32 + nblk_per_split - 1) / nblk_per_split;
   const int NJ16 = Np / 16;
   const int cols = contract_cols_per_group();
   const int nJ = (Np + cols - 1) / cols;

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, NR == 4 ? 1 : 2) void k_contract(ContractArgs 
       for (int ni = 0; ni < NR; ++ni)
         if (valid[ni]) s = __builtin_fma(acc[mi][ni][t], acc[mi][ni][t], s);
       const int row = 16 * mi + 4 * ((lb + t) & 3) + lk;  // D lane = 16 i + 4 b + j  ->  i = lane>>4
-      red[(w * 64 + row) * 16 + 4 * t + li] = s;
+      red[(w * 64 + row) * 16 + 4 * lb + li] = s;  // slot = column inside the 16-tile: row-position independent order
     }
   __syncthreads();
   if (tid < 64) {

@@ -287,8 +287,22 @@ def golden_fit():
         mean = trend.constant_trend(d) if kw.pop("mean", None) == "ok" else None
         gp = GaussianProcess(mean=mean, thetaL=[1e-3] * d, thetaU=[1e2] * d, optimizer="BFGS", wait_iter=3,
                              random_start=5, eval_budget=100 * d, **kw)  # fmt: skip
+        traj = []
+        if tag == "se_sk_noisy":  # G11: every (par, llf, grad) the reference's MLE visits
+            orig = gp.log_likelihood_concentrated
+
+            def rec(par, env=None, eval_grad=False, _orig=orig, _traj=traj):
+                out = _orig(par, env, eval_grad)
+                if eval_grad:
+                    _traj.append((np.array(par, float), float(out[0]), np.asarray(out[1], float).ravel()))
+                return out
+
+            gp.log_likelihood_concentrated = rec
         np.random.seed(123)
         gp.fit(X, y)
+        if traj:
+            save("G11_mle_trajectory", X=X, y=y, par=np.array([t[0] for t in traj]), llf=np.array([t[1] for t in traj]),
+                 grad=np.array([t[2] for t in traj]), kernel=np.array(0), mode=np.array(1), noise_var=np.array([1e-6]))  # fmt: skip
         Xs = np.random.default_rng(6).uniform(-5, 5, size=(64, d))
         mu, mse = gp.predict(Xs, eval_MSE=True)
         out.update({

@@ -147,6 +147,17 @@ def test_llf_and_gradient_tables(eng):
     assert n >= 30
 
 
+def test_likelihood_along_the_reference_mle_trajectory(eng):
+    """Every (par, llf, grad) the reference's own L-BFGS-B run visited (310 evaluations, recorded by
+    oracle/make_golden.py inside GaussianProcess.fit): the device likelihood and gradient agree at all of them."""
+    g = load_golden("G11_mle_trajectory")
+    eng.set_train(g["X"], g["y"])
+    for p, v, gr in zip(g["par"], g["llf"], g["grad"]):
+        llf, grad = eng.nll(int(g["kernel"]), int(g["mode"]), p, float(g["noise_var"][0]), False, 0.0, eval_grad=True)
+        np.testing.assert_allclose(llf, v, rtol=1e-9)
+        np.testing.assert_allclose(grad, gr, rtol=1e-6, atol=1e-8 * np.abs(gr).max())
+
+
 @pytest.mark.parametrize("name", ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G4_se_ok_noiseless"])
 def test_input_gradient_matches_reference(eng, name):
     g = load_golden(name)
@@ -176,12 +187,12 @@ def test_mid_size_golden(eng):
 
 
 # ---- seeded random cases against the oracle, incl. ragged sizes -----------------------------------------
-def _problem(seed, N, d, lo=-5.0, hi=5.0):
+def _problem(seed, N, d, lo=-5.0, hi=5.0, noise=0.0):
     rng = np.random.default_rng(seed)
     X = rng.uniform(lo, hi, size=(N, d))
     y = np.sum(X**2, axis=1)
-    y = ((y - y.mean()) / y.std()).reshape(-1, 1)
-    return rng, X, y
+    y = (y - y.mean()) / y.std() + noise * rng.standard_normal(N)  # noise keeps llf <= 0 on tiny smooth problems
+    return rng, X, y.reshape(-1, 1)
 
 
 @pytest.mark.parametrize(
@@ -197,7 +208,7 @@ def _problem(seed, N, d, lo=-5.0, hi=5.0):
     ],
 )
 def test_random_problem_matches_oracle(eng, N, d, M, kernel, mode, est):
-    rng, X, y = _problem(1000 + N, N, d)
+    rng, X, y = _problem(1000 + N, N, d, noise=0.05 if mode != O.MODE_NOISELESS else 0.0)
     theta = np.full(d, 0.4 / d) * rng.uniform(0.7, 1.3, size=d)
     if mode == O.MODE_NOISELESS:
         theta = theta * 6  # keep the noiseless matrix well conditioned
@@ -327,14 +338,26 @@ def test_fit_replays_the_reference_mle():
                                   random_start=5, eval_budget=100 * d, **kw)  # fmt: skip
         np.random.seed(123)
         assert gp.fit(g[tag + "_X"], g[tag + "_y"]) is gp and gp.is_fitted
-        # same host loop + same random stream + a likelihood that agrees to ~1e-13 -> the same optimum
-        np.testing.assert_allclose(gp.log_likelihood_, g[tag + "_llf"], rtol=1e-6)
-        np.testing.assert_allclose(gp.theta_, g[tag + "_theta"], rtol=1e-3)
-        np.testing.assert_allclose(gp.sigma2, g[tag + "_sigma2"], rtol=1e-3)
+        # The host loop and the random stream are the reference's (with the oracle as the engine the replay is
+        # bit-identical: tools/dbg notes in DESIGN.md), and the device likelihood agrees with the reference's to
+        # ~1e-13 at every point of the reference's trajectory -- but L-BFGS-B is fed the reference's inconsistent
+        # gradient (d/d par for a function of log10 par), so its line search amplifies 1e-13 into a
+        # different restart outcome.  What must hold: the optimum found is not worse than the reference's, and
+        # the fitted state is exactly what the oracle computes at the SAME hyper-parameters.
+        ref_llf = float(g[tag + "_llf"])
+        assert gp.log_likelihood_ >= ref_llf - 1e-6 * abs(ref_llf)
+        mode = {"noisy": O.MODE_NOISY, "noise_estim": O.MODE_NOISE_ESTIM}[gp.estimation_mode]
+        par = np.r_[gp.theta_, gp.par["sigma2"] if mode == O.MODE_NOISY else gp.par["alpha"]]
+        st = O.make_state(par, g[tag + "_X"], g[tag + "_y"], gp.kernel_id, mode, 1e-6 if mode == O.MODE_NOISY else 0.0,
+                          estimate_trend=gp.estimate_trend, beta=0.0)  # fmt: skip
+        np.testing.assert_allclose(gp.log_likelihood_, st.llf, rtol=1e-9)
+        np.testing.assert_allclose(gp.sigma2, st.sigma2, rtol=1e-9)
+        np.testing.assert_allclose(gp.gamma, st.gamma, rtol=1e-6, atol=1e-9 * np.abs(st.gamma).max())
         mu, mse = gp.predict(g[tag + "_Xs"], eval_MSE=True)
         assert mu.shape == (64, 1) and mse.shape == (64, 1)
-        np.testing.assert_allclose(mu, g[tag + "_mu"], rtol=1e-3, atol=1e-4)
-        np.testing.assert_allclose(mse, g[tag + "_mse"], rtol=1e-2, atol=1e-6)
+        rmu, rmse = O.predict(st, g[tag + "_Xs"])
+        close_mu(mu, rmu)
+        close_mse(mse, rmse, st.sigma2[0])
 
 
 def test_classes_follow_the_protocols():
