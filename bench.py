@@ -34,6 +34,20 @@ WORKLOADS = {
 }
 
 
+def measured_traffic(workload, n_per_launch):
+    """HBM bytes per k_contract launch from the committed PMC passes (profiles/r01_c3_pmc.json: FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE).  rocprofv3 counters cannot be collected from inside this process, so the figure is the
+    last committed measurement of the same workload / chunk size, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_c3_pmc.json")) as f:
+            p = json.load(f)
+        if workload == "C3" and int(p["candidates_per_launch"]) == int(n_per_launch) and not os.environ.get("BOGP_CHUNK_MB"):
+            return float(p["traffic_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -55,8 +69,10 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs a %d-rank torch.distributed.run launch (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run (also with 1 rank)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     w = WORKLOADS[args.workload]
@@ -87,7 +103,7 @@ def main():
         return distributed.exchange_argmax(best, idx + offset, None)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -103,7 +119,7 @@ def main():
             tim[k] += lt[k]
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -140,7 +156,8 @@ def main():
                        "parallelism": "candidate shards x%d, 1 all-gather of q*(val,idx) per step" % world},
             "roofline": {
                 "bound": "mfma", "kernel": "k_contract (v_mfma_f64_4x4x4_4b_f64)", "achieved": achieved, "peak": PEAK_FP64_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS,
+                "traffic": measured_traffic(args.workload, M * args.steps / max(1, tim["n_chunks"])),
                 "avg_launch_ms": tim["contract_ms"] / max(1, tim["n_chunks"]), "launches": tim["n_chunks"],
                 "flops_per_candidate": float(N) * N + 3.0 * N,
             },
@@ -155,7 +172,7 @@ def main():
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(w, X, y, par, plugin, Xh, args.cpu_sample, eng)
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
