@@ -157,7 +157,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": "k_contract (v_mfma_f64_4x4x4_4b_f64)", "achieved": achieved, "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS,
-                "traffic": measured_traffic(args.workload, M * args.steps / max(1, tim["n_chunks"])),
+                "traffic": measured_traffic(args.workload, ((1 << 30) // (((N + 31) // 32 * 32) * 8)) // 64 * 64),
                 "avg_launch_ms": tim["contract_ms"] / max(1, tim["n_chunks"]), "launches": tim["n_chunks"],
                 "flops_per_candidate": float(N) * N + 3.0 * N,
             },
