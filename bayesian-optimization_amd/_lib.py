@@ -37,6 +37,7 @@ SIGNATURES = {
     "bogp_candidates_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "bogp_predict": (C.c_int, [C.c_void_p, _dp, _dp]),
     "bogp_sweep": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, C.c_double, C.c_int, _dp, _lp, _dp]),
+    "bogp_sweep_topk": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, C.c_double, C.c_int, C.c_int, _dp, _lp]),
     "bogp_gradient": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "bogp_last_timing": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip]),
     "bogp_flops_per_candidate": (C.c_double, [C.c_void_p]),
@@ -202,6 +203,19 @@ class Engine:
                                  _ptr(best), idx.ctypes.data_as(_lp), _ptr(vals))
         )  # fmt: skip
         return (best, idx, vals) if return_values else (best, idx)
+
+    def sweep_topk(self, acq: Sequence[Tuple[int, float]], plugin: float, minimize=True, k: int = 1):
+        """k best candidates per criterion: (values (q, k), indices (q, k)); rank 0 is the argmax."""
+        q = len(acq)
+        ids = np.ascontiguousarray([a for a, _ in acq], dtype=np.int32)
+        pars = _f64([float(p) if p is not None else 0.0 for _, p in acq])
+        best = np.empty((q, k))
+        idx = np.empty((q, k), dtype=np.int64)
+        self._check(
+            self._lib.bogp_sweep_topk(self._h, q, ids.ctypes.data_as(_ip), _ptr(pars), float(plugin), int(bool(minimize)),
+                                      int(k), _ptr(best), idx.ctypes.data_as(_lp))
+        )  # fmt: skip
+        return best, idx
 
     def gradient(self, x):
         x = _f64(x).ravel()

@@ -582,6 +582,42 @@ extern "C" int bogp_sweep(bogp_handle* h, int q, const int* acq_id, const double
   return BOGP_OK;
 }
 
+extern "C" int bogp_sweep_topk(bogp_handle* h, int q, const int* acq_id, const double* acq_par, double plugin, int minimize,
+                               int k, double* best_val, int64_t* best_idx) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (k <= 0 || k > BOGP_MAX_TOPK) FAIL(h, BOGP_ERR_INVALID, "bogp_sweep_topk: k = %d outside [1, %d]", k, BOGP_MAX_TOPK);
+  if (q <= 0 || !acq_id || !best_val || !best_idx) FAIL(h, BOGP_ERR_INVALID, "bogp_sweep_topk: q > 0 and non-null acq_id/best_val/best_idx required");
+  for (int i = 0; i < q; ++i) {
+    if (acq_id[i] < 0 || acq_id[i] > 3) FAIL(h, BOGP_ERR_INVALID, "unknown acquisition id %d", acq_id[i]);
+    const bool zero_ok = acq_id[i] == BOGP_ACQ_EPSILON_PI;
+    if (acq_id[i] != BOGP_ACQ_EI && (!acq_par || !(acq_par[i] > 0 || (zero_ok && acq_par[i] == 0))))
+      FAIL(h, BOGP_ERR_INVALID, "acquisition parameter %d must be > 0", i);
+  }
+  int rc = run_sweep(h, false, q, acq_id, acq_par, plugin, minimize, true);  // keeps the q x M values on the device
+  if (rc) return rc;
+  const int64_t M = h->M;
+  const int64_t nblk = (M + 255) / 256;
+  hipStream_t st = h->stream;
+  // rank 0 is the sweep's own argmax; ranks 1..k-1 repeat the argmax with the winners so far masked out
+  std::vector<int64_t> taken(k);
+  for (int c = 0; c < q; ++c) {
+    for (int r = 0; r < k; ++r) {
+      if ((int64_t)r >= M) {  // fewer candidates than k: pad with (-inf, -1)
+        best_val[c * k + r] = -INFINITY;
+        best_idx[c * k + r] = -1;
+        continue;
+      }
+      HIPCHK(h, launch_block_argmax_excl(h->dacq_out + (size_t)c * M, M, taken.data(), r, h->dblk_val, h->dblk_idx, st));
+      HIPCHK(h, launch_argmax_final(h->dblk_val, h->dblk_idx, nblk, nblk, 1, h->dbest_val, h->dbest_idx, st));
+      HIPCHK(h, hipMemcpyAsync(&best_val[c * k + r], h->dbest_val, sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipMemcpyAsync(&best_idx[c * k + r], h->dbest_idx, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+      taken[r] = best_idx[c * k + r];
+    }
+  }
+  return BOGP_OK;
+}
+
 extern "C" int bogp_last_timing(bogp_handle* h, double* corr_ms, double* contract_ms, double* acquisition_ms, int* n_chunks) {
   if (!h) return BOGP_ERR_INVALID;
   if (corr_ms) *corr_ms = h->t_corr_ms;

@@ -146,6 +146,61 @@ __global__ __launch_bounds__(256) void k_argmax_final(const double* blk_val, con
   }
 }
 
+// top-k support: per-block argmax over stored acquisition values of criterion c, skipping indices already taken
+struct ExclArgs {
+  int n;
+  int64_t idx[BOGP_MAX_TOPK];
+};
+__global__ __launch_bounds__(256) void k_block_argmax_excl(const double* __restrict__ vals, int64_t M, ExclArgs ex,
+                                                           double* __restrict__ blk_val, int64_t* __restrict__ blk_idx) {
+  __shared__ double sv[4];
+  __shared__ int64_t si[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double v = -INFINITY;
+  int64_t idx = INT64_MAX;
+  if (i < M) {
+    bool taken = false;
+    for (int e = 0; e < ex.n; ++e) taken |= (ex.idx[e] == i);
+    if (!taken) {
+      v = vals[i];
+      idx = i;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double ov = shfl_xor_f64(v, off);
+    const int64_t oi = shfl_xor_i64(idx, off);
+    if (better(ov, oi, v, idx)) {
+      v = ov;
+      idx = oi;
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+    sv[w] = v;
+    si[w] = idx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k)
+      if (better(sv[k], si[k], v, idx)) {
+        v = sv[k];
+        idx = si[k];
+      }
+    blk_val[blockIdx.x] = v;
+    blk_idx[blockIdx.x] = idx;
+  }
+}
+
+hipError_t launch_block_argmax_excl(const double* vals, int64_t M, const int64_t* excl, int nexcl, double* blk_val,
+                                    int64_t* blk_idx, hipStream_t st) {
+  ExclArgs ex;
+  ex.n = nexcl;
+  for (int e = 0; e < nexcl; ++e) ex.idx[e] = excl[e];
+  hipLaunchKernelGGL(k_block_argmax_excl, dim3((unsigned)((M + 255) / 256)), 256, 0, st, vals, M, ex, blk_val, blk_idx);
+  return hipGetLastError();
+}
+
 hipError_t launch_acquisition(const AcqArgs& a, hipStream_t st) {
   const unsigned nblk = (unsigned)((a.mcount + 255) / 256);
   hipLaunchKernelGGL(k_acquisition, dim3(nblk), 256, 0, st, a);

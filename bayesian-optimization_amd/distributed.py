@@ -76,3 +76,67 @@ def exchange_argmax(best_val: np.ndarray, best_gidx: np.ndarray, best_x: Optiona
     ar = np.arange(q)
     out_x = allp[win, ar, 2:] if d else None
     return vals[win, ar].copy(), idxs[win, ar].copy(), out_x
+
+
+def merge_topk(vals: np.ndarray, idxs: np.ndarray, k: int):
+    """vals, idxs: (R, k_local) winners of R shards for ONE criterion (each row sorted best-first, padded with
+    (-inf, -1)).  Returns the global k best as (values (k,), indices (k,), source rank (k,), source slot (k,)) in
+    np.argmax order: larger value first, NaN before every number, ties -> lower global index."""
+    ent = []
+    R, kl = vals.shape
+    for r in range(R):
+        for s in range(kl):
+            if idxs[r, s] >= 0:
+                v = float(vals[r, s])
+                ent.append((0 if np.isnan(v) else 1, -v if not np.isnan(v) else 0.0, int(idxs[r, s]), r, s))
+    ent.sort()
+    ent = ent[:k]
+    ov = np.full(k, -np.inf)
+    oi = np.full(k, -1, dtype=np.int64)
+    orank = np.full(k, -1, dtype=np.int64)
+    oslot = np.full(k, -1, dtype=np.int64)
+    for j, (_, _, gi, r, s) in enumerate(ent):
+        ov[j], oi[j], orank[j], oslot[j] = vals[r, s], gi, r, s
+    return ov, oi, orank, oslot
+
+
+def exchange_topk(best_val: np.ndarray, best_gidx: np.ndarray, best_x: Optional[np.ndarray], k: int, group=None):
+    """Top-k flavour of `exchange_argmax`: inputs (q, k) values / global indices (+ (q, k, d) points) of this rank;
+    every rank returns the same global (q, k) winners.  Still ONE all-gather."""
+    best_val = np.ascontiguousarray(best_val, dtype=np.float64)
+    best_gidx = np.ascontiguousarray(best_gidx, dtype=np.int64)
+    q = best_val.shape[0]
+    d = 0 if best_x is None else best_x.shape[-1]
+    dist = _dist()
+    if dist is None or (dist.get_world_size(group) == 1 and not os.environ.get("BOGP_FORCE_EXCHANGE")):
+        allp = None
+        vals, idxs = best_val[None], best_gidx[None]
+        xs = None if best_x is None else best_x[None]
+    else:
+        import torch
+
+        world = dist.get_world_size(group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        pack = np.empty((q, k, 2 + d), dtype=np.float64)
+        pack[..., 0] = best_val
+        pack[..., 1] = best_gidx.view(np.float64)
+        if d:
+            pack[..., 2:] = best_x
+        mine = torch.from_numpy(pack).to(dev)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine, group=group)
+        allp = torch.stack(gathered).cpu().numpy()  # (R, q, k, 2 + d)
+        vals = allp[..., 0]
+        idxs = np.ascontiguousarray(allp[..., 1]).view(np.int64)
+        xs = allp[..., 2:] if d else None
+    out_v = np.empty((q, k))
+    out_i = np.empty((q, k), dtype=np.int64)
+    out_x = np.full((q, k, d), np.nan) if d else None
+    for c in range(q):
+        v, i, rr, ss = merge_topk(vals[:, c, :], idxs[:, c, :], k)
+        out_v[c], out_i[c] = v, i
+        if d:
+            for j in range(k):
+                if rr[j] >= 0:
+                    out_x[c, j] = xs[rr[j], c, ss[j]]
+    return out_v, out_i, out_x

@@ -69,6 +69,52 @@ def sweep_argmax(criteria: Sequence, Xs: np.ndarray, index_offset: int = 0, grou
     return distributed.exchange_argmax(best, gidx, xbest, group=group)
 
 
+def sweep_topk(criteria: Sequence, Xs: np.ndarray, k: int, index_offset: int = 0, group=None):
+    """As `sweep_argmax`, returning the k best candidates per criterion:
+    (values (q, k), global indices (q, k), points (q, k, d)), identical on every rank."""
+    c0 = criteria[0]
+    model = c0.model
+    if getattr(model, "_committed_par", None) is None:
+        raise Exception("The model is not fitted yet!")
+    Xs = model._check_X(Xs)
+    eng = model.engine
+    eng.upload_candidates(Xs)
+    best, idx = eng.sweep_topk([(c.acq_id, c.acq_par()) for c in criteria], c0.effective_plugin(), c0.minimize, k)
+    xb = np.where((idx >= 0)[..., None], Xs[np.clip(idx, 0, len(Xs) - 1)], np.nan)
+    gidx = np.where(idx >= 0, idx + int(index_offset), -1)
+    return distributed.exchange_topk(best, gidx, xb, k, group=group)
+
+
+def batch_argmax(criteria: Sequence, search_space, eval_budget: int, history: Optional[np.ndarray] = None, k: int = 8,
+                 index_offset: int = 0, group=None, Xs: Optional[np.ndarray] = None):
+    """The q-point proposal of `ParallelBO._batch_arg_max_acquisition` (bayes_opt.py:100-115) in ONE posterior pass:
+    q criteria (same model; they differ only in t / alpha) share (mu, MSE); each takes its best candidate that is
+    neither already taken by an earlier criterion nor `np.isclose` to an evaluated point in `history`
+    (BO.pre_eval_check, bayes_opt.py:27-55) -- falling back through its top-k instead of the reference's random
+    padding (base.py:282-289).  Returns (xopt: tuple of q lists, fopt: tuple of q floats) like the reference."""
+    if Xs is None:
+        Xs = np.asarray(search_space.sample(int(eval_budget), method="uniform"), dtype=float)
+    vals, gidx, pts = sweep_topk(criteria, Xs, k, index_offset=index_offset, group=group)
+    chosen_x, chosen_f, taken = [], [], set()
+    hist = None if history is None or len(history) == 0 else np.asarray(history, dtype=float)
+    for c in range(len(criteria)):
+        pick = None
+        for r in range(k):
+            gi = int(gidx[c, r])
+            if gi < 0 or gi in taken:
+                continue
+            if hist is not None and np.any(np.all(np.isclose(hist, pts[c, r]), axis=1)):
+                continue
+            pick = r
+            break
+        if pick is None:  # every fall-back exhausted: keep the argmax (the caller's duplicate check will pad)
+            pick = 0
+        taken.add(int(gidx[c, pick]))
+        chosen_x.append(pts[c, pick].tolist())
+        chosen_f.append(float(vals[c, pick]))
+    return tuple(chosen_x), tuple(chosen_f)
+
+
 def argmax_restart(
     obj_func: Callable,
     search_space,

@@ -64,7 +64,8 @@ typedef struct bogp_handle bogp_handle;
 /* trend (prior mean) bases: surrogate/gaussian_process/trend.py.  Only the constant basis (p = 1) is built. */
 #define BOGP_TREND_CONSTANT 0
 
-#define BOGP_MAX_Q 64 /* criteria evaluated in one sweep (ParallelBO batch size q) */
+#define BOGP_MAX_Q 64    /* criteria evaluated in one sweep (ParallelBO batch size q) */
+#define BOGP_MAX_TOPK 32 /* ranks returned per criterion by bogp_sweep_topk */
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
 int bogp_create(int device, bogp_handle** out);
@@ -129,6 +130,13 @@ int bogp_predict(bogp_handle* h, double* mu, double* mse);
  *   acq_out   optional HOST buffer (q x M row-major) receiving every acquisition value; NULL to skip     */
 int bogp_sweep(bogp_handle* h, int q, const int* acq_id, const double* acq_par, double plugin, int minimize,
                double* best_val, int64_t* best_idx, double* acq_out);
+
+/* Same sweep, returning the k best candidates per criterion (best_val, best_idx: q x k row-major, rank 0 = the
+ * argmax; ties -> lower index; slots beyond M are (-inf, -1)).  Gives BO.pre_eval_check (bayes_opt.py:27-55)
+ * and ParallelBO's q criteria fall-backs instead of the reference's random padding (base.py:282-289) when
+ * several criteria -- or a criterion and the history -- agree on the same candidate.                        */
+int bogp_sweep_topk(bogp_handle* h, int q, const int* acq_id, const double* acq_par, double plugin, int minimize,
+                    int k, double* best_val, int64_t* best_idx);
 
 /* ---- input-gradient of the posterior at ONE point ---------------------------------------------------
  * Replaces GaussianProcess.gradient(x) (gpr.py:537-576, corr_dx :600-661): dmu (d), dmse (d).            */

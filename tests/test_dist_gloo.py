@@ -39,7 +39,20 @@ def _worker(rank, world, port, q_out):
         li = np.array([int(np.argmax(loc[c])) for c in range(q)])
         lv = loc[np.arange(q), li]
         v, gi, x = distributed.exchange_argmax(lv, li + a, X[a:b][li])
-        q_out.put((rank, v, gi, x, table, X))
+        # top-k flavour of the same exchange
+        k = 5
+        kv = np.full((q, k), -np.inf)
+        ki = np.full((q, k), -1, dtype=np.int64)
+        kx = np.full((q, k, d), np.nan)
+        for c in range(q):
+            w = loc[c].copy()
+            for r in range(k):
+                cand = np.flatnonzero(~np.isneginf(w) | np.isnan(w)) if r else np.arange(len(w))
+                j = int(np.argmax(w))
+                kv[c, r], ki[c, r], kx[c, r] = loc[c, j], j + a, X[a + j]
+                w[j] = -np.inf
+        tv, ti, tx = distributed.exchange_topk(kv, ki, kx, k)
+        q_out.put((rank, v, gi, x, table, X, tv, ti, tx))
     finally:
         dist.destroy_process_group()
 
@@ -58,11 +71,19 @@ def test_two_rank_exchange_matches_global_argmax():
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
-    for rank, v, gi, x, table, X in res:
+    for rank, v, gi, x, table, X, tv, ti, tx in res:
         for c in range(table.shape[0]):
             ref = int(np.argmax(table[c]))
             assert gi[c] == ref, (rank, c, gi[c], ref)
             np.testing.assert_array_equal(v[c], table[c, ref])
             np.testing.assert_array_equal(x[c], X[ref])
+            # global top-5 = repeated np.argmax over the whole table
+            w = table[c].copy()
+            for r in range(5):
+                j = int(np.argmax(w))
+                assert ti[c, r] == j, (rank, c, r, ti[c, r], j)
+                np.testing.assert_array_equal(tv[c, r], table[c, j])
+                np.testing.assert_array_equal(tx[c, r], X[j])
+                w[j] = -np.inf
     # both ranks hold identical results
     np.testing.assert_array_equal(res[0][2], res[1][2])

@@ -411,3 +411,32 @@ def test_classes_follow_the_protocols():
         v = c(Xs).ravel()
         assert i == int(np.argmax(v)) and b == v[i]
         np.testing.assert_array_equal(xb_, Xs[i])
+
+
+def test_topk_and_batch_proposals():
+    g = load_golden("G1_se_sk_noisy")
+    d = g["X"].shape[1]
+    gp = bogp.GaussianProcess(corr="squared_exponential", thetaL=[1e-4] * d, thetaU=[1e2] * d, nugget=1e-6)
+    gp.set_state(g["par"], g["X"], g["y"])
+    rng = np.random.default_rng(11)
+    Xs = rng.uniform(-5, 5, size=(3000, d))
+    crit = [bogp.MGFI(model=gp, t=t) for t in (0.5, 2.0)] + [bogp.EI(model=gp)]
+    k = 6
+    vals, gidx, pts = bogp.sweep_topk(crit, Xs, k)
+    for c, cr in enumerate(crit):
+        v = cr(Xs).ravel()
+        order = np.lexsort((np.arange(len(v)), -v))[:k]  # value descending, ties -> lower index
+        np.testing.assert_array_equal(gidx[c], order)
+        np.testing.assert_array_equal(vals[c], v[order])
+        np.testing.assert_array_equal(pts[c], Xs[order])
+    # fewer candidates than k: padded with (-inf, -1)
+    v2, i2, _ = bogp.sweep_topk(crit[:1], Xs[:3], 5)
+    assert i2[0, 3:].tolist() == [-1, -1] and np.all(np.isneginf(v2[0, 3:])) and sorted(i2[0, :3].tolist()) == [0, 1, 2]
+    # q proposals in one pass: distinct points, none isclose to the history
+    box = bogp.optim.Box([(-5, 5)] * d, random_seed=2)
+    same = [bogp.EI(model=gp), bogp.EI(model=gp), bogp.EI(model=gp)]  # identical criteria agree on every rank
+    xs, fs = bogp.batch_argmax(same, box, eval_budget=4000, k=4, Xs=Xs)
+    assert len(xs) == 3 and len({tuple(x) for x in xs}) == 3 and fs[0] >= fs[1] >= fs[2]
+    top = Xs[int(np.argmax(same[0](Xs).ravel()))]
+    xs2, _ = bogp.batch_argmax(same[:1], box, eval_budget=4000, history=top[None, :], k=4, Xs=Xs)
+    assert not np.allclose(xs2[0], top)

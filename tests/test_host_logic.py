@@ -143,3 +143,37 @@ def test_box_space_protocol():
     box = optim.Box([(-1, 1), (0, 2)], random_seed=3)
     s = box.sample(5, method="uniform")
     assert box.dim == 2 and s.shape == (5, 2) and (s[:, 1] >= 0).all()
+
+
+def _repeated_argmax(v, k):
+    v = np.array(v, dtype=float)
+    out = []
+    mask = np.zeros(len(v), bool)
+    for _ in range(min(k, len(v))):
+        w = np.where(mask, -np.inf, v)
+        # np.argmax treats NaN as maximal; masked entries must never win
+        cand = np.flatnonzero(~mask)
+        i = cand[int(np.argmax(w[cand]))]
+        out.append(int(i))
+        mask[i] = True
+    return out
+
+
+def test_merge_topk_is_repeated_np_argmax():
+    rng = np.random.default_rng(3)
+    for trial in range(100):
+        R, m, k = int(rng.integers(1, 5)), 9, int(rng.integers(1, 7))
+        table = rng.standard_normal((R, m)).round(1)
+        if trial % 4 == 0:
+            table[rng.integers(R), rng.integers(m)] = np.nan
+        vals = np.full((R, k), -np.inf)
+        idxs = np.full((R, k), -1, dtype=np.int64)
+        for r in range(R):
+            loc = _repeated_argmax(table[r], k)
+            vals[r, : len(loc)] = table[r, loc]
+            idxs[r, : len(loc)] = np.array(loc) + r * m
+        v, i, rr, ss = distributed.merge_topk(vals, idxs, k)
+        ref = _repeated_argmax(table.reshape(-1), k)
+        assert i[: len(ref)].tolist() == ref
+        np.testing.assert_array_equal(v[: len(ref)], table.reshape(-1)[ref])
+        assert np.all(i[len(ref):] == -1)
