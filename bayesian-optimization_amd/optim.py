@@ -12,6 +12,8 @@ q x (value, global index) decides the winner (`distributed.exchange_argmax`).
 """
 from __future__ import annotations
 
+import functools
+import inspect
 from typing import Callable, List, Optional, Sequence
 
 import numpy as np
@@ -115,6 +117,30 @@ def batch_argmax(criteria: Sequence, search_space, eval_budget: int, history: Op
     return tuple(chosen_x), tuple(chosen_f)
 
 
+def unwrap_criterion(obj):
+    """Find the acquisition object behind what `BaseBO._create_acquisition` hands to `argmax_restart`
+    (base.py:482-494): `partial_argument(functools.partial(criterion, return_dx=...), var_name, fixed)` -- a
+    `functools.wraps` wrapper (utils.py:184-213).  Returns (criterion, masks, values): `masks` marks the variables
+    the wrapper fills in with the fixed `values` (None when nothing is fixed or `obj` is the criterion itself)."""
+    masks = values = None
+    for _ in range(8):
+        if hasattr(obj, "acq_id") and hasattr(obj, "acq_par"):
+            return obj, masks, values
+        if isinstance(obj, functools.partial):
+            obj = obj.func
+        elif hasattr(obj, "__wrapped__"):
+            try:
+                nl = inspect.getclosurevars(obj).nonlocals
+                if "masks" in nl and np.any(nl["masks"]):
+                    masks, values = np.asarray(nl["masks"], dtype=bool), list(nl["values"])
+            except TypeError:
+                pass
+            obj = obj.__wrapped__
+        else:
+            break
+    return None, None, None
+
+
 def argmax_restart(
     obj_func: Callable,
     search_space,
@@ -136,9 +162,17 @@ def argmax_restart(
     if optimizer == "sweep":
         if h is not None or g is not None:
             raise NotImplementedError("constraints are handled by the reference's penalised optimisers, not the sweep")
+        crit, masks, values = unwrap_criterion(obj_func)
+        if crit is None:
+            raise TypeError("optimizer='sweep' needs a bogp acquisition object (or the reference's wrapper around one)")
         Xs = np.asarray(search_space.sample(int(eval_budget), method="uniform"), dtype=float)
-        best, _, xb = sweep_argmax([obj_func], Xs)
-        return xb[0].tolist(), float(best[0])
+        full = Xs
+        if masks is not None:  # ask(fixed=...): the free columns are swept, the fixed ones are filled in
+            full = np.empty((len(Xs), len(masks)))
+            full[:, ~masks] = Xs
+            full[:, masks] = np.asarray(values, dtype=float)
+        best, gidx, _ = sweep_argmax([crit], full, return_points=False)
+        return Xs[int(gidx[0])].tolist(), float(best[0])
     if optimizer != "BFGS":
         raise NotImplementedError("optimizer %r is out of scope here (SURVEY.md 2 rows 6-7); use 'BFGS' or 'sweep'" % optimizer)
 
@@ -147,8 +181,11 @@ def argmax_restart(
     wait_count = 0
     bounds = np.array(search_space.bounds)
 
+    direct = hasattr(obj_func, "acq_id")  # our criterion object itself; otherwise the reference's one-point wrapper
+
     def neg(x):  # Penalized without constraints (optim/__init__.py:45-52)
-        f, fg = obj_func(np.asarray(x, dtype=float).reshape(1, -1), return_dx=True)
+        x = np.asarray(x, dtype=float)
+        f, fg = obj_func(x.reshape(1, -1), return_dx=True) if direct else obj_func(x)
         return -1.0 * float(np.asarray(f, float).ravel()[0]), -1.0 * np.asarray(fg, float).ravel()
 
     for iteration in range(n_restart):

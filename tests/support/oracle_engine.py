@@ -1,0 +1,76 @@
+"""TEST-ONLY stand-in for `bogp._lib.Engine` backed by the CPU oracle.
+
+Purpose: exercise the HOST logic of the drop-in layer (protocol plumbing with the real `bayes_optim` drivers, the
+MLE restart loop, pickling) in the build container, which has no GPU.  It is never importable from the product
+package and nothing in the product path can reach it; GPU parity is established separately by `-m gpu` tests."""
+import numpy as np
+
+from bogp import _lib
+from oracle import gp_oracle as O
+
+
+class OracleEngine:
+    def __init__(self, device=0):
+        self.N = self.d = self.M = 0
+        self.st = None
+
+    def close(self):
+        pass
+
+    def set_train(self, X, y):
+        self.X, self.y = np.asarray(X, float), np.asarray(y, float).reshape(len(X), -1)
+        self.N, self.d = self.X.shape
+        self.st = None
+
+    def nll(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False):
+        out = O.log_likelihood_concentrated(par, self.X, self.y, kernel, mode, noise_var, 0, estimate_trend, beta, eval_grad=eval_grad)
+        llf = out[0] if eval_grad else out
+        if not np.isfinite(llf):
+            raise _lib.NotPositiveDefinite(_lib.ERR_NOT_POSDEF, "oracle: -inf")
+        return (out[0], np.asarray(out[1], float).ravel()) if eval_grad else out
+
+    def commit(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0):
+        try:
+            self.st = O.make_state(par, self.X, self.y, kernel, mode, noise_var, estimate_trend=estimate_trend, beta=beta)
+        except np.linalg.LinAlgError as e:
+            raise _lib.NotPositiveDefinite(_lib.ERR_NOT_POSDEF, str(e))
+        return self.st.llf
+
+    def get_state(self, with_C=True):
+        st = self.st
+        z = np.zeros(self.N)
+        return dict(C=st.C, gamma=st.gamma.ravel(), rho=st.rho.ravel(), Yt=st.Yt.ravel(),
+                    Ft=z if st.Ft is None else st.Ft.ravel(), Q=z if st.Q is None else st.Q.ravel(),
+                    G=0.0 if st.G is None else float(st.G[0, 0]), beta=float(st.beta[0, 0]), sigma2=float(st.sigma2[0]),
+                    noise_var=st.noise_var)  # fmt: skip
+
+    def upload_candidates(self, Xs):
+        self.Xs = np.asarray(Xs, float)
+        self.M = len(self.Xs)
+
+    def predict(self, eval_MSE=True):
+        mu, mse = O.predict_chunked(self.st, self.Xs, 1024)
+        return mu.ravel(), (mse.ravel() if eval_MSE else None)
+
+    def _vals(self, acq, plugin, minimize):
+        mu, mse = self.predict()
+        return [O.acquisition(a, p, mu, mse, plugin, self.st.sigma2[0], minimize) for a, p in acq]
+
+    def sweep(self, acq, plugin, minimize=True, return_values=False):
+        vals = self._vals(acq, plugin, minimize)
+        idx = np.array([int(np.argmax(v)) for v in vals], dtype=np.int64)
+        best = np.array([v[i] for v, i in zip(vals, idx)])
+        return (best, idx, np.array(vals)) if return_values else (best, idx)
+
+    def sweep_topk(self, acq, plugin, minimize=True, k=1):
+        vals = self._vals(acq, plugin, minimize)
+        best = np.full((len(acq), k), -np.inf)
+        idx = np.full((len(acq), k), -1, dtype=np.int64)
+        for c, v in enumerate(vals):
+            order = np.lexsort((np.arange(len(v)), -v))[:k]
+            best[c, : len(order)], idx[c, : len(order)] = v[order], order
+        return best, idx
+
+    def gradient(self, x):
+        a, b = O.gradient(self.st, x)
+        return a.ravel(), b.ravel()

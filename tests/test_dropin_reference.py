@@ -1,0 +1,106 @@
+"""Drop-in protocol test with the REAL reference drivers (`bayes_optim.BO / ParallelBO`), build container only.
+
+`/root/reference` exists only here (never on the GPU box), and here there is no GPU -- so the engine under the
+bogp classes is the oracle-backed stand-in of tests/support/oracle_engine.py.  What this proves is the HOST side of
+INTEGRATION.md: the reference's ask/tell loop runs unmodified against `bogp.GaussianProcess`, finds the `bogp`
+acquisition classes by name, and accepts `bogp.argmax_restart` (optimizer="sweep" and "BFGS") behind its own
+`argmax_restart` signature.  Numerical parity of the device path is the job of the `-m gpu` tests."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "bayes_optim")), reason="reference tree not present")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    for p in (REF, os.path.join(ROOT, "oracle", "shims")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import warnings
+
+    warnings.filterwarnings("ignore")
+    import bayes_optim
+    import bayes_optim.base as rbase
+    import bayes_optim.bayes_opt as ropt
+
+    import bogp
+    from support.oracle_engine import OracleEngine
+
+    saved = (rbase.argmax_restart, rbase.AcquisitionFunction, ropt.AcquisitionFunction)
+    rbase.argmax_restart = bogp.argmax_restart
+    rbase.AcquisitionFunction = ropt.AcquisitionFunction = bogp.acquisition  # section 3
+    yield bayes_optim, bogp, OracleEngine
+    rbase.argmax_restart, rbase.AcquisitionFunction, ropt.AcquisitionFunction = saved
+
+
+def _model(bogp, OracleEngine, dim, **kw):
+    gp = bogp.GaussianProcess(
+        mean=bogp.trend.constant_trend(dim), corr="matern", thetaL=1e-3 * np.ones(dim) * 10, thetaU=1e3 * np.ones(dim) * 10,
+        nugget=1e-6, optimizer="BFGS", wait_iter=3, random_start=max(5, dim), eval_budget=100 * dim, **kw)  # fmt: skip
+    gp._engine = OracleEngine()
+    return gp
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("inner", ["sweep", "BFGS"])
+def test_reference_BO_runs_on_bogp_classes(ref, inner):
+    bayes_optim, bogp, OracleEngine = ref
+    from bayes_optim import BO, RealSpace
+
+    np.random.seed(42)
+    dim = 2
+    space = RealSpace([-5, 5]) * dim
+    model = _model(bogp, OracleEngine, dim)
+    aq = {"optimizer": "sweep", "max_FEs": 2000} if inner == "sweep" else {"optimizer": "BFGS", "max_FEs": 100, "n_restart": 3}
+    opt = BO(search_space=space, obj_fun=lambda x: float(np.sum(np.asarray(x) ** 2)), model=model, DoE_size=5,
+             max_FEs=14, verbose=False, n_point=1, acquisition_fun="EI", acquisition_optimization=aq, random_seed=42)  # fmt: skip
+    xopt, fopt, _ = opt.run()
+    assert opt.eval_count == 14 and model.is_fitted and len(xopt) == dim
+    assert fopt < 1.5  # sphere on [-5,5]^2: random search averages ~4 after 14 evaluations
+    assert type(model).__module__.startswith("bogp")
+
+
+@pytest.mark.timeout(600)
+def test_reference_ParallelBO_with_mgfi(ref):
+    bayes_optim, bogp, OracleEngine = ref
+    from bayes_optim import ParallelBO, RealSpace
+
+    np.random.seed(1)
+    dim = 3
+    space = RealSpace([-5, 5]) * dim
+    model = _model(bogp, OracleEngine, dim)
+    opt = ParallelBO(search_space=space, obj_fun=lambda x: float(np.sum(np.asarray(x) ** 2)), model=model, DoE_size=6,
+                     max_FEs=15, verbose=False, n_point=3, acquisition_fun="MGFI", acquisition_par={"t": 2},
+                     acquisition_optimization={"optimizer": "sweep", "max_FEs": 1500}, random_seed=1)  # fmt: skip
+    X = opt.ask()
+    assert len(X) == 6  # DoE
+    opt.tell(X, [float(np.sum(np.asarray(x) ** 2)) for x in X])
+    X = opt.ask()
+    assert len(X) == 3 and model.is_fitted
+    opt.tell(X, [float(np.sum(np.asarray(x) ** 2)) for x in X])
+    assert opt.eval_count == 9
+
+
+@pytest.mark.timeout(300)
+def test_save_load_roundtrip_through_dill(ref, tmp_path):
+    bayes_optim, bogp, OracleEngine = ref
+    from bayes_optim import BO, RealSpace
+
+    np.random.seed(3)
+    dim = 2
+    model = _model(bogp, OracleEngine, dim)
+    opt = BO(search_space=RealSpace([-5, 5]) * dim, obj_fun=lambda x: float(np.sum(np.asarray(x) ** 2)), model=model,
+             DoE_size=5, max_FEs=7, verbose=False, n_point=1, acquisition_fun="EI",
+             acquisition_optimization={"optimizer": "sweep", "max_FEs": 500}, random_seed=3)  # fmt: skip
+    opt.step()
+    f = str(tmp_path / "opt.pkl")
+    opt.save(f)  # base.py:499-519 dills the whole optimiser, model included
+    opt2 = BO.load(f)
+    assert opt2.model._engine is None  # device/engine handles never travel
+    assert opt2.model.is_fitted and np.allclose(opt2.model.theta_, model.theta_)
