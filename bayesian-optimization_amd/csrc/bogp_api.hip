@@ -23,6 +23,7 @@ static std::string g_create_error;
 struct bogp_handle {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // producer stream: k_corr_chunk of chunk c+1 runs beside k_contract of chunk c
   rocblas_handle blas = nullptr;
   std::string err;
 
@@ -54,8 +55,9 @@ struct bogp_handle {
   int64_t M = 0;
 
   // sweep scratch
-  double *drT = nullptr, *dmu_part = nullptr, *dw_part = nullptr, *dss_part = nullptr;
-  size_t rT_cap = 0, mu_part_cap = 0, w_part_cap = 0, ss_part_cap = 0;
+  double *drT[2] = {nullptr, nullptr}, *dmu_part[2] = {nullptr, nullptr}, *dw_part[2] = {nullptr, nullptr};
+  double* dss_part = nullptr;
+  size_t rT_cap[2] = {0, 0}, mu_part_cap[2] = {0, 0}, w_part_cap[2] = {0, 0}, ss_part_cap = 0;
   double *dblk_val = nullptr, *dmu_out = nullptr, *dmse_out = nullptr, *dacq_out = nullptr, *dbest_val = nullptr;
   int64_t *dblk_idx = nullptr, *dbest_idx = nullptr;
   size_t blk_val_cap = 0, blk_idx_cap = 0, mu_out_cap = 0, mse_out_cap = 0, acq_out_cap = 0;
@@ -130,6 +132,7 @@ extern "C" int bogp_create(int device, bogp_handle** out) {
   bogp_handle* h = new bogp_handle();
   h->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
       rocblas_create_handle(&h->blas) != rocblas_status_success ||
       rocblas_set_stream(h->blas, h->stream) != rocblas_status_success ||
       hipMalloc((void**)&h->dinfo, sizeof(rocblas_int)) != hipSuccess ||
@@ -155,12 +158,15 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   free_train(h);
-  dfree(h->dXs_owned); dfree(h->drT); dfree(h->dmu_part); dfree(h->dw_part); dfree(h->dss_part);
+  (void)hipStreamSynchronize(h->stream2);
+  dfree(h->dXs_owned); dfree(h->dss_part);
+  for (int b = 0; b < 2; ++b) { dfree(h->drT[b]); dfree(h->dmu_part[b]); dfree(h->dw_part[b]); }
   dfree(h->dblk_val); dfree(h->dblk_idx); dfree(h->dmu_out); dfree(h->dmse_out); dfree(h->dacq_out);
   dfree(h->dbest_val); dfree(h->dbest_idx); dfree(h->dinfo); dfree(h->dscal); dfree(h->dgrad_partial);
   for (auto e : h->ev) (void)hipEventDestroy(e);
   if (h->blas) rocblas_destroy_handle(h->blas);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   delete h;
 }
 
@@ -489,10 +495,19 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
   const int64_t nchunk = (M + Mc - 1) / Mc;
   const int64_t nblk_total = (M + 255) / 256 + nchunk;  // per-chunk block counts are rounded up
 
+  // Optional two-stream mode (BOGP_OVERLAP=1): the correlation producer of chunk c+1 (FP64 VALU) runs beside the
+  // contraction of chunk c (FP64 MFMA), everything the producer writes double buffered.  Measured on MI355X (r01,
+  // C3): the kernels do overlap (contract 75.9 -> 81.9 ms, corr 6.8 -> 11.7 ms) but the step time is unchanged
+  // (83.3 -> 83.0 ms): the DP pipe is the shared resource.  Off by default: it costs a second 1-GiB chunk buffer.
+  const bool overlap = nchunk > 1 && getenv("BOGP_OVERLAP") && atoi(getenv("BOGP_OVERLAP")) == 1;
+  hipStream_t stP = overlap ? h->stream2 : st;
+  const int nbuf = overlap ? 2 : 1;
   int e;
-  if ((e = ensure(h, &h->drT, &h->rT_cap, (size_t)Np * Mc))) return e;
-  if ((e = ensure(h, &h->dmu_part, &h->mu_part_cap, (size_t)S * Mc))) return e;
-  if ((e = ensure(h, &h->dw_part, &h->w_part_cap, (size_t)S * Mc))) return e;
+  for (int b = 0; b < nbuf; ++b) {
+    if ((e = ensure(h, &h->drT[b], &h->rT_cap[b], (size_t)Np * Mc))) return e;
+    if ((e = ensure(h, &h->dmu_part[b], &h->mu_part_cap[b], (size_t)S * Mc))) return e;
+    if ((e = ensure(h, &h->dw_part[b], &h->w_part_cap[b], (size_t)S * Mc))) return e;
+  }
   if ((e = ensure(h, &h->dss_part, &h->ss_part_cap, (size_t)nJ * Mc))) return e;
   if (q > 0) {
     if ((e = ensure(h, &h->dblk_val, &h->blk_val_cap, (size_t)q * nblk_total))) return e;
@@ -507,29 +522,45 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
   if (want_acq_out)
     if ((e = ensure(h, &h->dacq_out, &h->acq_out_cap, (size_t)q * M))) return e;
 
+  // events per chunk: [0] corr start, [1] corr end (producer stream); [2] contract start, [3] contract end,
+  // [4] acquisition end = chunk done (main stream)
+  constexpr int EPC = 5;
+  for (int64_t c = 0; c < nchunk; ++c)
+    for (int k = 0; k < EPC; ++k)
+      if (!get_event(h, (size_t)(c * EPC + k))) FAIL(h, BOGP_ERR_HIP, "hipEventCreate failed");
+  hipEvent_t ev_begin = get_event(h, (size_t)(nchunk * EPC));
+  if (!ev_begin) FAIL(h, BOGP_ERR_HIP, "hipEventCreate failed");
+  if (overlap) {  // the producer stream must see everything queued on the main stream so far (commit, uploads)
+    HIPCHK(h, hipEventRecord(ev_begin, st));
+    HIPCHK(h, hipStreamWaitEvent(stP, ev_begin, 0));
+  }
+
   int64_t blk_offset = 0;
-  size_t nev = 0;
   for (int64_t c = 0; c < nchunk; ++c) {
+    const int b = overlap ? (int)(c & 1) : 0;
+    hipEvent_t* ev = &h->ev[(size_t)(c * EPC)];
     const int64_t m0 = c * Mc;
     const int64_t mcount = std::min<int64_t>(Mc, M - m0);
     const int64_t Mc_eff = ((mcount + 63) / 64) * 64;  // rows actually launched; array stride stays Mc
     CorrArgs ca;
     ca.Xs = h->dXs; ca.M = M; ca.m0 = m0; ca.Mc = Mc; ca.d = d; ca.Np = Np; ca.nblk_per_split = nblk_per_split;
     ca.sqrt_theta = h->dsqrt_theta; ca.XthT = h->dXthT; ca.gamma = h->dgamma; ca.wvec = h->dw;
-    ca.rT = h->drT; ca.mu_part = h->dmu_part; ca.w_part = h->dw_part;
+    ca.rT = h->drT[b]; ca.mu_part = h->dmu_part[b]; ca.w_part = h->dw_part[b];
     ContractArgs ka;
-    ka.rT = h->drT; ka.Vp = h->dVp; ka.ss_part = h->dss_part; ka.Mc = Mc; ka.nMt = (int)(Mc_eff / 64); ka.nJ = nJ;
+    ka.rT = h->drT[b]; ka.Vp = h->dVp; ka.ss_part = h->dss_part; ka.Mc = Mc; ka.nMt = (int)(Mc_eff / 64); ka.nJ = nJ;
     ka.NJ16 = NJ16; ka.NKP = Np / 8;
-    hipEvent_t e0 = get_event(h, nev++), e1 = get_event(h, nev++), e2 = get_event(h, nev++), e3 = get_event(h, nev++);
-    if (!e0 || !e1 || !e2 || !e3) FAIL(h, BOGP_ERR_HIP, "hipEventCreate failed");
-    HIPCHK(h, hipEventRecord(e0, st));
-    HIPCHK(h, launch_corr_chunk(h->kernel, ca, (int)(Mc_eff / 64), S, st));
-    HIPCHK(h, hipEventRecord(e1, st));
+    // producer: may reuse buffer b only after chunk c-2 (its previous user) is completely done
+    if (overlap && c >= 2) HIPCHK(h, hipStreamWaitEvent(stP, h->ev[(size_t)((c - 2) * EPC + 4)], 0));
+    HIPCHK(h, hipEventRecord(ev[0], stP));
+    HIPCHK(h, launch_corr_chunk(h->kernel, ca, (int)(Mc_eff / 64), S, stP));
+    HIPCHK(h, hipEventRecord(ev[1], stP));
+    if (overlap) HIPCHK(h, hipStreamWaitEvent(st, ev[1], 0));
+    HIPCHK(h, hipEventRecord(ev[2], st));
     HIPCHK(h, launch_contract(ka, st));
-    HIPCHK(h, hipEventRecord(e2, st));
+    HIPCHK(h, hipEventRecord(ev[3], st));
     AcqArgs aa;
     memset(&aa, 0, sizeof(aa));
-    aa.mu_part = h->dmu_part; aa.w_part = h->dw_part; aa.ss_part = h->dss_part; aa.S = S; aa.nJ = nJ; aa.Mc = Mc;
+    aa.mu_part = h->dmu_part[b]; aa.w_part = h->dw_part[b]; aa.ss_part = h->dss_part; aa.S = S; aa.nJ = nJ; aa.Mc = Mc;
     aa.mcount = mcount; aa.m0 = m0; aa.beta = h->beta; aa.G = h->G; aa.estimate_trend = h->estimate_trend;
     aa.sigma2 = h->sigma2; aa.mu_out = want_out ? h->dmu_out : nullptr; aa.mse_out = want_out ? h->dmse_out : nullptr;
     aa.q = q;
@@ -537,18 +568,20 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     aa.plugin = plugin; aa.minimize = minimize; aa.acq_out = want_acq_out ? h->dacq_out : nullptr; aa.M = M;
     aa.blk_val = h->dblk_val; aa.blk_idx = h->dblk_idx; aa.blk_offset = blk_offset; aa.nblk_total = nblk_total;
     HIPCHK(h, launch_acquisition(aa, st));
-    HIPCHK(h, hipEventRecord(e3, st));
+    HIPCHK(h, hipEventRecord(ev[4], st));
     blk_offset += (mcount + 255) / 256;
   }
   if (q > 0) HIPCHK(h, launch_argmax_final(h->dblk_val, h->dblk_idx, blk_offset, nblk_total, q, h->dbest_val, h->dbest_idx, st));
   HIPCHK(h, hipStreamSynchronize(st));
+  if (overlap) HIPCHK(h, hipStreamSynchronize(stP));
   h->t_corr_ms = h->t_contract_ms = h->t_acq_ms = 0;
-  for (size_t i = 0; i + 3 < nev; i += 4) {
-    float a = 0, b = 0, c2 = 0;
-    (void)hipEventElapsedTime(&a, h->ev[i], h->ev[i + 1]);
-    (void)hipEventElapsedTime(&b, h->ev[i + 1], h->ev[i + 2]);
-    (void)hipEventElapsedTime(&c2, h->ev[i + 2], h->ev[i + 3]);
-    h->t_corr_ms += a; h->t_contract_ms += b; h->t_acq_ms += c2;
+  for (int64_t c = 0; c < nchunk; ++c) {
+    float a = 0, b2 = 0, c2 = 0;
+    hipEvent_t* ev = &h->ev[(size_t)(c * EPC)];
+    (void)hipEventElapsedTime(&a, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&b2, ev[2], ev[3]);
+    (void)hipEventElapsedTime(&c2, ev[3], ev[4]);
+    h->t_corr_ms += a; h->t_contract_ms += b2; h->t_acq_ms += c2;
   }
   h->n_chunks = (int)nchunk;
   return BOGP_OK;
