@@ -114,15 +114,22 @@ constexpr int NWJ = 4;               // waves per workgroup (along j)
 constexpr int KB = 32;               // training points per staged block
 constexpr int PITCH = 64 + 16;       // LDS row pitch in doubles: 640 B == 128 (mod 256) -> conflict-free A reads
 
-__device__ __forceinline__ double mfma4(double a, double b, double c) {
-  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+// In-place accumulate (vDst == SrcC) through inline asm.  With the builtin, hipcc gives the MFMA a destination
+// different from its SrcC and then restores the accumulator layout with ~128 v_accvgpr_mov per 512-MFMA block at
+// the loop back-edge (and more around every guarded branch); tying the operand removes all of them.
+// Hazards (cdna_hip_programming.md 5.7): A/B operands come straight from LDS / global loads (the compiler's own
+// s_waitcnt covers them, no VALU write precedes the MFMA); D is only ever consumed by the next MFMA on the same
+// accumulator as its whole SrcC (0 wait states) until the epilogue, which is fenced by BOGP_MFMA_DRAIN().
+__device__ __forceinline__ void mfma4_acc(double a, double b, double& c) {
+  asm("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
+#define BOGP_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
 // One 32-row block of n: 4 k-pairs x 2 k-steps x (MR x NR x 4) MFMAs.  GUARDED = this block touches the diagonal
 // (16x16 tiles above it are skipped, wave-uniform predicates).  All global loads are unconditional (addresses
 // clamped) so that the compiler can keep counted vmcnt waits and the B prefetch stays one k-pair ahead.
-template <bool GUARDED, int NR>
-__device__ __forceinline__ void contract_block(const double* __restrict__ tile, const double2* __restrict__ vp,
+template <int NR>
+__device__ __forceinline__ void contract_block(const bool GUARDED, const double* __restrict__ tile, const double2* __restrict__ vp,
                                                const size_t (&boff)[NR], const int (&jt)[NR], const int (&aoff)[4],
                                                int kb, int kp_last, double2 (&bq)[2][NR], double (&acc)[MR][NR][4]) {
 #pragma unroll
@@ -149,7 +156,7 @@ __device__ __forceinline__ void contract_block(const double* __restrict__ tile, 
 #pragma unroll
           for (int mi = 0; mi < MR; ++mi)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[mi][ni][t] = mfma4(af[mi][t], bv, acc[mi][ni][t]);
+            for (int t = 0; t < 4; ++t) mfma4_acc(af[mi][t], bv, acc[mi][ni][t]);
         }
       }
     }
@@ -157,7 +164,7 @@ __device__ __forceinline__ void contract_block(const double* __restrict__ tile, 
 }
 
 template <int NR>
-__global__ __launch_bounds__(256, NR == 4 ? 1 : 2) void k_contract(ContractArgs a) {
+__global__ __launch_bounds__(256, 2) void k_contract(ContractArgs a) {
   constexpr int JT16 = NWJ * NR;  // sixteen-wide column tiles per workgroup
   __shared__ __attribute__((aligned(16))) double lds[2 * KB * PITCH];  // 40 KB: two r tiles [32][80]
 
@@ -238,16 +245,14 @@ __global__ __launch_bounds__(256, NR == 4 ? 1 : 2) void k_contract(ContractArgs 
     __syncthreads();                       // tile kb is in lds[kb & 1]; every wave is done with the other buffer
     BOGP_STAGE_LOAD(min(kb + 1, nkb - 1));  // next tile -> registers, in flight during the MFMAs
     const double* tile = &lds[(kb & 1) * KB * PITCH];
-    if (kb < nkb_full)
-      contract_block<false, NR>(tile, vp, boff, jt, aoff, kb, kp_last, bq, acc);
-    else
-      contract_block<true, NR>(tile, vp, boff, jt, aoff, kb, kp_last, bq, acc);
+    contract_block<NR>(kb >= nkb_full, tile, vp, boff, jt, aoff, kb, kp_last, bq, acc);
     BOGP_STAGE_STORE((kb + 1) & 1);
   }
 #undef BOGP_STAGE_LOAD
 #undef BOGP_STAGE_STORE
 
   // ---- epilogue: sum of squares over this group's columns, per candidate row -----------------------
+  BOGP_MFMA_DRAIN();
   __syncthreads();
   double* red = lds;  // [NWJ][64 rows][16 slots]
 #pragma unroll

@@ -7,7 +7,7 @@
 #include <cstdio>
 __device__ __forceinline__ double mf(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 template <int V>
-__global__ __launch_bounds__(256, 1) void k(double* out, const double2* __restrict__ gB, int iters, long long* clk) {
+__global__ __launch_bounds__(256, 2) void k(double* out, const double2* __restrict__ gB, int iters, long long* clk) {
   __shared__ __attribute__((aligned(16))) double lds[32 * 80];
   const int lane = threadIdx.x & 63;
   for (int i = threadIdx.x; i < 32 * 80; i += 256) lds[i] = 1.0 + i * 1e-6;
@@ -100,24 +100,25 @@ __global__ __launch_bounds__(256, 1) void k(double* out, const double2* __restri
 }
 int main() {
   double* out; double2* gB; long long* clk; long long h[2];
-  hipMalloc(&out, 256 * 256 * 8); hipMalloc(&gB, 1024 * 64 * 16); hipMemset(gB, 0, 1024 * 64 * 16); hipMalloc(&clk, 16);
+  hipMalloc(&out, 512 * 256 * 8); hipMalloc(&gB, 1024 * 64 * 16); hipMemset(gB, 0, 1024 * 64 * 16); hipMalloc(&clk, 16);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 20000;
+  for (int grid = 256; grid <= 512; grid += 256)
   for (int v = 0; v < 6; ++v) {
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
       hipEventRecord(e0);
-      if (v == 0) hipLaunchKernelGGL(k<0>, 256, 256, 0, 0, out, gB, iters, clk);
-      if (v == 1) hipLaunchKernelGGL(k<1>, 256, 256, 0, 0, out, gB, iters, clk);
-      if (v == 2) hipLaunchKernelGGL(k<2>, 256, 256, 0, 0, out, gB, iters, clk);
-      if (v == 3) hipLaunchKernelGGL(k<3>, 256, 256, 0, 0, out, gB, iters, clk);
-      if (v == 4) hipLaunchKernelGGL(k<4>, 256, 256, 0, 0, out, gB, iters, clk);
-      if (v == 5) hipLaunchKernelGGL(k<5>, 256, 256, 0, 0, out, gB, iters, clk);
+      if (v == 0) hipLaunchKernelGGL(k<0>, grid, 256, 0, 0, out, gB, iters, clk);
+      if (v == 1) hipLaunchKernelGGL(k<1>, grid, 256, 0, 0, out, gB, iters, clk);
+      if (v == 2) hipLaunchKernelGGL(k<2>, grid, 256, 0, 0, out, gB, iters, clk);
+      if (v == 3) hipLaunchKernelGGL(k<3>, grid, 256, 0, 0, out, gB, iters, clk);
+      if (v == 4) hipLaunchKernelGGL(k<4>, grid, 256, 0, 0, out, gB, iters, clk);
+      if (v == 5) hipLaunchKernelGGL(k<5>, grid, 256, 0, 0, out, gB, iters, clk);
       hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     }
     hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
     double nm = (double)iters * 128;
-    printf("variant %d: %.3f ms  %.2f TF/s   s_memtime ticks/MFMA %.2f   wall ns/MFMA %.3f  memtime/realtime ratio %.3f (x100MHz)\n", v, ms,
-           nm * 512 * 1024 / ms * 1e-9, (double)h[0] / nm, ms * 1e6 / nm, (double)h[0] / (double)h[1]);
+    printf("grid %d variant %d: %.3f ms  %.2f TF/s   s_memtime ticks/MFMA %.2f   wall ns/MFMA %.3f  memtime/realtime ratio %.3f (x100MHz)\n", grid, v, ms,
+           nm * 512 * 4 * grid / ms * 1e-9, (double)h[0] / nm, ms * 1e6 / nm, (double)h[0] / (double)h[1]);
   }
 }
