@@ -35,6 +35,8 @@ SIGNATURES = {
     "bogp_get_state": (C.c_int, [C.c_void_p] + [_dp] * 10),
     "bogp_candidates_upload": (C.c_int, [C.c_void_p, _dp, C.c_int64]),
     "bogp_candidates_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "bogp_candidates_generate": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_uint64, C.c_int64]),
+    "bogp_candidates_read": (C.c_int, [C.c_void_p, _lp, C.c_int, _dp]),
     "bogp_predict": (C.c_int, [C.c_void_p, _dp, _dp]),
     "bogp_sweep": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, C.c_double, C.c_int, _dp, _lp, _dp]),
     "bogp_sweep_topk": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, C.c_double, C.c_int, C.c_int, _dp, _lp]),
@@ -183,6 +185,22 @@ class Engine:
         self._check(self._lib.bogp_candidates_bind(self._h, C.c_void_p(int(device_ptr)), int(M)))
         self.M = int(M)
         self._keep = owner
+
+    def generate_candidates(self, lo, hi, M: int, seed: int, first_row: int = 0):
+        """M uniform points in the box [lo, hi] drawn ON the device (Philox4x32-10 stream `seed`, rows
+        [first_row, first_row + M)): no host sampling, no H2D copy."""
+        lo, hi = _f64(lo).ravel(), _f64(hi).ravel()
+        if len(lo) != self.d or len(hi) != self.d:
+            raise ValueError("bounds must have %d entries" % self.d)
+        self._check(self._lib.bogp_candidates_generate(self._h, _ptr(lo), _ptr(hi), int(M), C.c_uint64(int(seed) & (2**64 - 1)), int(first_row)))
+        self.M = int(M)
+        self._keep = None
+
+    def read_candidates(self, rows) -> np.ndarray:
+        rows = np.ascontiguousarray(rows, dtype=np.int64).ravel()
+        out = np.empty((len(rows), self.d))
+        self._check(self._lib.bogp_candidates_read(self._h, rows.ctypes.data_as(_lp), len(rows), _ptr(out)))
+        return out
 
     # -- posterior / sweep ----------------------------------------------------------------------------
     def predict(self, eval_MSE=True) -> Tuple[np.ndarray, Optional[np.ndarray]]:

@@ -52,6 +52,8 @@ struct bogp_handle {
   const double* dXs = nullptr;
   double* dXs_owned = nullptr;
   size_t xs_cap = 0;
+  double* dbounds = nullptr;
+  size_t bounds_cap = 0;
   int64_t M = 0;
 
   // sweep scratch
@@ -159,7 +161,7 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   free_train(h);
   (void)hipStreamSynchronize(h->stream2);
-  dfree(h->dXs_owned); dfree(h->dss_part);
+  dfree(h->dXs_owned); dfree(h->dss_part); dfree(h->dbounds);
   for (int b = 0; b < 2; ++b) { dfree(h->drT[b]); dfree(h->dmu_part[b]); dfree(h->dw_part[b]); }
   dfree(h->dblk_val); dfree(h->dblk_idx); dfree(h->dmu_out); dfree(h->dmse_out); dfree(h->dacq_out);
   dfree(h->dbest_val); dfree(h->dbest_idx); dfree(h->dinfo); dfree(h->dscal); dfree(h->dgrad_partial);
@@ -447,6 +449,41 @@ extern "C" int bogp_candidates_upload(bogp_handle* h, const double* Xs, int64_t 
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->dXs = h->dXs_owned;
   h->M = M;
+  return BOGP_OK;
+}
+
+extern "C" int bogp_candidates_generate(bogp_handle* h, const double* lo, const double* hi, int64_t M, uint64_t seed,
+                                        int64_t first_row) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_generate: call bogp_set_train first (d is unknown)");
+  if (!lo || !hi || M <= 0 || first_row < 0) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_generate: bounds must be non-null, M > 0, first_row >= 0");
+  const int d = h->d;
+  for (int k = 0; k < d; ++k)
+    if (!(std::isfinite(lo[k]) && std::isfinite(hi[k]) && lo[k] <= hi[k])) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_generate: bad bounds in dimension %d", k);
+  HIPCHK(h, hipSetDevice(h->device));
+  int e = ensure(h, &h->dXs_owned, &h->xs_cap, (size_t)M * d);
+  if (e) return e;
+  if ((e = ensure(h, &h->dbounds, &h->bounds_cap, (size_t)2 * d))) return e;
+  HIPCHK(h, hipMemcpyAsync(h->dbounds, lo, d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->dbounds + d, hi, d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, launch_generate_uniform(h->dXs_owned, M * d, d, h->dbounds, h->dbounds + d, seed, (uint64_t)first_row * (uint64_t)d, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // lo / hi are caller memory
+  h->dXs = h->dXs_owned;
+  h->M = M;
+  return BOGP_OK;
+}
+
+extern "C" int bogp_candidates_read(bogp_handle* h, const int64_t* rows, int n, double* out) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!h->dXs || h->M <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_read: no candidates");
+  if (!rows || !out || n < 0) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_read: null pointer");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int d = h->d;
+  for (int i = 0; i < n; ++i) {
+    if (rows[i] < 0 || rows[i] >= h->M) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_read: row %lld outside [0, %lld)", (long long)rows[i], (long long)h->M);
+    HIPCHK(h, hipMemcpyAsync(out + (size_t)i * d, h->dXs + (size_t)rows[i] * d, d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return BOGP_OK;
 }
 

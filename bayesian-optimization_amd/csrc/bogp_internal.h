@@ -73,6 +73,9 @@ hipError_t launch_argmax_final(const double* blk_val, const int64_t* blk_idx, in
 hipError_t launch_block_argmax_excl(const double* vals, int64_t M, const int64_t* excl, int nexcl, double* blk_val,
                                     int64_t* blk_idx, hipStream_t st);
 
+hipError_t launch_generate_uniform(double* Xs, int64_t n_elem, int d, const double* lo, const double* hi, uint64_t seed,
+                                   uint64_t first_elem, hipStream_t st);
+
 // fit-path kernels (kernels_fit.hip)
 hipError_t launch_build_R(int kernel, const double* X, int N, int d, const double* theta, double off_scale, double diag,
                           double* R, int ld, hipStream_t st);

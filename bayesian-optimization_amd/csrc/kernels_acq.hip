@@ -201,6 +201,56 @@ hipError_t launch_block_argmax_excl(const double* vals, int64_t M, const int64_t
   return hipGetLastError();
 }
 
+// ---- on-device candidate generation ---------------------------------------------------------------------
+// Uniform points in a box from the counter-based Philox4x32-10 generator (Salmon et al., SC'11; constants below
+// are the published ones).  Element e = row * d + k of the M x d candidate array is a pure function of
+// (seed, first_row * d + e): counter = (E >> 1, 0, 0, 0), key = (seed_lo, seed_hi); the pair of 32-bit outputs
+// (0,1) serves even E, (2,3) odd E; u = ((a >> 5) * 2^26 + (b >> 6)) * 2^-53 in [0, 1); x = lo + (hi - lo) * u.
+// Replaces the host-side `RealSpace._sample` (search_space.py:742-754) + the 8 d M byte H2D copy; the oracle
+// restates the same integer arithmetic in NumPy (oracle/philox.py), so parity is bit-exact.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void k_generate_uniform(double* __restrict__ Xs, int64_t n_elem, int d,
+                                                          const double* __restrict__ lo, const double* __restrict__ hi,
+                                                          uint64_t seed, uint64_t first_elem) {
+#pragma clang fp contract(off)
+  // one thread per PAIR of consecutive GLOBAL elements (2P, 2P+1) = one Philox call with counter P
+  const uint64_t P = (first_elem >> 1) + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (2 * P >= first_elem + (uint64_t)n_elem) return;
+  uint32_t w[4];
+  philox4x32_10((uint32_t)P, (uint32_t)(P >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint64_t E = 2 * P + h;
+    if (E < first_elem || E >= first_elem + (uint64_t)n_elem) continue;
+    const double u = ((double)(w[2 * h] >> 5) * 67108864.0 + (double)(w[2 * h + 1] >> 6)) * (1.0 / 9007199254740992.0);
+    const int k = (int)(E % (uint64_t)d);
+    // separately rounded multiply and add (fp contract is off in this kernel): bit-identical to the NumPy restatement
+    const double width = hi[k] - lo[k];
+    const double scaled = width * u;
+    Xs[E - first_elem] = lo[k] + scaled;
+  }
+}
+
+hipError_t launch_generate_uniform(double* Xs, int64_t n_elem, int d, const double* lo, const double* hi, uint64_t seed,
+                                   uint64_t first_elem, hipStream_t st) {
+  const int64_t npair = (n_elem + 1) / 2 + 1;
+  hipLaunchKernelGGL(k_generate_uniform, dim3((unsigned)((npair + 255) / 256)), 256, 0, st, Xs, n_elem, d, lo, hi, seed, first_elem);
+  return hipGetLastError();
+}
+
 hipError_t launch_acquisition(const AcqArgs& a, hipStream_t st) {
   const unsigned nblk = (unsigned)((a.mcount + 255) / 256);
   hipLaunchKernelGGL(k_acquisition, dim3(nblk), 256, 0, st, a);

@@ -71,6 +71,23 @@ def sweep_argmax(criteria: Sequence, Xs: np.ndarray, index_offset: int = 0, grou
     return distributed.exchange_argmax(best, gidx, xbest, group=group)
 
 
+def sweep_generated(criteria: Sequence, bounds, M: int, seed: int, rank: int = 0, world: int = 1, group=None):
+    """`sweep_argmax` over M uniform candidates in `bounds` that never touch the host: rank r draws rows
+    [r M / R, (r+1) M / R) of the Philox stream `seed` on its GPU, sweeps them, and the ranks exchange their
+    winners (value, global row, point).  The union of the shards is the same M-point set for every world size."""
+    c0 = criteria[0]
+    model = c0.model
+    if getattr(model, "_committed_par", None) is None:
+        raise Exception("The model is not fitted yet!")
+    lo = np.array([b[0] for b in bounds], dtype=float)
+    hi = np.array([b[1] for b in bounds], dtype=float)
+    a, b_ = shard_bounds(int(M), rank, world)
+    eng = model.engine
+    eng.generate_candidates(lo, hi, b_ - a, seed, first_row=a)
+    best, idx = eng.sweep([(c.acq_id, c.acq_par()) for c in criteria], c0.effective_plugin(), c0.minimize)
+    return distributed.exchange_argmax(best, idx + a, eng.read_candidates(idx), group=group)
+
+
 def sweep_topk(criteria: Sequence, Xs: np.ndarray, k: int, index_offset: int = 0, group=None):
     """As `sweep_argmax`, returning the k best candidates per criterion:
     (values (q, k), global indices (q, k), points (q, k, d)), identical on every rank."""
@@ -159,6 +176,12 @@ def argmax_restart(
     optimizer="BFGS": the reference's multi-restart L-BFGS-B loop on `obj_func(x) -> (value, dx)` (host; every
     evaluation is one device call through the acquisition object).
     """
+    if optimizer == "sweep-device":  # candidates drawn on the GPU; the stream is seeded from the global np.random
+        crit, masks, _ = unwrap_criterion(obj_func)
+        if crit is None or masks is not None or h is not None or g is not None:
+            raise NotImplementedError("optimizer='sweep-device' takes an unconstrained bogp criterion without fixed variables")
+        best, _, xb = sweep_generated([crit], search_space.bounds, int(eval_budget), int(np.random.randint(0, 2**62)))
+        return xb[0].tolist(), float(best[0])
     if optimizer == "sweep":
         if h is not None or g is not None:
             raise NotImplementedError("constraints are handled by the reference's penalised optimisers, not the sweep")

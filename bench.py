@@ -125,13 +125,20 @@ def main():
         elapsed = float(t.item())
 
     # PCIe-inclusive ask(): H2D of the shard + one step (noted, never `value`)
-    h2d_ms = None
+    h2d_ms = gen_ms = None
     if rank == 0:
         Xh = Xs.cpu().numpy()
         t1 = time.perf_counter()
         eng.upload_candidates(Xh)
         eng.sweep(w["acq"], plugin, True)
         h2d_ms = (time.perf_counter() - t1) * 1e3
+        # fully on-device ask(): candidates drawn by the library's Philox kernel (no host sampling, no H2D) + sweep
+        eng.generate_candidates([-5.0] * d, [5.0] * d, M, seed=99)
+        t1 = time.perf_counter()
+        eng.generate_candidates([-5.0] * d, [5.0] * d, M, seed=100)
+        gb, gi = eng.sweep(w["acq"], plugin, True)
+        eng.read_candidates(gi)
+        gen_ms = (time.perf_counter() - t1) * 1e3
         eng.bind_candidates(Xs.data_ptr(), M, owner=Xs)
 
     if rank == 0:
@@ -165,6 +172,7 @@ def main():
             "whole_step_tflops": eng.flops_per_candidate() * M / (elapsed / args.steps) / 1e12,
             "ask_ms": elapsed / args.steps * 1e3,
             "ask_ms_with_h2d": h2d_ms,
+            "ask_ms_device_generated": gen_ms,
             "commit_s": commit_s,
             "llf": llf,
             "argmax": [int(i) for i in out[1]],

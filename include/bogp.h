@@ -112,6 +112,13 @@ int bogp_get_state(bogp_handle* h, double* C, double* gamma, double* rho, double
  * (e.g. a torch tensor's data_ptr()) without copying -- it must stay alive until the next upload/bind.   */
 int bogp_candidates_upload(bogp_handle* h, const double* Xs, int64_t M);
 int bogp_candidates_bind(bogp_handle* h, const void* d_Xs, int64_t M);
+/* `generate` draws M uniform points in the box [lo, hi] ON the device (replaces RealSpace._sample,
+ * search_space/search_space.py:742-754, and the H2D copy): counter-based Philox4x32-10, element (row, k) is a pure
+ * function of (seed, (first_row + row) * d + k), so shards of one stream are drawn independently per rank.
+ * `read` copies chosen rows (e.g. the argmax) of the current candidates back: out is n x d.                  */
+int bogp_candidates_generate(bogp_handle* h, const double* lo, const double* hi, int64_t M, uint64_t seed,
+                             int64_t first_row);
+int bogp_candidates_read(bogp_handle* h, const int64_t* rows, int n, double* out);
 
 /* ---- posterior ------------------------------------------------------------------------------------
  * Replaces GaussianProcess.predict(X, eval_MSE) (gpr.py:486-510) on the current candidates:

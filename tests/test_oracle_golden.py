@@ -177,3 +177,30 @@ def test_mid_size():
 def test_fmin_plumbing_invariants_recorded():
     g = load_golden("G9_fmin_plumbing")
     assert int(g["n_ret"]) == 5 and int(g["n_x"]) == 2 and int(g["n_iter"]) == 21 and int(g["n_eval"]) == 30
+
+
+def test_philox_known_answers():
+    """Known-answer vectors of Philox4x32-10 from the Random123 distribution (kat_vectors): they pin the generator
+    that the device kernel and oracle/philox.py both implement."""
+    from oracle import philox as P
+
+    def run(c, k):
+        out = P.philox4x32_10(*[np.array([x], dtype=np.uint32) for x in c], np.uint32(k[0]), np.uint32(k[1]))
+        return [int(o[0]) for o in out]
+
+    assert run((0, 0, 0, 0), (0, 0)) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert run((0xFFFFFFFF,) * 4, (0xFFFFFFFF, 0xFFFFFFFF)) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert run((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0)) == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_philox_uniform_box_properties():
+    from oracle import philox as P
+
+    lo, hi = np.array([-5.0, 0.0, 2.0]), np.array([5.0, 1.0, 2.5])
+    X = P.uniform_box(lo, hi, 4001, seed=12345)
+    assert X.shape == (4001, 3) and np.all(X >= lo) and np.all(X < hi + 1e-15)
+    # shards of one stream are independent of how it is cut
+    parts = np.vstack([P.uniform_box(lo, hi, 1000, 12345, 0), P.uniform_box(lo, hi, 3001, 12345, 1000)])
+    np.testing.assert_array_equal(parts, X)
+    assert abs(X[:, 0].mean()) < 0.2 and abs(X[:, 1].mean() - 0.5) < 0.02
+    assert not np.array_equal(P.uniform_box(lo, hi, 10, 1), P.uniform_box(lo, hi, 10, 2))
