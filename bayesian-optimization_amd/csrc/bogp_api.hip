@@ -211,7 +211,7 @@ struct FitOut {
 static int factorize(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
                      int estimate_trend, double beta, bool want_gamma, FitOut* o, std::vector<double>* theta_out) {
   if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "no training set: call bogp_set_train first");
-  if (kernel < 0 || kernel > 3) FAIL(h, BOGP_ERR_INVALID, "unknown kernel id %d", kernel);
+  if (kernel < 0 || kernel > BOGP_KERNEL_ABSEXP) FAIL(h, BOGP_ERR_INVALID, "unknown kernel id %d", kernel);
   if (mode < 0 || mode > 2) FAIL(h, BOGP_ERR_INVALID, "unknown estimation mode %d", mode);
   if (trend != BOGP_TREND_CONSTANT) FAIL(h, BOGP_ERR_UNSUPPORTED, "only the constant trend basis is built (trend id %d)", trend);
   const int N = h->N, d = h->d;
@@ -221,7 +221,8 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   for (int k = 0; k < d; ++k) {
     th[k] = par[n_theta == 1 ? 0 : k];
     if (!(th[k] > 0) || !std::isfinite(th[k])) FAIL(h, BOGP_ERR_INVALID, "theta[%d] = %g must be finite and > 0", k, th[k]);
-    sth[k] = std::sqrt(th[k]);
+    // coordinates are pre-scaled so that the producer forms (a - b)^2 (radial kernels) or |a - b| (absolute_exponential)
+    sth[k] = kernel == BOGP_KERNEL_ABSEXP ? th[k] : std::sqrt(th[k]);
   }
   if (theta_out) *theta_out = th;
   hipStream_t st = h->stream;

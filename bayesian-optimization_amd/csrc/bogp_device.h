@@ -12,9 +12,20 @@ namespace bogp {
 // s2 = sum_k theta_k (x_k - y_k)^2 computed by the caller.  Operation order follows the reference:
 //   matern: dists = sqrt(s2); K = dists * sqrt(nu2); (1 + K [+ K^2/3]) * exp(-K)      (kernel.py:186-200)
 // ---------------------------------------------------------------------------------------------------
+// One term of the weighted distance: theta_k d_k^2 for the radial kernels, theta_k |d_k| for absolute_exponential.
+template <int KERNEL>
+__device__ __forceinline__ double dist_term(double theta_k, double diff) {
+  return KERNEL == BOGP_KERNEL_ABSEXP ? theta_k * fabs(diff) : theta_k * (diff * diff);
+}
+// Same term when both points were pre-scaled (by sqrt(theta_k), or by theta_k for absolute_exponential).
+template <int KERNEL>
+__device__ __forceinline__ double dist_accumulate(double diff_scaled, double acc) {
+  return KERNEL == BOGP_KERNEL_ABSEXP ? acc + fabs(diff_scaled) : __builtin_fma(diff_scaled, diff_scaled, acc);
+}
+
 template <int KERNEL>
 __device__ __forceinline__ double corr_profile(double s2) {
-  if (KERNEL == BOGP_KERNEL_SE) return exp(-s2);
+  if (KERNEL == BOGP_KERNEL_SE || KERNEL == BOGP_KERNEL_ABSEXP) return exp(-s2);
   const double dists = sqrt(s2);
   if (KERNEL == BOGP_KERNEL_MATERN12) return exp(-dists);
   if (KERNEL == BOGP_KERNEL_MATERN32) {
@@ -29,9 +40,14 @@ __device__ __forceinline__ double corr_profile(double s2) {
 
 // -h(D) such that dR0/dtheta_k = -(x_ik - x_jk)^2 * h  (gpr.py:736-770 corr_grad_theta):
 //   SE r; Matern-3/2 1.5 exp(-sqrt3 D); [extensions: Matern-5/2 (5/6)(1+sqrt5 D)exp(-sqrt5 D); Matern-1/2 r/(2D)]
+//   absolute_exponential: dR0/dtheta_k = -|x_ik - x_jk| * r  (:761-762) -- same h = r, first power of the distance
+template <int KERNEL>
+__device__ __forceinline__ double dtheta_weight(double diff) {
+  return KERNEL == BOGP_KERNEL_ABSEXP ? fabs(diff) : diff * diff;
+}
 template <int KERNEL>
 __device__ __forceinline__ double corr_dtheta_profile(double s2, double r) {
-  if (KERNEL == BOGP_KERNEL_SE) return r;
+  if (KERNEL == BOGP_KERNEL_SE || KERNEL == BOGP_KERNEL_ABSEXP) return r;
   const double D = sqrt(s2);
   if (KERNEL == BOGP_KERNEL_MATERN32) return 1.5 * exp(-1.7320508075688772 * D);
   if (KERNEL == BOGP_KERNEL_MATERN52) return (5.0 / 6.0) * (1.0 + 2.23606797749979 * D) * exp(-2.23606797749979 * D);

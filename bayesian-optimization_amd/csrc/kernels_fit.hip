@@ -26,8 +26,7 @@ __global__ __launch_bounds__(256) void k_build_R(const double* __restrict__ X, i
   } else {
     double s2 = 0.0;
     for (int k = 0; k < d; ++k) {
-      const double df = fabs(X[(size_t)i * d + k] - X[(size_t)j * d + k]);
-      s2 += theta[k] * (df * df);
+      s2 += dist_term<KERNEL>(theta[k], fabs(X[(size_t)i * d + k] - X[(size_t)j * d + k]));
     }
     v = off_scale * corr_profile<KERNEL>(s2);
   }
@@ -48,8 +47,7 @@ __global__ __launch_bounds__(256) void k_build_R_div(const double* __restrict__ 
   } else {
     double s2 = 0.0;
     for (int k = 0; k < d; ++k) {
-      const double df = fabs(X[(size_t)i * d + k] - X[(size_t)j * d + k]);
-      s2 += theta[k] * (df * df);
+      s2 += dist_term<KERNEL>(theta[k], fabs(X[(size_t)i * d + k] - X[(size_t)j * d + k]));
     }
     v = (mul * corr_profile<KERNEL>(s2)) / div;
   }
@@ -64,6 +62,7 @@ hipError_t launch_build_R(int kernel, const double* X, int N, int d, const doubl
     case BOGP_KERNEL_SE: hipLaunchKernelGGL(k_build_R<BOGP_KERNEL_SE>, grid, 256, 0, st, X, N, d, theta, off_scale, diag, R, ld); break;
     case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL(k_build_R<BOGP_KERNEL_MATERN12>, grid, 256, 0, st, X, N, d, theta, off_scale, diag, R, ld); break;
     case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL(k_build_R<BOGP_KERNEL_MATERN32>, grid, 256, 0, st, X, N, d, theta, off_scale, diag, R, ld); break;
+    case BOGP_KERNEL_ABSEXP: hipLaunchKernelGGL(k_build_R<BOGP_KERNEL_ABSEXP>, grid, 256, 0, st, X, N, d, theta, off_scale, diag, R, ld); break;
     default: hipLaunchKernelGGL(k_build_R<BOGP_KERNEL_MATERN52>, grid, 256, 0, st, X, N, d, theta, off_scale, diag, R, ld); break;
   }
   return hipGetLastError();
@@ -76,6 +75,7 @@ hipError_t launch_build_R_div(int kernel, const double* X, int N, int d, const d
     case BOGP_KERNEL_SE: hipLaunchKernelGGL(k_build_R_div<BOGP_KERNEL_SE>, grid, 256, 0, st, X, N, d, theta, mul, div, diag, R, ld); break;
     case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL(k_build_R_div<BOGP_KERNEL_MATERN12>, grid, 256, 0, st, X, N, d, theta, mul, div, diag, R, ld); break;
     case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL(k_build_R_div<BOGP_KERNEL_MATERN32>, grid, 256, 0, st, X, N, d, theta, mul, div, diag, R, ld); break;
+    case BOGP_KERNEL_ABSEXP: hipLaunchKernelGGL(k_build_R_div<BOGP_KERNEL_ABSEXP>, grid, 256, 0, st, X, N, d, theta, mul, div, diag, R, ld); break;
     default: hipLaunchKernelGGL(k_build_R_div<BOGP_KERNEL_MATERN52>, grid, 256, 0, st, X, N, d, theta, mul, div, diag, R, ld); break;
   }
   return hipGetLastError();
@@ -163,8 +163,7 @@ __global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict_
   if (ok) {
     double s2 = 0.0;
     for (int k = 0; k < d; ++k) {
-      const double df = X[(size_t)i * d + k] - X[(size_t)j * d + k];
-      s2 += theta[k] * (df * df);
+      s2 += dist_term<KERNEL>(theta[k], X[(size_t)i * d + k] - X[(size_t)j * d + k]);
     }
     r0 = corr_profile<KERNEL>(s2);
     h = corr_dtheta_profile<KERNEL>(s2, r0);
@@ -176,7 +175,7 @@ __global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict_
     if (ok) {
       if (k < d) {
         const double df = X[(size_t)i * d + k] - X[(size_t)j * d + k];
-        v = A * (-(df * df) * h);
+        v = A * (-dtheta_weight<KERNEL>(df) * h);
       } else {
         v = A * r0;
       }
@@ -202,6 +201,7 @@ hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const
     case BOGP_KERNEL_SE: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_SE>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, partial, nt); break;
     case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN12>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, partial, nt); break;
     case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN32>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, partial, nt); break;
+    case BOGP_KERNEL_ABSEXP: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_ABSEXP>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, partial, nt); break;
     default: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN52>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, partial, nt); break;
   }
   return hipGetLastError();
@@ -237,8 +237,7 @@ __global__ void k_point_corr(const double* __restrict__ X, int N, int d, const d
   if (n >= N) return;
   double s2 = 0.0;
   for (int k = 0; k < d; ++k) {
-    const double df = fabs(x[k] - X[(size_t)n * d + k]);
-    s2 += theta[k] * (df * df);
+    s2 += dist_term<KERNEL>(theta[k], fabs(x[k] - X[(size_t)n * d + k]));
   }
   const double rv = corr_profile<KERNEL>(s2);
   r[n] = rv;
@@ -246,7 +245,9 @@ __global__ void k_point_corr(const double* __restrict__ X, int N, int d, const d
   for (int k = 0; k < d; ++k) {
     const double diff = x[k] - X[(size_t)n * d + k];
     double g;
-    if (KERNEL == BOGP_KERNEL_SE) {
+    if (KERNEL == BOGP_KERNEL_ABSEXP) {
+      g = -1.0 * rv * theta[k] * (diff > 0.0 ? 1.0 : (diff < 0.0 ? -1.0 : 0.0));  // -r theta sign(diff) (gpr.py:650-651)
+    } else if (KERNEL == BOGP_KERNEL_SE) {
       g = -2 * rv * (theta[k] * diff);
     } else if (KERNEL == BOGP_KERNEL_MATERN32) {
       g = D > 0.0 ? (diff * theta[k] / D) * (-3.0 * D * exp(-1.7320508075688772 * D)) : 0.0;
@@ -265,6 +266,7 @@ hipError_t launch_point_corr(int kernel, const double* X, int N, int d, const do
     case BOGP_KERNEL_SE: hipLaunchKernelGGL(k_point_corr<BOGP_KERNEL_SE>, grid, 256, 0, st, X, N, d, theta, x, r, rdx); break;
     case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL(k_point_corr<BOGP_KERNEL_MATERN12>, grid, 256, 0, st, X, N, d, theta, x, r, rdx); break;
     case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL(k_point_corr<BOGP_KERNEL_MATERN32>, grid, 256, 0, st, X, N, d, theta, x, r, rdx); break;
+    case BOGP_KERNEL_ABSEXP: hipLaunchKernelGGL(k_point_corr<BOGP_KERNEL_ABSEXP>, grid, 256, 0, st, X, N, d, theta, x, r, rdx); break;
     default: hipLaunchKernelGGL(k_point_corr<BOGP_KERNEL_MATERN52>, grid, 256, 0, st, X, N, d, theta, x, r, rdx); break;
   }
   return hipGetLastError();

@@ -78,8 +78,7 @@ __global__ __launch_bounds__(256) void k_corr_chunk(const double* __restrict__ X
       const double* __restrict__ xr = XthT + (size_t)k * a.Np + n0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const double diff = xk - xr[i];
-        acc[i] = __builtin_fma(diff, diff, acc[i]);
+        acc[i] = dist_accumulate<KERNEL>(xk - xr[i], acc[i]);
       }
     }
 #pragma unroll
@@ -289,6 +288,7 @@ hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipS
     case BOGP_KERNEL_SE: BOGP_LAUNCH_CORR(BOGP_KERNEL_SE); break;
     case BOGP_KERNEL_MATERN12: BOGP_LAUNCH_CORR(BOGP_KERNEL_MATERN12); break;
     case BOGP_KERNEL_MATERN32: BOGP_LAUNCH_CORR(BOGP_KERNEL_MATERN32); break;
+    case BOGP_KERNEL_ABSEXP: BOGP_LAUNCH_CORR(BOGP_KERNEL_ABSEXP); break;
     default: BOGP_LAUNCH_CORR(BOGP_KERNEL_MATERN52); break;
   }
 #undef BOGP_LAUNCH_CORR

@@ -30,8 +30,11 @@ _KERNEL_IDS = {
     "matern12": _lib.KERNEL_MATERN12,
     "matern32": _lib.KERNEL_MATERN32,
     "matern52": _lib.KERNEL_MATERN52,
+    "absolute_exponential": _lib.KERNEL_ABSEXP,
 }
-_UNBUILT_KERNELS = ("absolute_exponential", "generalized_exponential", "cubic", "linear")
+# generalized_exponential / cubic cannot be fitted by the reference either (their theta-derivatives are `pass`,
+# gpr.py:763-766) and are not built; "linear" / "pure_nugget" are not in its correlation table at all (gpr.py:198-207)
+_UNBUILT_KERNELS = ("generalized_exponential", "cubic", "linear")
 _NU_IDS = {0.5: _lib.KERNEL_MATERN12, 1.5: _lib.KERNEL_MATERN32, 2.5: _lib.KERNEL_MATERN52}
 
 
@@ -47,6 +50,8 @@ def kernel_id_of(corr) -> int:
     name = getattr(func, "__name__", "")
     if name == "squared_exponential":
         return _lib.KERNEL_SE
+    if name == "absolute_exponential":
+        return _lib.KERNEL_ABSEXP
     if name == "matern":
         nu = (getattr(corr, "keywords", None) or {}).get("nu", 1.5)
         if nu in _NU_IDS:

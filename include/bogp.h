@@ -45,6 +45,7 @@ typedef struct bogp_handle bogp_handle;
 #define BOGP_KERNEL_MATERN12 1
 #define BOGP_KERNEL_MATERN32 2
 #define BOGP_KERNEL_MATERN52 3
+#define BOGP_KERNEL_ABSEXP 4 /* absolute_exponential :247-286   exp(-sum_k theta_k |d_k|) */
 
 /* estimation modes: gpr.py:252-263; parameter layouts gpr.py:1073-1086
  *   NOISELESS   par = [theta]          sigma2 = sum(rho^2)/(N-k)

@@ -30,7 +30,8 @@ KERNEL_SE = 0
 KERNEL_MATERN12 = 1
 KERNEL_MATERN32 = 2
 KERNEL_MATERN52 = 3
-KERNEL_NAMES = {"squared_exponential": KERNEL_SE, "matern": KERNEL_MATERN32}
+KERNEL_ABSEXP = 4
+KERNEL_NAMES = {"squared_exponential": KERNEL_SE, "matern": KERNEL_MATERN32, "absolute_exponential": KERNEL_ABSEXP}
 
 # estimation modes (surrogate/gaussian_process/gpr.py:252-263)
 MODE_NOISELESS = 0
@@ -77,6 +78,13 @@ def corr(kernel: int, theta: np.ndarray, d: np.ndarray) -> np.ndarray:
     theta = np.asarray(theta, dtype=np.float64)
     d = np.asarray(d, dtype=np.float64)
     n_features = d.shape[1] if d.ndim > 1 else 1
+    if kernel == KERNEL_ABSEXP:  # kernel.py:247-286: exp(-sum_k theta_k |d_k|)
+        d = np.abs(d)
+        if theta.size == 1:
+            return np.exp(-theta[0] * np.sum(d, axis=1))
+        if theta.size != n_features:
+            raise ValueError("Length of theta must be 1 or %s" % n_features)
+        return np.exp(-np.sum(theta.reshape(1, n_features) * d, axis=1))
     if theta.size == 1:
         s = theta[0] * np.sum(d**2, axis=1)
     else:
@@ -110,6 +118,8 @@ def corr_grad_theta(kernel: int, theta: np.ndarray, X: np.ndarray, R0: np.ndarra
     diff = (X[:, np.newaxis, :] - X[np.newaxis, :, :]) ** 2.0
     if kernel == KERNEL_SE:
         return -diff * R0[..., np.newaxis]
+    if kernel == KERNEL_ABSEXP:  # :761-762
+        return -np.sqrt(diff) * R0[..., np.newaxis]
     D = np.sqrt(np.sum(theta * diff, axis=-1))
     if kernel == KERNEL_MATERN32:
         return -3 * np.exp(-_SQRT3 * D)[..., np.newaxis] * diff / 2.0
@@ -404,6 +414,8 @@ def corr_dx(st: GPState, x: np.ndarray, r: np.ndarray) -> np.ndarray:
     theta = st.theta.reshape(-1, 1)
     if st.kernel == KERNEL_SE:
         return -2 * r * (theta * diff)
+    if st.kernel == KERNEL_ABSEXP:  # :650-651
+        return -1.0 * r * theta * np.sign(diff)
     D = np.sqrt(np.sum(theta * diff**2.0, axis=0))
     if st.kernel == KERNEL_MATERN32:
         with np.errstate(all="raise"):

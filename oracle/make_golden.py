@@ -264,6 +264,32 @@ def main():
          gamma=gp.gamma, sigma2=gp.sigma2, kernel=np.array(0), mode=np.array(1),
          **_g8_outputs(gp, Xs.astype(np.float32).astype(np.float64)))  # fmt: skip
 
+    # ---- G12: absolute_exponential (the third kernel the reference can actually fit): state, values, gradients,
+    #           llf tables in the three modes -----------------------------------------------------------------------
+    X, y = make_data(12, 60, 4)
+    d = 4
+    gp = GaussianProcess(mean=trend.constant_trend(d), corr="absolute_exponential", thetaL=[1e-4] * d, thetaU=[1e2] * d, nugget=1e-6)
+    par = np.r_[0.11, 0.07, 0.16, 0.09, 0.85]
+    llf = pin(gp, X, y, par)
+    rng = np.random.default_rng(112)
+    Xs = rng.uniform(-5, 5, size=(256, d))
+    mu, mse = gp.predict(Xs, eval_MSE=True)
+    tabs = {}
+    rng2 = np.random.default_rng(212)
+    for mname, mid, kw in (("noiseless", 0, dict(nugget=0)), ("noisy", 1, dict(nugget=1e-6)), ("noise_estim", 2, dict(nugget=1e-6, noise_estim=True))):
+        for tname, mean in (("sk", None), ("ok", trend.constant_trend(d))):
+            g2 = GaussianProcess(mean=mean, corr="absolute_exponential", thetaL=[1e-4] * d, thetaU=[1e2] * d, **kw)
+            g2._check_data(X, y)
+            pars = []
+            for _ in range(4):
+                th = 10 ** rng2.uniform(-1.3, -0.5, size=d)
+                pars.append(th if mid == 0 else np.r_[th, rng2.uniform(0.4, 1.1) if mid == 1 else rng2.uniform(0.7, 0.999)])
+            v, gr = llf_table(g2, pars)
+            key = "t_m%d_%s" % (mid, tname)
+            tabs[key + "_par"], tabs[key + "_llf"], tabs[key + "_grad"] = np.array(pars), v, gr
+    save("G12_absexp_ok_noisy", par=par, Xs=Xs, mu=mu, mse=mse, kernel=np.array(4), mode=np.array(1),
+         **state_dict(gp, llf), **acq_rows(gp, Xs), **grad_rows(gp, Xs[:8]), **tabs)  # fmt: skip
+
     # ---- G9: plumbing invariants of fmin (trajectory depends on the LHS stand-in; not a golden) -----
     np.random.seed(42)
     res = bayes_optim.fmin(lambda x: float(np.sum(np.asarray(x) ** 2)), [-5.0, -5.0], [5.0, 5.0], max_FEs=30, seed=42, verbose=False)

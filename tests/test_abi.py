@@ -52,7 +52,8 @@ def test_abi_version_and_constants_match_header():
 def test_oracle_ids_match_library_ids():
     from oracle import gp_oracle as O
 
-    assert (O.KERNEL_SE, O.KERNEL_MATERN12, O.KERNEL_MATERN32, O.KERNEL_MATERN52) == (0, 1, 2, 3)
+    assert (O.KERNEL_SE, O.KERNEL_MATERN12, O.KERNEL_MATERN32, O.KERNEL_MATERN52, O.KERNEL_ABSEXP) == (0, 1, 2, 3, 4)
+    assert _lib.KERNEL_ABSEXP == 4
     assert (O.MODE_NOISELESS, O.MODE_NOISY, O.MODE_NOISE_ESTIM) == (_lib.MODE_NOISELESS, _lib.MODE_NOISY, _lib.MODE_NOISE_ESTIM)
     assert (O.ACQ_EI, O.ACQ_EPSILON_PI, O.ACQ_UCB, O.ACQ_MGFI) == (_lib.ACQ_EI, _lib.ACQ_EPSILON_PI, _lib.ACQ_UCB, _lib.ACQ_MGFI)
 

@@ -22,7 +22,8 @@ pytestmark = pytest.mark.gpu
 import bogp  # noqa: E402
 from bogp import _lib  # noqa: E402
 
-STATE_FILES = ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G3_m52_sk_noisy", "G4_se_ok_noiseless", "G5_se_sk_noise_estim", "G7_edges"]
+STATE_FILES = ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G3_m52_sk_noisy", "G4_se_ok_noiseless", "G5_se_sk_noise_estim", "G7_edges",
+               "G12_absexp_ok_noisy"]
 ACQ_KEYS = [("EI", O.ACQ_EI, 0.0), ("EpsilonPI_1e-10", O.ACQ_EPSILON_PI, 1e-10), ("UCB_0.5", O.ACQ_UCB, 0.5),
             ("MGFI_1", O.ACQ_MGFI, 1.0), ("MGFI_2", O.ACQ_MGFI, 2.0), ("MGFI_100", O.ACQ_MGFI, 100.0)]  # fmt: skip
 
@@ -147,6 +148,26 @@ def test_llf_and_gradient_tables(eng):
     assert n >= 30
 
 
+def test_absexp_llf_and_gradient_tables(eng):
+    g = load_golden("G12_absexp_ok_noisy")
+    eng.set_train(g["X"], g["y"])
+    n = 0
+    for mid in (0, 1, 2):
+        for tname in ("sk", "ok"):
+            key = "t_m%d_%s" % (mid, tname)
+            for p, v, gr in zip(g[key + "_par"], g[key + "_llf"], g[key + "_grad"]):
+                nv = 1e-6 if mid == 1 else 0.0
+                if np.isneginf(v):
+                    with pytest.raises(_lib.NotPositiveDefinite):
+                        eng.nll(O.KERNEL_ABSEXP, mid, p, nv, tname == "ok", 0.0, eval_grad=True)
+                    continue
+                llf, grad = eng.nll(O.KERNEL_ABSEXP, mid, p, nv, tname == "ok", 0.0, eval_grad=True)
+                np.testing.assert_allclose(llf, v, rtol=1e-9)
+                np.testing.assert_allclose(grad, gr, rtol=1e-6, atol=1e-8 * np.abs(gr).max())
+                n += 1
+    assert n >= 12
+
+
 def test_likelihood_along_the_reference_mle_trajectory(eng):
     """Every (par, llf, grad) the reference's own L-BFGS-B run visited (310 evaluations, recorded by
     oracle/make_golden.py inside GaussianProcess.fit): the device likelihood and gradient agree at all of them."""
@@ -158,7 +179,7 @@ def test_likelihood_along_the_reference_mle_trajectory(eng):
         np.testing.assert_allclose(grad, gr, rtol=1e-6, atol=1e-8 * np.abs(gr).max())
 
 
-@pytest.mark.parametrize("name", ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G4_se_ok_noiseless"])
+@pytest.mark.parametrize("name", ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G4_se_ok_noiseless", "G12_absexp_ok_noisy"])
 def test_input_gradient_matches_reference(eng, name):
     g = load_golden(name)
     commit_golden(eng, g)
@@ -205,6 +226,7 @@ def _problem(seed, N, d, lo=-5.0, hi=5.0, noise=0.0):
         (300, 5, 777, O.KERNEL_SE, O.MODE_NOISE_ESTIM, True),
         (520, 12, 3000, O.KERNEL_MATERN32, O.MODE_NOISELESS, True),
         (1000, 50, 2048, O.KERNEL_SE, O.MODE_NOISY, False),  # d = 50 (config C5's dimension)
+        (400, 8, 1500, O.KERNEL_ABSEXP, O.MODE_NOISY, True),
     ],
 )
 def test_random_problem_matches_oracle(eng, N, d, M, kernel, mode, est):

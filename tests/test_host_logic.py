@@ -20,6 +20,7 @@ def test_kernel_name_mapping_follows_the_reference():
     assert kernel_id_of(functools.partial(matern, nu=2.5)) == _lib.KERNEL_MATERN52
     assert kernel_id_of(functools.partial(matern, nu=0.5)) == _lib.KERNEL_MATERN12
     assert kernel_id_of(matern) == _lib.KERNEL_MATERN32
+    assert kernel_id_of("absolute_exponential") == _lib.KERNEL_ABSEXP
     with pytest.raises(NotImplementedError):
         kernel_id_of("cubic")
     with pytest.raises(ValueError):

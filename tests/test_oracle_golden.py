@@ -8,7 +8,8 @@ from conftest import load_golden, state_from_golden
 from oracle import gp_oracle as O
 
 RT = 1e-12
-STATE_FILES = ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G3_m52_sk_noisy", "G4_se_ok_noiseless", "G5_se_sk_noise_estim", "G7_edges"]
+STATE_FILES = ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G3_m52_sk_noisy", "G4_se_ok_noiseless", "G5_se_sk_noise_estim", "G7_edges",
+               "G12_absexp_ok_noisy"]
 
 
 def close(a, b, rtol=RT, atol=0.0):
@@ -126,7 +127,7 @@ def test_edge_semantics():
     )  # MGFI(t=100).t == 22.36 (clamp, acquisition_fun.py:260-263)
 
 
-@pytest.mark.parametrize("name", ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G4_se_ok_noiseless"])
+@pytest.mark.parametrize("name", ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G4_se_ok_noiseless", "G12_absexp_ok_noisy"])
 def test_gradient_matches_reference(name):
     g = load_golden(name)
     st = state_from_golden(g)
@@ -204,3 +205,21 @@ def test_philox_uniform_box_properties():
     np.testing.assert_array_equal(parts, X)
     assert abs(X[:, 0].mean()) < 0.2 and abs(X[:, 1].mean() - 0.5) < 0.02
     assert not np.array_equal(P.uniform_box(lo, hi, 10, 1), P.uniform_box(lo, hi, 10, 2))
+
+
+def test_absexp_llf_tables():
+    g = load_golden("G12_absexp_ok_noisy")
+    n = 0
+    for mid in (0, 1, 2):
+        for tname in ("sk", "ok"):
+            key = "t_m%d_%s" % (mid, tname)
+            for p, v, gr in zip(g[key + "_par"], g[key + "_llf"], g[key + "_grad"]):
+                out = O.log_likelihood_concentrated(p, g["X"], g["y"], O.KERNEL_ABSEXP, mid, noise_var=1e-6 if mid == 1 else 0.0,
+                                                    estimate_trend=(tname == "ok"), beta=0.0, eval_grad=True)  # fmt: skip
+                if np.isneginf(v):
+                    assert np.isneginf(out[0])
+                    continue
+                close(out[0], v, rtol=1e-11)
+                close(out[1], gr, rtol=1e-8, atol=1e-9)
+                n += 1
+    assert n >= 12
