@@ -507,3 +507,50 @@ def test_sweep_generated_and_device_optimizer():
     xopt, fopt = bogp.argmax_restart(crit[0], bogp.optim.Box(bounds), eval_budget=20000, optimizer="sweep-device")
     assert len(xopt) == d and fopt > 0
     np.testing.assert_allclose(float(np.ravel(crit[0](np.array(xopt).reshape(1, -1)))[0]), fopt, rtol=1e-9)
+
+
+@pytest.mark.parametrize("mode_kw", [dict(nugget=0, noise_estim=False), dict(nugget=1e-6, noise_estim=False), dict(nugget=1e-6, noise_estim=True)])
+def test_reference_surrogate_scenario(mode_kw):
+    """The scenario of the reference's own GP test (unittest/test_surrogate.py:56-109: N=100, d=10, SE, the three
+    estimation modes, theta0 given, BFGS MLE) -- there it only has to run; here the fitted state is also checked
+    against the oracle at the fitted hyper-parameters."""
+    np.random.seed(42)
+    n_sample, dim = 100, 10
+    X = np.random.rand(n_sample, dim)
+    y = np.sum(X**2.0, axis=1)
+    thetaL, thetaU = 1e-10 * np.ones(dim), 10 * np.ones(dim)
+    model = bogp.GaussianProcess(
+        theta0=np.random.rand(dim) * (thetaU - thetaL) + thetaL, thetaL=thetaL, thetaU=thetaU, optimizer="BFGS", wait_iter=3,
+        random_start=dim, likelihood="concentrated", eval_budget=100 * dim, **mode_kw)  # fmt: skip
+    model.fit(X, y)
+    assert model.is_fitted and np.isfinite(model.log_likelihood_)
+    mu, mse = model.predict(X, eval_MSE=True)
+    assert mu.shape == (n_sample, 1) and mse.shape == (n_sample, 1) and np.all(mse >= 0)
+    mode = {"noiseless": O.MODE_NOISELESS, "noisy": O.MODE_NOISY, "noise_estim": O.MODE_NOISE_ESTIM}[model.estimation_mode]
+    par = {O.MODE_NOISELESS: model.theta_, O.MODE_NOISY: np.r_[model.theta_, model.par.get("sigma2", [0])[0]],
+           O.MODE_NOISE_ESTIM: np.r_[model.theta_, model.par.get("alpha", [0])[0]]}[mode]  # fmt: skip
+    nv = float(np.atleast_1d(model.noise_var)[0]) if mode == O.MODE_NOISY else 0.0
+    st = O.make_state(par, X, y.reshape(-1, 1), O.KERNEL_SE, mode, nv, estimate_trend=False, beta=0.0)
+    np.testing.assert_allclose(model.log_likelihood_, st.llf, rtol=1e-8)
+    rmu, rmse = O.predict(st, X)
+    # at the training points of a (nearly) noiseless model MSE is a pure cancellation: absolute tolerance only
+    np.testing.assert_allclose(mu, rmu, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(mse, rmse, rtol=1e-6, atol=1e-9 * float(st.sigma2[0]) + 1e-12)
+
+
+def test_tiny_training_sets(eng):
+    """N = 1 and N = 2 (one 32-row block, almost all padding), d = 1."""
+    for N in (1, 2, 3):
+        X = np.linspace(-1, 1, N).reshape(-1, 1) if N > 1 else np.array([[0.3]])
+        y = np.array([0.5, -0.2, 0.1][:N]).reshape(-1, 1)
+        par = np.r_[0.7, 0.9]
+        st = O.make_state(par, X, y, O.KERNEL_MATERN32, O.MODE_NOISY, 1e-3, estimate_trend=False, beta=0.0)
+        eng.set_train(X, y)
+        llf = eng.commit(O.KERNEL_MATERN32, O.MODE_NOISY, par, 1e-3, False, 0.0)
+        np.testing.assert_allclose(llf, st.llf, rtol=1e-12)
+        Xs = np.linspace(-2, 2, 9).reshape(-1, 1)
+        eng.upload_candidates(Xs)
+        mu, mse = eng.predict()
+        rmu, rmse = O.predict(st, Xs)
+        close_mu(mu, rmu)
+        close_mse(mse, rmse, 0.9)
