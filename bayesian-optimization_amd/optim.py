@@ -196,8 +196,23 @@ def argmax_restart(
             full[:, masks] = np.asarray(values, dtype=float)
         best, gidx, _ = sweep_argmax([crit], full, return_points=False)
         return Xs[int(gidx[0])].tolist(), float(best[0])
+    starts = None
+    if optimizer == "sweep-BFGS":
+        # hybrid: the sweep picks the n_restart most promising candidates, the reference's L-BFGS-B
+        # loop then polishes each of them instead of starting from uniform random points
+        crit, masks, _ = unwrap_criterion(obj_func)
+        if crit is None or masks is not None or h is not None or g is not None:
+            raise NotImplementedError("optimizer='sweep-BFGS' takes an unconstrained bogp criterion without fixed variables")
+        Xs = np.asarray(search_space.sample(int(eval_budget), method="uniform"), dtype=float)
+        k = int(max(1, min(n_restart, 32, len(Xs))))
+        tv, _, tx = sweep_topk([crit], Xs, k)
+        starts = [tx[0, r] for r in range(k) if np.isfinite(tv[0, r])]
+        n_restart, eval_budget, wait_iter = len(starts), 50 * len(starts), len(starts) + 1
+        obj_func, optimizer = crit, "BFGS"
     if optimizer != "BFGS":
-        raise NotImplementedError("optimizer %r is out of scope here (SURVEY.md 2 rows 6-7); use 'BFGS' or 'sweep'" % optimizer)
+        raise NotImplementedError(
+            "optimizer %r is out of scope here (SURVEY.md 2 rows 6-7); use 'BFGS', 'sweep', 'sweep-device' or 'sweep-BFGS'" % optimizer
+        )
 
     xopt, fopt = [], []
     best = -np.inf
@@ -212,8 +227,12 @@ def argmax_restart(
         return -1.0 * float(np.asarray(f, float).ravel()[0]), -1.0 * np.asarray(fg, float).ravel()
 
     for iteration in range(n_restart):
-        x0 = np.asarray(search_space.sample(N=1, method="uniform")[0], dtype=float)
-        xopt_, fopt_, stop_dict = fmin_l_bfgs_b(neg, x0, pgtol=1e-8, factr=1e6, bounds=bounds, maxfun=eval_budget)
+        if starts is None:
+            x0 = np.asarray(search_space.sample(N=1, method="uniform")[0], dtype=float)
+        else:
+            x0 = np.asarray(starts[iteration], dtype=float)
+        maxfun = eval_budget if starts is None else 50
+        xopt_, fopt_, stop_dict = fmin_l_bfgs_b(neg, x0, pgtol=1e-8, factr=1e6, bounds=bounds, maxfun=maxfun)
         xopt_ = xopt_.flatten().tolist()
         fopt_ = -float(fopt_)
         if fopt_ > best:

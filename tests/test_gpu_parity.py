@@ -554,3 +554,16 @@ def test_tiny_training_sets(eng):
         rmu, rmse = O.predict(st, Xs)
         close_mu(mu, rmu)
         close_mse(mse, rmse, 0.9)
+
+
+def test_hybrid_sweep_then_bfgs_polish():
+    g = load_golden("G1_se_sk_noisy")
+    d = g["X"].shape[1]
+    gp = bogp.GaussianProcess(corr="squared_exponential", thetaL=[1e-4] * d, thetaU=[1e2] * d, nugget=1e-6)
+    gp.set_state(g["par"], g["X"], g["y"])
+    crit = bogp.EI(model=gp)
+    x1, f1 = bogp.argmax_restart(crit, bogp.optim.Box([(-5, 5)] * d, random_seed=4), eval_budget=3000, optimizer="sweep")
+    x2, f2 = bogp.argmax_restart(crit, bogp.optim.Box([(-5, 5)] * d, random_seed=4), eval_budget=3000, n_restart=4,
+                                 optimizer="sweep-BFGS")  # fmt: skip
+    assert f2 >= f1 * (1 - 1e-12) and len(x2) == d and all(-5 <= v <= 5 for v in x2)
+    np.testing.assert_allclose(float(np.ravel(crit(np.array(x2).reshape(1, -1)))[0]), f2, rtol=1e-8)
