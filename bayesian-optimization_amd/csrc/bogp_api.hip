@@ -176,7 +176,7 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
   if (!h) return BOGP_ERR_INVALID;
   if (!X || !y || N <= 0 || d <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_set_train: X, y must be non-null and N, d > 0");
   if (n_targets != 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_set_train: n_targets = %d; only single-target GPs are built (multi-target y is MOBO-only)", n_targets);
-  if (d > 1024) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_set_train: d = %d > 1024 exceeds the LDS tile of the sweep producer", d);
+  if (d > 128) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_set_train: d = %d > 128: the sweep producer keeps a 64 x d candidate tile in 64 KB of LDS", d);
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   free_train(h);

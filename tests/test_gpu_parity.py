@@ -282,6 +282,13 @@ def test_error_codes(eng):
         e2.commit(0, 1, [0.1, 0.2, 0.3, 0.9], 1e-6)  # wrong len(theta)
     with pytest.raises(_lib.BogpError):
         e2.set_train(X, np.zeros((5, 2)))  # multi-target
+    with pytest.raises(_lib.BogpError) as ei:
+        e2.set_train(np.zeros((4, 129)), np.zeros(4))  # d beyond the producer's LDS tile
+    assert ei.value.code == _lib.ERR_UNSUPPORTED
+    e2.set_train(np.random.default_rng(0).uniform(-1, 1, (40, 128)), np.arange(40.0) / 40)  # d = 128 works
+    e2.commit(0, 1, np.r_[np.full(128, 0.02), 0.9], 1e-6)
+    e2.upload_candidates(np.zeros((3, 128)))
+    assert np.all(np.isfinite(e2.predict()[0]))
     # duplicated rows, no nugget -> singular correlation matrix -> the -inf convention
     Xd = np.vstack([X, X[:1]])
     e2.set_train(Xd, np.arange(6.0))
