@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-sample", type=int, default=16384, help="candidates timed through the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-sample", type=int, default=49152, help="candidates timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
