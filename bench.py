@@ -30,6 +30,10 @@ WORKLOADS = {
     "C2": dict(N=512, d=10, M=100_000, kernel=0, theta=0.02, acq=[(0, 0.0)], name="C2: N=512 d=10 M=1e5 SE EI"),
     "C3": dict(N=2048, d=20, M=1_000_000, kernel=3, theta=0.01, acq=[(3, 2.0), (0, 0.0)],
                name="C3: N=2048 d=20 M=1e6/GPU Matern-5/2 MGFI(t=2)+EI"),  # fmt: skip
+    # configs[3]: ParallelBO batch q = 8, t_i = exp(log 2 + 0.5 z_i) (bayes_opt.py:84-86), z from a seeded rng; 1e6 per GPU
+    "C4": dict(N=2048, d=20, M=1_000_000, kernel=3, theta=0.01,
+               acq=[(3, float(t)) for t in np.exp(np.log(2.0) + 0.5 * np.random.default_rng(4).standard_normal(8))],
+               name="C4: N=2048 d=20 M=1e6/GPU Matern-5/2 q=8 MGFI(t_i ~ logN(log 2, 0.5))"),
     "C5": dict(N=8192, d=50, M=500_000, kernel=0, theta=0.004, acq=[(2, 0.5)], name="C5: N=8192 d=50 M=5e5/GPU SE UCB"),
 }
 
