@@ -41,6 +41,7 @@ SIGNATURES = {
     "bogp_sweep": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, C.c_double, C.c_int, _dp, _lp, _dp]),
     "bogp_sweep_topk": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, C.c_double, C.c_int, C.c_int, _dp, _lp]),
     "bogp_gradient": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
+    "bogp_gradient_batch": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
     "bogp_last_timing": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip]),
     "bogp_flops_per_candidate": (C.c_double, [C.c_void_p]),
 }
@@ -241,6 +242,16 @@ class Engine:
             raise Exception("x does not have the right size!")
         dmu, dmse = np.empty(self.d), np.empty(self.d)
         self._check(self._lib.bogp_gradient(self._h, _ptr(x), _ptr(dmu), _ptr(dmse)))
+        return dmu, dmse
+
+    def gradient_batch(self, Xb):
+        """(d mu / dx, d MSE / dx) at B points: two (B, d) arrays."""
+        Xb = _f64(Xb)
+        if Xb.ndim != 2 or Xb.shape[1] != self.d:
+            raise Exception("x does not have the right size!")
+        B = Xb.shape[0]
+        dmu, dmse = np.empty((B, self.d)), np.empty((B, self.d))
+        self._check(self._lib.bogp_gradient_batch(self._h, _ptr(Xb), B, _ptr(dmu), _ptr(dmse)))
         return dmu, dmse
 
     def last_timing(self) -> dict:

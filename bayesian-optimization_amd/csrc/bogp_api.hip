@@ -40,6 +40,8 @@ struct bogp_handle {
   rocblas_int* dinfo = nullptr;
   double* dgrad_partial = nullptr;
   size_t grad_partial_cap = 0;
+  double* dbatch = nullptr;
+  size_t batch_cap = 0;
 
   // committed state
   bool committed = false;
@@ -164,7 +166,7 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   dfree(h->dXs_owned); dfree(h->dss_part); dfree(h->dbounds);
   for (int b = 0; b < 2; ++b) { dfree(h->drT[b]); dfree(h->dmu_part[b]); dfree(h->dw_part[b]); }
   dfree(h->dblk_val); dfree(h->dblk_idx); dfree(h->dmu_out); dfree(h->dmse_out); dfree(h->dacq_out);
-  dfree(h->dbest_val); dfree(h->dbest_idx); dfree(h->dinfo); dfree(h->dscal); dfree(h->dgrad_partial);
+  dfree(h->dbest_val); dfree(h->dbest_idx); dfree(h->dinfo); dfree(h->dscal); dfree(h->dgrad_partial); dfree(h->dbatch);
   for (auto e : h->ev) (void)hipEventDestroy(e);
   if (h->blas) rocblas_destroy_handle(h->blas);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -255,7 +257,6 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   HIPCHK(h, hipStreamSynchronize(st));
   if (info != 0) FAIL(h, BOGP_ERR_NOT_POSDEF, "correlation matrix is not positive definite (potrf info = %d)", (int)info);
 
-  const double one = 1.0;
   double ftyt = 0, ftft = 0, G = 0, beta_eff = beta;
   if (estimate_trend) {
     // Ft = L^-1 F, F = ones (constant trend); economic QR of a single column: G = -sign(Ft[0]) |Ft|, Q = Ft / G (:803-806)
@@ -285,7 +286,6 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
       HIPCHK(h, hipStreamSynchronize(st));
     }
   }
-  (void)one;
   double rho_ss = 0, logdet = 0;
   BLASCHK(h, rocblas_ddot(h->blas, N, h->drho, 1, h->drho, 1, &rho_ss));
   HIPCHK(h, hipMemcpyAsync(&logdet, h->dscal, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -746,3 +746,44 @@ extern "C" int bogp_gradient(bogp_handle* h, const double* x, double* dmu, doubl
   }
   return BOGP_OK;
 }
+
+// Batched flavour: B points, one pair of triangular solves with B right-hand sides
+// (rocBLAS dtrsm = the reference's solve_triangular twice) and one reduction kernel; dmu, dmse are B x d row-major.
+extern "C" int bogp_gradient_batch(bogp_handle* h, const double* Xb, int B, double* dmu, double* dmse) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "bogp_gradient_batch: no committed model");
+  if (!Xb || !dmu || !dmse || B <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_gradient_batch: null pointer or B <= 0");
+  const int N = h->N, d = h->d;
+  hipStream_t st = h->stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t nout = (size_t)B * (3 * d + 1);
+  int e = ensure(h, &h->dbatch, &h->batch_cap, (size_t)3 * N * B + (size_t)B * d + nout);
+  if (e) return e;
+  double* dr = h->dbatch;               // N x B (column b = r of point b)
+  double* ds2 = dr + (size_t)N * B;     // N x B
+  double* dZ = ds2 + (size_t)N * B;     // N x B
+  double* dXb = dZ + (size_t)N * B;     // B x d
+  double* dout = dXb + (size_t)B * d;   // B x (3d + 1)
+  HIPCHK(h, hipMemcpyAsync(dXb, Xb, (size_t)B * d * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(h, launch_batch_corr(h->kernel, h->dX, N, d, h->dtheta, dXb, B, dr, ds2, st));
+  HIPCHK(h, hipMemcpyAsync(dZ, dr, (size_t)N * B * sizeof(double), hipMemcpyDeviceToDevice, st));
+  const double one = 1.0;
+  BLASCHK(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, B, &one, h->dR, N, dZ, N));
+  BLASCHK(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, B, &one, h->dR, N, dZ, N));
+  HIPCHK(h, launch_batch_grad(h->kernel, h->dX, N, d, h->dtheta, dXb, B, dr, ds2, dZ, h->dgamma, h->dw, dout, st));
+  std::vector<double> out(nout);
+  HIPCHK(h, hipMemcpyAsync(out.data(), dout, nout * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  for (int b = 0; b < B; ++b) {
+    const double* o = &out[(size_t)b * (3 * d + 1)];
+    const double wr = o[3 * d];
+    for (int k = 0; k < d; ++k) {
+      dmu[(size_t)b * d + k] = o[k];
+      double m = -1.0 * o[d + k];
+      if (h->estimate_trend) m += (wr - 1.0) * (1.0 / h->ftft) * o[2 * d + k];
+      dmse[(size_t)b * d + k] = 2.0 * h->sigma2 * m;
+    }
+  }
+  return BOGP_OK;
+}
+

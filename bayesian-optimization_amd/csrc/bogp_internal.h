@@ -93,4 +93,10 @@ int grad_contract_blocks(int N);
 hipError_t launch_point_corr(int kernel, const double* X, int N, int d, const double* theta, const double* x,
                              double* r, double* rdx, hipStream_t st);
 
+hipError_t launch_batch_corr(int kernel, const double* X, int N, int d, const double* theta, const double* Xb, int B,
+                             double* r, double* s2, hipStream_t st);
+hipError_t launch_batch_grad(int kernel, const double* X, int N, int d, const double* theta, const double* Xb, int B,
+                             const double* r, const double* s2, const double* Z, const double* gamma,
+                             const double* wvec, double* out, hipStream_t st);
+
 }  // namespace bogp

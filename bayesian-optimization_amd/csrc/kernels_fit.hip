@@ -272,4 +272,113 @@ hipError_t launch_point_corr(int kernel, const double* X, int N, int d, const do
   return hipGetLastError();
 }
 
+// ---- batched input-gradients: B points at once ----------------------------------------------
+// k_batch_corr:  r[b*N + n] = corr(theta, |x_b - X_n|),  s2[b*N + n] = the weighted distance it was computed from
+template <int KERNEL>
+__global__ __launch_bounds__(256) void k_batch_corr(const double* __restrict__ X, int N, int d,
+                                                    const double* __restrict__ theta, const double* __restrict__ Xb,
+                                                    double* __restrict__ r, double* __restrict__ s2out) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (n >= N) return;
+  double s2 = 0.0;
+  for (int k = 0; k < d; ++k) s2 += dist_term<KERNEL>(theta[k], fabs(Xb[(size_t)b * d + k] - X[(size_t)n * d + k]));
+  r[(size_t)b * N + n] = corr_profile<KERNEL>(s2);
+  s2out[(size_t)b * N + n] = s2;
+}
+
+// d r / d x_k of one (point, training row) pair; same formulas as k_point_corr (corr_dx, gpr.py:600-661)
+template <int KERNEL>
+__device__ __forceinline__ double corr_dx_entry(double rv, double s2, double theta_k, double diff) {
+  if (KERNEL == BOGP_KERNEL_ABSEXP) return -1.0 * rv * theta_k * (diff > 0.0 ? 1.0 : (diff < 0.0 ? -1.0 : 0.0));
+  if (KERNEL == BOGP_KERNEL_SE) return -2 * rv * (theta_k * diff);
+  const double D = sqrt(s2);
+  if (KERNEL == BOGP_KERNEL_MATERN32) return D > 0.0 ? (diff * theta_k / D) * (-3.0 * D * exp(-1.7320508075688772 * D)) : 0.0;
+  if (KERNEL == BOGP_KERNEL_MATERN52)
+    return (-(5.0 / 3.0) * (1.0 + 2.23606797749979 * D) * exp(-2.23606797749979 * D)) * (theta_k * diff);
+  return D > 0.0 ? -diff * theta_k / D * rv : 0.0;
+}
+
+// One workgroup per point b.  out[b][0..d) = sum_n gamma_n dr_n/dx_k, [d..2d) = sum_n z_n dr_n/dx_k,
+// [2d..3d) = sum_n w_n dr_n/dx_k, [3d] = sum_n w_n r_n   (z = R^-1 r, column b of Z)
+template <int KERNEL>
+__global__ __launch_bounds__(256) void k_batch_grad(const double* __restrict__ X, int N, int d,
+                                                    const double* __restrict__ theta, const double* __restrict__ Xb,
+                                                    const double* __restrict__ r, const double* __restrict__ s2,
+                                                    const double* __restrict__ Z, const double* __restrict__ gamma,
+                                                    const double* __restrict__ wvec, double* __restrict__ out) {
+  __shared__ double red[3][4];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const double* rb = r + (size_t)b * N;
+  const double* sb = s2 + (size_t)b * N;
+  const double* zb = Z + (size_t)b * N;
+  double* ob = out + (size_t)b * (3 * d + 1);
+  for (int k = 0; k <= d; ++k) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+      if (k < d) {
+        const double g = corr_dx_entry<KERNEL>(rb[n], sb[n], theta[k], Xb[(size_t)b * d + k] - X[(size_t)n * d + k]);
+        a0 += gamma[n] * g;
+        a1 += zb[n] * g;
+        a2 += wvec[n] * g;
+      } else {
+        a0 += wvec[n] * rb[n];
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      a0 += shfl_xor_f64(a0, off);
+      a1 += shfl_xor_f64(a1, off);
+      a2 += shfl_xor_f64(a2, off);
+    }
+    if (lane == 0) {
+      red[0][wv] = a0;
+      red[1][wv] = a1;
+      red[2][wv] = a2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double t0 = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+      const double t1 = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+      const double t2 = ((red[2][0] + red[2][1]) + red[2][2]) + red[2][3];
+      if (k < d) {
+        ob[k] = t0;
+        ob[d + k] = t1;
+        ob[2 * d + k] = t2;
+      } else {
+        ob[3 * d] = t0;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+#define BOGP_DISPATCH_KERNEL(kernel, CALL)                       \
+  switch (kernel) {                                              \
+    case BOGP_KERNEL_SE: CALL(BOGP_KERNEL_SE); break;            \
+    case BOGP_KERNEL_MATERN12: CALL(BOGP_KERNEL_MATERN12); break; \
+    case BOGP_KERNEL_MATERN32: CALL(BOGP_KERNEL_MATERN32); break; \
+    case BOGP_KERNEL_ABSEXP: CALL(BOGP_KERNEL_ABSEXP); break;    \
+    default: CALL(BOGP_KERNEL_MATERN52); break;                  \
+  }
+
+hipError_t launch_batch_corr(int kernel, const double* X, int N, int d, const double* theta, const double* Xb, int B,
+                             double* r, double* s2, hipStream_t st) {
+  dim3 grid((N + 255) / 256, B);
+#define CALL(K) hipLaunchKernelGGL(k_batch_corr<K>, grid, 256, 0, st, X, N, d, theta, Xb, r, s2)
+  BOGP_DISPATCH_KERNEL(kernel, CALL)
+#undef CALL
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_grad(int kernel, const double* X, int N, int d, const double* theta, const double* Xb, int B,
+                             const double* r, const double* s2, const double* Z, const double* gamma,
+                             const double* wvec, double* out, hipStream_t st) {
+#define CALL(K) hipLaunchKernelGGL(k_batch_grad<K>, dim3(B), 256, 0, st, X, N, d, theta, Xb, r, s2, Z, gamma, wvec, out)
+  BOGP_DISPATCH_KERNEL(kernel, CALL)
+#undef CALL
+  return hipGetLastError();
+}
+
 }  // namespace bogp

@@ -406,3 +406,10 @@ class GaussianProcess:
             raise Exception("x must be a vector!")
         dmu, dmse = self.engine.gradient(x[0])
         return dmu.reshape(-1, 1), dmse.reshape(-1, 1)
+
+    def gradient_batch(self, X):
+        """`gradient` at B rows in one device call: (d mu / dx (B, d), d MSE / dx (B, d)).  Not in the reference
+        (its gradient takes one row, gpr.py:548-549); SURVEY.md 8 f2."""
+        if self._committed_par is None:
+            raise Exception("The model is not fitted yet!")
+        return self.engine.gradient_batch(self._check_X(X))

@@ -149,6 +149,9 @@ int bogp_sweep_topk(bogp_handle* h, int q, const int* acq_id, const double* acq_
 /* ---- input-gradient of the posterior at ONE point ---------------------------------------------------
  * Replaces GaussianProcess.gradient(x) (gpr.py:537-576, corr_dx :600-661): dmu (d), dmse (d).            */
 int bogp_gradient(bogp_handle* h, const double* x, double* dmu, double* dmse);
+/* The same for B points at once (Xb: B x d; dmu, dmse: B x d row-major): one pair of triangular solves with B
+ * right-hand sides + one reduction kernel.  Feeds multi-start local refinement of the sweep's top-k.      */
+int bogp_gradient_batch(bogp_handle* h, const double* Xb, int B, double* dmu, double* dmse);
 
 /* ---- measurement ----------------------------------------------------------------------------------
  * HIP-event durations (ms, summed over candidate chunks) of the kernels of the LAST bogp_predict /

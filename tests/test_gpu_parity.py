@@ -574,3 +574,26 @@ def test_hybrid_sweep_then_bfgs_polish():
                                  optimizer="sweep-BFGS")  # fmt: skip
     assert f2 >= f1 * (1 - 1e-12) and len(x2) == d and all(-5 <= v <= 5 for v in x2)
     np.testing.assert_allclose(float(np.ravel(crit(np.array(x2).reshape(1, -1)))[0]), f2, rtol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G4_se_ok_noiseless", "G12_absexp_ok_noisy", "G3_m52_sk_noisy"])
+def test_batched_input_gradients(eng, name):
+    """bogp_gradient_batch == the single-point gradient of the reference (goldens) / of the oracle, point by point."""
+    g = load_golden(name)
+    st = state_from_golden(g)
+    commit_golden(eng, g)
+    Xb = g["Xs"][:33]
+    dmu, dmse = eng.gradient_batch(Xb)
+    assert dmu.shape == dmse.shape == (33, g["X"].shape[1])
+    for i in range(len(Xb)):
+        rmu, rmse = O.gradient(st, Xb[i])
+        np.testing.assert_allclose(dmu[i], rmu.ravel(), rtol=1e-6, atol=1e-10)
+        np.testing.assert_allclose(dmse[i], rmse.ravel(), rtol=1e-6, atol=1e-10)
+        if i < 3:  # and it is the same number the single-point entry returns
+            a, b = eng.gradient(Xb[i])
+            np.testing.assert_allclose(dmu[i], a, rtol=1e-9, atol=1e-13)
+            np.testing.assert_allclose(dmse[i], b, rtol=1e-9, atol=1e-13)
+    if "grad_mu" in g:
+        for i in range(len(g["grad_mu"])):
+            np.testing.assert_allclose(dmu[i], g["grad_mu"][i].ravel(), rtol=1e-6, atol=1e-10)
+            np.testing.assert_allclose(dmse[i], g["grad_mse"][i].ravel(), rtol=1e-6, atol=1e-10)
