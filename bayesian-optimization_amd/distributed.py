@@ -140,3 +140,22 @@ def exchange_topk(best_val: np.ndarray, best_gidx: np.ndarray, best_x: Optional[
                 if rr[j] >= 0:
                     out_x[c, j] = xs[rr[j], c, ss[j]]
     return out_v, out_i, out_x
+
+
+def exchange_best_parameters(param: np.ndarray, neg_llf: float, group=None):
+    """MLE restarts spread over ranks: all-gather (objective, parameter vector) and return the
+    pair with the smallest objective (ties -> lowest rank), identical on every rank."""
+    dist = _dist()
+    if dist is None or dist.get_world_size(group) == 1:
+        return param, neg_llf
+    import torch
+
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    v = neg_llf if np.isfinite(neg_llf) else np.inf
+    mine = torch.from_numpy(np.r_[v, np.asarray(param, dtype=np.float64)]).to(dev)
+    gathered = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(gathered, mine, group=group)
+    allp = torch.stack(gathered).cpu().numpy()
+    obj = np.where(np.isnan(allp[:, 0]), np.inf, allp[:, 0])
+    w = int(np.argmin(obj))  # first minimum = lowest rank
+    return allp[w, 1:].copy(), float(allp[w, 0])

@@ -21,7 +21,7 @@ import warnings
 import numpy as np
 from scipy.optimize import fmin_l_bfgs_b
 
-from . import _lib
+from . import _lib, distributed
 from .prior_mean import constant_trend, device_trend_of
 
 _KERNEL_IDS = {
@@ -84,6 +84,7 @@ class GaussianProcess:
         random_state=None,
         verbose=False,
         device=0,
+        distribute_restarts=False,
     ):
         self.mean = mean
         self.corr = corr
@@ -93,6 +94,7 @@ class GaussianProcess:
         self.kernel_id = kernel_id_of(corr)
         self.is_fitted = False
         self.device = int(device)
+        self.distribute_restarts = bool(distribute_restarts)
 
         self.theta0 = np.array(theta0, dtype=float).flatten() if theta0 is not None else None
         if thetaL is None or thetaU is None:
@@ -300,15 +302,29 @@ class GaussianProcess:
             llf, grad = self.log_likelihood_concentrated(param, eval_grad=True)
             return -1.0 * llf, -1.0 * np.asarray(grad, dtype=float).ravel()
 
+        # Restarts: sequential with a shared budget and stagnation counter, as the reference (gpr.py:1127-1162).
+        # With `distribute_restarts=True` under an initialised torch.distributed group, restart i runs
+        # on rank i % R with budget / R evaluations; every rank still draws ALL starting points from the (identically
+        # seeded) global np.random stream, so the union of starts is the sequential run's; ONE all-gather of
+        # (-llf, parameters) then picks the winner on every rank.
+        rank, world = (0, 1)
+        dist = distributed._dist() if self.distribute_restarts else None
+        if dist is not None:
+            rank, world = dist.get_rank(), dist.get_world_size()
+            eval_budget = max(1, -(-eval_budget // world))
         wait_count = 0
+        param_opt, llf_opt = np.array(log10param, dtype=float), np.inf
+        first = True
         for iteration in range(self.random_start):
             if iteration != 0:
                 log10param = np.random.uniform(log10bounds[:, 0], log10bounds[:, 1])
+            if iteration % world != rank:
+                continue
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 param_opt_, llf_opt_, info = fmin_l_bfgs_b(obj_func, log10param, bounds=log10bounds, maxfun=eval_budget)
-            if iteration == 0:
-                param_opt, llf_opt = param_opt_, llf_opt_
+            if first:
+                param_opt, llf_opt, first = param_opt_, llf_opt_, False
             elif llf_opt_ <= llf_opt:
                 param_opt, llf_opt = param_opt_, llf_opt_
                 wait_count = 0
@@ -320,6 +336,8 @@ class GaussianProcess:
             eval_budget -= info["funcalls"]
             if eval_budget <= 0 or wait_count >= self.wait_iter:
                 break
+        if world > 1:
+            param_opt, llf_opt = distributed.exchange_best_parameters(np.asarray(param_opt, float), float(llf_opt))
 
         optimal_param = 10.0**param_opt
         env = {}

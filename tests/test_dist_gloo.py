@@ -87,3 +87,47 @@ def test_two_rank_exchange_matches_global_argmax():
                 w[j] = -np.inf
     # both ranks hold identical results
     np.testing.assert_array_equal(res[0][2], res[1][2])
+
+
+def _fit_worker(rank, world, port, q_out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    import bogp
+    from support.oracle_engine import OracleEngine
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(3)
+        X = rng.uniform(-5, 5, size=(40, 3))
+        y = np.sum(X**2, axis=1)
+        y = (y - y.mean()) / y.std() + 0.05 * rng.standard_normal(40)
+        gp = bogp.GaussianProcess(thetaL=[1e-3] * 3, thetaU=[1e2] * 3, nugget=1e-6, random_start=6, wait_iter=6,
+                                  eval_budget=240, distribute_restarts=True)  # fmt: skip
+        gp._engine = OracleEngine()  # host-logic test: see tests/support/oracle_engine.py
+        np.random.seed(11)  # identical stream on every rank
+        gp.fit(X, y)
+        q_out.put((rank, gp.log_likelihood_, gp.theta_.copy(), gp.eval_count))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_mle_restarts_spread_over_two_ranks():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, q_out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q_out.get(timeout=250) for _ in procs])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (r0, llf0, th0, n0), (r1, llf1, th1, n1) = res
+    assert llf0 == llf1 and np.array_equal(th0, th1)  # every rank commits the same winner
+    assert np.isfinite(llf0) and n0 <= 135 and n1 <= 135  # ~half the budget each (L-BFGS-B overshoots maxfun by a line search)
