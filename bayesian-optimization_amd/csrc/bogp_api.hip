@@ -533,6 +533,52 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
   const int64_t nchunk = (M + Mc - 1) / Mc;
   const int64_t nblk_total = (M + 255) / 256 + nchunk;  // per-chunk block counts are rounded up
 
+  // Small batches (the reference's one-point-per-call usage through L-BFGS-B): the tiled contraction would leave one
+  // workgroup walking all N columns alone (~0.3 ms at N = 2048).  For M <= BOGP_SMALL_M the posterior is instead
+  // r -> rt = V r (rocBLAS dtrmm with M right-hand sides) -> column reductions, feeding the same acquisition kernel.
+  int small_m = 32;
+  if (const char* env = getenv("BOGP_SMALL_M")) small_m = atoi(env);
+  if (M <= small_m) {
+    const int B = (int)M, N = h->N;
+    int e2;
+    if ((e2 = ensure(h, &h->dbatch, &h->batch_cap, (size_t)3 * N * B + 3 * (size_t)B))) return e2;
+    double* dr = h->dbatch;
+    double* ds2 = dr + (size_t)N * B;
+    double* drt = ds2 + (size_t)N * B;
+    double* dred = drt + (size_t)N * B;  // mu[B], wd[B], ss[B]
+    if (q > 0) {
+      if ((e2 = ensure(h, &h->dblk_val, &h->blk_val_cap, (size_t)q * 2))) return e2;
+      if ((e2 = ensure(h, &h->dblk_idx, &h->blk_idx_cap, (size_t)q * 2))) return e2;
+      if (!h->dbest_val) HIPCHK(h, hipMalloc((void**)&h->dbest_val, BOGP_MAX_Q * sizeof(double)));
+      if (!h->dbest_idx) HIPCHK(h, hipMalloc((void**)&h->dbest_idx, BOGP_MAX_Q * sizeof(int64_t)));
+    }
+    if (want_out) {
+      if ((e2 = ensure(h, &h->dmu_out, &h->mu_out_cap, (size_t)M))) return e2;
+      if ((e2 = ensure(h, &h->dmse_out, &h->mse_out_cap, (size_t)M))) return e2;
+    }
+    if (want_acq_out)
+      if ((e2 = ensure(h, &h->dacq_out, &h->acq_out_cap, (size_t)q * M))) return e2;
+    HIPCHK(h, launch_batch_corr(h->kernel, h->dX, N, d, h->dtheta, h->dXs, B, dr, ds2, st));
+    const double one = 1.0;
+    BLASCHK(h, rocblas_dtrmm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, B, &one, h->dV, N, dr, N, drt, N));
+    HIPCHK(h, launch_col_reduce(dr, drt, N, B, h->dgamma, h->dw, dred, dred + B, dred + 2 * B, st));
+    AcqArgs aa;
+    memset(&aa, 0, sizeof(aa));
+    aa.mu_part = dred; aa.w_part = dred + B; aa.ss_part = dred + 2 * B; aa.S = 1; aa.nJ = 1; aa.Mc = B;
+    aa.mcount = B; aa.m0 = 0; aa.beta = h->beta; aa.G = h->G; aa.estimate_trend = h->estimate_trend;
+    aa.sigma2 = h->sigma2; aa.mu_out = want_out ? h->dmu_out : nullptr; aa.mse_out = want_out ? h->dmse_out : nullptr;
+    aa.q = q;
+    for (int i = 0; i < q; ++i) { aa.acq_id[i] = acq_id[i]; aa.acq_par[i] = acq_par ? acq_par[i] : 0.0; }
+    aa.plugin = plugin; aa.minimize = minimize; aa.acq_out = want_acq_out ? h->dacq_out : nullptr; aa.M = M;
+    aa.blk_val = h->dblk_val; aa.blk_idx = h->dblk_idx; aa.blk_offset = 0; aa.nblk_total = 1;
+    HIPCHK(h, launch_acquisition(aa, st));
+    if (q > 0) HIPCHK(h, launch_argmax_final(h->dblk_val, h->dblk_idx, 1, 1, q, h->dbest_val, h->dbest_idx, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    h->t_corr_ms = h->t_contract_ms = h->t_acq_ms = 0;
+    h->n_chunks = 0;
+    return BOGP_OK;
+  }
+
   // Optional two-stream mode (BOGP_OVERLAP=1): the correlation producer of chunk c+1 (FP64 VALU) runs beside the
   // contraction of chunk c (FP64 MFMA), everything the producer writes double buffered.  Measured on MI355X (r01,
   // C3): the kernels do overlap (contract 75.9 -> 81.9 ms, corr 6.8 -> 11.7 ms) but the step time is unchanged
@@ -723,10 +769,11 @@ extern "C" int bogp_gradient(bogp_handle* h, const double* x, double* dmu, doubl
   double* dout = dx + d;                    // 3 d
   HIPCHK(h, hipMemcpyAsync(dx, x, d * sizeof(double), hipMemcpyHostToDevice, st));
   HIPCHK(h, launch_point_corr(h->kernel, h->dX, N, d, h->dtheta, dx, dr, drdx, st));
-  // z = L^-T L^-1 r
+  // z = L^-T L^-1 r = V^T (V r) with the explicit V = L^-1 kept from the commit: two triangular matrix-vector
+  // products (bandwidth bound, ~50 us at N = 2048) instead of two dependent triangular solves (~350 us each)
   HIPCHK(h, hipMemcpyAsync(dz, dr, N * sizeof(double), hipMemcpyDeviceToDevice, st));
-  BLASCHK(h, rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, h->dR, N, dz, 1));
-  BLASCHK(h, rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, h->dR, N, dz, 1));
+  BLASCHK(h, rocblas_dtrmv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, h->dV, N, dz, 1));
+  BLASCHK(h, rocblas_dtrmv(h->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, h->dV, N, dz, 1));
   const double one = 1.0, zero = 0.0;
   BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, h->dgamma, 1, &zero, dout, 1));
   BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, dz, 1, &zero, dout + d, 1));

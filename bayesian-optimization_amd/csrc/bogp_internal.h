@@ -93,6 +93,8 @@ int grad_contract_blocks(int N);
 hipError_t launch_point_corr(int kernel, const double* X, int N, int d, const double* theta, const double* x,
                              double* r, double* rdx, hipStream_t st);
 
+hipError_t launch_col_reduce(const double* r, const double* rt, int N, int B, const double* gamma, const double* wvec,
+                             double* mu, double* wd, double* ss, hipStream_t st);
 hipError_t launch_batch_corr(int kernel, const double* X, int N, int d, const double* theta, const double* Xb, int B,
                              double* r, double* s2, hipStream_t st);
 hipError_t launch_batch_grad(int kernel, const double* X, int N, int d, const double* theta, const double* Xb, int B,

@@ -354,6 +354,45 @@ __global__ __launch_bounds__(256) void k_batch_grad(const double* __restrict__ X
   }
 }
 
+// Column reductions of the small-batch posterior path: for column b of r (N x B) and rt = V r (N x B):
+// mu[b] = sum_n r gamma, wd[b] = sum_n r w, ss[b] = sum_n rt^2   (one workgroup per column, fixed order)
+__global__ __launch_bounds__(256) void k_col_reduce(const double* __restrict__ r, const double* __restrict__ rt, int N,
+                                                    const double* __restrict__ gamma, const double* __restrict__ wvec,
+                                                    double* __restrict__ mu, double* __restrict__ wd, double* __restrict__ ss) {
+  __shared__ double red[3][4];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const double rv = r[(size_t)b * N + n], tv = rt[(size_t)b * N + n];
+    a0 = __builtin_fma(rv, gamma[n], a0);
+    a1 = __builtin_fma(rv, wvec[n], a1);
+    a2 = __builtin_fma(tv, tv, a2);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    a0 += shfl_xor_f64(a0, off);
+    a1 += shfl_xor_f64(a1, off);
+    a2 += shfl_xor_f64(a2, off);
+  }
+  if (lane == 0) {
+    red[0][wv] = a0;
+    red[1][wv] = a1;
+    red[2][wv] = a2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mu[b] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    wd[b] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    ss[b] = ((red[2][0] + red[2][1]) + red[2][2]) + red[2][3];
+  }
+}
+hipError_t launch_col_reduce(const double* r, const double* rt, int N, int B, const double* gamma, const double* wvec,
+                             double* mu, double* wd, double* ss, hipStream_t st) {
+  hipLaunchKernelGGL(k_col_reduce, dim3(B), 256, 0, st, r, rt, N, gamma, wvec, mu, wd, ss);
+  return hipGetLastError();
+}
+
 #define BOGP_DISPATCH_KERNEL(kernel, CALL)                       \
   switch (kernel) {                                              \
     case BOGP_KERNEL_SE: CALL(BOGP_KERNEL_SE); break;            \
