@@ -206,6 +206,10 @@ class GaussianProcess:
         par = np.asarray(par, dtype=np.float64).ravel()
         est, beta = self._trend_args()
         mode = self._MODE[self.estimation_mode]
+        if not (np.all(np.isfinite(par)) and np.all(par > 0)):
+            # L-BFGS-B can step to NaN after an infinite objective; the reference's Cholesky then raises
+            # ValueError/LinAlgError on the NaN matrix, which it turns into -inf (gpr.py:946-947, 960-961, 978-979)
+            return (-np.inf, np.zeros((len(par), 1))) if eval_grad else -np.inf
         try:
             if env is not None:
                 llf = self._commit(par, refresh_attributes=False)
