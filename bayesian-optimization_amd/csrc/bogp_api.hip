@@ -3,7 +3,6 @@
 // the gfx950 device, and every failure is reported as an error code + message.
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
-#include <rocsolver/rocsolver.h>
 
 #include <algorithm>
 #include <cmath>
@@ -29,10 +28,13 @@ struct bogp_handle {
 
   // training set
   int N = 0, d = 0, Np = 0;
+  int ldr = 0;  // leading dimension of dR / dV / dRinv: N rounded up to 64 (identity padding, kernels_chol.hip)
   double *dX = nullptr, *dy = nullptr;
 
-  // factorisation workspace (column-major N x N, ld = N)
-  double *dR = nullptr, *dV = nullptr, *dRinv = nullptr;
+  // factorisation workspace (column-major, ld = ldr)
+  double *dR = nullptr, *dV = nullptr, *dU = nullptr, *dT = nullptr, *dRinv = nullptr;  // L, L^-1, L^-T, scratch, R^-1
+  double* dones = nullptr;  // N ones (the constant trend basis)
+  double* ddinv = nullptr;  // ldr x 64: inverses of the diagonal blocks of the running factorisation (kernels_chol.hip)
   double *dyt = nullptr, *dft = nullptr, *drho = nullptr, *dtmp = nullptr;  // N each
   double *dgamma = nullptr, *dw = nullptr;                                  // Np each (zero padded)
   double *dtheta = nullptr, *dsqrt_theta = nullptr;                         // d each
@@ -151,7 +153,7 @@ extern "C" int bogp_create(int device, bogp_handle** out) {
 }
 
 static void free_train(bogp_handle* h) {
-  dfree(h->dX); dfree(h->dy); dfree(h->dR); dfree(h->dV); dfree(h->dRinv);
+  dfree(h->dX); dfree(h->dy); dfree(h->dR); dfree(h->dV); dfree(h->dU); dfree(h->dT); dfree(h->dRinv); dfree(h->ddinv); dfree(h->dones);
   dfree(h->dyt); dfree(h->dft); dfree(h->drho); dfree(h->dtmp); dfree(h->dgamma); dfree(h->dw);
   dfree(h->dtheta); dfree(h->dsqrt_theta); dfree(h->dXthT); dfree(h->dVp);
   h->committed = false;
@@ -185,10 +187,24 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
   h->N = N;
   h->d = d;
   h->Np = ((N + 31) / 32) * 32;
-  const size_t NN = (size_t)N * N;
+  h->ldr = ((N + 63) / 64) * 64;
+  const size_t NN = (size_t)h->ldr * h->ldr;
   HIPCHK(h, hipMalloc((void**)&h->dX, (size_t)N * d * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&h->dy, N * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&h->dR, NN * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->ddinv, (size_t)h->ldr * 64 * sizeof(double)));
+  HIPCHK(h, launch_pad_identity(h->dR, N, h->ldr, h->stream));
+  // V = L^-1 and U = V^T keep exact zeros in their other triangle (set once here; kernels_chol.hip never writes there)
+  HIPCHK(h, hipMalloc((void**)&h->dV, NN * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->dU, NN * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->dT, NN * sizeof(double)));
+  HIPCHK(h, hipMemsetAsync(h->dV, 0, NN * sizeof(double), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->dU, 0, NN * sizeof(double), h->stream));
+  {
+    std::vector<double> ones(N, 1.0);
+    HIPCHK(h, hipMalloc((void**)&h->dones, N * sizeof(double)));
+    HIPCHK(h, hipMemcpy(h->dones, ones.data(), N * sizeof(double), hipMemcpyHostToDevice));
+  }
   HIPCHK(h, hipMalloc((void**)&h->dyt, N * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&h->dft, N * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&h->drho, N * sizeof(double)));
@@ -216,7 +232,7 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   if (kernel < 0 || kernel > BOGP_KERNEL_ABSEXP) FAIL(h, BOGP_ERR_INVALID, "unknown kernel id %d", kernel);
   if (mode < 0 || mode > 2) FAIL(h, BOGP_ERR_INVALID, "unknown estimation mode %d", mode);
   if (trend != BOGP_TREND_CONSTANT) FAIL(h, BOGP_ERR_UNSUPPORTED, "only the constant trend basis is built (trend id %d)", trend);
-  const int N = h->N, d = h->d;
+  const int N = h->N, d = h->d, ldr = h->ldr;
   const int n_theta = n_par - (mode == BOGP_MODE_NOISELESS ? 0 : 1);
   if (n_theta != d && n_theta != 1) FAIL(h, BOGP_ERR_INVALID, "len(theta) = %d must be 1 or d = %d", n_theta, d);
   std::vector<double> th(d), sth(d);
@@ -236,33 +252,33 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   // correlation matrix with the per-mode normalisation (gpr.py:931-969)
   double s2t = 0, alpha = 0, sigma2_par = 0;
   if (mode == BOGP_MODE_NOISELESS) {
-    HIPCHK(h, launch_build_R(kernel, h->dX, N, d, h->dtheta, 1.0, 1.0, h->dR, N, st));
+    HIPCHK(h, launch_build_R(kernel, h->dX, N, d, h->dtheta, 1.0, 1.0, h->dR, ldr, st));
   } else if (mode == BOGP_MODE_NOISE_ESTIM) {
     alpha = par[n_par - 1];
-    HIPCHK(h, launch_build_R(kernel, h->dX, N, d, h->dtheta, alpha, alpha * 1.0 + (1 - alpha) * 1.0, h->dR, N, st));
+    HIPCHK(h, launch_build_R(kernel, h->dX, N, d, h->dtheta, alpha, alpha * 1.0 + (1 - alpha) * 1.0, h->dR, ldr, st));
   } else {
     sigma2_par = par[n_par - 1];
     s2t = sigma2_par + noise_var;
     HIPCHK(h, launch_build_R_div(kernel, h->dX, N, d, h->dtheta, sigma2_par, s2t, (sigma2_par * 1.0 + noise_var * 1.0) / s2t,
-                                 h->dR, N, st));
+                                 h->dR, ldr, st));
   }
   // L = chol(R) (gpr.py:795)
-  BLASCHK(h, rocsolver_dpotrf(h->blas, rocblas_fill_lower, N, h->dR, N, h->dinfo));
+  HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st));
   rocblas_int info = 0;
   HIPCHK(h, hipMemcpyAsync(&info, h->dinfo, sizeof(info), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, launch_logdet(h->dR, N, N, h->dscal, st));
+  HIPCHK(h, launch_logdet(h->dR, N, ldr, h->dscal, st));
+  // V = L^-1, U = L^-T: every triangular solve of gpr.py:795-808 / :787-788 / :997 becomes a product with V or U
+  HIPCHK(h, launch_tri_inverse(h->dR, h->ddinv, h->dV, h->dU, h->dT, ldr, st));
+  const double one = 1.0, zero = 0.0;
   // Yt = L^-1 y (:799)
-  HIPCHK(h, hipMemcpyAsync(h->dyt, h->dy, N * sizeof(double), hipMemcpyDeviceToDevice, st));
-  BLASCHK(h, rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, h->dR, N, h->dyt, 1));
+  BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, N, N, &one, h->dV, ldr, h->dy, 1, &zero, h->dyt, 1));
   HIPCHK(h, hipStreamSynchronize(st));
   if (info != 0) FAIL(h, BOGP_ERR_NOT_POSDEF, "correlation matrix is not positive definite (potrf info = %d)", (int)info);
 
   double ftyt = 0, ftft = 0, G = 0, beta_eff = beta;
   if (estimate_trend) {
     // Ft = L^-1 F, F = ones (constant trend); economic QR of a single column: G = -sign(Ft[0]) |Ft|, Q = Ft / G (:803-806)
-    std::vector<double> ones(N, 1.0);
-    HIPCHK(h, hipMemcpyAsync(h->dft, ones.data(), N * sizeof(double), hipMemcpyHostToDevice, st));
-    BLASCHK(h, rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, h->dR, N, h->dft, 1));
+    BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, N, N, &one, h->dV, ldr, h->dones, 1, &zero, h->dft, 1));
     double nrm = 0;
     BLASCHK(h, rocblas_dnrm2(h->blas, N, h->dft, 1, &nrm));
     BLASCHK(h, rocblas_ddot(h->blas, N, h->dft, 1, h->dyt, 1, &ftyt));
@@ -278,12 +294,8 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   } else {
     HIPCHK(h, hipMemcpyAsync(h->drho, h->dyt, N * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (beta != 0.0) {  // rho = Yt - L^-1 (beta * 1) (:808)
-      std::vector<double> bv(N, beta);
-      HIPCHK(h, hipMemcpyAsync(h->dtmp, bv.data(), N * sizeof(double), hipMemcpyHostToDevice, st));
-      BLASCHK(h, rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, h->dR, N, h->dtmp, 1));
-      const double m1 = -1.0;
-      BLASCHK(h, rocblas_daxpy(h->blas, N, &m1, h->dtmp, 1, h->drho, 1));
-      HIPCHK(h, hipStreamSynchronize(st));
+      const double mbeta = -beta;  // rho -= V (beta 1)
+      BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, N, N, &mbeta, h->dV, ldr, h->dones, 1, &one, h->drho, 1));
     }
   }
   double rho_ss = 0, logdet = 0;
@@ -315,8 +327,7 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
 
   if (want_gamma) {  // gamma = L^-T rho (:788 / :996)
     HIPCHK(h, hipMemsetAsync(h->dgamma, 0, h->Np * sizeof(double), st));
-    HIPCHK(h, hipMemcpyAsync(h->dgamma, h->drho, N * sizeof(double), hipMemcpyDeviceToDevice, st));
-    BLASCHK(h, rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, h->dR, N, h->dgamma, 1));
+    BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, N, N, &one, h->dU, ldr, h->drho, 1, &zero, h->dgamma, 1));
   }
   return BOGP_OK;
 }
@@ -337,27 +348,24 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
   if (n_theta != d) FAIL(h, BOGP_ERR_UNSUPPORTED, "gradient with isotropic theta (len 1, d = %d) is not built: the reference's own gradient is inconsistent there (gpr.py:1001-1037 index the (N,N,d) tensor by parameter)", d);
   hipStream_t st = h->stream;
   // R^-1 = cho_solve(L, I) (:997) via potri on a copy of L
-  if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)N * N * sizeof(double)));
-  HIPCHK(h, hipMemcpyAsync(h->dRinv, h->dR, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, st));
-  BLASCHK(h, rocsolver_dpotri(h->blas, rocblas_fill_lower, N, h->dRinv, N, h->dinfo));
+  const int ldr = h->ldr;
+  if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)ldr * ldr * sizeof(double)));
+  HIPCHK(h, launch_uut(h->dU, h->dRinv, ldr, st));  // R^-1 = L^-T L^-1, lower triangle
   const int nblk = grad_contract_blocks(N);
   int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)nblk * (d + 1) + (d + 1));
   if (e) return e;
   const double c1 = 1.0 / (mode == BOGP_MODE_NOISELESS ? o.sigma2 : o.s2t);
-  HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, h->dgamma, c1, h->dRinv, N, h->dgrad_partial, nblk, st));
+  HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, h->dgamma, c1, h->dRinv, ldr, h->dgrad_partial, nblk, st));
   double* dS = h->dgrad_partial + (size_t)nblk * (d + 1);
   HIPCHK(h, launch_grad_reduce(h->dgrad_partial, nblk, d + 1, dS, st));
   std::vector<double> S(d + 1);
   HIPCHK(h, hipMemcpyAsync(S.data(), dS, (d + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
   double tr = 0, gg = 0;
   if (mode == BOGP_MODE_NOISY) {
-    BLASCHK(h, rocblas_dasum(h->blas, N, h->dRinv, N + 1, &tr));  // trace: the diagonal of an SPD inverse is positive
+    BLASCHK(h, rocblas_dasum(h->blas, N, h->dRinv, ldr + 1, &tr));  // trace: the diagonal of an SPD inverse is positive
     BLASCHK(h, rocblas_ddot(h->blas, N, h->dgamma, 1, h->dgamma, 1, &gg));
   }
   HIPCHK(h, hipStreamSynchronize(st));
-  rocblas_int info = 0;
-  HIPCHK(h, hipMemcpy(&info, h->dinfo, sizeof(info), hipMemcpyDeviceToHost));
-  if (info != 0) FAIL(h, BOGP_ERR_NOT_POSDEF, "potri failed (info = %d)", (int)info);
   if (mode == BOGP_MODE_NOISELESS) {
     for (int k = 0; k < d; ++k) grad[k] = S[k];
   } else if (mode == BOGP_MODE_NOISE_ESTIM) {
@@ -384,23 +392,18 @@ extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* p
   const int N = h->N, d = h->d, Np = h->Np;
   hipStream_t st = h->stream;
   // V = L^-1 (the triangular solve of gpr.py:494 becomes a triangular GEMM against V)
-  if (!h->dV) HIPCHK(h, hipMalloc((void**)&h->dV, (size_t)N * N * sizeof(double)));
-  HIPCHK(h, hipMemcpyAsync(h->dV, h->dR, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, st));
-  BLASCHK(h, rocsolver_dtrtri(h->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, N, h->dV, N, h->dinfo));
+  const int ldr = h->ldr;
   if (!h->dVp) HIPCHK(h, hipMalloc((void**)&h->dVp, (size_t)Np * Np * sizeof(double)));
-  HIPCHK(h, launch_pack_V(h->dV, N, N, Np, h->dVp, st));
+  HIPCHK(h, launch_pack_V(h->dV, N, ldr, Np, h->dVp, st));
   // w = L^-T Ft  (so that Ft^T L^-1 r = w . r, gpr.py:496-498)
   HIPCHK(h, hipMemsetAsync(h->dw, 0, Np * sizeof(double), st));
   if (estimate_trend) {
-    HIPCHK(h, hipMemcpyAsync(h->dw, h->dft, N * sizeof(double), hipMemcpyDeviceToDevice, st));
-    BLASCHK(h, rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, h->dR, N, h->dw, 1));
+    const double one = 1.0, zero = 0.0;
+    BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, N, N, &one, h->dU, ldr, h->dft, 1, &zero, h->dw, 1));
   }
   if (!h->dXthT) HIPCHK(h, hipMalloc((void**)&h->dXthT, (size_t)d * Np * sizeof(double)));
   HIPCHK(h, launch_scale_transpose(h->dX, N, d, Np, h->dsqrt_theta, h->dXthT, st));
   HIPCHK(h, hipStreamSynchronize(st));
-  rocblas_int info = 0;
-  HIPCHK(h, hipMemcpy(&info, h->dinfo, sizeof(info), hipMemcpyDeviceToHost));
-  if (info != 0) FAIL(h, BOGP_ERR_NOT_POSDEF, "trtri failed (info = %d)", (int)info);
   h->kernel = kernel; h->mode = mode; h->estimate_trend = estimate_trend;
   h->beta = o.beta; h->G = o.G; h->sigma2 = o.sigma2; h->noise_var = o.noise_var; h->llf = o.llf; h->ftft = o.ftft;
   h->committed = true;
@@ -415,8 +418,8 @@ extern "C" int bogp_get_state(bogp_handle* h, double* C, double* gamma, double* 
   hipStream_t st = h->stream;
   HIPCHK(h, hipSetDevice(h->device));
   if (C) {
-    if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)N * N * sizeof(double)));
-    HIPCHK(h, launch_copy_lower(h->dR, N, N, h->dRinv, st));
+    if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)h->ldr * h->ldr * sizeof(double)));
+    HIPCHK(h, launch_copy_lower(h->dR, N, h->ldr, h->dRinv, st));
     HIPCHK(h, hipMemcpyAsync(C, h->dRinv, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, st));
   }
   if (gamma) HIPCHK(h, hipMemcpyAsync(gamma, h->dgamma, N * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -560,7 +563,7 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
       if ((e2 = ensure(h, &h->dacq_out, &h->acq_out_cap, (size_t)q * M))) return e2;
     HIPCHK(h, launch_batch_corr(h->kernel, h->dX, N, d, h->dtheta, h->dXs, B, dr, ds2, st));
     const double one = 1.0;
-    BLASCHK(h, rocblas_dtrmm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, B, &one, h->dV, N, dr, N, drt, N));
+    BLASCHK(h, rocblas_dtrmm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, B, &one, h->dV, h->ldr, dr, N, drt, N));
     HIPCHK(h, launch_col_reduce(dr, drt, N, B, h->dgamma, h->dw, dred, dred + B, dred + 2 * B, st));
     AcqArgs aa;
     memset(&aa, 0, sizeof(aa));
@@ -772,8 +775,8 @@ extern "C" int bogp_gradient(bogp_handle* h, const double* x, double* dmu, doubl
   // z = L^-T L^-1 r = V^T (V r) with the explicit V = L^-1 kept from the commit: two triangular matrix-vector
   // products (bandwidth bound, ~50 us at N = 2048) instead of two dependent triangular solves (~350 us each)
   HIPCHK(h, hipMemcpyAsync(dz, dr, N * sizeof(double), hipMemcpyDeviceToDevice, st));
-  BLASCHK(h, rocblas_dtrmv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, h->dV, N, dz, 1));
-  BLASCHK(h, rocblas_dtrmv(h->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, h->dV, N, dz, 1));
+  BLASCHK(h, rocblas_dtrmv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, h->dV, h->ldr, dz, 1));
+  BLASCHK(h, rocblas_dtrmv(h->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, h->dV, h->ldr, dz, 1));
   const double one = 1.0, zero = 0.0;
   BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, h->dgamma, 1, &zero, dout, 1));
   BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, dz, 1, &zero, dout + d, 1));
@@ -815,8 +818,8 @@ extern "C" int bogp_gradient_batch(bogp_handle* h, const double* Xb, int B, doub
   HIPCHK(h, launch_batch_corr(h->kernel, h->dX, N, d, h->dtheta, dXb, B, dr, ds2, st));
   HIPCHK(h, hipMemcpyAsync(dZ, dr, (size_t)N * B * sizeof(double), hipMemcpyDeviceToDevice, st));
   const double one = 1.0;
-  BLASCHK(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, B, &one, h->dR, N, dZ, N));
-  BLASCHK(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, B, &one, h->dR, N, dZ, N));
+  BLASCHK(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, B, &one, h->dR, h->ldr, dZ, N));
+  BLASCHK(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, B, &one, h->dR, h->ldr, dZ, N));
   HIPCHK(h, launch_batch_grad(h->kernel, h->dX, N, d, h->dtheta, dXb, B, dr, ds2, dZ, h->dgamma, h->dw, dout, st));
   std::vector<double> out(nout);
   HIPCHK(h, hipMemcpyAsync(out.data(), dout, nout * sizeof(double), hipMemcpyDeviceToHost, st));

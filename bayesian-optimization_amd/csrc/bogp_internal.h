@@ -85,6 +85,11 @@ hipError_t launch_scale_transpose(const double* X, int N, int d, int Np, const d
                                   hipStream_t st);
 hipError_t launch_pack_V(const double* Vcm, int N, int ld, int Np, double2* Vp, hipStream_t st);
 hipError_t launch_logdet(const double* L, int N, int ld, double* out, hipStream_t st);
+// kernels_chol.hip: in-place lower Cholesky of a column-major matrix whose ld is a multiple of 64 (identity padded)
+hipError_t launch_pad_identity(double* A, int N, int ld, hipStream_t st);
+hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStream_t st);
+hipError_t launch_tri_inverse(const double* L, const double* Winv, double* V, double* U, double* T, int ld, hipStream_t st);
+hipError_t launch_uut(const double* U, double* Rinv, int ld, hipStream_t st);
 hipError_t launch_copy_lower(const double* L, int N, int ld, double* dst, hipStream_t st);
 hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const double* theta, const double* gamma,
                                 double c1, const double* Rinv, int ld, double* partial, int nblk, hipStream_t st);

@@ -223,8 +223,10 @@ class GaussianProcess:
                 if not eval_grad:
                     return llf
             out = self.engine.nll(self.kernel_id, mode, par, self._nv(), est, beta, eval_grad=eval_grad)
-            if env is not None and eval_grad:
-                self._committed_par = None  # nll overwrote the factor buffers
+            if self._committed_par is not None:
+                # nll overwrote the factor buffers of the committed model: restore it, so that (as in the reference)
+                # evaluating the likelihood of a fitted model leaves predict() / gradient() untouched
+                self._commit(self._committed_par, refresh_attributes=False)
             return out
         except _lib.NotPositiveDefinite:
             # Cholesky failure or llf > 0: the reference's -inf convention (gpr.py:946-947, 981-982)
