@@ -34,6 +34,8 @@ struct bogp_handle {
   // factorisation workspace (column-major, ld = ldr)
   double *dR = nullptr, *dV = nullptr, *dU = nullptr, *dT = nullptr, *dRinv = nullptr;  // L, L^-1, L^-T, scratch, R^-1
   double* dones = nullptr;  // N ones (the constant trend basis)
+  double* dgemv_scratch = nullptr;  // segment partials of launch_gemv2
+  std::vector<double> h_theta, h_sqrt_theta;
   double* ddinv = nullptr;  // ldr x 64: inverses of the diagonal blocks of the running factorisation (kernels_chol.hip)
   double *dyt = nullptr, *dft = nullptr, *drho = nullptr, *dtmp = nullptr;  // N each
   double *dgamma = nullptr, *dw = nullptr;                                  // Np each (zero padded)
@@ -153,7 +155,7 @@ extern "C" int bogp_create(int device, bogp_handle** out) {
 }
 
 static void free_train(bogp_handle* h) {
-  dfree(h->dX); dfree(h->dy); dfree(h->dR); dfree(h->dV); dfree(h->dU); dfree(h->dT); dfree(h->dRinv); dfree(h->ddinv); dfree(h->dones);
+  dfree(h->dX); dfree(h->dy); dfree(h->dR); dfree(h->dV); dfree(h->dU); dfree(h->dT); dfree(h->dRinv); dfree(h->ddinv); dfree(h->dones); dfree(h->dgemv_scratch);
   dfree(h->dyt); dfree(h->dft); dfree(h->drho); dfree(h->dtmp); dfree(h->dgamma); dfree(h->dw);
   dfree(h->dtheta); dfree(h->dsqrt_theta); dfree(h->dXthT); dfree(h->dVp);
   h->committed = false;
@@ -203,6 +205,7 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
   {
     std::vector<double> ones(N, 1.0);
     HIPCHK(h, hipMalloc((void**)&h->dones, N * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dgemv_scratch, gemv2_scratch_doubles(N) * sizeof(double)));
     HIPCHK(h, hipMemcpy(h->dones, ones.data(), N * sizeof(double), hipMemcpyHostToDevice));
   }
   HIPCHK(h, hipMalloc((void**)&h->dyt, N * sizeof(double)));
@@ -235,7 +238,10 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   const int N = h->N, d = h->d, ldr = h->ldr;
   const int n_theta = n_par - (mode == BOGP_MODE_NOISELESS ? 0 : 1);
   if (n_theta != d && n_theta != 1) FAIL(h, BOGP_ERR_INVALID, "len(theta) = %d must be 1 or d = %d", n_theta, d);
-  std::vector<double> th(d), sth(d);
+  std::vector<double>& th = h->h_theta;  // handle-owned: the asynchronous uploads below outlive this scope
+  std::vector<double>& sth = h->h_sqrt_theta;
+  th.resize(d);
+  sth.resize(d);
   for (int k = 0; k < d; ++k) {
     th[k] = par[n_theta == 1 ? 0 : k];
     if (!(th[k] > 0) || !std::isfinite(th[k])) FAIL(h, BOGP_ERR_INVALID, "theta[%d] = %g must be finite and > 0", k, th[k]);
@@ -247,7 +253,6 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(h->dtheta, th.data(), d * sizeof(double), hipMemcpyHostToDevice, st));
   HIPCHK(h, hipMemcpyAsync(h->dsqrt_theta, sth.data(), d * sizeof(double), hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipStreamSynchronize(st));  // th/sth are stack vectors
 
   // correlation matrix with the per-mode normalisation (gpr.py:931-969)
   double s2t = 0, alpha = 0, sigma2_par = 0;
@@ -262,46 +267,39 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
     HIPCHK(h, launch_build_R_div(kernel, h->dX, N, d, h->dtheta, sigma2_par, s2t, (sigma2_par * 1.0 + noise_var * 1.0) / s2t,
                                  h->dR, ldr, st));
   }
-  // L = chol(R) (gpr.py:795)
+  // The whole evaluation is queued without a host round trip and read back once:
+  //   L = chol(R) (gpr.py:795)                      kernels_chol.hip
+  //   V = L^-1, U = L^-T                            every triangular solve of :799-808 / :787-788 / :997 becomes a product
+  //   Yt = V y (:799), Ft = V 1 (:803)              one pass over V
+  //   rho (:806 / :808), |Ft|, Ft.Yt, rho.rho       k_fit_rho
+  //   gamma = U rho (:788 / :996)
   HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st));
-  rocblas_int info = 0;
-  HIPCHK(h, hipMemcpyAsync(&info, h->dinfo, sizeof(info), hipMemcpyDeviceToHost, st));
   HIPCHK(h, launch_logdet(h->dR, N, ldr, h->dscal, st));
-  // V = L^-1, U = L^-T: every triangular solve of gpr.py:795-808 / :787-788 / :997 becomes a product with V or U
   HIPCHK(h, launch_tri_inverse(h->dR, h->ddinv, h->dV, h->dU, h->dT, ldr, st));
-  const double one = 1.0, zero = 0.0;
-  // Yt = L^-1 y (:799)
-  BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, N, N, &one, h->dV, ldr, h->dy, 1, &zero, h->dyt, 1));
+  HIPCHK(h, launch_gemv2(h->dV, ldr, N, 1, h->dy, h->dones, h->dyt, h->dft, h->dgemv_scratch, st));
+  HIPCHK(h, launch_fit_rho(h->dyt, h->dft, N, estimate_trend, beta, h->drho, h->dscal, st));
+  if (want_gamma) {
+    HIPCHK(h, hipMemsetAsync(h->dgamma, 0, h->Np * sizeof(double), st));
+    HIPCHK(h, launch_gemv2(h->dU, ldr, N, 2, h->drho, nullptr, h->dgamma, nullptr, h->dgemv_scratch, st));
+  }
+  rocblas_int info = 0;
+  double sc[4] = {0, 0, 0, 0};  // sum(log diag L), |Ft|, Ft.Yt, rho.rho
+  HIPCHK(h, hipMemcpyAsync(&info, h->dinfo, sizeof(info), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(sc, h->dscal, sizeof(sc), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   if (info != 0) FAIL(h, BOGP_ERR_NOT_POSDEF, "correlation matrix is not positive definite (potrf info = %d)", (int)info);
 
+  const double logdet = sc[0], rho_ss = sc[3];
   double ftyt = 0, ftft = 0, G = 0, beta_eff = beta;
   if (estimate_trend) {
-    // Ft = L^-1 F, F = ones (constant trend); economic QR of a single column: G = -sign(Ft[0]) |Ft|, Q = Ft / G (:803-806)
-    BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, N, N, &one, h->dV, ldr, h->dones, 1, &zero, h->dft, 1));
-    double nrm = 0;
-    BLASCHK(h, rocblas_dnrm2(h->blas, N, h->dft, 1, &nrm));
-    BLASCHK(h, rocblas_ddot(h->blas, N, h->dft, 1, h->dyt, 1, &ftyt));
-    HIPCHK(h, hipStreamSynchronize(st));
-    G = -nrm;  // Ft[0] = 1 / L[0][0] > 0
+    // economic QR of the single column Ft: G = -sign(Ft[0]) |Ft|, Ft[0] = 1 / L[0][0] > 0 (:803-806)
+    const double nrm = sc[1];
+    ftyt = sc[2];
+    G = -nrm;
     ftft = nrm * nrm;
     const double qty = ftyt / G;  // Q^T Yt
-    // rho = Yt - Q (Q^T Yt)
-    HIPCHK(h, hipMemcpyAsync(h->drho, h->dyt, N * sizeof(double), hipMemcpyDeviceToDevice, st));
-    const double coef = -(qty / G);
-    BLASCHK(h, rocblas_daxpy(h->blas, N, &coef, h->dft, 1, h->drho, 1));
-    beta_eff = qty / G;  // beta = G^-1 Q^T Yt (:785-787)
-  } else {
-    HIPCHK(h, hipMemcpyAsync(h->drho, h->dyt, N * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if (beta != 0.0) {  // rho = Yt - L^-1 (beta * 1) (:808)
-      const double mbeta = -beta;  // rho -= V (beta 1)
-      BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, N, N, &mbeta, h->dV, ldr, h->dones, 1, &one, h->drho, 1));
-    }
+    beta_eff = qty / G;           // beta = G^-1 Q^T Yt (:785-787)
   }
-  double rho_ss = 0, logdet = 0;
-  BLASCHK(h, rocblas_ddot(h->blas, N, h->drho, 1, h->drho, 1, &rho_ss));
-  HIPCHK(h, hipMemcpyAsync(&logdet, h->dscal, sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
 
   const double TWO_PI = 2.0 * 3.141592653589793;
   double llf, sigma2, nv;
@@ -325,10 +323,6 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   o->llf = llf; o->sigma2 = sigma2; o->noise_var = nv; o->s2t = s2t; o->G = G; o->beta = beta_eff; o->ftyt = ftyt; o->ftft = ftft;
   if (llf > 0) FAIL(h, BOGP_ERR_LLF_POSITIVE, "log-likelihood %g > 0 is rejected by the reference (gpr.py:981-982)", llf);
 
-  if (want_gamma) {  // gamma = L^-T rho (:788 / :996)
-    HIPCHK(h, hipMemsetAsync(h->dgamma, 0, h->Np * sizeof(double), st));
-    BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, N, N, &one, h->dU, ldr, h->drho, 1, &zero, h->dgamma, 1));
-  }
   return BOGP_OK;
 }
 
@@ -349,23 +343,20 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
   hipStream_t st = h->stream;
   // R^-1 = cho_solve(L, I) (:997) via potri on a copy of L
   const int ldr = h->ldr;
-  if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)ldr * ldr * sizeof(double)));
+  if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * ldr * ldr * sizeof(double)));
   HIPCHK(h, launch_uut(h->dU, h->dRinv, ldr, st));  // R^-1 = L^-T L^-1, lower triangle
   const int nblk = grad_contract_blocks(N);
-  int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)nblk * (d + 1) + (d + 1));
+  int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)nblk * (d + 1) + (d + 3));
   if (e) return e;
   const double c1 = 1.0 / (mode == BOGP_MODE_NOISELESS ? o.sigma2 : o.s2t);
-  HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, h->dgamma, c1, h->dRinv, ldr, h->dgrad_partial, nblk, st));
+  HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, h->dgamma, c1, h->dRinv, ldr, UUT_PARTS, (size_t)ldr * ldr, h->dgrad_partial, nblk, st));
   double* dS = h->dgrad_partial + (size_t)nblk * (d + 1);
   HIPCHK(h, launch_grad_reduce(h->dgrad_partial, nblk, d + 1, dS, st));
-  std::vector<double> S(d + 1);
-  HIPCHK(h, hipMemcpyAsync(S.data(), dS, (d + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
-  double tr = 0, gg = 0;
-  if (mode == BOGP_MODE_NOISY) {
-    BLASCHK(h, rocblas_dasum(h->blas, N, h->dRinv, ldr + 1, &tr));  // trace: the diagonal of an SPD inverse is positive
-    BLASCHK(h, rocblas_ddot(h->blas, N, h->dgamma, 1, h->dgamma, 1, &gg));
-  }
+  std::vector<double> S(d + 3);
+  if (mode == BOGP_MODE_NOISY) HIPCHK(h, launch_trace_gg(h->dRinv, ldr, UUT_PARTS, (size_t)ldr * ldr, N, h->dgamma, dS + d + 1, st));
+  HIPCHK(h, hipMemcpyAsync(S.data(), dS, (d + 3) * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
+  const double tr = S[d + 1], gg = S[d + 2];
   if (mode == BOGP_MODE_NOISELESS) {
     for (int k = 0; k < d; ++k) grad[k] = S[k];
   } else if (mode == BOGP_MODE_NOISE_ESTIM) {
@@ -398,8 +389,7 @@ extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* p
   // w = L^-T Ft  (so that Ft^T L^-1 r = w . r, gpr.py:496-498)
   HIPCHK(h, hipMemsetAsync(h->dw, 0, Np * sizeof(double), st));
   if (estimate_trend) {
-    const double one = 1.0, zero = 0.0;
-    BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, N, N, &one, h->dU, ldr, h->dft, 1, &zero, h->dw, 1));
+    HIPCHK(h, launch_gemv2(h->dU, ldr, N, 2, h->dft, nullptr, h->dw, nullptr, h->dgemv_scratch, st));
   }
   if (!h->dXthT) HIPCHK(h, hipMalloc((void**)&h->dXthT, (size_t)d * Np * sizeof(double)));
   HIPCHK(h, launch_scale_transpose(h->dX, N, d, Np, h->dsqrt_theta, h->dXthT, st));
@@ -418,7 +408,7 @@ extern "C" int bogp_get_state(bogp_handle* h, double* C, double* gamma, double* 
   hipStream_t st = h->stream;
   HIPCHK(h, hipSetDevice(h->device));
   if (C) {
-    if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)h->ldr * h->ldr * sizeof(double)));
+    if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * h->ldr * h->ldr * sizeof(double)));
     HIPCHK(h, launch_copy_lower(h->dR, N, h->ldr, h->dRinv, st));
     HIPCHK(h, hipMemcpyAsync(C, h->dRinv, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, st));
   }

@@ -78,27 +78,28 @@ __device__ __forceinline__ void mma_64(const double* lds, const double (&bv)[16]
 }
 
 // ---- diagonal block: Cholesky factor and its inverse, blocked by 4 columns -----------------------------------------
-// Thread (tr, tc) = (tid >> 4, tid & 15) owns rows 4 tr .. 4 tr + 3, columns 4 tc .. 4 tc + 3 of the block (a) and of
-// W = L^-1 (w).  Block step jb (columns 4 jb .. 4 jb + 3), two barriers:
-//   A  thread (jb, jb) factors its 4x4 block in registers and inverts the 4x4 factor (M), publishes M
-//   B  column owners (tc == jb, tr > jb):  a <- a M^T  (final L);    row owners (tr == jb, tc <= jb):  w <- M w  (final W);
-//      both publish their 4x4 (strip of L: 64 x 4, block row of W: 4 x 64)
-//   C  threads below (tr > jb):  a -= Lr Lc^T  (tc > jb)   or   w -= Lr Wr  (tc <= jb):  64 FMAs on 4x4 register tiles
-// cs: 64 x 65 staging of the input block; sb: 16 (M) + 256 (strip) + 256 (block row of W) doubles.
-// Returns 0 or 1 + the first column with a non-positive pivot (LAPACK's info), uniformly over the workgroup.
-constexpr int DIAG_SB = 16 + 2 * 4 * CB + 2;
-__device__ __forceinline__ int diag_factor_invert(const double* cs, double* sb, double (&a)[4][4], double (&w)[4][4], int tid) {
+// Thread (tr, tc) = (tid >> 4, tid & 15) owns ONE 4x4 register tile z of the symmetric block (rows 4 tr.., columns
+// 4 tc..; both triangles are kept).  With M = (4x4 diagonal factor)^-1 of block step jb, the block row
+//     Y = M z(jb, :)                                            (published by the 16 threads tr == jb)
+// is at the same time the strip of L (L[4 tc + c][4 jb + k] = Y[k][4 tc + c] for tc > jb, by symmetry) and, left of the
+// diagonal, the final block row of W = L^-1 -- so every thread below applies the SAME update z -= lr yc with
+// lr[i][k] = Y[k][4 tr + i], yc[k][c] = Y[k][4 tc + c], whether its tile still belongs to the trailing block (tc > jb) or
+// already accumulates W (tc <= jb; the tile switches role at jb == tc, where lr is its final piece of L).
+// Two barriers per 4 columns; the serial part is the diagonal thread's 4x4 potf2 + inverse.
+// cs: 64 x 65 staging of the input block; sb: DIAG_SB doubles.  On return `lo` holds the L tile (tc <= tr) and z the
+// W tile (tc <= tr).  Returns 0 or 1 + the first column with a non-positive pivot (LAPACK's info), workgroup-uniform.
+constexpr int DIAG_SB = 16 + 4 * CB + 2;
+__device__ __forceinline__ int diag_factor_invert(const double* cs, double* sb, double (&lo)[4][4], double (&z)[4][4], int tid) {
   const int tr = tid >> 4, tc = tid & 15;
-  double* mini = sb;             // [4][4] row-major, lower
-  double* strip = sb + 16;       // [64][4]
-  double* wrow = sb + 16 + 256;  // [4][64]
-  double* flag = sb + 16 + 512;  // 1 + first bad column (as a double), 0 if none
+  double* mini = sb;            // [4][4] row-major, lower
+  double* Y = sb + 16;          // [4][64]
+  double* flag = sb + 16 + 256; // 1 + first bad column (as a double), 0 if none
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      a[i][c] = cs[(4 * tr + i) * (CB + 1) + 4 * tc + c];
-      w[i][c] = 0.0;
+      z[i][c] = cs[(4 * tr + i) * (CB + 1) + 4 * tc + c];
+      lo[i][c] = 0.0;
     }
   if (tid == 0) flag[0] = 0.0;
   for (int jb = 0; jb < 16; ++jb) {
@@ -108,7 +109,7 @@ __device__ __forceinline__ int diag_factor_invert(const double* cs, double* sb, 
       int bad = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        double piv = a[j][j];
+        double piv = z[j][j];
         if (!(piv > 0.0)) {
           if (bad == 0) bad = 4 * jb + j + 1;
           piv = 1.0;
@@ -119,11 +120,11 @@ __device__ __forceinline__ int diag_factor_invert(const double* cs, double* sb, 
         l[j][j] = sq;
         iv[j] = inv;
 #pragma unroll
-        for (int i = j + 1; i < 4; ++i) l[i][j] = a[i][j] * inv;
+        for (int i = j + 1; i < 4; ++i) l[i][j] = z[i][j] * inv;
 #pragma unroll
         for (int i = j + 1; i < 4; ++i)
 #pragma unroll
-          for (int c = j + 1; c <= i; ++c) a[i][c] = __builtin_fma(-l[i][j], l[c][j], a[i][c]);
+          for (int c = j + 1; c <= i; ++c) z[i][c] = __builtin_fma(-l[i][j], l[c][j], z[i][c]);
       }
       // M = l^-1 (lower), by forward substitution on the identity
       double mm[4][4];
@@ -147,86 +148,60 @@ __device__ __forceinline__ int diag_factor_invert(const double* cs, double* sb, 
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          a[i][c] = c <= i ? l[i][c] : 0.0;
-          w[i][c] = mm[i][c];
+          lo[i][c] = c <= i ? l[i][c] : 0.0;
+          z[i][c] = mm[i][c];
           mini[4 * i + c] = mm[i][c];
-          wrow[i * CB + 4 * tc + c] = mm[i][c];
+          Y[i * CB + 4 * tc + c] = mm[i][c];
         }
       if (bad != 0 && flag[0] == 0.0) flag[0] = (double)bad;
     }
     __syncthreads();
-    // ---- B: strip of L and block row of W ----------------------------------------------------------------
-    if (tc == jb && tr > jb) {
-      double x[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          double sacc = 0.0;
-#pragma unroll
-          for (int k = 0; k <= c; ++k) sacc = __builtin_fma(a[i][k], mini[4 * c + k], sacc);
-          x[i][c] = sacc;
-        }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          a[i][c] = x[i][c];
-          strip[(4 * tr + i) * 4 + c] = x[i][c];
-        }
-    }
+    // ---- B: block row Y = M z(jb, :) ---------------------------------------------------------------------
     if (tr == jb && tc != jb) {
-      double x[4][4];
+      double y[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           double sacc = 0.0;
 #pragma unroll
-          for (int k = 0; k <= i; ++k) sacc = __builtin_fma(mini[4 * i + k], w[k][c], sacc);
-          x[i][c] = tc < jb ? sacc : 0.0;
+          for (int k = 0; k <= i; ++k) sacc = __builtin_fma(mini[4 * i + k], z[k][c], sacc);
+          y[i][c] = sacc;
         }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          w[i][c] = x[i][c];
-          wrow[i * CB + 4 * tc + c] = x[i][c];
+          z[i][c] = y[i][c];
+          Y[i * CB + 4 * tc + c] = y[i][c];
         }
     }
     __syncthreads();
-    // ---- C: rank-4 updates below the block row -----------------------------------------------------------
+    // ---- C: rank-4 update of every tile below the block row ----------------------------------------------
     if (tr > jb) {
-      double lr[4][4];
+      double lr[4][4], yc[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          lr[i][k] = Y[k * CB + 4 * tr + i];
+          yc[k][i] = Y[k * CB + 4 * tc + i];
+        }
+      if (tc == jb) {  // this tile's piece of L is final; from here on the registers accumulate W
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            lo[i][k] = lr[i][k];
+            z[i][k] = 0.0;
+          }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) lr[i][k] = strip[(4 * tr + i) * 4 + k];
-      if (tc > jb) {
-        double lc[4][4];
-#pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int k = 0; k < 4; ++k) lc[c][k] = strip[(4 * tc + c) * 4 + k];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) a[i][c] = __builtin_fma(-lr[i][k], lc[c][k], a[i][c]);
-      } else {
-        double wr[4][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) wr[k][c] = wrow[k * CB + 4 * tc + c];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) w[i][c] = __builtin_fma(-lr[i][k], wr[k][c], w[i][c]);
-      }
+          for (int k = 0; k < 4; ++k) z[i][c] = __builtin_fma(-lr[i][k], yc[k][c], z[i][c]);
     }
   }
   __syncthreads();
@@ -243,7 +218,7 @@ __device__ __forceinline__ void diag_store(double* __restrict__ Ad /* &A[i0 + i0
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * tr + i, col = 4 * tc + c;
       if (r >= col) Ad[(size_t)col * ld + r] = a[i][c];
-      Wk[col * CB + r] = r >= col ? w[i][c] : 0.0;
+      Wk[col * CB + r] = tc <= tr ? w[i][c] : 0.0;  // W tiles carry their own zeros above the diagonal
     }
 }
 
@@ -375,9 +350,12 @@ __global__ __launch_bounds__(256) void k_tri_gemm(TriArgs a, int mode0) {
     if (bj > bi) return;
     Bs = a.U + (size_t)bi * CB;
     As = a.U + (size_t)bj * CB;
-    out = a.Rinv + (size_t)bi * CB + (size_t)bj * CB * ld;
-    kb0 = bi;
-    kb1 = a.nb;
+    // K-slice blockIdx.y of UUT_PARTS: the k-blocks [bi, nb) of a tile are long for small bi (one workgroup would walk
+    // all nb of them); slices go to separate matrices that the consumers add, so the result stays deterministic
+    const int per = (a.nb + UUT_PARTS - 1) / UUT_PARTS;
+    out = a.Rinv + (size_t)blockIdx.y * ld * ld + (size_t)bi * CB + (size_t)bj * CB * ld;
+    kb0 = max(bi, (int)blockIdx.y * per);
+    kb1 = min(a.nb, ((int)blockIdx.y + 1) * per);
     alpha = 1.0;
   } else {
     const int nbb = 1 << a.level;
@@ -417,6 +395,8 @@ __global__ __launch_bounds__(256) void k_tri_gemm(TriArgs a, int mode0) {
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[mi][t] = 0.0;
+  // no explicit software pipeline: prefetching the next k-block into registers (measured) costs 222 VGPRs, halves the
+  // occupancy and makes the launch 1.5x slower -- four resident workgroups per CU hide the load latency better
   for (int kb = kb0; kb < kb1; ++kb) {
     const size_t koff = (size_t)kb * CB * ld;
     __syncthreads();  // the previous tile has been consumed
@@ -461,11 +441,11 @@ hipError_t launch_tri_inverse(const double* L, const double* Winv, double* V, do
   return hipGetLastError();
 }
 
-// Rinv (lower triangle, full diagonal tiles) = U U^T = L^-T L^-1
+// sum of the UUT_PARTS slices at Rinv + q*ld*ld (lower triangle, full diagonal tiles) = U U^T = L^-T L^-1
 hipError_t launch_uut(const double* U, double* Rinv, int ld, hipStream_t st) {
   const int nb = ld / CB;
   TriArgs a{nullptr, nullptr, const_cast<double*>(U), nullptr, Rinv, ld, nb, 0};
-  hipLaunchKernelGGL(k_tri_gemm, dim3(nb * nb, 1, 1), 256, 0, st, a, (int)TG_UUT);
+  hipLaunchKernelGGL(k_tri_gemm, dim3(nb * nb, UUT_PARTS, 1), 256, 0, st, a, (int)TG_UUT);
   return hipGetLastError();
 }
 

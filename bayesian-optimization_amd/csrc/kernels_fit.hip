@@ -16,7 +16,9 @@ namespace bogp {
 template <int KERNEL>
 __global__ __launch_bounds__(256) void k_build_R(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
                                                  double off_scale, double diag, double* __restrict__ R, int ld) {
-  // 16x16 tile per workgroup; both triangles are written (exactly symmetric: (a-b)^2 == (b-a)^2)
+  // 16x16 tile per workgroup; exactly symmetric where both triangles are written: (a-b)^2 == (b-a)^2
+  // only the lower triangle and the (full, symmetric) 64 x 64 diagonal blocks are consumed (kernels_chol.hip)
+  if (blockIdx.y < blockIdx.x && (blockIdx.y >> 2) != (blockIdx.x >> 2)) return;
   const int i = blockIdx.y * 16 + (threadIdx.x >> 4);
   const int j = blockIdx.x * 16 + (threadIdx.x & 15);
   if (i >= N || j >= N) return;
@@ -38,6 +40,8 @@ template <int KERNEL>
 __global__ __launch_bounds__(256) void k_build_R_div(const double* __restrict__ X, int N, int d,
                                                      const double* __restrict__ theta, double mul, double div,
                                                      double diag, double* __restrict__ R, int ld) {
+  // only the lower triangle and the (full, symmetric) 64 x 64 diagonal blocks are consumed (kernels_chol.hip)
+  if (blockIdx.y < blockIdx.x && (blockIdx.y >> 2) != (blockIdx.x >> 2)) return;
   const int i = blockIdx.y * 16 + (threadIdx.x >> 4);
   const int j = blockIdx.x * 16 + (threadIdx.x & 15);
   if (i >= N || j >= N) return;
@@ -126,6 +130,134 @@ hipError_t launch_logdet(const double* L, int N, int ld, double* out, hipStream_
   return hipGetLastError();
 }
 
+// ---- matrix-vector products with V = L^-1 / U = L^-T (what the reference's triangular solves become) --------------
+// y0 = M x0 and y1 = M x1 (x1 / y1 may be null) for a column-major N x N matrix M that is lower (tri = 1: columns <= row)
+// or upper (tri = 2: columns >= row) triangular with explicit zeros elsewhere.  Stage 1: grid (row blocks of 64,
+// column segments of 256) -> part[seg][rhs][row]; stage 2 adds the segments in a fixed order (deterministic).
+constexpr int GV_SEG = 256;
+__global__ __launch_bounds__(256) void k_gemv2_part(const double* __restrict__ M, int ld, int N, int Nr, int tri,
+                                                    const double* __restrict__ x0, const double* __restrict__ x1,
+                                                    double* __restrict__ part) {
+  __shared__ double red[2][4][64];
+  const int tid = threadIdx.x, rl = tid & 63, cg = tid >> 6;
+  const int rb = blockIdx.x * 64, seg = blockIdx.y;
+  const int c0 = seg * GV_SEG, c1 = min(N, c0 + GV_SEG);
+  const int row = rb + rl;
+  double a0 = 0.0, a1 = 0.0;
+  const bool live = tri == 1 ? (c0 <= rb + 63) : (tri == 2 ? (c1 - 1 >= rb) : true);
+  if (live && row < N) {
+    const double* m = M + row;
+#pragma unroll 8
+    for (int c = c0 + cg; c < c1; c += 4) {
+      const double v = m[(size_t)c * ld];
+      a0 = __builtin_fma(v, x0[c], a0);
+      if (x1) a1 = __builtin_fma(v, x1[c], a1);
+    }
+  }
+  red[0][cg][rl] = a0;
+  red[1][cg][rl] = a1;
+  __syncthreads();
+  if (tid < 128) {
+    const int r = tid >> 6, q = tid & 63;
+    part[((size_t)seg * 2 + r) * Nr + rb + q] = ((red[r][0][q] + red[r][1][q]) + red[r][2][q]) + red[r][3][q];
+  }
+}
+__global__ void k_gemv2_sum(const double* __restrict__ part, int nseg, int Nr, int N, double* __restrict__ y0, double* __restrict__ y1) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= N) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int sg = 0; sg < nseg; ++sg) {
+    s0 += part[((size_t)sg * 2 + 0) * Nr + row];
+    if (y1) s1 += part[((size_t)sg * 2 + 1) * Nr + row];
+  }
+  y0[row] = s0;
+  if (y1) y1[row] = s1;
+}
+size_t gemv2_scratch_doubles(int N) {
+  const int nrb = (N + 63) / 64, nseg = (N + GV_SEG - 1) / GV_SEG;
+  return (size_t)nseg * 2 * nrb * 64;
+}
+hipError_t launch_gemv2(const double* M, int ld, int N, int tri, const double* x0, const double* x1, double* y0, double* y1,
+                        double* scratch, hipStream_t st) {
+  const int nrb = (N + 63) / 64, nseg = (N + GV_SEG - 1) / GV_SEG, Nr = nrb * 64;
+  hipLaunchKernelGGL(k_gemv2_part, dim3(nrb, nseg), 256, 0, st, M, ld, N, Nr, tri, x0, x1, scratch);
+  hipLaunchKernelGGL(k_gemv2_sum, dim3((N + 255) / 256), 256, 0, st, scratch, nseg, Nr, N, y0, y1);
+  return hipGetLastError();
+}
+
+// ---- rho and the scalars of the concentrated likelihood, on the device (gpr.py:803-808 for p = 1) --------------------
+// Ordinary kriging: economic QR of the single column Ft: G = -|Ft|, Q = Ft / G, rho = Yt - Q (Q^T Yt);
+// simple kriging: rho = Yt - beta Ft (Ft = L^-1 1).  scal[1] = |Ft|, scal[2] = Ft . Yt, scal[3] = rho . rho.
+__device__ __forceinline__ double block_sum_1024(double v, double* red /* [16] */) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) s += red[wv];
+  return s;
+}
+__global__ __launch_bounds__(1024) void k_fit_rho(const double* __restrict__ Yt, const double* __restrict__ Ft, int N,
+                                                  int estimate_trend, double beta, double* __restrict__ rho,
+                                                  double* __restrict__ scal) {
+  __shared__ double red[16];
+  double sff = 0.0, sfy = 0.0;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    const double f = Ft[i];
+    sff = __builtin_fma(f, f, sff);
+    sfy = __builtin_fma(f, Yt[i], sfy);
+  }
+  sff = block_sum_1024(sff, red);
+  sfy = block_sum_1024(sfy, red);
+  const double nrm = sqrt(sff);
+  double coef;
+  if (estimate_trend) {
+    const double G = -nrm, qty = sfy / G;
+    coef = -(qty / G);
+  } else {
+    coef = -beta;
+  }
+  double srr = 0.0;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    const double r = __builtin_fma(coef, Ft[i], Yt[i]);
+    rho[i] = r;
+    srr = __builtin_fma(r, r, srr);
+  }
+  srr = block_sum_1024(srr, red);
+  if (threadIdx.x == 0) {
+    scal[1] = nrm;
+    scal[2] = sfy;
+    scal[3] = srr;
+  }
+}
+hipError_t launch_fit_rho(const double* Yt, const double* Ft, int N, int estimate_trend, double beta, double* rho, double* scal,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(k_fit_rho, dim3(1), 1024, 0, st, Yt, Ft, N, estimate_trend, beta, rho, scal);
+  return hipGetLastError();
+}
+
+// out[0] = trace(Rinv), out[1] = gamma . gamma   (the sigma2 derivative of the NOISY likelihood, gpr.py:1030-1036)
+__global__ __launch_bounds__(1024) void k_trace_gg(const double* __restrict__ Rinv, int ld, int nparts, size_t part_stride, int N,
+                                                   const double* __restrict__ gamma, double* __restrict__ out) {
+  __shared__ double red[16];
+  double tr = 0.0, gg = 0.0;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    for (int q = 0; q < nparts; ++q) tr += Rinv[q * part_stride + (size_t)i * ld + i];
+    gg = __builtin_fma(gamma[i], gamma[i], gg);
+  }
+  tr = block_sum_1024(tr, red);
+  gg = block_sum_1024(gg, red);
+  if (threadIdx.x == 0) {
+    out[0] = tr;
+    out[1] = gg;
+  }
+}
+hipError_t launch_trace_gg(const double* Rinv, int ld, int nparts, size_t part_stride, int N, const double* gamma, double* out,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(k_trace_gg, dim3(1), 1024, 0, st, Rinv, ld, nparts, part_stride, N, gamma, out);
+  return hipGetLastError();
+}
+
 // dst (row-major N x N, strict upper = 0)  <-  lower triangle of column-major L
 __global__ void k_copy_lower(const double* __restrict__ L, int N, int ld, double* __restrict__ dst) {
   const int j = blockIdx.x * 16 + (threadIdx.x & 15);  // column
@@ -146,8 +278,8 @@ template <int KERNEL>
 __global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict__ X, int N, int d,
                                                        const double* __restrict__ theta,
                                                        const double* __restrict__ gamma, double c1,
-                                                       const double* __restrict__ Rinv, int ld,
-                                                       double* __restrict__ partial, int ntile) {
+                                                       const double* __restrict__ Rinv, int ld, int nparts,
+                                                       size_t part_stride, double* __restrict__ partial, int ntile) {
   __shared__ double red[256];
   // linear tile id -> (bi <= bj)
   int t = blockIdx.x, bi = 0;
@@ -167,7 +299,9 @@ __global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict_
     }
     r0 = corr_profile<KERNEL>(s2);
     h = corr_dtheta_profile<KERNEL>(s2, r0);
-    A = gamma[i] * gamma[j] * c1 - Rinv[(size_t)i * ld + j];  // element (j, i) of the lower triangle, column-major
+    double rinv = 0.0;  // element (j, i) of the lower triangle, column-major; R^-1 arrives as nparts K-slices of U U^T
+    for (int q = 0; q < nparts; ++q) rinv += Rinv[q * part_stride + (size_t)i * ld + j];
+    A = gamma[i] * gamma[j] * c1 - rinv;
   }
   double* out = partial + (size_t)blockIdx.x * (d + 1);
   for (int k = 0; k <= d; ++k) {
@@ -195,14 +329,15 @@ int grad_contract_blocks(int N) {
   return nt * (nt + 1) / 2;
 }
 hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const double* theta, const double* gamma,
-                                double c1, const double* Rinv, int ld, double* partial, int nblk, hipStream_t st) {
+                                double c1, const double* Rinv, int ld, int nparts, size_t part_stride, double* partial, int nblk,
+                                hipStream_t st) {
   const int nt = (N + 15) / 16;
   switch (kernel) {
-    case BOGP_KERNEL_SE: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_SE>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, partial, nt); break;
-    case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN12>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, partial, nt); break;
-    case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN32>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, partial, nt); break;
-    case BOGP_KERNEL_ABSEXP: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_ABSEXP>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, partial, nt); break;
-    default: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN52>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, partial, nt); break;
+    case BOGP_KERNEL_SE: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_SE>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, nparts, part_stride, partial, nt); break;
+    case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN12>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, nparts, part_stride, partial, nt); break;
+    case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN32>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, nparts, part_stride, partial, nt); break;
+    case BOGP_KERNEL_ABSEXP: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_ABSEXP>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, nparts, part_stride, partial, nt); break;
+    default: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN52>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, nparts, part_stride, partial, nt); break;
   }
   return hipGetLastError();
 }
