@@ -56,7 +56,7 @@ class BogpError(RuntimeError):
 
 
 class NotPositiveDefinite(BogpError, np.linalg.LinAlgError):
-    """rocSOLVER potrf info > 0 (or llf > 0, which the reference also rejects): the host maps it to llf = -inf."""
+    """Cholesky info > 0 (or llf > 0, which the reference also rejects): the host maps it to llf = -inf."""
 
 
 def load():

@@ -3,7 +3,7 @@
 Satisfies the surrogate protocol of SURVEY.md section 8b (who calls what: `base.py:423-446` fit/predict,
 `acquisition_fun.py:52-80` predict/gradient, attributes `sigma2`, `y`, `is_fitted`) with the same constructor
 keywords as the reference (`surrogate/gaussian_process/gpr.py:211-228`).  All O(N^2)+ arithmetic runs in libbogp
-(HIP kernels + rocSOLVER); the host keeps only what the reference keeps on the host: the L-BFGS-B restart loop of
+(HIP kernels); the host keeps only what the reference keeps on the host: the L-BFGS-B restart loop of
 the MLE (`gpr.py:1058-1197`) and input validation.  There is no CPU fallback.
 
 Differences from the reference, all deliberate and listed in DESIGN.md:

@@ -9,7 +9,7 @@
  *   - plain pointers and sizes only; every host array is C-contiguous float64 / int32 / int64
  *   - return value: 0 = BOGP_OK, < 0 = error code (never throws across the ABI);
  *     `bogp_last_error(h)` gives a human-readable message for the last failing call on that handle
- *   - BOGP_ERR_NOT_POSDEF is the "Cholesky failed" outcome (rocSOLVER info > 0); the Python host maps it to
+ *   - BOGP_ERR_NOT_POSDEF is the "Cholesky failed" outcome (LAPACK-style info > 0); the Python host maps it to
  *     llf = -inf exactly like the reference maps LinAlgError (surrogate/gaussian_process/gpr.py:946-947,
  *     960-961, 978-979)
  *   - the library owns all device memory; the caller owns all host buffers
@@ -30,7 +30,7 @@ typedef struct bogp_handle bogp_handle;
 /* error codes */
 #define BOGP_OK 0
 #define BOGP_ERR_INVALID (-1)      /* bad argument / call order                                           */
-#define BOGP_ERR_HIP (-2)          /* HIP runtime / rocBLAS / rocSOLVER failure                            */
+#define BOGP_ERR_HIP (-2)          /* HIP runtime / rocBLAS failure                                        */
 #define BOGP_ERR_NOT_POSDEF (-3)   /* correlation matrix not positive definite (potrf info > 0)            */
 #define BOGP_ERR_UNSUPPORTED (-4)  /* valid in the reference but not built yet (see DESIGN.md "out of scope") */
 #define BOGP_ERR_NO_DEVICE (-5)    /* no usable gfx950 device                                              */
@@ -83,13 +83,13 @@ int bogp_set_train(bogp_handle* h, const double* X, const double* y, int N, int 
 /* ---- likelihood -----------------------------------------------------------------------------------
  * Replaces GaussianProcess.log_likelihood_concentrated(par, eval_grad) (gpr.py:920-1040):
  * correlation_matrix (:772-782) -> _compute_aux_var (:790-811: potrf, L^-1 y, trend QR, rho) -> llf ->
- * gradient (:994-1038: gamma, R^-1 via potri, corr_grad_theta contraction without the (N,N,d) tensor).
+ * gradient (:994-1038: gamma, R^-1 = L^-T L^-1, corr_grad_theta contraction without the (N,N,d) tensor).
  *   par           [theta (n_theta = d or 1), then sigma2 | alpha per mode], NOT log10
  *   noise_var     nugget tau^2 (NOISY mode); ignored otherwise
  *   estimate_trend 1: beta is GLS-estimated (ordinary kriging);  0: fixed `beta` (simple kriging)
  *   llf           out, scalar
  *   grad          out, n_par doubles, d llf / d par (the un-scaled gradient the reference hands L-BFGS-B,
- *                 SURVEY 8a quirks); NULL to skip the gradient (saves potri + contraction)
+ *                 SURVEY 8a quirks); NULL to skip the gradient (saves R^-1 + contraction)
  * Returns BOGP_ERR_NOT_POSDEF / BOGP_ERR_LLF_POSITIVE where the reference returns -inf.                 */
 int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
              int estimate_trend, double beta, double* llf, double* grad);
