@@ -16,7 +16,7 @@ ERR_INVALID, ERR_HIP, ERR_NOT_POSDEF, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_LLF_PO
 KERNEL_SE, KERNEL_MATERN12, KERNEL_MATERN32, KERNEL_MATERN52, KERNEL_ABSEXP = 0, 1, 2, 3, 4
 MODE_NOISELESS, MODE_NOISY, MODE_NOISE_ESTIM = 0, 1, 2
 ACQ_EI, ACQ_EPSILON_PI, ACQ_UCB, ACQ_MGFI = 0, 1, 2, 3
-TREND_CONSTANT = 0
+TREND_CONSTANT, TREND_LINEAR, TREND_QUADRATIC = 0, 1, 2
 MAX_Q = 64
 
 _dp = C.POINTER(C.c_double)
@@ -33,6 +33,9 @@ SIGNATURES = {
     "bogp_nll": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp, _dp]),
     "bogp_commit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp]),
     "bogp_get_state": (C.c_int, [C.c_void_p] + [_dp] * 10),
+    "bogp_trend_size": (C.c_int, [C.c_int, C.c_int]),
+    "bogp_set_trend_beta": (C.c_int, [C.c_void_p, _dp, C.c_int]),
+    "bogp_get_trend_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
     "bogp_candidates_upload": (C.c_int, [C.c_void_p, _dp, C.c_int64]),
     "bogp_candidates_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "bogp_candidates_generate": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_uint64, C.c_int64]),
@@ -109,6 +112,7 @@ class Engine:
         self._h = h
         self.device = int(device)
         self.N = self.d = 0
+        self.trend, self.estimate_trend = TREND_CONSTANT, False
         self.M = 0
         self._keep = None  # keeps bound device memory owners alive
 
@@ -138,25 +142,41 @@ class Engine:
         self._check(self._lib.bogp_set_train(self._h, _ptr(X), _ptr(y), X.shape[0], X.shape[1], y.shape[1]))
         self.N, self.d = X.shape
 
-    def nll(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False):
+    def _trend_beta(self, trend, estimate_trend, beta) -> float:
+        """Fixed coefficients of a p > 1 basis travel through bogp_set_trend_beta; the scalar argument serves p = 1."""
+        if trend == TREND_CONSTANT:
+            return float(np.ravel(beta)[0]) if np.ndim(beta) else float(beta)
+        if not estimate_trend:
+            b = _f64(beta).ravel()
+            self._check(self._lib.bogp_set_trend_beta(self._h, _ptr(b), len(b)))
+        return 0.0
+
+    def nll(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False, trend=TREND_CONSTANT):
         """log-likelihood (and d llf / d par) at `par`; raises NotPositiveDefinite where the reference returns -inf."""
         par = _f64(par).ravel()
         llf = C.c_double()
         grad = np.zeros(len(par)) if eval_grad else None
+        b = self._trend_beta(trend, estimate_trend, beta)
         self._check(
-            self._lib.bogp_nll(self._h, kernel, mode, _ptr(par), len(par), float(noise_var), TREND_CONSTANT,
-                               int(bool(estimate_trend)), float(beta), C.byref(llf), _ptr(grad))
+            self._lib.bogp_nll(self._h, kernel, mode, _ptr(par), len(par), float(noise_var), int(trend),
+                               int(bool(estimate_trend)), b, C.byref(llf), _ptr(grad))
         )  # fmt: skip
         return (llf.value, grad) if eval_grad else llf.value
 
-    def commit(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0) -> float:
+    def commit(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, trend=TREND_CONSTANT) -> float:
         par = _f64(par).ravel()
         llf = C.c_double()
+        b = self._trend_beta(trend, estimate_trend, beta)
         self._check(
-            self._lib.bogp_commit(self._h, kernel, mode, _ptr(par), len(par), float(noise_var), TREND_CONSTANT,
-                                  int(bool(estimate_trend)), float(beta), C.byref(llf))
+            self._lib.bogp_commit(self._h, kernel, mode, _ptr(par), len(par), float(noise_var), int(trend),
+                                  int(bool(estimate_trend)), b, C.byref(llf))
         )  # fmt: skip
+        self.trend = int(trend)
+        self.estimate_trend = bool(estimate_trend)
         return llf.value
+
+    def trend_size(self, trend=None) -> int:
+        return int(self._lib.bogp_trend_size(int(self.trend if trend is None else trend), int(self.d)))
 
     def get_state(self, with_C=True) -> dict:
         N = self.N
@@ -170,6 +190,13 @@ class Engine:
         out = dict(v, G=s[0].value, beta=s[1].value, sigma2=s[2].value, noise_var=s[3].value)
         if with_C:
             out["C"] = Cm
+        if getattr(self, "trend", TREND_CONSTANT) != TREND_CONSTANT:  # p > 1: Ft, Q (N, p), G (p, p), beta (p,)
+            p = self.trend_size()
+            est = getattr(self, "estimate_trend", False)
+            Ft, Q, G, beta = np.zeros((N, p)), np.zeros((N, p)), np.zeros((p, p)), np.zeros(p)
+            self._check(self._lib.bogp_get_trend_state(self._h, _ptr(Ft) if est else None, _ptr(Q) if est else None,
+                                                       _ptr(G) if est else None, _ptr(beta)))  # fmt: skip
+            out.update(Ft=Ft, Q=Q, G=G, beta=beta)
         return out
 
     # -- candidates ---------------------------------------------------------------------------------

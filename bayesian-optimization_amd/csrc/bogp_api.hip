@@ -70,6 +70,20 @@ struct bogp_handle {
   int64_t *dblk_idx = nullptr, *dbest_idx = nullptr;
   size_t blk_val_cap = 0, blk_idx_cap = 0, mu_out_cap = 0, mse_out_cap = 0, acq_out_cap = 0;
 
+  // polynomial trend bases with p > 1 columns (linear / quadratic; the constant basis keeps its scalar fast path)
+  int trend = BOGP_TREND_CONSTANT, p = 1;  // committed
+  int tr_built = -1, tr_p = 0, ldp = 0;    // basis currently held in dF / sizes of the buffers below
+  std::vector<double> h_beta_fixed;        // bogp_set_trend_beta: simple-kriging coefficients
+  std::vector<double> h_betav, h_Sinv;     // committed beta (p) and (Ft^T Ft)^-1 (p x p, column-major) for bogp_gradient
+  double *dF = nullptr, *dFt = nullptr, *dQ1 = nullptr, *dQ = nullptr;  // N x p, column-major, ld = N
+  double* dWp = nullptr;                                                // Np x p: L^-T Ft, zero-padded rows
+  double *dA[2] = {nullptr, nullptr}, *dAV[2] = {nullptr, nullptr}, *dAU[2] = {nullptr, nullptr};  // ldp x ldp (CholeskyQR2)
+  double *dAw = nullptr, *dAT = nullptr;                                // ldp x 64, ldp x ldp scratch
+  double *dGinv = nullptr, *dSinv = nullptr, *dbetav = nullptr, *dqty = nullptr;  // p x p, p x p, p, p
+  rocblas_int* dinfo2 = nullptr;
+  double *dTt = nullptr, *dCS = nullptr, *duu = nullptr, *dmtrend = nullptr;  // per sweep chunk: Mc x p, Mc x p, Mc, Mc
+  size_t Tt_cap = 0, CS_cap = 0, uu_cap = 0, mtrend_cap = 0;
+
   // timing of the last sweep/predict
   std::vector<hipEvent_t> ev;
   double t_corr_ms = 0, t_contract_ms = 0, t_acq_ms = 0;
@@ -111,7 +125,7 @@ static void dfree(T*& p) {
   p = nullptr;
 }
 
-extern "C" int bogp_abi_version(void) { return 1; }
+extern "C" int bogp_abi_version(void) { return 2; }
 
 extern "C" const char* bogp_last_error(const bogp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -154,10 +168,18 @@ extern "C" int bogp_create(int device, bogp_handle** out) {
   return BOGP_OK;
 }
 
+static void free_trend(bogp_handle* h) {
+  dfree(h->dF); dfree(h->dFt); dfree(h->dQ1); dfree(h->dQ); dfree(h->dWp);
+  for (int b = 0; b < 2; ++b) { dfree(h->dA[b]); dfree(h->dAV[b]); dfree(h->dAU[b]); }
+  dfree(h->dAw); dfree(h->dAT); dfree(h->dGinv); dfree(h->dSinv); dfree(h->dbetav); dfree(h->dqty); dfree(h->dinfo2);
+  h->tr_built = -1; h->tr_p = 0; h->ldp = 0; h->trend = BOGP_TREND_CONSTANT; h->p = 1;
+}
+
 static void free_train(bogp_handle* h) {
   dfree(h->dX); dfree(h->dy); dfree(h->dR); dfree(h->dV); dfree(h->dU); dfree(h->dT); dfree(h->dRinv); dfree(h->ddinv); dfree(h->dones); dfree(h->dgemv_scratch);
   dfree(h->dyt); dfree(h->dft); dfree(h->drho); dfree(h->dtmp); dfree(h->dgamma); dfree(h->dw);
   dfree(h->dtheta); dfree(h->dsqrt_theta); dfree(h->dXthT); dfree(h->dVp);
+  free_trend(h);
   h->committed = false;
 }
 
@@ -171,6 +193,7 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   for (int b = 0; b < 2; ++b) { dfree(h->drT[b]); dfree(h->dmu_part[b]); dfree(h->dw_part[b]); }
   dfree(h->dblk_val); dfree(h->dblk_idx); dfree(h->dmu_out); dfree(h->dmse_out); dfree(h->dacq_out);
   dfree(h->dbest_val); dfree(h->dbest_idx); dfree(h->dinfo); dfree(h->dscal); dfree(h->dgrad_partial); dfree(h->dbatch);
+  dfree(h->dTt); dfree(h->dCS); dfree(h->duu); dfree(h->dmtrend);
   for (auto e : h->ev) (void)hipEventDestroy(e);
   if (h->blas) rocblas_destroy_handle(h->blas);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -229,12 +252,112 @@ struct FitOut {
   double llf = 0, sigma2 = 0, noise_var = 0, s2t = 0, G = 0, beta = 0, ftyt = 0, ftft = 0;
 };
 
+static int trend_size(int trend, int d) {
+  return trend == BOGP_TREND_CONSTANT ? 1 : trend == BOGP_TREND_LINEAR ? d + 1 : (d + 1) * (d + 2) / 2;
+}
+extern "C" int bogp_trend_size(int trend, int d) {
+  if (trend < BOGP_TREND_CONSTANT || trend > BOGP_TREND_QUADRATIC || d <= 0) return BOGP_ERR_INVALID;
+  return trend_size(trend, d);
+}
+
+extern "C" int bogp_set_trend_beta(bogp_handle* h, const double* beta, int p) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!beta || p <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_set_trend_beta: beta must be non-null and p > 0");
+  h->h_beta_fixed.assign(beta, beta + p);
+  return BOGP_OK;
+}
+
+// buffers of the p > 1 path, (re)allocated when p changes; F is rebuilt when the basis id changes
+static int ensure_trend(bogp_handle* h, int trend) {
+  const int N = h->N, d = h->d, Np = h->Np;
+  const int p = trend_size(trend, d);
+  if (p > 1024) FAIL(h, BOGP_ERR_UNSUPPORTED, "trend with p = %d basis functions (> 1024)", p);
+  if (p > N) FAIL(h, BOGP_ERR_INVALID, "trend with p = %d basis functions needs at least as many training points (N = %d)", p, N);
+  hipStream_t st = h->stream;
+  if (h->tr_p != p) {
+    const bool was_committed = h->committed;
+    const int tr0 = h->trend, p0 = h->p;
+    free_trend(h);
+    h->trend = tr0; h->p = p0;
+    if (was_committed && p0 > 1) h->committed = false;  // the committed W / beta lived in the freed buffers
+    const int ldp = ((p + 63) / 64) * 64;
+    const size_t np_ = (size_t)N * p, pp = (size_t)ldp * ldp;
+    HIPCHK(h, hipMalloc((void**)&h->dF, np_ * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dFt, np_ * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dQ1, np_ * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dQ, np_ * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dWp, (size_t)Np * p * sizeof(double)));
+    for (int b = 0; b < 2; ++b) {
+      HIPCHK(h, hipMalloc((void**)&h->dA[b], pp * sizeof(double)));
+      HIPCHK(h, hipMalloc((void**)&h->dAV[b], pp * sizeof(double)));
+      HIPCHK(h, hipMalloc((void**)&h->dAU[b], pp * sizeof(double)));
+      HIPCHK(h, hipMemsetAsync(h->dAV[b], 0, pp * sizeof(double), st));  // launch_tri_inverse keeps the other triangle zero
+      HIPCHK(h, hipMemsetAsync(h->dAU[b], 0, pp * sizeof(double), st));
+    }
+    HIPCHK(h, hipMalloc((void**)&h->dAw, (size_t)ldp * 64 * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dAT, pp * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dGinv, (size_t)p * p * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dSinv, (size_t)p * p * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dbetav, p * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dqty, p * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dinfo2, 2 * sizeof(rocblas_int)));
+    HIPCHK(h, hipMemsetAsync(h->dinfo2, 0, 2 * sizeof(rocblas_int), st));
+    h->tr_p = p;
+    h->ldp = ldp;
+    h->tr_built = -1;
+  }
+  if (h->tr_built != trend) {
+    HIPCHK(h, launch_trend_train(trend, h->dX, N, d, h->dF, st));
+    h->tr_built = trend;
+  }
+  return BOGP_OK;
+}
+
+// Universal / simple kriging with a p > 1 polynomial basis (gpr.py:799-808 with a matrix F).  On entry V = L^-1, U = L^-T
+// are current and Yt = V y is queued.  Everything is queued on the handle's stream; nothing is read back here.
+//   Ft = V F;  economic QR of Ft by CholeskyQR2 (two passes of: A = Ft^T Ft, chol, Q = Ft R^-1 -- the second pass restores
+//   the orthogonality the first loses to cond(Ft)^2; both small factorisations run through kernels_chol.hip);
+//   G = R2 R1 (positive diagonal: LAPACK's Householder QR differs by row signs, which no consumer can see),
+//   rho = Yt - Q Q^T Yt,  beta = G^-1 Q^T Yt,  (Ft^T Ft)^-1 = G^-1 G^-T for the variance term u^T u.
+static int trend_solve(bogp_handle* h, int trend, int estimate_trend) {
+  int e = ensure_trend(h, trend);
+  if (e) return e;
+  const int N = h->N, p = h->tr_p, ldp = h->ldp, ldr = h->ldr;
+  hipStream_t st = h->stream;
+  const double one = 1.0, zero = 0.0, mone = -1.0;
+  BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_none, N, p, N, &one, h->dV, ldr, h->dF, N, &zero, h->dFt, N));
+  HIPCHK(h, hipMemcpyAsync(h->drho, h->dyt, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (!estimate_trend) {
+    if ((int)h->h_beta_fixed.size() != p) FAIL(h, BOGP_ERR_INVALID, "trend with p = %d fixed coefficients: call bogp_set_trend_beta first (have %d)", p, (int)h->h_beta_fixed.size());
+    HIPCHK(h, hipMemcpyAsync(h->dbetav, h->h_beta_fixed.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
+    BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, N, p, &mone, h->dFt, N, h->dbetav, 1, &one, h->drho, 1));  // :808
+    return BOGP_OK;
+  }
+  const double* src = h->dFt;
+  for (int pass = 0; pass < 2; ++pass) {
+    double* dst = pass == 0 ? h->dQ1 : h->dQ;
+    BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_transpose, rocblas_operation_none, p, p, N, &one, src, N, src, N, &zero, h->dA[pass], ldp));
+    HIPCHK(h, launch_pad_identity(h->dA[pass], p, ldp, st));
+    HIPCHK(h, launch_chol_lower(h->dA[pass], ldp, h->dAw, h->dinfo2 + pass, st));
+    HIPCHK(h, launch_tri_inverse(h->dA[pass], h->dAw, h->dAV[pass], h->dAU[pass], h->dAT, ldp, st));
+    BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_none, N, p, p, &one, src, N, h->dAU[pass], ldp, &zero, dst, N));
+    src = dst;
+  }
+  BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_none, p, p, p, &one, h->dAU[0], ldp, h->dAU[1], ldp, &zero, h->dGinv, p));
+  BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, p, &one, h->dQ, N, h->dyt, 1, &zero, h->dqty, 1));
+  BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, N, p, &mone, h->dQ, N, h->dqty, 1, &one, h->drho, 1));  // :806
+  BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, p, p, &one, h->dGinv, p, h->dqty, 1, &zero, h->dbetav, 1));  // :785-787
+  BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_transpose, p, p, p, &one, h->dGinv, p, h->dGinv, p, &zero, h->dSinv, p));
+  return BOGP_OK;
+}
+
 static int factorize(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
                      int estimate_trend, double beta, bool want_gamma, FitOut* o, std::vector<double>* theta_out) {
   if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "no training set: call bogp_set_train first");
   if (kernel < 0 || kernel > BOGP_KERNEL_ABSEXP) FAIL(h, BOGP_ERR_INVALID, "unknown kernel id %d", kernel);
   if (mode < 0 || mode > 2) FAIL(h, BOGP_ERR_INVALID, "unknown estimation mode %d", mode);
-  if (trend != BOGP_TREND_CONSTANT) FAIL(h, BOGP_ERR_UNSUPPORTED, "only the constant trend basis is built (trend id %d)", trend);
+  if (trend < BOGP_TREND_CONSTANT || trend > BOGP_TREND_QUADRATIC) FAIL(h, BOGP_ERR_INVALID, "unknown trend id %d", trend);
+  const int ptrend = trend_size(trend, h->d);
   const int N = h->N, d = h->d, ldr = h->ldr;
   const int n_theta = n_par - (mode == BOGP_MODE_NOISELESS ? 0 : 1);
   if (n_theta != d && n_theta != 1) FAIL(h, BOGP_ERR_INVALID, "len(theta) = %d must be 1 or d = %d", n_theta, d);
@@ -276,8 +399,15 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st));
   HIPCHK(h, launch_logdet(h->dR, N, ldr, h->dscal, st));
   HIPCHK(h, launch_tri_inverse(h->dR, h->ddinv, h->dV, h->dU, h->dT, ldr, st));
-  HIPCHK(h, launch_gemv2(h->dV, ldr, N, 1, h->dy, h->dones, h->dyt, h->dft, h->dgemv_scratch, st));
-  HIPCHK(h, launch_fit_rho(h->dyt, h->dft, N, estimate_trend, beta, h->drho, h->dscal, st));
+  if (ptrend == 1) {
+    HIPCHK(h, launch_gemv2(h->dV, ldr, N, 1, h->dy, h->dones, h->dyt, h->dft, h->dgemv_scratch, st));
+    HIPCHK(h, launch_fit_rho(h->dyt, h->dft, N, estimate_trend, beta, h->drho, h->dscal, st));
+  } else {
+    HIPCHK(h, launch_gemv2(h->dV, ldr, N, 1, h->dy, nullptr, h->dyt, nullptr, h->dgemv_scratch, st));
+    int et = trend_solve(h, trend, estimate_trend);
+    if (et) return et;
+    HIPCHK(h, launch_sumsq(h->drho, N, h->dscal + 3, st));
+  }
   if (want_gamma) {
     HIPCHK(h, hipMemsetAsync(h->dgamma, 0, h->Np * sizeof(double), st));
     HIPCHK(h, launch_gemv2(h->dU, ldr, N, 2, h->drho, nullptr, h->dgamma, nullptr, h->dgemv_scratch, st));
@@ -286,12 +416,15 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   double sc[4] = {0, 0, 0, 0};  // sum(log diag L), |Ft|, Ft.Yt, rho.rho
   HIPCHK(h, hipMemcpyAsync(&info, h->dinfo, sizeof(info), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(sc, h->dscal, sizeof(sc), hipMemcpyDeviceToHost, st));
+  rocblas_int info2[2] = {0, 0};
+  if (ptrend > 1 && estimate_trend) HIPCHK(h, hipMemcpyAsync(info2, h->dinfo2, sizeof(info2), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   if (info != 0) FAIL(h, BOGP_ERR_NOT_POSDEF, "correlation matrix is not positive definite (potrf info = %d)", (int)info);
+  if (info2[0] != 0 || info2[1] != 0) FAIL(h, BOGP_ERR_NOT_POSDEF, "trend basis is rank deficient after whitening (Ft^T Ft not positive definite, info = %d / %d)", (int)info2[0], (int)info2[1]);
 
   const double logdet = sc[0], rho_ss = sc[3];
   double ftyt = 0, ftft = 0, G = 0, beta_eff = beta;
-  if (estimate_trend) {
+  if (estimate_trend && ptrend == 1) {
     // economic QR of the single column Ft: G = -sign(Ft[0]) |Ft|, Ft[0] = 1 / L[0][0] > 0 (:803-806)
     const double nrm = sc[1];
     ftyt = sc[2];
@@ -304,7 +437,7 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   const double TWO_PI = 2.0 * 3.141592653589793;
   double llf, sigma2, nv;
   if (mode == BOGP_MODE_NOISELESS) {  // :941-945
-    const int k = estimate_trend ? 1 : 0;
+    const int k = estimate_trend ? ptrend : 0;  // rank(Q Q^T) (:941), full column rank assumed
     sigma2 = rho_ss / (N - k);
     nv = 0;
     s2t = sigma2;
@@ -388,13 +521,26 @@ extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* p
   HIPCHK(h, launch_pack_V(h->dV, N, ldr, Np, h->dVp, st));
   // w = L^-T Ft  (so that Ft^T L^-1 r = w . r, gpr.py:496-498)
   HIPCHK(h, hipMemsetAsync(h->dw, 0, Np * sizeof(double), st));
-  if (estimate_trend) {
+  const int ptrend = trend_size(trend, d);
+  if (estimate_trend && ptrend == 1) {
     HIPCHK(h, launch_gemv2(h->dU, ldr, N, 2, h->dft, nullptr, h->dw, nullptr, h->dgemv_scratch, st));
+  }
+  if (ptrend > 1) {
+    h->h_betav.assign(ptrend, 0.0);
+    h->h_Sinv.assign((size_t)ptrend * ptrend, 0.0);
+    HIPCHK(h, hipMemcpyAsync(h->h_betav.data(), h->dbetav, ptrend * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (estimate_trend) {  // W = L^-T Ft (N x p), zero rows in the padding
+      const double one = 1.0, zero = 0.0;
+      HIPCHK(h, hipMemsetAsync(h->dWp, 0, (size_t)Np * ptrend * sizeof(double), st));
+      BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_none, N, ptrend, N, &one, h->dU, ldr, h->dFt, N, &zero, h->dWp, Np));
+      HIPCHK(h, hipMemcpyAsync(h->h_Sinv.data(), h->dSinv, (size_t)ptrend * ptrend * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
   }
   if (!h->dXthT) HIPCHK(h, hipMalloc((void**)&h->dXthT, (size_t)d * Np * sizeof(double)));
   HIPCHK(h, launch_scale_transpose(h->dX, N, d, Np, h->dsqrt_theta, h->dXthT, st));
   HIPCHK(h, hipStreamSynchronize(st));
   h->kernel = kernel; h->mode = mode; h->estimate_trend = estimate_trend;
+  h->trend = trend; h->p = ptrend;
   h->beta = o.beta; h->G = o.G; h->sigma2 = o.sigma2; h->noise_var = o.noise_var; h->llf = o.llf; h->ftft = o.ftft;
   h->committed = true;
   return BOGP_OK;
@@ -415,17 +561,63 @@ extern "C" int bogp_get_state(bogp_handle* h, double* C, double* gamma, double* 
   if (gamma) HIPCHK(h, hipMemcpyAsync(gamma, h->dgamma, N * sizeof(double), hipMemcpyDeviceToHost, st));
   if (rho) HIPCHK(h, hipMemcpyAsync(rho, h->drho, N * sizeof(double), hipMemcpyDeviceToHost, st));
   if (Yt) HIPCHK(h, hipMemcpyAsync(Yt, h->dyt, N * sizeof(double), hipMemcpyDeviceToHost, st));
-  if (h->estimate_trend) {
+  if (h->estimate_trend && h->p == 1) {  // p > 1: bogp_get_trend_state
     if (Ft) HIPCHK(h, hipMemcpyAsync(Ft, h->dft, N * sizeof(double), hipMemcpyDeviceToHost, st));
     if (Q) HIPCHK(h, hipMemcpyAsync(Q, h->dft, N * sizeof(double), hipMemcpyDeviceToHost, st));
   }
   HIPCHK(h, hipStreamSynchronize(st));
-  if (h->estimate_trend && Q)
+  if (h->estimate_trend && h->p == 1 && Q)
     for (int i = 0; i < N; ++i) Q[i] /= h->G;
   if (G) *G = h->G;
   if (beta) *beta = h->beta;
   if (sigma2) *sigma2 = h->sigma2;
   if (noise_var) *noise_var = h->noise_var;
+  return BOGP_OK;
+}
+
+// State of a polynomial trend (p > 1): Ft, Q (N x p, row-major), G (p x p, row-major, upper, positive diagonal), beta (p).
+// Works for p = 1 as well.  Any pointer may be NULL.
+extern "C" int bogp_get_trend_state(bogp_handle* h, double* Ft, double* Q, double* G, double* beta) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "bogp_get_trend_state: no committed state");
+  const int N = h->N, pt = h->p;
+  hipStream_t st = h->stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (pt == 1) {
+    std::vector<double> ft(N, 0.0);
+    if (h->estimate_trend) HIPCHK(h, hipMemcpy(ft.data(), h->dft, N * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; ++i) {
+      if (Ft) Ft[i] = ft[i];
+      if (Q) Q[i] = h->estimate_trend ? ft[i] / h->G : 0.0;
+    }
+    if (G) *G = h->G;
+    if (beta) *beta = h->beta;
+    return BOGP_OK;
+  }
+  if (beta) for (int c = 0; c < pt; ++c) beta[c] = h->h_betav[c];
+  if (!h->estimate_trend) return BOGP_OK;  // Ft / Q / G exist only when the coefficients are estimated (gpr.py:801-806)
+  std::vector<double> tmp((size_t)N * pt);
+  for (int which = 0; which < 2; ++which) {
+    double* dst = which == 0 ? Ft : Q;
+    if (!dst) continue;
+    HIPCHK(h, hipMemcpyAsync(tmp.data(), which == 0 ? h->dFt : h->dQ, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    for (int i = 0; i < N; ++i)
+      for (int c = 0; c < pt; ++c) dst[(size_t)i * pt + c] = tmp[(size_t)c * N + i];
+  }
+  if (G) {  // G = R2 R1 with R = L^T of the two CholeskyQR passes (lower triangles of dA[1], dA[0])
+    const int ldp = h->ldp;
+    std::vector<double> a0((size_t)ldp * ldp), a1((size_t)ldp * ldp);
+    HIPCHK(h, hipMemcpyAsync(a0.data(), h->dA[0], a0.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(a1.data(), h->dA[1], a1.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    for (int i = 0; i < pt; ++i)
+      for (int j = 0; j < pt; ++j) {
+        double acc = 0.0;
+        for (int k = i; k <= j; ++k) acc += a1[(size_t)i * ldp + k] * a0[(size_t)k * ldp + j];  // R2[i][k] = L2[k][i], R1[k][j] = L1[j][k]
+        G[(size_t)i * pt + j] = j >= i ? acc : 0.0;
+      }
+  }
   return BOGP_OK;
 }
 
@@ -531,7 +723,7 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
   // r -> rt = V r (rocBLAS dtrmm with M right-hand sides) -> column reductions, feeding the same acquisition kernel.
   int small_m = 32;
   if (const char* env = getenv("BOGP_SMALL_M")) small_m = atoi(env);
-  if (M <= small_m) {
+  if (M <= small_m && h->p == 1) {
     const int B = (int)M, N = h->N;
     int e2;
     if ((e2 = ensure(h, &h->dbatch, &h->batch_cap, (size_t)3 * N * B + 3 * (size_t)B))) return e2;
@@ -586,6 +778,13 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     if ((e = ensure(h, &h->dw_part[b], &h->w_part_cap[b], (size_t)S * Mc))) return e;
   }
   if ((e = ensure(h, &h->dss_part, &h->ss_part_cap, (size_t)nJ * Mc))) return e;
+  if (h->p > 1) {
+    if (Mc > 0x7fffffff / 2) FAIL(h, BOGP_ERR_UNSUPPORTED, "chunk of %lld candidates is too large for the trend GEMM (lower BOGP_CHUNK_MB)", (long long)Mc);
+    if ((e = ensure(h, &h->dTt, &h->Tt_cap, (size_t)Mc * h->p))) return e;
+    if ((e = ensure(h, &h->dCS, &h->CS_cap, (size_t)Mc * h->p))) return e;
+    if ((e = ensure(h, &h->duu, &h->uu_cap, (size_t)Mc))) return e;
+    if ((e = ensure(h, &h->dmtrend, &h->mtrend_cap, (size_t)Mc))) return e;
+  }
   if (q > 0) {
     if ((e = ensure(h, &h->dblk_val, &h->blk_val_cap, (size_t)q * nblk_total))) return e;
     if ((e = ensure(h, &h->dblk_idx, &h->blk_idx_cap, (size_t)q * nblk_total))) return e;
@@ -644,6 +843,25 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     for (int i = 0; i < q; ++i) { aa.acq_id[i] = acq_id[i]; aa.acq_par[i] = acq_par ? acq_par[i] : 0.0; }
     aa.plugin = plugin; aa.minimize = minimize; aa.acq_out = want_acq_out ? h->dacq_out : nullptr; aa.M = M;
     aa.blk_val = h->dblk_val; aa.blk_idx = h->dblk_idx; aa.blk_offset = blk_offset; aa.nblk_total = nblk_total;
+    if (h->p > 1) {
+      // polynomial trend: mean f(x*) . beta, and under universal kriging u = G^-T (Ft^T L^-1 r - f(x*)) (gpr.py:496-498):
+      // T = r W (Mc x p, library GEMM on the chunk that k_contract has just read), c = T - f(x*), u^T u = c^T (Ft^T Ft)^-1 c
+      const int pt = h->p;
+      const double one = 1.0, zero = 0.0;
+      double* Tt = nullptr;
+      if (h->estimate_trend) {
+        BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_none, (int)Mc_eff, pt, Np, &one, h->drT[b], (int)Mc, h->dWp, Np, &zero, h->dTt, (int)Mc));
+        Tt = h->dTt;
+      }
+      HIPCHK(h, launch_trend_terms(h->trend, h->dXs, m0, mcount, d, Mc, h->dbetav, Tt, h->dmtrend, st));
+      if (h->estimate_trend) {
+        BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_none, (int)Mc_eff, pt, pt, &one, h->dTt, (int)Mc, h->dSinv, pt, &zero, h->dCS, (int)Mc));
+        HIPCHK(h, launch_rowdot(h->dTt, h->dCS, Mc, mcount, pt, h->duu, st));
+        aa.uu = h->duu;
+      }
+      aa.mtrend = h->dmtrend;
+      aa.estimate_trend = 0;  // the scalar w_part path is for the constant basis
+    }
     HIPCHK(h, launch_acquisition(aa, st));
     HIPCHK(h, hipEventRecord(ev[4], st));
     blk_offset += (mcount + 255) / 256;
@@ -753,13 +971,17 @@ extern "C" int bogp_gradient(bogp_handle* h, const double* x, double* dmu, doubl
   const int N = h->N, d = h->d;
   hipStream_t st = h->stream;
   HIPCHK(h, hipSetDevice(h->device));
-  int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)N * (d + 2) + 4 * d + 8);
+  const int pt = h->p;
+  if (pt > 1 && h->trend == BOGP_TREND_QUADRATIC)
+    FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_gradient: the quadratic trend has no Jacobian in the reference either (trend.py:138-139)");
+  int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)N * (d + 2) + 4 * d + 8 + (size_t)pt * (d + 1));
   if (e) return e;
   double* dr = h->dgrad_partial;            // N
-  double* drdx = dr + N;                    // d x N (column k = dr/dx_k)
+  double* drdx = dr + N;                    // d x N (column k = dr/dx_k); [r | dr/dx] is one N x (d+1) column-major matrix
   double* dz = drdx + (size_t)N * d;        // N
   double* dx = dz + N;                      // d
   double* dout = dx + d;                    // 3 d
+  double* dtw = dout + 3 * d + 8;           // p x (d+1): W^T [r | dr/dx]
   HIPCHK(h, hipMemcpyAsync(dx, x, d * sizeof(double), hipMemcpyHostToDevice, st));
   HIPCHK(h, launch_point_corr(h->kernel, h->dX, N, d, h->dtheta, dx, dr, drdx, st));
   // z = L^-T L^-1 r = V^T (V r) with the explicit V = L^-1 kept from the commit: two triangular matrix-vector
@@ -771,13 +993,39 @@ extern "C" int bogp_gradient(bogp_handle* h, const double* x, double* dmu, doubl
   BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, h->dgamma, 1, &zero, dout, 1));
   BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, dz, 1, &zero, dout + d, 1));
   double wr = 0;
-  if (h->estimate_trend) {
+  if (h->estimate_trend && pt == 1) {
     BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, h->dw, 1, &zero, dout + 2 * d, 1));
     BLASCHK(h, rocblas_ddot(h->blas, N, h->dw, 1, dr, 1, &wr));
   }
-  std::vector<double> out(3 * d, 0.0);
-  HIPCHK(h, hipMemcpyAsync(out.data(), dout, (h->estimate_trend ? 3 : 2) * d * sizeof(double), hipMemcpyDeviceToHost, st));
+  std::vector<double> out(3 * d, 0.0), tw;
+  if (h->estimate_trend && pt > 1) {  // (Ft^T L^-1) [r | dr/dx] = W^T [r | dr/dx]   (gpr.py:570-571)
+    BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_transpose, rocblas_operation_none, pt, d + 1, N, &one, h->dWp, h->Np, dr, N, &zero, dtw, pt));
+    tw.resize((size_t)pt * (d + 1));
+    HIPCHK(h, hipMemcpyAsync(tw.data(), dtw, tw.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(h, hipMemcpyAsync(out.data(), dout, (h->estimate_trend && pt == 1 ? 3 : 2) * d * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
+  if (pt > 1) {  // linear basis: f = [1, x], Jacobian rows 1..d = identity (trend.py:104-112)
+    std::vector<double> su;  // S u with u = Ft^T rt - f and S = (Ft^T Ft)^-1 (:570-573)
+    if (h->estimate_trend) {
+      std::vector<double> u(pt);
+      for (int c = 0; c < pt; ++c) u[c] = tw[c] - (c == 0 ? 1.0 : x[c - 1]);
+      su.assign(pt, 0.0);
+      for (int c = 0; c < pt; ++c)
+        for (int r = 0; r < pt; ++r) su[r] += h->h_Sinv[(size_t)c * pt + r] * u[c];  // S symmetric, column-major
+    }
+    for (int k = 0; k < d; ++k) {
+      dmu[k] = h->h_betav[1 + k] + out[k];  // beta^T f_dx + gamma^T r_dx (:561)
+      double m = -1.0 * out[d + k];
+      if (h->estimate_trend) {
+        double acc = 0.0;
+        for (int c = 0; c < pt; ++c) acc += su[c] * (tw[(size_t)(1 + k) * pt + c] - (c == 1 + k ? 1.0 : 0.0));  // u_dx = Ft^T rt_dx - f_dx
+        m += acc;
+      }
+      dmse[k] = 2.0 * h->sigma2 * m;
+    }
+    return BOGP_OK;
+  }
   for (int k = 0; k < d; ++k) {
     dmu[k] = out[k];  // beta^T f_dx = 0 for the constant basis
     double m = -1.0 * out[d + k];
@@ -793,6 +1041,7 @@ extern "C" int bogp_gradient_batch(bogp_handle* h, const double* Xb, int B, doub
   if (!h) return BOGP_ERR_INVALID;
   if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "bogp_gradient_batch: no committed model");
   if (!Xb || !dmu || !dmse || B <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_gradient_batch: null pointer or B <= 0");
+  if (h->p > 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_gradient_batch: polynomial trends (p = %d) are served by bogp_gradient only", h->p);
   const int N = h->N, d = h->d;
   hipStream_t st = h->stream;
   HIPCHK(h, hipSetDevice(h->device));

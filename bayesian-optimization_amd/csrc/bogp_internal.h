@@ -45,6 +45,8 @@ struct AcqArgs {
   int64_t mcount;  // valid candidates in this chunk
   int64_t m0;      // global index of the chunk's first candidate
   double beta;     // trend coefficient (constant basis)
+  const double* mtrend;  // [Mc] f(x*) . beta for polynomial bases (replaces beta), or null
+  const double* uu;      // [Mc] u^T u for polynomial bases under universal kriging (replaces the w_part term), or null
   double G;        // QR factor of Ft (ordinary kriging), unused otherwise
   int estimate_trend;
   double sigma2;
@@ -98,6 +100,12 @@ hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const
 hipError_t launch_grad_reduce(const double* partial, int nblk, int nout, double* out, hipStream_t st);
 int grad_contract_blocks(int N);
 size_t gemv2_scratch_doubles(int N);
+// polynomial trends (p > 1)
+hipError_t launch_trend_train(int trend, const double* X, int N, int d, double* F, hipStream_t st);
+hipError_t launch_trend_terms(int trend, const double* Xs, int64_t m0, int64_t mcount, int d, int64_t Mc, const double* beta,
+                              double* T, double* mtrend, hipStream_t st);
+hipError_t launch_rowdot(const double* Cm, const double* CS, int64_t Mc, int64_t mcount, int p, double* uu, hipStream_t st);
+hipError_t launch_sumsq(const double* v, int N, double* out, hipStream_t st);
 hipError_t launch_gemv2(const double* M, int ld, int N, int tri, const double* x0, const double* x1, double* y0, double* y1,
                         double* scratch, hipStream_t st);
 hipError_t launch_fit_rho(const double* Yt, const double* Ft, int N, int estimate_trend, double beta, double* rho, double* scal,

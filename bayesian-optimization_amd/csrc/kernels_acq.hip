@@ -55,9 +55,11 @@ __global__ __launch_bounds__(256) void k_acquisition(AcqArgs a) {
       wd += a.w_part[(size_t)s * a.Mc + i];
     }
     for (int j = 0; j < a.nJ; ++j) ss += a.ss_part[(size_t)j * a.Mc + i];
-    mu = a.beta + mu;
+    mu = (a.mtrend ? a.mtrend[i] : a.beta) + mu;
     double u2 = 0.0;
-    if (a.estimate_trend) {
+    if (a.uu) {
+      u2 = a.uu[i];
+    } else if (a.estimate_trend) {
       const double u = (wd - 1.0) / a.G;
       u2 = u * u;
     }

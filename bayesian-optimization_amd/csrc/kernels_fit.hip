@@ -236,6 +236,19 @@ hipError_t launch_fit_rho(const double* Yt, const double* Ft, int N, int estimat
   return hipGetLastError();
 }
 
+// out[0] = v . v
+__global__ __launch_bounds__(1024) void k_sumsq(const double* __restrict__ v, int N, double* __restrict__ out) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) s = __builtin_fma(v[i], v[i], s);
+  s = block_sum_1024(s, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+hipError_t launch_sumsq(const double* v, int N, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_sumsq, dim3(1), 1024, 0, st, v, N, out);
+  return hipGetLastError();
+}
+
 // out[0] = trace(Rinv), out[1] = gamma . gamma   (the sigma2 derivative of the NOISY likelihood, gpr.py:1030-1036)
 __global__ __launch_bounds__(1024) void k_trace_gg(const double* __restrict__ Rinv, int ld, int nparts, size_t part_stride, int N,
                                                    const double* __restrict__ gamma, double* __restrict__ out) {
@@ -255,6 +268,66 @@ __global__ __launch_bounds__(1024) void k_trace_gg(const double* __restrict__ Ri
 hipError_t launch_trace_gg(const double* Rinv, int ld, int nparts, size_t part_stride, int N, const double* gamma, double* out,
                            hipStream_t st) {
   hipLaunchKernelGGL(k_trace_gg, dim3(1), 1024, 0, st, Rinv, ld, nparts, part_stride, N, gamma, out);
+  return hipGetLastError();
+}
+
+// ---- polynomial trend bases (surrogate/gaussian_process/trend.py:66-142) ----------------------------------------
+// column order of F: constant [1]; linear [1, x_0 .. x_{d-1}] (:104-107); quadratic [1, x, then for k = 0..d-1:
+// x_k x_j, j = k..d-1] (:130-136).  `emit(col, value)` is called once per column, in order.
+template <typename Emit>
+__device__ __forceinline__ void trend_basis(int trend, const double* __restrict__ x, int d, Emit emit) {
+  emit(0, 1.0);
+  if (trend == BOGP_TREND_CONSTANT) return;
+  for (int k = 0; k < d; ++k) emit(1 + k, x[k]);
+  if (trend == BOGP_TREND_LINEAR) return;
+  int col = 1 + d;
+  for (int k = 0; k < d; ++k) {
+    const double xk = x[k];
+    for (int j = k; j < d; ++j) emit(col++, xk * x[j]);
+  }
+}
+
+// F (N x p, column-major, ld = N) at the training points
+__global__ void k_trend_train(int trend, const double* __restrict__ X, int N, int d, double* __restrict__ F) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  trend_basis(trend, X + (size_t)n * d, d, [&](int col, double v) { F[(size_t)col * N + n] = v; });
+}
+hipError_t launch_trend_train(int trend, const double* X, int N, int d, double* F, hipStream_t st) {
+  hipLaunchKernelGGL(k_trend_train, dim3((N + 255) / 256), 256, 0, st, trend, X, N, d, F);
+  return hipGetLastError();
+}
+
+// per candidate of a chunk: mtrend = f(x*) . beta  and, when T is given (universal kriging), T <- T - f(x*) in place
+// (T is Mc x p column-major: T(m, col) = (Ft^T L^-1 r)_col, gpr.py:496-498 before the G solve)
+__global__ void k_trend_terms(int trend, const double* __restrict__ Xs, int64_t m0, int64_t mcount, int d, int64_t Mc,
+                              const double* __restrict__ beta, double* __restrict__ T, double* __restrict__ mtrend) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= mcount) return;
+  double acc = 0.0;
+  trend_basis(trend, Xs + (size_t)(m0 + i) * d, d, [&](int col, double v) {
+    acc = __builtin_fma(v, beta[col], acc);
+    if (T) T[(size_t)col * Mc + i] -= v;
+  });
+  mtrend[i] = acc;
+}
+hipError_t launch_trend_terms(int trend, const double* Xs, int64_t m0, int64_t mcount, int d, int64_t Mc, const double* beta,
+                              double* T, double* mtrend, hipStream_t st) {
+  hipLaunchKernelGGL(k_trend_terms, dim3((unsigned)((mcount + 255) / 256)), 256, 0, st, trend, Xs, m0, mcount, d, Mc, beta, T, mtrend);
+  return hipGetLastError();
+}
+
+// uu[m] = sum_col C(m, col) * CS(m, col)   (= u^T u with u = G^-T c, because CS = C (G^T G)^-1)
+__global__ void k_rowdot(const double* __restrict__ Cm, const double* __restrict__ CS, int64_t Mc, int64_t mcount, int p,
+                         double* __restrict__ uu) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= mcount) return;
+  double s = 0.0;
+  for (int col = 0; col < p; ++col) s = __builtin_fma(Cm[(size_t)col * Mc + i], CS[(size_t)col * Mc + i], s);
+  uu[i] = s;
+}
+hipError_t launch_rowdot(const double* Cm, const double* CS, int64_t Mc, int64_t mcount, int p, double* uu, hipStream_t st) {
+  hipLaunchKernelGGL(k_rowdot, dim3((unsigned)((mcount + 255) / 256)), 256, 0, st, Cm, CS, Mc, mcount, p, uu);
   return hipGetLastError();
 }
 

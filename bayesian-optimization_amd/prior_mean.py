@@ -5,9 +5,8 @@ names (`constant_trend`, `linear_trend`, `quadratic_trend`), constructor argumen
 `beta=None` asks for the GLS estimate (ordinary / universal kriging), a number fixes it (simple kriging,
 `gpr.py:269-270`).  Implementation differs: one table-driven class instead of a hierarchy.
 
-Device support: only the constant basis (p = 1) is evaluated by libbogp (`BOGP_TREND_CONSTANT`).  The other two
-are "next" rows of SURVEY.md section 8; they can be constructed (so user code that builds them keeps working) but
-`GaussianProcess.fit` rejects them with NotImplementedError.
+Device support: all three bases are evaluated by libbogp (`BOGP_TREND_CONSTANT / LINEAR / QUADRATIC`); the constant
+basis keeps a scalar fast path, p > 1 goes through a CholeskyQR2 of `L^-1 F` on the device.
 """
 from __future__ import annotations
 
@@ -106,15 +105,19 @@ class quadratic_trend(Trend):
     kind = "quadratic"
 
 
+_TREND_IDS = {"constant_trend": 0, "linear_trend": 1, "quadratic_trend": 2}  # BOGP_TREND_* of include/bogp.h
+
+
 def device_trend_of(mean):
-    """Map a trend object (ours or the reference's, duck-typed by class name) to what libbogp supports:
-    returns (estimate_trend: bool, beta: float).  Raises NotImplementedError for non-constant bases."""
+    """Map a trend object (ours or the reference's, duck-typed by class name) to libbogp's arguments:
+    returns (trend_id, estimate_trend: bool, beta) with beta a float for the constant basis and a (p,) vector
+    otherwise.  Raises NotImplementedError for bases the device does not evaluate (e.g. NonparametricTrend)."""
     name = type(mean).__name__
-    if name != "constant_trend":
-        raise NotImplementedError(
-            "trend %r is not built on the device yet (only constant_trend; linear/quadratic are SURVEY.md 8 'next' rows)" % name
-        )
+    if name not in _TREND_IDS:
+        raise NotImplementedError("trend %r is not built on the device (constant, linear and quadratic bases are)" % name)
+    tid = _TREND_IDS[name]
     b = mean.beta
     if b is None:
-        return True, 0.0
-    return False, float(np.asarray(b, dtype=float).ravel()[0])
+        return tid, True, 0.0
+    b = np.asarray(b, dtype=float).ravel()
+    return tid, False, (float(b[0]) if tid == 0 else b)

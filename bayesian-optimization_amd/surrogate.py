@@ -7,8 +7,8 @@ keywords as the reference (`surrogate/gaussian_process/gpr.py:211-228`).  All O(
 the MLE (`gpr.py:1058-1197`) and input validation.  There is no CPU fallback.
 
 Differences from the reference, all deliberate and listed in DESIGN.md:
-  * `optimizer="CMA"`, `likelihood="restricted"`, multi-target y, non-constant trends: NotImplementedError
-    (out of scope / "next" rows) instead of running on the CPU.
+  * `optimizer="CMA"`, `likelihood="restricted"`, multi-target y: NotImplementedError (out of scope / "next" rows)
+    instead of running on the CPU.  The three polynomial trends (constant / linear / quadratic) are all on the device.
   * Matern-5/2 (`corr=functools.partial(matern, nu=2.5)` or `"matern52"`) can be FITTED: the device has its
     theta- and x-derivatives, which the reference leaves as `pass` (gpr.py:647-648, 758-759).
   * `predict(batch_size=...)` works (the reference's branch is dead code on Python 3, gpr.py:513-535); chunking
@@ -156,9 +156,18 @@ class GaussianProcess:
         self.__dict__.update(st)
 
     def _trend_args(self):
-        _, beta = device_trend_of(self.mean)  # raises for bases the device does not evaluate
+        tid, _, beta = device_trend_of(self.mean)  # raises for bases the device does not evaluate
         # the estimation mode is fixed at construction (gpr.py:273-275); fit() later fills mean.beta with the GLS value
-        return self.estimate_trend, (0.0 if self.estimate_trend else beta)
+        return tid, self.estimate_trend, (0.0 if self.estimate_trend else beta)
+
+    @staticmethod
+    def _trend_views(st, est):
+        """Ft, G, Q, beta of an engine state in the reference's shapes: (N, p), (p, p), (N, p), (p, 1)."""
+        if not est:
+            return None, None, None, np.atleast_1d(st["beta"]).reshape(-1, 1)
+        if np.ndim(st["G"]) == 0:  # constant basis: the C ABI hands back vectors and a scalar
+            return st["Ft"].reshape(-1, 1), np.array([[st["G"]]]), st["Q"].reshape(-1, 1), np.array([[st["beta"]]])
+        return st["Ft"], st["G"], st["Q"], np.asarray(st["beta"], dtype=float).reshape(-1, 1)
 
     def _nv(self) -> float:
         return float(np.atleast_1d(self.noise_var)[0]) if self.estimation_mode == "noisy" else 0.0
@@ -204,7 +213,7 @@ class GaussianProcess:
     # ------------------------------------------------------------------------------------------------
     def log_likelihood_concentrated(self, par, env=None, eval_grad=False):
         par = np.asarray(par, dtype=np.float64).ravel()
-        est, beta = self._trend_args()
+        tid, est, beta = self._trend_args()
         mode = self._MODE[self.estimation_mode]
         if not (np.all(np.isfinite(par)) and np.all(par > 0)):
             # L-BFGS-B can step to NaN after an infinite objective; the reference's Cholesky then raises
@@ -214,15 +223,15 @@ class GaussianProcess:
             if env is not None:
                 llf = self._commit(par, refresh_attributes=False)
                 st = self.engine.get_state()
+                Ft, G, Q, b = self._trend_views(st, est)
                 env.update(
                     sigma2=np.atleast_1d(st["sigma2"]), noise_var=st["noise_var"], rho=st["rho"].reshape(-1, 1),
-                    Yt=st["Yt"].reshape(-1, 1), C=st["C"], Ft=st["Ft"].reshape(-1, 1) if est else None,
-                    G=np.array([[st["G"]]]) if est else None, Q=st["Q"].reshape(-1, 1) if est else None,
-                    beta=st["beta"], gamma=st["gamma"].reshape(-1, 1),
+                    Yt=st["Yt"].reshape(-1, 1), C=st["C"], Ft=Ft, G=G, Q=Q,
+                    beta=float(b[0, 0]) if b.size == 1 else b, gamma=st["gamma"].reshape(-1, 1),
                 )  # fmt: skip
                 if not eval_grad:
                     return llf
-            out = self.engine.nll(self.kernel_id, mode, par, self._nv(), est, beta, eval_grad=eval_grad)
+            out = self.engine.nll(self.kernel_id, mode, par, self._nv(), est, beta, eval_grad=eval_grad, trend=tid)
             if self._committed_par is not None:
                 # nll overwrote the factor buffers of the committed model: restore it, so that (as in the reference)
                 # evaluating the likelihood of a fitted model leaves predict() / gradient() untouched
@@ -233,8 +242,8 @@ class GaussianProcess:
             return (-np.inf, np.zeros((len(par), 1))) if eval_grad else -np.inf
 
     def _commit(self, par, refresh_attributes=True) -> float:
-        est, beta = self._trend_args()
-        llf = self.engine.commit(self.kernel_id, self._MODE[self.estimation_mode], par, self._nv(), est, beta)
+        tid, est, beta = self._trend_args()
+        llf = self.engine.commit(self.kernel_id, self._MODE[self.estimation_mode], par, self._nv(), est, beta, trend=tid)
         self._committed_par = np.array(par, dtype=float)
         if refresh_attributes:
             self._pull_state(par)
@@ -252,10 +261,8 @@ class GaussianProcess:
         self.C = st["C"]
         self.gamma = st["gamma"].reshape(-1, 1)
         if self.estimate_trend:
-            self.Ft = st["Ft"].reshape(-1, 1)
-            self.G = np.array([[st["G"]]])
-            self.Q = st["Q"].reshape(-1, 1)
-            self.mean.beta = st["beta"]
+            self.Ft, self.G, self.Q, b = self._trend_views(st, True)
+            self.mean.beta = float(b[0, 0]) if b.size == 1 else b.ravel()
 
     # ------------------------------------------------------------------------------------------------
     # MLE (gpr.py:1042-1197): the host loop is the reference's; every objective evaluation is a device call
@@ -428,6 +435,8 @@ class GaussianProcess:
             raise Exception("x does not have the right size!")
         if x.shape[0] != 1:
             raise Exception("x must be a vector!")
+        if type(self.mean).__name__ == "quadratic_trend":
+            raise NotImplementedError  # quadratic_trend.Jacobian raises in the reference (trend.py:138-139)
         dmu, dmse = self.engine.gradient(x[0])
         return dmu.reshape(-1, 1), dmse.reshape(-1, 1)
 
@@ -436,4 +445,8 @@ class GaussianProcess:
         (its gradient takes one row, gpr.py:548-549); SURVEY.md 8 f2."""
         if self._committed_par is None:
             raise Exception("The model is not fitted yet!")
-        return self.engine.gradient_batch(self._check_X(X))
+        X = self._check_X(X)
+        if self._trend_args()[0] != _lib.TREND_CONSTANT:  # polynomial bases: the batched kernel serves p = 1 only
+            rows = [self.gradient(x.reshape(1, -1)) for x in X]
+            return np.array([r[0].ravel() for r in rows]), np.array([r[1].ravel() for r in rows])
+        return self.engine.gradient_batch(X)

@@ -64,6 +64,8 @@ typedef struct bogp_handle bogp_handle;
 
 /* trend (prior mean) bases: surrogate/gaussian_process/trend.py.  Only the constant basis (p = 1) is built. */
 #define BOGP_TREND_CONSTANT 0
+#define BOGP_TREND_LINEAR 1    /* [1, x]                      trend.py:94-118  */
+#define BOGP_TREND_QUADRATIC 2 /* [1, x, x_k x_j (j >= k)]    trend.py:121-142 */
 
 #define BOGP_MAX_Q 64    /* criteria evaluated in one sweep (ParallelBO batch size q) */
 #define BOGP_MAX_TOPK 32 /* ranks returned per criterion by bogp_sweep_topk */
@@ -107,6 +109,19 @@ int bogp_commit(bogp_handle* h, int kernel, int mode, const double* par, int n_p
  *   noise_var (scalars).                                                                                */
 int bogp_get_state(bogp_handle* h, double* C, double* gamma, double* rho, double* Yt, double* Ft, double* Q,
                    double* G, double* beta, double* sigma2, double* noise_var);
+
+/* ---- polynomial trend bases (trend.py:66-142) --------------------------------------------------------
+ * `trend` in bogp_nll / bogp_commit selects the basis F: BOGP_TREND_CONSTANT (p = 1, the scalar `beta` argument),
+ * BOGP_TREND_LINEAR (p = d + 1), BOGP_TREND_QUADRATIC (p = (d+1)(d+2)/2).  With estimate_trend = 1 the coefficients are
+ * the GLS estimate (universal kriging, gpr.py:801-806: Ft = L^-1 F, Q G = Ft, rho = Yt - Q Q^T Yt, beta = G^-1 Q^T Yt);
+ * with estimate_trend = 0 and p > 1 they are the p values last given to bogp_set_trend_beta (the scalar `beta` argument
+ * is ignored).  The QR factor G has a positive diagonal (LAPACK's Householder G differs by row signs; beta, rho, the
+ * predictor and the likelihood do not depend on them).
+ *   bogp_trend_size       p for a basis id and d
+ *   bogp_get_trend_state  Ft, Q (N x p row-major), G (p x p row-major), beta (p) of the committed model; any may be NULL */
+int bogp_trend_size(int trend, int d);
+int bogp_set_trend_beta(bogp_handle* h, const double* beta, int p);
+int bogp_get_trend_state(bogp_handle* h, double* Ft, double* Q, double* G, double* beta);
 
 /* ---- candidates -----------------------------------------------------------------------------------
  * M x d row-major float64.  `upload` copies from host (PCIe); `bind` adopts caller-owned DEVICE memory

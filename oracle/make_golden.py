@@ -346,5 +346,47 @@ def _g8_outputs(gp, Xs):
     return dict(mu=mu, mse=mse, EI=eiv, argmax_EI=np.array([int(np.argmax(eiv))]))
 
 
+def golden_trends():
+    """G13-G15: polynomial trend bases with p > 1 (trend.py:94-142) through the reference's fit-side and predict-side
+    code: pinned state, predictor, acquisition rows, input gradients (linear only: quadratic_trend.Jacobian raises),
+    likelihood + gradient tables in the three estimation modes."""
+    cases = (
+        # name, trend class, trend id, kernel name, kernel id, N, d, fixed beta
+        ("G13_linear_uk_se", trend.linear_trend, 1, "squared_exponential", 0, 48, 3, None),
+        ("G14_quadratic_uk_m32", trend.quadratic_trend, 2, "matern", 2, 64, 3, None),
+        ("G15_linear_sk_se", trend.linear_trend, 1, "squared_exponential", 0, 40, 4, [0.1, -0.05, 0.02, 0.03, -0.01]),
+    )
+    for seed, (name, tcls, tid, corr, kid, N, d, beta) in enumerate(cases, start=13):
+        X, y = make_data(seed, N, d)
+        # a linear component for the trend to pick up + noise (a quadratic basis would otherwise fit sum(x^2) exactly
+        # and every likelihood would be > 0, i.e. rejected, gpr.py:981-982)
+        y = y + 0.3 * X[:, :1] / 5.0 + 0.25 * np.random.default_rng(300 + seed).standard_normal(y.shape)
+        gp = GaussianProcess(mean=tcls(d, beta=beta), corr=corr, thetaL=[1e-4] * d, thetaU=[1e2] * d, nugget=1e-6)
+        par = np.r_[np.full(d, 0.06) * np.linspace(0.7, 1.4, d), 0.85]
+        llf = pin(gp, X, y, par)
+        rng = np.random.default_rng(100 + seed)
+        Xs = rng.uniform(-5, 5, size=(192, d))
+        mu, mse = gp.predict(Xs, eval_MSE=True)
+        extra = grad_rows(gp, Xs[:8]) if tid == 1 else {}
+        tabs = {}
+        rng2 = np.random.default_rng(200 + seed)
+        for mname, mid, kw in (("noiseless", 0, dict(nugget=0)), ("noisy", 1, dict(nugget=1e-6)), ("noise_estim", 2, dict(nugget=1e-6, noise_estim=True))):
+            g2 = GaussianProcess(mean=tcls(d, beta=beta), corr=corr, thetaL=[1e-4] * d, thetaU=[1e2] * d, **kw)
+            g2._check_data(X, y)
+            pars = []
+            for _ in range(4):
+                th = 10 ** rng2.uniform(-1.6, -0.8, size=d)
+                pars.append(th if mid == 0 else np.r_[th, rng2.uniform(0.4, 1.1) if mid == 1 else rng2.uniform(0.7, 0.999)])
+            v, gr = llf_table(g2, pars)
+            key = "t_m%d" % mid
+            tabs[key + "_par"], tabs[key + "_llf"], tabs[key + "_grad"] = np.array(pars), v, gr
+        save(name, par=par, Xs=Xs, mu=mu, mse=mse, kernel=np.array(kid), mode=np.array(1), trend=np.array(tid),
+             **state_dict(gp, llf), **acq_rows(gp, Xs), **extra, **tabs)  # fmt: skip
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["trends"]:
+        golden_trends()
+    else:
+        main()
+        golden_trends()

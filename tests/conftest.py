@@ -31,4 +31,6 @@ def state_from_golden(g):
     mode, kernel = int(g["mode"]), int(g["kernel"])
     est = bool(g["estimate_trend"]) if "estimate_trend" in g else False
     nv = float(g["noise_var"][0]) if mode == O.MODE_NOISY else 0.0
-    return O.make_state(g["par"], g["X"], g["y"], kernel, mode, noise_var=nv, estimate_trend=est, beta=None if est else 0.0)
+    trend = int(g["trend"]) if "trend" in g else O.TREND_CONSTANT
+    beta = None if est else (np.asarray(g["beta"], float).ravel() if trend != O.TREND_CONSTANT else 0.0)
+    return O.make_state(g["par"], g["X"], g["y"], kernel, mode, noise_var=nv, trend=trend, estimate_trend=est, beta=beta)

@@ -22,16 +22,16 @@ class OracleEngine:
         self.N, self.d = self.X.shape
         self.st = None
 
-    def nll(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False):
-        out = O.log_likelihood_concentrated(par, self.X, self.y, kernel, mode, noise_var, 0, estimate_trend, beta, eval_grad=eval_grad)
+    def nll(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False, trend=0):
+        out = O.log_likelihood_concentrated(par, self.X, self.y, kernel, mode, noise_var, trend, estimate_trend, beta, eval_grad=eval_grad)
         llf = out[0] if eval_grad else out
         if not np.isfinite(llf):
             raise _lib.NotPositiveDefinite(_lib.ERR_NOT_POSDEF, "oracle: -inf")
         return (out[0], np.asarray(out[1], float).ravel()) if eval_grad else out
 
-    def commit(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0):
+    def commit(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, trend=0):
         try:
-            self.st = O.make_state(par, self.X, self.y, kernel, mode, noise_var, estimate_trend=estimate_trend, beta=beta)
+            self.st = O.make_state(par, self.X, self.y, kernel, mode, noise_var, trend=trend, estimate_trend=estimate_trend, beta=beta)
         except np.linalg.LinAlgError as e:
             raise _lib.NotPositiveDefinite(_lib.ERR_NOT_POSDEF, str(e))
         return self.st.llf
@@ -39,6 +39,9 @@ class OracleEngine:
     def get_state(self, with_C=True):
         st = self.st
         z = np.zeros(self.N)
+        if st.trend != 0:  # p > 1: matrices, as bogp_get_trend_state returns them
+            return dict(C=st.C, gamma=st.gamma.ravel(), rho=st.rho.ravel(), Yt=st.Yt.ravel(), Ft=st.Ft, Q=st.Q, G=st.G,
+                        beta=st.beta.ravel(), sigma2=float(st.sigma2[0]), noise_var=st.noise_var)  # fmt: skip
         return dict(C=st.C, gamma=st.gamma.ravel(), rho=st.rho.ravel(), Yt=st.Yt.ravel(),
                     Ft=z if st.Ft is None else st.Ft.ravel(), Q=z if st.Q is None else st.Q.ravel(),
                     G=0.0 if st.G is None else float(st.G[0, 0]), beta=float(st.beta[0, 0]), sigma2=float(st.sigma2[0]),

@@ -38,7 +38,7 @@ def test_ctypes_table_covers_the_header_exactly():
 
 def test_abi_version_and_constants_match_header():
     lib = _lib.load()
-    assert lib.bogp_abi_version() == 1
+    assert lib.bogp_abi_version() == 2
     src = open(HEADER).read()
     consts = dict(re.findall(r"#define\s+(BOGP_[A-Z_0-9]+)\s+\(?(-?\d+)\)?", src))
     assert int(consts["BOGP_KERNEL_MATERN52"]) == _lib.KERNEL_MATERN52 == 3
@@ -47,6 +47,8 @@ def test_abi_version_and_constants_match_header():
     assert int(consts["BOGP_ERR_NOT_POSDEF"]) == _lib.ERR_NOT_POSDEF == -3
     assert int(consts["BOGP_ERR_LLF_POSITIVE"]) == _lib.ERR_LLF_POSITIVE == -6
     assert int(consts["BOGP_MAX_Q"]) == _lib.MAX_Q
+    assert int(consts["BOGP_TREND_QUADRATIC"]) == _lib.TREND_QUADRATIC == 2
+    assert lib.bogp_trend_size(0, 7) == 1 and lib.bogp_trend_size(1, 7) == 8 and lib.bogp_trend_size(2, 7) == 36
 
 
 def test_oracle_ids_match_library_ids():
@@ -56,6 +58,7 @@ def test_oracle_ids_match_library_ids():
     assert _lib.KERNEL_ABSEXP == 4
     assert (O.MODE_NOISELESS, O.MODE_NOISY, O.MODE_NOISE_ESTIM) == (_lib.MODE_NOISELESS, _lib.MODE_NOISY, _lib.MODE_NOISE_ESTIM)
     assert (O.ACQ_EI, O.ACQ_EPSILON_PI, O.ACQ_UCB, O.ACQ_MGFI) == (_lib.ACQ_EI, _lib.ACQ_EPSILON_PI, _lib.ACQ_UCB, _lib.ACQ_MGFI)
+    assert (O.TREND_CONSTANT, O.TREND_LINEAR, O.TREND_QUADRATIC) == (_lib.TREND_CONSTANT, _lib.TREND_LINEAR, _lib.TREND_QUADRATIC)
 
 
 def _has_gpu():

@@ -104,3 +104,27 @@ def test_save_load_roundtrip_through_dill(ref, tmp_path):
     opt2 = BO.load(f)
     assert opt2.model._engine is None  # device/engine handles never travel
     assert opt2.model.is_fitted and np.allclose(opt2.model.theta_, model.theta_)
+
+
+@pytest.mark.timeout(600)
+def test_reference_BO_with_a_linear_trend_model(ref):
+    """Universal kriging (linear_trend, p = d + 1): the host layer's matrix-shaped trend state (Ft, G, Q, beta) under the
+    reference's own BO loop with the gradient-based inner optimiser (which calls model.gradient through EI.return_dx)."""
+    bayes_optim, bogp, OracleEngine = ref
+    from bayes_optim import BO, RealSpace
+
+    np.random.seed(7)
+    dim = 2
+    gp = bogp.GaussianProcess(mean=bogp.trend.linear_trend(dim), corr="squared_exponential", thetaL=[1e-2] * dim, thetaU=[1e2] * dim,
+                              nugget=1e-6, random_start=3, eval_budget=60)  # fmt: skip
+    gp._engine = OracleEngine()
+    opt = BO(search_space=RealSpace([-5, 5]) * dim, obj_fun=lambda x: float(np.sum(np.asarray(x) ** 2) + x[0]), model=gp, DoE_size=6,
+             max_FEs=10, verbose=False, n_point=1, acquisition_fun="EI",
+             acquisition_optimization={"optimizer": "BFGS", "max_FEs": 60, "n_restart": 2}, random_seed=7)  # fmt: skip
+    opt.run()
+    assert opt.eval_count == 10 and gp.is_fitted
+    assert gp.Ft.shape == (gp.X.shape[0], dim + 1) and gp.G.shape == (dim + 1, dim + 1) and np.ravel(gp.mean.beta).shape == (dim + 1,)
+    mu, mse = gp.predict(np.zeros((3, dim)), eval_MSE=True)
+    assert mu.shape == (3, 1) and np.all(mse >= 0)
+    dmu, dmse = gp.gradient(np.zeros((1, dim)))
+    assert dmu.shape == (dim, 1) and dmse.shape == (dim, 1)

@@ -616,3 +616,135 @@ def test_example_loop_minimises_the_sphere():
     spec.loader.exec_module(mod)
     xopt, fopt, n = mod.fmin_sphere()
     assert n == 30 and len(xopt) == 2 and fopt < 0.05
+
+
+# ---- polynomial trends with p > 1 columns (trend.py:94-142) --------------------------------------------
+TREND_FILES = ["G13_linear_uk_se", "G14_quadratic_uk_m32", "G15_linear_sk_se"]
+
+
+def commit_trend_golden(eng, g):
+    est = bool(g["estimate_trend"])
+    beta = 0.0 if est else np.asarray(g["beta"], float).ravel()
+    eng.set_train(g["X"], g["y"])
+    return eng.commit(int(g["kernel"]), int(g["mode"]), g["par"], float(g["noise_var"][0]), est, beta, trend=int(g["trend"]))
+
+
+@pytest.mark.parametrize("name", TREND_FILES)
+def test_trend_state_and_posterior_match_reference(eng, name):
+    g = load_golden(name)
+    llf = commit_trend_golden(eng, g)
+    np.testing.assert_allclose(llf, g["llf"], rtol=1e-9)
+    s = eng.get_state()
+    np.testing.assert_allclose(s["C"], g["C"], rtol=0, atol=1e-11 * np.abs(g["C"]).max())
+    np.testing.assert_allclose(s["gamma"], g["gamma"].ravel(), rtol=1e-6, atol=1e-8 * np.abs(g["gamma"]).max())
+    np.testing.assert_allclose(s["rho"], g["rho"].ravel(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(s["beta"], g["beta"].ravel(), rtol=1e-6, atol=1e-9)
+    if bool(g["estimate_trend"]):
+        p = g["G"].shape[0]
+        assert s["Ft"].shape == g["Ft"].shape and s["G"].shape == (p, p)
+        np.testing.assert_allclose(s["Ft"], g["Ft"], rtol=1e-7, atol=1e-10)
+        # the QR factors are unique up to the signs LAPACK's Householder reflections pick: compare |G| row by row, Q G = Ft
+        # and the orthonormality of Q
+        np.testing.assert_allclose(np.abs(s["G"]), np.abs(g["G"]), rtol=1e-6, atol=1e-9 * np.abs(g["G"]).max())
+        assert np.all(np.diag(s["G"]) > 0) and np.all(np.tril(s["G"], -1) == 0)
+        np.testing.assert_allclose(s["Q"] @ s["G"], g["Ft"], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(s["Q"].T @ s["Q"], np.eye(p), atol=1e-12)
+    eng.upload_candidates(g["Xs"])
+    mu, mse = eng.predict()
+    close_mu(mu, g["mu"])
+    close_mse(mse, g["mse"], g["sigma2"][0])
+    # sweep: criterion values row by row and the argmax of each (np.argmax semantics)
+    st = state_from_golden(g)
+    pl = O.plugin_value(st.y, True)
+    acq = [(a, p) for _, a, p in ACQ_KEYS]
+    best, idx, vals = eng.sweep(acq, pl, True, return_values=True)
+    for (key, _, _), b, i, v in zip(ACQ_KEYS, best, idx, vals):
+        ref = g[key]
+        ok = g["mse"].ravel() > 1e-12 * float(g["sigma2"][0])
+        np.testing.assert_allclose(v[ok], ref[ok], rtol=1e-6, atol=1e-300)
+        assert i == int(g["argmax_" + key][0])
+        np.testing.assert_allclose(b, ref[i], rtol=1e-6)
+    # a batch below the small-batch threshold takes the same (chunked) path for p > 1
+    eng.upload_candidates(g["Xs"][:5])
+    mu5, mse5 = eng.predict()
+    close_mu(mu5, g["mu"][:5])
+    close_mse(mse5, g["mse"][:5], g["sigma2"][0])
+
+
+@pytest.mark.parametrize("name", TREND_FILES)
+def test_trend_likelihood_tables(eng, name):
+    g = load_golden(name)
+    est = bool(g["estimate_trend"])
+    beta = 0.0 if est else np.asarray(g["beta"], float).ravel()
+    eng.set_train(g["X"], g["y"])
+    n = 0
+    for mid in (0, 1, 2):
+        key = "t_m%d" % mid
+        for p, v, gr in zip(g[key + "_par"], g[key + "_llf"], g[key + "_grad"]):
+            try:
+                llf, grad = eng.nll(int(g["kernel"]), mid, p, 1e-6 if mid == 1 else 0.0, est, beta, eval_grad=True, trend=int(g["trend"]))
+            except _lib.NotPositiveDefinite:
+                assert np.isneginf(v)
+                continue
+            np.testing.assert_allclose(llf, v, rtol=1e-9)
+            np.testing.assert_allclose(grad, gr, rtol=1e-6, atol=1e-7 * np.abs(gr).max())
+            n += 1
+    assert n >= 9
+
+
+@pytest.mark.parametrize("name", ["G13_linear_uk_se", "G15_linear_sk_se"])
+def test_trend_input_gradients(eng, name):
+    g = load_golden(name)
+    commit_trend_golden(eng, g)
+    for i in range(len(g["grad_mu"])):
+        dmu, dmse = eng.gradient(g["Xs"][i])
+        np.testing.assert_allclose(dmu, g["grad_mu"][i].ravel(), rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(dmse, g["grad_mse"][i].ravel(), rtol=1e-6, atol=1e-9)
+
+
+def test_quadratic_trend_gradient_is_refused_like_the_reference(eng):
+    g = load_golden("G14_quadratic_uk_m32")
+    commit_trend_golden(eng, g)
+    with pytest.raises(_lib.BogpError):
+        eng.gradient(g["Xs"][0])
+    d = g["X"].shape[1]
+    gp = bogp.GaussianProcess(mean=bogp.trend.quadratic_trend(d), corr="matern", thetaL=[1e-4] * d, thetaU=[1e2] * d, nugget=1e-6)
+    gp.set_state(g["par"], g["X"], g["y"])
+    with pytest.raises(NotImplementedError):
+        gp.gradient(g["Xs"][:1])
+
+
+def test_trend_classes_end_to_end():
+    """The drop-in class with a linear trend: pinned state, attributes in the reference's shapes, predict, gradient,
+    an acquisition with return_dx, and a full fit."""
+    g = load_golden("G13_linear_uk_se")
+    d = g["X"].shape[1]
+    gp = bogp.GaussianProcess(mean=bogp.trend.linear_trend(d), corr="squared_exponential", thetaL=[1e-4] * d, thetaU=[1e2] * d, nugget=1e-6)
+    gp.set_state(g["par"], g["X"], g["y"])
+    assert gp.Ft.shape == g["Ft"].shape and gp.G.shape == g["G"].shape and gp.Q.shape == g["Q"].shape
+    np.testing.assert_allclose(np.ravel(gp.mean.beta), g["beta"].ravel(), rtol=1e-6, atol=1e-9)
+    mu, mse = gp.predict(g["Xs"], eval_MSE=True)
+    close_mu(mu, g["mu"])
+    close_mse(mse, g["mse"], g["sigma2"][0])
+    dmu, dmse = gp.gradient(g["Xs"][:1])
+    np.testing.assert_allclose(dmu.ravel(), g["grad_mu"][0].ravel(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(dmse.ravel(), g["grad_mse"][0].ravel(), rtol=1e-6, atol=1e-9)
+    ei = bogp.EI(model=gp, minimize=True)
+    v, dx = ei(g["Xs"][:1], return_dx=True)
+    np.testing.assert_allclose(np.ravel(v)[0], g["dx_val_EI"][0], rtol=1e-6)
+    np.testing.assert_allclose(np.ravel(dx), g["dx_EI"][0], rtol=1e-5, atol=1e-9)
+    gb = gp.gradient_batch(g["Xs"][:3])
+    np.testing.assert_allclose(gb[0][2], g["grad_mu"][2].ravel(), rtol=1e-6, atol=1e-9)
+    # a real fit with the GLS trend (MLE on the device, universal kriging)
+    fit = bogp.GaussianProcess(mean=bogp.trend.linear_trend(d), corr="squared_exponential", thetaL=[1e-3] * d, thetaU=[1e2] * d,
+                               nugget=1e-6, random_start=2, eval_budget=60)  # fmt: skip
+    np.random.seed(3)
+    assert fit.fit(g["X"], g["y"]) is fit and fit.is_fitted
+    assert np.isfinite(fit.log_likelihood_) and np.ravel(fit.mean.beta).shape == (d + 1,)
+    st = O.make_state(np.r_[fit.theta_, fit.par["sigma2"]], g["X"], g["y"], O.KERNEL_SE, O.MODE_NOISY, 1e-6, trend=O.TREND_LINEAR,
+                      estimate_trend=True, beta=None)  # fmt: skip
+    np.testing.assert_allclose(fit.log_likelihood_, st.llf, rtol=1e-9)
+    rmu, rmse = O.predict(st, g["Xs"])
+    m2, s2 = fit.predict(g["Xs"], eval_MSE=True)
+    close_mu(m2, rmu)
+    close_mse(s2, rmse, st.sigma2[0])

@@ -67,8 +67,17 @@ def test_trend_objects():
     np.testing.assert_array_equal(q.F(X)[:, 5], X[:, 0] * X[:, 1])
     lin = bogp.trend.linear_trend(3)
     assert lin.F(X).shape == (4, 4)
+    assert bogp.trend.device_trend_of(lin) == (1, True, 0.0)
+    tid, est, b = bogp.trend.device_trend_of(bogp.trend.linear_trend(3, beta=[1.0, 2.0, 3.0, 4.0]))
+    assert (tid, est) == (1, False) and b.tolist() == [1.0, 2.0, 3.0, 4.0]
+    assert bogp.trend.device_trend_of(bogp.trend.constant_trend(3, beta=2.0)) == (0, False, 2.0)
+    assert bogp.trend.device_trend_of(q)[0] == 2
+
+    class NonparametricTrend:  # not a basis expansion: no device counterpart
+        beta = None
+
     with pytest.raises(NotImplementedError):
-        bogp.trend.device_trend_of(lin)
+        bogp.trend.device_trend_of(NonparametricTrend())
     with pytest.raises(Exception):
         bogp.trend.constant_trend(3)(X)  # beta not set
     pickle.loads(pickle.dumps(q))

@@ -9,7 +9,7 @@ from oracle import gp_oracle as O
 
 RT = 1e-12
 STATE_FILES = ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G3_m52_sk_noisy", "G4_se_ok_noiseless", "G5_se_sk_noise_estim", "G7_edges",
-               "G12_absexp_ok_noisy"]
+               "G12_absexp_ok_noisy", "G13_linear_uk_se", "G14_quadratic_uk_m32", "G15_linear_sk_se"]
 
 
 def close(a, b, rtol=RT, atol=0.0):
@@ -127,7 +127,8 @@ def test_edge_semantics():
     )  # MGFI(t=100).t == 22.36 (clamp, acquisition_fun.py:260-263)
 
 
-@pytest.mark.parametrize("name", ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G4_se_ok_noiseless", "G12_absexp_ok_noisy"])
+@pytest.mark.parametrize("name", ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G4_se_ok_noiseless", "G12_absexp_ok_noisy",
+                                  "G13_linear_uk_se", "G15_linear_sk_se"])
 def test_gradient_matches_reference(name):
     g = load_golden(name)
     st = state_from_golden(g)
@@ -223,3 +224,30 @@ def test_absexp_llf_tables():
                 close(out[1], gr, rtol=1e-8, atol=1e-9)
                 n += 1
     assert n >= 12
+
+
+@pytest.mark.parametrize("name", ["G13_linear_uk_se", "G14_quadratic_uk_m32", "G15_linear_sk_se"])
+def test_trend_llf_tables(name):
+    """Polynomial trends with p > 1 columns (trend.py:94-142): likelihood + gradient in the three modes."""
+    g = load_golden(name)
+    est = bool(g["estimate_trend"])
+    beta = None if est else np.asarray(g["beta"], float).ravel()
+    n = 0
+    for mid in (0, 1, 2):
+        key = "t_m%d" % mid
+        for p, v, gr in zip(g[key + "_par"], g[key + "_llf"], g[key + "_grad"]):
+            out = O.log_likelihood_concentrated(p, g["X"], g["y"], int(g["kernel"]), mid, noise_var=1e-6 if mid == 1 else 0.0,
+                                                trend=int(g["trend"]), estimate_trend=est, beta=beta, eval_grad=True)  # fmt: skip
+            if np.isneginf(v):
+                assert np.isneginf(out[0])
+                continue
+            close(out[0], v, rtol=1e-11)
+            close(out[1], gr, rtol=1e-8, atol=1e-9)
+            n += 1
+    assert n >= 9
+
+
+def test_quadratic_trend_has_no_jacobian():
+    g = load_golden("G14_quadratic_uk_m32")
+    with pytest.raises(NotImplementedError):
+        O.gradient(state_from_golden(g), g["Xs"][0])
