@@ -32,6 +32,7 @@ SIGNATURES = {
     "bogp_set_train": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_int]),
     "bogp_nll": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp, _dp]),
     "bogp_commit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp]),
+    "bogp_nll_restricted": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp, _dp]),
     "bogp_get_state": (C.c_int, [C.c_void_p] + [_dp] * 10),
     "bogp_trend_size": (C.c_int, [C.c_int, C.c_int]),
     "bogp_set_trend_beta": (C.c_int, [C.c_void_p, _dp, C.c_int]),
@@ -161,6 +162,19 @@ class Engine:
             self._lib.bogp_nll(self._h, kernel, mode, _ptr(par), len(par), float(noise_var), int(trend),
                                int(bool(estimate_trend)), b, C.byref(llf), _ptr(grad))
         )  # fmt: skip
+        return (llf.value, grad) if eval_grad else llf.value
+
+    def nll_restricted(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False):
+        """Restricted (REML) log-likelihood, gpr.py:813-918.  exp(llf) > 1 gives -inf WITH the gradient of the finite
+        value, as the reference returns it; a failed factorisation raises NotPositiveDefinite."""
+        par = _f64(par).ravel()
+        llf = C.c_double()
+        grad = np.zeros(len(par)) if eval_grad else None
+        rc = self._lib.bogp_nll_restricted(self._h, kernel, mode, _ptr(par), len(par), float(noise_var), TREND_CONSTANT,
+                                           int(bool(estimate_trend)), float(beta), C.byref(llf), _ptr(grad))  # fmt: skip
+        if rc == ERR_LLF_POSITIVE:
+            return (-np.inf, grad) if eval_grad else -np.inf
+        self._check(rc)
         return (llf.value, grad) if eval_grad else llf.value
 
     def commit(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, trend=TREND_CONSTANT) -> float:

@@ -249,7 +249,7 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
 // factorise at `par` (shared by bogp_nll and bogp_commit)
 // ------------------------------------------------------------------------------------------------------
 struct FitOut {
-  double llf = 0, sigma2 = 0, noise_var = 0, s2t = 0, G = 0, beta = 0, ftyt = 0, ftft = 0;
+  double llf = 0, sigma2 = 0, noise_var = 0, s2t = 0, G = 0, beta = 0, ftyt = 0, ftft = 0, logdet = 0, rho_ss = 0;
 };
 
 static int trend_size(int trend, int d) {
@@ -352,7 +352,8 @@ static int trend_solve(bogp_handle* h, int trend, int estimate_trend) {
 }
 
 static int factorize(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
-                     int estimate_trend, double beta, bool want_gamma, FitOut* o, std::vector<double>* theta_out) {
+                     int estimate_trend, double beta, bool want_gamma, FitOut* o, std::vector<double>* theta_out,
+                     bool reject_positive = true) {
   if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "no training set: call bogp_set_train first");
   if (kernel < 0 || kernel > BOGP_KERNEL_ABSEXP) FAIL(h, BOGP_ERR_INVALID, "unknown kernel id %d", kernel);
   if (mode < 0 || mode > 2) FAIL(h, BOGP_ERR_INVALID, "unknown estimation mode %d", mode);
@@ -453,8 +454,9 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
     llf = -0.5 * (N * std::log(TWO_PI * s2t) + 2.0 * logdet + rho_ss / s2t);
   }
   if (!std::isfinite(llf)) FAIL(h, BOGP_ERR_NOT_POSDEF, "log-likelihood is not finite (%g): degenerate factorisation", llf);
+  o->logdet = logdet; o->rho_ss = rho_ss;
   o->llf = llf; o->sigma2 = sigma2; o->noise_var = nv; o->s2t = s2t; o->G = G; o->beta = beta_eff; o->ftyt = ftyt; o->ftft = ftft;
-  if (llf > 0) FAIL(h, BOGP_ERR_LLF_POSITIVE, "log-likelihood %g > 0 is rejected by the reference (gpr.py:981-982)", llf);
+  if (llf > 0 && reject_positive) FAIL(h, BOGP_ERR_LLF_POSITIVE, "log-likelihood %g > 0 is rejected by the reference (gpr.py:981-982)", llf);
 
   return BOGP_OK;
 }
@@ -479,14 +481,14 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
   if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * ldr * ldr * sizeof(double)));
   HIPCHK(h, launch_uut(h->dU, h->dRinv, ldr, st));  // R^-1 = L^-T L^-1, lower triangle
   const int nblk = grad_contract_blocks(N);
-  int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)nblk * (d + 1) + (d + 3));
+  int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)nblk * (d + 1) + (d + 4));
   if (e) return e;
   const double c1 = 1.0 / (mode == BOGP_MODE_NOISELESS ? o.sigma2 : o.s2t);
-  HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, h->dgamma, c1, h->dRinv, ldr, UUT_PARTS, (size_t)ldr * ldr, h->dgrad_partial, nblk, st));
+  HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, h->dgamma, c1, nullptr, 0.0, h->dRinv, ldr, UUT_PARTS, (size_t)ldr * ldr, h->dgrad_partial, nblk, st));
   double* dS = h->dgrad_partial + (size_t)nblk * (d + 1);
   HIPCHK(h, launch_grad_reduce(h->dgrad_partial, nblk, d + 1, dS, st));
   std::vector<double> S(d + 3);
-  if (mode == BOGP_MODE_NOISY) HIPCHK(h, launch_trace_gg(h->dRinv, ldr, UUT_PARTS, (size_t)ldr * ldr, N, h->dgamma, dS + d + 1, st));
+  if (mode == BOGP_MODE_NOISY) HIPCHK(h, launch_trace_gg(h->dRinv, ldr, UUT_PARTS, (size_t)ldr * ldr, N, h->dgamma, nullptr, dS + d + 1, st));
   HIPCHK(h, hipMemcpyAsync(S.data(), dS, (d + 3) * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   const double tr = S[d + 1], gg = S[d + 2];
@@ -503,6 +505,73 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
   return BOGP_OK;
 }
 
+// Restricted likelihood (gpr.py:813-918).  par: noiseless [theta, sigma2]; noisy [theta, sigma2] + the fixed noise_var
+// argument; noise_estim [theta, sigma2, noise_var].  The factorisation is the NOISY-mode one (R = (sigma2 R0 + nv I) /
+// (sigma2 + nv), :836-839), so the device work is shared with bogp_nll; only the scalar formula and the extra
+// (L^-T Q)(L^-T Q)^T term of the gradient differ.  Returns BOGP_ERR_LLF_POSITIVE when exp(llf) > 1 (:868-871) -- with the
+// gradient of the finite value filled in, as the reference returns it.
+extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var,
+                                   int trend, int estimate_trend, double beta, double* llf, double* grad) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!par || !llf || n_par <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_nll_restricted: par/llf must be non-null");
+  if (mode < 0 || mode > 2) FAIL(h, BOGP_ERR_INVALID, "unknown estimation mode %d", mode);
+  if (trend != BOGP_TREND_CONSTANT) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_restricted: only the constant trend basis is built (trend id %d)", trend);
+  h->committed = false;
+  const int n_tail = mode == BOGP_MODE_NOISE_ESTIM ? 2 : 1;
+  const int n_theta = n_par - n_tail;
+  if (n_theta <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_nll_restricted: %d parameters for mode %d", n_par, mode);
+  const double sigma2 = par[n_theta];
+  const double nv = mode == BOGP_MODE_NOISELESS ? 0.0 : (mode == BOGP_MODE_NOISY ? noise_var : par[n_theta + 1]);
+  if (!(sigma2 > 0) || !(nv >= 0) || !std::isfinite(sigma2) || !std::isfinite(nv)) FAIL(h, BOGP_ERR_INVALID, "bogp_nll_restricted: sigma2 = %g, noise_var = %g", sigma2, nv);
+  std::vector<double> p2(par, par + n_theta + 1);  // [theta, sigma2]
+  FitOut o;
+  *llf = -INFINITY;
+  int rc = factorize(h, kernel, BOGP_MODE_NOISY, p2.data(), n_theta + 1, nv, trend, estimate_trend, beta, grad != nullptr, &o, nullptr, false);
+  if (rc != BOGP_OK) return rc;
+  const int N = h->N, d = h->d, ldr = h->ldr;
+  const double tv = sigma2 + nv, TWO_PI = 2.0 * 3.141592653589793;
+  double v;
+  if (estimate_trend)  // p = 1: det(F^T F) = N, prod(diag G)^2 = |Ft|^2  (:850-860)
+    v = -0.5 * ((N - 1) * std::log(TWO_PI * tv) - std::log((double)N) + 2.0 * o.logdet + std::log(o.ftft) + o.rho_ss / tv);
+  else  // the reference SUBTRACTS the log-determinant here (:861-866)
+    v = -0.5 * (N * std::log(TWO_PI * tv) - 2.0 * o.logdet + o.rho_ss / tv);
+  if (!std::isfinite(v)) FAIL(h, BOGP_ERR_NOT_POSDEF, "restricted log-likelihood is not finite (%g)", v);
+  const bool positive = v > 0;  // exp(llf) > 1
+  *llf = v;
+  if (grad) {
+    if (n_theta != d) FAIL(h, BOGP_ERR_UNSUPPORTED, "gradient with isotropic theta (len %d, d = %d) is not built", n_theta, d);
+    hipStream_t st = h->stream;
+    if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * ldr * ldr * sizeof(double)));
+    HIPCHK(h, launch_uut(h->dU, h->dRinv, ldr, st));
+    const double* qv = nullptr;
+    double c2 = 0.0;
+    if (estimate_trend) {  // q = L^-T Q = (L^-T Ft) / G
+      HIPCHK(h, hipMemsetAsync(h->dw, 0, h->Np * sizeof(double), st));
+      HIPCHK(h, launch_gemv2(h->dU, ldr, N, 2, h->dft, nullptr, h->dw, nullptr, h->dgemv_scratch, st));
+      qv = h->dw;
+      c2 = tv / o.ftft;
+    }
+    const int nblk = grad_contract_blocks(N);
+    int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)nblk * (d + 1) + (d + 4));
+    if (e) return e;
+    HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, h->dgamma, 1.0 / tv, qv, c2, h->dRinv, ldr, UUT_PARTS,
+                                   (size_t)ldr * ldr, h->dgrad_partial, nblk, st));
+    double* dS = h->dgrad_partial + (size_t)nblk * (d + 1);
+    HIPCHK(h, launch_grad_reduce(h->dgrad_partial, nblk, d + 1, dS, st));
+    HIPCHK(h, launch_trace_gg(h->dRinv, ldr, UUT_PARTS, (size_t)ldr * ldr, N, h->dgamma, qv, dS + d + 1, st));
+    std::vector<double> S(d + 4);
+    HIPCHK(h, hipMemcpyAsync(S.data(), dS, (d + 4) * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    const double tr = S[d + 1], gg = S[d + 2], qq = estimate_trend ? S[d + 3] / o.ftft : 0.0;
+    const double diag = -0.5 * (tr / tv - gg / (tv * tv) - qq);  // sum over the diagonal of (Cinv - gamma_ gamma_^T - term)
+    for (int k = 0; k < d; ++k) grad[k] = S[k];
+    grad[d] = S[d] / tv + diag;                              // d / d sigma2: C_grad = R0 (:883)
+    if (mode == BOGP_MODE_NOISE_ESTIM) grad[d + 1] = diag;   // d / d noise_var: C_grad = I (:885-887)
+  }
+  if (positive) FAIL(h, BOGP_ERR_LLF_POSITIVE, "restricted log-likelihood %g > 0 is rejected by the reference (gpr.py:868-871)", v);
+  return BOGP_OK;
+}
+
 extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
                            int estimate_trend, double beta, double* llf) {
   if (!h) return BOGP_ERR_INVALID;
@@ -510,7 +579,9 @@ extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* p
   h->committed = false;
   FitOut o;
   std::vector<double> th;
-  int rc = factorize(h, kernel, mode, par, n_par, noise_var, trend, estimate_trend, beta, true, &o, &th);
+  // committing builds a state; rejecting llf > 0 is a rule of the likelihood EVALUATION (bogp_nll), and the REML path
+  // commits at parameters whose concentrated value may well be positive
+  int rc = factorize(h, kernel, mode, par, n_par, noise_var, trend, estimate_trend, beta, true, &o, &th, false);
   if (llf) *llf = o.llf;
   if (rc != BOGP_OK) return rc;
   const int N = h->N, d = h->d, Np = h->Np;

@@ -95,8 +95,8 @@ constexpr int UUT_PARTS = 4;  // R^-1 = U U^T is produced as this many K-slices 
 hipError_t launch_uut(const double* U, double* Rinv, int ld, hipStream_t st);
 hipError_t launch_copy_lower(const double* L, int N, int ld, double* dst, hipStream_t st);
 hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const double* theta, const double* gamma,
-                                double c1, const double* Rinv, int ld, int nparts, size_t part_stride, double* partial, int nblk,
-                                hipStream_t st);
+                                double c1, const double* qv, double c2, const double* Rinv, int ld, int nparts,
+                                size_t part_stride, double* partial, int nblk, hipStream_t st);
 hipError_t launch_grad_reduce(const double* partial, int nblk, int nout, double* out, hipStream_t st);
 int grad_contract_blocks(int N);
 size_t gemv2_scratch_doubles(int N);
@@ -110,8 +110,8 @@ hipError_t launch_gemv2(const double* M, int ld, int N, int tri, const double* x
                         double* scratch, hipStream_t st);
 hipError_t launch_fit_rho(const double* Yt, const double* Ft, int N, int estimate_trend, double beta, double* rho, double* scal,
                           hipStream_t st);
-hipError_t launch_trace_gg(const double* Rinv, int ld, int nparts, size_t part_stride, int N, const double* gamma, double* out,
-                           hipStream_t st);
+hipError_t launch_trace_gg(const double* Rinv, int ld, int nparts, size_t part_stride, int N, const double* gamma,
+                           const double* qv, double* out, hipStream_t st);
 hipError_t launch_point_corr(int kernel, const double* X, int N, int d, const double* theta, const double* x,
                              double* r, double* rdx, hipStream_t st);
 

@@ -249,25 +249,29 @@ hipError_t launch_sumsq(const double* v, int N, double* out, hipStream_t st) {
   return hipGetLastError();
 }
 
-// out[0] = trace(Rinv), out[1] = gamma . gamma   (the sigma2 derivative of the NOISY likelihood, gpr.py:1030-1036)
+// out[0] = trace(Rinv), out[1] = gamma . gamma, out[2] = qv . qv (0 without qv)   (the sigma2 derivative of the NOISY likelihood, gpr.py:1030-1036)
 __global__ __launch_bounds__(1024) void k_trace_gg(const double* __restrict__ Rinv, int ld, int nparts, size_t part_stride, int N,
-                                                   const double* __restrict__ gamma, double* __restrict__ out) {
+                                                   const double* __restrict__ gamma, const double* __restrict__ qv,
+                                                   double* __restrict__ out) {
   __shared__ double red[16];
-  double tr = 0.0, gg = 0.0;
+  double tr = 0.0, gg = 0.0, qq = 0.0;
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
     for (int q = 0; q < nparts; ++q) tr += Rinv[q * part_stride + (size_t)i * ld + i];
     gg = __builtin_fma(gamma[i], gamma[i], gg);
+    if (qv) qq = __builtin_fma(qv[i], qv[i], qq);
   }
   tr = block_sum_1024(tr, red);
   gg = block_sum_1024(gg, red);
+  qq = block_sum_1024(qq, red);
   if (threadIdx.x == 0) {
     out[0] = tr;
     out[1] = gg;
+    out[2] = qq;
   }
 }
-hipError_t launch_trace_gg(const double* Rinv, int ld, int nparts, size_t part_stride, int N, const double* gamma, double* out,
-                           hipStream_t st) {
-  hipLaunchKernelGGL(k_trace_gg, dim3(1), 1024, 0, st, Rinv, ld, nparts, part_stride, N, gamma, out);
+hipError_t launch_trace_gg(const double* Rinv, int ld, int nparts, size_t part_stride, int N, const double* gamma,
+                           const double* qv, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_trace_gg, dim3(1), 1024, 0, st, Rinv, ld, nparts, part_stride, N, gamma, qv, out);
   return hipGetLastError();
 }
 
@@ -351,6 +355,7 @@ template <int KERNEL>
 __global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict__ X, int N, int d,
                                                        const double* __restrict__ theta,
                                                        const double* __restrict__ gamma, double c1,
+                                                       const double* __restrict__ qv, double c2,
                                                        const double* __restrict__ Rinv, int ld, int nparts,
                                                        size_t part_stride, double* __restrict__ partial, int ntile) {
   __shared__ double red[256];
@@ -375,6 +380,7 @@ __global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict_
     double rinv = 0.0;  // element (j, i) of the lower triangle, column-major; R^-1 arrives as nparts K-slices of U U^T
     for (int q = 0; q < nparts; ++q) rinv += Rinv[q * part_stride + (size_t)i * ld + j];
     A = gamma[i] * gamma[j] * c1 - rinv;
+    if (qv) A += qv[i] * qv[j] * c2;  // REML: the (L^-T Q)(L^-T Q)^T term of gpr.py:876-878, 896-898
   }
   double* out = partial + (size_t)blockIdx.x * (d + 1);
   for (int k = 0; k <= d; ++k) {
@@ -402,15 +408,15 @@ int grad_contract_blocks(int N) {
   return nt * (nt + 1) / 2;
 }
 hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const double* theta, const double* gamma,
-                                double c1, const double* Rinv, int ld, int nparts, size_t part_stride, double* partial, int nblk,
-                                hipStream_t st) {
+                                double c1, const double* qv, double c2, const double* Rinv, int ld, int nparts,
+                                size_t part_stride, double* partial, int nblk, hipStream_t st) {
   const int nt = (N + 15) / 16;
   switch (kernel) {
-    case BOGP_KERNEL_SE: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_SE>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, nparts, part_stride, partial, nt); break;
-    case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN12>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, nparts, part_stride, partial, nt); break;
-    case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN32>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, nparts, part_stride, partial, nt); break;
-    case BOGP_KERNEL_ABSEXP: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_ABSEXP>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, nparts, part_stride, partial, nt); break;
-    default: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN52>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, Rinv, ld, nparts, part_stride, partial, nt); break;
+    case BOGP_KERNEL_SE: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_SE>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, qv, c2, Rinv, ld, nparts, part_stride, partial, nt); break;
+    case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN12>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, qv, c2, Rinv, ld, nparts, part_stride, partial, nt); break;
+    case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN32>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, qv, c2, Rinv, ld, nparts, part_stride, partial, nt); break;
+    case BOGP_KERNEL_ABSEXP: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_ABSEXP>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, qv, c2, Rinv, ld, nparts, part_stride, partial, nt); break;
+    default: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN52>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, qv, c2, Rinv, ld, nparts, part_stride, partial, nt); break;
   }
   return hipGetLastError();
 }

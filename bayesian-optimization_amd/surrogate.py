@@ -7,8 +7,10 @@ keywords as the reference (`surrogate/gaussian_process/gpr.py:211-228`).  All O(
 the MLE (`gpr.py:1058-1197`) and input validation.  There is no CPU fallback.
 
 Differences from the reference, all deliberate and listed in DESIGN.md:
-  * `optimizer="CMA"`, `likelihood="restricted"`, multi-target y: NotImplementedError (out of scope / "next" rows)
-    instead of running on the CPU.  The three polynomial trends (constant / linear / quadratic) are all on the device.
+  * `optimizer="CMA"`, multi-target y: NotImplementedError (out of scope / "next" rows) instead of running on the CPU.
+    The three polynomial trends (constant / linear / quadratic) are all on the device.
+  * `likelihood="restricted"` (REML, gpr.py:813-918) is evaluated on the device AND `fit` completes with it; the
+    reference's own `fit` raises TypeError at gpr.py:405 after the optimisation (sigma2 comes back as a scalar).
   * Matern-5/2 (`corr=functools.partial(matern, nu=2.5)` or `"matern52"`) can be FITTED: the device has its
     theta- and x-derivatives, which the reference leaves as `pass` (gpr.py:647-648, 758-759).
   * `predict(batch_size=...)` works (the reference's branch is dead code on Python 3, gpr.py:513-535); chunking
@@ -144,7 +146,7 @@ class GaussianProcess:
             if hasattr(self, "X"):
                 self._engine.set_train(self.X, self.y)
                 if self._committed_par is not None:
-                    self._commit(self._committed_par, refresh_attributes=False)
+                    self._commit(self._committed_par, refresh_attributes=False, restricted=getattr(self, "_committed_restricted", False))
         return self._engine
 
     def __getstate__(self):
@@ -185,8 +187,8 @@ class GaussianProcess:
             raise ValueError("optimizer should be one of %s" % self._optimizer_types)
         if self.optimizer == "CMA":
             raise NotImplementedError("optimizer='CMA' is out of scope (SURVEY.md 2 row 8); use 'BFGS'")
-        if self.likelihood == "restricted":
-            raise NotImplementedError("likelihood='restricted' (REML, gpr.py:813-918) is a 'next' row; use 'concentrated'")
+        if self.likelihood == "restricted" and type(self.mean).__name__ != "constant_trend":
+            raise NotImplementedError("likelihood='restricted' is built for the constant trend basis only")
 
     def _check_data(self, X, y):
         """gpr.py:279-310 without the pair-distance list (never built on the device)."""
@@ -221,7 +223,9 @@ class GaussianProcess:
             return (-np.inf, np.zeros((len(par), 1))) if eval_grad else -np.inf
         try:
             if env is not None:
-                llf = self._commit(par, refresh_attributes=False)
+                llf = self._commit(par, refresh_attributes=False, restricted=False)
+                if llf > 0:  # rejected before env is touched (gpr.py:981-982); bogp_commit itself only builds the state
+                    return (-np.inf, np.zeros((len(par), 1))) if eval_grad else -np.inf
                 st = self.engine.get_state()
                 Ft, G, Q, b = self._trend_views(st, est)
                 env.update(
@@ -235,14 +239,53 @@ class GaussianProcess:
             if self._committed_par is not None:
                 # nll overwrote the factor buffers of the committed model: restore it, so that (as in the reference)
                 # evaluating the likelihood of a fitted model leaves predict() / gradient() untouched
-                self._commit(self._committed_par, refresh_attributes=False)
+                self._commit(self._committed_par, refresh_attributes=False, restricted=getattr(self, "_committed_restricted", False))
             return out
         except _lib.NotPositiveDefinite:
             # Cholesky failure or llf > 0: the reference's -inf convention (gpr.py:946-947, 981-982)
             return (-np.inf, np.zeros((len(par), 1))) if eval_grad else -np.inf
 
-    def _commit(self, par, refresh_attributes=True) -> float:
+    def _split_restricted(self, par):
+        """(theta, sigma2, noise_var) of a REML parameter vector (gpr.py:826-834)."""
+        par = np.asarray(par, dtype=np.float64).ravel()
+        if self.estimation_mode == "noise_estim":
+            return par[:-2], float(par[-2]), float(par[-1])
+        return par[:-1], float(par[-1]), (self._nv() if self.estimation_mode == "noisy" else 0.0)
+
+    def log_likelihood_restricted(self, par, env=None, eval_grad=False):
+        """The restricted likelihood of gpr.py:813-918 on the device (same return convention as the concentrated one:
+        llf or (llf, d llf / d par), -inf where the reference gives -inf).  `env` receives what the reference puts
+        there (:902-911) -- the NOISY-mode factorisation at (theta, sigma2, noise_var), which is also the state `fit`
+        commits for prediction."""
+        par = np.asarray(par, dtype=np.float64).ravel()
         tid, est, beta = self._trend_args()
+        if not (np.all(np.isfinite(par)) and np.all(par > 0)):
+            return (-np.inf, np.zeros((len(par), 1))) if eval_grad else -np.inf
+        try:
+            if env is not None:
+                self._commit(par, refresh_attributes=False, restricted=True)
+                st = self.engine.get_state()
+                Ft, G, Q, b = self._trend_views(st, est)
+                env.update(sigma2=np.atleast_1d(st["sigma2"]), noise_var=st["noise_var"], rho=st["rho"].reshape(-1, 1),
+                           Yt=st["Yt"].reshape(-1, 1), C=st["C"], Ft=Ft, G=G, Q=Q, gamma=st["gamma"].reshape(-1, 1))  # fmt: skip
+            out = self.engine.nll_restricted(self.kernel_id, self._MODE[self.estimation_mode], par, self._nv(), est, beta, eval_grad=eval_grad)
+            if self._committed_par is not None:
+                self._commit(self._committed_par, refresh_attributes=False, restricted=getattr(self, "_committed_restricted", False))
+            return out
+        except _lib.NotPositiveDefinite:
+            return (-np.inf, np.zeros((len(par), 1))) if eval_grad else -np.inf
+
+    def _commit(self, par, refresh_attributes=True, restricted=None) -> float:
+        tid, est, beta = self._trend_args()
+        restricted = (self.likelihood == "restricted") if restricted is None else restricted
+        self._committed_restricted = restricted  # how `_committed_par` is to be read when the state is rebuilt
+        if restricted:  # R = (sigma2 R0 + nv I) / (sigma2 + nv): the NOISY-mode state (gpr.py:836-839)
+            theta, s2, nv = self._split_restricted(par)
+            llf = self.engine.commit(self.kernel_id, _lib.MODE_NOISY, np.r_[theta, s2], nv, est, beta, trend=tid)
+            self._committed_par = np.array(par, dtype=float)
+            if refresh_attributes:
+                self._pull_state(par)
+            return llf
         llf = self.engine.commit(self.kernel_id, self._MODE[self.estimation_mode], par, self._nv(), est, beta, trend=tid)
         self._committed_par = np.array(par, dtype=float)
         if refresh_attributes:
@@ -274,17 +317,19 @@ class GaussianProcess:
                 bounds.append(np.c_[self.thetaL, self.thetaU])
             elif name == "sigma2":
                 bounds.append(np.atleast_2d([1e-5, max(1e-3, self.y.std() ** 2)]))
-            elif name == "alpha":
+            elif name in ("alpha", "noise_var"):  # noise_var: the reference's "TODO" bound (gpr.py:1052-1054)
                 bounds.append(np.atleast_2d([1e-10, 1.0 - 1e-10]))
         return np.concatenate(bounds, axis=0)
 
     def _optimize_hyperparameter(self):
+        restricted = self.likelihood == "restricted"
+        llf_fun = self.log_likelihood_restricted if restricted else self.log_likelihood_concentrated
         par_list, par_len = ["theta"], [len(self.thetaL)]
-        if self.estimation_mode == "noisy":
+        if restricted or self.estimation_mode == "noisy":  # gpr.py:1075-1078
             par_list.append("sigma2")
             par_len.append(1)
-        if self.estimation_mode == "noise_estim":
-            par_list.append("alpha")
+        if self.estimation_mode == "noise_estim":  # :1080-1086
+            par_list.append("noise_var" if restricted else "alpha")
             par_len.append(1)
         bounds = self._hyperparameter_bound(par_list)
         log10bounds = np.log10(bounds)
@@ -298,7 +343,7 @@ class GaussianProcess:
                 if self.theta0 is not None
                 else np.random.uniform(np.log10(self.thetaL), np.log10(self.thetaU))
             )
-        if self.estimation_mode == "noiseless":
+        if self.estimation_mode == "noiseless" and not restricted:  # :1104-1107
             log10param = log10theta0
         else:
             log10param = np.r_[log10theta0, np.random.uniform(log10bounds[n_theta:, 0], log10bounds[n_theta:, 1])]
@@ -312,7 +357,7 @@ class GaussianProcess:
             # gpr.py:1113-1123); reproduced so that the optimiser walks the reference's trajectory
             self.eval_count += 1
             param = 10.0 ** np.array(log10param)
-            llf, grad = self.log_likelihood_concentrated(param, eval_grad=True)
+            llf, grad = llf_fun(param, eval_grad=True)
             return -1.0 * llf, -1.0 * np.asarray(grad, dtype=float).ravel()
 
         # Restarts: sequential with a shared budget and stagnation counter, as the reference (gpr.py:1127-1162).
@@ -354,7 +399,7 @@ class GaussianProcess:
 
         optimal_param = 10.0**param_opt
         env = {}
-        optimal_llf_value = self.log_likelihood_concentrated(optimal_param, env)
+        optimal_llf_value = llf_fun(optimal_param, env)  # :1185-1188
         param, i = {}, 0
         for name, len_ in zip(par_list, par_len):
             param[name] = optimal_param[i : i + len_]

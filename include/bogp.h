@@ -110,6 +110,16 @@ int bogp_commit(bogp_handle* h, int kernel, int mode, const double* par, int n_p
 int bogp_get_state(bogp_handle* h, double* C, double* gamma, double* rho, double* Yt, double* Ft, double* Q,
                    double* G, double* beta, double* sigma2, double* noise_var);
 
+/* ---- restricted (REML) likelihood ---------------------------------------------------------------------
+ * Replaces GaussianProcess.log_likelihood_restricted(par, eval_grad) (gpr.py:813-918).  Parameter layout (:826-834):
+ * NOISELESS [theta, sigma2]; NOISY [theta, sigma2] with the fixed `noise_var`; NOISE_ESTIM [theta, sigma2, noise_var].
+ * Constant trend basis only.  Quirks kept: the simple-kriging value subtracts the log-determinant term (:861-866);
+ * exp(llf) > 1 is rejected (:868-871): BOGP_ERR_LLF_POSITIVE, with *llf = the finite value and grad (if requested)
+ * filled as the reference returns it.  The state for prediction at REML parameters is the NOISY-mode one:
+ * bogp_commit(mode = BOGP_MODE_NOISY, par = [theta, sigma2], noise_var).                                       */
+int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
+                        int estimate_trend, double beta, double* llf, double* grad);
+
 /* ---- polynomial trend bases (trend.py:66-142) --------------------------------------------------------
  * `trend` in bogp_nll / bogp_commit selects the basis F: BOGP_TREND_CONSTANT (p = 1, the scalar `beta` argument),
  * BOGP_TREND_LINEAR (p = d + 1), BOGP_TREND_QUADRATIC (p = (d+1)(d+2)/2).  With estimate_trend = 1 the coefficients are

@@ -336,6 +336,88 @@ def log_likelihood_concentrated(
     return llf.sum(), g.sum(axis=1)
 
 
+def log_likelihood_restricted(
+    par: np.ndarray,
+    X: np.ndarray,
+    y: np.ndarray,
+    kernel: int,
+    mode: int,
+    noise_var=0.0,
+    trend: int = TREND_CONSTANT,
+    estimate_trend: bool = False,
+    beta=None,
+    eval_grad: bool = False,
+    env: Optional[dict] = None,
+):
+    """Restricted (REML) log-likelihood (+ gradient w.r.t. `par`).  gpr.py:813-918.
+
+    Parameter layouts (:826-834): noiseless [theta, sigma2] (noise 0); noisy [theta, sigma2] with the model's fixed
+    noise_var; noise_estim [theta, sigma2, noise_var].  Quirks kept: the simple-kriging branch SUBTRACTS the
+    log-determinant term (:861-866); `beta hat` is not differentiated (:896); `exp(llf) > 1` -> -inf (:868-871), after
+    which the gradient is still the one of the finite value (:873-900).  Single target.
+    """
+    par = np.asarray(par, dtype=np.float64)
+    y = y.reshape(len(y), -1)
+    n, n_par = X.shape[0], len(par)
+    if mode == MODE_NOISELESS:
+        theta, sigma2, nv = par[:-1], par[-1], 0.0
+    elif mode == MODE_NOISY:
+        theta, sigma2, nv = par[:-1], par[-1], float(np.ravel(noise_var)[0])
+    elif mode == MODE_NOISE_ESTIM:
+        theta, sigma2, nv = par[:-2], par[-2], par[-1]
+    else:
+        raise ValueError("unknown mode")
+    Fx = trend_F(trend, X)
+    F = Fx if estimate_trend else None
+    mean_vec = None
+    if not estimate_trend:
+        b = np.asarray(beta if beta is not None else 0.0, dtype=np.float64)
+        b = np.full((Fx.shape[1], 1), float(b)) if b.ndim == 0 else b.reshape(Fx.shape[1], -1)
+        mean_vec = Fx.dot(b)
+    R0 = correlation_matrix(kernel, theta, X)
+    total_var = sigma2 + nv
+    C = sigma2 * R0 + nv * np.eye(n)
+    R = C / total_var
+    try:
+        L, Ft, Yt, Q, G, rho = compute_aux_var(R, y, F, mean_vec)
+    except (np.linalg.LinAlgError, ValueError):  # :841-848
+        return (-np.inf, np.zeros((n_par, 1))) if eval_grad else -np.inf
+    if estimate_trend:  # :850-860
+        p = Ft.shape[1]
+        llf = -0.5 * (
+            (n - p) * np.log(2.0 * np.pi * total_var)
+            - np.log(np.linalg.det(Fx.T.dot(Fx)))
+            + 2.0 * np.log(np.diag(L)).sum()
+            + np.log(np.diag(G).prod() ** 2)
+            + rho.T.dot(rho) / total_var
+        ).sum()
+    else:  # :861-866, sign of the log-determinant as in the reference
+        llf = -0.5 * (n * np.log(2.0 * np.pi * total_var) - 2.0 * np.log(np.diag(L)).sum() + rho.T.dot(rho) / total_var).sum()
+    llf_ret = -np.inf if np.exp(llf) > 1 else float(llf)
+    if env is not None:
+        env.update(sigma2=sigma2, noise_var=nv, rho=rho, Yt=Yt, C=L, Ft=Ft, G=G, Q=Q)
+    if not eval_grad:
+        return llf_ret
+    gamma_ = solve_triangular(L.T, rho).reshape(-1, 1) / total_var  # :874-875
+    Cinv = cho_solve((L, True), np.eye(n)) / total_var
+    term = None
+    if estimate_trend:
+        q = solve_triangular(L.T, Q)
+        term = q.dot(q.T)
+    T = total_var * corr_grad_theta(kernel, theta, X, R0)  # :881-887
+    T = np.concatenate([T, R0[..., np.newaxis]], axis=2)
+    if mode == MODE_NOISE_ESTIM:
+        T = np.concatenate([T, np.eye(n)[..., np.newaxis]], axis=2)
+    g = np.zeros((n_par, 1))
+    for i in range(n_par):  # :889-900
+        Cg = T[:, :, i]
+        v = np.sum(Cinv * Cg) - gamma_.T.dot(Cg).dot(gamma_)
+        if estimate_trend:
+            v = v - np.sum(term * Cg)
+        g[i] = -0.5 * v
+    return llf_ret, g.ravel()
+
+
 def make_state(
     par, X, y, kernel, mode, noise_var=0.0, trend=TREND_CONSTANT, estimate_trend=False, beta=None
 ) -> GPState:

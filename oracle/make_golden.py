@@ -384,9 +384,44 @@ def golden_trends():
              **state_dict(gp, llf), **acq_rows(gp, Xs), **extra, **tabs)  # fmt: skip
 
 
+def golden_reml():
+    """G16: the restricted likelihood (gpr.py:813-918) and its gradient as the reference computes them, three modes x
+    {simple, ordinary kriging} x {SE, Matern-3/2}.  Only the FUNCTION is a golden: `fit(likelihood="restricted")` itself
+    raises TypeError in the reference (gpr.py:405, sigma2 comes back as a scalar)."""
+    X, y = make_data(16, 40, 3)
+    y = y + 0.2 * np.random.default_rng(316).standard_normal(y.shape)
+    d = 3
+    out = dict(X=X, y=y)
+    rng = np.random.default_rng(216)
+    n = 0
+    for kid, corr in ((0, "squared_exponential"), (2, "matern")):
+        for mid, kw in ((0, dict(nugget=0)), (1, dict(nugget=1e-6)), (2, dict(nugget=1e-6, noise_estim=True))):
+            for tname, mean in (("sk", None), ("ok", trend.constant_trend(d))):
+                gp = GaussianProcess(mean=mean, corr=corr, thetaL=[1e-4] * d, thetaU=[1e2] * d, likelihood="restricted", **kw)
+                gp._check_data(X, y)
+                pars, vals, grads = [], [], []
+                for _ in range(4):
+                    th = 10 ** rng.uniform(-1.5, -0.6, size=d)
+                    p = np.r_[th, rng.uniform(0.3, 1.2)]
+                    if mid == 2:
+                        p = np.r_[p, 10 ** rng.uniform(-4, -1)]
+                    v, g = gp.log_likelihood_restricted(p, eval_grad=True)
+                    pars.append(p)
+                    vals.append(float(v))
+                    grads.append(np.asarray(g, float).ravel())
+                    n += 1
+                key = "k%d_m%d_%s" % (kid, mid, tname)
+                out[key + "_par"], out[key + "_llf"], out[key + "_grad"] = np.array(pars), np.array(vals), np.array(grads)
+    assert n == 48
+    save("G16_reml_tables", **out)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["trends"]:
         golden_trends()
+    elif sys.argv[1:] == ["reml"]:
+        golden_reml()
     else:
         main()
         golden_trends()
+        golden_reml()

@@ -128,3 +128,32 @@ def test_reference_BO_with_a_linear_trend_model(ref):
     assert mu.shape == (3, 1) and np.all(mse >= 0)
     dmu, dmse = gp.gradient(np.zeros((1, dim)))
     assert dmu.shape == (dim, 1) and dmse.shape == (dim, 1)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("kw", [dict(nugget=1e-6), dict(nugget=1e-6, noise_estim=True)])
+def test_fit_with_the_restricted_likelihood_host_logic(kw):
+    """REML through the host layer (parameter lists of gpr.py:1073-1086, the NOISY-mode commit, env, attribute refresh),
+    with the oracle as the engine.  The reference's own fit(likelihood="restricted") raises TypeError at gpr.py:405."""
+    import bogp
+    from oracle import gp_oracle as O
+    from support.oracle_engine import OracleEngine
+
+    rng = np.random.default_rng(3)
+    X = rng.uniform(-5, 5, size=(30, 2))
+    y = (np.sum(X**2, axis=1) + rng.standard_normal(30)).reshape(-1, 1)
+    y = (y - y.mean()) / y.std()
+    gp = bogp.GaussianProcess(mean=bogp.trend.constant_trend(2), corr="matern", thetaL=[1e-2] * 2, thetaU=[1e2] * 2,
+                              likelihood="restricted", random_start=2, eval_budget=80, **kw)  # fmt: skip
+    gp._engine = OracleEngine()
+    np.random.seed(5)
+    assert gp.fit(X, y) is gp and gp.is_fitted
+    names = ["theta", "sigma2"] + (["noise_var"] if kw.get("noise_estim") else [])
+    assert list(gp.par) == names
+    par = np.concatenate([np.ravel(gp.par[k]) for k in names])
+    mode = O.MODE_NOISE_ESTIM if kw.get("noise_estim") else O.MODE_NOISY
+    ref = O.log_likelihood_restricted(par, X, y, O.KERNEL_MATERN32, mode, noise_var=1e-6, estimate_trend=True, beta=None)
+    assert gp.log_likelihood_ == ref and np.isfinite(ref)
+    assert gp.sigma2.shape == (1,) and float(gp.sigma2[0]) == float(gp.par["sigma2"][0])
+    mu, mse = gp.predict(X[:4], eval_MSE=True)
+    assert mu.shape == (4, 1) and np.all(mse >= 0)

@@ -748,3 +748,53 @@ def test_trend_classes_end_to_end():
     m2, s2 = fit.predict(g["Xs"], eval_MSE=True)
     close_mu(m2, rmu)
     close_mse(s2, rmse, st.sigma2[0])
+
+
+# ---- restricted likelihood (a19, gpr.py:813-918) ----------------------------------------------------------------------
+def test_reml_tables(eng):
+    g = load_golden("G16_reml_tables")
+    eng.set_train(g["X"], g["y"])
+    n = 0
+    for kid in (0, 2):
+        for mid in (0, 1, 2):
+            for tname in ("sk", "ok"):
+                key = "k%d_m%d_%s" % (kid, mid, tname)
+                for p, v, gr in zip(g[key + "_par"], g[key + "_llf"], g[key + "_grad"]):
+                    llf, grad = eng.nll_restricted(kid, mid, p, 1e-6 if mid == 1 else 0.0, tname == "ok", 0.0, eval_grad=True)
+                    np.testing.assert_allclose(llf, v, rtol=1e-9)
+                    np.testing.assert_allclose(grad, gr, rtol=1e-6, atol=1e-7 * np.abs(gr).max())
+                    assert eng.nll_restricted(kid, mid, p, 1e-6 if mid == 1 else 0.0, tname == "ok", 0.0) == llf
+                    n += 1
+    assert n == 48
+
+
+@pytest.mark.parametrize("kw", [dict(nugget=1e-6), dict(nugget=0), dict(nugget=1e-6, noise_estim=True)])
+def test_fit_with_the_restricted_likelihood(kw):
+    """`fit(likelihood="restricted")` completes here (the reference raises TypeError at gpr.py:405 after optimising); the
+    fitted value is the oracle's REML at the fitted parameters and the posterior is the NOISY-mode state there."""
+    g = load_golden("G16_reml_tables")
+    X, y = g["X"], g["y"]
+    d = X.shape[1]
+    gp = bogp.GaussianProcess(mean=bogp.trend.constant_trend(d), corr="squared_exponential", thetaL=[1e-3] * d, thetaU=[1e2] * d,
+                              likelihood="restricted", random_start=3, eval_budget=120, **kw)  # fmt: skip
+    np.random.seed(11)
+    assert gp.fit(X, y) is gp and gp.is_fitted
+    mode = {"noiseless": O.MODE_NOISELESS, "noisy": O.MODE_NOISY, "noise_estim": O.MODE_NOISE_ESTIM}[gp.estimation_mode]
+    par = np.r_[gp.par["theta"], gp.par["sigma2"]] if mode != O.MODE_NOISE_ESTIM else np.r_[gp.par["theta"], gp.par["sigma2"], gp.par["noise_var"]]
+    nv = float(np.ravel(gp.nugget)[0]) if mode == O.MODE_NOISY else 0.0
+    ref = O.log_likelihood_restricted(par, X, y, O.KERNEL_SE, mode, noise_var=nv, estimate_trend=True, beta=None)
+    np.testing.assert_allclose(gp.log_likelihood_, ref, rtol=1e-9)
+    assert np.isfinite(gp.log_likelihood_) and gp.log_likelihood_ <= 0
+    theta, s2, nvar = gp._split_restricted(par)
+    st = O.make_state(np.r_[theta, s2], X, y, O.KERNEL_SE, O.MODE_NOISY, nvar, estimate_trend=True, beta=None)
+    np.testing.assert_allclose(gp.sigma2, st.sigma2, rtol=1e-12)
+    np.testing.assert_allclose(gp.gamma, st.gamma, rtol=1e-6, atol=1e-9 * np.abs(st.gamma).max())
+    Xs = np.random.default_rng(5).uniform(-5, 5, size=(100, d))
+    mu, mse = gp.predict(Xs, eval_MSE=True)
+    rmu, rmse = O.predict(st, Xs)
+    close_mu(mu, rmu)
+    close_mse(mse, rmse, st.sigma2[0])
+    # evaluating either likelihood on the fitted model leaves the committed state alone
+    gp.log_likelihood_restricted(par * 1.1, eval_grad=True)
+    mu2 = gp.predict(Xs)
+    np.testing.assert_array_equal(mu2, mu)

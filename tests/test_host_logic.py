@@ -43,8 +43,9 @@ def test_constructor_contract():
         bogp.GaussianProcess(thetaL=[1.0], thetaU=[0.5])
     with pytest.raises(NotImplementedError):
         bogp.GaussianProcess(thetaL=[1e-3], thetaU=[1e2], optimizer="CMA")
-    with pytest.raises(NotImplementedError):
-        bogp.GaussianProcess(thetaL=[1e-3], thetaU=[1e2], likelihood="restricted")
+    assert bogp.GaussianProcess(thetaL=[1e-3], thetaU=[1e2], likelihood="restricted").likelihood == "restricted"
+    with pytest.raises(NotImplementedError):  # REML is built for the constant basis
+        bogp.GaussianProcess(mean=bogp.trend.linear_trend(1), thetaL=[1e-3], thetaU=[1e2], likelihood="restricted")
     assert hasattr(gp, "gradient")  # its presence selects the BFGS inner optimiser (base.py:201)
 
 

@@ -251,3 +251,23 @@ def test_quadratic_trend_has_no_jacobian():
     g = load_golden("G14_quadratic_uk_m32")
     with pytest.raises(NotImplementedError):
         O.gradient(state_from_golden(g), g["Xs"][0])
+
+
+def test_reml_tables():
+    """The restricted likelihood (gpr.py:813-918): value + gradient, three modes x {sk, ok} x {SE, Matern-3/2}."""
+    g = load_golden("G16_reml_tables")
+    n = 0
+    for kid in (0, 2):
+        for mid in (0, 1, 2):
+            for tname in ("sk", "ok"):
+                key = "k%d_m%d_%s" % (kid, mid, tname)
+                for p, v, gr in zip(g[key + "_par"], g[key + "_llf"], g[key + "_grad"]):
+                    out = O.log_likelihood_restricted(p, g["X"], g["y"], kid, mid, noise_var=1e-6 if mid == 1 else 0.0,
+                                                      estimate_trend=(tname == "ok"), beta=0.0, eval_grad=True)  # fmt: skip
+                    if np.isneginf(v):
+                        assert np.isneginf(out[0])
+                    else:
+                        close(out[0], v, rtol=1e-11)
+                    close(out[1], gr, rtol=1e-8, atol=1e-9)
+                    n += 1
+    assert n == 48
