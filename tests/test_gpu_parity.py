@@ -798,3 +798,43 @@ def test_fit_with_the_restricted_likelihood(kw):
     gp.log_likelihood_restricted(par * 1.1, eval_grad=True)
     mu2 = gp.predict(Xs)
     np.testing.assert_array_equal(mu2, mu)
+
+
+# ---- kernels_chol.hip at its block boundaries ---------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [63, 64, 65, 127, 128, 129, 191, 193, 449])
+def test_factorisation_block_boundaries(eng, N):
+    """The blocked Cholesky / triangular inverse work on 64-wide blocks with an identity-padded tail: sizes just below, at
+    and just above multiples of 64 against the oracle (likelihood, its gradient, L, gamma)."""
+    d = 4
+    rng = np.random.default_rng(N)
+    X = rng.uniform(-5, 5, size=(N, d))
+    y = np.sum(X**2, axis=1) + X[:, 0] + 3.0 * rng.standard_normal(N)  # noise keeps the likelihood <= 0 (not rejected)
+    y = ((y - y.mean()) / y.std()).reshape(-1, 1)
+    par = np.r_[10 ** rng.uniform(-1.5, -0.8, size=d), 0.8]
+    for est in (False, True):
+        ref = O.log_likelihood_concentrated(par, X, y, O.KERNEL_SE, O.MODE_NOISY, 1e-6, estimate_trend=est, beta=0.0, eval_grad=True)
+        eng.set_train(X, y)
+        llf, grad = eng.nll(O.KERNEL_SE, O.MODE_NOISY, par, 1e-6, est, 0.0, eval_grad=True)
+        np.testing.assert_allclose(llf, ref[0], rtol=1e-10)
+        np.testing.assert_allclose(grad, ref[1], rtol=1e-6, atol=1e-8 * np.abs(ref[1]).max())
+        st = O.make_state(par, X, y, O.KERNEL_SE, O.MODE_NOISY, 1e-6, estimate_trend=est, beta=None if est else 0.0)
+        eng.commit(O.KERNEL_SE, O.MODE_NOISY, par, 1e-6, est, 0.0)
+        s = eng.get_state()
+        np.testing.assert_allclose(s["C"], st.C, rtol=0, atol=1e-11 * np.abs(st.C).max())
+        np.testing.assert_allclose(s["gamma"], st.gamma.ravel(), rtol=1e-6, atol=1e-8 * np.abs(st.gamma).max())
+
+
+def test_singular_matrix_is_reported_like_lapack(eng):
+    """Duplicate training points without a nugget: the pivot of the second copy is <= 0 -> BOGP_ERR_NOT_POSDEF, which the
+    host maps to the reference's -inf (gpr.py:946-947), wherever in the matrix (first block, later block) it happens."""
+    rng = np.random.default_rng(0)
+    for N, dup in ((40, (3, 17)), (200, (150, 199)), (130, (5, 129))):
+        X = rng.uniform(-5, 5, size=(N, 2))
+        X[dup[1]] = X[dup[0]]
+        y = rng.standard_normal((N, 1))
+        eng.set_train(X, y)
+        with pytest.raises(_lib.NotPositiveDefinite):
+            eng.nll(O.KERNEL_SE, O.MODE_NOISELESS, np.r_[0.3, 0.2], 0.0, False, 0.0, eval_grad=True)
+        gp = bogp.GaussianProcess(corr="squared_exponential", thetaL=[1e-2] * 2, thetaU=[1e1] * 2, nugget=0)
+        gp._check_data(X, y)
+        assert gp.log_likelihood_concentrated(np.r_[0.3, 0.2]) == -np.inf
