@@ -1,89 +1,16 @@
-// kernels_fit.hip -- fit-side kernels of libbogp (gfx950): everything around the rocSOLVER factorisation.
+// kernels_fit.hip -- fit-side kernels of libbogp (gfx950): everything around the factorisation (kernels_chol.hip).
 //
-//   k_build_R        correlation_matrix (gpr.py:772-782) + the per-mode normalisation (:949-969) without the
-//                    N(N-1)/2 x d pair list of l1_cross_distances (:48-61)
+//   (k_build_R and k_grad_contract, the two N^2 d pair kernels, live in kernels_pairs.hip)
 //   k_scale_transpose theta-scaled, transposed copy of X that the sweep's producer reads with scalar loads
 //   k_pack_V         L^-1 -> MFMA B-fragment order for k_contract
 //   k_logdet         sum(log(diag(L)))  (gpr.py:943-945)
-//   k_grad_contract  the d trace-contractions of the llf gradient (gpr.py:994-1038) formed on the fly from X:
-//                    sum_{i<j} (gamma_i gamma_j c1 - Rinv_ij) dR0_ij/dtheta_k -- no (N,N,d) tensor (:736-770)
+//   k_gemv2, k_fit_rho, k_trace_gg, k_sumsq   products with V = L^-1 / U = L^-T and the scalars of the likelihood
+//   k_trend_*        polynomial trend bases with p > 1 columns (trend.py:94-142)
 //   k_point_corr     r and dr/dx at ONE point for GaussianProcess.gradient (gpr.py:537-576, corr_dx :600-661)
 #include "bogp_device.h"
 #include "bogp_internal.h"
 
 namespace bogp {
-
-template <int KERNEL>
-__global__ __launch_bounds__(256) void k_build_R(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
-                                                 double off_scale, double diag, double* __restrict__ R, int ld) {
-  // 16x16 tile per workgroup; exactly symmetric where both triangles are written: (a-b)^2 == (b-a)^2
-  // only the lower triangle and the (full, symmetric) 64 x 64 diagonal blocks are consumed (kernels_chol.hip)
-  if (blockIdx.y < blockIdx.x && (blockIdx.y >> 2) != (blockIdx.x >> 2)) return;
-  const int i = blockIdx.y * 16 + (threadIdx.x >> 4);
-  const int j = blockIdx.x * 16 + (threadIdx.x & 15);
-  if (i >= N || j >= N) return;
-  double v;
-  if (i == j) {
-    v = diag;
-  } else {
-    double s2 = 0.0;
-    for (int k = 0; k < d; ++k) {
-      s2 += dist_term<KERNEL>(theta[k], fabs(X[(size_t)i * d + k] - X[(size_t)j * d + k]));
-    }
-    v = off_scale * corr_profile<KERNEL>(s2);
-  }
-  R[(size_t)j * ld + i] = v;  // column-major (symmetric anyway)
-}
-
-// NOISY mode divides after the multiply (C = sigma2 R0 + tau2 I; R = C / sigma2_total, gpr.py:966-967)
-template <int KERNEL>
-__global__ __launch_bounds__(256) void k_build_R_div(const double* __restrict__ X, int N, int d,
-                                                     const double* __restrict__ theta, double mul, double div,
-                                                     double diag, double* __restrict__ R, int ld) {
-  // only the lower triangle and the (full, symmetric) 64 x 64 diagonal blocks are consumed (kernels_chol.hip)
-  if (blockIdx.y < blockIdx.x && (blockIdx.y >> 2) != (blockIdx.x >> 2)) return;
-  const int i = blockIdx.y * 16 + (threadIdx.x >> 4);
-  const int j = blockIdx.x * 16 + (threadIdx.x & 15);
-  if (i >= N || j >= N) return;
-  double v;
-  if (i == j) {
-    v = diag;
-  } else {
-    double s2 = 0.0;
-    for (int k = 0; k < d; ++k) {
-      s2 += dist_term<KERNEL>(theta[k], fabs(X[(size_t)i * d + k] - X[(size_t)j * d + k]));
-    }
-    v = (mul * corr_profile<KERNEL>(s2)) / div;
-  }
-  R[(size_t)j * ld + i] = v;
-}
-
-hipError_t launch_build_R(int kernel, const double* X, int N, int d, const double* theta, double off_scale, double diag,
-                          double* R, int ld, hipStream_t st) {
-  // multiply-only form (NOISELESS: off_scale = 1; NOISE_ESTIM: off_scale = alpha); NOISY uses launch_build_R_div
-  dim3 grid((N + 15) / 16, (N + 15) / 16);
-  switch (kernel) {
-    case BOGP_KERNEL_SE: hipLaunchKernelGGL(k_build_R<BOGP_KERNEL_SE>, grid, 256, 0, st, X, N, d, theta, off_scale, diag, R, ld); break;
-    case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL(k_build_R<BOGP_KERNEL_MATERN12>, grid, 256, 0, st, X, N, d, theta, off_scale, diag, R, ld); break;
-    case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL(k_build_R<BOGP_KERNEL_MATERN32>, grid, 256, 0, st, X, N, d, theta, off_scale, diag, R, ld); break;
-    case BOGP_KERNEL_ABSEXP: hipLaunchKernelGGL(k_build_R<BOGP_KERNEL_ABSEXP>, grid, 256, 0, st, X, N, d, theta, off_scale, diag, R, ld); break;
-    default: hipLaunchKernelGGL(k_build_R<BOGP_KERNEL_MATERN52>, grid, 256, 0, st, X, N, d, theta, off_scale, diag, R, ld); break;
-  }
-  return hipGetLastError();
-}
-
-hipError_t launch_build_R_div(int kernel, const double* X, int N, int d, const double* theta, double mul, double div,
-                              double diag, double* R, int ld, hipStream_t st) {
-  dim3 grid((N + 15) / 16, (N + 15) / 16);
-  switch (kernel) {
-    case BOGP_KERNEL_SE: hipLaunchKernelGGL(k_build_R_div<BOGP_KERNEL_SE>, grid, 256, 0, st, X, N, d, theta, mul, div, diag, R, ld); break;
-    case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL(k_build_R_div<BOGP_KERNEL_MATERN12>, grid, 256, 0, st, X, N, d, theta, mul, div, diag, R, ld); break;
-    case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL(k_build_R_div<BOGP_KERNEL_MATERN32>, grid, 256, 0, st, X, N, d, theta, mul, div, diag, R, ld); break;
-    case BOGP_KERNEL_ABSEXP: hipLaunchKernelGGL(k_build_R_div<BOGP_KERNEL_ABSEXP>, grid, 256, 0, st, X, N, d, theta, mul, div, diag, R, ld); break;
-    default: hipLaunchKernelGGL(k_build_R_div<BOGP_KERNEL_MATERN52>, grid, 256, 0, st, X, N, d, theta, mul, div, diag, R, ld); break;
-  }
-  return hipGetLastError();
-}
 
 __global__ void k_scale_transpose(const double* __restrict__ X, int N, int d, int Np, const double* __restrict__ sth,
                                   double* __restrict__ XthT) {
@@ -344,80 +271,6 @@ __global__ void k_copy_lower(const double* __restrict__ L, int N, int ld, double
 }
 hipError_t launch_copy_lower(const double* L, int N, int ld, double* dst, hipStream_t st) {
   hipLaunchKernelGGL(k_copy_lower, dim3((N + 15) / 16, (N + 15) / 16), 256, 0, st, L, N, ld, dst);
-  return hipGetLastError();
-}
-
-// ---- likelihood-gradient contraction ------------------------------------------------------------------
-// One workgroup per 16x16 tile on or above the diagonal; thread (ti, tj) owns pair (i, j), i < j only.
-// partial[blk][0..d-1] = sum A_ij * (-(x_ik - x_jk)^2 h_ij),  partial[blk][d] = sum A_ij R0_ij,
-// with A_ij = gamma_i gamma_j c1 - Rinv_ij.  MAXD bounds d for the per-thread accumulators via chunking over k.
-template <int KERNEL>
-__global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict__ X, int N, int d,
-                                                       const double* __restrict__ theta,
-                                                       const double* __restrict__ gamma, double c1,
-                                                       const double* __restrict__ qv, double c2,
-                                                       const double* __restrict__ Rinv, int ld, int nparts,
-                                                       size_t part_stride, double* __restrict__ partial, int ntile) {
-  __shared__ double red[256];
-  // linear tile id -> (bi <= bj)
-  int t = blockIdx.x, bi = 0;
-  while (t >= ntile - bi) {
-    t -= ntile - bi;
-    ++bi;
-  }
-  const int bj = bi + t;
-  const int i = bi * 16 + (threadIdx.x >> 4);
-  const int j = bj * 16 + (threadIdx.x & 15);
-  const bool ok = i < N && j < N && i < j;
-  double A = 0.0, h = 0.0, r0 = 0.0;
-  if (ok) {
-    double s2 = 0.0;
-    for (int k = 0; k < d; ++k) {
-      s2 += dist_term<KERNEL>(theta[k], X[(size_t)i * d + k] - X[(size_t)j * d + k]);
-    }
-    r0 = corr_profile<KERNEL>(s2);
-    h = corr_dtheta_profile<KERNEL>(s2, r0);
-    double rinv = 0.0;  // element (j, i) of the lower triangle, column-major; R^-1 arrives as nparts K-slices of U U^T
-    for (int q = 0; q < nparts; ++q) rinv += Rinv[q * part_stride + (size_t)i * ld + j];
-    A = gamma[i] * gamma[j] * c1 - rinv;
-    if (qv) A += qv[i] * qv[j] * c2;  // REML: the (L^-T Q)(L^-T Q)^T term of gpr.py:876-878, 896-898
-  }
-  double* out = partial + (size_t)blockIdx.x * (d + 1);
-  for (int k = 0; k <= d; ++k) {
-    double v = 0.0;
-    if (ok) {
-      if (k < d) {
-        const double df = X[(size_t)i * d + k] - X[(size_t)j * d + k];
-        v = A * (-dtheta_weight<KERNEL>(df) * h);
-      } else {
-        v = A * r0;
-      }
-    }
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) out[k] = red[0];
-    __syncthreads();
-  }
-}
-int grad_contract_blocks(int N) {
-  const int nt = (N + 15) / 16;
-  return nt * (nt + 1) / 2;
-}
-hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const double* theta, const double* gamma,
-                                double c1, const double* qv, double c2, const double* Rinv, int ld, int nparts,
-                                size_t part_stride, double* partial, int nblk, hipStream_t st) {
-  const int nt = (N + 15) / 16;
-  switch (kernel) {
-    case BOGP_KERNEL_SE: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_SE>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, qv, c2, Rinv, ld, nparts, part_stride, partial, nt); break;
-    case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN12>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, qv, c2, Rinv, ld, nparts, part_stride, partial, nt); break;
-    case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN32>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, qv, c2, Rinv, ld, nparts, part_stride, partial, nt); break;
-    case BOGP_KERNEL_ABSEXP: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_ABSEXP>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, qv, c2, Rinv, ld, nparts, part_stride, partial, nt); break;
-    default: hipLaunchKernelGGL(k_grad_contract<BOGP_KERNEL_MATERN52>, dim3(nblk), 256, 0, st, X, N, d, theta, gamma, c1, qv, c2, Rinv, ld, nparts, part_stride, partial, nt); break;
-  }
   return hipGetLastError();
 }
 

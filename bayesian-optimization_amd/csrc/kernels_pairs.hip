@@ -1,0 +1,238 @@
+// kernels_pairs.hip -- the two N^2 d pair kernels of the likelihood path of libbogp (gfx950):
+//
+//   k_build_R        correlation_matrix (gpr.py:772-782) + the per-mode normalisation (:949-969), without the
+//                    N(N-1)/2 x d pair list of l1_cross_distances (:48-61)
+//   k_grad_contract  the d + 1 trace-contractions of the likelihood gradient (gpr.py:994-1038) formed on the fly from
+//                    X:  sum_{i<j} A_ij dR0_ij/dtheta_k  and  sum_{i<j} A_ij R0_ij  with
+//                    A_ij = gamma_i gamma_j c1 + q_i q_j c2 - Rinv_ij  -- no (N, N, d) tensor (:736-770)
+//
+// Both walk 64 x 64 tiles of point pairs with 256 threads (4 x 4 pairs each) and stage the coordinates of the two point
+// blocks through LDS in chunks of 16 dimensions (k-major, pitch 65: conflict-free stores and reads).  The first
+// versions gave one THREAD one pair and re-read 2 d coordinates from global memory per pair; at N = 8192, d = 50 they
+// took 2.5 ms and 5.2 ms of a 29-ms likelihood + gradient evaluation (profiles/r01_nll_n8192_kernel_stats.csv).
+#include "bogp_device.h"
+#include "bogp_internal.h"
+
+namespace bogp {
+
+namespace {
+
+constexpr int PT = 64;        // points per tile side
+constexpr int KC = 16;        // dimensions per staged chunk
+constexpr int PP = PT + 1;    // LDS pitch (doubles)
+
+// coordinates of points p0 .. p0 + 63, dimensions kc .. kc + 15 -> dst[kk][p]; zero beyond N / d
+__device__ __forceinline__ void stage_points(double* dst, const double* __restrict__ X, int N, int d, int p0, int kc, int tid) {
+#pragma unroll
+  for (int it = 0; it < (PT * KC) / 256; ++it) {
+    const int idx = tid + 256 * it;
+    const int p = idx / KC, kk = idx % KC;
+    const int gp = p0 + p, gk = kc + kk;
+    dst[kk * PP + p] = (gp < N && gk < d) ? X[(size_t)gp * d + gk] : 0.0;
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += shfl_xor_f64(v, o);
+  return v;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// R (lower 64 x 64 tiles, diagonal tiles complete and exactly symmetric) into a column-major matrix.
+//   DIV = false:  off-diagonal = a * corr          (NOISELESS a = 1; NOISE_ESTIM a = alpha, gpr.py:951)
+//   DIV = true:   off-diagonal = (a * corr) / b    (NOISY: C = sigma2 R0 + tau2 I; R = C / sigma2_total, :966-967)
+// ---------------------------------------------------------------------------------------------------------------
+template <int KERNEL, bool DIV>
+__global__ __launch_bounds__(256) void k_build_R(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
+                                                 double a, double b, double diag, double* __restrict__ R, int ld) {
+  __shared__ double xi[KC * PP], xj[KC * PP];
+  const int bi = blockIdx.y, bj = blockIdx.x;  // row tile, column tile
+  if (bj > bi) return;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int i0 = bi * PT, j0 = bj * PT;
+  double s2[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s2[r][c] = 0.0;
+  for (int kc = 0; kc < d; kc += KC) {
+    __syncthreads();
+    stage_points(xi, X, N, d, i0, kc, tid);
+    stage_points(xj, X, N, d, j0, kc, tid);
+    __syncthreads();
+    const int kn = min(KC, d - kc);
+    for (int kk = 0; kk < kn; ++kk) {
+      const double th = theta[kc + kk];
+      double vi[4], vj[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vi[r] = xi[kk * PP + 4 * ty + r];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vj[c] = xj[kk * PP + 4 * tx + c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s2[r][c] += dist_term<KERNEL>(th, fabs(vi[r] - vj[c]));
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 4 * ty + r, j = j0 + 4 * tx + c;
+      if (i >= N || j >= N) continue;
+      double v;
+      if (i == j)
+        v = diag;
+      else if (DIV)
+        v = (a * corr_profile<KERNEL>(s2[r][c])) / b;
+      else
+        v = a * corr_profile<KERNEL>(s2[r][c]);
+      R[(size_t)j * ld + i] = v;
+    }
+}
+
+#define BOGP_FOR_KERNEL(kernel, CALL)                      \
+  switch (kernel) {                                        \
+    case BOGP_KERNEL_SE: { CALL(BOGP_KERNEL_SE); } break;             \
+    case BOGP_KERNEL_MATERN12: { CALL(BOGP_KERNEL_MATERN12); } break; \
+    case BOGP_KERNEL_MATERN32: { CALL(BOGP_KERNEL_MATERN32); } break; \
+    case BOGP_KERNEL_ABSEXP: { CALL(BOGP_KERNEL_ABSEXP); } break;     \
+    default: { CALL(BOGP_KERNEL_MATERN52); } break;                   \
+  }
+
+hipError_t launch_build_R(int kernel, const double* X, int N, int d, const double* theta, double off_scale, double diag,
+                          double* R, int ld, hipStream_t st) {
+  const int nt = (N + PT - 1) / PT;
+  const dim3 grid(nt, nt);
+#define CALL(K) hipLaunchKernelGGL((k_build_R<K, false>), grid, 256, 0, st, X, N, d, theta, off_scale, 1.0, diag, R, ld)
+  BOGP_FOR_KERNEL(kernel, CALL)
+#undef CALL
+  return hipGetLastError();
+}
+
+hipError_t launch_build_R_div(int kernel, const double* X, int N, int d, const double* theta, double mul, double div,
+                              double diag, double* R, int ld, hipStream_t st) {
+  const int nt = (N + PT - 1) / PT;
+  const dim3 grid(nt, nt);
+#define CALL(K) hipLaunchKernelGGL((k_build_R<K, true>), grid, 256, 0, st, X, N, d, theta, mul, div, diag, R, ld)
+  BOGP_FOR_KERNEL(kernel, CALL)
+#undef CALL
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// partial[blk][k] = sum over the tile's pairs i < j of A_ij * dR0_ij/dtheta_k  (k < d),  partial[blk][d] = sum A_ij R0_ij
+// Rinv arrives as `nparts` K-slices (lower triangles, part_stride doubles apart) that are added here.
+// Tile (bi <= bj): i in tile bi (thread columns), j in tile bj (thread rows); blk = bj (bj + 1) / 2 + bi.
+// ---------------------------------------------------------------------------------------------------------------
+template <int KERNEL>
+__global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
+                                                       const double* __restrict__ gamma, double c1,
+                                                       const double* __restrict__ qv, double c2,
+                                                       const double* __restrict__ Rinv, int ld, int nparts, size_t part_stride,
+                                                       double* __restrict__ partial) {
+  __shared__ double xi[KC * PP], xj[KC * PP];
+  __shared__ double red[4][KC + 1];
+  const int bj = blockIdx.y, bi = blockIdx.x;  // j (rows, the larger index) tile, i (columns) tile
+  if (bi > bj) return;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15, lane = tid & 63, wv = tid >> 6;
+  const int i0 = bi * PT, j0 = bj * PT;
+  double* out = partial + ((size_t)bj * (bj + 1) / 2 + bi) * (d + 1);
+
+  // ---- pass 1: weighted distances of the 16 pairs -> r0, h, A ------------------------------------------
+  double s2[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s2[r][c] = 0.0;
+  for (int kc = 0; kc < d; kc += KC) {
+    __syncthreads();
+    stage_points(xi, X, N, d, i0, kc, tid);
+    stage_points(xj, X, N, d, j0, kc, tid);
+    __syncthreads();
+    const int kn = min(KC, d - kc);
+    for (int kk = 0; kk < kn; ++kk) {
+      const double th = theta[kc + kk];
+      double vj[4], vi[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vj[r] = xj[kk * PP + 4 * ty + r];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vi[c] = xi[kk * PP + 4 * tx + c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s2[r][c] += dist_term<KERNEL>(th, vi[c] - vj[r]);
+    }
+  }
+  double B[4][4];  // A_ij * h_ij (zero for pairs outside i < j < N)
+  double sd = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = i0 + 4 * tx + c, j = j0 + 4 * ty + r;
+      double bb = 0.0;
+      if (i < j && j < N) {
+        const double r0 = corr_profile<KERNEL>(s2[r][c]);
+        const double h = corr_dtheta_profile<KERNEL>(s2[r][c], r0);
+        double rinv = 0.0;  // element (j, i) of the lower triangle, column-major
+        for (int q = 0; q < nparts; ++q) rinv += Rinv[q * part_stride + (size_t)i * ld + j];
+        double A = gamma[i] * gamma[j] * c1 - rinv;
+        if (qv) A += qv[i] * qv[j] * c2;  // REML: the (L^-T Q)(L^-T Q)^T term of gpr.py:876-878, 896-898
+        bb = A * h;
+        sd += A * r0;
+      }
+      B[r][c] = bb;
+    }
+  sd = wave_sum(sd);
+  if (lane == 0) red[wv][KC] = sd;
+
+  // ---- pass 2: the d contractions, 16 dimensions at a time ---------------------------------------------
+  for (int kc = 0; kc < d; kc += KC) {
+    __syncthreads();
+    stage_points(xi, X, N, d, i0, kc, tid);
+    stage_points(xj, X, N, d, j0, kc, tid);
+    __syncthreads();
+    const int kn = min(KC, d - kc);
+    for (int kk = 0; kk < kn; ++kk) {
+      double vj[4], vi[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vj[r] = xj[kk * PP + 4 * ty + r];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vi[c] = xi[kk * PP + 4 * tx + c];
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc += B[r][c] * (-dtheta_weight<KERNEL>(vi[c] - vj[r]));
+      acc = wave_sum(acc);
+      if (lane == 0) red[wv][kk] = acc;
+    }
+    __syncthreads();
+    if (tid < kn) out[kc + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+  }
+  __syncthreads();
+  if (tid == 0) out[d] = ((red[0][KC] + red[1][KC]) + red[2][KC]) + red[3][KC];
+}
+
+int grad_contract_blocks(int N) {
+  const int nt = (N + PT - 1) / PT;
+  return nt * (nt + 1) / 2;
+}
+hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const double* theta, const double* gamma,
+                                double c1, const double* qv, double c2, const double* Rinv, int ld, int nparts,
+                                size_t part_stride, double* partial, int nblk, hipStream_t st) {
+  const int nt = (N + PT - 1) / PT;
+  (void)nblk;
+  const dim3 grid(nt, nt);
+#define CALL(K) \
+  hipLaunchKernelGGL((k_grad_contract<K>), grid, 256, 0, st, X, N, d, theta, gamma, c1, qv, c2, Rinv, ld, nparts, part_stride, partial)
+  BOGP_FOR_KERNEL(kernel, CALL)
+#undef CALL
+  return hipGetLastError();
+}
+
+}  // namespace bogp
