@@ -79,3 +79,10 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "gp_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_graft_entry_build_is_consistent_with_the_abi():
+    """The driver's build check: `make` (a no-op when the library is current) + the ABI version assertion."""
+    import __graft_entry__ as entry
+
+    entry.build()
