@@ -276,6 +276,167 @@ __global__ __launch_bounds__(256, 2) void k_contract(ContractArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Kernel B': the same contraction on v_mfma_f64_16x16x4_f64.
+//
+// The first probe of this instruction (builtin, accumulators where the compiler put them: AGPRs) measured 130-150
+// cycles = half the FP64 rate, which is why kernel B was built on the 4x4x4 form.  With the accumulator tied in place in
+// ARCHITECTURAL VGPRs it issues every 64.0 cycles = 77.5 TF/s, at 1-4 waves per SIMD (tools/ubench_mfma16.hip,
+// profiles/r01_ubench_mfma16.txt; AGPR accumulators: 130 cycles) -- and it needs ONE A register and ONE B register per
+// 2048 flop where the 4x4x4 form needs four rotated A registers: a quarter of the LDS reads, no rotation, a quarter
+// of the MFMA issue slots.  Lane layout (tools/probe_mfma_layout.hip): A lane = 16 k + i, B lane = 16 k + j (the SAME
+// order k_pack_V already produces), D[i][j] in lane 16 (i % 4) + j, register i / 4.
+// Tiling, staging, guards and the epilogue's summation order are those of kernel B.
+// ---------------------------------------------------------------------------------------------------
+typedef double d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma16_acc(double a, double b, d4& c) {
+  asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// 16 passes: the result of the last MFMA must not be read by the VALU before it has left the pipe
+#define BOGP_MFMA16_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
+
+template <int NR>
+__device__ __forceinline__ void contract_block16(const bool GUARDED, const double* __restrict__ tile, const double2* __restrict__ vp,
+                                                 const size_t (&boff)[NR], const int (&jt)[NR], int aoff, int kb, int kp_last,
+                                                 double2 (&bq)[2][NR], d4 (&acc)[MR][NR]) {
+  // A fragments are read one k-step AHEAD of the MFMAs that use them (two register sets): with only four LDS reads per
+  // sixteen MFMAs their latency would otherwise sit in front of every k-step
+  double af[2][MR];
+#pragma unroll
+  for (int mi = 0; mi < MR; ++mi) af[0][mi] = tile[aoff + 16 * mi];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int kp = kb * 4 + s;
+    const int kb16 = kp >> 1;
+    {  // prefetch the next k-pair of B fragments (clamped at the end of this group's range)
+      const int kpn = min(kp + 1, kp_last);
+#pragma unroll
+      for (int ni = 0; ni < NR; ++ni) bq[(s + 1) & 1][ni] = vp[boff[ni] + (size_t)kpn * 64];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int sub = 2 * s + h;
+      if (sub < 7) {
+        const double* trow = tile + (4 * (sub + 1)) * PITCH;
+#pragma unroll
+        for (int mi = 0; mi < MR; ++mi) af[(sub + 1) & 1][mi] = trow[aoff + 16 * mi];
+      }
+#pragma unroll
+      for (int ni = 0; ni < NR; ++ni) {
+        if (!GUARDED || kb16 <= jt[ni]) {
+          const double bv = h == 0 ? bq[s & 1][ni].x : bq[s & 1][ni].y;
+#pragma unroll
+          for (int mi = 0; mi < MR; ++mi) mfma16_acc(af[sub & 1][mi], bv, acc[mi][ni]);
+        }
+      }
+    }
+  }
+}
+
+template <int NR>
+__global__ __launch_bounds__(256, 2) void k_contract16(ContractArgs a) {
+  constexpr int JT16 = NWJ * NR;
+  __shared__ __attribute__((aligned(16))) double lds[2 * KB * PITCH];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nMt = a.nMt;
+  const int jg = a.nJ - 1 - (int)(blockIdx.x / nMt);
+  const int mt = blockIdx.x % nMt;
+  const int64_t mc0 = (int64_t)mt * 64;
+  const int NJ16 = a.NJ16, NKP = a.NKP;
+  const int kmax16 = min((jg + 1) * JT16, NJ16);
+  const int nkb = kmax16 >> 1;
+  const int nkb_full = jg * (JT16 / 2);
+  const int kp_last = 2 * kmax16 - 1;
+
+  int jt[NR];
+  size_t boff[NR];
+  bool valid[NR];
+#pragma unroll
+  for (int ni = 0; ni < NR; ++ni) {
+    const int j = jg * JT16 + w + NWJ * ni;
+    valid[ni] = j < NJ16;
+    jt[ni] = valid[ni] ? j : -1;
+    boff[ni] = (size_t)min(j, NJ16 - 1) * NKP * 64;
+  }
+
+  d4 acc[MR][NR];
+#pragma unroll
+  for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  const int srow = tid >> 5;
+  const int scol = (tid & 31) * 2;
+  const double* __restrict__ rbase = a.rT + mc0 + scol;
+  const size_t Mc = (size_t)a.Mc;
+  double2 st0, st1, st2, st3;
+#define BOGP_STAGE_LOAD(kb_)                                                                         \
+  do {                                                                                               \
+    const double* p_ = rbase + (size_t)((kb_)*KB + srow) * Mc;                                       \
+    st0 = *reinterpret_cast<const double2*>(p_);                                                     \
+    st1 = *reinterpret_cast<const double2*>(p_ + 8 * Mc);                                            \
+    st2 = *reinterpret_cast<const double2*>(p_ + 16 * Mc);                                           \
+    st3 = *reinterpret_cast<const double2*>(p_ + 24 * Mc);                                           \
+  } while (0)
+#define BOGP_STAGE_STORE(buf_)                                                                       \
+  do {                                                                                               \
+    double* q_ = &lds[(buf_)*KB * PITCH + srow * PITCH + scol];                                      \
+    *reinterpret_cast<double2*>(q_) = st0;                                                           \
+    *reinterpret_cast<double2*>(q_ + 8 * PITCH) = st1;                                               \
+    *reinterpret_cast<double2*>(q_ + 16 * PITCH) = st2;                                              \
+    *reinterpret_cast<double2*>(q_ + 24 * PITCH) = st3;                                              \
+  } while (0)
+
+  const double2* __restrict__ vp = a.Vp + lane;
+  double2 bq[2][NR];
+#pragma unroll
+  for (int ni = 0; ni < NR; ++ni) bq[0][ni] = vp[boff[ni]];
+
+  // A lane = 16 k + i reads row k of the k-step, candidate 16 mi + i: pitch 640 B puts the four rows of a read in four
+  // different 128-byte bank groups
+  const int aoff = (lane >> 4) * PITCH + (lane & 15);
+
+  BOGP_STAGE_LOAD(0);
+  BOGP_STAGE_STORE(0);
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();
+    BOGP_STAGE_LOAD(min(kb + 1, nkb - 1));
+    const double* tile = &lds[(kb & 1) * KB * PITCH];
+    contract_block16<NR>(kb >= nkb_full, tile, vp, boff, jt, aoff, kb, kp_last, bq, acc);
+    BOGP_STAGE_STORE((kb + 1) & 1);
+  }
+#undef BOGP_STAGE_LOAD
+#undef BOGP_STAGE_STORE
+
+  // ---- epilogue: D[i][j] sits in lane 16 (i % 4) + j, register i / 4 ---------------------------------
+  BOGP_MFMA16_DRAIN();
+  __syncthreads();
+  double* red = lds;  // [NWJ][64 rows][16 slots]
+  const int q = lane >> 4, jc = lane & 15;
+#pragma unroll
+  for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double s = 0.0;
+#pragma unroll
+      for (int ni = 0; ni < NR; ++ni)
+        if (valid[ni]) s = __builtin_fma(acc[mi][ni][r], acc[mi][ni][r], s);
+      red[(w * 64 + 16 * mi + 4 * r + q) * 16 + jc] = s;  // slot = column inside the 16-tile, as in kernel B
+    }
+  __syncthreads();
+  if (tid < 64) {
+    double s = 0.0;
+    for (int ww = 0; ww < NWJ; ++ww)
+#pragma unroll
+      for (int sl = 0; sl < 16; ++sl) s += red[(ww * 64 + tid) * 16 + sl];
+    a.ss_part[(size_t)jg * a.Mc + mc0 + tid] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------------
 hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipStream_t st) {
@@ -303,7 +464,19 @@ static int contract_nr() {
   return nr;
 }
 
+static bool contract_use_16x16() {
+  static bool v = [] {
+    const char* e = getenv("BOGP_CONTRACT_MFMA");  // "4x4": kernel B (v_mfma_f64_4x4x4_4b_f64), kept for A/B measurements
+    return !(e && e[0] == '4');
+  }();
+  return v;
+}
+
 hipError_t launch_contract(const ContractArgs& a, hipStream_t st) {
+  if (contract_use_16x16() && contract_nr() == 4) {
+    hipLaunchKernelGGL(k_contract16<4>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
+    return hipGetLastError();
+  }
   if (contract_nr() == 4)
     hipLaunchKernelGGL(k_contract<4>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
   else
