@@ -9,7 +9,7 @@
 // case); only the lower triangle (and the diagonal blocks) is read or written.  Right-looking, 64-wide block columns,
 // two launches per block column:
 //   k_chol_panel(k)   X = A[k+1:, k] W_k^T with W_k = L_kk^-1 (explicit 64x64 inverse): a 64x64x64 product per 64 rows
-//                     on v_mfma_f64_4x4x4_4b_f64 -- no serial substitution in the panel
+//                     on v_mfma_f64_16x16x4_f64 -- no serial substitution in the panel
 //   k_chol_update(k)  workgroup 0:  A_{k+1,k+1} -= X_{k+1} X_{k+1}^T (MFMA), then factors that block AND inverts the
 //                                   factor, blocked by 4 columns (256 threads, 4x4 elements each in registers, strips
 //                                   exchanged through 4 KB of LDS, two barriers per 4 columns); the serial chain of
@@ -27,10 +27,15 @@ namespace {
 constexpr int CB = 64;           // block size
 constexpr int CPITCH = 64 + 16;  // LDS pitch (doubles) of a k-major tile: conflict-free rotated A-fragment reads
 
-__device__ __forceinline__ void mfma4(double a, double b, double& c) {
-  asm("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+// v_mfma_f64_16x16x4_f64 accumulating in place in ARCHITECTURAL VGPRs: 64-cycle issue = the FP64 matrix peak (with AGPR
+// accumulators the same instruction takes 130 cycles, tools/ubench_mfma16.hip); one A and one B register per 2048 flop.
+// Lanes: A = 16 k + i, B = 16 k + j, D[i][j] in lane 16 (i % 4) + j, component i / 4.
+typedef double d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma16(double a, double b, d4& c) {
+  asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
-#define BOGP_CHOL_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
+// 16 passes: nothing may read the last results before they have left the pipe
+#define BOGP_CHOL_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
 
 // 1/sqrt(x): hardware estimate + two Newton-Raphson steps (FMA form), ~1 ulp
 __device__ __forceinline__ double rsqrt_nr(double x) {
@@ -46,7 +51,7 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 // acc[mi][t] += sum_kk Bside(row, kk) * Aside(col, kk) for the calling wave's 16 rows (16 w .. 16 w + 15) and all 64
 // columns.  Aside is staged by the whole workgroup into LDS as tile[kk][col] (k-major, pitch CPITCH) from a
 // column-major source with element (col, kk) at As[col + kk*lda]; Bside comes straight from global, element (row, kk)
-// at Bs[row + kk*ldb].  Result element of (mi, t) in this lane: row 16 w + (lane & 15), col 16 mi + 4 ((lb+t)&3) + lk.
+// at Bs[row + kk*ldb].  Result element acc[mi][t] of this lane: row 16 w + (lane & 15), column 16 mi + 4 t + (lane >> 4).
 __device__ __forceinline__ void stage_aside(double* lds, const double* __restrict__ As, int lda, int tid) {
   const int srow = tid >> 5, scol = (tid & 31) * 2;
 #pragma unroll
@@ -62,19 +67,26 @@ __device__ __forceinline__ void load_bside(double (&bv)[16], const double* __res
   for (int ks = 0; ks < 16; ++ks) bv[ks] = Bs[(size_t)(4 * ks + lk) * ldb + 16 * w + (lane & 15)];
 }
 __device__ __forceinline__ void mma_64(const double* lds, const double (&bv)[16], double (&acc)[4][4], int lane) {
-  const int lk = lane >> 4, lb = (lane >> 2) & 3, li = lane & 3;
-  int aoff[4];
+  const int aoff = (lane >> 4) * CPITCH + (lane & 15);  // MFMA-A = the LDS-staged side: lane (k, i) reads tile[k][16 mi + i]
+  d4 c[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) aoff[t] = lk * CPITCH + 4 * ((lb + t) & 3) + li;
+  for (int mi = 0; mi < 4; ++mi) c[mi] = (d4){acc[mi][0], acc[mi][1], acc[mi][2], acc[mi][3]};
+  // The MFMAs are inline asm, invisible to the compiler's hazard recogniser: the VALU moves that build c (and whatever
+  // register they recycle) must retire before the first MFMA reads c as SrcC -- these wait states are placed by hand.
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     const double* trow = &lds[4 * ks * CPITCH];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) mfma4(trow[aoff[t] + 16 * mi], bv[ks], acc[mi][t]);
+    for (int mi = 0; mi < 4; ++mi) mfma16(trow[aoff + 16 * mi], bv[ks], c[mi]);
   }
-  BOGP_CHOL_DRAIN();
+  // the drain names the accumulators as in/out operands so that no read of them can be scheduled above it
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+               : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[mi][t] = c[mi][t];
 }
 
 // ---- diagonal block: Cholesky factor and its inverse, blocked by 4 columns -----------------------------------------
@@ -260,11 +272,11 @@ __global__ __launch_bounds__(256) void k_chol_panel(const double* __restrict__ W
     for (int t = 0; t < 4; ++t) acc[mi][t] = 0.0;
   __syncthreads();
   mma_64(lds, bv, acc, lane);
-  const int lk = lane >> 4, lb = (lane >> 2) & 3;
+  const int lk = lane >> 4;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) Pb[(size_t)(16 * mi + 4 * ((lb + t) & 3) + lk) * ld + 16 * w + (lane & 15)] = acc[mi][t];
+    for (int t = 0; t < 4; ++t) Pb[(size_t)(16 * mi + 4 * t + lk) * ld + 16 * w + (lane & 15)] = acc[mi][t];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, con
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i0 = k0 + CB * (1 + bi), j0 = k0 + CB * (1 + bj);  // first row / column of the output block
-  const int lk = lane >> 4, lb = (lane >> 2) & 3;
+  const int lk = lane >> 4;
 
   stage_aside(lds, Xc + j0, ld, tid);  // tile[kk][c] = X(j0 + c, kk)
   double bv[16];
@@ -291,7 +303,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, con
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[mi][t] = -Ab[(size_t)(16 * mi + 4 * ((lb + t) & 3) + lk) * ld + 16 * w + (lane & 15)];
+    for (int t = 0; t < 4; ++t) acc[mi][t] = -Ab[(size_t)(16 * mi + 4 * t + lk) * ld + 16 * w + (lane & 15)];
   __syncthreads();
   mma_64(lds, bv, acc, lane);
 
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, con
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) Ab[(size_t)(16 * mi + 4 * ((lb + t) & 3) + lk) * ld + 16 * w + (lane & 15)] = -acc[mi][t];
+      for (int t = 0; t < 4; ++t) Ab[(size_t)(16 * mi + 4 * t + lk) * ld + 16 * w + (lane & 15)] = -acc[mi][t];
     return;
   }
   // ---- next diagonal block: stage the updated block in LDS (row-major, pitch 65), factor, invert -------------
@@ -307,7 +319,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, con
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) lds[(16 * w + (lane & 15)) * (CB + 1) + 16 * mi + 4 * ((lb + t) & 3) + lk] = -acc[mi][t];
+    for (int t = 0; t < 4; ++t) lds[(16 * w + (lane & 15)) * (CB + 1) + 16 * mi + 4 * t + lk] = -acc[mi][t];
   __syncthreads();
   double a[4][4], ww[4][4];
   const int bad = diag_factor_invert(lds, sb, a, ww, tid);
@@ -406,11 +418,11 @@ __global__ __launch_bounds__(256) void k_tri_gemm(TriArgs a, int mode0) {
     __syncthreads();
     mma_64(lds, bv, acc, lane);
   }
-  const int lk = lane >> 4, lb = (lane >> 2) & 3;
+  const int lk = lane >> 4;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) out[(size_t)(16 * mi + 4 * ((lb + t) & 3) + lk) * ld + 16 * w + (lane & 15)] = alpha * acc[mi][t];
+    for (int t = 0; t < 4; ++t) out[(size_t)(16 * mi + 4 * t + lk) * ld + 16 * w + (lane & 15)] = alpha * acc[mi][t];
 }
 
 // diagonal blocks: V_kk = W_k, U_kk = W_k^T (dense 64 x 64 blocks, zeros included)

@@ -333,7 +333,7 @@ __device__ __forceinline__ void contract_block16(const bool GUARDED, const doubl
 }
 
 template <int NR>
-__global__ __launch_bounds__(256, 2) void k_contract16(ContractArgs a) {
+__global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArgs a) {
   constexpr int JT16 = NWJ * NR;
   __shared__ __attribute__((aligned(16))) double lds[2 * KB * PITCH];
 
@@ -475,6 +475,10 @@ static bool contract_use_16x16() {
 hipError_t launch_contract(const ContractArgs& a, hipStream_t st) {
   if (contract_use_16x16() && contract_nr() == 4) {
     hipLaunchKernelGGL(k_contract16<4>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
+    return hipGetLastError();
+  }
+  if (contract_use_16x16() && contract_nr() == 2) {
+    hipLaunchKernelGGL(k_contract16<2>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
     return hipGetLastError();
   }
   if (contract_nr() == 4)
