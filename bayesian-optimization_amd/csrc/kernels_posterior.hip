@@ -297,7 +297,7 @@ __device__ __forceinline__ void mfma16_acc(double a, double b, d4& c) {
 template <int NR>
 __device__ __forceinline__ void contract_block16(const bool GUARDED, const double* __restrict__ tile, const double2* __restrict__ vp,
                                                  const size_t (&boff)[NR], const int (&jt)[NR], int aoff, int kb, int kp_last,
-                                                 double2 (&bq)[2][NR], d4 (&acc)[MR][NR]) {
+                                                 double2 (&bq)[4][NR], d4 (&acc)[MR][NR]) {
   // A fragments are read one k-step AHEAD of the MFMAs that use them (two register sets): with only four LDS reads per
   // sixteen MFMAs their latency would otherwise sit in front of every k-step
   double af[2][MR];
@@ -307,10 +307,10 @@ __device__ __forceinline__ void contract_block16(const bool GUARDED, const doubl
   for (int s = 0; s < 4; ++s) {
     const int kp = kb * 4 + s;
     const int kb16 = kp >> 1;
-    {  // prefetch the next k-pair of B fragments (clamped at the end of this group's range)
-      const int kpn = min(kp + 1, kp_last);
+    {  // B fragments are requested TWO k-pairs ahead (four slots = the four k-pairs of a block; clamped at the end)
+      const int kpn = min(kp + 2, kp_last);
 #pragma unroll
-      for (int ni = 0; ni < NR; ++ni) bq[(s + 1) & 1][ni] = vp[boff[ni] + (size_t)kpn * 64];
+      for (int ni = 0; ni < NR; ++ni) bq[(s + 2) & 3][ni] = vp[boff[ni] + (size_t)kpn * 64];
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -323,7 +323,7 @@ __device__ __forceinline__ void contract_block16(const bool GUARDED, const doubl
 #pragma unroll
       for (int ni = 0; ni < NR; ++ni) {
         if (!GUARDED || kb16 <= jt[ni]) {
-          const double bv = h == 0 ? bq[s & 1][ni].x : bq[s & 1][ni].y;
+          const double bv = h == 0 ? bq[s][ni].x : bq[s][ni].y;
 #pragma unroll
           for (int mi = 0; mi < MR; ++mi) mfma16_acc(af[sub & 1][mi], bv, acc[mi][ni]);
         }
@@ -390,9 +390,12 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
   } while (0)
 
   const double2* __restrict__ vp = a.Vp + lane;
-  double2 bq[2][NR];
+  double2 bq[4][NR];
 #pragma unroll
-  for (int ni = 0; ni < NR; ++ni) bq[0][ni] = vp[boff[ni]];
+  for (int ni = 0; ni < NR; ++ni) {
+    bq[0][ni] = vp[boff[ni]];
+    bq[1][ni] = vp[boff[ni] + (size_t)min(1, kp_last) * 64];
+  }
 
   // A lane = 16 k + i reads row k of the k-step, candidate 16 mi + i: pitch 640 B puts the four rows of a read in four
   // different 128-byte bank groups
