@@ -179,7 +179,7 @@ def main():
             "config": {"workload": w["name"], "N": N, "d": d, "M_per_gpu": M, "q": len(w["acq"]),
                        "parallelism": "candidate shards x%d, 1 all-gather of q*(val,idx) per step" % world},
             "roofline": {
-                "bound": "mfma", "kernel": "k_contract (v_mfma_f64_4x4x4_4b_f64)", "achieved": achieved, "peak": PEAK_FP64_TFLOPS,
+                "bound": "mfma", "kernel": "k_contract16 (v_mfma_f64_16x16x4_f64, VGPR accumulators)" if os.environ.get("BOGP_CONTRACT_MFMA", "16")[0] != "4" else "k_contract (v_mfma_f64_4x4x4_4b_f64)", "achieved": achieved, "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS,
                 "traffic": measured_traffic(args.workload, ((1 << 30) // (((N + 31) // 32 * 32) * 8)) // 64 * 64),
                 "avg_launch_ms": tim["contract_ms"] / max(1, tim["n_chunks"]), "launches": tim["n_chunks"],
