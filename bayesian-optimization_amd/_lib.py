@@ -40,6 +40,8 @@ SIGNATURES = {
     "bogp_candidates_upload": (C.c_int, [C.c_void_p, _dp, C.c_int64]),
     "bogp_candidates_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "bogp_candidates_generate": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_uint64, C.c_int64]),
+    "bogp_candidates_generate_lhs": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_uint64, C.c_int64, C.c_int64]),
+    "bogp_candidates_generate_sobol": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int64, C.POINTER(C.c_uint64), C.c_int]),
     "bogp_candidates_read": (C.c_int, [C.c_void_p, _lp, C.c_int, _dp]),
     "bogp_predict": (C.c_int, [C.c_void_p, _dp, _dp]),
     "bogp_sweep": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, C.c_double, C.c_int, _dp, _lp, _dp]),
@@ -99,6 +101,15 @@ def _f64(a, shape=None) -> np.ndarray:
 
 def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(_dp)
+
+
+def sobol_direction_numbers(d: int) -> np.ndarray:
+    """The (d, bits) direction numbers of scipy's unscrambled Sobol' generator (Joe & Kuo tables, bits = 30): what
+    the reference's `sobol_seq` call resolves to in this image.  Data for
+    `bogp_candidates_generate_sobol`, which carries no table of its own."""
+    from scipy.stats import qmc
+
+    return np.ascontiguousarray(qmc.Sobol(d=int(d), scramble=False)._sv, dtype=np.uint64)
 
 
 class Engine:
@@ -228,13 +239,32 @@ class Engine:
         self.M = int(M)
         self._keep = owner
 
-    def generate_candidates(self, lo, hi, M: int, seed: int, first_row: int = 0):
-        """M uniform points in the box [lo, hi] drawn ON the device (Philox4x32-10 stream `seed`, rows
-        [first_row, first_row + M)): no host sampling, no H2D copy."""
+    def generate_candidates(self, lo, hi, M: int, seed: int = 0, first_row: int = 0, method: str = "uniform",
+                            n_total: Optional[int] = None, sobol_sv: Optional[np.ndarray] = None):
+        """M points in the box [lo, hi] drawn ON the device -- no host sampling, no H2D copy.  `method` follows
+        RealSpace._sample (search_space.py:742-754): "uniform" (Philox4x32-10 stream `seed`, rows [first_row,
+        first_row + M)); "LHS" (rows [first_row, first_row + M) of an `n_total`-point Latin hypercube, default M);
+        "sobol" (points first_row + 1 ... of the unscrambled sequence -- the reference skips point 0 -- for the
+        direction numbers `sobol_sv` (d x bits), default scipy's)."""
         lo, hi = _f64(lo).ravel(), _f64(hi).ravel()
         if len(lo) != self.d or len(hi) != self.d:
             raise ValueError("bounds must have %d entries" % self.d)
-        self._check(self._lib.bogp_candidates_generate(self._h, _ptr(lo), _ptr(hi), int(M), C.c_uint64(int(seed) & (2**64 - 1)), int(first_row)))
+        useed = C.c_uint64(int(seed) & (2**64 - 1))
+        if method == "uniform":
+            rc = self._lib.bogp_candidates_generate(self._h, _ptr(lo), _ptr(hi), int(M), useed, int(first_row))
+        elif method == "LHS":
+            n_total = int(M) + int(first_row) if n_total is None else int(n_total)
+            rc = self._lib.bogp_candidates_generate_lhs(self._h, _ptr(lo), _ptr(hi), int(M), useed, int(first_row), n_total)
+        elif method == "sobol":
+            sv = sobol_direction_numbers(self.d) if sobol_sv is None else sobol_sv
+            sv = np.ascontiguousarray(sv, dtype=np.uint64)
+            if sv.ndim != 2 or sv.shape[0] != self.d:
+                raise ValueError("sobol_sv must be (d, bits)")
+            rc = self._lib.bogp_candidates_generate_sobol(self._h, _ptr(lo), _ptr(hi), int(M), int(first_row) + 1,
+                                                          sv.ctypes.data_as(C.POINTER(C.c_uint64)), int(sv.shape[1]))  # fmt: skip
+        else:
+            raise ValueError("method must be 'uniform', 'LHS' or 'sobol'")
+        self._check(rc)
         self.M = int(M)
         self._keep = None
 

@@ -60,6 +60,8 @@ struct bogp_handle {
   size_t xs_cap = 0;
   double* dbounds = nullptr;
   size_t bounds_cap = 0;
+  double* dsobol = nullptr;  // d x bits direction numbers (uint64 bit patterns)
+  size_t sobol_cap = 0;
   int64_t M = 0;
 
   // sweep scratch
@@ -189,7 +191,7 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   free_train(h);
   (void)hipStreamSynchronize(h->stream2);
-  dfree(h->dXs_owned); dfree(h->dss_part); dfree(h->dbounds);
+  dfree(h->dXs_owned); dfree(h->dss_part); dfree(h->dbounds); dfree(h->dsobol);
   for (int b = 0; b < 2; ++b) { dfree(h->drT[b]); dfree(h->dmu_part[b]); dfree(h->dw_part[b]); }
   dfree(h->dblk_val); dfree(h->dblk_idx); dfree(h->dmu_out); dfree(h->dmse_out); dfree(h->dacq_out);
   dfree(h->dbest_val); dfree(h->dbest_idx); dfree(h->dinfo); dfree(h->dscal); dfree(h->dgrad_partial); dfree(h->dbatch);
@@ -709,25 +711,63 @@ extern "C" int bogp_candidates_upload(bogp_handle* h, const double* Xs, int64_t 
   return BOGP_OK;
 }
 
-extern "C" int bogp_candidates_generate(bogp_handle* h, const double* lo, const double* hi, int64_t M, uint64_t seed,
-                                        int64_t first_row) {
-  if (!h) return BOGP_ERR_INVALID;
-  if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_generate: call bogp_set_train first (d is unknown)");
-  if (!lo || !hi || M <= 0 || first_row < 0) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_generate: bounds must be non-null, M > 0, first_row >= 0");
+// shared front end of the three on-device generators: validates the box, sizes the candidate buffer, stages lo / hi
+static int generate_prepare(bogp_handle* h, const char* who, const double* lo, const double* hi, int64_t M, int64_t first) {
+  if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "%s: call bogp_set_train first (d is unknown)", who);
+  if (!lo || !hi || M <= 0 || first < 0) FAIL(h, BOGP_ERR_INVALID, "%s: bounds must be non-null, M > 0, first row/index >= 0", who);
   const int d = h->d;
   for (int k = 0; k < d; ++k)
-    if (!(std::isfinite(lo[k]) && std::isfinite(hi[k]) && lo[k] <= hi[k])) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_generate: bad bounds in dimension %d", k);
+    if (!(std::isfinite(lo[k]) && std::isfinite(hi[k]) && lo[k] <= hi[k])) FAIL(h, BOGP_ERR_INVALID, "%s: bad bounds in dimension %d", who, k);
   HIPCHK(h, hipSetDevice(h->device));
   int e = ensure(h, &h->dXs_owned, &h->xs_cap, (size_t)M * d);
   if (e) return e;
   if ((e = ensure(h, &h->dbounds, &h->bounds_cap, (size_t)2 * d))) return e;
   HIPCHK(h, hipMemcpyAsync(h->dbounds, lo, d * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->dbounds + d, hi, d * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, launch_generate_uniform(h->dXs_owned, M * d, d, h->dbounds, h->dbounds + d, seed, (uint64_t)first_row * (uint64_t)d, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));  // lo / hi are caller memory
+  return BOGP_OK;
+}
+
+static int generate_finish(bogp_handle* h, int64_t M) {
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // lo / hi (and sv) are caller memory
   h->dXs = h->dXs_owned;
   h->M = M;
   return BOGP_OK;
+}
+
+extern "C" int bogp_candidates_generate(bogp_handle* h, const double* lo, const double* hi, int64_t M, uint64_t seed,
+                                        int64_t first_row) {
+  if (!h) return BOGP_ERR_INVALID;
+  int e = generate_prepare(h, "bogp_candidates_generate", lo, hi, M, first_row);
+  if (e) return e;
+  const int d = h->d;
+  HIPCHK(h, launch_generate_uniform(h->dXs_owned, M * d, d, h->dbounds, h->dbounds + d, seed, (uint64_t)first_row * (uint64_t)d, h->stream));
+  return generate_finish(h, M);
+}
+
+extern "C" int bogp_candidates_generate_lhs(bogp_handle* h, const double* lo, const double* hi, int64_t M, uint64_t seed,
+                                            int64_t first_row, int64_t n_strata) {
+  if (!h) return BOGP_ERR_INVALID;
+  int e = generate_prepare(h, "bogp_candidates_generate_lhs", lo, hi, M, first_row);
+  if (e) return e;
+  if (n_strata < first_row + M) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_generate_lhs: rows [%lld, %lld) exceed the %lld strata", (long long)first_row, (long long)(first_row + M), (long long)n_strata);
+  const int d = h->d;
+  HIPCHK(h, launch_generate_lhs(h->dXs_owned, M * d, d, h->dbounds, h->dbounds + d, seed, (uint64_t)first_row * (uint64_t)d, (uint64_t)n_strata, h->stream));
+  return generate_finish(h, M);
+}
+
+extern "C" int bogp_candidates_generate_sobol(bogp_handle* h, const double* lo, const double* hi, int64_t M,
+                                              int64_t first_index, const uint64_t* sv, int bits) {
+  if (!h) return BOGP_ERR_INVALID;
+  int e = generate_prepare(h, "bogp_candidates_generate_sobol", lo, hi, M, first_index);
+  if (e) return e;
+  if (!sv || bits < 1 || bits > 53) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_generate_sobol: direction numbers must be non-null with 1 <= bits <= 53");
+  if (((uint64_t)(first_index + M - 1) >> bits) != 0) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_generate_sobol: index %lld needs more than %d bits", (long long)(first_index + M - 1), bits);
+  const int d = h->d;
+  if ((e = ensure(h, &h->dsobol, &h->sobol_cap, (size_t)d * bits))) return e;
+  HIPCHK(h, hipMemcpyAsync(h->dsobol, sv, (size_t)d * bits * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, launch_generate_sobol(h->dXs_owned, M * d, d, h->dbounds, h->dbounds + d, (const uint64_t*)h->dsobol, bits,
+                                  (uint64_t)first_index * (uint64_t)d, h->stream));
+  return generate_finish(h, M);
 }
 
 extern "C" int bogp_candidates_read(bogp_handle* h, const int64_t* rows, int n, double* out) {
@@ -736,9 +776,13 @@ extern "C" int bogp_candidates_read(bogp_handle* h, const int64_t* rows, int n, 
   if (!rows || !out || n < 0) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_read: null pointer");
   HIPCHK(h, hipSetDevice(h->device));
   const int d = h->d;
-  for (int i = 0; i < n; ++i) {
+  for (int i = 0; i < n; ++i)
     if (rows[i] < 0 || rows[i] >= h->M) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_read: row %lld outside [0, %lld)", (long long)rows[i], (long long)h->M);
-    HIPCHK(h, hipMemcpyAsync(out + (size_t)i * d, h->dXs + (size_t)rows[i] * d, d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  for (int i = 0; i < n;) {  // one copy per run of consecutive rows
+    int j = i + 1;
+    while (j < n && rows[j] == rows[j - 1] + 1) ++j;
+    HIPCHK(h, hipMemcpyAsync(out + (size_t)i * d, h->dXs + (size_t)rows[i] * d, (size_t)(j - i) * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    i = j;
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return BOGP_OK;

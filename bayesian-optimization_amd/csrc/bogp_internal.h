@@ -77,6 +77,10 @@ hipError_t launch_block_argmax_excl(const double* vals, int64_t M, const int64_t
 
 hipError_t launch_generate_uniform(double* Xs, int64_t n_elem, int d, const double* lo, const double* hi, uint64_t seed,
                                    uint64_t first_elem, hipStream_t st);
+hipError_t launch_generate_lhs(double* Xs, int64_t n_elem, int d, const double* lo, const double* hi, uint64_t seed,
+                               uint64_t first_elem, uint64_t n_strata, hipStream_t st);
+hipError_t launch_generate_sobol(double* Xs, int64_t n_elem, int d, const double* lo, const double* hi, const uint64_t* sv,
+                                 int bits, uint64_t first_elem, hipStream_t st);
 
 // fit-path kernels (kernels_fit.hip)
 hipError_t launch_build_R(int kernel, const double* X, int N, int d, const double* theta, double off_scale, double diag,

@@ -253,6 +253,106 @@ hipError_t launch_generate_uniform(double* Xs, int64_t n_elem, int d, const doub
   return hipGetLastError();
 }
 
+// Latin hypercube in a box (RealSpace._sample method "LHS", search_space.py:747-751, which calls pyDOE's lhs:
+// one point per stratum and dimension, strata shuffled independently per dimension).  Counter-based so that rank
+// shards are independent: row i of dimension k lands in stratum pi_k(i), a keyed pseudo-random PERMUTATION of
+// [0, n_strata) evaluated per element -- a 6-round balanced Feistel network on 2*hb bits (hb = ceil(bits(n-1)/2))
+// with cycle walking, round function fmix32 (the MurmurHash3 finaliser), round keys = Philox(counter (k, 'LHS', r/4),
+// key seed).  The jitter u inside the stratum is the element's word of the uniform stream above;
+// x = lo + (hi - lo) * ((pi + u) / n).  pyDOE's "maximin" criterion (5 O(n^2 d) pdist passes) is not reproduced: it
+// is infeasible at sweep sizes in the reference too (n = 1e6 -> 4 TB of pair distances).  oracle/philox.py restates
+// the integer arithmetic, so parity is bit-exact.
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+
+__global__ __launch_bounds__(256) void k_generate_lhs(double* __restrict__ Xs, int64_t n_elem, int d,
+                                                      const double* __restrict__ lo, const double* __restrict__ hi,
+                                                      uint64_t seed, uint64_t first_elem, uint64_t n_strata, int hb) {
+#pragma clang fp contract(off)
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_elem) return;
+  const uint64_t E = first_elem + (uint64_t)e;
+  const uint32_t k = (uint32_t)(E % (uint64_t)d);
+  uint64_t i = E / (uint64_t)d;
+  uint32_t rk[8];
+  {
+    uint32_t w[4];
+    philox4x32_10(k, 0x4C4853u, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    rk[0] = w[0]; rk[1] = w[1]; rk[2] = w[2]; rk[3] = w[3];
+    philox4x32_10(k, 0x4C4853u, 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    rk[4] = w[0]; rk[5] = w[1]; rk[6] = w[2]; rk[7] = w[3];
+  }
+  const uint32_t mask = (uint32_t)((1ull << hb) - 1ull);
+  if (n_strata > 1) {
+    do {
+      uint32_t L = (uint32_t)(i >> hb), R = (uint32_t)i & mask;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const uint32_t F = fmix32(R ^ rk[r]) & mask;
+        const uint32_t t = L ^ F;
+        L = R;
+        R = t;
+      }
+      i = ((uint64_t)L << hb) | (uint64_t)R;
+    } while (i >= n_strata);
+  } else {
+    i = 0;
+  }
+  const uint64_t P = E >> 1;
+  uint32_t w[4];
+  philox4x32_10((uint32_t)P, (uint32_t)(P >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  const int h2 = (int)(E & 1ull);
+  const double u = ((double)(w[2 * h2] >> 5) * 67108864.0 + (double)(w[2 * h2 + 1] >> 6)) * (1.0 / 9007199254740992.0);
+  const double t = ((double)i + u) / (double)n_strata;
+  const double width = hi[k] - lo[k];
+  const double scaled = width * t;
+  Xs[e] = lo[k] + scaled;
+}
+
+hipError_t launch_generate_lhs(double* Xs, int64_t n_elem, int d, const double* lo, const double* hi, uint64_t seed,
+                               uint64_t first_elem, uint64_t n_strata, hipStream_t st) {
+  int bits = 0;
+  while (bits < 63 && ((n_strata - 1) >> bits) != 0) ++bits;
+  const int hb = bits < 2 ? 1 : (bits + 1) / 2;
+  hipLaunchKernelGGL(k_generate_lhs, dim3((unsigned)((n_elem + 255) / 256)), 256, 0, st, Xs, n_elem, d, lo, hi, seed, first_elem,
+                     n_strata, hb);
+  return hipGetLastError();
+}
+
+// Sobol' points in a box (RealSpace._sample method "sobol", search_space.py:752-753).  The direction numbers are an
+// INPUT (d x bits integers, sv[k][b] for bit b of the Gray code, as scipy.stats.qmc.Sobol holds them in `_sv`), so
+// the library carries no table; point n is XOR_{b in gray(n)} sv[k][b], scaled by 2^-bits -- exactly the sequence
+// scipy's unscrambled generator produces, any block [first_index, first_index + M) of it independently per rank.
+__global__ __launch_bounds__(256) void k_generate_sobol(double* __restrict__ Xs, int64_t n_elem, int d,
+                                                        const double* __restrict__ lo, const double* __restrict__ hi,
+                                                        const uint64_t* __restrict__ sv, int bits, uint64_t first_elem) {
+#pragma clang fp contract(off)
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_elem) return;
+  const uint64_t E = first_elem + (uint64_t)e;
+  const int k = (int)(E % (uint64_t)d);
+  const uint64_t n = E / (uint64_t)d;
+  uint64_t g = n ^ (n >> 1), v = 0;
+  const uint64_t* svk = sv + (size_t)k * bits;
+  while (g) {
+    const int b = __builtin_ctzll(g);
+    v ^= svk[b];
+    g &= g - 1;
+  }
+  const double t = (double)v * __builtin_ldexp(1.0, -bits);
+  const double width = hi[k] - lo[k];
+  const double scaled = width * t;
+  Xs[e] = lo[k] + scaled;
+}
+
+hipError_t launch_generate_sobol(double* Xs, int64_t n_elem, int d, const double* lo, const double* hi, const uint64_t* sv,
+                                 int bits, uint64_t first_elem, hipStream_t st) {
+  hipLaunchKernelGGL(k_generate_sobol, dim3((unsigned)((n_elem + 255) / 256)), 256, 0, st, Xs, n_elem, d, lo, hi, sv, bits, first_elem);
+  return hipGetLastError();
+}
+
 hipError_t launch_acquisition(const AcqArgs& a, hipStream_t st) {
   const unsigned nblk = (unsigned)((a.mcount + 255) / 256);
   hipLaunchKernelGGL(k_acquisition, dim3(nblk), 256, 0, st, a);

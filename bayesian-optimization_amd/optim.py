@@ -71,10 +71,13 @@ def sweep_argmax(criteria: Sequence, Xs: np.ndarray, index_offset: int = 0, grou
     return distributed.exchange_argmax(best, gidx, xbest, group=group)
 
 
-def sweep_generated(criteria: Sequence, bounds, M: int, seed: int, rank: int = 0, world: int = 1, group=None):
-    """`sweep_argmax` over M uniform candidates in `bounds` that never touch the host: rank r draws rows
-    [r M / R, (r+1) M / R) of the Philox stream `seed` on its GPU, sweeps them, and the ranks exchange their
-    winners (value, global row, point).  The union of the shards is the same M-point set for every world size."""
+def sweep_generated(criteria: Sequence, bounds, M: int, seed: int, rank: int = 0, world: int = 1, group=None,
+                    method: str = "uniform"):
+    """`sweep_argmax` over M candidates in `bounds` that never touch the host: rank r draws rows
+    [r M / R, (r+1) M / R) of the design on its GPU, sweeps them, and the ranks exchange their winners (value, global
+    row, point).  `method` names the design like `RealSpace._sample` does (search_space.py:742-754): "uniform" (Philox
+    stream `seed`), "LHS" (an M-point Latin hypercube of stream `seed`), "sobol" (points 1..M of the unscrambled
+    sequence; `seed` unused).  The union of the shards is the same M-point set for every world size."""
     c0 = criteria[0]
     model = c0.model
     if getattr(model, "_committed_par", None) is None:
@@ -83,7 +86,7 @@ def sweep_generated(criteria: Sequence, bounds, M: int, seed: int, rank: int = 0
     hi = np.array([b[1] for b in bounds], dtype=float)
     a, b_ = shard_bounds(int(M), rank, world)
     eng = model.engine
-    eng.generate_candidates(lo, hi, b_ - a, seed, first_row=a)
+    eng.generate_candidates(lo, hi, b_ - a, seed, first_row=a, method=method, n_total=int(M))
     best, idx = eng.sweep([(c.acq_id, c.acq_par()) for c in criteria], c0.effective_plugin(), c0.minimize)
     return distributed.exchange_argmax(best, idx + a, eng.read_candidates(idx), group=group)
 
@@ -158,6 +161,10 @@ def unwrap_criterion(obj):
     return None, None, None
 
 
+# optimizer name -> sampling method of RealSpace._sample (search_space.py:742-754) realised on the device
+DEVICE_DESIGNS = {"sweep-device": "uniform", "sweep-device-lhs": "LHS", "sweep-device-sobol": "sobol"}
+
+
 def argmax_restart(
     obj_func: Callable,
     search_space,
@@ -173,14 +180,17 @@ def argmax_restart(
 
     optimizer="sweep": `obj_func` must be one of this package's acquisition objects; `eval_budget` candidates are
     drawn with `search_space.sample(N, "uniform")` and swept on the GPU.
+    optimizer="sweep-device" / "sweep-device-lhs" / "sweep-device-sobol": the candidates (uniform / Latin hypercube /
+    Sobol') are generated on the GPU and never touch the host.
     optimizer="BFGS": the reference's multi-restart L-BFGS-B loop on `obj_func(x) -> (value, dx)` (host; every
     evaluation is one device call through the acquisition object).
     """
-    if optimizer == "sweep-device":  # candidates drawn on the GPU; the stream is seeded from the global np.random
+    if optimizer in DEVICE_DESIGNS:  # candidates drawn on the GPU; the stream is seeded from the global np.random
         crit, masks, _ = unwrap_criterion(obj_func)
         if crit is None or masks is not None or h is not None or g is not None:
-            raise NotImplementedError("optimizer='sweep-device' takes an unconstrained bogp criterion without fixed variables")
-        best, _, xb = sweep_generated([crit], search_space.bounds, int(eval_budget), int(np.random.randint(0, 2**62)))
+            raise NotImplementedError("optimizer=%r takes an unconstrained bogp criterion without fixed variables" % optimizer)
+        best, _, xb = sweep_generated([crit], search_space.bounds, int(eval_budget), int(np.random.randint(0, 2**62)),
+                                      method=DEVICE_DESIGNS[optimizer])  # fmt: skip
         return xb[0].tolist(), float(best[0])
     if optimizer == "sweep":
         if h is not None or g is not None:
@@ -211,7 +221,7 @@ def argmax_restart(
         obj_func, optimizer = crit, "BFGS"
     if optimizer != "BFGS":
         raise NotImplementedError(
-            "optimizer %r is out of scope here (SURVEY.md 2 rows 6-7); use 'BFGS', 'sweep', 'sweep-device' or 'sweep-BFGS'" % optimizer
+            "optimizer %r is out of scope here (SURVEY.md 2 rows 6-7); use 'BFGS', 'sweep', 'sweep-device[-lhs|-sobol]' or 'sweep-BFGS'" % optimizer
         )
 
     xopt, fopt = [], []

@@ -144,6 +144,19 @@ int bogp_candidates_bind(bogp_handle* h, const void* d_Xs, int64_t M);
  * `read` copies chosen rows (e.g. the argmax) of the current candidates back: out is n x d.                  */
 int bogp_candidates_generate(bogp_handle* h, const double* lo, const double* hi, int64_t M, uint64_t seed,
                              int64_t first_row);
+/* `generate_lhs`: rows [first_row, first_row + M) of an n_strata-point Latin hypercube (method "LHS",
+ * search_space.py:747-751 -> pyDOE.lhs): per dimension one point in each of n_strata equal strata, the strata
+ * visited in a keyed pseudo-random permutation (Feistel network + cycle walking, evaluated per element, so no sort
+ * and no exchange between ranks), jitter inside the stratum from the uniform stream.  pyDOE's "maximin" selection
+ * among 5 such designs costs O(n^2 d) per design and is not reproduced.
+ * `generate_sobol`: points [first_index, first_index + M) of the unscrambled Sobol' sequence (method "sobol",
+ * search_space.py:752-753 -> sobol_seq.i4_sobol_generate, whose skip = 1 is first_index = 1) for caller-supplied
+ * direction numbers sv (d x bits, row-major, sv[k][b] is XORed in when bit b of the Gray code of the index is set --
+ * the layout of scipy.stats.qmc.Sobol._sv); value = integer * 2^-bits, then lo + (hi - lo) * value.            */
+int bogp_candidates_generate_lhs(bogp_handle* h, const double* lo, const double* hi, int64_t M, uint64_t seed,
+                                 int64_t first_row, int64_t n_strata);
+int bogp_candidates_generate_sobol(bogp_handle* h, const double* lo, const double* hi, int64_t M, int64_t first_index,
+                                   const uint64_t* sv, int bits);
 int bogp_candidates_read(bogp_handle* h, const int64_t* rows, int n, double* out);
 
 /* ---- posterior ------------------------------------------------------------------------------------

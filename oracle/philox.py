@@ -47,3 +47,87 @@ def uniform_box(lo, hi, M, seed, first_row=0):
     u = ((a >> np.uint64(5)).astype(np.float64) * 67108864.0 + (b >> np.uint64(6)).astype(np.float64)) * (1.0 / 9007199254740992.0)
     k = (E % np.uint64(d)).astype(np.int64)
     return (lo[k] + (hi[k] - lo[k]) * u).reshape(M, d)
+
+
+def _unit_words(E, seed):
+    """u in [0, 1) for the global element indices E (uint64 array) of stream `seed`: the words `uniform_box` uses."""
+    P = E >> np.uint64(1)
+    z = np.zeros(len(E), dtype=np.uint32)
+    w = philox4x32_10((P & MASK).astype(np.uint32), (P >> np.uint64(32)).astype(np.uint32), z, z,
+                      np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF))  # fmt: skip
+    odd = (E & np.uint64(1)).astype(bool)
+    a = np.where(odd, w[2], w[0]).astype(np.uint64)
+    b = np.where(odd, w[3], w[1]).astype(np.uint64)
+    return ((a >> np.uint64(5)).astype(np.float64) * 67108864.0 + (b >> np.uint64(6)).astype(np.float64)) * (1.0 / 9007199254740992.0)
+
+
+def fmix32(h):
+    """MurmurHash3's 32-bit finaliser (Appleby, public domain)."""
+    h = np.asarray(h, dtype=np.uint32).copy()
+    with np.errstate(over="ignore"):
+        h ^= h >> np.uint32(16)
+        h *= np.uint32(0x85EBCA6B)
+        h ^= h >> np.uint32(13)
+        h *= np.uint32(0xC2B2AE35)
+        h ^= h >> np.uint32(16)
+    return h
+
+
+def lhs_permutation(i, k, seed, n):
+    """pi_k(i): the keyed permutation of [0, n) libbogp's Latin hypercube uses for dimension k (arrays i, k of equal
+    length).  6-round balanced Feistel network on 2*hb bits + cycle walking; round keys = the 8 words of
+    Philox(counter (k, 0x4C4853, 0|1, 0), key seed), the first six used."""
+    i = np.asarray(i, dtype=np.uint64).copy()
+    k = np.asarray(k, dtype=np.uint32)
+    if n <= 1:
+        return np.zeros_like(i)
+    bits = int(n - 1).bit_length()
+    hb = 1 if bits < 2 else (bits + 1) // 2
+    mask = np.uint32((1 << hb) - 1)
+    z = np.zeros(len(i), dtype=np.uint32)
+    tag = np.full(len(i), 0x4C4853, dtype=np.uint32)
+    k0, k1 = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+    rk = list(philox4x32_10(k, tag, z, z, k0, k1)) + list(philox4x32_10(k, tag, z + np.uint32(1), z, k0, k1))
+    todo = np.ones(len(i), dtype=bool)
+    while todo.any():
+        v = i[todo]
+        L = (v >> np.uint64(hb)).astype(np.uint32)
+        R = v.astype(np.uint32) & mask
+        for r in range(6):
+            F = fmix32(R ^ rk[r][todo]) & mask
+            L, R = R, L ^ F
+        v = (L.astype(np.uint64) << np.uint64(hb)) | R.astype(np.uint64)
+        i[todo] = v
+        todo[todo] = v >= np.uint64(n)
+    return i
+
+
+def lhs_box(lo, hi, M, seed, first_row=0, n_strata=None):
+    """Rows [first_row, first_row + M) of the n_strata-point Latin hypercube of stream `seed` in the box [lo, hi]
+    (csrc/kernels_acq.hip k_generate_lhs; follows pyDOE's classic design: one jittered point per stratum and
+    dimension, strata shuffled per dimension)."""
+    lo = np.asarray(lo, dtype=np.float64)
+    hi = np.asarray(hi, dtype=np.float64)
+    d = len(lo)
+    n = int(first_row + M if n_strata is None else n_strata)
+    E = np.arange(first_row * d, (first_row + M) * d, dtype=np.uint64)
+    k = (E % np.uint64(d)).astype(np.int64)
+    pi = lhs_permutation(E // np.uint64(d), k.astype(np.uint32), seed, n)
+    t = (pi.astype(np.float64) + _unit_words(E, seed)) / float(n)
+    return (lo[k] + (hi[k] - lo[k]) * t).reshape(M, d)
+
+
+def sobol_box(lo, hi, M, sv, first_index=1):
+    """Points [first_index, first_index + M) of the unscrambled Sobol' sequence with direction numbers sv (d, bits) in
+    the box [lo, hi] (k_generate_sobol): XOR of sv[:, b] over the set bits b of the index's Gray code."""
+    lo = np.asarray(lo, dtype=np.float64)
+    hi = np.asarray(hi, dtype=np.float64)
+    sv = np.asarray(sv, dtype=np.uint64)
+    d, bits = sv.shape
+    n = np.arange(first_index, first_index + M, dtype=np.uint64)
+    g = n ^ (n >> np.uint64(1))
+    v = np.zeros((M, d), dtype=np.uint64)
+    for b in range(bits):
+        sel = ((g >> np.uint64(b)) & np.uint64(1)).astype(bool)
+        v[sel] ^= sv[:, b]
+    return lo + (hi - lo) * (v.astype(np.float64) * 2.0**-bits)

@@ -503,6 +503,55 @@ def test_device_candidate_generation_is_bit_exact_and_shardable(eng):
     np.testing.assert_array_equal(eng.read_candidates(idx), Xs[oidx])
 
 
+def test_device_latin_hypercube_and_sobol_are_bit_exact_and_shardable(eng):
+    """f4: the two other designs of RealSpace._sample (search_space.py:742-754) drawn on the device."""
+    from oracle import philox as P
+
+    g = load_golden("G1_se_sk_noisy")
+    commit_golden(eng, g)
+    d = g["X"].shape[1]
+    lo, hi = np.full(d, -5.0), np.linspace(1.0, 5.0, d)
+    for M, first, n in ((1, 0, 1), (7, 0, 7), (4097, 0, 4097), (1000, 123457, 200000), (513, 0, 513)):
+        eng.generate_candidates(lo, hi, M, seed=0xFEEDFACE1234, first_row=first, method="LHS", n_total=n)
+        np.testing.assert_array_equal(eng.read_candidates(np.arange(M)), P.lhs_box(lo, hi, M, 0xFEEDFACE1234, first, n))
+    sv = bogp._lib.sobol_direction_numbers(d)
+    for M, first in ((1, 0), (4096, 0), (1000, 987654)):
+        eng.generate_candidates(lo, hi, M, first_row=first, method="sobol")
+        np.testing.assert_array_equal(eng.read_candidates(np.arange(M)), P.sobol_box(lo, hi, M, sv, first + 1))
+    # the sequence the reference would have drawn (scipy's generator minus point 0), bit for bit
+    import warnings
+
+    from scipy.stats import qmc
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = (hi - lo) * qmc.Sobol(d=d, scramble=False).random(2049)[1:] + lo
+    eng.generate_candidates(lo, hi, 2048, method="sobol")
+    np.testing.assert_array_equal(eng.read_candidates(np.arange(2048)), ref)
+    with pytest.raises(bogp._lib.BogpError):
+        eng.generate_candidates(lo, hi, 16, first_row=2**30, method="sobol")  # beyond the 30-bit sequence
+    with pytest.raises(bogp._lib.BogpError):
+        eng.generate_candidates(lo, hi, 16, first_row=10, method="LHS", n_total=20)  # rows outside the design
+
+
+def test_device_latin_hypercube_at_full_size_has_one_point_per_stratum():
+    """Size-independent property at BASELINE's C3 candidate count: every column visits each of the 1e6 strata once."""
+    N, d, M = 64, 20, 1_000_000
+    rng = np.random.default_rng(0)
+    e = bogp.Engine()
+    e.set_train(rng.uniform(-5, 5, (N, d)), rng.standard_normal((N, 1)))
+    lo, hi = np.full(d, -5.0), np.full(d, 5.0)
+    halves = []
+    for a, b in ((0, 400_000), (400_000, M)):
+        e.generate_candidates(lo, hi, b - a, seed=11, first_row=a, method="LHS", n_total=M)
+        halves.append(e.read_candidates(np.arange(b - a)))
+    X = np.vstack(halves)
+    strata = np.floor((X - lo) / (hi - lo) * M).astype(np.int64)
+    for k in range(d):
+        assert np.array_equal(np.sort(strata[:, k]), np.arange(M)), k
+    assert np.abs(np.corrcoef(X[:, :4].T) - np.eye(4)).max() < 0.01
+
+
 def test_sweep_generated_and_device_optimizer():
     g = load_golden("G1_se_sk_noisy")
     d = g["X"].shape[1]
@@ -521,6 +570,15 @@ def test_sweep_generated_and_device_optimizer():
     xopt, fopt = bogp.argmax_restart(crit[0], bogp.optim.Box(bounds), eval_budget=20000, optimizer="sweep-device")
     assert len(xopt) == d and fopt > 0
     np.testing.assert_allclose(float(np.ravel(crit[0](np.array(xopt).reshape(1, -1)))[0]), fopt, rtol=1e-9)
+    for name in ("sweep-device-lhs", "sweep-device-sobol"):
+        xo, fo = bogp.argmax_restart(crit[0], bogp.optim.Box(bounds), eval_budget=20000, optimizer=name)
+        assert len(xo) == d and fo > 0
+        np.testing.assert_allclose(float(np.ravel(crit[0](np.array(xo).reshape(1, -1)))[0]), fo, rtol=1e-9)
+    # Sobol' is deterministic: shards of it give the same winner as the whole
+    ws = bogp.sweep_generated(crit, bounds, 30000, seed=0, method="sobol")
+    ps = [bogp.sweep_generated(crit, bounds, 30000, seed=0, rank=r, world=2, method="sobol") for r in range(2)]
+    r = int(np.argmax([p[0][0] for p in ps]))
+    assert ps[r][1][0] == ws[1][0] and ps[r][0][0] == ws[0][0]
 
 
 @pytest.mark.parametrize("mode_kw", [dict(nugget=0, noise_estim=False), dict(nugget=1e-6, noise_estim=False), dict(nugget=1e-6, noise_estim=True)])

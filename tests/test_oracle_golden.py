@@ -208,6 +208,49 @@ def test_philox_uniform_box_properties():
     assert not np.array_equal(P.uniform_box(lo, hi, 10, 1), P.uniform_box(lo, hi, 10, 2))
 
 
+def test_latin_hypercube_restatement_properties():
+    """One point per stratum and dimension (what pyDOE's classic design guarantees, search_space.py:747-751), for
+    every n incl. non-powers of two; shards of one design are independent of how it is cut."""
+    from oracle import philox as P
+
+    lo, hi = np.array([-5.0, 0.0, 2.0]), np.array([5.0, 1.0, 2.5])
+    for n in (1, 2, 3, 7, 64, 1000, 4097):
+        X = P.lhs_box(lo, hi, n, seed=99)
+        strata = np.floor((X - lo) / (hi - lo) * n).astype(int)
+        for k in range(3):
+            assert sorted(strata[:, k].tolist()) == list(range(n)), (n, k)
+    whole = P.lhs_box(lo, hi, 1000, 7)
+    parts = np.vstack([P.lhs_box(lo, hi, 400, 7, 0, 1000), P.lhs_box(lo, hi, 600, 7, 400, 1000)])
+    np.testing.assert_array_equal(parts, whole)
+    # per-dimension permutations differ from each other and between seeds
+    big = P.lhs_box(lo, hi, 4096, 5)
+    assert np.abs(np.corrcoef(big.T) - np.eye(3)).max() < 0.08
+    assert not np.array_equal(P.lhs_box(lo, hi, 64, 1), P.lhs_box(lo, hi, 64, 2))
+    # the keyed permutation is a bijection on awkward domain sizes
+    for n in (2, 5, 17, 1025):
+        pi = P.lhs_permutation(np.arange(n), np.zeros(n, dtype=np.uint32), 3, n)
+        assert sorted(pi.tolist()) == list(range(n))
+
+
+def test_sobol_restatement_equals_the_reference_generator():
+    """RealSpace._sample(method="sobol") (search_space.py:752-753) = (ub - lb) * i4_sobol_generate(dim, N) + lb; in
+    this image `sobol_seq` resolves to scipy's unscrambled generator minus its first point."""
+    import warnings
+
+    from scipy.stats import qmc
+
+    from oracle import philox as P
+
+    for d in (1, 3, 20, 50):
+        lo, hi = np.linspace(-5, -1, d), np.linspace(1, 5, d)
+        sv = qmc.Sobol(d=d, scramble=False)._sv
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = (hi - lo) * qmc.Sobol(d=d, scramble=False).random(1000 + 1)[1:] + lo
+        np.testing.assert_array_equal(P.sobol_box(lo, hi, 1000, sv, 1), ref)
+        np.testing.assert_array_equal(P.sobol_box(lo, hi, 300, sv, 701), ref[700:])
+
+
 def test_absexp_llf_tables():
     g = load_golden("G12_absexp_ok_noisy")
     n = 0
