@@ -18,6 +18,7 @@ MODE_NOISELESS, MODE_NOISY, MODE_NOISE_ESTIM = 0, 1, 2
 ACQ_EI, ACQ_EPSILON_PI, ACQ_UCB, ACQ_MGFI = 0, 1, 2, 3
 TREND_CONSTANT, TREND_LINEAR, TREND_QUADRATIC = 0, 1, 2
 MAX_Q = 64
+MAX_TARGETS = 8
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -30,6 +31,7 @@ SIGNATURES = {
     "bogp_last_error": (C.c_char_p, [C.c_void_p]),
     "bogp_abi_version": (C.c_int, []),
     "bogp_set_train": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_int]),
+    "bogp_select_target": (C.c_int, [C.c_void_p, C.c_int]),
     "bogp_nll": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp, _dp]),
     "bogp_commit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp]),
     "bogp_nll_restricted": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp, _dp]),
@@ -153,6 +155,11 @@ class Engine:
         y = _f64(y).reshape(len(X), -1)
         self._check(self._lib.bogp_set_train(self._h, _ptr(X), _ptr(y), X.shape[0], X.shape[1], y.shape[1]))
         self.N, self.d = X.shape
+        self.n_t = y.shape[1]
+
+    def select_target(self, t: int):
+        """Column of a multi-target y that get_state / predict / sweep / gradient work on (0 after set_train, commit)."""
+        self._check(self._lib.bogp_select_target(self._h, int(t)))
 
     def _trend_beta(self, trend, estimate_trend, beta) -> float:
         """Fixed coefficients of a p > 1 basis travel through bogp_set_trend_beta; the scalar argument serves p = 1."""
@@ -204,6 +211,21 @@ class Engine:
         return int(self._lib.bogp_trend_size(int(self.trend if trend is None else trend), int(self.d)))
 
     def get_state(self, with_C=True) -> dict:
+        if getattr(self, "n_t", 1) > 1:  # one column per target: gamma, rho, Yt (N, n_t); sigma2, noise_var (n_t,)
+            cols = []
+            for t in range(self.n_t):
+                self.select_target(t)
+                cols.append(self._get_state_active(with_C and t == 0))
+            self.select_target(0)
+            out = dict(cols[0])
+            for k in ("gamma", "rho", "Yt"):
+                out[k] = np.column_stack([c[k] for c in cols])
+            out["sigma2"] = np.array([c["sigma2"] for c in cols])
+            out["noise_var"] = np.array([c["noise_var"] for c in cols])
+            return out
+        return self._get_state_active(with_C)
+
+    def _get_state_active(self, with_C=True) -> dict:
         N = self.N
         Cm = np.empty((N, N)) if with_C else None
         v = {k: np.zeros(N) for k in ("gamma", "rho", "Yt", "Ft", "Q")}

@@ -30,6 +30,11 @@ struct bogp_handle {
   int N = 0, d = 0, Np = 0;
   int ldr = 0;  // leading dimension of dR / dV / dRinv: N rounded up to 64 (identity padding, kernels_chol.hip)
   double *dX = nullptr, *dy = nullptr;
+  // multi-target y (gpr.py:463,490,502-505): the factorisation is shared, the vectors exist once per target.  dy / dyt /
+  // drho / dgamma above and `sigma2` below always point at the ACTIVE target (bogp_select_target) inside these slabs.
+  int n_t = 1, target = 0;
+  double *dy_base = nullptr, *dyt_base = nullptr, *drho_base = nullptr, *dgamma_base = nullptr;
+  std::vector<double> sigma2_t, nv_t;  // committed, per target
 
   // factorisation workspace (column-major, ld = ldr)
   double *dR = nullptr, *dV = nullptr, *dU = nullptr, *dT = nullptr, *dRinv = nullptr;  // L, L^-1, L^-T, scratch, R^-1
@@ -178,8 +183,10 @@ static void free_trend(bogp_handle* h) {
 }
 
 static void free_train(bogp_handle* h) {
-  dfree(h->dX); dfree(h->dy); dfree(h->dR); dfree(h->dV); dfree(h->dU); dfree(h->dT); dfree(h->dRinv); dfree(h->ddinv); dfree(h->dones); dfree(h->dgemv_scratch);
-  dfree(h->dyt); dfree(h->dft); dfree(h->drho); dfree(h->dtmp); dfree(h->dgamma); dfree(h->dw);
+  dfree(h->dX); dfree(h->dy_base); h->dy = nullptr; dfree(h->dR); dfree(h->dV); dfree(h->dU); dfree(h->dT); dfree(h->dRinv); dfree(h->ddinv); dfree(h->dones); dfree(h->dgemv_scratch);
+  dfree(h->dyt_base); dfree(h->dft); dfree(h->drho_base); dfree(h->dtmp); dfree(h->dgamma_base); dfree(h->dw);
+  h->dyt = h->drho = h->dgamma = nullptr;
+  h->n_t = 1; h->target = 0;
   dfree(h->dtheta); dfree(h->dsqrt_theta); dfree(h->dXthT); dfree(h->dVp);
   free_trend(h);
   h->committed = false;
@@ -203,21 +210,34 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   delete h;
 }
 
+// point the per-target views (and the committed sigma2) at target t
+static void select_target(bogp_handle* h, int t) {
+  h->target = t;
+  h->dy = h->dy_base + (size_t)t * h->N;
+  h->dyt = h->dyt_base + (size_t)t * h->N;
+  h->drho = h->drho_base + (size_t)t * h->N;
+  h->dgamma = h->dgamma_base + (size_t)t * h->Np;
+  if (h->committed && t < (int)h->sigma2_t.size()) h->sigma2 = h->sigma2_t[t];
+}
+
 extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, int N, int d, int n_targets) {
   if (!h) return BOGP_ERR_INVALID;
   if (!X || !y || N <= 0 || d <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_set_train: X, y must be non-null and N, d > 0");
-  if (n_targets != 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_set_train: n_targets = %d; only single-target GPs are built (multi-target y is MOBO-only)", n_targets);
+  if (n_targets < 1 || n_targets > BOGP_MAX_TARGETS) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_set_train: n_targets = %d outside [1, %d]", n_targets, BOGP_MAX_TARGETS);
   if (d > 128) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_set_train: d = %d > 128: the sweep producer keeps a 64 x d candidate tile in 64 KB of LDS", d);
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   free_train(h);
   h->N = N;
   h->d = d;
+  h->n_t = n_targets;
+  h->target = 0;
   h->Np = ((N + 31) / 32) * 32;
   h->ldr = ((N + 63) / 64) * 64;
   const size_t NN = (size_t)h->ldr * h->ldr;
   HIPCHK(h, hipMalloc((void**)&h->dX, (size_t)N * d * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&h->dy, N * sizeof(double)));
+  const size_t nt = (size_t)n_targets;
+  HIPCHK(h, hipMalloc((void**)&h->dy_base, nt * N * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&h->dR, NN * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&h->ddinv, (size_t)h->ldr * 64 * sizeof(double)));
   HIPCHK(h, launch_pad_identity(h->dR, N, h->ldr, h->stream));
@@ -233,17 +253,29 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
     HIPCHK(h, hipMalloc((void**)&h->dgemv_scratch, gemv2_scratch_doubles(N) * sizeof(double)));
     HIPCHK(h, hipMemcpy(h->dones, ones.data(), N * sizeof(double), hipMemcpyHostToDevice));
   }
-  HIPCHK(h, hipMalloc((void**)&h->dyt, N * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->dyt_base, nt * N * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&h->dft, N * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&h->drho, N * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->drho_base, nt * N * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&h->dtmp, N * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&h->dgamma, h->Np * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->dgamma_base, nt * h->Np * sizeof(double)));
+  select_target(h, 0);
   HIPCHK(h, hipMalloc((void**)&h->dw, h->Np * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&h->dtheta, d * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&h->dsqrt_theta, d * sizeof(double)));
   HIPCHK(h, hipMemcpyAsync(h->dX, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->dy, y, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  std::vector<double> ycols(nt * N);  // y arrives (N, n_targets) row-major; one contiguous column per target here
+  for (int i = 0; i < N; ++i)
+    for (int t = 0; t < n_targets; ++t) ycols[(size_t)t * N + i] = y[(size_t)i * n_targets + t];
+  HIPCHK(h, hipMemcpyAsync(h->dy_base, ycols.data(), nt * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  return BOGP_OK;
+}
+
+extern "C" int bogp_select_target(bogp_handle* h, int target) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "bogp_select_target: no training set");
+  if (target < 0 || target >= h->n_t) FAIL(h, BOGP_ERR_INVALID, "bogp_select_target: target %d outside [0, %d)", target, h->n_t);
+  select_target(h, target);
   return BOGP_OK;
 }
 
@@ -252,6 +284,8 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
 // ------------------------------------------------------------------------------------------------------
 struct FitOut {
   double llf = 0, sigma2 = 0, noise_var = 0, s2t = 0, G = 0, beta = 0, ftyt = 0, ftft = 0, logdet = 0, rho_ss = 0;
+  // per target (n_t > 1: llf above is the SUM over targets, gpr.py:1040; sigma2 / s2t / rho_ss above are target 0's)
+  double sigma2_t[BOGP_MAX_TARGETS] = {0}, s2t_t[BOGP_MAX_TARGETS] = {0}, nv_t[BOGP_MAX_TARGETS] = {0};
 };
 
 static int trend_size(int trend, int d) {
@@ -402,9 +436,14 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st));
   HIPCHK(h, launch_logdet(h->dR, N, ldr, h->dscal, st));
   HIPCHK(h, launch_tri_inverse(h->dR, h->ddinv, h->dV, h->dU, h->dT, ldr, st));
+  const int n_t = h->n_t;
+  if (n_t > 1 && (ptrend != 1 || estimate_trend))
+    FAIL(h, BOGP_ERR_UNSUPPORTED, "multi-target y (%d targets) is built for a FIXED constant trend only: with estimated coefficients the reference raises at gpr.py:787 (beta gets one row per target)", n_t);
   if (ptrend == 1) {
-    HIPCHK(h, launch_gemv2(h->dV, ldr, N, 1, h->dy, h->dones, h->dyt, h->dft, h->dgemv_scratch, st));
-    HIPCHK(h, launch_fit_rho(h->dyt, h->dft, N, estimate_trend, beta, h->drho, h->dscal, st));
+    for (int t = 0; t < n_t; ++t) {  // scal[4 t + 1..3] = |Ft|, Ft.Yt_t, rho_t.rho_t
+      HIPCHK(h, launch_gemv2(h->dV, ldr, N, 1, h->dy_base + (size_t)t * N, h->dones, h->dyt_base + (size_t)t * N, h->dft, h->dgemv_scratch, st));
+      HIPCHK(h, launch_fit_rho(h->dyt_base + (size_t)t * N, h->dft, N, estimate_trend, beta, h->drho_base + (size_t)t * N, h->dscal + 4 * t, st));
+    }
   } else {
     HIPCHK(h, launch_gemv2(h->dV, ldr, N, 1, h->dy, nullptr, h->dyt, nullptr, h->dgemv_scratch, st));
     int et = trend_solve(h, trend, estimate_trend);
@@ -412,13 +451,14 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
     HIPCHK(h, launch_sumsq(h->drho, N, h->dscal + 3, st));
   }
   if (want_gamma) {
-    HIPCHK(h, hipMemsetAsync(h->dgamma, 0, h->Np * sizeof(double), st));
-    HIPCHK(h, launch_gemv2(h->dU, ldr, N, 2, h->drho, nullptr, h->dgamma, nullptr, h->dgemv_scratch, st));
+    HIPCHK(h, hipMemsetAsync(h->dgamma_base, 0, (size_t)n_t * h->Np * sizeof(double), st));
+    for (int t = 0; t < n_t; ++t)
+      HIPCHK(h, launch_gemv2(h->dU, ldr, N, 2, h->drho_base + (size_t)t * N, nullptr, h->dgamma_base + (size_t)t * h->Np, nullptr, h->dgemv_scratch, st));
   }
   rocblas_int info = 0;
-  double sc[4] = {0, 0, 0, 0};  // sum(log diag L), |Ft|, Ft.Yt, rho.rho
+  double sc[4 * BOGP_MAX_TARGETS] = {0, 0, 0, 0};  // sum(log diag L), |Ft|, Ft.Yt, rho.rho (the last three per target)
   HIPCHK(h, hipMemcpyAsync(&info, h->dinfo, sizeof(info), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipMemcpyAsync(sc, h->dscal, sizeof(sc), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(sc, h->dscal, 4 * n_t * sizeof(double), hipMemcpyDeviceToHost, st));
   rocblas_int info2[2] = {0, 0};
   if (ptrend > 1 && estimate_trend) HIPCHK(h, hipMemcpyAsync(info2, h->dinfo2, sizeof(info2), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
@@ -458,7 +498,27 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   if (!std::isfinite(llf)) FAIL(h, BOGP_ERR_NOT_POSDEF, "log-likelihood is not finite (%g): degenerate factorisation", llf);
   o->logdet = logdet; o->rho_ss = rho_ss;
   o->llf = llf; o->sigma2 = sigma2; o->noise_var = nv; o->s2t = s2t; o->G = G; o->beta = beta_eff; o->ftyt = ftyt; o->ftft = ftft;
-  if (llf > 0 && reject_positive) FAIL(h, BOGP_ERR_LLF_POSITIVE, "log-likelihood %g > 0 is rejected by the reference (gpr.py:981-982)", llf);
+  o->sigma2_t[0] = sigma2; o->s2t_t[0] = s2t; o->nv_t[0] = nv;
+  bool positive = llf > 0;
+  for (int t = 1; t < n_t; ++t) {  // the same three formulas per target; the reference sums them (:1040) and rejects
+    const double rss = sc[4 * t + 3];  // when ANY target's value is positive (:981)
+    double l_t, s_t, st_t, nv_t;
+    if (mode == BOGP_MODE_NOISELESS) {
+      s_t = rss / N; nv_t = 0; st_t = s_t;
+      l_t = -0.5 * (N * std::log(TWO_PI * s_t) + 2.0 * logdet + N);
+    } else if (mode == BOGP_MODE_NOISE_ESTIM) {
+      st_t = rss / N; s_t = alpha * st_t; nv_t = (1 - alpha) * st_t;
+      l_t = -0.5 * (N * std::log(TWO_PI * st_t) + 2.0 * logdet + N);
+    } else {
+      s_t = sigma2_par; nv_t = noise_var; st_t = s2t;
+      l_t = -0.5 * (N * std::log(TWO_PI * st_t) + 2.0 * logdet + rss / st_t);
+    }
+    if (!std::isfinite(l_t)) FAIL(h, BOGP_ERR_NOT_POSDEF, "log-likelihood of target %d is not finite (%g)", t, l_t);
+    o->sigma2_t[t] = s_t; o->s2t_t[t] = st_t; o->nv_t[t] = nv_t;
+    o->llf += l_t;
+    positive = positive || l_t > 0;
+  }
+  if (positive && reject_positive) FAIL(h, BOGP_ERR_LLF_POSITIVE, "log-likelihood %g > 0 is rejected by the reference (gpr.py:981-982)", o->llf);
 
   return BOGP_OK;
 }
@@ -485,15 +545,30 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
   const int nblk = grad_contract_blocks(N);
   int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)nblk * (d + 1) + (d + 4));
   if (e) return e;
-  const double c1 = 1.0 / (mode == BOGP_MODE_NOISELESS ? o.sigma2 : o.s2t);
-  HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, h->dgamma, c1, nullptr, 0.0, h->dRinv, ldr, UUT_PARTS, (size_t)ldr * ldr, h->dgrad_partial, nblk, st));
+  // Per-target weights of gamma_t gamma_t^T (single target: 1 / sigma2 resp. 1 / sigma2_total).  With several targets the
+  // reference sums gamma gamma^T over ALL targets before dividing by each target's variance in the theta rows of the
+  // noiseless / noise_estim modes (`_upper`, :999 with :1008-1020), but uses each target's own variance in the alpha row
+  // (:1024-1026) and in the noisy mode (:1036); the R^-1 term is counted once per target (`.sum(axis=1)`, :1038).
+  const int n_t = h->n_t;
+  GradVecs gv;
+  gv.v = h->dgamma_base; gv.stride = (size_t)h->Np; gv.n = n_t; gv.c0 = (double)n_t;
+  double inv_sum = 0.0;
+  for (int t = 0; t < n_t; ++t) inv_sum += 1.0 / (mode == BOGP_MODE_NOISELESS ? o.sigma2_t[t] : o.s2t_t[t]);
+  for (int t = 0; t < n_t; ++t) {
+    gv.cB[t] = 1.0 / o.s2t_t[t];
+    gv.cA[t] = mode == BOGP_MODE_NOISY ? gv.cB[t] : inv_sum;
+  }
+  HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, gv, nullptr, 0.0, h->dRinv, ldr, UUT_PARTS, (size_t)ldr * ldr, h->dgrad_partial, nblk, st));
   double* dS = h->dgrad_partial + (size_t)nblk * (d + 1);
   HIPCHK(h, launch_grad_reduce(h->dgrad_partial, nblk, d + 1, dS, st));
   std::vector<double> S(d + 3);
-  if (mode == BOGP_MODE_NOISY) HIPCHK(h, launch_trace_gg(h->dRinv, ldr, UUT_PARTS, (size_t)ldr * ldr, N, h->dgamma, nullptr, dS + d + 1, st));
+  if (mode == BOGP_MODE_NOISY) {
+    HIPCHK(h, launch_trace_gg(h->dRinv, ldr, UUT_PARTS, (size_t)ldr * ldr, N, h->dgamma_base, nullptr, dS + d + 1, st));
+    if (n_t > 1) HIPCHK(h, launch_sumsq(h->dgamma_base, n_t * h->Np, dS + d + 2, st));  // sum_t gamma_t . gamma_t (zero padding)
+  }
   HIPCHK(h, hipMemcpyAsync(S.data(), dS, (d + 3) * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
-  const double tr = S[d + 1], gg = S[d + 2];
+  const double tr = n_t * S[d + 1], gg = S[d + 2];
   if (mode == BOGP_MODE_NOISELESS) {
     for (int k = 0; k < d; ++k) grad[k] = S[k];
   } else if (mode == BOGP_MODE_NOISE_ESTIM) {
@@ -518,6 +593,7 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
   if (!par || !llf || n_par <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_nll_restricted: par/llf must be non-null");
   if (mode < 0 || mode > 2) FAIL(h, BOGP_ERR_INVALID, "unknown estimation mode %d", mode);
   if (trend != BOGP_TREND_CONSTANT) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_restricted: only the constant trend basis is built (trend id %d)", trend);
+  if (h->n_t != 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_restricted: single-target y only (have %d targets)", h->n_t);
   h->committed = false;
   const int n_tail = mode == BOGP_MODE_NOISE_ESTIM ? 2 : 1;
   const int n_theta = n_par - n_tail;
@@ -556,7 +632,9 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
     const int nblk = grad_contract_blocks(N);
     int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)nblk * (d + 1) + (d + 4));
     if (e) return e;
-    HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, h->dgamma, 1.0 / tv, qv, c2, h->dRinv, ldr, UUT_PARTS,
+    GradVecs gv;
+    gv.v = h->dgamma; gv.stride = 0; gv.n = 1; gv.c0 = 1.0; gv.cA[0] = gv.cB[0] = 1.0 / tv;
+    HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, gv, qv, c2, h->dRinv, ldr, UUT_PARTS,
                                    (size_t)ldr * ldr, h->dgrad_partial, nblk, st));
     double* dS = h->dgrad_partial + (size_t)nblk * (d + 1);
     HIPCHK(h, launch_grad_reduce(h->dgrad_partial, nblk, d + 1, dS, st));
@@ -615,7 +693,10 @@ extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* p
   h->kernel = kernel; h->mode = mode; h->estimate_trend = estimate_trend;
   h->trend = trend; h->p = ptrend;
   h->beta = o.beta; h->G = o.G; h->sigma2 = o.sigma2; h->noise_var = o.noise_var; h->llf = o.llf; h->ftft = o.ftft;
+  h->sigma2_t.assign(o.sigma2_t, o.sigma2_t + h->n_t);
+  h->nv_t.assign(o.nv_t, o.nv_t + h->n_t);
   h->committed = true;
+  select_target(h, 0);
   return BOGP_OK;
 }
 
@@ -644,7 +725,7 @@ extern "C" int bogp_get_state(bogp_handle* h, double* C, double* gamma, double* 
   if (G) *G = h->G;
   if (beta) *beta = h->beta;
   if (sigma2) *sigma2 = h->sigma2;
-  if (noise_var) *noise_var = h->noise_var;
+  if (noise_var) *noise_var = h->target < (int)h->nv_t.size() ? h->nv_t[h->target] : h->noise_var;
   return BOGP_OK;
 }
 

@@ -98,8 +98,17 @@ hipError_t launch_tri_inverse(const double* L, const double* Winv, double* V, do
 constexpr int UUT_PARTS = 4;  // R^-1 = U U^T is produced as this many K-slices (ld*ld doubles apart) that the consumers add
 hipError_t launch_uut(const double* U, double* Rinv, int ld, hipStream_t st);
 hipError_t launch_copy_lower(const double* L, int N, int ld, double* dst, hipStream_t st);
-hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const double* theta, const double* gamma,
-                                double c1, const double* qv, double c2, const double* Rinv, int ld, int nparts,
+// the rank-1 terms of the likelihood gradient: vectors v + t * stride (t < n) with weights cA (theta contractions) and
+// cB (R0 contraction); c0 multiplies R^-1
+struct GradVecs {
+  const double* v;
+  size_t stride;
+  int n;
+  double c0;
+  double cA[BOGP_MAX_TARGETS], cB[BOGP_MAX_TARGETS];
+};
+hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const double* theta, const GradVecs& gv,
+                                const double* qv, double c2, const double* Rinv, int ld, int nparts,
                                 size_t part_stride, double* partial, int nblk, hipStream_t st);
 hipError_t launch_grad_reduce(const double* partial, int nblk, int nout, double* out, hipStream_t st);
 int grad_contract_blocks(int N);

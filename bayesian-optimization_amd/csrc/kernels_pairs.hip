@@ -130,7 +130,7 @@ hipError_t launch_build_R_div(int kernel, const double* X, int N, int d, const d
 // ---------------------------------------------------------------------------------------------------------------
 template <int KERNEL>
 __global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
-                                                       const double* __restrict__ gamma, double c1,
+                                                       const GradVecs gv,
                                                        const double* __restrict__ qv, double c2,
                                                        const double* __restrict__ Rinv, int ld, int nparts, size_t part_stride,
                                                        double* __restrict__ partial) {
@@ -180,10 +180,22 @@ __global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict_
         const double h = corr_dtheta_profile<KERNEL>(s2[r][c], r0);
         double rinv = 0.0;  // element (j, i) of the lower triangle, column-major
         for (int q = 0; q < nparts; ++q) rinv += Rinv[q * part_stride + (size_t)i * ld + j];
-        double A = gamma[i] * gamma[j] * c1 - rinv;
-        if (qv) A += qv[i] * qv[j] * c2;  // REML: the (L^-T Q)(L^-T Q)^T term of gpr.py:876-878, 896-898
+        // A = sum_t c_t gamma_t gamma_t^T - c0 R^-1: one vector per target (gpr.py:996-1037 with n_targets columns);
+        // the theta contractions (cA) and the R0 contraction (cB) weigh the targets differently in noise_estim mode
+        double gA = 0.0, gB = 0.0;
+        for (int t = 0; t < gv.n; ++t) {
+          const double gg = gv.v[t * gv.stride + i] * gv.v[t * gv.stride + j];
+          gA = __builtin_fma(gg, gv.cA[t], gA);
+          gB = __builtin_fma(gg, gv.cB[t], gB);
+        }
+        double A = gA - gv.c0 * rinv, A2 = gB - gv.c0 * rinv;
+        if (qv) {  // REML: the (L^-T Q)(L^-T Q)^T term of gpr.py:876-878, 896-898
+          const double qq = qv[i] * qv[j] * c2;
+          A += qq;
+          A2 += qq;
+        }
         bb = A * h;
-        sd += A * r0;
+        sd += A2 * r0;
       }
       B[r][c] = bb;
     }
@@ -222,14 +234,14 @@ int grad_contract_blocks(int N) {
   const int nt = (N + PT - 1) / PT;
   return nt * (nt + 1) / 2;
 }
-hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const double* theta, const double* gamma,
-                                double c1, const double* qv, double c2, const double* Rinv, int ld, int nparts,
+hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const double* theta, const GradVecs& gv,
+                                const double* qv, double c2, const double* Rinv, int ld, int nparts,
                                 size_t part_stride, double* partial, int nblk, hipStream_t st) {
   const int nt = (N + PT - 1) / PT;
   (void)nblk;
   const dim3 grid(nt, nt);
 #define CALL(K) \
-  hipLaunchKernelGGL((k_grad_contract<K>), grid, 256, 0, st, X, N, d, theta, gamma, c1, qv, c2, Rinv, ld, nparts, part_stride, partial)
+  hipLaunchKernelGGL((k_grad_contract<K>), grid, 256, 0, st, X, N, d, theta, gv, qv, c2, Rinv, ld, nparts, part_stride, partial)
   BOGP_FOR_KERNEL(kernel, CALL)
 #undef CALL
   return hipGetLastError();

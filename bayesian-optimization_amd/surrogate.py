@@ -202,8 +202,12 @@ class GaussianProcess:
             raise ValueError("Found input variables with inconsistent numbers of samples: [%d, %d]" % (X.shape[0], y.shape[0]))
         if not (np.isfinite(X).all() and np.isfinite(y).all()):
             raise ValueError("Input contains NaN, infinity or a value too large for dtype('float64').")
-        if y.shape[1] != 1:
-            raise NotImplementedError("multi-target y is only used by MOBO and is not built on the device (SURVEY.md 8 f3)")
+        if y.shape[1] > 1 and (self.estimate_trend or type(self.mean).__name__ != "constant_trend" or self.likelihood == "restricted"):
+            # the reference gets through the MLE and then raises "Shapes of beta and F do not match." (gpr.py:787 assigns
+            # a (p, n_targets) beta); only a fixed constant trend works there with several targets
+            raise NotImplementedError("multi-target y needs a fixed constant trend (constant_trend(dim, beta=...)) and the concentrated likelihood")
+        if y.shape[1] > _lib.MAX_TARGETS:
+            raise NotImplementedError("at most %d targets" % _lib.MAX_TARGETS)
         if self.thetaL.size not in (1, X.shape[1]):
             raise ValueError("Length of theta must be 1 or %s" % X.shape[1])
         self.X, self.y = np.ascontiguousarray(X), np.ascontiguousarray(y)
@@ -229,9 +233,9 @@ class GaussianProcess:
                 st = self.engine.get_state()
                 Ft, G, Q, b = self._trend_views(st, est)
                 env.update(
-                    sigma2=np.atleast_1d(st["sigma2"]), noise_var=st["noise_var"], rho=st["rho"].reshape(-1, 1),
-                    Yt=st["Yt"].reshape(-1, 1), C=st["C"], Ft=Ft, G=G, Q=Q,
-                    beta=float(b[0, 0]) if b.size == 1 else b, gamma=st["gamma"].reshape(-1, 1),
+                    sigma2=np.atleast_1d(st["sigma2"]), noise_var=st["noise_var"], rho=st["rho"].reshape(len(self.X), -1),
+                    Yt=st["Yt"].reshape(len(self.X), -1), C=st["C"], Ft=Ft, G=G, Q=Q,
+                    beta=float(b[0, 0]) if b.size == 1 else b, gamma=st["gamma"].reshape(len(self.X), -1),
                 )  # fmt: skip
                 if not eval_grad:
                     return llf
@@ -299,10 +303,10 @@ class GaussianProcess:
         self.theta_ = np.array(par[:n_theta], dtype=float)
         self.noise_var = st["noise_var"]
         self.sigma2 = np.atleast_1d(st["sigma2"]).astype(float)
-        self.rho = st["rho"].reshape(-1, 1)
-        self.Yt = st["Yt"].reshape(-1, 1)
+        self.rho = st["rho"].reshape(len(self.X), -1)
+        self.Yt = st["Yt"].reshape(len(self.X), -1)
         self.C = st["C"]
-        self.gamma = st["gamma"].reshape(-1, 1)
+        self.gamma = st["gamma"].reshape(len(self.X), -1)
         if self.estimate_trend:
             self.Ft, self.G, self.Q, b = self._trend_views(st, True)
             self.mean.beta = float(b[0, 0]) if b.size == 1 else b.ravel()
@@ -469,6 +473,15 @@ class GaussianProcess:
             raise Exception("batch_size must be a positive integer")
         eng = self.engine
         eng.upload_candidates(X)
+        n_t = self.y.shape[1]
+        if n_t > 1:  # (M, n_targets) like gpr.py:490, 502-505: one posterior pass per column of y, factorisation shared
+            cols = []
+            for t in range(n_t):
+                eng.select_target(t)
+                cols.append(eng.predict(eval_MSE=eval_MSE))
+            eng.select_target(0)
+            mu = np.column_stack([c[0] for c in cols])
+            return (mu, np.column_stack([c[1] for c in cols])) if eval_MSE else mu
         mu, mse = eng.predict(eval_MSE=eval_MSE)
         if eval_MSE:
             return mu.reshape(-1, 1), mse.reshape(-1, 1)
@@ -482,6 +495,8 @@ class GaussianProcess:
             raise Exception("x must be a vector!")
         if type(self.mean).__name__ == "quadratic_trend":
             raise NotImplementedError  # quadratic_trend.Jacobian raises in the reference (trend.py:138-139)
+        if self.y.shape[1] > 1:  # the reference's gradient raises ValueError (a broadcast of (n_targets,) with (1, d))
+            raise NotImplementedError("gradient of a multi-target model")
         dmu, dmse = self.engine.gradient(x[0])
         return dmu.reshape(-1, 1), dmse.reshape(-1, 1)
 

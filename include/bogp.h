@@ -67,6 +67,7 @@ typedef struct bogp_handle bogp_handle;
 #define BOGP_TREND_LINEAR 1    /* [1, x]                      trend.py:94-118  */
 #define BOGP_TREND_QUADRATIC 2 /* [1, x, x_k x_j (j >= k)]    trend.py:121-142 */
 
+#define BOGP_MAX_TARGETS 8 /* columns of y (n_targets, gpr.py:463) */
 #define BOGP_MAX_Q 64    /* criteria evaluated in one sweep (ParallelBO batch size q) */
 #define BOGP_MAX_TOPK 32 /* ranks returned per criterion by bogp_sweep_topk */
 
@@ -79,8 +80,14 @@ int bogp_abi_version(void);                        /* bumps whenever a signature
 /* ---- training set --------------------------------------------------------------------------------
  * Replaces GaussianProcess._check_data (gpr.py:279-310): X (N x d, row-major), y (N x n_targets).
  * The pair-distance list D of the reference (gpr.py:48-61, 13.4 GB at N=8192,d=50) is never built.
- * n_targets must be 1 (multi-target y is used only by MOBO, out of scope).                              */
+ * 1 <= n_targets <= BOGP_MAX_TARGETS.  With several targets (gpr.py:463, 490, 502-505, 931-1040) the correlation
+ * model and its factorisation are shared and Yt / rho / gamma / sigma2 exist once per target: bogp_nll returns the SUM
+ * of the per-target likelihoods and of their gradients exactly as the reference forms them, bogp_commit commits all
+ * targets, and every per-target consumer (bogp_get_state, bogp_predict, bogp_sweep*, bogp_gradient*) works on the
+ * target chosen with bogp_select_target (0 after set_train / commit).  As in the reference, only a FIXED constant
+ * trend works with n_targets > 1 (estimating it raises at gpr.py:787); REML is single-target.                  */
 int bogp_set_train(bogp_handle* h, const double* X, const double* y, int N, int d, int n_targets);
+int bogp_select_target(bogp_handle* h, int target);
 
 /* ---- likelihood -----------------------------------------------------------------------------------
  * Replaces GaussianProcess.log_likelihood_concentrated(par, eval_grad) (gpr.py:920-1040):

@@ -416,12 +416,54 @@ def golden_reml():
     save("G16_reml_tables", **out)
 
 
+def golden_multitarget():
+    """G17: y with three columns (gpr.py:463, 490, 502-505, 931-1040).  In the reference only a FIXED constant trend
+    survives `fit` with several targets (estimating it raises at :787), so that is the golden: likelihood + gradient
+    tables for the three modes x {SE, Matern-3/2}, one pinned state per mode with predictions, and one real `fit`."""
+    rng = np.random.default_rng(417)
+    N, d = 48, 4
+    X = rng.uniform(-5, 5, size=(N, d))
+    Y = np.c_[np.sum(X**2, 1), np.sum(np.sin(X), 1), X[:, 0] * X[:, 1] - X[:, 2]]
+    Y = (Y - Y.mean(0)) / Y.std(0) + 0.25 * rng.standard_normal((N, 3)) * np.array([1.0, 0.6, 1.4])
+    Xs = rng.uniform(-5, 5, size=(200, d))
+    out = dict(X=X, y=Y, Xs=Xs)
+    n = 0
+    for kid, corr in ((0, "squared_exponential"), (2, "matern")):
+        for mid, kw in ((0, dict(nugget=0)), (1, dict(nugget=1e-3)), (2, dict(nugget=1e-6, noise_estim=True))):
+            gp = GaussianProcess(mean=trend.constant_trend(d, beta=0.0), corr=corr, thetaL=[1e-4] * d, thetaU=[1e2] * d, **kw)
+            gp._check_data(X, Y)
+            pars = []
+            for _ in range(4):
+                th = 10 ** rng.uniform(-1.6, -0.7, size=d)
+                pars.append(th if mid == 0 else np.r_[th, rng.uniform(0.4, 0.95)])
+            vals, grads = llf_table(gp, pars)
+            assert np.all(np.isfinite(vals)), (kid, mid, vals)
+            key = "k%d_m%d" % (kid, mid)
+            out[key + "_par"], out[key + "_llf"], out[key + "_grad"] = np.array(pars), vals, grads
+            n += len(pars)
+            llf = pin(gp, X, Y, pars[0])
+            mu, mse = gp.predict(Xs, eval_MSE=True)
+            out.update({key + "_st_" + k: v for k, v in state_dict(gp, llf).items() if k not in ("X", "y", "C")})
+            out[key + "_mu"], out[key + "_mse"] = mu, mse
+    assert n == 24
+    np.random.seed(7)
+    gp = GaussianProcess(mean=trend.constant_trend(d, beta=0.0), corr="squared_exponential", thetaL=[1e-3] * d, thetaU=[10.0] * d,
+                         nugget=1e-3, optimizer="BFGS", wait_iter=3, random_start=3, eval_budget=300, random_state=7)  # fmt: skip
+    gp.fit(X, Y)
+    mu, mse = gp.predict(Xs, eval_MSE=True)
+    out.update(fit_theta=gp.theta_, fit_sigma2=gp.sigma2, fit_mu=mu, fit_mse=mse, fit_gamma=gp.gamma)
+    save("G17_multitarget", **out)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["trends"]:
         golden_trends()
     elif sys.argv[1:] == ["reml"]:
         golden_reml()
+    elif sys.argv[1:] == ["multitarget"]:
+        golden_multitarget()
     else:
         main()
         golden_trends()
         golden_reml()
+        golden_multitarget()

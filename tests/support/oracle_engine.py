@@ -20,7 +20,12 @@ class OracleEngine:
     def set_train(self, X, y):
         self.X, self.y = np.asarray(X, float), np.asarray(y, float).reshape(len(X), -1)
         self.N, self.d = self.X.shape
+        self.n_t, self.target = self.y.shape[1], 0
         self.st = None
+
+    def select_target(self, t):
+        assert 0 <= t < self.n_t
+        self.target = int(t)
 
     def nll(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False, trend=0):
         out = O.log_likelihood_concentrated(par, self.X, self.y, kernel, mode, noise_var, trend, estimate_trend, beta, eval_grad=eval_grad)
@@ -38,11 +43,15 @@ class OracleEngine:
             self.st = O.make_state(par, self.X, self.y, kernel, mode, noise_var, trend=trend, estimate_trend=estimate_trend, beta=beta)
         except np.linalg.LinAlgError as e:
             raise _lib.NotPositiveDefinite(_lib.ERR_NOT_POSDEF, str(e))
+        self.target = 0
         return self.st.llf
 
     def get_state(self, with_C=True):
         st = self.st
         z = np.zeros(self.N)
+        if self.n_t > 1:  # the shapes bogp._lib.Engine.get_state stacks for several targets
+            return dict(C=st.C, gamma=st.gamma, rho=st.rho, Yt=st.Yt, Ft=z, Q=z, G=0.0, beta=float(st.beta[0, 0]),
+                        sigma2=st.sigma2, noise_var=np.broadcast_to(np.asarray(st.noise_var, float).ravel(), (self.n_t,)).copy())  # fmt: skip
         if st.trend != 0:  # p > 1: matrices, as bogp_get_trend_state returns them
             return dict(C=st.C, gamma=st.gamma.ravel(), rho=st.rho.ravel(), Yt=st.Yt.ravel(), Ft=st.Ft, Q=st.Q, G=st.G,
                         beta=st.beta.ravel(), sigma2=float(st.sigma2[0]), noise_var=st.noise_var)  # fmt: skip
@@ -57,7 +66,7 @@ class OracleEngine:
 
     def predict(self, eval_MSE=True):
         mu, mse = O.predict_chunked(self.st, self.Xs, 1024)
-        return mu.ravel(), (mse.ravel() if eval_MSE else None)
+        return mu[:, self.target].copy(), (mse[:, self.target].copy() if eval_MSE else None)
 
     def _vals(self, acq, plugin, minimize):
         mu, mse = self.predict()

@@ -157,3 +157,32 @@ def test_fit_with_the_restricted_likelihood_host_logic(kw):
     assert gp.sigma2.shape == (1,) and float(gp.sigma2[0]) == float(gp.par["sigma2"][0])
     mu, mse = gp.predict(X[:4], eval_MSE=True)
     assert mu.shape == (4, 1) and np.all(mse >= 0)
+
+
+@pytest.mark.timeout(600)
+def test_multitarget_fit_host_logic():
+    """Y (N, 3) through the host layer (shapes of sigma2 / gamma / rho / Yt, the (M, 3) posterior) with the oracle as the
+    engine; the device path is checked against the reference's own outputs in tests/test_gpu_parity.py (G17)."""
+    import bogp
+    from oracle import gp_oracle as O
+    from support.oracle_engine import OracleEngine
+
+    rng = np.random.default_rng(4)
+    X = rng.uniform(-5, 5, size=(30, 2))
+    Y = np.c_[np.sum(X**2, axis=1), np.sin(X[:, 0]) + X[:, 1]] + 0.3 * rng.standard_normal((30, 2))
+    Y = (Y - Y.mean(0)) / Y.std(0)
+    gp = bogp.GaussianProcess(mean=bogp.trend.constant_trend(2, beta=0.0), corr="matern", thetaL=[1e-2] * 2, thetaU=[1e2] * 2,
+                              nugget=1e-3, random_start=2, eval_budget=80)  # fmt: skip
+    gp._engine = OracleEngine()
+    np.random.seed(5)
+    assert gp.fit(X, Y) is gp and gp.is_fitted
+    par = np.r_[gp.theta_, gp.sigma2[0]]
+    assert gp.log_likelihood_ == O.log_likelihood_concentrated(par, X, Y, O.KERNEL_MATERN32, O.MODE_NOISY, 1e-3, beta=0.0)
+    assert gp.sigma2.shape == (2,) and gp.gamma.shape == (30, 2) and gp.rho.shape == (30, 2) and gp.Yt.shape == (30, 2)
+    mu, mse = gp.predict(X[:4], eval_MSE=True)
+    st = O.make_state(par, X, Y, O.KERNEL_MATERN32, O.MODE_NOISY, 1e-3, beta=0.0)
+    omu, omse = O.predict(st, X[:4])
+    np.testing.assert_array_equal(mu, omu)
+    np.testing.assert_array_equal(mse, omse)
+    with pytest.raises(NotImplementedError):
+        bogp.GaussianProcess(mean=bogp.trend.constant_trend(2), corr="matern", thetaL=[1e-2] * 2, thetaU=[1e2] * 2, nugget=1e-3).fit(X, Y)

@@ -281,7 +281,7 @@ def test_error_codes(eng):
     with pytest.raises(_lib.BogpError):
         e2.commit(0, 1, [0.1, 0.2, 0.3, 0.9], 1e-6)  # wrong len(theta)
     with pytest.raises(_lib.BogpError):
-        e2.set_train(X, np.zeros((5, 2)))  # multi-target
+        e2.set_train(X, np.zeros((5, _lib.MAX_TARGETS + 1)))  # more targets than BOGP_MAX_TARGETS
     with pytest.raises(_lib.BogpError) as ei:
         e2.set_train(np.zeros((4, 129)), np.zeros(4))  # d beyond the producer's LDS tile
     assert ei.value.code == _lib.ERR_UNSUPPORTED
@@ -538,7 +538,7 @@ def test_device_latin_hypercube_at_full_size_has_one_point_per_stratum():
     """Size-independent property at BASELINE's C3 candidate count: every column visits each of the 1e6 strata once."""
     N, d, M = 64, 20, 1_000_000
     rng = np.random.default_rng(0)
-    e = bogp.Engine()
+    e = _lib.Engine(0)
     e.set_train(rng.uniform(-5, 5, (N, d)), rng.standard_normal((N, 1)))
     lo, hi = np.full(d, -5.0), np.full(d, 5.0)
     halves = []
@@ -896,3 +896,75 @@ def test_singular_matrix_is_reported_like_lapack(eng):
         gp = bogp.GaussianProcess(corr="squared_exponential", thetaL=[1e-2] * 2, thetaU=[1e1] * 2, nugget=0)
         gp._check_data(X, y)
         assert gp.log_likelihood_concentrated(np.r_[0.3, 0.2]) == -np.inf
+
+
+MT_NV = {0: 0.0, 1: 1e-3, 2: 0.0}
+
+
+def test_multitarget_likelihood_state_and_posterior(eng):
+    """f3: y with three columns (gpr.py:463, 490, 502-505, 931-1040) against the reference's own outputs (G17): the
+    summed likelihood, its gradient with the reference's cross-target weighting, per-target sigma2 / gamma / rho and
+    the (M, 3) posterior.  One factorisation serves all targets."""
+    g = load_golden("G17_multitarget")
+    X, Y, Xs = g["X"], g["y"], g["Xs"]
+    eng.set_train(X, Y)
+    n = 0
+    for kid in (0, 2):
+        for mid in (0, 1, 2):
+            key = "k%d_m%d" % (kid, mid)
+            for p, v, gr in zip(g[key + "_par"], g[key + "_llf"], g[key + "_grad"]):
+                llf, grad = eng.nll(kid, mid, p, MT_NV[mid], False, 0.0, eval_grad=True)
+                np.testing.assert_allclose(llf, v, rtol=1e-9)
+                np.testing.assert_allclose(grad, gr, rtol=1e-6, atol=1e-7 * np.abs(gr).max())
+                n += 1
+            eng.commit(kid, mid, g[key + "_par"][0], MT_NV[mid], False, 0.0)
+            st = eng.get_state()
+            np.testing.assert_allclose(st["sigma2"], g[key + "_st_sigma2"], rtol=1e-9)
+            np.testing.assert_allclose(st["gamma"], g[key + "_st_gamma"], rtol=1e-6, atol=1e-8 * np.abs(g[key + "_st_gamma"]).max())
+            np.testing.assert_allclose(st["rho"], g[key + "_st_rho"], rtol=1e-6, atol=1e-9)
+            np.testing.assert_allclose(st["Yt"], g[key + "_st_Yt"], rtol=1e-6, atol=1e-9)
+            eng.upload_candidates(Xs)
+            for t in range(3):
+                eng.select_target(t)
+                mu, mse = eng.predict()
+                close_mu(mu, g[key + "_mu"][:, t])
+                close_mse(mse, g[key + "_mse"][:, t], st["sigma2"][t])
+            eng.select_target(0)
+    assert n == 24
+    with pytest.raises(_lib.BogpError):
+        eng.select_target(3)
+    with pytest.raises(_lib.BogpError):  # estimated trend + several targets: the reference raises at gpr.py:787
+        eng.nll(0, 1, g["k0_m1_par"][0], 1e-3, True, 0.0)
+    # a single-target training set afterwards is unaffected by the slabs of the previous one
+    eng.set_train(X, Y[:, 1:2])
+    llf1 = eng.nll(0, 1, g["k0_m1_par"][0], 1e-3, False, 0.0)
+    np.testing.assert_allclose(llf1, O.log_likelihood_concentrated(g["k0_m1_par"][0], X, Y[:, 1:2], 0, 1, 1e-3, beta=0.0), rtol=1e-9)
+
+
+def test_multitarget_model_class_fits_and_predicts():
+    """`GaussianProcess.fit(X, Y)` with Y (N, 3) and a fixed constant trend, as MOBO drives it (mobo.py:155-160): the
+    state at the reference's fitted theta equals the reference's, and our own fit returns a model at least as likely."""
+    g = load_golden("G17_multitarget")
+    X, Y, Xs = g["X"], g["y"], g["Xs"]
+    d = X.shape[1]
+    gp = bogp.GaussianProcess(mean=bogp.trend.constant_trend(d, beta=0.0), corr="squared_exponential", thetaL=[1e-3] * d,
+                              thetaU=[10.0] * d, nugget=1e-3, optimizer="BFGS", wait_iter=3, random_start=3, eval_budget=300,
+                              random_state=7)  # fmt: skip
+    par_ref = np.r_[g["fit_theta"], g["fit_sigma2"][0]]
+    gp.set_state(par_ref, X, Y)
+    np.testing.assert_allclose(gp.gamma, g["fit_gamma"], rtol=1e-6, atol=1e-8 * np.abs(g["fit_gamma"]).max())
+    mu, mse = gp.predict(Xs, eval_MSE=True)
+    assert mu.shape == (len(Xs), 3) and mse.shape == (len(Xs), 3)
+    close_mu(mu, g["fit_mu"])
+    np.testing.assert_allclose(mse, g["fit_mse"], rtol=1e-6, atol=1e-12)
+    llf_ref = gp.log_likelihood_
+    np.random.seed(7)
+    assert gp.fit(X, Y) is gp and gp.is_fitted
+    assert gp.sigma2.shape == (3,) and gp.gamma.shape == (len(X), 3) and gp.rho.shape == (len(X), 3)
+    assert gp.log_likelihood_ >= llf_ref - 1e-6 * abs(llf_ref)
+    assert gp.predict(Xs[:5]).shape == (5, 3)
+    with pytest.raises(NotImplementedError):
+        gp.gradient(Xs[:1])
+    with pytest.raises(NotImplementedError):  # estimated trend: the reference cannot finish this fit either
+        bogp.GaussianProcess(mean=bogp.trend.constant_trend(d), corr="squared_exponential", thetaL=[1e-3] * d, thetaU=[10.0] * d,
+                             nugget=1e-3).fit(X, Y)  # fmt: skip

@@ -314,3 +314,32 @@ def test_reml_tables():
                     close(out[1], gr, rtol=1e-8, atol=1e-9)
                     n += 1
     assert n == 48
+
+
+MT_NV = {0: 0.0, 1: 1e-3, 2: 0.0}  # nugget of G17's noisy-mode model
+
+
+def test_multitarget_tables_and_states():
+    """y with three columns (gpr.py:463, 490, 502-505, 931-1040): the likelihood is summed over targets, its gradient
+    sums gamma gamma^T over ALL targets in the theta rows; sigma2 / gamma / mu / MSE get one column per target."""
+    g = load_golden("G17_multitarget")
+    X, Y, Xs = g["X"], g["y"], g["Xs"]
+    assert Y.shape[1] == 3
+    n = 0
+    for kid in (0, 2):
+        for mid in (0, 1, 2):
+            key = "k%d_m%d" % (kid, mid)
+            for p, v, gr in zip(g[key + "_par"], g[key + "_llf"], g[key + "_grad"]):
+                out = O.log_likelihood_concentrated(p, X, Y, kid, mid, noise_var=MT_NV[mid], beta=0.0, eval_grad=True)
+                close(out[0], v, rtol=1e-11)
+                close(out[1], gr, rtol=1e-8, atol=1e-9)
+                n += 1
+            st = O.make_state(g[key + "_par"][0], X, Y, kid, mid, noise_var=MT_NV[mid], beta=0.0)
+            close(st.sigma2, g[key + "_st_sigma2"], rtol=1e-11)
+            close(st.gamma, g[key + "_st_gamma"], rtol=1e-7, atol=1e-9)
+            close(st.rho, g[key + "_st_rho"], rtol=1e-8, atol=1e-11)
+            mu, mse = O.predict(st, Xs)
+            assert mu.shape == (len(Xs), 3) and mse.shape == (len(Xs), 3)
+            close(mu, g[key + "_mu"], rtol=1e-8, atol=1e-10)
+            close(mse, g[key + "_mse"], rtol=1e-7, atol=1e-10)
+    assert n == 24
