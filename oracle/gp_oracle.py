@@ -136,6 +136,15 @@ def corr_grad_theta(kernel: int, theta: np.ndarray, X: np.ndarray, R0: np.ndarra
 def correlation_matrix(kernel: int, theta: np.ndarray, X: np.ndarray) -> np.ndarray:
     """Symmetric R0 with unit diagonal scattered from the pair list.  gpr.py:772-782."""
     n = X.shape[0]
+    if n > 3072:
+        # the pair list of gpr.py:48-61 would need N(N-1)/2 x d doubles (13.4 GB at N = 8192, d = 50): evaluate the same
+        # elementwise function |x_i - x_j| -> corr in row blocks instead; every entry is bit-identical to the scattered one
+        R = np.empty((n, n))
+        step = max(1, (1 << 21) // (n * X.shape[1]))  # ~16 MB temporaries: stays in cache
+        for a in range(0, n, step):
+            R[a : a + step] = corr(kernel, theta, l1_cross_distances(X[a : a + step], X)).reshape(-1, n)
+        R[np.diag_indices(n)] = 1.0
+        return R
     D, ij = l1_pair_distances(X)
     r = corr(kernel, theta, D)
     R = np.eye(n)

@@ -304,12 +304,17 @@ def _bench_problem(N, d, kernel, theta):
     return rng, X, y, par, kernel
 
 
-@pytest.mark.parametrize("cfg", ["C2", "C3"])
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4", "C5"])
 def test_full_size_properties(eng, cfg):
+    """BASELINE.json's configs at their full per-GPU sizes (C4 / C5 are 8-GPU configs: one rank's shard here)."""
     N, d, M, kernel, theta, acq = {
         "C2": (512, 10, 100_000, O.KERNEL_SE, 0.02, [(O.ACQ_EI, 0.0)]),
         "C3": (2048, 20, 1_000_000, O.KERNEL_MATERN52, 0.01, [(O.ACQ_MGFI, 2.0), (O.ACQ_EI, 0.0)]),
-    }[cfg]
+        "C4": (2048, 20, 1_000_000, O.KERNEL_MATERN52, 0.01,
+               [(O.ACQ_MGFI, float(t)) for t in np.exp(np.log(2.0) + 0.5 * np.random.default_rng(4).standard_normal(8))]),
+        "C5": (8192, 50, 500_000, O.KERNEL_SE, 0.004, [(O.ACQ_UCB, 0.5)]),
+    }[cfg]  # fmt: skip
+    n_sub = 256 if cfg == "C5" else 2048
     rng, X, y, par, kernel = _bench_problem(N, d, kernel, theta)
     eng.set_train(X, y)
     eng.commit(kernel, O.MODE_NOISY, par, 1e-6, False, 0.0)
@@ -325,9 +330,11 @@ def test_full_size_properties(eng, cfg):
         np.testing.assert_allclose(b, v[i], rtol=1e-9)
     # (2) oracle parity on a random sub-sample of rows (the oracle needs seconds for 2048 rows)
     st = O.make_state(par, X, y, kernel, O.MODE_NOISY, 1e-6)
-    rows = np.sort(rng.choice(M, size=2048, replace=False))
+    rows = np.sort(rng.choice(M, size=n_sub, replace=False))
     rows[0] = idx[0]  # include the winner
-    rmu, rmse = O.predict_chunked(st, Xs[rows], 512)
+    rmu, rmse = O.predict_chunked(st, Xs[rows], 64 if cfg == "C5" else 512)
+    np.testing.assert_allclose(eng.nll(kernel, O.MODE_NOISY, par, 1e-6, False, 0.0), st.llf, rtol=1e-9)
+    eng.commit(kernel, O.MODE_NOISY, par, 1e-6, False, 0.0)  # nll overwrote the factor buffers
     close_mu(mu[rows], rmu)
     close_mse(mse[rows], rmse, 0.9)
     # (3) chunking is invisible: a different chunk size gives bit-identical outputs
