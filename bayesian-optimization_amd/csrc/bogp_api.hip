@@ -536,7 +536,11 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
 
   const int N = h->N, d = h->d;
   const int n_theta = n_par - (mode == BOGP_MODE_NOISELESS ? 0 : 1);
-  if (n_theta != d) FAIL(h, BOGP_ERR_UNSUPPORTED, "gradient with isotropic theta (len 1, d = %d) is not built: the reference's own gradient is inconsistent there (gpr.py:1001-1037 index the (N,N,d) tensor by parameter)", d);
+  // Isotropic theta (len 1, d > 1): corr_grad_theta still returns the (N, N, d) per-dimension tensor (gpr.py:745-770) and the
+  // loops of :1001-1037 index it BY PARAMETER, so row 0 is the derivative along dimension 0 only and, in the noisy mode,
+  // the "sigma2" row is the derivative along dimension 1 (slice 1 of the d + 1 slices).  That is what the reference's MLE
+  // is driven by, so it is reproduced here from the same d + 1 contractions.
+  const bool iso = n_theta != d;
   hipStream_t st = h->stream;
   // R^-1 = cho_solve(L, I) (:997) via potri on a copy of L
   const int ldr = h->ldr;
@@ -569,7 +573,11 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
   HIPCHK(h, hipMemcpyAsync(S.data(), dS, (d + 3) * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   const double tr = n_t * S[d + 1], gg = S[d + 2];
-  if (mode == BOGP_MODE_NOISELESS) {
+  if (iso) {
+    grad[0] = mode == BOGP_MODE_NOISE_ESTIM ? par[n_par - 1] * S[0] : S[0];
+    if (mode == BOGP_MODE_NOISE_ESTIM) grad[1] = S[d];
+    if (mode == BOGP_MODE_NOISY) grad[1] = S[1];
+  } else if (mode == BOGP_MODE_NOISELESS) {
     for (int k = 0; k < d; ++k) grad[k] = S[k];
   } else if (mode == BOGP_MODE_NOISE_ESTIM) {
     const double alpha = par[n_par - 1];

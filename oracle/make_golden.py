@@ -455,6 +455,34 @@ def golden_multitarget():
     save("G17_multitarget", **out)
 
 
+def golden_isotropic():
+    """G18: one theta for all d > 1 dimensions (kernel.py:319-320).  The likelihood value is the ordinary one; its gradient
+    is what the reference's loops produce when they index the (N, N, d) tensor of `corr_grad_theta` by PARAMETER
+    (gpr.py:1001-1037): the derivative along dimension 0 in the theta row and, in the noisy mode, along dimension 1 in
+    the sigma2 row.  That vector drives the reference's MLE, so it is the golden."""
+    X, y = make_data(18, 44, 3)
+    y = y + 0.15 * np.random.default_rng(518).standard_normal(y.shape)
+    d = 3
+    out = dict(X=X, y=y)
+    rng = np.random.default_rng(618)
+    n = 0
+    for kid, corr in ((0, "squared_exponential"), (2, "matern"), (4, "absolute_exponential")):
+        for mid, kw in ((0, dict(nugget=0)), (1, dict(nugget=1e-6)), (2, dict(nugget=1e-6, noise_estim=True))):
+            for tname, mean in (("sk", trend.constant_trend(d, beta=0.0)), ("ok", trend.constant_trend(d))):
+                gp = GaussianProcess(mean=mean, corr=corr, thetaL=[1e-4], thetaU=[1e2], **kw)
+                gp._check_data(X, y)
+                pars = []
+                for _ in range(3):
+                    th = 10 ** rng.uniform(-1.8, -0.9, size=1)
+                    pars.append(th if mid == 0 else np.r_[th, rng.uniform(0.4, 0.95)])
+                vals, grads = llf_table(gp, pars)
+                key = "k%d_m%d_%s" % (kid, mid, tname)
+                out[key + "_par"], out[key + "_llf"], out[key + "_grad"] = np.array(pars), vals, grads
+                n += int(np.isfinite(vals).sum())
+    assert n >= 40, n
+    save("G18_isotropic_tables", **out)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["trends"]:
         golden_trends()
@@ -462,8 +490,11 @@ if __name__ == "__main__":
         golden_reml()
     elif sys.argv[1:] == ["multitarget"]:
         golden_multitarget()
+    elif sys.argv[1:] == ["isotropic"]:
+        golden_isotropic()
     else:
         main()
         golden_trends()
         golden_reml()
         golden_multitarget()
+        golden_isotropic()

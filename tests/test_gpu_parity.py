@@ -975,3 +975,32 @@ def test_multitarget_model_class_fits_and_predicts():
     with pytest.raises(NotImplementedError):  # estimated trend: the reference cannot finish this fit either
         bogp.GaussianProcess(mean=bogp.trend.constant_trend(d), corr="squared_exponential", thetaL=[1e-3] * d, thetaU=[10.0] * d,
                              nugget=1e-3).fit(X, Y)  # fmt: skip
+
+
+def test_isotropic_theta_likelihood_gradient_is_the_reference_one(eng):
+    """len(theta) = 1 with d = 3 (G18): the reference indexes the per-dimension derivative tensor by parameter
+    (gpr.py:1001-1037); its MLE is driven by exactly that vector, so the device returns it too."""
+    g = load_golden("G18_isotropic_tables")
+    eng.set_train(g["X"], g["y"])
+    n = 0
+    for kid in (0, 2, 4):
+        for mid in (0, 1, 2):
+            for tname in ("sk", "ok"):
+                key = "k%d_m%d_%s" % (kid, mid, tname)
+                for p, v, gr in zip(g[key + "_par"], g[key + "_llf"], g[key + "_grad"]):
+                    if np.isneginf(v):
+                        with pytest.raises(_lib.NotPositiveDefinite):
+                            eng.nll(kid, mid, p, 1e-6 if mid == 1 else 0.0, tname == "ok", 0.0, eval_grad=True)
+                        continue
+                    llf, grad = eng.nll(kid, mid, p, 1e-6 if mid == 1 else 0.0, tname == "ok", 0.0, eval_grad=True)
+                    np.testing.assert_allclose(llf, v, rtol=1e-9)
+                    np.testing.assert_allclose(grad, gr, rtol=1e-6, atol=1e-7 * np.abs(gr).max())
+                    n += 1
+    assert n >= 40
+    # and a complete fit with one theta runs through the host loop
+    d = g["X"].shape[1]
+    gp = bogp.GaussianProcess(mean=bogp.trend.constant_trend(d), corr="matern", thetaL=[1e-3], thetaU=[10.0], nugget=1e-6,
+                              random_start=2, eval_budget=120)  # fmt: skip
+    np.random.seed(3)
+    assert gp.fit(g["X"], g["y"]).is_fitted and gp.theta_.shape == (1,)
+    assert gp.predict(g["X"][:3]).shape == (3, 1)

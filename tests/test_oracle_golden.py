@@ -343,3 +343,24 @@ def test_multitarget_tables_and_states():
             close(mu, g[key + "_mu"], rtol=1e-8, atol=1e-10)
             close(mse, g[key + "_mse"], rtol=1e-7, atol=1e-10)
     assert n == 24
+
+
+def test_isotropic_theta_tables():
+    """One theta for d = 3 dimensions: the value is the ordinary likelihood, the gradient is the reference's
+    parameter-indexed slice of the per-dimension tensor (gpr.py:1001-1037)."""
+    g = load_golden("G18_isotropic_tables")
+    n = 0
+    for kid in (0, 2, 4):
+        for mid in (0, 1, 2):
+            for tname in ("sk", "ok"):
+                key = "k%d_m%d_%s" % (kid, mid, tname)
+                for p, v, gr in zip(g[key + "_par"], g[key + "_llf"], g[key + "_grad"]):
+                    out = O.log_likelihood_concentrated(p, g["X"], g["y"], kid, mid, noise_var=1e-6 if mid == 1 else 0.0,
+                                                        estimate_trend=(tname == "ok"), beta=0.0, eval_grad=True)  # fmt: skip
+                    if np.isneginf(v):
+                        assert np.isneginf(out[0])
+                        continue
+                    close(out[0], v, rtol=1e-11)
+                    close(out[1], gr, rtol=1e-8, atol=1e-9)
+                    n += 1
+    assert n >= 40
