@@ -50,6 +50,7 @@ SIGNATURES = {
     "bogp_sweep_topk": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, C.c_double, C.c_int, C.c_int, _dp, _lp]),
     "bogp_gradient": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "bogp_gradient_batch": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
+    "bogp_point_eval": (C.c_int, [C.c_void_p, _dp, C.c_int, _ip, _dp, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "bogp_last_timing": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip]),
     "bogp_flops_per_candidate": (C.c_double, [C.c_void_p]),
 }
@@ -336,6 +337,24 @@ class Engine:
         dmu, dmse = np.empty(self.d), np.empty(self.d)
         self._check(self._lib.bogp_gradient(self._h, _ptr(x), _ptr(dmu), _ptr(dmse)))
         return dmu, dmse
+
+    def point_eval(self, x, acq: Sequence[Tuple[int, float]] = (), plugin: float = 0.0, minimize: bool = True):
+        """mu, mse, dmu (d,), dmse (d,), criterion values (q,) at ONE point with one device round trip
+        (bogp_point_eval: what `criterion(x, return_dx=True)` needs).  Constant trend basis."""
+        x = _f64(x).ravel()
+        if len(x) != self.d:
+            raise Exception("x does not have the right size!")
+        q = len(acq)
+        ids = np.ascontiguousarray([a for a, _ in acq], dtype=np.int32)
+        pars = np.ascontiguousarray([p for _, p in acq], dtype=np.float64)
+        mu, mse = C.c_double(), C.c_double()
+        dmu, dmse, vals = np.empty(self.d), np.empty(self.d), np.empty(max(q, 1))
+        self._check(
+            self._lib.bogp_point_eval(self._h, _ptr(x), q, ids.ctypes.data_as(_ip) if q else None, _ptr(pars) if q else None,
+                                      float(plugin), int(bool(minimize)), C.cast(C.byref(mu), _dp), C.cast(C.byref(mse), _dp),
+                                      _ptr(dmu), _ptr(dmse), _ptr(vals) if q else None)
+        )  # fmt: skip
+        return mu.value, mse.value, dmu, dmse, vals[:q]
 
     def gradient_batch(self, Xb):
         """(d mu / dx, d MSE / dx) at B points: two (B, d) arrays."""

@@ -50,10 +50,13 @@ class _Moments:
     """Posterior moments and their input-gradients at ONE row, in the orientation the criteria use:
     y (sign-flipped when maximising, `:52-64`), sd = sqrt(MSE), dy and dsd as (1, d) rows (`:66-80`)."""
 
-    def __init__(self, criterion: "AcquisitionFunction", X: np.ndarray):
+    def __init__(self, criterion: "AcquisitionFunction", X: np.ndarray, moments=None):
         model, sign = criterion.model, (1.0 if criterion.minimize else -1.0)
-        mu, mse = model.predict(X, eval_MSE=True)
-        dmu, dmse = model.gradient(np.array(X, dtype=float))
+        if moments is None:
+            mu, mse = model.predict(X, eval_MSE=True)
+            dmu, dmse = model.gradient(np.array(X, dtype=float))
+        else:  # already computed by the fused one-point device call
+            mu, mse, dmu, dmse = moments
         self.y = sign * mu
         self.sd = np.sqrt(mse)
         self.dy = sign * dmu.T
@@ -107,8 +110,28 @@ class AcquisitionFunction:
 
     _single_row_shape = (1,)
 
+    def _fused_point(self, X: np.ndarray):
+        """value + moments + their gradients at one row in ONE device call (bogp_point_eval), or None when the model
+        needs the separate predict / gradient entry points (polynomial trend basis, several targets, foreign model)."""
+        model = self._model
+        if getattr(model, "_committed_par", None) is None:
+            raise Exception("The model is not fitted yet!")
+        eng = getattr(model, "engine", None)
+        fused = getattr(model, "_fused_point_ok", None)
+        if eng is None or fused is None or not hasattr(eng, "point_eval") or not fused():
+            return None
+        x = model._check_X(X)
+        mu, mse, dmu, dmse, vals = eng.point_eval(x[0], [(self.acq_id, self.acq_par())], self.effective_plugin(), self.minimize)
+        mom = (np.array([[mu]]), np.array([[mse]]), dmu.reshape(-1, 1), dmse.reshape(-1, 1))
+        return vals, mom
+
     def __call__(self, X, return_dx: bool = False):
         X = self.check_X(X)
+        if X.shape[0] == 1:  # the one-point call of the reference's inner optimisers: one device round trip
+            fused = self._fused_point(X)
+            if fused is not None:
+                value = fused[0].reshape(self._single_row_shape)
+                return self._dx(_Moments(self, X, fused[1]), value) if return_dx else value
         v = self._values(X)
         value = v.reshape(self._single_row_shape) if X.shape[0] == 1 else v.reshape(-1, 1)
         if not return_dx:

@@ -1239,6 +1239,75 @@ extern "C" int bogp_gradient(bogp_handle* h, const double* x, double* dmu, doubl
   return BOGP_OK;
 }
 
+// Everything the reference's default inner optimiser asks for at ONE point -- criterion(x, return_dx=True) =
+// predict (gpr.py:486-510) + gradient (:537-576) + the closed form (acquisition_fun.py) -- in one call with one host
+// synchronisation: the intermediates of bogp_gradient (r, V r, V^T V r) also give mu = beta + r.gamma and
+// MSE = sigma2 (1 - |V r|^2 + u^2), and the q criteria run through the same k_acquisition as a sweep row.
+// Constant trend basis only (polynomial bases: BOGP_ERR_UNSUPPORTED, callers use the separate entry points).
+extern "C" int bogp_point_eval(bogp_handle* h, const double* x, int q, const int* acq_id, const double* acq_par, double plugin,
+                               int minimize, double* mu, double* mse, double* dmu, double* dmse, double* acq) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "bogp_point_eval: no committed model");
+  if (!x || !mu || !mse || !dmu || !dmse) FAIL(h, BOGP_ERR_INVALID, "bogp_point_eval: null pointer");
+  if (q < 0 || q > BOGP_MAX_Q || (q > 0 && (!acq_id || !acq))) FAIL(h, BOGP_ERR_INVALID, "bogp_point_eval: 0 <= q <= %d with non-null acq_id / acq", BOGP_MAX_Q);
+  if (h->p > 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_point_eval: constant trend basis only (use bogp_predict + bogp_gradient)");
+  for (int i = 0; i < q; ++i) {
+    if (acq_id[i] < 0 || acq_id[i] > 3) FAIL(h, BOGP_ERR_INVALID, "unknown acquisition id %d", acq_id[i]);
+    const bool zero_ok = acq_id[i] == BOGP_ACQ_EPSILON_PI;
+    if (acq_id[i] != BOGP_ACQ_EI && (!acq_par || !(acq_par[i] > 0 || (zero_ok && acq_par[i] == 0))))
+      FAIL(h, BOGP_ERR_INVALID, "acquisition parameter %d must be > 0 (the reference asserts alpha/epsilon/t > 0)", i);
+  }
+  const int N = h->N, d = h->d;
+  hipStream_t st = h->stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)N * (d + 2) + 4 * d + 16 + BOGP_MAX_Q);
+  if (e) return e;
+  if ((e = ensure(h, &h->dblk_val, &h->blk_val_cap, (size_t)BOGP_MAX_Q * 2))) return e;
+  if ((e = ensure(h, &h->dblk_idx, &h->blk_idx_cap, (size_t)BOGP_MAX_Q * 2))) return e;
+  double* dr = h->dgrad_partial;      // N
+  double* drdx = dr + N;              // d x N (column k = dr/dx_k)
+  double* dz = drdx + (size_t)N * d;  // N
+  double* dx = dz + N;                // d
+  double* dout = dx + d;              // 3 d: gamma^T r_dx, z^T r_dx, w^T r_dx
+  double* dred = dout + 3 * d;        // r.gamma, r.w, |V r|^2, mu, mse
+  double* dacq = dred + 8;            // q
+  HIPCHK(h, hipMemcpyAsync(dx, x, d * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(h, launch_point_corr(h->kernel, h->dX, N, d, h->dtheta, dx, dr, drdx, st));
+  HIPCHK(h, hipMemcpyAsync(dz, dr, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+  BLASCHK(h, rocblas_dtrmv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, h->dV, h->ldr, dz, 1));
+  HIPCHK(h, launch_col_reduce(dr, dz, N, 1, h->dgamma, h->dw, dred, dred + 1, dred + 2, st));  // before dz becomes V^T V r
+  BLASCHK(h, rocblas_dtrmv(h->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, h->dV, h->ldr, dz, 1));
+  const double one = 1.0, zero = 0.0;
+  BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, h->dgamma, 1, &zero, dout, 1));
+  BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, dz, 1, &zero, dout + d, 1));
+  if (h->estimate_trend)
+    BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, h->dw, 1, &zero, dout + 2 * d, 1));
+  AcqArgs aa;
+  memset(&aa, 0, sizeof(aa));
+  aa.mu_part = dred; aa.w_part = dred + 1; aa.ss_part = dred + 2; aa.S = 1; aa.nJ = 1; aa.Mc = 1;
+  aa.mcount = 1; aa.m0 = 0; aa.beta = h->beta; aa.G = h->G; aa.estimate_trend = h->estimate_trend;
+  aa.sigma2 = h->sigma2; aa.mu_out = dred + 3; aa.mse_out = dred + 4;
+  aa.q = q;
+  for (int i = 0; i < q; ++i) { aa.acq_id[i] = acq_id[i]; aa.acq_par[i] = acq_par ? acq_par[i] : 0.0; }
+  aa.plugin = plugin; aa.minimize = minimize; aa.acq_out = q > 0 ? dacq : nullptr; aa.M = 1;
+  aa.blk_val = h->dblk_val; aa.blk_idx = h->dblk_idx; aa.blk_offset = 0; aa.nblk_total = 1;
+  HIPCHK(h, launch_acquisition(aa, st));
+  std::vector<double> out((size_t)3 * d + 8 + (q > 0 ? q : 0), 0.0);  // dout | dred | dacq are contiguous
+  HIPCHK(h, hipMemcpyAsync(out.data(), dout, out.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  const double wr = out[3 * d + 1];
+  *mu = out[3 * d + 3];
+  *mse = out[3 * d + 4];
+  for (int i = 0; i < q; ++i) acq[i] = out[3 * d + 8 + i];
+  for (int k = 0; k < d; ++k) {
+    dmu[k] = out[k];  // beta^T f_dx = 0 for the constant basis
+    double m = -1.0 * out[d + k];
+    if (h->estimate_trend) m += (wr - 1.0) * (1.0 / h->ftft) * out[2 * d + k];
+    dmse[k] = 2.0 * h->sigma2 * m;
+  }
+  return BOGP_OK;
+}
+
 // Batched flavour: B points, one pair of triangular solves with B right-hand sides
 // (rocBLAS dtrsm = the reference's solve_triangular twice) and one reduction kernel; dmu, dmse are B x d row-major.
 extern "C" int bogp_gradient_batch(bogp_handle* h, const double* Xb, int B, double* dmu, double* dmse) {

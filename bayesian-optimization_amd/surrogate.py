@@ -500,6 +500,10 @@ class GaussianProcess:
         dmu, dmse = self.engine.gradient(x[0])
         return dmu.reshape(-1, 1), dmse.reshape(-1, 1)
 
+    def _fused_point_ok(self) -> bool:
+        """bogp_point_eval serves the constant trend basis with a single target."""
+        return self._trend_args()[0] == _lib.TREND_CONSTANT and self.y.shape[1] == 1
+
     def gradient_batch(self, X):
         """`gradient` at B rows in one device call: (d mu / dx (B, d), d MSE / dx (B, d)).  Not in the reference
         (its gradient takes one row, gpr.py:548-549); SURVEY.md 8 f2."""

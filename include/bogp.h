@@ -197,6 +197,12 @@ int bogp_gradient(bogp_handle* h, const double* x, double* dmu, double* dmse);
 /* The same for B points at once (Xb: B x d; dmu, dmse: B x d row-major): one pair of triangular solves with B
  * right-hand sides + one reduction kernel.  Feeds multi-start local refinement of the sweep's top-k.      */
 int bogp_gradient_batch(bogp_handle* h, const double* Xb, int B, double* dmu, double* dmse);
+/* One point, everything at once: what `criterion(x, return_dx=True)` needs (acquisition_fun.py:139-146, 181-188,
+ * 220-227, 292-309 call predict, gradient and the closed form) -- mu, mse, dmu (d), dmse (d) and the q criterion values --
+ * with a single host synchronisation.  This is the call the reference's DEFAULT inner optimiser (multi-restart
+ * L-BFGS-B, base.py:201-243) makes thousands of times per ask().  Constant trend basis; q may be 0.            */
+int bogp_point_eval(bogp_handle* h, const double* x, int q, const int* acq_id, const double* acq_par, double plugin,
+                    int minimize, double* mu, double* mse, double* dmu, double* dmse, double* acq);
 
 /* ---- measurement ----------------------------------------------------------------------------------
  * HIP-event durations (ms, summed over candidate chunks) of the kernels of the LAST bogp_predict /

@@ -1004,3 +1004,36 @@ def test_isotropic_theta_likelihood_gradient_is_the_reference_one(eng):
     np.random.seed(3)
     assert gp.fit(g["X"], g["y"]).is_fitted and gp.theta_.shape == (1,)
     assert gp.predict(g["X"][:3]).shape == (3, 1)
+
+
+@pytest.mark.parametrize("name", ["G1_se_sk_noisy", "G2_m32_ok_noisy", "G4_se_ok_noiseless", "G12_absexp_ok_noisy", "G3_m52_sk_noisy"])
+def test_fused_point_evaluation_equals_the_separate_calls(eng, name):
+    """bogp_point_eval (one round trip) against bogp_predict + bogp_gradient + bogp_sweep on the same row, and against
+    the oracle: the call the reference's default L-BFGS-B inner optimiser makes per evaluation."""
+    g = load_golden(name)
+    commit_golden(eng, g)
+    st = state_from_golden(g)
+    pl = O.plugin_value(st.y, True)
+    acq = [(O.ACQ_EI, 0.0), (O.ACQ_EPSILON_PI, 1e-10), (O.ACQ_UCB, 0.5), (O.ACQ_MGFI, 2.0)]
+    rng = np.random.default_rng(3)
+    pts = np.vstack([g["Xs"][:4], g["X"][:2] + 1e-3 * rng.standard_normal((2, g["X"].shape[1]))])
+    for x in pts:
+        mu, mse, dmu, dmse, vals = eng.point_eval(x, acq, pl, True)
+        eng.upload_candidates(x[None, :])
+        mu1, mse1 = eng.predict()
+        _, _, v1 = eng.sweep(acq, pl, True, return_values=True)
+        np.testing.assert_allclose(mu, mu1[0], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(mse, mse1[0], rtol=1e-9, atol=1e-15 * float(st.sigma2[0]))
+        np.testing.assert_allclose(vals, v1[:, 0], rtol=1e-8, atol=1e-300)
+        omu, omse = O.predict(st, x[None, :])
+        close_mu(mu, omu)
+        close_mse(mse, omse, st.sigma2[0])
+        if name != "G3_m52_sk_noisy":  # the reference (hence the oracle) has no Matern-5/2 derivative
+            odmu, odmse = O.gradient(st, x)
+            np.testing.assert_allclose(dmu, np.ravel(odmu), rtol=1e-6, atol=1e-9)
+            np.testing.assert_allclose(dmse, np.ravel(odmse), rtol=1e-6, atol=1e-9 * float(st.sigma2[0]))
+        g1, g2 = eng.gradient(x)
+        np.testing.assert_allclose(dmu, g1, rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(dmse, g2, rtol=1e-10, atol=1e-14)
+    mu, mse, dmu, dmse, vals = eng.point_eval(pts[0])  # q = 0: moments only
+    assert vals.shape == (0,) and np.isfinite(mu) and mse >= 0
