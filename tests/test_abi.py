@@ -86,3 +86,31 @@ def test_graft_entry_build_is_consistent_with_the_abi():
     import __graft_entry__ as entry
 
     entry.build()
+
+
+def _build_c_client(tmp_path):
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "abi_smoke")
+    pkg = os.path.join(ROOT, "bayesian-optimization_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", exe, "-L", pkg, "-lbogp", "-Wl,-rpath," + pkg]  # fmt: skip
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """include/bogp.h compiles as C99 (-pedantic -Werror) and a C program links against libbogp.so with no Python in
+    the process.  Without a GPU the client must stop at bogp_create with BOGP_ERR_NO_DEVICE (exit code 3), loudly."""
+    import subprocess
+
+    exe = _build_c_client(tmp_path)
+    res = subprocess.run([exe, "50", "3", "100", "7"], capture_output=True, text=True, timeout=120)
+    if res.returncode == 0:  # a GPU is present: the numbers are checked by the -m gpu test
+        assert "best" in res.stdout
+    else:
+        assert res.returncode == 3 and "bogp_create" in res.stderr, (res.returncode, res.stderr)

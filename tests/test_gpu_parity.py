@@ -1037,3 +1037,49 @@ def test_fused_point_evaluation_equals_the_separate_calls(eng, name):
         np.testing.assert_allclose(dmse, g2, rtol=1e-10, atol=1e-14)
     mu, mse, dmu, dmse, vals = eng.point_eval(pts[0])  # q = 0: moments only
     assert vals.shape == (0,) and np.isfinite(mu) and mse >= 0
+
+
+def test_plain_c_client_gets_the_same_numbers(tmp_path):
+    """tests/c/abi_smoke.c (gcc -std=c99, no Python, no torch in the process) against the same calls through ctypes:
+    the C ABI is the product boundary, the Python classes only sit on top of it."""
+    import subprocess
+
+    from test_abi import _build_c_client
+
+    N, d, M, seed = 200, 6, 5000, 7
+    exe = _build_c_client(tmp_path)
+    res = subprocess.run([exe, str(N), str(d), str(M), str(seed)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    got = {ln.split()[0]: [float(v) for v in ln.split()[1:]] for ln in res.stdout.strip().splitlines()}
+    s = seed
+    X = np.empty((N, d))
+    y = np.empty(N)
+    for i in range(N):  # the client's LCG (Knuth MMIX constants), 53-bit mantissas
+        for k in range(d):
+            s = (s * 6364136223846793005 + 1442695040888963407) % 2**64
+            X[i, k] = -5.0 + 10.0 * ((s >> 11) / 9007199254740992.0)
+        acc = 0.0
+        for k in range(d):  # the client's left-to-right accumulation
+            acc += X[i, k] * X[i, k]
+        y[i] = acc / (8.0 * d) - 1.0
+    e = _lib.Engine(0)
+    e.set_train(X, y)
+    par = np.r_[np.full(d, 0.02), 0.9]
+    llf = e.commit(O.KERNEL_MATERN32, O.MODE_NOISY, par, 1e-6, False, 0.0)
+    e.generate_candidates(np.full(d, -5.0), np.full(d, 5.0), M, seed=42)
+    best, idx = e.sweep([(O.ACQ_EI, 0.0)], float(y.min()), True)
+    mu, mse = e.predict()
+    np.testing.assert_allclose(got["llf"][0], llf, rtol=1e-12)
+    assert int(got["best"][1]) == int(idx[0])
+    np.testing.assert_allclose(got["best"][0], best[0], rtol=1e-12)
+    np.testing.assert_allclose(got["mu0"][0], mu[0], rtol=1e-12)
+    np.testing.assert_allclose(got["mse0"][0], mse[0], rtol=1e-12)
+    # and the oracle agrees with both
+    st = O.make_state(par, X, y.reshape(-1, 1), O.KERNEL_MATERN32, O.MODE_NOISY, 1e-6)
+    from oracle import philox as P
+
+    Xs = P.uniform_box(np.full(d, -5.0), np.full(d, 5.0), M, 42)
+    obest, oidx = O.sweep(st, Xs, [(O.ACQ_EI, 0.0)], float(y.min()), True)
+    assert int(oidx[0]) == int(idx[0])
+    np.testing.assert_allclose(got["best"][0], obest[0], rtol=1e-6)
+    e.close()
