@@ -18,7 +18,7 @@
 //
 // Triangular contraction.  With V = L^-1 (lower triangular, packed once per fit into B-fragment order),
 // rt = V r and sum(rt^2) = sum_j (sum_{n<=j} V[j][n] r[n])^2.  A workgroup owns 64 candidates x 256 columns j
-// (4 waves x 4 sixteen-wide column tiles, interleaved so every wave meets the diagonal equally) and walks n in
+// (4 waves x 4 sixteen-wide column tiles, dealt so that every wave carries the same share of the diagonal) and walks n in
 // blocks of 32; 16x16 blocks above the diagonal are skipped (executed flops ~= N^2 (1 + 16/N) per candidate).
 // A 16x16 output tile is 4 instructions: instruction t pairs A row-block (b+t)%4 with B column-block b, so ONE
 // B register and four rotated A reads (LDS) feed 2048 flop.
@@ -355,7 +355,9 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
   bool valid[NR];
 #pragma unroll
   for (int ni = 0; ni < NR; ++ni) {
-    const int j = jg * JT16 + w + NWJ * ni;
+    // serpentine tile assignment {w, 7-w, 8+w, 15-w}: in the diagonal zone tile t carries t+1 sixteen-row groups, so every
+    // wave gets the same 34 of them (the plain interleave w + 4 ni gives wave 3 640 MFMAs against wave 0's 448)
+    const int j = jg * JT16 + ((ni & 1) ? NWJ * (ni + 1) - 1 - w : NWJ * ni + w);
     valid[ni] = j < NJ16;
     jt[ni] = valid[ni] ? j : -1;
     boff[ni] = (size_t)min(j, NJ16 - 1) * NKP * 64;
