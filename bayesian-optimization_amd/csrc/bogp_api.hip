@@ -224,7 +224,7 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
   if (!h) return BOGP_ERR_INVALID;
   if (!X || !y || N <= 0 || d <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_set_train: X, y must be non-null and N, d > 0");
   if (n_targets < 1 || n_targets > BOGP_MAX_TARGETS) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_set_train: n_targets = %d outside [1, %d]", n_targets, BOGP_MAX_TARGETS);
-  if (d > 128) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_set_train: d = %d > 128: the sweep producer keeps a 64 x d candidate tile in 64 KB of LDS", d);
+  if (d > BOGP_MAX_DIM) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_set_train: d = %d > %d: the sweep producer keeps a 64 x d candidate tile in the CU's 160 KB of LDS", d, BOGP_MAX_DIM);
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   free_train(h);

@@ -448,8 +448,19 @@ hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipS
   dim3 grid((unsigned)nMt, (unsigned)S);
   size_t shm = (size_t)max(64 * a.d, 512) * sizeof(double);
   CorrDims dm{a.M, a.m0, a.Mc, a.d, a.Np, a.nblk_per_split};
-#define BOGP_LAUNCH_CORR(K) \
-  hipLaunchKernelGGL(k_corr_chunk<K>, grid, 256, shm, st, a.Xs, a.sqrt_theta, a.XthT, a.gamma, a.wvec, a.rT, a.mu_part, a.w_part, dm)
+  // the candidate tile is 64 x d doubles of dynamic LDS: above the 64 KB default (d > 128) the kernel has to be allowed
+  // more, up to the CU's 160 KB (d <= 320; occupancy then drops to one workgroup per CU, which only matters for the
+  // ~10 % of the sweep this producer accounts for)
+#define BOGP_LAUNCH_CORR(K)                                                                                              \
+  do {                                                                                                                   \
+    if (shm > 64 * 1024) {                                                                                               \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_corr_chunk<K>),                               \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                         \
+      if (e_ != hipSuccess) return e_;                                                                                   \
+    }                                                                                                                    \
+    hipLaunchKernelGGL(k_corr_chunk<K>, grid, 256, shm, st, a.Xs, a.sqrt_theta, a.XthT, a.gamma, a.wvec, a.rT, a.mu_part, \
+                       a.w_part, dm);                                                                                    \
+  } while (0)
   switch (kernel) {
     case BOGP_KERNEL_SE: BOGP_LAUNCH_CORR(BOGP_KERNEL_SE); break;
     case BOGP_KERNEL_MATERN12: BOGP_LAUNCH_CORR(BOGP_KERNEL_MATERN12); break;

@@ -67,6 +67,7 @@ typedef struct bogp_handle bogp_handle;
 #define BOGP_TREND_LINEAR 1    /* [1, x]                      trend.py:94-118  */
 #define BOGP_TREND_QUADRATIC 2 /* [1, x, x_k x_j (j >= k)]    trend.py:121-142 */
 
+#define BOGP_MAX_DIM 320   /* input dimensions d (64 x d doubles of LDS in the sweep's producer) */
 #define BOGP_MAX_TARGETS 8 /* columns of y (n_targets, gpr.py:463) */
 #define BOGP_MAX_Q 64    /* criteria evaluated in one sweep (ParallelBO batch size q) */
 #define BOGP_MAX_TOPK 32 /* ranks returned per criterion by bogp_sweep_topk */

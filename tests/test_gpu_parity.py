@@ -283,12 +283,23 @@ def test_error_codes(eng):
     with pytest.raises(_lib.BogpError):
         e2.set_train(X, np.zeros((5, _lib.MAX_TARGETS + 1)))  # more targets than BOGP_MAX_TARGETS
     with pytest.raises(_lib.BogpError) as ei:
-        e2.set_train(np.zeros((4, 129)), np.zeros(4))  # d beyond the producer's LDS tile
+        e2.set_train(np.zeros((4, 321)), np.zeros(4))  # d beyond the producer's LDS tile (64 x d doubles <= 160 KB)
     assert ei.value.code == _lib.ERR_UNSUPPORTED
-    e2.set_train(np.random.default_rng(0).uniform(-1, 1, (40, 128)), np.arange(40.0) / 40)  # d = 128 works
-    e2.commit(0, 1, np.r_[np.full(128, 0.02), 0.9], 1e-6)
-    e2.upload_candidates(np.zeros((3, 128)))
-    assert np.all(np.isfinite(e2.predict()[0]))
+    for dd in (128, 129, 320):  # 64 KB of dynamic LDS is the default ceiling; above it the kernel opts in to more
+        rg = np.random.default_rng(dd)
+        Xd_, yd_ = rg.uniform(-1, 1, (60, dd)), rg.standard_normal((60, 1))
+        pard = np.r_[np.full(dd, 0.5 / dd), 0.9]
+        e2.set_train(Xd_, yd_)
+        e2.commit(3, 1, pard, 1e-6)
+        Xsd = rg.uniform(-1, 1, (130, dd))
+        e2.upload_candidates(Xsd)
+        mu_d, mse_d = e2.predict()
+        std = O.make_state(pard, Xd_, yd_, 3, 1, 1e-6)
+        omu, omse = O.predict(std, Xsd)
+        close_mu(mu_d, omu)
+        close_mse(mse_d, omse, 0.9)
+        g1, g2 = e2.gradient(Xsd[0])
+        assert np.all(np.isfinite(g1)) and np.all(np.isfinite(g2))
     # duplicated rows, no nugget -> singular correlation matrix -> the -inf convention
     Xd = np.vstack([X, X[:1]])
     e2.set_train(Xd, np.arange(6.0))
