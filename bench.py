@@ -178,13 +178,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": w["name"], "N": N, "d": d, "M_per_gpu": M, "q": len(w["acq"]),
                        "parallelism": "candidate shards x%d, 1 all-gather of q*(val,idx) per step" % world},
-            "roofline": {
+            "roofline": (lambda r: dict(r, hbm_GBps=(r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) if r["traffic"] else None))({
                 "bound": "mfma", "kernel": "k_contract16 (v_mfma_f64_16x16x4_f64, VGPR accumulators)" if os.environ.get("BOGP_CONTRACT_MFMA", "16")[0] != "4" else "k_contract (v_mfma_f64_4x4x4_4b_f64)", "achieved": achieved, "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS,
                 "traffic": measured_traffic(args.workload, ((1 << 30) // (((N + 31) // 32 * 32) * 8)) // 64 * 64),
                 "avg_launch_ms": tim["contract_ms"] / max(1, tim["n_chunks"]), "launches": tim["n_chunks"],
                 "flops_per_candidate": float(N) * N + 3.0 * N,
-            },
+                # what the kernel executes: 16 x 16 tiles on and below the diagonal of the (padded) triangle
+                "executed_flops_per_candidate": 256.0 * ((N + 31) // 32 * 2) * ((N + 31) // 32 * 2 + 1),
+            }),
             "kernels_ms_per_step": {k: tim[k] / args.steps for k in ("corr_ms", "contract_ms", "acquisition_ms")},
             "whole_step_tflops": eng.flops_per_candidate() * M / (elapsed / args.steps) / 1e12,
             "ask_ms": elapsed / args.steps * 1e3,
