@@ -419,7 +419,12 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
   // ---- epilogue: D[i][j] sits in lane 16 (i % 4) + j, register i / 4 ---------------------------------
   BOGP_MFMA16_DRAIN();
   __syncthreads();
-  double* red = lds;  // [NWJ][64 rows][16 slots]
+  // red[slot][wave][row] with a row pitch of 65 doubles: the writes (lanes = 4 rows x 16 slots) fall on (4 slot + row)
+  // mod 32 = every bank pair twice, the reads (lanes = 64 consecutive rows) are conflict free.  (The first layout,
+  // [wave][row][slot], made every read a 64-way bank conflict: 13.7k cycles of epilogue per workgroup.)
+  constexpr int RP = 65;
+  double* red = lds;                    // [16 slots][NWJ][RP]
+  double* red2 = lds + 16 * NWJ * RP;   // [NWJ][64]: per-wave partial sums
   const int q = lane >> 4, jc = lane & 15;
 #pragma unroll
   for (int mi = 0; mi < MR; ++mi)
@@ -429,16 +434,17 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
 #pragma unroll
       for (int ni = 0; ni < NR; ++ni)
         if (valid[ni]) s = __builtin_fma(acc[mi][ni][r], acc[mi][ni][r], s);
-      red[(w * 64 + 16 * mi + 4 * r + q) * 16 + jc] = s;  // slot = column inside the 16-tile, as in kernel B
+      red[(jc * NWJ + w) * RP + 16 * mi + 4 * r + q] = s;  // slot = column inside the 16-tile
     }
   __syncthreads();
-  if (tid < 64) {
+  {  // every thread adds the 16 slots of one (wave, row) in a fixed order, then 64 threads add the four waves
     double s = 0.0;
-    for (int ww = 0; ww < NWJ; ++ww)
 #pragma unroll
-      for (int sl = 0; sl < 16; ++sl) s += red[(ww * 64 + tid) * 16 + sl];
-    a.ss_part[(size_t)jg * a.Mc + mc0 + tid] = s;
+    for (int sl = 0; sl < 16; ++sl) s += red[(sl * NWJ + w) * RP + lane];
+    red2[w * 64 + lane] = s;
   }
+  __syncthreads();
+  if (tid < 64) a.ss_part[(size_t)jg * a.Mc + mc0 + tid] = ((red2[tid] + red2[64 + tid]) + red2[128 + tid]) + red2[192 + tid];
 }
 
 // ---------------------------------------------------------------------------------------------------
