@@ -106,6 +106,11 @@ def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(_dp)
 
 
+def trend_size_of(trend: int, d: int) -> int:
+    """Columns of the trend basis (bogp_trend_size; needs no device)."""
+    return 1 if trend == TREND_CONSTANT else (d + 1 if trend == TREND_LINEAR else (d + 1) * (d + 2) // 2)
+
+
 def sobol_direction_numbers(d: int) -> np.ndarray:
     """The (d, bits) direction numbers of scipy's unscrambled Sobol' generator (Joe & Kuo tables, bits = 30): what
     the reference's `sobol_seq` call resolves to in this image.  Data for

@@ -198,6 +198,8 @@ class GaussianProcess:
             raise ValueError("Expected 2D array, got %dD array instead" % X.ndim)
         if y.ndim == 1:
             y = y.reshape(-1, 1)
+        if X.shape[0] == 0:
+            raise ValueError("Found array with 0 sample(s) (shape=%s) while a minimum of 1 is required." % (X.shape,))
         if X.shape[0] != y.shape[0]:
             raise ValueError("Found input variables with inconsistent numbers of samples: [%d, %d]" % (X.shape[0], y.shape[0]))
         if not (np.isfinite(X).all() and np.isfinite(y).all()):
@@ -210,6 +212,11 @@ class GaussianProcess:
             raise NotImplementedError("at most %d targets" % _lib.MAX_TARGETS)
         if self.thetaL.size not in (1, X.shape[1]):
             raise ValueError("Length of theta must be 1 or %s" % X.shape[1])
+        if self.estimate_trend:
+            p = _lib.trend_size_of(self._trend_args()[0], X.shape[1])
+            if p > X.shape[0]:  # gpr.py:299-308
+                raise Exception("Ordinary least squares problem is undetermined n_samples=%d must be greater than the "
+                                "meanession model size p=%d." % (X.shape[0], p))  # fmt: skip
         self.X, self.y = np.ascontiguousarray(X), np.ascontiguousarray(y)
         self._committed_par = None
         self.engine.set_train(self.X, self.y)
@@ -455,6 +462,10 @@ class GaussianProcess:
         X = np.asarray(X, dtype=np.float64)
         if X.ndim == 1:
             X = X.reshape(1, -1)
+        if X.ndim != 2:
+            raise ValueError("Expected 2D array, got %dD array instead" % X.ndim)
+        if X.shape[0] == 0:  # sklearn's check_array, which the reference calls first (gpr.py:460)
+            raise ValueError("Found array with 0 sample(s) (shape=%s) while a minimum of 1 is required." % (X.shape,))
         if X.shape[1] != self.X.shape[1]:
             raise ValueError(
                 "The number of features in X (X.shape[1] = %d) should match the number of features used for fit() which is %d."

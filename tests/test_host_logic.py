@@ -188,3 +188,32 @@ def test_merge_topk_is_repeated_np_argmax():
         assert i[: len(ref)].tolist() == ref
         np.testing.assert_array_equal(v[: len(ref)], table.reshape(-1)[ref])
         assert np.all(i[len(ref):] == -1)
+
+
+def test_input_validation_follows_the_reference_checks():
+    """check_X_y / check_array (gpr.py:281, 460) and the basis-size check (gpr.py:299-308): same exception types for
+    empty, non-finite, mis-shaped and under-determined inputs -- raised on the host before any device call."""
+    import bogp
+    from support.oracle_engine import OracleEngine
+
+    d = 3
+    gp = bogp.GaussianProcess(mean=bogp.trend.linear_trend(d), corr="squared_exponential", thetaL=[1e-3] * d, thetaU=[10.0] * d, nugget=1e-6)
+    gp._engine = OracleEngine()
+    rng = np.random.default_rng(0)
+    with pytest.raises(ValueError):
+        gp._check_data(np.zeros((0, d)), np.zeros((0, 1)))
+    with pytest.raises(ValueError):
+        gp._check_data(rng.standard_normal((5, d)), np.r_[1.0, np.nan, 0.0, 0.0, 0.0])
+    with pytest.raises(ValueError):
+        gp._check_data(rng.standard_normal((5, d)), np.zeros(4))
+    with pytest.raises(Exception, match="undetermined"):
+        gp._check_data(rng.standard_normal((3, d)), np.zeros(3))  # p = 4 columns, 3 rows
+    X, y = rng.standard_normal((12, d)), rng.standard_normal((12, 1))
+    gp.set_state(np.r_[np.full(d, 0.3), 0.9], X, y)
+    with pytest.raises(ValueError, match="0 sample"):
+        gp.predict(np.zeros((0, d)))
+    with pytest.raises(ValueError):
+        gp.predict(np.zeros((2, d + 1)))
+    with pytest.raises(ValueError):
+        gp.predict(np.array([[0.0, np.inf, 0.0]]))
+    assert gp.predict(np.zeros(d)).shape == (1, 1)  # one row given as a vector
