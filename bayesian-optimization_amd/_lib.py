@@ -50,6 +50,8 @@ SIGNATURES = {
     "bogp_sweep_topk": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, C.c_double, C.c_int, C.c_int, _dp, _lp]),
     "bogp_gradient": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "bogp_gradient_batch": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
+    "bogp_hessian": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "bogp_prior_corr": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp]),
     "bogp_point_eval": (C.c_int, [C.c_void_p, _dp, C.c_int, _ip, _dp, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "bogp_last_timing": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip]),
     "bogp_flops_per_candidate": (C.c_double, [C.c_void_p]),
@@ -360,6 +362,24 @@ class Engine:
                                       _ptr(dmu), _ptr(dmse), _ptr(vals) if q else None)
         )  # fmt: skip
         return mu.value, mse.value, dmu, dmse, vals[:q]
+
+    def hessian(self, x) -> np.ndarray:
+        """(d, d) Hessian of the posterior mean at x (squared exponential; constant / linear trend)."""
+        x = _f64(x).ravel()
+        if len(x) != self.d:
+            raise Exception("x does not have the right size!")
+        H = np.empty((self.d, self.d))
+        self._check(self._lib.bogp_hessian(self._h, _ptr(x), _ptr(H)))
+        return H
+
+    def prior_corr(self, X1) -> np.ndarray:
+        """(n1, n1) correlation matrix of the rows of X1 at the committed theta."""
+        X1 = _f64(X1)
+        if X1.ndim != 2 or X1.shape[1] != self.d:
+            raise ValueError("X1 must have shape (n1, %d)" % self.d)
+        R = np.empty((X1.shape[0], X1.shape[0]))
+        self._check(self._lib.bogp_prior_corr(self._h, _ptr(X1), X1.shape[0], _ptr(R)))
+        return R
 
     def gradient_batch(self, Xb):
         """(d mu / dx, d MSE / dx) at B points: two (B, d) arrays."""

@@ -1308,6 +1308,53 @@ extern "C" int bogp_point_eval(bogp_handle* h, const double* x, int q, const int
   return BOGP_OK;
 }
 
+// Hessian of the posterior mean at x (GaussianProcess.Hessian, gpr.py:578-598): f_dx2 . beta + r_dx2 . gamma.  The trend
+// part is zero for the constant and linear bases (trend.py:88-91, 113-116; the quadratic one raises); the correlation part
+// exists for the squared exponential only (corr_Hessian, :663-734, leaves H undefined for every other kernel).
+extern "C" int bogp_hessian(bogp_handle* h, const double* x, double* H) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "bogp_hessian: no committed model");
+  if (!x || !H) FAIL(h, BOGP_ERR_INVALID, "bogp_hessian: null pointer");
+  if (h->kernel != BOGP_KERNEL_SE) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_hessian: squared exponential only (the reference's corr_Hessian defines no other kernel)");
+  if (h->trend == BOGP_TREND_QUADRATIC) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_hessian: the quadratic trend has no Hessian in the reference (trend.py:141-142)");
+  const int N = h->N, d = h->d;
+  hipStream_t st = h->stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)N * (d + 1) + d + (size_t)d * d);
+  if (e) return e;
+  double* dr = h->dgrad_partial;
+  double* drdx = dr + N;
+  double* dx = drdx + (size_t)N * d;
+  double* dH = dx + d;
+  HIPCHK(h, hipMemcpyAsync(dx, x, d * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(h, launch_point_corr(h->kernel, h->dX, N, d, h->dtheta, dx, dr, drdx, st));
+  HIPCHK(h, launch_point_hessian(h->dX, N, d, h->dtheta, dx, dr, drdx, h->dgamma, dH, st));
+  HIPCHK(h, hipMemcpyAsync(H, dH, (size_t)d * d * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  return BOGP_OK;
+}
+
+// Correlation between the rows of X1 at the committed theta (GaussianProcess.prior_cov(X1, corr=True), gpr.py:318-353;
+// its X2 argument cannot be used in the reference: `if X2` on an array raises).  R is n1 x n1, row-major.
+extern "C" int bogp_prior_corr(bogp_handle* h, const double* X1, int n1, double* R) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "bogp_prior_corr: no committed model");
+  if (!X1 || !R || n1 <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_prior_corr: X1 / R must be non-null and n1 > 0");
+  const int d = h->d;
+  hipStream_t st = h->stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  int e = ensure(h, &h->dbatch, &h->batch_cap, (size_t)n1 * d + 2 * (size_t)n1 * n1);
+  if (e) return e;
+  double* dX1 = h->dbatch;
+  double* dr = dX1 + (size_t)n1 * d;
+  double* ds2 = dr + (size_t)n1 * n1;
+  HIPCHK(h, hipMemcpyAsync(dX1, X1, (size_t)n1 * d * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(h, launch_batch_corr(h->kernel, dX1, n1, d, h->dtheta, dX1, n1, dr, ds2, st));
+  HIPCHK(h, hipMemcpyAsync(R, dr, (size_t)n1 * n1 * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  return BOGP_OK;
+}
+
 // Batched flavour: B points, one pair of triangular solves with B right-hand sides
 // (rocBLAS dtrsm = the reference's solve_triangular twice) and one reduction kernel; dmu, dmse are B x d row-major.
 extern "C" int bogp_gradient_batch(bogp_handle* h, const double* Xb, int B, double* dmu, double* dmse) {

@@ -125,6 +125,8 @@ hipError_t launch_fit_rho(const double* Yt, const double* Ft, int N, int estimat
                           hipStream_t st);
 hipError_t launch_trace_gg(const double* Rinv, int ld, int nparts, size_t part_stride, int N, const double* gamma,
                            const double* qv, double* out, hipStream_t st);
+hipError_t launch_point_hessian(const double* X, int N, int d, const double* theta, const double* x, const double* r,
+                                const double* rdx, const double* gamma, double* H, hipStream_t st);
 hipError_t launch_point_corr(int kernel, const double* X, int N, int d, const double* theta, const double* x,
                              double* r, double* rdx, hipStream_t st);
 

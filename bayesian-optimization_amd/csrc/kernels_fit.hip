@@ -339,6 +339,33 @@ hipError_t launch_point_corr(int kernel, const double* X, int N, int d, const do
   return hipGetLastError();
 }
 
+// ---- Hessian of the posterior mean at one point (GaussianProcess.Hessian, gpr.py:578-598; squared exponential only:
+// corr_Hessian :663-734 leaves H undefined for the other kernels) -------------------------------------------------------
+// H[k][l] = sum_n gamma_n * (-2) * (g[k][n] * theta_l (x_l - X_nl) + [k == l] r_n theta_k),  g = dr/dx from k_point_corr
+__global__ __launch_bounds__(256) void k_point_hessian(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
+                                                       const double* __restrict__ x, const double* __restrict__ r,
+                                                       const double* __restrict__ rdx, const double* __restrict__ gamma,
+                                                       double* __restrict__ H) {
+  __shared__ double red[4];
+  const int k = blockIdx.y, l = blockIdx.x;
+  const double tl = theta[l], tk = theta[k], xl = x[l];
+  double acc = 0.0;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    double v = rdx[(size_t)k * N + n] * (tl * (xl - X[(size_t)n * d + l]));
+    if (k == l) v += r[n] * tk;
+    acc = __builtin_fma(gamma[n], -2.0 * v, acc);
+  }
+  for (int m = 32; m >= 1; m >>= 1) acc += shfl_xor_f64(acc, m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) H[(size_t)k * d + l] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+hipError_t launch_point_hessian(const double* X, int N, int d, const double* theta, const double* x, const double* r,
+                                const double* rdx, const double* gamma, double* H, hipStream_t st) {
+  hipLaunchKernelGGL(k_point_hessian, dim3(d, d), 256, 0, st, X, N, d, theta, x, r, rdx, gamma, H);
+  return hipGetLastError();
+}
+
 // ---- batched input-gradients: B points at once ----------------------------------------------
 // k_batch_corr:  r[b*N + n] = corr(theta, |x_b - X_n|),  s2[b*N + n] = the weighted distance it was computed from
 template <int KERNEL>

@@ -511,6 +511,35 @@ class GaussianProcess:
         dmu, dmse = self.engine.gradient(x[0])
         return dmu.reshape(-1, 1), dmse.reshape(-1, 1)
 
+    def Hessian(self, x):
+        """Hessian of the posterior mean at one row (gpr.py:578-598): (d, d).  As in the reference it exists for the
+        squared-exponential kernel (corr_Hessian, :663-734, defines no other) and the constant / linear trends."""
+        if self._committed_par is None:
+            raise Exception("The model is not fitted yet!")
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        if x.shape[1] != self.X.shape[1]:
+            raise Exception("x does not have the right size!")
+        if x.shape[0] != 1:
+            raise Exception("x must be a vector!")
+        if self.kernel_id != _lib.KERNEL_SE or type(self.mean).__name__ == "quadratic_trend" or self.y.shape[1] != 1:
+            raise NotImplementedError("Hessian: squared_exponential kernel, constant or linear trend, one target")
+        return self.engine.hessian(x[0])
+
+    def prior_cov(self, X1, X2=None, corr=False):
+        """Prior correlation / covariance between the rows of X1 (gpr.py:318-353).  `X2` is accepted as None only: the
+        reference's `if X2` raises for any array."""
+        if X2 is not None:
+            raise ValueError("The truth value of an array with more than one element is ambiguous. Use a.any() or a.all()")
+        if self._committed_par is None:
+            raise Exception("The model is not fitted yet!")
+        X1 = self._check_X(np.atleast_2d(X1))
+        R = self.engine.prior_corr(X1)
+        if corr:
+            return R
+        n_t = self.y.shape[1]
+        C_prior = np.array([self.sigma2[i] * R for i in range(n_t)])  # :350-351
+        return np.sqrt((C_prior**2.0).sum(axis=0) / n_t)
+
     def _fused_point_ok(self) -> bool:
         """bogp_point_eval serves the constant trend basis with a single target."""
         return self._trend_args()[0] == _lib.TREND_CONSTANT and self.y.shape[1] == 1

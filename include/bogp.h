@@ -198,6 +198,12 @@ int bogp_gradient(bogp_handle* h, const double* x, double* dmu, double* dmse);
 /* The same for B points at once (Xb: B x d; dmu, dmse: B x d row-major): one pair of triangular solves with B
  * right-hand sides + one reduction kernel.  Feeds multi-start local refinement of the sweep's top-k.      */
 int bogp_gradient_batch(bogp_handle* h, const double* Xb, int B, double* dmu, double* dmse);
+/* Hessian of the posterior mean at x (GaussianProcess.Hessian, gpr.py:578-598), d x d row-major.  Squared exponential
+ * only, like the reference's corr_Hessian (:663-734); constant / linear trend (their Hessians are zero, trend.py:88-116). */
+int bogp_hessian(bogp_handle* h, const double* x, double* H);
+/* Correlation matrix of the rows of X1 (n1 x d) at the committed theta: GaussianProcess.prior_cov(X1, corr=True)
+ * (gpr.py:318-353).  R is n1 x n1 row-major; the covariance flavour is R scaled on the host (:350-351).               */
+int bogp_prior_corr(bogp_handle* h, const double* X1, int n1, double* R);
 /* One point, everything at once: what `criterion(x, return_dx=True)` needs (acquisition_fun.py:139-146, 181-188,
  * 220-227, 292-309 call predict, gradient and the closed form) -- mu, mse, dmu (d), dmse (d) and the q criterion values --
  * with a single host synchronisation.  This is the call the reference's DEFAULT inner optimiser (multi-restart

@@ -555,6 +555,42 @@ def gradient(st: GPState, x: np.ndarray):
 # (the reference's EI/EpsilonPI/MGFI raise on >1 row, so the batched semantics
 # are the per-row map with the guards turned into per-row selects).
 # ----------------------------------------------------------------------------------------------
+def hessian(st: GPState, x: np.ndarray) -> np.ndarray:
+    """Hessian of the posterior mean at one point, (d, d).  gpr.py:578-598 with corr_Hessian :663-734 (squared exponential
+    branch :693-702; the other kernels leave H undefined there) and the zero Hessians of the constant / linear trends
+    (trend.py:88-91, 113-116)."""
+    if st.kernel != KERNEL_SE:
+        raise NotImplementedError("corr_Hessian defines H for the squared exponential only")
+    if st.trend == TREND_QUADRATIC:
+        raise NotImplementedError("quadratic_trend.Hessian raises (trend.py:141-142)")
+    x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+    n, d = st.X.shape
+    r = corr(st.kernel, st.theta, l1_cross_distances(x, st.X)).reshape(1, n)
+    diff = (x - st.X).T  # (d, N)
+    theta = np.broadcast_to(st.theta, (d,)).reshape(-1, 1)
+    diff_ = theta * diff
+    g = -2 * r * diff_
+    H = []
+    for k in range(d):
+        e = np.zeros((d, n))
+        e[k, :] = theta[k]
+        H.append(-2 * (g[k, :] * (theta * diff) + r * e))
+    H = np.atleast_3d(H)  # (d, d, N)
+    return H.dot(st.gamma)[..., 0]
+
+
+def prior_cov(st: GPState, X1: np.ndarray, corr_only: bool = False) -> np.ndarray:
+    """gpr.py:318-353 with X2 = None."""
+    X1 = np.atleast_2d(np.asarray(X1, dtype=np.float64))
+    n1 = X1.shape[0]
+    R = corr(st.kernel, st.theta, l1_cross_distances(X1, X1)).reshape(n1, n1)
+    if corr_only:
+        return R
+    n_t = st.y.shape[1]
+    C = np.array([st.sigma2[i] * R for i in range(n_t)])
+    return np.sqrt((C**2.0).sum(axis=0) / n_t)
+
+
 def _yhat_sd(mu, mse, minimize):
     """acquisition_fun.py:52-64: y_hat negated iff maximising; sd = sqrt(MSE)."""
     y_hat = mu if minimize else -1 * mu

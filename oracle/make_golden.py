@@ -483,6 +483,24 @@ def golden_isotropic():
     save("G18_isotropic_tables", **out)
 
 
+def golden_hessian_prior():
+    """G19: GaussianProcess.Hessian (gpr.py:578-598; squared exponential, the only kernel corr_Hessian defines) and
+    prior_cov (gpr.py:318-353) as the reference returns them, for a simple-kriging and an ordinary-kriging SE model."""
+    out = {}
+    for tag, mean_of, nug in (("sk", lambda d: None, 1e-6), ("ok", lambda d: trend.constant_trend(d), 0)):
+        X, y = make_data(19, 60, 4)
+        d = 4
+        gp = GaussianProcess(mean=mean_of(d), corr="squared_exponential", thetaL=[1e-4] * d, thetaU=[1e2] * d, nugget=nug)
+        par = np.r_[[0.03, 0.05, 0.02, 0.08], 0.9] if nug else np.array([0.03, 0.05, 0.02, 0.08])
+        pin(gp, X, y, par)
+        rng = np.random.default_rng(719)
+        P = rng.uniform(-5, 5, size=(6, d))
+        out.update({tag + "_X": X, tag + "_y": y, tag + "_par": par, tag + "_P": P,
+                    tag + "_H": np.array([gp.Hessian(p) for p in P]),
+                    tag + "_corr": gp.prior_cov(P, corr=True), tag + "_cov": gp.prior_cov(P)})  # fmt: skip
+    save("G19_hessian_prior_cov", **out)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["trends"]:
         golden_trends()
@@ -492,9 +510,12 @@ if __name__ == "__main__":
         golden_multitarget()
     elif sys.argv[1:] == ["isotropic"]:
         golden_isotropic()
+    elif sys.argv[1:] == ["hessian"]:
+        golden_hessian_prior()
     else:
         main()
         golden_trends()
         golden_reml()
         golden_multitarget()
         golden_isotropic()
+        golden_hessian_prior()

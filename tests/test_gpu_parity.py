@@ -1094,3 +1094,29 @@ def test_plain_c_client_gets_the_same_numbers(tmp_path):
     assert int(oidx[0]) == int(idx[0])
     np.testing.assert_allclose(got["best"][0], obest[0], rtol=1e-6)
     e.close()
+
+
+def test_hessian_and_prior_cov_match_the_reference():
+    """GaussianProcess.Hessian / prior_cov on the device against the reference's outputs (G19) through the model class."""
+    g = load_golden("G19_hessian_prior_cov")
+    d = g["sk_X"].shape[1]
+    for tag, kw in (("sk", dict(nugget=1e-6)), ("ok", dict(mean=bogp.trend.constant_trend(d), nugget=0))):
+        gp = bogp.GaussianProcess(corr="squared_exponential", thetaL=[1e-4] * d, thetaU=[1e2] * d, **kw)
+        gp.set_state(g[tag + "_par"], g[tag + "_X"], g[tag + "_y"])
+        for p, H in zip(g[tag + "_P"], g[tag + "_H"]):
+            Hd = gp.Hessian(p)
+            assert Hd.shape == (d, d)
+            np.testing.assert_allclose(Hd, H, rtol=1e-6, atol=1e-9 * np.abs(H).max())
+            np.testing.assert_allclose(Hd, Hd.T, rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(gp.prior_cov(g[tag + "_P"], corr=True), g[tag + "_corr"], rtol=1e-12)
+        np.testing.assert_allclose(gp.prior_cov(g[tag + "_P"]), g[tag + "_cov"], rtol=1e-9)
+    m32 = bogp.GaussianProcess(corr="matern", thetaL=[1e-4] * d, thetaU=[1e2] * d, nugget=1e-6)
+    m32.set_state(np.r_[np.full(d, 0.05), 0.9], g["sk_X"], g["sk_y"])
+    with pytest.raises(NotImplementedError):
+        m32.Hessian(g["sk_P"][0])  # the reference's corr_Hessian defines the squared exponential only
+    # the Hessian is the derivative of `gradient`: central differences of d mu / dx
+    gp = bogp.GaussianProcess(corr="squared_exponential", thetaL=[1e-4] * d, thetaU=[1e2] * d, nugget=1e-6)
+    gp.set_state(g["sk_par"], g["sk_X"], g["sk_y"])
+    x0, hstep = g["sk_P"][0], 1e-5
+    fd = np.array([(gp.gradient(x0 + hstep * e)[0] - gp.gradient(x0 - hstep * e)[0]).ravel() / (2 * hstep) for e in np.eye(d)])
+    np.testing.assert_allclose(gp.Hessian(x0), fd, rtol=1e-5, atol=1e-8)

@@ -364,3 +364,17 @@ def test_isotropic_theta_tables():
                     close(out[1], gr, rtol=1e-8, atol=1e-9)
                     n += 1
     assert n >= 40
+
+
+def test_hessian_and_prior_cov_restatements():
+    """GaussianProcess.Hessian (gpr.py:578-598) and prior_cov (gpr.py:318-353) against the reference's outputs (G19)."""
+    g = load_golden("G19_hessian_prior_cov")
+    for tag, mode, est in (("sk", O.MODE_NOISY, False), ("ok", O.MODE_NOISELESS, True)):
+        st = O.make_state(g[tag + "_par"], g[tag + "_X"], g[tag + "_y"], O.KERNEL_SE, mode, 1e-6 if mode == O.MODE_NOISY else 0.0,
+                          estimate_trend=est, beta=None if est else 0.0)  # fmt: skip
+        for p, H in zip(g[tag + "_P"], g[tag + "_H"]):
+            close(O.hessian(st, p), H, rtol=1e-9, atol=1e-12)
+        close(O.prior_cov(st, g[tag + "_P"], corr_only=True), g[tag + "_corr"], rtol=1e-13, atol=0)
+        close(O.prior_cov(st, g[tag + "_P"]), g[tag + "_cov"], rtol=1e-9, atol=0)
+    with pytest.raises(NotImplementedError):
+        O.hessian(state_from_golden(load_golden("G2_m32_ok_noisy")), np.zeros(2))
