@@ -511,6 +511,12 @@ class GaussianProcess:
         dmu, dmse = self.engine.gradient(x[0])
         return dmu.reshape(-1, 1), dmse.reshape(-1, 1)
 
+    def sampling_prior(self, X):  # stubs in the reference as well (gpr.py:312-316)
+        pass
+
+    def sampling_posterior(self, X):
+        pass
+
     def Hessian(self, x):
         """Hessian of the posterior mean at one row (gpr.py:578-598): (d, d).  As in the reference it exists for the
         squared-exponential kernel (corr_Hessian, :663-734, defines no other) and the constant / linear trends."""
