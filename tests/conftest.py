@@ -12,6 +12,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built library (*.so is git-ignored): build it once, exactly as __graft_entry__.build() does
+    if not os.path.exists(os.path.join(ROOT, "bayesian-optimization_amd", "libbogp.so")):
+        import subprocess
+
+        subprocess.run(["make", "-C", os.path.join(ROOT, "bayesian-optimization_amd", "csrc")], check=True, capture_output=True)
 
 
 def load_golden(name):
