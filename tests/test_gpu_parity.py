@@ -1120,3 +1120,73 @@ def test_hessian_and_prior_cov_match_the_reference():
     x0, hstep = g["sk_P"][0], 1e-5
     fd = np.array([(gp.gradient(x0 + hstep * e)[0] - gp.gradient(x0 - hstep * e)[0]).ravel() / (2 * hstep) for e in np.eye(d)])
     np.testing.assert_allclose(gp.Hessian(x0), fd, rtol=1e-5, atol=1e-8)
+
+
+def test_randomised_configurations_match_the_oracle(eng):
+    """A seeded sweep over the configuration space (kernel x mode x trend basis x estimated / fixed coefficients x
+    minimise / maximise x ragged N, d, M): state, likelihood (+ gradient where the reference defines one), posterior,
+    input gradients and the argmax of all four criteria against the oracle.  Catches interactions the hand-picked
+    cases above do not enumerate."""
+    rng = np.random.default_rng(20260928)
+    n_done = n_grad = n_dx = 0
+    for case in range(36):
+        kernel = int(rng.choice([O.KERNEL_SE, O.KERNEL_MATERN12, O.KERNEL_MATERN32, O.KERNEL_MATERN52, O.KERNEL_ABSEXP]))
+        mode = int(rng.choice([O.MODE_NOISELESS, O.MODE_NOISY, O.MODE_NOISE_ESTIM]))
+        d = int(rng.integers(1, 9))
+        trend = int(rng.choice([O.TREND_CONSTANT, O.TREND_CONSTANT, O.TREND_LINEAR, O.TREND_QUADRATIC if d <= 4 else O.TREND_LINEAR]))
+        p = 1 if trend == 0 else (d + 1 if trend == 1 else (d + 1) * (d + 2) // 2)
+        N = int(rng.integers(max(3, p + 2), 330))
+        M = int(rng.integers(1, 1500))
+        est = bool(rng.integers(0, 2))
+        minimize = bool(rng.integers(0, 2))
+        X = rng.uniform(-5, 5, size=(N, d))
+        y = np.sum(np.sin(X) + 0.1 * X**2, axis=1)
+        y = ((y - y.mean()) / (y.std() + 1e-12) + 0.3 * rng.standard_normal(N)).reshape(-1, 1)
+        theta = (0.06 / d) * rng.uniform(0.5, 2.0, size=d) * (6.0 if mode == O.MODE_NOISELESS else 1.0)
+        par = {O.MODE_NOISELESS: theta, O.MODE_NOISY: np.r_[theta, 0.8], O.MODE_NOISE_ESTIM: np.r_[theta, 0.9]}[mode]
+        nv = 1e-4 if mode == O.MODE_NOISY else 0.0
+        beta = None if est else (0.25 if trend == 0 else rng.uniform(-0.2, 0.2, size=p))
+        tag = "case %d: kernel %d mode %d trend %d est %s N %d d %d M %d" % (case, kernel, mode, trend, est, N, d, M)
+        R0 = O.correlation_matrix(kernel, theta, X)
+        Rn = R0 if mode == O.MODE_NOISELESS else ((0.8 * R0 + nv * np.eye(N)) / (0.8 + nv) if mode == O.MODE_NOISY else 0.9 * R0 + 0.1 * np.eye(N))
+        if np.linalg.cond(Rn) > 1e9:
+            continue  # both factorisations are valid to cond * eps only; conditioning has its own test (tools/stress_cond.py)
+        try:
+            st = O.make_state(par, X, y, kernel, mode, nv, trend=trend, estimate_trend=est, beta=beta)
+        except np.linalg.LinAlgError:
+            continue  # llf > 0 or a singular matrix: the -inf convention is covered elsewhere
+        eng.set_train(X, y)
+        llf = eng.commit(kernel, mode, par, nv, est, 0.0 if beta is None else beta, trend=trend)
+        np.testing.assert_allclose(llf, st.llf, rtol=1e-9, err_msg=tag)
+        Xs = rng.uniform(-5, 5, size=(M, d))
+        eng.upload_candidates(Xs)
+        mu, mse = eng.predict()
+        rmu, rmse = O.predict_chunked(st, Xs, 512)
+        np.testing.assert_allclose(mu, rmu.ravel(), rtol=1e-6, atol=1e-8, err_msg=tag)
+        np.testing.assert_allclose(mse, rmse.ravel(), rtol=1e-6, atol=1e-10 * float(st.sigma2[0]), err_msg=tag)
+        pl = O.plugin_value(y, minimize)
+        acq = [(O.ACQ_EI, 0.0), (O.ACQ_MGFI, 1.5), (O.ACQ_UCB, 0.7), (O.ACQ_EPSILON_PI, 1e-10)]
+        best, idx, vals = eng.sweep(acq, pl, minimize, return_values=True)
+        for c, (a, pa) in enumerate(acq):
+            ov = O.acquisition(a, pa, rmu.ravel(), rmse.ravel(), pl, st.sigma2[0], minimize)
+            oi = O.nan_first_argmax(ov)
+            # the winner may differ only between candidates whose values agree to rounding
+            assert idx[c] == oi or np.isclose(ov[idx[c]], ov[oi], rtol=1e-9, atol=1e-300), tag
+            np.testing.assert_allclose(vals[c], ov, rtol=1e-5, atol=1e-12, err_msg=tag)
+        if kernel in (O.KERNEL_SE, O.KERNEL_MATERN32, O.KERNEL_ABSEXP) and trend == O.TREND_CONSTANT:
+            ollf, ograd = O.log_likelihood_concentrated(par, X, y, kernel, mode, nv, trend, est, beta, eval_grad=True)
+            if np.isfinite(ollf):
+                dl, dg = eng.nll(kernel, mode, par, nv, est, 0.0 if beta is None else beta, eval_grad=True, trend=trend)
+                np.testing.assert_allclose(dl, ollf, rtol=1e-9, err_msg=tag)
+                np.testing.assert_allclose(dg, np.ravel(ograd), rtol=1e-6, atol=1e-7 * np.abs(ograd).max(), err_msg=tag)
+                n_grad += 1
+                eng.commit(kernel, mode, par, nv, est, 0.0 if beta is None else beta, trend=trend)
+        if kernel in (O.KERNEL_SE, O.KERNEL_MATERN32, O.KERNEL_ABSEXP) and trend != O.TREND_QUADRATIC:
+            x0 = Xs[0]
+            odmu, odmse = O.gradient(st, x0)
+            dmu, dmse = eng.gradient(x0)
+            np.testing.assert_allclose(dmu, np.ravel(odmu), rtol=1e-6, atol=1e-9, err_msg=tag)
+            np.testing.assert_allclose(dmse, np.ravel(odmse), rtol=1e-6, atol=1e-9 * float(st.sigma2[0]), err_msg=tag)
+            n_dx += 1
+        n_done += 1
+    assert n_done >= 28 and n_grad >= 8 and n_dx >= 12, (n_done, n_grad, n_dx)
