@@ -107,16 +107,42 @@ def sweep_topk(criteria: Sequence, Xs: np.ndarray, k: int, index_offset: int = 0
     return distributed.exchange_topk(best, gidx, xb, k, group=group)
 
 
+def sweep_topk_generated(criteria: Sequence, bounds, M: int, k: int, seed: int, rank: int = 0, world: int = 1, group=None,
+                         method: str = "uniform"):
+    """`sweep_topk` over M candidates generated on the device (`method` as in `sweep_generated`): rank r draws and sweeps
+    its block of the design; (values (q, k), global rows (q, k), points (q, k, d)) are identical on every rank."""
+    c0 = criteria[0]
+    model = c0.model
+    if getattr(model, "_committed_par", None) is None:
+        raise Exception("The model is not fitted yet!")
+    lo = np.array([b[0] for b in bounds], dtype=float)
+    hi = np.array([b[1] for b in bounds], dtype=float)
+    a, b_ = shard_bounds(int(M), rank, world)
+    eng = model.engine
+    eng.generate_candidates(lo, hi, b_ - a, seed, first_row=a, method=method, n_total=int(M))
+    best, idx = eng.sweep_topk([(c.acq_id, c.acq_par()) for c in criteria], c0.effective_plugin(), c0.minimize, k)
+    flat = np.clip(idx, 0, b_ - a - 1).ravel()
+    xb = np.where((idx >= 0)[..., None], eng.read_candidates(flat).reshape(idx.shape + (len(lo),)), np.nan)
+    gidx = np.where(idx >= 0, idx + a, -1)
+    return distributed.exchange_topk(best, gidx, xb, k, group=group)
+
+
 def batch_argmax(criteria: Sequence, search_space, eval_budget: int, history: Optional[np.ndarray] = None, k: int = 8,
-                 index_offset: int = 0, group=None, Xs: Optional[np.ndarray] = None):
+                 index_offset: int = 0, group=None, Xs: Optional[np.ndarray] = None, design: Optional[str] = None,
+                 seed: Optional[int] = None, rank: int = 0, world: int = 1):
     """The q-point proposal of `ParallelBO._batch_arg_max_acquisition` (bayes_opt.py:100-115) in ONE posterior pass:
     q criteria (same model; they differ only in t / alpha) share (mu, MSE); each takes its best candidate that is
     neither already taken by an earlier criterion nor `np.isclose` to an evaluated point in `history`
     (BO.pre_eval_check, bayes_opt.py:27-55) -- falling back through its top-k instead of the reference's random
-    padding (base.py:282-289).  Returns (xopt: tuple of q lists, fopt: tuple of q floats) like the reference."""
-    if Xs is None:
-        Xs = np.asarray(search_space.sample(int(eval_budget), method="uniform"), dtype=float)
-    vals, gidx, pts = sweep_topk(criteria, Xs, k, index_offset=index_offset, group=group)
+    padding (base.py:282-289).  Returns (xopt: tuple of q lists, fopt: tuple of q floats) like the reference.
+    `design` = "uniform" | "LHS" | "sobol" draws the `eval_budget` candidates on the device (rank r of `world` its block)."""
+    if design is not None:  # "uniform" | "LHS" | "sobol": the candidates are drawn on the GPU(s) and never touch the host
+        seed = int(np.random.randint(0, 2**62)) if seed is None else int(seed)
+        vals, gidx, pts = sweep_topk_generated(criteria, search_space.bounds, int(eval_budget), k, seed, rank, world, group, design)
+    else:
+        if Xs is None:
+            Xs = np.asarray(search_space.sample(int(eval_budget), method="uniform"), dtype=float)
+        vals, gidx, pts = sweep_topk(criteria, Xs, k, index_offset=index_offset, group=group)
     chosen_x, chosen_f, taken = [], [], set()
     hist = None if history is None or len(history) == 0 else np.asarray(history, dtype=float)
     for c in range(len(criteria)):

@@ -1190,3 +1190,35 @@ def test_randomised_configurations_match_the_oracle(eng):
             n_dx += 1
         n_done += 1
     assert n_done >= 28 and n_grad >= 8 and n_dx >= 12, (n_done, n_grad, n_dx)
+
+
+def test_batch_proposal_over_device_generated_designs():
+    """ParallelBO's q-point proposal (bayes_opt.py:100-115) with the candidates drawn on the GPU: same winners as the
+    host-side path on the oracle's restatement of the same design, for every design and for sharded ranks."""
+    from oracle import philox as P
+
+    g = load_golden("G1_se_sk_noisy")
+    d = g["X"].shape[1]
+    gp = bogp.GaussianProcess(corr="squared_exponential", thetaL=[1e-4] * d, thetaU=[1e2] * d, nugget=1e-6)
+    gp.set_state(g["par"], g["X"], g["y"])
+    bounds = [(-5.0, 5.0)] * d
+    box = bogp.optim.Box(bounds)
+    crit = [bogp.MGFI(model=gp, t=t) for t in (0.5, 1.0, 2.0, 4.0)]
+    lo, hi = np.full(d, -5.0), np.full(d, 5.0)
+    M = 20000
+    for design, Xs in (("uniform", P.uniform_box(lo, hi, M, 11)), ("LHS", P.lhs_box(lo, hi, M, 11)),
+                       ("sobol", P.sobol_box(lo, hi, M, _lib.sobol_direction_numbers(d), 1))):  # fmt: skip
+        xs_dev, fs_dev = bogp.batch_argmax(crit, box, M, k=4, design=design, seed=11)
+        xs_host, fs_host = bogp.batch_argmax(crit, box, M, k=4, Xs=Xs)
+        np.testing.assert_array_equal(np.array(xs_dev), np.array(xs_host))
+        np.testing.assert_allclose(fs_dev, fs_host, rtol=1e-12)
+        assert len({tuple(x) for x in xs_dev}) == len(crit)  # q distinct proposals
+    # three "ranks" swept one after the other: merging their top-k by hand gives the single-rank answer
+    whole = bogp.sweep_topk_generated(crit, bounds, M, 4, seed=5, method="LHS")
+    parts = [bogp.sweep_topk_generated(crit, bounds, M, 4, seed=5, rank=r, world=3, method="LHS") for r in range(3)]
+    for c in range(len(crit)):
+        v = np.stack([p[0][c] for p in parts])
+        i = np.stack([p[1][c] for p in parts])
+        mv, mi, _, _ = bogp.distributed.merge_topk(v, i, 4)
+        np.testing.assert_array_equal(mi, whole[1][c])
+        np.testing.assert_array_equal(mv, whole[0][c])
