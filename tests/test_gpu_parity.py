@@ -1222,3 +1222,25 @@ def test_batch_proposal_over_device_generated_designs():
         mv, mi, _, _ = bogp.distributed.merge_topk(v, i, 4)
         np.testing.assert_array_equal(mi, whole[1][c])
         np.testing.assert_array_equal(mv, whole[0][c])
+
+
+def test_unsupported_combinations_are_refused_loudly(eng):
+    """Entry points that serve a subset of the models say so with BOGP_ERR_UNSUPPORTED instead of computing something
+    else: the fused one-point call and the Hessian with a polynomial basis / a non-SE kernel, REML with several targets."""
+    g = load_golden("G13_linear_uk_se")
+    commit_trend_golden(eng, g)
+    x = g["Xs"][0]
+    with pytest.raises(_lib.BogpError) as ei:
+        eng.point_eval(x, [(O.ACQ_EI, 0.0)], 0.0, True)
+    assert ei.value.code == _lib.ERR_UNSUPPORTED
+    assert eng.hessian(x).shape == (len(x), len(x))  # linear trend: its Hessian is zero, the SE part is served
+    g2 = load_golden("G2_m32_ok_noisy")
+    commit_golden(eng, g2)
+    with pytest.raises(_lib.BogpError) as ei:
+        eng.hessian(g2["Xs"][0])
+    assert ei.value.code == _lib.ERR_UNSUPPORTED
+    g17 = load_golden("G17_multitarget")
+    eng.set_train(g17["X"], g17["y"])
+    with pytest.raises(_lib.BogpError) as ei:
+        eng.nll_restricted(0, 1, np.r_[g17["k0_m1_par"][0]], 1e-3, False, 0.0)
+    assert ei.value.code == _lib.ERR_UNSUPPORTED
