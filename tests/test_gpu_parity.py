@@ -1244,3 +1244,16 @@ def test_unsupported_combinations_are_refused_loudly(eng):
     with pytest.raises(_lib.BogpError) as ei:
         eng.nll_restricted(0, 1, np.r_[g17["k0_m1_par"][0]], 1e-3, False, 0.0)
     assert ei.value.code == _lib.ERR_UNSUPPORTED
+
+
+def test_readme_example_runs():
+    """The quick-start block of README.md, executed as written."""
+    import re
+
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "README.md")).read()
+    code = re.search(r"```python\n(import bogp, numpy as np\n.*?)```", text, re.S).group(1)
+    ns = {}
+    exec(compile(code, "README.md", "exec"), ns)
+    assert ns["mu"].shape == (5, 1) and ns["mse"].shape == (5, 1)
+    assert ns["best"].shape == (4,) and ns["x"].shape == (4, 4) and len(ns["xs"]) == 4
+    assert np.ravel(ns["value"]).shape == (1,) and np.asarray(ns["dx"]).size == 4
