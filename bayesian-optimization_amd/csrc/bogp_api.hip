@@ -898,7 +898,7 @@ static hipEvent_t get_event(bogp_handle* h, size_t i) {
 }
 
 static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, const double* acq_par, double plugin,
-                     int minimize, bool want_acq_out) {
+                     int minimize, bool want_acq_out, bool need_var = true) {
   if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "no committed model: call bogp_commit first");
   if (!h->dXs || h->M <= 0) FAIL(h, BOGP_ERR_INVALID, "no candidates: call bogp_candidates_upload/bind first");
   if (q < 0 || q > BOGP_MAX_Q) FAIL(h, BOGP_ERR_INVALID, "q = %d outside [0, %d]", q, BOGP_MAX_Q);
@@ -1036,11 +1036,13 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     HIPCHK(h, hipEventRecord(ev[1], stP));
     if (overlap) HIPCHK(h, hipStreamWaitEvent(st, ev[1], 0));
     HIPCHK(h, hipEventRecord(ev[2], st));
-    HIPCHK(h, launch_contract(ka, st));
+    // predict(X) without eval_MSE (gpr.py:486-491 returns before the triangular solve): the N^2 contraction is skipped
+    // and k_acquisition sums zero variance groups (its MSE output is not read)
+    if (need_var) HIPCHK(h, launch_contract(ka, st));
     HIPCHK(h, hipEventRecord(ev[3], st));
     AcqArgs aa;
     memset(&aa, 0, sizeof(aa));
-    aa.mu_part = h->dmu_part[b]; aa.w_part = h->dw_part[b]; aa.ss_part = h->dss_part; aa.S = S; aa.nJ = nJ; aa.Mc = Mc;
+    aa.mu_part = h->dmu_part[b]; aa.w_part = h->dw_part[b]; aa.ss_part = h->dss_part; aa.S = S; aa.nJ = need_var ? nJ : 0; aa.Mc = Mc;
     aa.mcount = mcount; aa.m0 = m0; aa.beta = h->beta; aa.G = h->G; aa.estimate_trend = h->estimate_trend;
     aa.sigma2 = h->sigma2; aa.mu_out = want_out ? h->dmu_out : nullptr; aa.mse_out = want_out ? h->dmse_out : nullptr;
     aa.q = q;
@@ -1089,7 +1091,7 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
 extern "C" int bogp_predict(bogp_handle* h, double* mu, double* mse) {
   if (!h) return BOGP_ERR_INVALID;
   if (!mu) FAIL(h, BOGP_ERR_INVALID, "bogp_predict: mu must be non-null");
-  int rc = run_sweep(h, true, 0, nullptr, nullptr, 0.0, 1, false);
+  int rc = run_sweep(h, true, 0, nullptr, nullptr, 0.0, 1, false, mse != nullptr);
   if (rc) return rc;
   HIPCHK(h, hipMemcpy(mu, h->dmu_out, (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost));
   if (mse) HIPCHK(h, hipMemcpy(mse, h->dmse_out, (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost));

@@ -169,7 +169,8 @@ int bogp_candidates_read(bogp_handle* h, const int64_t* rows, int n, double* out
 
 /* ---- posterior ------------------------------------------------------------------------------------
  * Replaces GaussianProcess.predict(X, eval_MSE) (gpr.py:486-510) on the current candidates:
- * mu (M) and mse (M, may be NULL) are HOST buffers.                                                     */
+ * mu (M) and mse (M, may be NULL) are HOST buffers.  With mse == NULL the N^2-per-candidate variance contraction is
+ * not run at all (the reference's eval_MSE=False path also returns before its triangular solve, :491).          */
 int bogp_predict(bogp_handle* h, double* mu, double* mse);
 
 /* ---- sweep: posterior + q acquisition criteria + argmax ---------------------------------------------

@@ -1257,3 +1257,35 @@ def test_readme_example_runs():
     assert ns["mu"].shape == (5, 1) and ns["mse"].shape == (5, 1)
     assert ns["best"].shape == (4,) and ns["x"].shape == (4, 4) and len(ns["xs"]) == 4
     assert np.ravel(ns["value"]).shape == (1,) and np.asarray(ns["dx"]).size == 4
+
+
+def test_mean_only_predict_skips_the_contraction_and_returns_the_same_mean(eng):
+    """predict(X) without eval_MSE (gpr.py:486-491 returns before the triangular solve): the same mu bit for bit, no
+    N^2 work -- for the constant and the polynomial trend bases."""
+    import time
+
+    for name, commit in (("big", None), ("G13_linear_uk_se", commit_trend_golden)):
+        rng = np.random.default_rng(1)
+        if commit is None:
+            _, X, y = _problem(3, 1024, 10, noise=0.05)
+            eng.set_train(X, y)
+            eng.commit(O.KERNEL_MATERN52, O.MODE_NOISY, np.r_[np.full(10, 0.03), 0.9], 1e-6, False, 0.0)
+            dd = 10
+        else:
+            g = load_golden(name)
+            commit(eng, g)
+            dd = g["X"].shape[1]
+        Xs = rng.uniform(-5, 5, size=(200_000, dd))
+        eng.upload_candidates(Xs)
+        mu_full, mse = eng.predict()
+        t0 = time.perf_counter()
+        eng.predict()
+        t_full = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        mu_only, none = eng.predict(eval_MSE=False)
+        t_mean = time.perf_counter() - t0
+        assert none is None
+        np.testing.assert_array_equal(mu_only, mu_full)
+        assert eng.last_timing()["contract_ms"] < 0.05  # nothing was launched between the two events
+        if name == "big":
+            assert t_mean < t_full
