@@ -485,14 +485,19 @@ class GaussianProcess:
         eng = self.engine
         eng.upload_candidates(X)
         n_t = self.y.shape[1]
-        if n_t > 1:  # (M, n_targets) like gpr.py:490, 502-505: one posterior pass per column of y, factorisation shared
+        if n_t > 1:  # (M, n_targets) like gpr.py:490, 502-505; the factorisation is shared by the targets
+            # MSE = (1 - sum rt^2 + sum u^2) sigma2_t: when the targets share sigma2 (always in the noisy mode, gpr.py:970) the
+            # variance of target 0 IS the variance of every target, so the others take the mean-only path (no contraction)
+            same_var = bool(np.all(np.asarray(self.sigma2) == np.asarray(self.sigma2).ravel()[0]))
             cols = []
             for t in range(n_t):
                 eng.select_target(t)
-                cols.append(eng.predict(eval_MSE=eval_MSE))
+                cols.append(eng.predict(eval_MSE=eval_MSE and (t == 0 or not same_var)))
             eng.select_target(0)
             mu = np.column_stack([c[0] for c in cols])
-            return (mu, np.column_stack([c[1] for c in cols])) if eval_MSE else mu
+            if not eval_MSE:
+                return mu
+            return mu, np.column_stack([cols[0][1] if c[1] is None else c[1] for c in cols])
         mu, mse = eng.predict(eval_MSE=eval_MSE)
         if eval_MSE:
             return mu.reshape(-1, 1), mse.reshape(-1, 1)
