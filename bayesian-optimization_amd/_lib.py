@@ -190,14 +190,15 @@ class Engine:
         )  # fmt: skip
         return (llf.value, grad) if eval_grad else llf.value
 
-    def nll_restricted(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False):
+    def nll_restricted(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False, trend=TREND_CONSTANT):
         """Restricted (REML) log-likelihood, gpr.py:813-918.  exp(llf) > 1 gives -inf WITH the gradient of the finite
         value, as the reference returns it; a failed factorisation raises NotPositiveDefinite."""
         par = _f64(par).ravel()
         llf = C.c_double()
         grad = np.zeros(len(par)) if eval_grad else None
-        rc = self._lib.bogp_nll_restricted(self._h, kernel, mode, _ptr(par), len(par), float(noise_var), TREND_CONSTANT,
-                                           int(bool(estimate_trend)), float(beta), C.byref(llf), _ptr(grad))  # fmt: skip
+        b = self._trend_beta(trend, estimate_trend, beta)
+        rc = self._lib.bogp_nll_restricted(self._h, kernel, mode, _ptr(par), len(par), float(noise_var), int(trend),
+                                           int(bool(estimate_trend)), b, C.byref(llf), _ptr(grad))  # fmt: skip
         if rc == ERR_LLF_POSITIVE:
             return (-np.inf, grad) if eval_grad else -np.inf
         self._check(rc)

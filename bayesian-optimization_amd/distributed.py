@@ -21,6 +21,12 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
+def rank_world(group=None):
+    """(rank, world size) of the initialised process group, (0, 1) without one."""
+    dist = _dist()
+    return (0, 1) if dist is None else (dist.get_rank(group), dist.get_world_size(group))
+
+
 def reduce_pairs(vals: np.ndarray, idxs: np.ndarray) -> np.ndarray:
     """vals, idxs: (R, q).  Per criterion pick the winning rank with np.argmax semantics over the concatenated
     global array: the maximum value, a NaN (if any) beats every number, ties -> lowest global index."""

@@ -230,8 +230,13 @@ def argmax_restart(
             full = np.empty((len(Xs), len(masks)))
             full[:, ~masks] = Xs
             full[:, masks] = np.asarray(values, dtype=float)
-        best, gidx, _ = sweep_argmax([crit], full, return_points=False)
-        return Xs[int(gidx[0])].tolist(), float(best[0])
+        # Under an initialised process group every rank sweeps ITS OWN draw of `eval_budget` candidates (the union is
+        # world x eval_budget points; global row = rank x eval_budget + local row) and the winner's POINT comes out of the
+        # exchange, so that every rank returns the same (xopt, fopt) whatever its local sample was.
+        rank, world = distributed.rank_world()
+        best, _, xb = sweep_argmax([crit], full, index_offset=rank * len(full), return_points=True)
+        x = np.asarray(xb[0], dtype=float)
+        return (x[~masks] if masks is not None else x).tolist(), float(best[0])
     starts = None
     if optimizer == "sweep-BFGS":
         # hybrid: the sweep picks the n_restart most promising candidates, the reference's L-BFGS-B
@@ -241,7 +246,8 @@ def argmax_restart(
             raise NotImplementedError("optimizer='sweep-BFGS' takes an unconstrained bogp criterion without fixed variables")
         Xs = np.asarray(search_space.sample(int(eval_budget), method="uniform"), dtype=float)
         k = int(max(1, min(n_restart, 32, len(Xs))))
-        tv, _, tx = sweep_topk([crit], Xs, k)
+        rank, world = distributed.rank_world()  # as above: per-rank draws, points travel with the exchange
+        tv, _, tx = sweep_topk([crit], Xs, k, index_offset=rank * len(Xs))
         starts = [tx[0, r] for r in range(k) if np.isfinite(tv[0, r])]
         n_restart, eval_budget, wait_iter = len(starts), 50 * len(starts), len(starts) + 1
         obj_func, optimizer = crit, "BFGS"
@@ -249,6 +255,14 @@ def argmax_restart(
         raise NotImplementedError(
             "optimizer %r is out of scope here (SURVEY.md 2 rows 6-7); use 'BFGS', 'sweep', 'sweep-device[-lhs|-sobol]' or 'sweep-BFGS'" % optimizer
         )
+    if h is not None or g is not None:
+        # the reference wraps the objective in Penalized(obj_func, h, g) and keeps a restart only if the constraints hold
+        # (optim/__init__.py:33-52, 125-140); that wrapper is out of scope, and returning constraint-violating points
+        # silently is worse than refusing
+        raise NotImplementedError("constraints (h, g) are handled by the reference's penalised optimisers, not here")
+    if not (isinstance(search_space, Box) or "RealSpace" in [c.__name__ for c in type(search_space).__mro__]):
+        # optim/__init__.py:71-73 reroutes every other space to MIES, which is out of scope here
+        raise NotImplementedError("optimizer='BFGS' needs a continuous space (RealSpace / Box); the reference reroutes others to MIES")
 
     xopt, fopt = [], []
     best = -np.inf

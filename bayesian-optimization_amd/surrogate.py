@@ -7,8 +7,9 @@ keywords as the reference (`surrogate/gaussian_process/gpr.py:211-228`).  All O(
 the MLE (`gpr.py:1058-1197`) and input validation.  There is no CPU fallback.
 
 Differences from the reference, all deliberate and listed in DESIGN.md:
-  * `optimizer="CMA"`, multi-target y: NotImplementedError (out of scope / "next" rows) instead of running on the CPU.
-    The three polynomial trends (constant / linear / quadratic) are all on the device.
+  * `optimizer="CMA"`: NotImplementedError (out of scope) instead of running on the CPU.  Multi-target y is served for a
+    fixed constant trend (the only case the reference's own `fit` survives).  The three polynomial trends
+    (constant / linear / quadratic) are all on the device.
   * `likelihood="restricted"` (REML, gpr.py:813-918) is evaluated on the device AND `fit` completes with it; the
     reference's own `fit` raises TypeError at gpr.py:405 after the optimisation (sigma2 comes back as a scalar).
   * Matern-5/2 (`corr=functools.partial(matern, nu=2.5)` or `"matern52"`) can be FITTED: the device has its
@@ -224,7 +225,17 @@ class GaussianProcess:
     # ------------------------------------------------------------------------------------------------
     # likelihood (gpr.py:920-1040) -- evaluated on the device
     # ------------------------------------------------------------------------------------------------
-    def log_likelihood_concentrated(self, par, env=None, eval_grad=False):
+    def _restore(self, prev):
+        """Put the device back into the committed state `prev` = (par, restricted) -- or mark the model as holding none."""
+        if prev[0] is None:
+            self._committed_par = None
+        else:
+            self._commit(prev[0], refresh_attributes=False, restricted=prev[1])
+
+    def log_likelihood_concentrated(self, par, env=None, eval_grad=False, _adopt=False):
+        """gpr.py:920-1040.  As in the reference, evaluating the likelihood has no side effect on the fitted model: the
+        committed state is re-established afterwards, also when `env` is filled or the factorisation fails.  Only the
+        MLE's final evaluation (`_adopt=True`, gpr.py:1183-1188) keeps the state it built."""
         par = np.asarray(par, dtype=np.float64).ravel()
         tid, est, beta = self._trend_args()
         mode = self._MODE[self.estimation_mode]
@@ -232,10 +243,13 @@ class GaussianProcess:
             # L-BFGS-B can step to NaN after an infinite objective; the reference's Cholesky then raises
             # ValueError/LinAlgError on the NaN matrix, which it turns into -inf (gpr.py:946-947, 960-961, 978-979)
             return (-np.inf, np.zeros((len(par), 1))) if eval_grad else -np.inf
+        prev = (self._committed_par, getattr(self, "_committed_restricted", False))
+        after = prev
         try:
             if env is not None:
                 llf = self._commit(par, refresh_attributes=False, restricted=False)
                 if llf > 0:  # rejected before env is touched (gpr.py:981-982); bogp_commit itself only builds the state
+                    self._restore(prev)
                     return (-np.inf, np.zeros((len(par), 1))) if eval_grad else -np.inf
                 st = self.engine.get_state()
                 Ft, G, Q, b = self._trend_views(st, est)
@@ -244,16 +258,19 @@ class GaussianProcess:
                     Yt=st["Yt"].reshape(len(self.X), -1), C=st["C"], Ft=Ft, G=G, Q=Q,
                     beta=float(b[0, 0]) if b.size == 1 else b, gamma=st["gamma"].reshape(len(self.X), -1),
                 )  # fmt: skip
+                if _adopt:
+                    after = (np.array(par, dtype=float), False)
                 if not eval_grad:
+                    if not _adopt:
+                        self._restore(prev)
                     return llf
             out = self.engine.nll(self.kernel_id, mode, par, self._nv(), est, beta, eval_grad=eval_grad, trend=tid)
-            if self._committed_par is not None:
-                # nll overwrote the factor buffers of the committed model: restore it, so that (as in the reference)
-                # evaluating the likelihood of a fitted model leaves predict() / gradient() untouched
-                self._commit(self._committed_par, refresh_attributes=False, restricted=getattr(self, "_committed_restricted", False))
+            # nll overwrote the factor buffers: re-establish the state that is to survive this call
+            self._restore(after)
             return out
         except _lib.NotPositiveDefinite:
             # Cholesky failure or llf > 0: the reference's -inf convention (gpr.py:946-947, 981-982)
+            self._restore(prev)
             return (-np.inf, np.zeros((len(par), 1))) if eval_grad else -np.inf
 
     def _split_restricted(self, par):
@@ -263,15 +280,18 @@ class GaussianProcess:
             return par[:-2], float(par[-2]), float(par[-1])
         return par[:-1], float(par[-1]), (self._nv() if self.estimation_mode == "noisy" else 0.0)
 
-    def log_likelihood_restricted(self, par, env=None, eval_grad=False):
+    def log_likelihood_restricted(self, par, env=None, eval_grad=False, _adopt=False):
         """The restricted likelihood of gpr.py:813-918 on the device (same return convention as the concentrated one:
         llf or (llf, d llf / d par), -inf where the reference gives -inf).  `env` receives what the reference puts
         there (:902-911) -- the NOISY-mode factorisation at (theta, sigma2, noise_var), which is also the state `fit`
-        commits for prediction."""
+        commits for prediction (`_adopt=True`: the MLE's final evaluation keeps it; any other call leaves the fitted
+        model as it was)."""
         par = np.asarray(par, dtype=np.float64).ravel()
         tid, est, beta = self._trend_args()
         if not (np.all(np.isfinite(par)) and np.all(par > 0)):
             return (-np.inf, np.zeros((len(par), 1))) if eval_grad else -np.inf
+        prev = (self._committed_par, getattr(self, "_committed_restricted", False))
+        after = prev
         try:
             if env is not None:
                 self._commit(par, refresh_attributes=False, restricted=True)
@@ -279,11 +299,13 @@ class GaussianProcess:
                 Ft, G, Q, b = self._trend_views(st, est)
                 env.update(sigma2=np.atleast_1d(st["sigma2"]), noise_var=st["noise_var"], rho=st["rho"].reshape(-1, 1),
                            Yt=st["Yt"].reshape(-1, 1), C=st["C"], Ft=Ft, G=G, Q=Q, gamma=st["gamma"].reshape(-1, 1))  # fmt: skip
-            out = self.engine.nll_restricted(self.kernel_id, self._MODE[self.estimation_mode], par, self._nv(), est, beta, eval_grad=eval_grad)
-            if self._committed_par is not None:
-                self._commit(self._committed_par, refresh_attributes=False, restricted=getattr(self, "_committed_restricted", False))
+                if _adopt:
+                    after = (np.array(par, dtype=float), True)
+            out = self.engine.nll_restricted(self.kernel_id, self._MODE[self.estimation_mode], par, self._nv(), est, beta, eval_grad=eval_grad, trend=tid)
+            self._restore(after)
             return out
         except _lib.NotPositiveDefinite:
+            self._restore(prev)
             return (-np.inf, np.zeros((len(par), 1))) if eval_grad else -np.inf
 
     def _commit(self, par, refresh_attributes=True, restricted=None) -> float:
@@ -400,8 +422,7 @@ class GaussianProcess:
             else:
                 wait_count += 1
             if self.verbose:
-                print("restart {} takes {} evals".format(iteration + 1, info["funcalls"]))
-                print("best log likekihood value: {}".format(-llf_opt))
+                print("MLE restart %d: %d likelihood evaluations, best llf so far %.10g" % (iteration + 1, info["funcalls"], -llf_opt))
             eval_budget -= info["funcalls"]
             if eval_budget <= 0 or wait_count >= self.wait_iter:
                 break
@@ -410,7 +431,7 @@ class GaussianProcess:
 
         optimal_param = 10.0**param_opt
         env = {}
-        optimal_llf_value = llf_fun(optimal_param, env)  # :1185-1188
+        optimal_llf_value = llf_fun(optimal_param, env, _adopt=True)  # :1185-1188; keeps the state it builds
         param, i = {}, 0
         for name, len_ in zip(par_list, par_len):
             param[name] = optimal_param[i : i + len_]
@@ -422,6 +443,7 @@ class GaussianProcess:
         self._check_data(X, y)
         n_retry = 0
         while True:
+            self._committed_par = None  # nothing of an earlier (or rejected) state survives into this optimisation
             self.par, self.log_likelihood_, env, optimal_param = self._optimize_hyperparameter()
             if np.isinf(self.log_likelihood_):
                 print("Invalid likelihood value. Increasing nugget...")  # gpr.py:384-399

@@ -34,8 +34,8 @@ class OracleEngine:
             raise _lib.NotPositiveDefinite(_lib.ERR_NOT_POSDEF, "oracle: -inf")
         return (out[0], np.asarray(out[1], float).ravel()) if eval_grad else out
 
-    def nll_restricted(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False):
-        out = O.log_likelihood_restricted(par, self.X, self.y, kernel, mode, noise_var, 0, estimate_trend, beta, eval_grad=eval_grad)
+    def nll_restricted(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False, trend=0):
+        out = O.log_likelihood_restricted(par, self.X, self.y, kernel, mode, noise_var, trend, estimate_trend, beta, eval_grad=eval_grad)
         return (out[0], np.asarray(out[1], float).ravel()) if eval_grad else out
 
     def commit(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, trend=0):

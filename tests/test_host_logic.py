@@ -217,3 +217,82 @@ def test_input_validation_follows_the_reference_checks():
     with pytest.raises(ValueError):
         gp.predict(np.array([[0.0, np.inf, 0.0]]))
     assert gp.predict(np.zeros(d)).shape == (1, 1)  # one row given as a vector
+
+
+def _smooth_problem(n=40, d=2, seed=2):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1, 1, size=(n, d))
+    y = np.sum(X**2, axis=1)
+    return X, ((y - y.mean()) / y.std()).reshape(-1, 1)
+
+
+def test_nugget_retry_switches_noiseless_to_noisy_with_a_clean_state():
+    """gpr.py:384-399: a noiseless model whose likelihood is rejected (llf > 0 on smooth data, :981-982) is refitted in
+    the noisy mode with nugget 1e-5.  The rejected final evaluation must not leave a committed parameter vector of the
+    OLD layout behind ([theta] vs [theta, sigma2]): that once crashed the retry."""
+    from support.oracle_engine import OracleEngine
+
+    X, y = _smooth_problem()
+    gp = bogp.GaussianProcess(corr="squared_exponential", thetaL=[1e-2] * 2, thetaU=[1.0] * 2, nugget=0, random_start=2,
+                              eval_budget=60)  # fmt: skip
+    gp._engine = OracleEngine()
+    assert gp.estimation_mode == "noiseless"
+    np.random.seed(0)
+    gp.fit(X, y)
+    assert gp.is_fitted and gp.estimation_mode == "noisy" and float(np.ravel(gp.noise_var)[0]) >= 1e-5
+    assert len(gp._committed_par) == 3  # [theta, sigma2]: the layout of the mode the fit ended in
+    mu, mse = gp.predict(X[:3], eval_MSE=True)
+    assert mu.shape == (3, 1) and np.all(np.isfinite(mu)) and np.all(mse >= 0)
+
+
+def test_likelihood_calls_leave_the_fitted_model_alone():
+    """The reference's likelihood has no side effect on the fitted model; here the device state is re-established after
+    every evaluation, also when `env` is filled, when the value is rejected and when the factorisation fails."""
+    from support.oracle_engine import OracleEngine
+
+    rng = np.random.default_rng(1)
+    X = rng.uniform(-5, 5, size=(25, 2))
+    y = (np.sum(X**2, axis=1) + rng.standard_normal(25)).reshape(-1, 1)
+    y = (y - y.mean()) / y.std()
+    gp = bogp.GaussianProcess(corr="matern", thetaL=[1e-2] * 2, thetaU=[1e2] * 2, nugget=1e-6, random_start=2, eval_budget=60)
+    gp._engine = OracleEngine()
+    np.random.seed(3)
+    gp.fit(X, y)
+    par0, mu0 = gp._committed_par.copy(), gp.predict(X[:5])
+    other = par0 * np.array([3.0, 0.3, 1.0])
+    env = {}
+    llf = gp.log_likelihood_concentrated(other, env)
+    assert np.isfinite(llf) and "C" in env and not np.allclose(env["C"], gp.C)
+    np.testing.assert_array_equal(gp._committed_par, par0)
+    np.testing.assert_array_equal(gp.predict(X[:5]), mu0)
+    gp.log_likelihood_concentrated(other, {}, eval_grad=True)
+    gp.log_likelihood_concentrated(other, eval_grad=True)
+    assert gp.log_likelihood_concentrated(np.r_[par0[:2], np.nan]) == -np.inf
+    np.testing.assert_array_equal(gp._committed_par, par0)
+    np.testing.assert_array_equal(gp.predict(X[:5]), mu0)
+    # an unfitted model stays unfitted after an env call
+    gp2 = bogp.GaussianProcess(corr="matern", thetaL=[1e-2] * 2, thetaU=[1e2] * 2, nugget=1e-6)
+    gp2._engine = OracleEngine()
+    gp2._check_data(X, y)
+    gp2.log_likelihood_concentrated(other, {})
+    assert gp2._committed_par is None
+
+
+def test_bfgs_path_refuses_what_it_does_not_implement():
+    """optim/__init__.py:71-73, 125-140: constraints go through `Penalized` + a feasibility filter and non-continuous
+    spaces through MIES in the reference; both are out of scope and must not be silently ignored."""
+    box = optim.Box([(-1, 1)] * 2, random_seed=0)
+    crit = lambda x: (0.0, np.zeros(2))  # noqa: E731
+    with pytest.raises(NotImplementedError, match="constraints"):
+        optim.argmax_restart(crit, box, h=lambda x: [0.0], optimizer="BFGS")
+    with pytest.raises(NotImplementedError, match="constraints"):
+        optim.argmax_restart(crit, box, g=lambda x: [0.0], optimizer="BFGS")
+
+    class Lattice:  # anything that is not a RealSpace / Box
+        bounds = [(0, 3)] * 2
+
+        def sample(self, N=1, method="uniform"):
+            return np.zeros((N, 2))
+
+    with pytest.raises(NotImplementedError, match="continuous"):
+        optim.argmax_restart(crit, Lattice(), optimizer="BFGS")
