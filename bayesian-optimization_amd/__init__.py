@@ -6,6 +6,7 @@ The directory is named `bayesian-optimization_amd/`; import it as `bogp` (bogp/_
   bogp.acquisition.{EI,PI,EpsilonPI,UCB,MGFI} <-> bayes_optim.acquisition.acquisition_fun.*
   bogp.optim.argmax_restart      <-> bayes_optim.acquisition.optim.argmax_restart (+ optimizer="sweep")
   bogp.trend                     <-> bayes_optim.surrogate.trend
+  bogp.install(bayes_optim)      re-points the reference's three extension points + ParallelBO's q-criterion loop
   bogp._lib.Engine               ctypes binding of libbogp.so (include/bogp.h)
 
 Every numerical step runs on the GPU through libbogp.so; importing works anywhere, but creating an engine without
@@ -13,8 +14,9 @@ a gfx950 device (or without the built library) raises -- there is no CPU fallbac
 """
 __version__ = "0.1.0"
 
-from . import _lib, acquisition, distributed, optim  # noqa: E402,F401
+from . import _lib, acquisition, distributed, integration, optim  # noqa: E402,F401
 from . import prior_mean as trend  # noqa: E402,F401
 from .acquisition import EI, MGFI, PI, UCB, EpsilonPI  # noqa: E402,F401
 from .optim import argmax_restart, batch_argmax, sweep_argmax, sweep_generated, sweep_topk, sweep_topk_generated  # noqa: E402,F401
+from .integration import install, uninstall  # noqa: E402,F401
 from .surrogate import GaussianProcess  # noqa: E402,F401

@@ -19,6 +19,7 @@ ACQ_EI, ACQ_EPSILON_PI, ACQ_UCB, ACQ_MGFI = 0, 1, 2, 3
 TREND_CONSTANT, TREND_LINEAR, TREND_QUADRATIC = 0, 1, 2
 MAX_Q = 64
 MAX_TARGETS = 8
+COMM_ID_BYTES = 128
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -53,6 +54,15 @@ SIGNATURES = {
     "bogp_hessian": (C.c_int, [C.c_void_p, _dp, _dp]),
     "bogp_prior_corr": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp]),
     "bogp_point_eval": (C.c_int, [C.c_void_p, _dp, C.c_int, _ip, _dp, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "bogp_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "bogp_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    "bogp_comm_attach": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bogp_comm_info": (C.c_int, [C.c_void_p, _ip, _ip]),
+    "bogp_comm_destroy": (C.c_int, [C.c_void_p]),
+    "bogp_exchange_argmax": (C.c_int, [C.c_void_p, C.c_int64, _dp, _lp, _dp]),
+    "bogp_exchange_topk": (C.c_int, [C.c_void_p, C.c_int64, _dp, _lp, _dp]),
+    "bogp_reduce_pairs": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _lp, _dp]),
+    "bogp_merge_topk": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _lp, _dp]),
     "bogp_last_timing": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip]),
     "bogp_flops_per_candidate": (C.c_double, [C.c_void_p]),
 }
@@ -108,6 +118,41 @@ def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(_dp)
 
 
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through libbogp (call on ONE rank, distribute the 128 bytes to the others)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load().bogp_comm_unique_id(buf)
+    if rc != OK:
+        raise BogpError(rc, "bogp_comm_unique_id failed (librccl missing?)")
+    return buf.raw
+
+
+def reduce_pairs_c(gathered: np.ndarray):
+    """bogp_reduce_pairs on host records (R, q, 2 + d): (values (q,), global indices (q,), points (q, d) or None)."""
+    g = _f64(gathered)
+    R, q, rec = g.shape
+    d = rec - 2
+    val, idx = np.empty(q), np.empty(q, dtype=np.int64)
+    x = np.empty((q, d)) if d else None
+    rc = load().bogp_reduce_pairs(R, q, d, _ptr(g), _ptr(val), idx.ctypes.data_as(_lp), _ptr(x))
+    if rc != OK:
+        raise BogpError(rc, "bogp_reduce_pairs: invalid arguments")
+    return val, idx, x
+
+
+def merge_topk_c(gathered: np.ndarray):
+    """bogp_merge_topk on host records (R, q, k, 2 + d): (values (q, k), global indices (q, k), points (q, k, d) or None)."""
+    g = _f64(gathered)
+    R, q, k, rec = g.shape
+    d = rec - 2
+    val, idx = np.empty((q, k)), np.empty((q, k), dtype=np.int64)
+    x = np.empty((q, k, d)) if d else None
+    rc = load().bogp_merge_topk(R, q, k, d, _ptr(g), _ptr(val), idx.ctypes.data_as(_lp), _ptr(x))
+    if rc != OK:
+        raise BogpError(rc, "bogp_merge_topk: invalid arguments")
+    return val, idx, x
+
+
 def trend_size_of(trend: int, d: int) -> int:
     """Columns of the trend basis (bogp_trend_size; needs no device)."""
     return 1 if trend == TREND_CONSTANT else (d + 1 if trend == TREND_LINEAR else (d + 1) * (d + 2) // 2)
@@ -136,6 +181,7 @@ class Engine:
         self.N = self.d = 0
         self.trend, self.estimate_trend = TREND_CONSTANT, False
         self.M = 0
+        self.comm_rank, self.comm_world = 0, 0  # world > 0 once a communicator is set (comm_init / comm_attach)
         self._keep = None  # keeps bound device memory owners alive
 
     def close(self):
@@ -391,6 +437,43 @@ class Engine:
         dmu, dmse = np.empty((B, self.d)), np.empty((B, self.d))
         self._check(self._lib.bogp_gradient_batch(self._h, _ptr(Xb), B, _ptr(dmu), _ptr(dmse)))
         return dmu, dmse
+
+    # -- multi-GPU exchange (bogp_comm.hip; one process per GPU) ---------------------------------------------
+    def comm_init(self, comm_id: bytes, rank: int, world: int):
+        """RCCL communicator over `world` handles (one per process / GPU); `comm_id` = comm_unique_id() of ONE rank."""
+        if len(comm_id) != COMM_ID_BYTES:
+            raise ValueError("comm_id must be %d bytes" % COMM_ID_BYTES)
+        self._check(self._lib.bogp_comm_init(self._h, comm_id, int(rank), int(world)))
+        self.comm_rank, self.comm_world = int(rank), int(world)
+
+    def comm_attach(self, nccl_comm_ptr: int):
+        self._check(self._lib.bogp_comm_attach(self._h, C.c_void_p(int(nccl_comm_ptr))))
+        self.comm_rank, self.comm_world = self.comm_info()
+
+    def comm_info(self) -> Tuple[int, int]:
+        """(rank, world); world == 0 when the handle has no communicator."""
+        r, w = C.c_int(), C.c_int()
+        self._check(self._lib.bogp_comm_info(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def comm_destroy(self):
+        self._check(self._lib.bogp_comm_destroy(self._h))
+        self.comm_rank, self.comm_world = 0, 0
+
+    def exchange_argmax(self, q: int, index_offset: int = 0, with_points: bool = True):
+        """After sweep(): the global winners over all ranks' shards, identical on every rank:
+        (best_val (q,), best_global_idx (q,), best_x (q, d) or None).  ONE ncclAllGather on device records."""
+        best, gidx = np.empty(q), np.empty(q, dtype=np.int64)
+        x = np.empty((q, self.d)) if with_points else None
+        self._check(self._lib.bogp_exchange_argmax(self._h, int(index_offset), _ptr(best), gidx.ctypes.data_as(_lp), _ptr(x)))
+        return best, gidx, x
+
+    def exchange_topk(self, q: int, k: int, index_offset: int = 0, with_points: bool = True):
+        """After sweep_topk(): (values (q, k), global indices (q, k), points (q, k, d) or None), identical on every rank."""
+        best, gidx = np.empty((q, k)), np.empty((q, k), dtype=np.int64)
+        x = np.empty((q, k, self.d)) if with_points else None
+        self._check(self._lib.bogp_exchange_topk(self._h, int(index_offset), _ptr(best), gidx.ctypes.data_as(_lp), _ptr(x)))
+        return best, gidx, x
 
     def last_timing(self) -> dict:
         a, b, c = C.c_double(), C.c_double(), C.c_double()

@@ -13,126 +13,14 @@
 #include <vector>
 
 #include "../../include/bogp.h"
+#include "bogp_handle.h"
 #include "bogp_internal.h"
 
 using namespace bogp;
 
 static std::string g_create_error;
 
-struct bogp_handle {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;  // producer stream: k_corr_chunk of chunk c+1 runs beside k_contract of chunk c
-  rocblas_handle blas = nullptr;
-  std::string err;
-
-  // training set
-  int N = 0, d = 0, Np = 0;
-  int ldr = 0;  // leading dimension of dR / dV / dRinv: N rounded up to 64 (identity padding, kernels_chol.hip)
-  double *dX = nullptr, *dy = nullptr;
-  // multi-target y (gpr.py:463,490,502-505): the factorisation is shared, the vectors exist once per target.  dy / dyt /
-  // drho / dgamma above and `sigma2` below always point at the ACTIVE target (bogp_select_target) inside these slabs.
-  int n_t = 1, target = 0;
-  double *dy_base = nullptr, *dyt_base = nullptr, *drho_base = nullptr, *dgamma_base = nullptr;
-  std::vector<double> sigma2_t, nv_t;  // committed, per target
-
-  // factorisation workspace (column-major, ld = ldr)
-  double *dR = nullptr, *dV = nullptr, *dU = nullptr, *dT = nullptr, *dRinv = nullptr;  // L, L^-1, L^-T, scratch, R^-1
-  double* dones = nullptr;  // N ones (the constant trend basis)
-  double* dgemv_scratch = nullptr;  // segment partials of launch_gemv2
-  std::vector<double> h_theta, h_sqrt_theta;
-  double* ddinv = nullptr;  // ldr x 64: inverses of the diagonal blocks of the running factorisation (kernels_chol.hip)
-  double *dyt = nullptr, *dft = nullptr, *drho = nullptr, *dtmp = nullptr;  // N each
-  double *dgamma = nullptr, *dw = nullptr;                                  // Np each (zero padded)
-  double *dtheta = nullptr, *dsqrt_theta = nullptr;                         // d each
-  double* dscal = nullptr;                                                  // small scalar scratch
-  rocblas_int* dinfo = nullptr;
-  double* dgrad_partial = nullptr;
-  size_t grad_partial_cap = 0;
-  double* dbatch = nullptr;
-  size_t batch_cap = 0;
-
-  // committed state
-  bool committed = false;
-  int kernel = 0, mode = 0, estimate_trend = 0;
-  double beta = 0, G = 0, sigma2 = 0, noise_var = 0, llf = 0, ftft = 0;
-  double* dXthT = nullptr;  // [d][Np]
-  double2* dVp = nullptr;   // [Np/16][Np/8][64]
-
-  // candidates
-  const double* dXs = nullptr;
-  double* dXs_owned = nullptr;
-  size_t xs_cap = 0;
-  double* dbounds = nullptr;
-  size_t bounds_cap = 0;
-  double* dsobol = nullptr;  // d x bits direction numbers (uint64 bit patterns)
-  size_t sobol_cap = 0;
-  int64_t M = 0;
-
-  // sweep scratch
-  double *drT[2] = {nullptr, nullptr}, *dmu_part[2] = {nullptr, nullptr}, *dw_part[2] = {nullptr, nullptr};
-  double* dss_part = nullptr;
-  size_t rT_cap[2] = {0, 0}, mu_part_cap[2] = {0, 0}, w_part_cap[2] = {0, 0}, ss_part_cap = 0;
-  double *dblk_val = nullptr, *dmu_out = nullptr, *dmse_out = nullptr, *dacq_out = nullptr, *dbest_val = nullptr;
-  int64_t *dblk_idx = nullptr, *dbest_idx = nullptr;
-  size_t blk_val_cap = 0, blk_idx_cap = 0, mu_out_cap = 0, mse_out_cap = 0, acq_out_cap = 0;
-
-  // polynomial trend bases with p > 1 columns (linear / quadratic; the constant basis keeps its scalar fast path)
-  int trend = BOGP_TREND_CONSTANT, p = 1;  // committed
-  int tr_built = -1, tr_p = 0, ldp = 0;    // basis currently held in dF / sizes of the buffers below
-  std::vector<double> h_beta_fixed;        // bogp_set_trend_beta: simple-kriging coefficients
-  std::vector<double> h_betav, h_Sinv;     // committed beta (p) and (Ft^T Ft)^-1 (p x p, column-major) for bogp_gradient
-  double *dF = nullptr, *dFt = nullptr, *dQ1 = nullptr, *dQ = nullptr;  // N x p, column-major, ld = N
-  double* dWp = nullptr;                                                // Np x p: L^-T Ft, zero-padded rows
-  double *dA[2] = {nullptr, nullptr}, *dAV[2] = {nullptr, nullptr}, *dAU[2] = {nullptr, nullptr};  // ldp x ldp (CholeskyQR2)
-  double *dAw = nullptr, *dAT = nullptr;                                // ldp x 64, ldp x ldp scratch
-  double *dGinv = nullptr, *dSinv = nullptr, *dbetav = nullptr, *dqty = nullptr;  // p x p, p x p, p, p
-  rocblas_int* dinfo2 = nullptr;
-  double *dTt = nullptr, *dCS = nullptr, *duu = nullptr, *dmtrend = nullptr;  // per sweep chunk: Mc x p, Mc x p, Mc, Mc
-  size_t Tt_cap = 0, CS_cap = 0, uu_cap = 0, mtrend_cap = 0;
-
-  // timing of the last sweep/predict
-  std::vector<hipEvent_t> ev;
-  double t_corr_ms = 0, t_contract_ms = 0, t_acq_ms = 0;
-  int n_chunks = 0;
-};
-
-#define FAIL(h, code, ...)                              \
-  do {                                                  \
-    char _b[512];                                       \
-    snprintf(_b, sizeof(_b), __VA_ARGS__);              \
-    (h)->err = _b;                                      \
-    return (code);                                      \
-  } while (0)
-#define HIPCHK(h, expr)                                                                                  \
-  do {                                                                                                   \
-    hipError_t _e = (expr);                                                                              \
-    if (_e != hipSuccess) FAIL(h, BOGP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-  } while (0)
-#define BLASCHK(h, expr)                                                                          \
-  do {                                                                                            \
-    rocblas_status _s = (expr);                                                                   \
-    if (_s != rocblas_status_success)                                                             \
-      FAIL(h, BOGP_ERR_HIP, "%s failed: rocblas_status %d (%s:%d)", #expr, (int)_s, __FILE__, __LINE__); \
-  } while (0)
-
-template <typename T>
-static int ensure(bogp_handle* h, T** p, size_t* cap, size_t n) {
-  if (*cap >= n && *p) return BOGP_OK;
-  if (*p) HIPCHK(h, hipFree(*p));
-  *p = nullptr;
-  *cap = 0;
-  HIPCHK(h, hipMalloc((void**)p, n * sizeof(T)));
-  *cap = n;
-  return BOGP_OK;
-}
-template <typename T>
-static void dfree(T*& p) {
-  if (p) (void)hipFree(p);
-  p = nullptr;
-}
-
-extern "C" int bogp_abi_version(void) { return 2; }
+extern "C" int bogp_abi_version(void) { return 3; }
 
 extern "C" const char* bogp_last_error(const bogp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -190,18 +78,20 @@ static void free_train(bogp_handle* h) {
   dfree(h->dtheta); dfree(h->dsqrt_theta); dfree(h->dXthT); dfree(h->dVp);
   free_trend(h);
   h->committed = false;
+  h->cap_ld = h->cap_d = h->cap_nt = 0;
 }
 
 extern "C" void bogp_destroy(bogp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  comm_release(h);
   free_train(h);
   (void)hipStreamSynchronize(h->stream2);
   dfree(h->dXs_owned); dfree(h->dss_part); dfree(h->dbounds); dfree(h->dsobol);
   for (int b = 0; b < 2; ++b) { dfree(h->drT[b]); dfree(h->dmu_part[b]); dfree(h->dw_part[b]); }
   dfree(h->dblk_val); dfree(h->dblk_idx); dfree(h->dmu_out); dfree(h->dmse_out); dfree(h->dacq_out);
-  dfree(h->dbest_val); dfree(h->dbest_idx); dfree(h->dinfo); dfree(h->dscal); dfree(h->dgrad_partial); dfree(h->dbatch);
+  dfree(h->dbest_val); dfree(h->dbest_idx); dfree(h->dtopk_val); dfree(h->dtopk_idx); dfree(h->dinfo); dfree(h->dscal); dfree(h->dgrad_partial); dfree(h->dbatch);
   dfree(h->dTt); dfree(h->dCS); dfree(h->duu); dfree(h->dmtrend);
   for (auto e : h->ev) (void)hipEventDestroy(e);
   if (h->blas) rocblas_destroy_handle(h->blas);
@@ -227,41 +117,53 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
   if (d > BOGP_MAX_DIM) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_set_train: d = %d > %d: the sweep producer keeps a 64 x d candidate tile in the CU's 160 KB of LDS", d, BOGP_MAX_DIM);
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  free_train(h);
+  const int ld_need = ((N + 63) / 64) * 64;
+  const bool fits = h->dX && ld_need <= h->cap_ld && d <= h->cap_d && n_targets <= h->cap_nt;
+  if (fits) {
+    free_trend(h);  // N x p buffers of a polynomial basis: rebuilt on demand
+    h->committed = false;
+  } else {
+    free_train(h);
+    // grow in steps of 256 rows once the set is larger than a block, so that a BO loop reallocates every 256 tell()s
+    h->cap_ld = ld_need <= 256 ? ld_need : ((ld_need + 255) / 256) * 256;
+    h->cap_d = d;
+    h->cap_nt = n_targets;
+    const size_t cl = (size_t)h->cap_ld, NNc = cl * cl, ntc = (size_t)n_targets;
+    HIPCHK(h, hipMalloc((void**)&h->dX, cl * d * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dy_base, ntc * cl * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dR, NNc * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->ddinv, cl * 64 * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dV, NNc * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dU, NNc * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dT, NNc * sizeof(double)));
+    {
+      std::vector<double> ones(cl, 1.0);
+      HIPCHK(h, hipMalloc((void**)&h->dones, cl * sizeof(double)));
+      HIPCHK(h, hipMalloc((void**)&h->dgemv_scratch, gemv2_scratch_doubles((int)cl) * sizeof(double)));
+      HIPCHK(h, hipMemcpy(h->dones, ones.data(), cl * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIPCHK(h, hipMalloc((void**)&h->dyt_base, ntc * cl * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dft, cl * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->drho_base, ntc * cl * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dtmp, cl * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dgamma_base, ntc * cl * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dw, cl * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dtheta, d * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dsqrt_theta, d * sizeof(double)));
+  }
   h->N = N;
   h->d = d;
   h->n_t = n_targets;
   h->target = 0;
   h->Np = ((N + 31) / 32) * 32;
-  h->ldr = ((N + 63) / 64) * 64;
+  h->ldr = ld_need;
   const size_t NN = (size_t)h->ldr * h->ldr;
-  HIPCHK(h, hipMalloc((void**)&h->dX, (size_t)N * d * sizeof(double)));
   const size_t nt = (size_t)n_targets;
-  HIPCHK(h, hipMalloc((void**)&h->dy_base, nt * N * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&h->dR, NN * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&h->ddinv, (size_t)h->ldr * 64 * sizeof(double)));
   HIPCHK(h, launch_pad_identity(h->dR, N, h->ldr, h->stream));
   // V = L^-1 and U = V^T keep exact zeros in their other triangle (set once here; kernels_chol.hip never writes there)
-  HIPCHK(h, hipMalloc((void**)&h->dV, NN * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&h->dU, NN * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&h->dT, NN * sizeof(double)));
   HIPCHK(h, hipMemsetAsync(h->dV, 0, NN * sizeof(double), h->stream));
   HIPCHK(h, hipMemsetAsync(h->dU, 0, NN * sizeof(double), h->stream));
-  {
-    std::vector<double> ones(N, 1.0);
-    HIPCHK(h, hipMalloc((void**)&h->dones, N * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->dgemv_scratch, gemv2_scratch_doubles(N) * sizeof(double)));
-    HIPCHK(h, hipMemcpy(h->dones, ones.data(), N * sizeof(double), hipMemcpyHostToDevice));
-  }
-  HIPCHK(h, hipMalloc((void**)&h->dyt_base, nt * N * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&h->dft, N * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&h->drho_base, nt * N * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&h->dtmp, N * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&h->dgamma_base, nt * h->Np * sizeof(double)));
   select_target(h, 0);
-  HIPCHK(h, hipMalloc((void**)&h->dw, h->Np * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&h->dtheta, d * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&h->dsqrt_theta, d * sizeof(double)));
   HIPCHK(h, hipMemcpyAsync(h->dX, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
   std::vector<double> ycols(nt * N);  // y arrives (N, n_targets) row-major; one contiguous column per target here
   for (int i = 0; i < N; ++i)
@@ -544,7 +446,7 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
   hipStream_t st = h->stream;
   // R^-1 = cho_solve(L, I) (:997) via potri on a copy of L
   const int ldr = h->ldr;
-  if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * ldr * ldr * sizeof(double)));
+  if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * h->cap_ld * h->cap_ld * sizeof(double)));
   HIPCHK(h, launch_uut(h->dU, h->dRinv, ldr, st));  // R^-1 = L^-T L^-1, lower triangle
   const int nblk = grad_contract_blocks(N);
   int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)nblk * (d + 1) + (d + 4));
@@ -627,7 +529,7 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
   if (grad) {
     if (n_theta != d) FAIL(h, BOGP_ERR_UNSUPPORTED, "gradient with isotropic theta (len %d, d = %d) is not built", n_theta, d);
     hipStream_t st = h->stream;
-    if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * ldr * ldr * sizeof(double)));
+    if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * h->cap_ld * h->cap_ld * sizeof(double)));
     HIPCHK(h, launch_uut(h->dU, h->dRinv, ldr, st));
     const double* qv = nullptr;
     double c2 = 0.0;
@@ -676,7 +578,7 @@ extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* p
   hipStream_t st = h->stream;
   // V = L^-1 (the triangular solve of gpr.py:494 becomes a triangular GEMM against V)
   const int ldr = h->ldr;
-  if (!h->dVp) HIPCHK(h, hipMalloc((void**)&h->dVp, (size_t)Np * Np * sizeof(double)));
+  if (!h->dVp) HIPCHK(h, hipMalloc((void**)&h->dVp, (size_t)h->cap_ld * h->cap_ld * sizeof(double)));
   HIPCHK(h, launch_pack_V(h->dV, N, ldr, Np, h->dVp, st));
   // w = L^-T Ft  (so that Ft^T L^-1 r = w . r, gpr.py:496-498)
   HIPCHK(h, hipMemsetAsync(h->dw, 0, Np * sizeof(double), st));
@@ -695,7 +597,7 @@ extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* p
       HIPCHK(h, hipMemcpyAsync(h->h_Sinv.data(), h->dSinv, (size_t)ptrend * ptrend * sizeof(double), hipMemcpyDeviceToHost, st));
     }
   }
-  if (!h->dXthT) HIPCHK(h, hipMalloc((void**)&h->dXthT, (size_t)d * Np * sizeof(double)));
+  if (!h->dXthT) HIPCHK(h, hipMalloc((void**)&h->dXthT, (size_t)h->cap_d * h->cap_ld * sizeof(double)));
   HIPCHK(h, launch_scale_transpose(h->dX, N, d, Np, h->dsqrt_theta, h->dXthT, st));
   HIPCHK(h, hipStreamSynchronize(st));
   h->kernel = kernel; h->mode = mode; h->estimate_trend = estimate_trend;
@@ -716,7 +618,7 @@ extern "C" int bogp_get_state(bogp_handle* h, double* C, double* gamma, double* 
   hipStream_t st = h->stream;
   HIPCHK(h, hipSetDevice(h->device));
   if (C) {
-    if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * h->ldr * h->ldr * sizeof(double)));
+    if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * h->cap_ld * h->cap_ld * sizeof(double)));
     HIPCHK(h, launch_copy_lower(h->dR, N, h->ldr, h->dRinv, st));
     HIPCHK(h, hipMemcpyAsync(C, h->dRinv, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, st));
   }
@@ -1108,8 +1010,10 @@ extern "C" int bogp_sweep(bogp_handle* h, int q, const int* acq_id, const double
     if (acq_id[i] != BOGP_ACQ_EI && (!acq_par || !(acq_par[i] > 0 || (zero_ok && acq_par[i] == 0))))
       FAIL(h, BOGP_ERR_INVALID, "acquisition parameter %d must be > 0 (the reference asserts alpha/epsilon/t > 0)", i);
   }
+  h->last_q = 0;
   int rc = run_sweep(h, false, q, acq_id, acq_par, plugin, minimize, acq_out != nullptr);
   if (rc) return rc;
+  h->last_q = q;  // dbest_val / dbest_idx hold this sweep's winners for bogp_exchange_argmax
   HIPCHK(h, hipMemcpy(best_val, h->dbest_val, q * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemcpy(best_idx, h->dbest_idx, q * sizeof(int64_t), hipMemcpyDeviceToHost));
   if (acq_out) HIPCHK(h, hipMemcpy(acq_out, h->dacq_out, (size_t)q * h->M * sizeof(double), hipMemcpyDeviceToHost));
@@ -1127,28 +1031,30 @@ extern "C" int bogp_sweep_topk(bogp_handle* h, int q, const int* acq_id, const d
     if (acq_id[i] != BOGP_ACQ_EI && (!acq_par || !(acq_par[i] > 0 || (zero_ok && acq_par[i] == 0))))
       FAIL(h, BOGP_ERR_INVALID, "acquisition parameter %d must be > 0", i);
   }
+  h->last_topk_q = h->last_topk_k = 0;
   int rc = run_sweep(h, false, q, acq_id, acq_par, plugin, minimize, true);  // keeps the q x M values on the device
   if (rc) return rc;
+  // rank 0 is the sweep's own argmax; ranks 1..k-1 repeat the argmax with the winners so far masked out -- all q criteria
+  // per launch, the winners kept on the device: 2 k queued launches and ONE read-back of q x k (value, index) pairs
   const int64_t M = h->M;
   const int64_t nblk = (M + 255) / 256;
   hipStream_t st = h->stream;
-  // rank 0 is the sweep's own argmax; ranks 1..k-1 repeat the argmax with the winners so far masked out
-  std::vector<int64_t> taken(k);
-  for (int c = 0; c < q; ++c) {
-    for (int r = 0; r < k; ++r) {
-      if ((int64_t)r >= M) {  // fewer candidates than k: pad with (-inf, -1)
-        best_val[c * k + r] = -INFINITY;
-        best_idx[c * k + r] = -1;
-        continue;
-      }
-      HIPCHK(h, launch_block_argmax_excl(h->dacq_out + (size_t)c * M, M, taken.data(), r, h->dblk_val, h->dblk_idx, st));
-      HIPCHK(h, launch_argmax_final(h->dblk_val, h->dblk_idx, nblk, nblk, 1, h->dbest_val, h->dbest_idx, st));
-      HIPCHK(h, hipMemcpyAsync(&best_val[c * k + r], h->dbest_val, sizeof(double), hipMemcpyDeviceToHost, st));
-      HIPCHK(h, hipMemcpyAsync(&best_idx[c * k + r], h->dbest_idx, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-      HIPCHK(h, hipStreamSynchronize(st));
-      taken[r] = best_idx[c * k + r];
+  int e;
+  if ((e = ensure(h, &h->dblk_val, &h->blk_val_cap, (size_t)q * (nblk + 1)))) return e;
+  if ((e = ensure(h, &h->dblk_idx, &h->blk_idx_cap, (size_t)q * (nblk + 1)))) return e;
+  if ((e = ensure(h, &h->dtopk_val, &h->topk_val_cap, (size_t)BOGP_MAX_Q * BOGP_MAX_TOPK))) return e;
+  if ((e = ensure(h, &h->dtopk_idx, &h->topk_idx_cap, (size_t)BOGP_MAX_Q * BOGP_MAX_TOPK))) return e;
+  HIPCHK(h, launch_topk(h->dacq_out, M, q, k, h->dblk_val, h->dblk_idx, h->dtopk_val, h->dtopk_idx, st));
+  HIPCHK(h, hipMemcpyAsync(best_val, h->dtopk_val, (size_t)q * k * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(best_idx, h->dtopk_idx, (size_t)q * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  h->last_topk_q = q;
+  h->last_topk_k = k;
+  for (int i = 0; i < q * k; ++i)
+    if (best_idx[i] == INT64_MAX) {  // fewer candidates than k: pad with (-inf, -1)
+      best_val[i] = -INFINITY;
+      best_idx[i] = -1;
     }
-  }
   return BOGP_OK;
 }
 

@@ -1,0 +1,145 @@
+// bogp_handle.h -- the device state behind an opaque bogp_handle (include/bogp.h) and the error plumbing shared by the
+// translation units that implement the C ABI (bogp_api.hip, bogp_comm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/bogp.h"
+#include "bogp_internal.h"
+
+struct bogp_handle;
+namespace bogp {
+void comm_release(bogp_handle* h);  // bogp_comm.hip: destroys an owned communicator, frees the exchange buffers
+}
+
+struct bogp_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // producer stream: k_corr_chunk of chunk c+1 runs beside k_contract of chunk c
+  rocblas_handle blas = nullptr;
+  std::string err;
+
+  // training set.  The buffers are sized for cap_ld rows / cap_d columns / cap_nt targets and re-used by every
+  // bogp_set_train that fits (a BO loop grows N by one point per tell(): no free / malloc of the N x N buffers per iteration)
+  int cap_ld = 0, cap_d = 0, cap_nt = 0;
+  int N = 0, d = 0, Np = 0;
+  int ldr = 0;  // leading dimension of dR / dV / dRinv: N rounded up to 64 (identity padding, kernels_chol.hip)
+  double *dX = nullptr, *dy = nullptr;
+  // multi-target y (gpr.py:463,490,502-505): the factorisation is shared, the vectors exist once per target.  dy / dyt /
+  // drho / dgamma above and `sigma2` below always point at the ACTIVE target (bogp_select_target) inside these slabs.
+  int n_t = 1, target = 0;
+  double *dy_base = nullptr, *dyt_base = nullptr, *drho_base = nullptr, *dgamma_base = nullptr;
+  std::vector<double> sigma2_t, nv_t;  // committed, per target
+
+  // factorisation workspace (column-major, ld = ldr)
+  double *dR = nullptr, *dV = nullptr, *dU = nullptr, *dT = nullptr, *dRinv = nullptr;  // L, L^-1, L^-T, scratch, R^-1
+  double* dones = nullptr;  // N ones (the constant trend basis)
+  double* dgemv_scratch = nullptr;  // segment partials of launch_gemv2
+  std::vector<double> h_theta, h_sqrt_theta;
+  double* ddinv = nullptr;  // ldr x 64: inverses of the diagonal blocks of the running factorisation (kernels_chol.hip)
+  double *dyt = nullptr, *dft = nullptr, *drho = nullptr, *dtmp = nullptr;  // N each
+  double *dgamma = nullptr, *dw = nullptr;                                  // Np each (zero padded)
+  double *dtheta = nullptr, *dsqrt_theta = nullptr;                         // d each
+  double* dscal = nullptr;                                                  // small scalar scratch
+  rocblas_int* dinfo = nullptr;
+  double* dgrad_partial = nullptr;
+  size_t grad_partial_cap = 0;
+  double* dbatch = nullptr;
+  size_t batch_cap = 0;
+
+  // committed state
+  bool committed = false;
+  int kernel = 0, mode = 0, estimate_trend = 0;
+  double beta = 0, G = 0, sigma2 = 0, noise_var = 0, llf = 0, ftft = 0;
+  double* dXthT = nullptr;  // [d][Np]
+  double2* dVp = nullptr;   // [Np/16][Np/8][64]
+
+  // candidates
+  const double* dXs = nullptr;
+  double* dXs_owned = nullptr;
+  size_t xs_cap = 0;
+  double* dbounds = nullptr;
+  size_t bounds_cap = 0;
+  double* dsobol = nullptr;  // d x bits direction numbers (uint64 bit patterns)
+  size_t sobol_cap = 0;
+  int64_t M = 0;
+
+  // sweep scratch
+  double *drT[2] = {nullptr, nullptr}, *dmu_part[2] = {nullptr, nullptr}, *dw_part[2] = {nullptr, nullptr};
+  double* dss_part = nullptr;
+  size_t rT_cap[2] = {0, 0}, mu_part_cap[2] = {0, 0}, w_part_cap[2] = {0, 0}, ss_part_cap = 0;
+  double *dblk_val = nullptr, *dmu_out = nullptr, *dmse_out = nullptr, *dacq_out = nullptr, *dbest_val = nullptr;
+  int64_t *dblk_idx = nullptr, *dbest_idx = nullptr;
+  double* dtopk_val = nullptr;   // [q][k] winners of bogp_sweep_topk (device-resident between its passes)
+  int64_t* dtopk_idx = nullptr;
+  size_t topk_val_cap = 0, topk_idx_cap = 0;
+  size_t blk_val_cap = 0, blk_idx_cap = 0, mu_out_cap = 0, mse_out_cap = 0, acq_out_cap = 0;
+
+  // polynomial trend bases with p > 1 columns (linear / quadratic; the constant basis keeps its scalar fast path)
+  int trend = BOGP_TREND_CONSTANT, p = 1;  // committed
+  int tr_built = -1, tr_p = 0, ldp = 0;    // basis currently held in dF / sizes of the buffers below
+  std::vector<double> h_beta_fixed;        // bogp_set_trend_beta: simple-kriging coefficients
+  std::vector<double> h_betav, h_Sinv;     // committed beta (p) and (Ft^T Ft)^-1 (p x p, column-major) for bogp_gradient
+  double *dF = nullptr, *dFt = nullptr, *dQ1 = nullptr, *dQ = nullptr;  // N x p, column-major, ld = N
+  double* dWp = nullptr;                                                // Np x p: L^-T Ft, zero-padded rows
+  double *dA[2] = {nullptr, nullptr}, *dAV[2] = {nullptr, nullptr}, *dAU[2] = {nullptr, nullptr};  // ldp x ldp (CholeskyQR2)
+  double *dAw = nullptr, *dAT = nullptr;                                // ldp x 64, ldp x ldp scratch
+  double *dGinv = nullptr, *dSinv = nullptr, *dbetav = nullptr, *dqty = nullptr;  // p x p, p x p, p, p
+  rocblas_int* dinfo2 = nullptr;
+  double *dTt = nullptr, *dCS = nullptr, *duu = nullptr, *dmtrend = nullptr;  // per sweep chunk: Mc x p, Mc x p, Mc, Mc
+  size_t Tt_cap = 0, CS_cap = 0, uu_cap = 0, mtrend_cap = 0;
+
+  // cross-rank exchange (bogp_comm.hip): RCCL communicator (owned or borrowed), send / receive records on the device, and
+  // what the last sweep left in dbest_* / dtopk_* for bogp_exchange_* to pack
+  void* comm = nullptr;
+  bool comm_owned = false;
+  int comm_rank = 0, comm_world = 0;
+  double *dxchg_send = nullptr, *dxchg_recv = nullptr;
+  size_t xchg_send_cap = 0, xchg_recv_cap = 0;
+  int last_q = 0, last_topk_q = 0, last_topk_k = 0;
+
+  // timing of the last sweep/predict
+  std::vector<hipEvent_t> ev;
+  double t_corr_ms = 0, t_contract_ms = 0, t_acq_ms = 0;
+  int n_chunks = 0;
+};
+
+#define FAIL(h, code, ...)                              \
+  do {                                                  \
+    char _b[512];                                       \
+    snprintf(_b, sizeof(_b), __VA_ARGS__);              \
+    (h)->err = _b;                                      \
+    return (code);                                      \
+  } while (0)
+#define HIPCHK(h, expr)                                                                                  \
+  do {                                                                                                   \
+    hipError_t _e = (expr);                                                                              \
+    if (_e != hipSuccess) FAIL(h, BOGP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define BLASCHK(h, expr)                                                                          \
+  do {                                                                                            \
+    rocblas_status _s = (expr);                                                                   \
+    if (_s != rocblas_status_success)                                                             \
+      FAIL(h, BOGP_ERR_HIP, "%s failed: rocblas_status %d (%s:%d)", #expr, (int)_s, __FILE__, __LINE__); \
+  } while (0)
+
+template <typename T>
+static inline int ensure(bogp_handle* h, T** p, size_t* cap, size_t n) {
+  if (*cap >= n && *p) return BOGP_OK;
+  if (*p) HIPCHK(h, hipFree(*p));
+  *p = nullptr;
+  *cap = 0;
+  HIPCHK(h, hipMalloc((void**)p, n * sizeof(T)));
+  *cap = n;
+  return BOGP_OK;
+}
+template <typename T>
+static inline void dfree(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+

@@ -72,8 +72,8 @@ hipError_t launch_acquisition(const AcqArgs& a, hipStream_t st);
 hipError_t launch_argmax_final(const double* blk_val, const int64_t* blk_idx, int64_t nblk, int64_t stride, int q,
                                double* out_val, int64_t* out_idx, hipStream_t st);
 
-hipError_t launch_block_argmax_excl(const double* vals, int64_t M, const int64_t* excl, int nexcl, double* blk_val,
-                                    int64_t* blk_idx, hipStream_t st);
+hipError_t launch_topk(const double* vals, int64_t M, int q, int k, double* blk_val, int64_t* blk_idx, double* out_val,
+                       int64_t* out_idx, hipStream_t st);
 
 hipError_t launch_generate_uniform(double* Xs, int64_t n_elem, int d, const double* lo, const double* hi, uint64_t seed,
                                    uint64_t first_elem, hipStream_t st);

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void k_acquisition(AcqArgs a) {
 
 // one workgroup per criterion: reduce the per-block partials (deterministic, index tie-break)
 __global__ __launch_bounds__(256) void k_argmax_final(const double* blk_val, const int64_t* blk_idx, int64_t nblk,
-                                                      int64_t stride, double* out_val, int64_t* out_idx) {
+                                                      int64_t stride, double* out_val, int64_t* out_idx, int out_stride,
+                                                      int out_off) {
   __shared__ double sv[4];
   __shared__ int64_t si[4];
   const int c = blockIdx.x;
@@ -143,28 +144,29 @@ __global__ __launch_bounds__(256) void k_argmax_final(const double* blk_val, con
         v = sv[k];
         idx = si[k];
       }
-    out_val[c] = v;
-    out_idx[c] = idx;
+    out_val[(size_t)c * out_stride + out_off] = v;
+    out_idx[(size_t)c * out_stride + out_off] = idx;
   }
 }
 
-// top-k support: per-block argmax over stored acquisition values of criterion c, skipping indices already taken
-struct ExclArgs {
-  int n;
-  int64_t idx[BOGP_MAX_TOPK];
-};
-__global__ __launch_bounds__(256) void k_block_argmax_excl(const double* __restrict__ vals, int64_t M, ExclArgs ex,
-                                                           double* __restrict__ blk_val, int64_t* __restrict__ blk_idx) {
+// top-k support: rank r of all q criteria in one launch (grid = blocks x q): per-block argmax over the stored criterion
+// values, skipping the r winners so far, which are read from DEVICE memory (taken[c][0..r)) -- so the k ranks are k queued
+// launch pairs with no host round trip between them.
+__global__ __launch_bounds__(256) void k_block_argmax_excl(const double* __restrict__ vals, int64_t M,
+                                                           const int64_t* __restrict__ taken, int kstride, int r,
+                                                           double* __restrict__ blk_val, int64_t* __restrict__ blk_idx,
+                                                           int64_t nblk) {
   __shared__ double sv[4];
   __shared__ int64_t si[4];
+  const int c = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   double v = -INFINITY;
   int64_t idx = INT64_MAX;
   if (i < M) {
-    bool taken = false;
-    for (int e = 0; e < ex.n; ++e) taken |= (ex.idx[e] == i);
-    if (!taken) {
-      v = vals[i];
+    bool tk = false;
+    for (int e = 0; e < r; ++e) tk |= (taken[(size_t)c * kstride + e] == i);
+    if (!tk) {
+      v = vals[(size_t)c * M + i];
       idx = i;
     }
   }
@@ -189,17 +191,20 @@ __global__ __launch_bounds__(256) void k_block_argmax_excl(const double* __restr
         v = sv[k];
         idx = si[k];
       }
-    blk_val[blockIdx.x] = v;
-    blk_idx[blockIdx.x] = idx;
+    blk_val[(size_t)c * nblk + blockIdx.x] = v;
+    blk_idx[(size_t)c * nblk + blockIdx.x] = idx;
   }
 }
 
-hipError_t launch_block_argmax_excl(const double* vals, int64_t M, const int64_t* excl, int nexcl, double* blk_val,
-                                    int64_t* blk_idx, hipStream_t st) {
-  ExclArgs ex;
-  ex.n = nexcl;
-  for (int e = 0; e < nexcl; ++e) ex.idx[e] = excl[e];
-  hipLaunchKernelGGL(k_block_argmax_excl, dim3((unsigned)((M + 255) / 256)), 256, 0, st, vals, M, ex, blk_val, blk_idx);
+// k best candidates of q criteria from their stored values vals[q][M]: out_val / out_idx are [q][k] on the device
+// (a rank beyond the number of candidates comes back as (-inf, INT64_MAX)).  2 k launches, nothing read back here.
+hipError_t launch_topk(const double* vals, int64_t M, int q, int k, double* blk_val, int64_t* blk_idx, double* out_val,
+                       int64_t* out_idx, hipStream_t st) {
+  const int64_t nblk = (M + 255) / 256;
+  for (int r = 0; r < k; ++r) {
+    hipLaunchKernelGGL(k_block_argmax_excl, dim3((unsigned)nblk, q), 256, 0, st, vals, M, out_idx, k, r, blk_val, blk_idx, nblk);
+    hipLaunchKernelGGL(k_argmax_final, dim3(q), 256, 0, st, blk_val, blk_idx, nblk, nblk, out_val, out_idx, k, r);
+  }
   return hipGetLastError();
 }
 
@@ -361,7 +366,7 @@ hipError_t launch_acquisition(const AcqArgs& a, hipStream_t st) {
 
 hipError_t launch_argmax_final(const double* blk_val, const int64_t* blk_idx, int64_t nblk, int64_t stride, int q,
                                double* out_val, int64_t* out_idx, hipStream_t st) {
-  hipLaunchKernelGGL(k_argmax_final, dim3(q), 256, 0, st, blk_val, blk_idx, nblk, stride, out_val, out_idx);
+  hipLaunchKernelGGL(k_argmax_final, dim3(q), 256, 0, st, blk_val, blk_idx, nblk, stride, out_val, out_idx, 1, 0);
   return hipGetLastError();
 }
 

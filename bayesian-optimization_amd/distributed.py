@@ -2,8 +2,17 @@
 
 RCCL has no MAXLOC and an (f64, i64) pair does not pack into one max-reducible 64-bit key, hence gather-then-reduce
 (SURVEY.md section 8e).  Over xGMI this is latency-bound (q * 16 B per rank); it is issued once per `ask()`, never
-per tile.  Works on any initialised `torch.distributed` backend: "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests.
-Without an initialised process group it is the identity (single GPU).
+per tile.
+
+Two transports, one rule:
+  * the library's own (`init_engine_comm` -> `bogp_comm_init`; `Engine.exchange_argmax / exchange_topk`): the winners are
+    packed on the device from the sweep's result buffers and gathered with ONE ncclAllGather (RCCL over xGMI), no host
+    bounce; a plain-C client of include/bogp.h shards the same way.  `optim.sweep_*` use it whenever the model's engine
+    has a communicator;
+  * `exchange_argmax / exchange_topk` below on host arrays through any initialised `torch.distributed` backend ("gloo"
+    in the CPU tests, where no device exists).  Without a process group they are the identity (single GPU).
+Both apply np.argmax over the concatenation of the shards: largest value, a NaN beats every number, ties -> lowest
+global index (`reduce_pairs` here, `bogp_reduce_pairs` in the library; checked against each other in tests/test_abi.py).
 """
 from __future__ import annotations
 
@@ -25,6 +34,26 @@ def rank_world(group=None):
     """(rank, world size) of the initialised process group, (0, 1) without one."""
     dist = _dist()
     return (0, 1) if dist is None else (dist.get_rank(group), dist.get_world_size(group))
+
+
+def init_engine_comm(engine, group=None):
+    """Give `engine` (one per process / GPU) the library's RCCL communicator spanning the ranks of the initialised
+    torch.distributed group: rank 0 creates the ncclUniqueId, the 128 bytes travel through the process group (any
+    backend), every rank joins with `bogp_comm_init`.  Without a process group: a one-rank communicator (the exchange
+    then still runs -- a device-side all-gather of one shard).  Returns (rank, world)."""
+    from . import _lib
+
+    if getattr(engine, "comm_world", 0):
+        return engine.comm_rank, engine.comm_world
+    dist = _dist()
+    if dist is None:
+        engine.comm_init(_lib.comm_unique_id(), 0, 1)
+        return 0, 1
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [_lib.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    engine.comm_init(box[0], rank, world)
+    return rank, world
 
 
 def reduce_pairs(vals: np.ndarray, idxs: np.ndarray) -> np.ndarray:

@@ -66,6 +66,8 @@ def sweep_argmax(criteria: Sequence, Xs: np.ndarray, index_offset: int = 0, grou
     eng.upload_candidates(Xs)
     acq = [(c.acq_id, c.acq_par()) for c in criteria]
     best, idx = eng.sweep(acq, c0.effective_plugin(), c0.minimize)
+    if getattr(eng, "comm_world", 0):  # the library's own exchange: device records, ONE ncclAllGather, no host bounce
+        return eng.exchange_argmax(len(acq), int(index_offset), return_points)
     gidx = idx + int(index_offset)
     xbest = Xs[idx] if return_points else None
     return distributed.exchange_argmax(best, gidx, xbest, group=group)
@@ -88,6 +90,8 @@ def sweep_generated(criteria: Sequence, bounds, M: int, seed: int, rank: int = 0
     eng = model.engine
     eng.generate_candidates(lo, hi, b_ - a, seed, first_row=a, method=method, n_total=int(M))
     best, idx = eng.sweep([(c.acq_id, c.acq_par()) for c in criteria], c0.effective_plugin(), c0.minimize)
+    if getattr(eng, "comm_world", 0):
+        return eng.exchange_argmax(len(criteria), a, True)
     return distributed.exchange_argmax(best, idx + a, eng.read_candidates(idx), group=group)
 
 
@@ -102,6 +106,8 @@ def sweep_topk(criteria: Sequence, Xs: np.ndarray, k: int, index_offset: int = 0
     eng = model.engine
     eng.upload_candidates(Xs)
     best, idx = eng.sweep_topk([(c.acq_id, c.acq_par()) for c in criteria], c0.effective_plugin(), c0.minimize, k)
+    if getattr(eng, "comm_world", 0):
+        return eng.exchange_topk(len(criteria), k, int(index_offset), True)
     xb = np.where((idx >= 0)[..., None], Xs[np.clip(idx, 0, len(Xs) - 1)], np.nan)
     gidx = np.where(idx >= 0, idx + int(index_offset), -1)
     return distributed.exchange_topk(best, gidx, xb, k, group=group)
@@ -121,6 +127,8 @@ def sweep_topk_generated(criteria: Sequence, bounds, M: int, k: int, seed: int, 
     eng = model.engine
     eng.generate_candidates(lo, hi, b_ - a, seed, first_row=a, method=method, n_total=int(M))
     best, idx = eng.sweep_topk([(c.acq_id, c.acq_par()) for c in criteria], c0.effective_plugin(), c0.minimize, k)
+    if getattr(eng, "comm_world", 0):
+        return eng.exchange_topk(len(criteria), k, a, True)
     flat = np.clip(idx, 0, b_ - a - 1).ravel()
     xb = np.where((idx >= 0)[..., None], eng.read_candidates(flat).reshape(idx.shape + (len(lo),)), np.nan)
     gidx = np.where(idx >= 0, idx + a, -1)
@@ -128,21 +136,35 @@ def sweep_topk_generated(criteria: Sequence, bounds, M: int, k: int, seed: int, 
 
 
 def batch_argmax(criteria: Sequence, search_space, eval_budget: int, history: Optional[np.ndarray] = None, k: int = 8,
-                 index_offset: int = 0, group=None, Xs: Optional[np.ndarray] = None, design: Optional[str] = None,
-                 seed: Optional[int] = None, rank: int = 0, world: int = 1):
+                 index_offset: Optional[int] = None, group=None, Xs: Optional[np.ndarray] = None, design: Optional[str] = None,
+                 seed: Optional[int] = None, rank: Optional[int] = None, world: Optional[int] = None, masks=None, values=None):
     """The q-point proposal of `ParallelBO._batch_arg_max_acquisition` (bayes_opt.py:100-115) in ONE posterior pass:
     q criteria (same model; they differ only in t / alpha) share (mu, MSE); each takes its best candidate that is
     neither already taken by an earlier criterion nor `np.isclose` to an evaluated point in `history`
     (BO.pre_eval_check, bayes_opt.py:27-55) -- falling back through its top-k instead of the reference's random
     padding (base.py:282-289).  Returns (xopt: tuple of q lists, fopt: tuple of q floats) like the reference.
-    `design` = "uniform" | "LHS" | "sobol" draws the `eval_budget` candidates on the device (rank r of `world` its block)."""
+    `design` = "uniform" | "LHS" | "sobol" draws the `eval_budget` candidates on the device (rank r of `world` its block
+    of ONE design); otherwise every rank sweeps its own host sample (`search_space.sample`, or `Xs`) and the union of the
+    world x eval_budget points competes.  `masks` / `values` (ask(fixed=...), utils.py:184-213): `search_space` spans the
+    free variables only, the fixed columns are filled in for the model, `history` holds full points, and the returned
+    points hold the free variables (the caller's `fillin_fixed_value` completes them, base.py:476)."""
+    if rank is None or world is None:
+        rank, world = distributed.rank_world(group)
     if design is not None:  # "uniform" | "LHS" | "sobol": the candidates are drawn on the GPU(s) and never touch the host
+        if masks is not None:
+            raise NotImplementedError("device-generated designs take no fixed variables")
         seed = int(np.random.randint(0, 2**62)) if seed is None else int(seed)
         vals, gidx, pts = sweep_topk_generated(criteria, search_space.bounds, int(eval_budget), k, seed, rank, world, group, design)
     else:
         if Xs is None:
             Xs = np.asarray(search_space.sample(int(eval_budget), method="uniform"), dtype=float)
-        vals, gidx, pts = sweep_topk(criteria, Xs, k, index_offset=index_offset, group=group)
+        full = np.asarray(Xs, dtype=float)
+        if masks is not None:
+            full = np.empty((len(Xs), len(masks)))
+            full[:, ~masks] = Xs
+            full[:, masks] = np.asarray(values, dtype=float)
+        off = rank * len(full) if index_offset is None else int(index_offset)
+        vals, gidx, pts = sweep_topk(criteria, full, k, index_offset=off, group=group)
     chosen_x, chosen_f, taken = [], [], set()
     hist = None if history is None or len(history) == 0 else np.asarray(history, dtype=float)
     for c in range(len(criteria)):
@@ -158,7 +180,8 @@ def batch_argmax(criteria: Sequence, search_space, eval_budget: int, history: Op
         if pick is None:  # every fall-back exhausted: keep the argmax (the caller's duplicate check will pad)
             pick = 0
         taken.add(int(gidx[c, pick]))
-        chosen_x.append(pts[c, pick].tolist())
+        x = np.asarray(pts[c, pick], dtype=float)
+        chosen_x.append((x[~masks] if masks is not None else x).tolist())
         chosen_f.append(float(vals[c, pick]))
     return tuple(chosen_x), tuple(chosen_f)
 

@@ -5,7 +5,9 @@
 
 A "step" is one pass of the hot path over one batch of synthetic candidates already resident in HBM: posterior
 (mu, MSE) of M candidates per GPU + q = 2 criteria (MGFI t=2, EI) + argmax, then the one cross-rank exchange of the
-per-shard winners.  Workload = BASELINE.json configs[2] ("C3", the configuration the metric is quoted on):
+per-shard winners -- `bogp_exchange_argmax`: the winners are packed on the device and gathered with ONE ncclAllGather
+on the library's own RCCL communicator; it runs at N = 1 too (a one-rank communicator), so the timed step always
+contains the collective.  `--scaling strong` keeps the TOTAL candidate count fixed (ragged contiguous shards).  Workload = BASELINE.json configs[2] ("C3", the configuration the metric is quoted on):
 N = 2048 training points, d = 20, Matern-5/2, M = 1e6 candidates per GPU (weak scaling: configs[3] is 8 x 1e6).
 Hyper-parameters are pinned (theta = 0.01, sigma2 = 0.9, nugget 1e-6, simple kriging), not fitted, as SURVEY.md
 section 8d prescribes; X ~ U[-5,5], y = sum x^2 standardised; seeds fixed.
@@ -38,18 +40,35 @@ WORKLOADS = {
 }
 
 
+PMC_FILE = os.path.join("profiles", "c3_pmc.json")
+
+
+def kernel_source_hash():
+    """sha256 of the translation unit that holds the dominant kernel: a committed PMC figure is only quoted for the
+    source it was measured on."""
+    import hashlib
+
+    with open(os.path.join(ROOT, "bayesian-optimization_amd", "csrc", "kernels_posterior.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def measured_traffic(workload, n_per_launch):
-    """HBM bytes per k_contract launch from the committed PMC passes (profiles/r01_c3_pmc.json: FETCH_SIZE x2 gfx950
-    correction + WRITE_SIZE).  rocprofv3 counters cannot be collected from inside this process, so the figure is the
-    last committed measurement of the same workload / chunk size, or None."""
+    """HBM bytes per launch of the dominant kernel.  rocprofv3 counters cannot be collected from inside this process, so
+    this is a COMMITTED figure: the last PMC passes (tools/pmc_sweep.py -> profiles/c3_pmc.json: FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, separate --pmc runs), quoted only when workload, chunk size AND the kernel source hash
+    recorded with it match the running code; otherwise (None, reason) -- never a stale number."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_c3_pmc.json")) as f:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
             p = json.load(f)
-        if workload == "C3" and int(p["candidates_per_launch"]) == int(n_per_launch) and not os.environ.get("BOGP_CHUNK_MB"):
-            return float(p["traffic_bytes_per_launch"])
     except Exception:
-        pass
-    return None
+        return None, "no committed PMC file (%s)" % PMC_FILE
+    if workload != p.get("workload", "C3") or os.environ.get("BOGP_CHUNK_MB"):
+        return None, "committed PMC passes are for %s at the default chunk size" % p.get("workload", "C3")
+    if int(p["candidates_per_launch"]) != int(n_per_launch):
+        return None, "committed PMC passes used %s candidates per launch" % p["candidates_per_launch"]
+    if p.get("kernel_source_sha256") != kernel_source_hash():
+        return None, "kernel source changed since the committed PMC passes (%s, commit %s)" % (PMC_FILE, p.get("commit", "?"))
+    return float(p["traffic_bytes_per_launch"]), "committed PMC passes of commit %s (%s); not collected in this run" % (p.get("commit", "?"), PMC_FILE)
 
 
 def main():
@@ -60,6 +79,8 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample", type=int, default=49152, help="candidates timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: M candidates per GPU (default); strong: the workload's total (C3 1e6, C4 8e6, C5 4e6) split over the ranks")
     args = ap.parse_args()
 
     import torch
@@ -81,6 +102,13 @@ def main():
 
     w = WORKLOADS[args.workload]
     N, d, M = w["N"], w["d"], w["M"]
+    offset = rank * M
+    if args.scaling == "strong":  # fixed total, contiguous ragged shards (optim.shard_bounds)
+        from bogp.optim import shard_bounds
+
+        total_strong = {"C2": 100_000, "C3": 1_000_000, "C4": 8_000_000, "C5": 4_000_000}[args.workload]
+        a_, b_ = shard_bounds(total_strong, rank, world)
+        M, offset = b_ - a_, a_
     rng = np.random.default_rng(0)  # the model is replicated: every rank builds and factorises the same one
     X = rng.uniform(-5, 5, size=(N, d))
     y = np.sum(X**2, axis=1)
@@ -113,11 +141,13 @@ def main():
     Xs = (torch.rand((M, d), dtype=torch.float64, device="cuda", generator=g) * 10.0 - 5.0).contiguous()
     torch.cuda.synchronize()
     eng.bind_candidates(Xs.data_ptr(), M, owner=Xs)
-    offset = rank * M
+    # the library's own RCCL communicator over the ranks (a one-rank communicator at N = 1: the collective still runs)
+    distributed.init_engine_comm(eng)
+    q = len(w["acq"])
 
     def step():
-        best, idx = eng.sweep(w["acq"], plugin, True)
-        return distributed.exchange_argmax(best, idx + offset, None)
+        eng.sweep(w["acq"], plugin, True)
+        return eng.exchange_argmax(q, offset, True)  # (values, GLOBAL indices, points), identical on every rank
 
     def fence():
         if use_dist:
@@ -142,8 +172,8 @@ def main():
         elapsed = float(t.item())
 
     # PCIe-inclusive ask(): H2D of the shard + one step (noted, never `value`)
-    h2d_ms = gen_ms = None
-    if rank == 0:
+    h2d_ms = gen_ms = full_ms = None
+    if rank == 0 and args.scaling == "weak":
         Xh = Xs.cpu().numpy()
         t1 = time.perf_counter()
         eng.upload_candidates(Xh)
@@ -156,11 +186,26 @@ def main():
         gb, gi = eng.sweep(w["acq"], plugin, True)
         eng.read_candidates(gi)
         gen_ms = (time.perf_counter() - t1) * 1e3
+        # a FULL ask() of the fused proposal (what integration.fused_batch_arg_max_acquisition does per ParallelBO.ask):
+        # candidates drawn on the device -> one posterior pass for the q criteria -> top-16 per criterion (de-duplication
+        # fall-backs) -> read-back of the 16 q winning points; measured on rank 0's shard, exchange not included
+        t1 = time.perf_counter()
+        eng.generate_candidates([-5.0] * d, [5.0] * d, M, seed=101)
+        tv, ti = eng.sweep_topk(w["acq"], plugin, True, 16)
+        eng.read_candidates(ti.ravel())
+        full_ms = (time.perf_counter() - t1) * 1e3
         eng.bind_candidates(Xs.data_ptr(), M, owner=Xs)
 
+    if use_dist:  # ragged shards under --scaling strong: the job's candidate count is the sum over ranks
+        tm = torch.tensor([float(M)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tm, op=dist.ReduceOp.SUM)
+        M_total = float(tm.item())
+    else:
+        M_total = float(M)
     if rank == 0:
-        total = float(M) * world * args.steps
+        total = M_total * args.steps
         value = total / elapsed
+        traffic, traffic_source = measured_traffic(args.workload, ((1 << 30) // (((N + 31) // 32 * 32) * 8)) // 64 * 64)
         flops_contract = (float(N) * N + 3.0 * N) * M * args.steps  # k_contract: forward substitution + sum of squares
         achieved = flops_contract / (tim["contract_ms"] * 1e-3) / 1e12
         res = {
@@ -172,16 +217,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": w["name"], "N": N, "d": d, "M_per_gpu": M, "q": len(w["acq"]),
-                       "parallelism": "candidate shards x%d, 1 all-gather of q*(val,idx) per step" % world},
+            "config": {"workload": w["name"], "N": N, "d": d, "M_per_gpu": M, "M_total": M_total, "q": len(w["acq"]),
+                       "parallelism": "candidate shards x%d, 1 ncclAllGather of q*(val,idx,x) per step (bogp_exchange_argmax)" % world},
             "roofline": (lambda r: dict(r, hbm_GBps=(r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) if r["traffic"] else None))({
                 "bound": "mfma", "kernel": "k_contract16 (v_mfma_f64_16x16x4_f64, VGPR accumulators)" if os.environ.get("BOGP_CONTRACT_MFMA", "16")[0] != "4" else "k_contract (v_mfma_f64_4x4x4_4b_f64)", "achieved": achieved, "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS,
-                "traffic": measured_traffic(args.workload, ((1 << 30) // (((N + 31) // 32 * 32) * 8)) // 64 * 64),
+                "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": tim["contract_ms"] / max(1, tim["n_chunks"]), "launches": tim["n_chunks"],
                 "flops_per_candidate": float(N) * N + 3.0 * N,
                 # what the kernel executes: 16 x 16 tiles on and below the diagonal of the (padded) triangle
@@ -192,13 +237,15 @@ def main():
             "ask_ms": elapsed / args.steps * 1e3,
             "ask_ms_with_h2d": h2d_ms,
             "ask_ms_device_generated": gen_ms,
+            "ask_ms_full": full_ms,
             "commit_s": commit_s,
             "fit": fit_ms,
             "llf": llf,
             "argmax": [int(i) for i in out[1]],
+            "exchange": "bogp_exchange_argmax over RCCL, world %d (executed inside every timed step)" % eng.comm_world,
         }
         if world == 1 and not args.no_cpu:
-            res["cpu_baseline"] = cpu_baseline(w, X, y, par, plugin, Xh, args.cpu_sample, eng)
+            res["cpu_baseline"] = cpu_baseline(w, X, y, par, plugin, Xs[: args.cpu_sample].cpu().numpy(), args.cpu_sample, eng)
         print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()

@@ -62,7 +62,7 @@ typedef struct bogp_handle bogp_handle;
 #define BOGP_ACQ_UCB 2
 #define BOGP_ACQ_MGFI 3
 
-/* trend (prior mean) bases: surrogate/gaussian_process/trend.py.  Only the constant basis (p = 1) is built. */
+/* trend (prior mean) bases: surrogate/gaussian_process/trend.py; all three are built (fit, predict, sweep) */
 #define BOGP_TREND_CONSTANT 0
 #define BOGP_TREND_LINEAR 1    /* [1, x]                      trend.py:94-118  */
 #define BOGP_TREND_QUADRATIC 2 /* [1, x, x_k x_j (j >= k)]    trend.py:121-142 */
@@ -71,6 +71,7 @@ typedef struct bogp_handle bogp_handle;
 #define BOGP_MAX_TARGETS 8 /* columns of y (n_targets, gpr.py:463) */
 #define BOGP_MAX_Q 64    /* criteria evaluated in one sweep (ParallelBO batch size q) */
 #define BOGP_MAX_TOPK 32 /* ranks returned per criterion by bogp_sweep_topk */
+#define BOGP_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
 int bogp_create(int device, bogp_handle** out);
@@ -211,6 +212,35 @@ int bogp_prior_corr(bogp_handle* h, const double* X1, int n1, double* R);
  * L-BFGS-B, base.py:201-243) makes thousands of times per ask().  Constant trend basis; q may be 0.            */
 int bogp_point_eval(bogp_handle* h, const double* x, int q, const int* acq_id, const double* acq_par, double plugin,
                     int minimize, double* mu, double* mse, double* dmu, double* dmse, double* acq);
+
+/* ---- multi-GPU: the one exchange step per sweep ------------------------------------------
+ * Nothing like it exists in the reference (its only parallelism is joblib over the q criteria, bayes_opt.py:108-111);
+ * this is the cross-rank half of the new inner maximiser behind acquisition/optim/__init__.py:55-153.  One process per
+ * GPU, each with its own handle and its own contiguous block of the M candidates; the model is replicated by redundant,
+ * deterministic factorisation (no broadcast).  After bogp_sweep / bogp_sweep_topk every rank calls bogp_exchange_*: its q
+ * (or q x k) winners -- (value, LOCAL index + index_offset, point) -- are packed on the device from the sweep's own result
+ * buffers, gathered with ONE ncclAllGather (RCCL over xGMI; q (2 + d) doubles per rank), read back once, and reduced by
+ * the same deterministic rule on every rank: np.argmax over the concatenation of all shards (largest value; a NaN beats
+ * every number; ties -> lowest global index).  All ranks return identical results.
+ *   bogp_comm_unique_id   fills BOGP_COMM_ID_BYTES bytes (ncclGetUniqueId); call on ONE rank, hand the bytes to all
+ *                         ranks by any means (MPI_Bcast, a file, torch.distributed's store ...)
+ *   bogp_comm_init        ncclCommInitRank on the handle's device; collective over the `world` ranks; world = 1 is fine
+ *   bogp_comm_attach      borrow an existing ncclComm_t instead (not destroyed with the handle)
+ *   bogp_comm_info        rank / world of the handle's communicator (world = 0: none)
+ *   bogp_exchange_argmax  after bogp_sweep:      best_val (q), best_gidx (q), best_x (q x d, may be NULL)
+ *   bogp_exchange_topk    after bogp_sweep_topk: best_val, best_gidx (q x k), best_x (q x k x d, may be NULL); global
+ *                         k best per criterion in the same order; empty slots (-inf, -1, NaN)
+ *   bogp_reduce_pairs / bogp_merge_topk   the reduce itself on HOST records [R][q( x k)][2 + d] = (value, index bit
+ *                         pattern, point) for callers that gather by their own transport (MPI, gloo); need no handle. */
+int bogp_comm_unique_id(unsigned char* id_out);
+int bogp_comm_init(bogp_handle* h, const unsigned char* id, int rank, int world);
+int bogp_comm_attach(bogp_handle* h, void* nccl_comm);
+int bogp_comm_info(const bogp_handle* h, int* rank, int* world);
+int bogp_comm_destroy(bogp_handle* h);
+int bogp_exchange_argmax(bogp_handle* h, int64_t index_offset, double* best_val, int64_t* best_gidx, double* best_x);
+int bogp_exchange_topk(bogp_handle* h, int64_t index_offset, double* best_val, int64_t* best_gidx, double* best_x);
+int bogp_reduce_pairs(int R, int q, int d, const double* gathered, double* val, int64_t* gidx, double* x);
+int bogp_merge_topk(int R, int q, int k, int d, const double* gathered, double* val, int64_t* gidx, double* x);
 
 /* ---- measurement ----------------------------------------------------------------------------------
  * HIP-event durations (ms, summed over candidate chunks) of the kernels of the LAST bogp_predict /

@@ -38,7 +38,7 @@ def test_ctypes_table_covers_the_header_exactly():
 
 def test_abi_version_and_constants_match_header():
     lib = _lib.load()
-    assert lib.bogp_abi_version() == 2
+    assert lib.bogp_abi_version() == 3
     src = open(HEADER).read()
     consts = dict(re.findall(r"#define\s+(BOGP_[A-Z_0-9]+)\s+\(?(-?\d+)\)?", src))
     assert int(consts["BOGP_KERNEL_MATERN52"]) == _lib.KERNEL_MATERN52 == 3
@@ -114,3 +114,50 @@ def test_header_is_plain_c_and_a_c_client_links(tmp_path):
         assert "best" in res.stdout
     else:
         assert res.returncode == 3 and "bogp_create" in res.stderr, (res.returncode, res.stderr)
+
+
+def test_c_reduce_rules_equal_the_python_ones():
+    """bogp_reduce_pairs / bogp_merge_topk (the library's side of the exchange, host code: no GPU needed) against the
+    Python rules of bogp.distributed on adversarial records: cross-rank ties, NaNs, -inf padding, empty slots."""
+    import numpy as np
+
+    from bogp import distributed
+
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        R, q, d = int(rng.integers(1, 9)), int(rng.integers(1, 6)), int(rng.integers(0, 4))
+        vals = rng.choice([0.0, 1.0, 2.5, -1.0, np.nan, np.inf, -np.inf], size=(R, q))  # many exact ties across ranks
+        idxs = rng.permutation(R * q * 10)[: R * q].reshape(R, q).astype(np.int64)
+        xs = rng.standard_normal((R, q, d))
+        rec = np.empty((R, q, 2 + d))
+        rec[..., 0], rec[..., 1], rec[..., 2:] = vals, idxs.view(np.float64), xs
+        v, i, x = _lib.reduce_pairs_c(rec)
+        win = distributed.reduce_pairs(vals, idxs)
+        ar = np.arange(q)
+        np.testing.assert_array_equal(v, vals[win, ar])
+        np.testing.assert_array_equal(i, idxs[win, ar])
+        if d:
+            np.testing.assert_array_equal(x, xs[win, ar])
+        # it is np.argmax over the concatenation ordered by global index
+        for c in range(q):
+            order = np.argsort(idxs[:, c])
+            assert i[c] == idxs[order, c][int(np.argmax(vals[order, c]))]
+    for trial in range(100):
+        R, q, k, d = int(rng.integers(1, 6)), int(rng.integers(1, 4)), int(rng.integers(1, 7)), int(rng.integers(0, 3))
+        vals = rng.choice([0.0, 1.0, 2.5, -1.0, np.nan, 7.0], size=(R, q, k))
+        idxs = rng.permutation(R * q * k * 4)[: R * q * k].reshape(R, q, k).astype(np.int64)
+        empty = rng.random((R, q, k)) < 0.2
+        idxs[empty], vals[empty] = -1, -np.inf
+        xs = rng.standard_normal((R, q, k, d))
+        rec = np.empty((R, q, k, 2 + d))
+        rec[..., 0], rec[..., 1], rec[..., 2:] = vals, idxs.view(np.float64), xs
+        v, i, x = _lib.merge_topk_c(rec)
+        for c in range(q):
+            pv, pi, pr, ps = distributed.merge_topk(vals[:, c, :], idxs[:, c, :], k)
+            np.testing.assert_array_equal(v[c], pv)
+            np.testing.assert_array_equal(i[c], pi)
+            for j in range(k):
+                if d and pr[j] >= 0:
+                    np.testing.assert_array_equal(x[c, j], xs[pr[j], c, ps[j]])
+                elif d:
+                    assert np.all(np.isnan(x[c, j]))

@@ -1,5 +1,7 @@
-"""world_size-2 `gloo` test of the one exchange step of the sharded sweep (runs on CPU: the local winners are
-synthetic, the collective + deterministic reduce are the product code)."""
+"""Multi-process `gloo` tests (world sizes 2, 4, 8) of the one exchange step of the sharded sweep (runs on CPU: the
+local winners are synthetic or come from the oracle-backed engine stand-in; the collective + deterministic reduce and
+the sharding rules are the product code).  No multi-GPU box is available to the build: the RCCL transport of the same
+exchange (bogp_exchange_argmax) is exercised with one rank on the GPU box, its reduce rule in tests/test_abi.py."""
 import os
 import socket
 import sys
@@ -31,8 +33,8 @@ def _worker(rank, world, port, q_out):
         rng = np.random.default_rng(7)  # every rank builds the SAME global table, then takes its shard
         table = rng.standard_normal((q, M)).round(2)
         table[1, :] = 0.25  # plateau -> global index 0 must win
-        table[2, 700] = np.nan  # NaN is maximal for np.argmax
-        table[3, [10, 900]] = 9.0  # cross-rank tie -> lower global index
+        table[2, [700, 300]] = np.nan  # NaN is maximal for np.argmax; two of them (different ranks) -> the first one
+        table[3, [10, 900, 455]] = 9.0  # cross-rank tie -> lower global index
         X = rng.uniform(-1, 1, size=(M, d))
         a, b = optim.shard_bounds(M, rank, world)
         loc = table[:, a:b]
@@ -57,20 +59,22 @@ def _worker(rank, world, port, q_out):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
-def test_two_rank_exchange_matches_global_argmax():
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 4, 8])  # M = 1001 divides by none of them: ragged shards
+def test_exchange_matches_global_argmax(world):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q_out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q_out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q_out)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q_out.get(timeout=150) for _ in procs]
+    res = [q_out.get(timeout=250) for _ in procs]
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
     for rank, v, gi, x, table, X, tv, ti, tx in res:
         for c in range(table.shape[0]):
             ref = int(np.argmax(table[c]))
@@ -85,8 +89,65 @@ def test_two_rank_exchange_matches_global_argmax():
                 np.testing.assert_array_equal(tv[c, r], table[c, j])
                 np.testing.assert_array_equal(tx[c, r], X[j])
                 w[j] = -np.inf
-    # both ranks hold identical results
-    np.testing.assert_array_equal(res[0][2], res[1][2])
+    # every rank holds identical results
+    for r in res[1:]:
+        np.testing.assert_array_equal(res[0][2], r[2])
+        np.testing.assert_array_equal(res[0][7], r[7])
+
+
+def _sweep_worker(rank, world, port, q_out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    import bogp
+    from bogp import optim
+    from support.oracle_engine import OracleEngine
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(3)
+        X = rng.uniform(-5, 5, size=(30, 2))
+        y = np.sum(X**2, axis=1, keepdims=True)
+        y = (y - y.mean()) / y.std() + 0.1 * rng.standard_normal((30, 1))
+        gp = bogp.GaussianProcess(thetaL=[1e-3] * 2, thetaU=[1e2] * 2, nugget=1e-6)
+        gp._engine = OracleEngine()
+        gp.set_state(np.r_[0.05, 0.05, 0.9], X, y)
+        crit = bogp.EI(model=gp)
+        box = optim.Box([(-5, 5)] * 2, random_seed=100 + rank)  # every rank draws DIFFERENT candidates
+        xopt, fopt = optim.argmax_restart(crit, box, eval_budget=300, optimizer="sweep")
+        own = float(np.ravel(crit(np.array(xopt).reshape(1, -1)))[0])
+        xs, fs = optim.batch_argmax([crit, bogp.EI(model=gp)], optim.Box([(-5, 5)] * 2, random_seed=200 + rank), 200, k=4)
+        q_out.put((rank, xopt, fopt, own, xs, fs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sweep_optimiser_returns_the_same_point_on_every_rank():
+    """under a process group `argmax_restart(optimizer="sweep")` once returned, on the losing ranks,
+    a local candidate that did not belong to the winning value.  Every rank samples its own candidates; the point must
+    come out of the exchange, so that all ranks return the identical (xopt, fopt) with fopt = criterion(xopt)."""
+    import torch.multiprocessing as mp
+
+    world = 4
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sweep_worker, args=(r, world, port, q_out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q_out.get(timeout=250) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    _, x0, f0, own0, xs0, fs0 = res[0]
+    np.testing.assert_allclose(f0, own0, rtol=1e-9)  # batched vs one-row BLAS rounding of the stand-in engine
+    for _, x, f, own, xs, fs in res[1:]:
+        assert x == x0 and f == f0 and own == own0
+        assert xs == xs0 and fs == fs0
+    assert xs0[0] != xs0[1]  # two identical criteria: the second takes its fall-back, not the same point
 
 
 def _fit_worker(rank, world, port, q_out):

@@ -87,6 +87,91 @@ def test_reference_ParallelBO_with_mgfi(ref):
     assert opt.eval_count == 9
 
 
+class _CountingEngine:
+    """OracleEngine that counts posterior passes (predict / sweep / sweep_topk each walk all candidates once)."""
+
+    def __new__(cls):
+        from support.oracle_engine import OracleEngine
+
+        class Counting(OracleEngine):
+            passes = 0
+
+            def predict(self, eval_MSE=True):
+                type(self).passes += 1
+                return super().predict(eval_MSE)
+
+        return Counting()
+
+
+@pytest.mark.timeout(600)
+def test_install_fuses_the_parallelbo_batch_into_one_posterior_pass(ref):
+    """SURVEY row f1 / VERDICT r01 item 4: through the REAL `ParallelBO.ask()` with n_point = 8, `bogp.install` makes the
+    q criteria share ONE posterior pass (the reference's loop costs 8), the proposals are 8 distinct points none of which
+    repeats an evaluated one.  (The t_i are drawn by the reference's own sampler before any candidate is sampled, in both
+    paths: bayes_opt.py:101-106.)"""
+    bayes_optim, bogp, OracleEngine = ref
+    from bayes_optim import ParallelBO, RealSpace
+
+    dim, q = 3, 8
+    f = lambda x: float(np.sum(np.asarray(x) ** 2))  # noqa: E731
+
+    def run(fused):
+        undo = bogp.install(bayes_optim, fuse_batch=fused)
+        try:
+            np.random.seed(11)
+            model = _model(bogp, OracleEngine, dim)
+            model._engine = _CountingEngine()
+            opt = ParallelBO(search_space=RealSpace([-5, 5]) * dim, obj_fun=f, model=model, DoE_size=10, max_FEs=40, verbose=False,
+                             n_point=q, acquisition_fun="MGFI", acquisition_par={"t": 2},
+                             acquisition_optimization={"optimizer": "sweep", "max_FEs": 3000}, random_seed=11)  # fmt: skip
+            X0 = opt.ask()
+            opt.tell(X0, [f(x) for x in X0])
+            np.random.seed(5)
+            before = type(model._engine).passes
+            X = opt.ask()
+            passes = type(model._engine).passes - before
+            return X, passes, np.asarray(opt.data, dtype=float)[:, :dim]
+        finally:
+            undo()
+
+    Xf, passes_f, hist = run(True)
+    Xr, passes_r, _ = run(False)
+    assert passes_f == 1 and passes_r == q
+    Xf = np.asarray(Xf, dtype=float)
+    assert Xf.shape == (q, dim)
+    assert len({tuple(np.round(x, 12)) for x in Xf}) == q  # distinct proposals: fall-backs instead of random padding
+    assert not any(np.any(np.all(np.isclose(hist, x), axis=1)) for x in Xf)
+
+
+@pytest.mark.timeout(600)
+def test_fused_batch_with_fixed_variables_and_ucb(ref):
+    """ask(fixed=...) through the fused batch (the free variables are swept, the fixed one is filled in for the model and
+    by the reference's `fillin_fixed_value` afterwards) and the UCB sampler (alpha_i logit-normal, bayes_opt.py:87-90)."""
+    bayes_optim, bogp, OracleEngine = ref
+    from bayes_optim import ParallelBO, RealSpace
+
+    dim = 3
+    f = lambda x: float(np.sum(np.asarray(x) ** 2))  # noqa: E731
+    undo = bogp.install(bayes_optim)
+    try:
+        np.random.seed(2)
+        model = _model(bogp, OracleEngine, dim)
+        model._engine = _CountingEngine()
+        opt = ParallelBO(search_space=RealSpace([-5, 5]) * dim, obj_fun=f, model=model, DoE_size=8, max_FEs=30, verbose=False,
+                         n_point=4, acquisition_fun="UCB", acquisition_par={"alpha": 0.5},
+                         acquisition_optimization={"optimizer": "sweep", "max_FEs": 1000}, random_seed=2)  # fmt: skip
+        X0 = opt.ask()
+        opt.tell(X0, [f(x) for x in X0])
+        before = type(model._engine).passes
+        name = opt.search_space.var_name[1]
+        X = np.asarray(opt.ask(fixed={name: 1.25}), dtype=float)
+        assert type(model._engine).passes - before == 1
+        assert X.shape == (4, dim) and np.all(X[:, 1] == 1.25)
+        assert len({tuple(x) for x in X}) == 4
+    finally:
+        undo()
+
+
 @pytest.mark.timeout(300)
 def test_save_load_roundtrip_through_dill(ref, tmp_path):
     bayes_optim, bogp, OracleEngine = ref

@@ -1,0 +1,185 @@
+"""GPU half of the round-2 host-integration rows: the fused q-criterion proposal behind ParallelBO's hook,
+the nugget-retry path of `fit`, and the device-resident top-k."""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+import bogp  # noqa: E402
+from bogp import _lib, integration  # noqa: E402
+from support.mini_driver import MiniParallelBO  # noqa: E402
+
+
+def _fitted_model(N=300, d=4, seed=3):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-5, 5, size=(N, d))
+    y = np.sum(X**2, axis=1)
+    y = ((y - y.mean()) / y.std()).reshape(-1, 1)
+    gp = bogp.GaussianProcess(corr="matern52", thetaL=[1e-4] * d, thetaU=[1e2] * d, nugget=1e-6)
+    gp.set_state(np.r_[np.full(d, 0.05), 0.9], X, y)
+    return gp, X, y
+
+
+class _Count:
+    """Counts the posterior passes an engine makes (every one of these entry points walks all candidates once)."""
+
+    def __init__(self, eng):
+        self.n = 0
+        for name in ("sweep", "sweep_topk", "predict"):
+            orig = getattr(eng, name)
+
+            def wrapped(*a, _o=orig, **kw):
+                self.n += 1
+                return _o(*a, **kw)
+
+            setattr(eng, name, wrapped)
+
+
+@pytest.mark.parametrize("fun,par", [("MGFI", {"t": 2}), ("UCB", {"alpha": 0.5})])
+def test_fused_batch_is_one_pass_and_picks_what_q_separate_sweeps_would(fun, par):
+    gp, X, y = _fitted_model()
+    d, q, M = X.shape[1], 8, 20000
+    hist = X[:50]
+    drv = MiniParallelBO(gp, [(-5, 5)] * d, fun, par, "sweep", M, seed=9, history=hist)
+    cnt = _Count(gp.engine)
+    np.random.seed(4)
+    xs, fs = integration.fused_batch_arg_max_acquisition(drv, q, False)
+    assert cnt.n == 1  # ONE posterior pass for the q criteria
+    assert len(xs) == q and len(fs) == q and all(len(x) == d for x in xs)
+    # replay by hand: same t_i / alpha_i draws, same candidates, q full-value sweeps, then the selection rule
+    np.random.seed(4)
+    pars = [drv._sampler(drv._acquisition_par) for _ in range(q)]
+    Xs = bogp.optim.Box([(-5, 5)] * d, random_seed=9).sample(M)
+    eng = gp.engine
+    eng.upload_candidates(Xs)
+    acq_id = {"MGFI": _lib.ACQ_MGFI, "UCB": _lib.ACQ_UCB}[fun]
+    pars_eff = [min(p, 22.36) if fun == "MGFI" else p for p in pars]
+    _, _, vals = eng.sweep([(acq_id, p) for p in pars_eff], float(np.min(y)), True, return_values=True)
+    taken = set()
+    for c in range(q):
+        order = np.lexsort((np.arange(M), -vals[c]))
+        pick = next(i for i in order if i not in taken and not np.any(np.all(np.isclose(hist, Xs[i]), axis=1)))
+        taken.add(int(pick))
+        np.testing.assert_array_equal(np.asarray(xs[c]), Xs[pick])
+        assert fs[c] == vals[c][pick]
+    assert len(taken) == q
+    # the oracle agrees on the values of the chosen rows
+    st = O.make_state(np.r_[np.full(d, 0.05), 0.9], X, y, O.KERNEL_MATERN52, O.MODE_NOISY, 1e-6)
+    mu, mse = O.predict(st, np.asarray(xs))
+    for c in range(q):
+        ref = O.acquisition(acq_id, pars_eff[c], mu[c : c + 1, 0], mse[c : c + 1, 0], float(np.min(y)), 0.9, True)[0]
+        np.testing.assert_allclose(fs[c], ref, rtol=1e-6)
+
+
+def test_fused_batch_on_device_generated_designs_and_other_optimisers_fall_through():
+    gp, X, y = _fitted_model(N=200, d=3)
+    drv = MiniParallelBO(gp, [(-5, 5)] * 3, "MGFI", {"t": 2}, "sweep-device-lhs", 30000, seed=1)
+    cnt = _Count(gp.engine)
+    np.random.seed(0)
+    xs, fs = integration.fused_batch_arg_max_acquisition(drv, 4, False)
+    assert cnt.n == 1 and len({tuple(x) for x in xs}) == 4
+    assert all(np.all(np.abs(np.asarray(x)) <= 5) for x in xs) and all(np.isfinite(fs))
+    # an optimiser the hook does not serve is handed to the original method untouched
+    integration._ORIGINAL["batch"] = lambda self, n, r, f=None: ("orig", n)
+    try:
+        drv._optimizer = "BFGS"
+        assert integration.fused_batch_arg_max_acquisition(drv, 4, True) == ("orig", 4)
+    finally:
+        integration._ORIGINAL.clear()
+
+
+def test_topk_is_repeated_argmax_for_every_criterion():
+    gp, X, y = _fitted_model(N=150, d=3)
+    eng = gp.engine
+    rng = np.random.default_rng(0)
+    Xs = rng.uniform(-5, 5, size=(5000, 3))
+    Xs[100] = Xs[7]  # an exact tie between two candidates: the lower index ranks first
+    eng.upload_candidates(Xs)
+    acq = [(_lib.ACQ_EI, 0.0), (_lib.ACQ_MGFI, 2.0), (_lib.ACQ_UCB, 0.5)]
+    pl = float(y.min())
+    _, _, vals = eng.sweep(acq, pl, True, return_values=True)
+    tv, ti = eng.sweep_topk(acq, pl, True, 32)
+    for c in range(3):
+        order = np.lexsort((np.arange(len(Xs)), -vals[c]))[:32]
+        np.testing.assert_array_equal(ti[c], order)
+        np.testing.assert_array_equal(tv[c], vals[c][order])
+    # fewer candidates than k: padded with (-inf, -1)
+    eng.upload_candidates(Xs[:5])
+    tv, ti = eng.sweep_topk(acq[:1], pl, True, 8)
+    assert np.all(ti[0, 5:] == -1) and np.all(np.isneginf(tv[0, 5:])) and sorted(ti[0, :5]) == [0, 1, 2, 3, 4]
+
+
+def _smooth(n=40, d=2, seed=2):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1, 1, size=(n, d))
+    y = np.sum(X**2, axis=1)
+    return X, ((y - y.mean()) / y.std()).reshape(-1, 1)
+
+
+@pytest.mark.parametrize("likelihood", ["concentrated", "restricted"])
+def test_nugget_retry_switches_noiseless_to_noisy_on_the_device(likelihood):
+    """gpr.py:384-399 on smooth data whose noiseless likelihood is rejected everywhere in the box (llf > 0 or a failed
+    Cholesky): the fit ends in the noisy mode with a grown nugget and a state of THAT mode's parameter layout."""
+    X, y = _smooth()
+    gp = bogp.GaussianProcess(mean=bogp.trend.constant_trend(2) if likelihood == "restricted" else None, corr="squared_exponential",
+                              thetaL=[1e-2] * 2, thetaU=[1.0] * 2, nugget=0, random_start=2, eval_budget=60, likelihood=likelihood)  # fmt: skip
+    assert gp.estimation_mode == "noiseless"
+    np.random.seed(0)
+    gp.fit(X, y)
+    assert gp.is_fitted and gp.estimation_mode == "noisy" and float(np.ravel(gp.noise_var)[0]) >= 1e-5
+    assert len(gp._committed_par) == 3 and np.isfinite(gp.log_likelihood_)
+    mu, mse = gp.predict(X[:4], eval_MSE=True)
+    assert np.all(np.isfinite(mu)) and np.all(mse >= 0)
+    if likelihood == "concentrated":
+        st = O.make_state(gp._committed_par, X, y, O.KERNEL_SE, O.MODE_NOISY, float(np.ravel(gp.noise_var)[0]))
+        np.testing.assert_allclose(gp.log_likelihood_, st.llf, rtol=1e-9)
+        omu, omse = O.predict(st, X[:4])
+        np.testing.assert_allclose(mu, omu, rtol=1e-6, atol=1e-9)
+
+
+def test_likelihood_calls_leave_the_fitted_device_state_alone():
+    gp, X, y = _fitted_model(N=120, d=3)
+    Xs = np.random.default_rng(1).uniform(-5, 5, size=(64, 3))
+    par0 = gp._committed_par.copy()
+    mu0, mse0 = gp.predict(Xs, eval_MSE=True)
+    other = par0 * np.array([3.0, 0.3, 2.0, 1.0])
+    env = {}
+    assert np.isfinite(gp.log_likelihood_concentrated(other, env)) and "C" in env
+    gp.log_likelihood_concentrated(other, eval_grad=True)
+    gp.log_likelihood_concentrated(other, {}, eval_grad=True)
+    np.testing.assert_array_equal(gp._committed_par, par0)
+    mu1, mse1 = gp.predict(Xs, eval_MSE=True)
+    np.testing.assert_array_equal(mu1, mu0)
+    np.testing.assert_array_equal(mse1, mse0)
+
+
+def test_set_train_reuses_its_buffers_across_a_growing_training_set():
+    """A BO loop adds points one tell() at a time: every size must give the state a fresh engine gives (the N x N
+    buffers are kept between bogp_set_train calls that fit their capacity)."""
+    rng = np.random.default_rng(5)
+    d = 3
+    Xall = rng.uniform(-5, 5, size=(400, d))
+    yall = np.sum(Xall**2, axis=1, keepdims=True) / 30.0
+    Xs = rng.uniform(-5, 5, size=(100, d))
+    par = np.r_[np.full(d, 0.05), 0.9]
+    e1 = _lib.Engine(0)
+    for N in (300, 301, 320, 333, 257, 64, 65, 400, 129):
+        e1.set_train(Xall[:N], yall[:N])
+        l1 = e1.commit(3, 1, par, 1e-6)
+        e1.upload_candidates(Xs)
+        m1, s1 = e1.predict()
+        g1 = e1.nll(3, 1, par, 1e-6, eval_grad=True)
+        e2 = _lib.Engine(0)
+        e2.set_train(Xall[:N], yall[:N])
+        l2 = e2.commit(3, 1, par, 1e-6)
+        e2.upload_candidates(Xs)
+        m2, s2 = e2.predict()
+        g2 = e2.nll(3, 1, par, 1e-6, eval_grad=True)
+        e2.close()
+        assert l1 == l2 and g1[0] == g2[0]
+        np.testing.assert_array_equal(m1, m2)
+        np.testing.assert_array_equal(s1, s2)
+        np.testing.assert_array_equal(g1[1], g2[1])
+    e1.close()
