@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
     fprintf(stderr, "bogp_create: %s\n", bogp_last_error(NULL));
     return 3;
   }
-  if (bogp_abi_version() != 2) return 4;
+  if (bogp_abi_version() != 3) return 4;
   double llf = 0.0;
   CHECK(bogp_set_train(h, X, y, N, d, 1));
   CHECK(bogp_commit(h, BOGP_KERNEL_MATERN32, BOGP_MODE_NOISY, par, d + 1, 1e-6, BOGP_TREND_CONSTANT, 0, 0.0, &llf));
@@ -65,6 +65,21 @@ int main(int argc, char** argv) {
     CHECK(bogp_sweep(h, 1, acq_id, acq_par, ymin, 1, &best, &idx, NULL));
     CHECK(bogp_predict(h, mu, mse));
     printf("llf %.17g\nbest %.17g %lld\nmu0 %.17g\nmse0 %.17g\n", llf, best, (long long)idx, mu[0], mse[0]);
+    { /* a plain-C client shards too: the library's own exchange (one-rank communicator here), global index = local + 1000 */
+      unsigned char id[BOGP_COMM_ID_BYTES];
+      double xbest = 0.0, gbest = 0.0;
+      int64_t gidx = -1;
+      int rank = -1, world = -1;
+      double* xb = (double*)malloc(sizeof(double) * d);
+      if (bogp_comm_unique_id(id) != BOGP_OK) return 5;
+      CHECK(bogp_comm_init(h, id, 0, 1));
+      CHECK(bogp_comm_info(h, &rank, &world));
+      CHECK(bogp_sweep(h, 1, acq_id, acq_par, ymin, 1, &best, &idx, NULL));
+      CHECK(bogp_exchange_argmax(h, 1000, &gbest, &gidx, xb));
+      CHECK(bogp_candidates_read(h, &idx, 1, &xbest));
+      printf("exchange %.17g %lld %d %d %.17g %.17g\n", gbest, (long long)gidx, rank, world, xb[0], xbest);
+      free(xb);
+    }
     free(mu);
     free(mse);
   }

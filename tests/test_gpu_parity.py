@@ -1061,7 +1061,8 @@ def test_plain_c_client_gets_the_same_numbers(tmp_path):
     exe = _build_c_client(tmp_path)
     res = subprocess.run([exe, str(N), str(d), str(M), str(seed)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr
-    got = {ln.split()[0]: [float(v) for v in ln.split()[1:]] for ln in res.stdout.strip().splitlines()}
+    keys = ("llf", "best", "mu0", "mse0", "exchange")  # (librccl prints a version banner on stdout when it initialises)
+    got = {ln.split()[0]: [float(v) for v in ln.split()[1:]] for ln in res.stdout.strip().splitlines() if ln.split() and ln.split()[0] in keys}
     s = seed
     X = np.empty((N, d))
     y = np.empty(N)
@@ -1085,6 +1086,10 @@ def test_plain_c_client_gets_the_same_numbers(tmp_path):
     np.testing.assert_allclose(got["best"][0], best[0], rtol=1e-12)
     np.testing.assert_allclose(got["mu0"][0], mu[0], rtol=1e-12)
     np.testing.assert_allclose(got["mse0"][0], mse[0], rtol=1e-12)
+    # the client's exchange (one-rank RCCL communicator): same winner, global index = local + its offset, point read back
+    assert got["exchange"][0] == got["best"][0] and int(got["exchange"][1]) == int(idx[0]) + 1000
+    assert (int(got["exchange"][2]), int(got["exchange"][3])) == (0, 1)
+    assert got["exchange"][4] == e.read_candidates(idx)[0, 0]
     # and the oracle agrees with both
     st = O.make_state(par, X, y.reshape(-1, 1), O.KERNEL_MATERN32, O.MODE_NOISY, 1e-6)
     from oracle import philox as P
