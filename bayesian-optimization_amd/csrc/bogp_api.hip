@@ -48,6 +48,7 @@ extern "C" int bogp_create(int device, bogp_handle** out) {
   }
   bogp_handle* h = new bogp_handle();
   h->device = device;
+  h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
       rocblas_create_handle(&h->blas) != rocblas_status_success ||
@@ -91,7 +92,7 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   dfree(h->dXs_owned); dfree(h->dss_part); dfree(h->dbounds); dfree(h->dsobol);
   for (int b = 0; b < 2; ++b) { dfree(h->drT[b]); dfree(h->dmu_part[b]); dfree(h->dw_part[b]); }
   dfree(h->dblk_val); dfree(h->dblk_idx); dfree(h->dmu_out); dfree(h->dmse_out); dfree(h->dacq_out);
-  dfree(h->dbest_val); dfree(h->dbest_idx); dfree(h->dtopk_val); dfree(h->dtopk_idx); dfree(h->dinfo); dfree(h->dscal); dfree(h->dgrad_partial); dfree(h->dbatch);
+  dfree(h->dbest_val); dfree(h->dbest_idx); dfree(h->dtopk_val); dfree(h->dtopk_idx); dfree(h->dcounter); dfree(h->dinfo); dfree(h->dscal); dfree(h->dgrad_partial); dfree(h->dbatch);
   dfree(h->dTt); dfree(h->dCS); dfree(h->duu); dfree(h->dmtrend);
   for (auto e : h->ev) (void)hipEventDestroy(e);
   if (h->blas) rocblas_destroy_handle(h->blas);
@@ -597,8 +598,10 @@ extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* p
       HIPCHK(h, hipMemcpyAsync(h->h_Sinv.data(), h->dSinv, (size_t)ptrend * ptrend * sizeof(double), hipMemcpyDeviceToHost, st));
     }
   }
-  if (!h->dXthT) HIPCHK(h, hipMalloc((void**)&h->dXthT, (size_t)h->cap_d * h->cap_ld * sizeof(double)));
+  // [d][Np] + two zero rows: k_sweep_small walks the dimensions three at a time
+  if (!h->dXthT) HIPCHK(h, hipMalloc((void**)&h->dXthT, (size_t)(h->cap_d + 2) * h->cap_ld * sizeof(double)));
   HIPCHK(h, launch_scale_transpose(h->dX, N, d, Np, h->dsqrt_theta, h->dXthT, st));
+  HIPCHK(h, hipMemsetAsync(h->dXthT + (size_t)d * Np, 0, (size_t)2 * Np * sizeof(double), st));
   HIPCHK(h, hipStreamSynchronize(st));
   h->kernel = kernel; h->mode = mode; h->estimate_trend = estimate_trend;
   h->trend = trend; h->p = ptrend;
@@ -867,6 +870,64 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     HIPCHK(h, hipStreamSynchronize(st));
     h->t_corr_ms = h->t_contract_ms = h->t_acq_ms = 0;
     h->n_chunks = 0;
+    return BOGP_OK;
+  }
+
+  // Small training sets (Np <= 512, d <= 60, constant trend): the whole sweep is ONE launch of k_sweep_small -- producer,
+  // triangular contraction, posterior, criteria and argmax fused, r never leaves LDS (kernels_small.hip).
+  if (h->p == 1 && sweep_small_supported(Np, d)) {
+    const int64_t nblk = std::max<int64_t>(sweep_small_blocks(M, h->n_cu), (M + 15) / 16);
+    int e2;
+    if (q > 0) {
+      if ((e2 = ensure(h, &h->dblk_val, &h->blk_val_cap, (size_t)q * nblk))) return e2;
+      if ((e2 = ensure(h, &h->dblk_idx, &h->blk_idx_cap, (size_t)q * nblk))) return e2;
+      if (!h->dbest_val) HIPCHK(h, hipMalloc((void**)&h->dbest_val, BOGP_MAX_Q * sizeof(double)));
+      if (!h->dbest_idx) HIPCHK(h, hipMalloc((void**)&h->dbest_idx, BOGP_MAX_Q * sizeof(int64_t)));
+    }
+    if (want_out) {
+      if ((e2 = ensure(h, &h->dmu_out, &h->mu_out_cap, (size_t)M))) return e2;
+      if ((e2 = ensure(h, &h->dmse_out, &h->mse_out_cap, (size_t)M))) return e2;
+    }
+    if (want_acq_out)
+      if ((e2 = ensure(h, &h->dacq_out, &h->acq_out_cap, (size_t)q * M))) return e2;
+    if (!h->dcounter) {
+      HIPCHK(h, hipMalloc((void**)&h->dcounter, sizeof(unsigned int)));
+      HIPCHK(h, hipMemsetAsync(h->dcounter, 0, sizeof(unsigned int), st));
+    }
+    SmallArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.Xs = h->dXs; sa.sqrt_theta = h->dsqrt_theta; sa.XthT = h->dXthT; sa.gamma = h->dgamma; sa.wvec = h->dw; sa.Vp = h->dVp;
+    sa.M = M; sa.d = d; sa.Np = Np; sa.NJ16 = Np / 16; sa.NKP = Np / 8; sa.need_var = need_var ? 1 : 0;
+    sa.beta = h->beta; sa.G = h->G; sa.sigma2 = h->sigma2; sa.plugin = plugin;
+    sa.estimate_trend = h->estimate_trend; sa.minimize = minimize; sa.q = q;
+    for (int i = 0; i < q; ++i) { sa.acq_id[i] = acq_id[i]; sa.acq_par[i] = acq_par ? acq_par[i] : 0.0; }
+    sa.mu_out = want_out ? h->dmu_out : nullptr; sa.mse_out = want_out ? h->dmse_out : nullptr;
+    sa.acq_out = want_acq_out ? h->dacq_out : nullptr;
+    sa.blk_val = h->dblk_val; sa.blk_idx = h->dblk_idx; sa.nblk = nblk; sa.counter = h->dcounter;
+    sa.best_val = h->dbest_val; sa.best_idx = h->dbest_idx;
+    const bool stamps = getenv("BOGP_SMALL_STAMPS") && atoi(getenv("BOGP_SMALL_STAMPS"));
+    if (stamps) {  // measurement aid: per-phase wave-cycles of this launch, printed on stderr
+      if ((e2 = ensure(h, &h->dbatch, &h->batch_cap, (size_t)8))) return e2;
+      HIPCHK(h, hipMemsetAsync(h->dbatch, 0, 8 * sizeof(double), st));
+      sa.stamps = (long long*)h->dbatch;
+    }
+    hipEvent_t e0 = get_event(h, 0), e1 = get_event(h, 1);
+    if (!e0 || !e1) FAIL(h, BOGP_ERR_HIP, "hipEventCreate failed");
+    HIPCHK(h, hipEventRecord(e0, st));
+    HIPCHK(h, launch_sweep_small(h->kernel, sa, h->n_cu, st));
+    HIPCHK(h, hipEventRecord(e1, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (stamps) {
+      long long sv[5] = {0, 0, 0, 0, 0};
+      HIPCHK(h, hipMemcpy(sv, h->dbatch, sizeof(sv), hipMemcpyDeviceToHost));
+      const double nw = (double)std::max<long long>(1, sv[4]);
+      fprintf(stderr, "k_sweep_small M=%lld: %.3f ms; per wave: produce %.0f, contract %.0f, wait-at-barrier %.0f, epilogue %.0f cycles (%lld waves)\n",
+              (long long)M, ms, sv[0] / nw, sv[1] / nw, sv[2] / nw, sv[3] / nw, sv[4]);
+    }
+    h->t_corr_ms = 0; h->t_contract_ms = ms; h->t_acq_ms = 0;  // one kernel: reported as the contraction's time
+    h->n_chunks = 1;
     return BOGP_OK;
   }
 

@@ -69,6 +69,49 @@ __device__ __forceinline__ double ndtr(double a) {
 // scipy.stats.norm.pdf: exp(-x**2/2.0) / sqrt(2*pi)
 __device__ __forceinline__ double norm_pdf(double x) { return exp(-(x * x) / 2.0) / 2.5066282746310002; }
 
+// The q acquisition criteria of one row, guards as selects (acquisition_fun.py:127-135, 153-176, 208-217, 265-290); shared by
+// k_acquisition (chunked sweep) and k_sweep_small (fused small-N sweep) so that both evaluate the same expressions.
+__device__ __forceinline__ double acq_value(int id, double par, double y_hat, double sd, double plugin, double sigma2) {
+  switch (id) {
+    case BOGP_ACQ_EI: {
+      if (sd / sqrt(sigma2) < 1e-6) return 0.0;
+      const double xcr_ = plugin - y_hat;
+      const double xcr = xcr_ / sd;
+      return xcr_ * ndtr(xcr) + sd * norm_pdf(xcr);
+    }
+    case BOGP_ACQ_EPSILON_PI: {
+      const double coef = y_hat > 0 ? 1 - par : 1 + par;
+      return ndtr((plugin - coef * y_hat) / sd);
+    }
+    case BOGP_ACQ_UCB: return y_hat + par * sd;
+    default: {  // MGFI
+      const double t = fmin(par, 22.36);
+      if (fabs(sd) <= 1e-8) return 0.0;  // np.isclose(sd, 0)
+      const double sd2 = sd * sd;
+      const double y_hat_p = y_hat - t * sd2;
+      const double beta_p = (plugin - y_hat_p) / sd;
+      const double term = t * (plugin - y_hat - 1);
+      const double e = exp(term + (t * t) * sd2 / 2.0);
+      const double f = ndtr(beta_p) * e;
+      return (isfinite(e) && isfinite(f)) ? f : 0.0;
+    }
+  }
+}
+
+// posterior of one row from its three sums (gpr.py:490, 496-510): mu = beta + r.gamma, MSE = (1 - |L^-1 r|^2 + u^2) sigma2
+// clipped at 0, u = (w.r - 1) / G under ordinary kriging with the constant basis
+__device__ __forceinline__ void posterior_of_sums(double rgamma, double wr, double ss, double beta, double G, int estimate_trend,
+                                                  double sigma2, double& mu, double& mse) {
+  mu = beta + rgamma;
+  double u2 = 0.0;
+  if (estimate_trend) {
+    const double u = (wr - 1.0) / G;
+    u2 = u * u;
+  }
+  mse = (1.0 - ss + u2) * sigma2;
+  if (mse < 0.0) mse = 0.0;
+}
+
 // argmax ordering identical to np.argmax over a 1-D float64 array: first maximal element, where a NaN
 // (if any) is maximal.  (value, index) pairs; `better(a,b)` == a should replace b.
 struct ArgMax {

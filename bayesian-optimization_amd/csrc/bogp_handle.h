@@ -18,6 +18,7 @@ void comm_release(bogp_handle* h);  // bogp_comm.hip: destroys an owned communic
 
 struct bogp_handle {
   int device = 0;
+  int n_cu = 256;  // compute units of the device (launch planning of the fused small-N sweep)
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // producer stream: k_corr_chunk of chunk c+1 runs beside k_contract of chunk c
   rocblas_handle blas = nullptr;
@@ -74,6 +75,7 @@ struct bogp_handle {
   size_t rT_cap[2] = {0, 0}, mu_part_cap[2] = {0, 0}, w_part_cap[2] = {0, 0}, ss_part_cap = 0;
   double *dblk_val = nullptr, *dmu_out = nullptr, *dmse_out = nullptr, *dacq_out = nullptr, *dbest_val = nullptr;
   int64_t *dblk_idx = nullptr, *dbest_idx = nullptr;
+  unsigned int* dcounter = nullptr;  // arrival ticket of k_sweep_small's last workgroup (zero between launches)
   double* dtopk_val = nullptr;   // [q][k] winners of bogp_sweep_topk (device-resident between its passes)
   int64_t* dtopk_idx = nullptr;
   size_t topk_val_cap = 0, topk_idx_cap = 0;

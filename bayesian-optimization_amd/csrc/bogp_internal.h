@@ -65,6 +65,39 @@ struct AcqArgs {
   int64_t nblk_total;
 };
 
+// the fused small-N sweep (kernels_small.hip): one launch = producer + contraction + posterior + q criteria + argmax
+struct SmallArgs {
+  const double* Xs;          // candidates, M x d row-major
+  const double* sqrt_theta;  // d
+  const double* XthT;        // [d][Np]
+  const double* gamma;       // Np
+  const double* wvec;        // Np
+  const double2* Vp;         // packed L^-1
+  int64_t M;
+  int d, Np, NJ16, NKP;
+  int need_var;              // 0: predict without MSE (no contraction)
+  double beta, G, sigma2, plugin;
+  int estimate_trend, minimize, q;
+  int acq_id[64];
+  double acq_par[64];
+  double* mu_out;            // [M] or null
+  double* mse_out;           // [M] or null
+  double* acq_out;           // [q][M] or null
+  double* blk_val;           // [q][nblk]
+  int64_t* blk_idx;
+  int64_t nblk;
+  unsigned int* counter;     // device word, zero between launches: ticket of the last workgroup
+  double* best_val;          // [q]
+  int64_t* best_idx;
+  long long* stamps;         // null, or 5 device words: wave-cycles producing / contracting / waiting / epilogue, waves
+  int64_t m_begin;           // first candidate of THIS launch (set by launch_sweep_small: bulk launch 0, tail launch after it)
+  int64_t blk_begin;         // first partial-argmax slot of this launch
+  int final_launch;          // the launch whose last workgroup reduces the partial winners
+};
+bool sweep_small_supported(int Np, int d);
+int64_t sweep_small_blocks(int64_t M, int n_cu);
+hipError_t launch_sweep_small(int kernel, const SmallArgs& a, int n_cu, hipStream_t st);
+
 hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipStream_t st);
 hipError_t launch_contract(const ContractArgs& a, hipStream_t st);
 int contract_cols_per_group();

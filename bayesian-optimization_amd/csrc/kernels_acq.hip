@@ -15,33 +15,6 @@
 
 namespace bogp {
 
-__device__ __forceinline__ double acq_value(int id, double par, double y_hat, double sd, double plugin, double sigma2) {
-  switch (id) {
-    case BOGP_ACQ_EI: {
-      if (sd / sqrt(sigma2) < 1e-6) return 0.0;
-      const double xcr_ = plugin - y_hat;
-      const double xcr = xcr_ / sd;
-      return xcr_ * ndtr(xcr) + sd * norm_pdf(xcr);
-    }
-    case BOGP_ACQ_EPSILON_PI: {
-      const double coef = y_hat > 0 ? 1 - par : 1 + par;
-      return ndtr((plugin - coef * y_hat) / sd);
-    }
-    case BOGP_ACQ_UCB: return y_hat + par * sd;
-    default: {  // MGFI
-      const double t = fmin(par, 22.36);
-      if (fabs(sd) <= 1e-8) return 0.0;  // np.isclose(sd, 0)
-      const double sd2 = sd * sd;
-      const double y_hat_p = y_hat - t * sd2;
-      const double beta_p = (plugin - y_hat_p) / sd;
-      const double term = t * (plugin - y_hat - 1);
-      const double e = exp(term + (t * t) * sd2 / 2.0);
-      const double f = ndtr(beta_p) * e;
-      return (isfinite(e) && isfinite(f)) ? f : 0.0;
-    }
-  }
-}
-
 __global__ __launch_bounds__(256) void k_acquisition(AcqArgs a) {
   __shared__ double sv[4];
   __shared__ int64_t si[4];

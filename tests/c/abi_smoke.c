@@ -67,18 +67,20 @@ int main(int argc, char** argv) {
     printf("llf %.17g\nbest %.17g %lld\nmu0 %.17g\nmse0 %.17g\n", llf, best, (long long)idx, mu[0], mse[0]);
     { /* a plain-C client shards too: the library's own exchange (one-rank communicator here), global index = local + 1000 */
       unsigned char id[BOGP_COMM_ID_BYTES];
-      double xbest = 0.0, gbest = 0.0;
+      double gbest = 0.0;
       int64_t gidx = -1;
       int rank = -1, world = -1;
       double* xb = (double*)malloc(sizeof(double) * d);
+      double* xr = (double*)malloc(sizeof(double) * d);
       if (bogp_comm_unique_id(id) != BOGP_OK) return 5;
       CHECK(bogp_comm_init(h, id, 0, 1));
       CHECK(bogp_comm_info(h, &rank, &world));
       CHECK(bogp_sweep(h, 1, acq_id, acq_par, ymin, 1, &best, &idx, NULL));
       CHECK(bogp_exchange_argmax(h, 1000, &gbest, &gidx, xb));
-      CHECK(bogp_candidates_read(h, &idx, 1, &xbest));
-      printf("exchange %.17g %lld %d %d %.17g %.17g\n", gbest, (long long)gidx, rank, world, xb[0], xbest);
+      CHECK(bogp_candidates_read(h, &idx, 1, xr));
+      printf("exchange %.17g %lld %d %d %.17g %.17g\n", gbest, (long long)gidx, rank, world, xb[d - 1], xr[d - 1]);
       free(xb);
+      free(xr);
     }
     free(mu);
     free(mse);

@@ -185,3 +185,64 @@ def test_set_train_reuses_its_buffers_across_a_growing_training_set():
         np.testing.assert_array_equal(s1, s2)
         np.testing.assert_array_equal(g1[1], g2[1])
     e1.close()
+
+
+@pytest.mark.parametrize("N,d,kernel,mode,est", [
+    (33, 1, O.KERNEL_SE, O.MODE_NOISY, False), (200, 6, O.KERNEL_MATERN52, O.MODE_NOISY, True),
+    (256, 10, O.KERNEL_SE, O.MODE_NOISY, False), (257, 3, O.KERNEL_MATERN32, O.MODE_NOISY, True),
+    (500, 20, O.KERNEL_ABSEXP, O.MODE_NOISY, False), (512, 10, O.KERNEL_SE, O.MODE_NOISY, True),
+    (480, 64, O.KERNEL_MATERN12, O.MODE_NOISY, False),
+])  # fmt: skip
+def test_fused_small_sweep_equals_the_chunked_schedule_and_the_oracle(N, d, kernel, mode, est):
+    """k_sweep_small (N <= 512: producer + contraction + criteria + argmax in one launch, r resident in LDS) against the
+    chunked three-kernel schedule of the same library (BOGP_NO_FUSED_SMALL=1) and against the oracle, ragged M included."""
+    import os
+
+    rng = np.random.default_rng(N + d)
+    X = rng.uniform(-5, 5, size=(N, d))
+    y = np.sum(X**2, axis=1)
+    y = ((y - y.mean()) / y.std() + 0.05 * rng.standard_normal(N)).reshape(-1, 1)
+    theta = np.full(d, 0.4 / d) * rng.uniform(0.7, 1.3, size=d)
+    par = np.r_[theta, 0.9 if mode == O.MODE_NOISY else 0.98]
+    nv = 1e-6 if mode == O.MODE_NOISY else 0.0
+    st = O.make_state(par, X, y, kernel, mode, nv, estimate_trend=est, beta=0.0)
+    eng = _lib.Engine(0)
+    eng.set_train(X, y)
+    eng.commit(kernel, mode, par, nv, est, 0.0)
+    acq = [(_lib.ACQ_EI, 0.0), (_lib.ACQ_MGFI, 2.0), (_lib.ACQ_UCB, 0.5), (_lib.ACQ_EPSILON_PI, 1e-10)]
+    pl = float(y.min())
+    for M in (33, 63, 64, 65, 1000, 4097, 16384 + 700, 16384 + 5000):  # the last two: bulk launch + 32- / 48-candidate tail launch
+        Xs = rng.uniform(-5, 5, size=(M, d))
+        Xs[M // 2] = X[3]  # a candidate on a training point: MSE at nugget level, guards in play
+        eng.upload_candidates(Xs)
+        out = {}
+        for tag, flag in (("fused", "0"), ("chunked", "1")):
+            os.environ["BOGP_NO_FUSED_SMALL"] = flag
+            try:
+                mu, mse = eng.predict()
+                mu_only, _ = eng.predict(eval_MSE=False)
+                best, idx, vals = eng.sweep(acq, pl, True, return_values=True)
+                b2, i2 = eng.sweep(acq, pl, True)
+            finally:
+                del os.environ["BOGP_NO_FUSED_SMALL"]
+            assert eng.last_timing()["n_chunks"] == 1
+            np.testing.assert_array_equal(mu_only, mu)
+            np.testing.assert_array_equal(i2, idx)
+            np.testing.assert_array_equal(b2, best)
+            for c in range(len(acq)):
+                assert idx[c] == int(np.argmax(vals[c])) and best[c] == vals[c][idx[c]]
+            out[tag] = (mu, mse, vals, idx)
+        omu, omse = O.predict_chunked(st, Xs, 512)
+        for tag in out:
+            np.testing.assert_allclose(out[tag][0], omu[:, 0], rtol=1e-6, atol=1e-9)
+            np.testing.assert_allclose(out[tag][1], omse[:, 0], rtol=1e-6, atol=1e-12 * float(st.sigma2[0]))
+        # two summation orders of the same sums (mu = sum r gamma cancels heavily when gamma is large: compare on its scale)
+        np.testing.assert_allclose(out["fused"][0], out["chunked"][0], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(out["fused"][1], out["chunked"][1], rtol=1e-7, atol=1e-12 * float(st.sigma2[0]))
+        solid = omse[:, 0] > 1e-9 * float(st.sigma2[0])  # away from training points the criteria are well conditioned
+        for c, (a_id, a_par) in enumerate(acq):
+            ref = O.acquisition(a_id, a_par, omu[:, 0], omse[:, 0], pl, float(st.sigma2[0]), True)
+            np.testing.assert_allclose(out["fused"][2][c][solid], ref[solid], rtol=1e-6, atol=1e-300)
+            if np.all(solid) or int(np.argmax(ref)) != M // 2:
+                assert out["fused"][3][c] == int(np.argmax(ref)) == out["chunked"][3][c]
+    eng.close()

@@ -1089,7 +1089,7 @@ def test_plain_c_client_gets_the_same_numbers(tmp_path):
     # the client's exchange (one-rank RCCL communicator): same winner, global index = local + its offset, point read back
     assert got["exchange"][0] == got["best"][0] and int(got["exchange"][1]) == int(idx[0]) + 1000
     assert (int(got["exchange"][2]), int(got["exchange"][3])) == (0, 1)
-    assert got["exchange"][4] == e.read_candidates(idx)[0, 0]
+    assert got["exchange"][4] == got["exchange"][5] == e.read_candidates(idx)[0, d - 1]
     # and the oracle agrees with both
     st = O.make_state(par, X, y.reshape(-1, 1), O.KERNEL_MATERN32, O.MODE_NOISY, 1e-6)
     from oracle import philox as P
