@@ -358,10 +358,17 @@ class Engine:
         self._check(self._lib.bogp_predict(self._h, _ptr(mu), _ptr(mse)))
         return mu, mse
 
-    def sweep(self, acq: Sequence[Tuple[int, float]], plugin: float, minimize=True, return_values=False):
+    def sweep(self, acq: Sequence[Tuple[int, float]], plugin: float, minimize=True, return_values=False, local_result=True):
+        """Posterior + q criteria + argmax over the current candidates: (best_val (q,), best_idx (q,)[, values (q, M)]).
+        local_result=False only queues the sweep (no host wait, returns None): its winners stay on the device for the
+        exchange_argmax() call that follows."""
         q = len(acq)
         ids = np.ascontiguousarray([a for a, _ in acq], dtype=np.int32)
         pars = _f64([float(p) if p is not None else 0.0 for _, p in acq])
+        if not local_result:
+            self._check(self._lib.bogp_sweep(self._h, q, ids.ctypes.data_as(_ip), _ptr(pars), float(plugin), int(bool(minimize)),
+                                             None, None, None))  # fmt: skip
+            return None
         best = np.empty(q)
         idx = np.empty(q, dtype=np.int64)
         vals = np.empty((q, self.M)) if return_values else None

@@ -802,8 +802,35 @@ static hipEvent_t get_event(bogp_handle* h, size_t i) {
   return h->ev[i];
 }
 
+// Event times of the last sweep are read lazily (bogp_last_timing, or the next sweep): reading them needs the events
+// to have completed, and an un-synchronised sweep (bogp_sweep without host outputs) must not wait for them.
+static void collect_timing(bogp_handle* h) {
+  if (!h->timing_pending) return;
+  h->timing_pending = false;
+  (void)hipSetDevice(h->device);
+  if (h->timing_fused) {
+    float ms = 0;
+    (void)hipEventSynchronize(h->ev[1]);
+    (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+    h->t_corr_ms = 0; h->t_contract_ms = ms; h->t_acq_ms = 0;  // one kernel: reported as the contraction's time
+    return;
+  }
+  constexpr int EPC = 5;
+  h->t_corr_ms = h->t_contract_ms = h->t_acq_ms = 0;
+  for (int64_t c = 0; c < h->n_chunks; ++c) {
+    float a = 0, b2 = 0, c2 = 0;
+    hipEvent_t* ev = &h->ev[(size_t)(c * EPC)];
+    (void)hipEventSynchronize(ev[4]);
+    (void)hipEventElapsedTime(&a, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&b2, ev[2], ev[3]);
+    (void)hipEventElapsedTime(&c2, ev[3], ev[4]);
+    h->t_corr_ms += a; h->t_contract_ms += b2; h->t_acq_ms += c2;
+  }
+}
+
 static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, const double* acq_par, double plugin,
-                     int minimize, bool want_acq_out, bool need_var = true) {
+                     int minimize, bool want_acq_out, bool need_var = true, bool sync = true) {
+  collect_timing(h);  // the events are about to be re-recorded
   if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "no committed model: call bogp_commit first");
   if (!h->dXs || h->M <= 0) FAIL(h, BOGP_ERR_INVALID, "no candidates: call bogp_candidates_upload/bind first");
   if (q < 0 || q > BOGP_MAX_Q) FAIL(h, BOGP_ERR_INVALID, "q = %d outside [0, %d]", q, BOGP_MAX_Q);
@@ -870,6 +897,7 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     HIPCHK(h, hipStreamSynchronize(st));
     h->t_corr_ms = h->t_contract_ms = h->t_acq_ms = 0;
     h->n_chunks = 0;
+    h->timing_pending = false;
     return BOGP_OK;
   }
 
@@ -916,18 +944,18 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     HIPCHK(h, hipEventRecord(e0, st));
     HIPCHK(h, launch_sweep_small(h->kernel, sa, h->n_cu, st));
     HIPCHK(h, hipEventRecord(e1, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1);
+    h->n_chunks = 1;
+    h->timing_pending = true;
+    h->timing_fused = true;
+    if (sync || stamps) HIPCHK(h, hipStreamSynchronize(st));
     if (stamps) {
+      collect_timing(h);
       long long sv[5] = {0, 0, 0, 0, 0};
       HIPCHK(h, hipMemcpy(sv, h->dbatch, sizeof(sv), hipMemcpyDeviceToHost));
       const double nw = (double)std::max<long long>(1, sv[4]);
       fprintf(stderr, "k_sweep_small M=%lld: %.3f ms; per wave: produce %.0f, contract %.0f, wait-at-barrier %.0f, epilogue %.0f cycles (%lld waves)\n",
-              (long long)M, ms, sv[0] / nw, sv[1] / nw, sv[2] / nw, sv[3] / nw, sv[4]);
+              (long long)M, h->t_contract_ms, sv[0] / nw, sv[1] / nw, sv[2] / nw, sv[3] / nw, sv[4]);
     }
-    h->t_corr_ms = 0; h->t_contract_ms = ms; h->t_acq_ms = 0;  // one kernel: reported as the contraction's time
-    h->n_chunks = 1;
     return BOGP_OK;
   }
 
@@ -1036,18 +1064,11 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     blk_offset += (mcount + 255) / 256;
   }
   if (q > 0) HIPCHK(h, launch_argmax_final(h->dblk_val, h->dblk_idx, blk_offset, nblk_total, q, h->dbest_val, h->dbest_idx, st));
-  HIPCHK(h, hipStreamSynchronize(st));
-  if (overlap) HIPCHK(h, hipStreamSynchronize(stP));
-  h->t_corr_ms = h->t_contract_ms = h->t_acq_ms = 0;
-  for (int64_t c = 0; c < nchunk; ++c) {
-    float a = 0, b2 = 0, c2 = 0;
-    hipEvent_t* ev = &h->ev[(size_t)(c * EPC)];
-    (void)hipEventElapsedTime(&a, ev[0], ev[1]);
-    (void)hipEventElapsedTime(&b2, ev[2], ev[3]);
-    (void)hipEventElapsedTime(&c2, ev[3], ev[4]);
-    h->t_corr_ms += a; h->t_contract_ms += b2; h->t_acq_ms += c2;
-  }
   h->n_chunks = (int)nchunk;
+  h->timing_pending = true;
+  h->timing_fused = false;
+  if (sync || overlap) HIPCHK(h, hipStreamSynchronize(st));
+  if (overlap) HIPCHK(h, hipStreamSynchronize(stP));
   return BOGP_OK;
 }
 
@@ -1064,7 +1085,9 @@ extern "C" int bogp_predict(bogp_handle* h, double* mu, double* mse) {
 extern "C" int bogp_sweep(bogp_handle* h, int q, const int* acq_id, const double* acq_par, double plugin, int minimize,
                           double* best_val, int64_t* best_idx, double* acq_out) {
   if (!h) return BOGP_ERR_INVALID;
-  if (q <= 0 || !acq_id || !best_val || !best_idx) FAIL(h, BOGP_ERR_INVALID, "bogp_sweep: q > 0 and non-null acq_id/best_val/best_idx required");
+  if (q <= 0 || !acq_id || (!best_val != !best_idx)) FAIL(h, BOGP_ERR_INVALID, "bogp_sweep: q > 0, non-null acq_id, and best_val / best_idx both given or both NULL");
+  const bool local = best_val != nullptr;  // NULL outputs: the winners stay on the device for bogp_exchange_argmax
+  if (!local && acq_out) FAIL(h, BOGP_ERR_INVALID, "bogp_sweep: acq_out needs best_val / best_idx");
   for (int i = 0; i < q; ++i) {
     if (acq_id[i] < 0 || acq_id[i] > 3) FAIL(h, BOGP_ERR_INVALID, "unknown acquisition id %d", acq_id[i]);
     const bool zero_ok = acq_id[i] == BOGP_ACQ_EPSILON_PI;  // epsilon = 0 is plain PI
@@ -1072,9 +1095,10 @@ extern "C" int bogp_sweep(bogp_handle* h, int q, const int* acq_id, const double
       FAIL(h, BOGP_ERR_INVALID, "acquisition parameter %d must be > 0 (the reference asserts alpha/epsilon/t > 0)", i);
   }
   h->last_q = 0;
-  int rc = run_sweep(h, false, q, acq_id, acq_par, plugin, minimize, acq_out != nullptr);
+  int rc = run_sweep(h, false, q, acq_id, acq_par, plugin, minimize, acq_out != nullptr, true, local);
   if (rc) return rc;
   h->last_q = q;  // dbest_val / dbest_idx hold this sweep's winners for bogp_exchange_argmax
+  if (!local) return BOGP_OK;  // queued, not waited for: the exchange that follows is ordered behind it on the stream
   HIPCHK(h, hipMemcpy(best_val, h->dbest_val, q * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemcpy(best_idx, h->dbest_idx, q * sizeof(int64_t), hipMemcpyDeviceToHost));
   if (acq_out) HIPCHK(h, hipMemcpy(acq_out, h->dacq_out, (size_t)q * h->M * sizeof(double), hipMemcpyDeviceToHost));
@@ -1121,6 +1145,7 @@ extern "C" int bogp_sweep_topk(bogp_handle* h, int q, const int* acq_id, const d
 
 extern "C" int bogp_last_timing(bogp_handle* h, double* corr_ms, double* contract_ms, double* acquisition_ms, int* n_chunks) {
   if (!h) return BOGP_ERR_INVALID;
+  collect_timing(h);
   if (corr_ms) *corr_ms = h->t_corr_ms;
   if (contract_ms) *contract_ms = h->t_contract_ms;
   if (acquisition_ms) *acquisition_ms = h->t_acq_ms;

@@ -108,6 +108,7 @@ struct bogp_handle {
   std::vector<hipEvent_t> ev;
   double t_corr_ms = 0, t_contract_ms = 0, t_acq_ms = 0;
   int n_chunks = 0;
+  bool timing_pending = false, timing_fused = false;  // event times not read back yet / of the one-launch small-N sweep
 };
 
 #define FAIL(h, code, ...)                              \

@@ -146,7 +146,7 @@ def main():
     q = len(w["acq"])
 
     def step():
-        eng.sweep(w["acq"], plugin, True)
+        eng.sweep(w["acq"], plugin, True, local_result=False)  # queued; the exchange below is the step's one host wait
         return eng.exchange_argmax(q, offset, True)  # (values, GLOBAL indices, points), identical on every rank
 
     def fence():

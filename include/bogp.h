@@ -183,7 +183,9 @@ int bogp_predict(bogp_handle* h, double* mu, double* mse);
  *   minimize  0/1 as AcquisitionFunction.minimize
  *   best_val  out (q): acquisition value at the argmax;  best_idx out (q): np.argmax index (first
  *             maximum; a NaN, if present, wins at its first position) -- local to these M candidates
- *   acq_out   optional HOST buffer (q x M row-major) receiving every acquisition value; NULL to skip     */
+ *   acq_out   optional HOST buffer (q x M row-major) receiving every acquisition value; NULL to skip
+ * best_val and best_idx may BOTH be NULL: the sweep is then only queued on the handle's stream (no host wait, no
+ * read-back) and its winners stay on the device for the bogp_exchange_argmax call that follows (multi-GPU step).  */
 int bogp_sweep(bogp_handle* h, int q, const int* acq_id, const double* acq_par, double plugin, int minimize,
                double* best_val, int64_t* best_idx, double* acq_out);
 

@@ -246,3 +246,42 @@ def test_fused_small_sweep_equals_the_chunked_schedule_and_the_oracle(N, d, kern
             if np.all(solid) or int(np.argmax(ref)) != M // 2:
                 assert out["fused"][3][c] == int(np.argmax(ref)) == out["chunked"][3][c]
     eng.close()
+
+
+def test_library_exchange_with_a_one_rank_communicator():
+    """bogp_comm_init + bogp_exchange_argmax / bogp_exchange_topk on a one-rank RCCL communicator (all a 1-GPU box can
+    run): the queued sweep (no host read-back) followed by the exchange returns the sweep's own winners with the index
+    offset applied and the winning points attached; the top-k flavour likewise."""
+    from bogp import distributed
+
+    gp, X, y = _fitted_model(N=700, d=5)  # N > 512: the chunked schedule; the fused one is covered below
+    eng = gp.engine
+    assert distributed.init_engine_comm(eng) == (0, 1) and eng.comm_info() == (0, 1)
+    rng = np.random.default_rng(3)
+    acq = [(_lib.ACQ_EI, 0.0), (_lib.ACQ_MGFI, 2.0), (_lib.ACQ_UCB, 0.5)]
+    pl = float(y.min())
+    for n_train in (700, 300):
+        if n_train != 700:
+            gp2, X2, y2 = _fitted_model(N=n_train, d=5)
+            eng = gp2.engine
+            distributed.init_engine_comm(eng)
+            pl = float(y2.min())
+        Xs = rng.uniform(-5, 5, size=(3000, 5))
+        eng.upload_candidates(Xs)
+        best, idx = eng.sweep(acq, pl, True)
+        assert eng.sweep(acq, pl, True, local_result=False) is None
+        gv, gi, gx = eng.exchange_argmax(len(acq), 10_000_000_000, True)
+        np.testing.assert_array_equal(gv, best)
+        np.testing.assert_array_equal(gi, idx + 10_000_000_000)
+        np.testing.assert_array_equal(gx, Xs[idx])
+        tv, ti = eng.sweep_topk(acq, pl, True, 7)
+        ev, ei, ex = eng.exchange_topk(len(acq), 7, 123, True)
+        np.testing.assert_array_equal(ev, tv)
+        np.testing.assert_array_equal(ei, ti + 123)
+        np.testing.assert_array_equal(ex, Xs[ti])
+        # the optimiser front ends pick the library transport up by themselves
+        crit = [bogp.MGFI(model=gp if n_train == 700 else gp2, t=1.0), bogp.MGFI(model=gp if n_train == 700 else gp2, t=3.0)]
+        v, g, x = bogp.sweep_argmax(crit, Xs, index_offset=50)
+        assert np.all(g >= 50) and np.array_equal(x, Xs[g - 50])
+    eng.comm_destroy()
+    assert eng.comm_info() == (0, 0)
