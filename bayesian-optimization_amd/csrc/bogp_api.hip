@@ -118,7 +118,8 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
   if (d > BOGP_MAX_DIM) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_set_train: d = %d > %d: the sweep producer keeps a 64 x d candidate tile in the CU's 160 KB of LDS", d, BOGP_MAX_DIM);
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  const int ld_need = ((N + 63) / 64) * 64;
+  // leading dimension: N rounded up to 64; to 128 from 4096 on, where the factorisation works on 128 x 128 tiles
+  const int ld_need = N > 4032 ? ((N + 127) / 128) * 128 : ((N + 63) / 64) * 64;
   const bool fits = h->dX && ld_need <= h->cap_ld && d <= h->cap_d && n_targets <= h->cap_nt;
   if (fits) {
     free_trend(h);  // N x p buffers of a polynomial basis: rebuilt on demand
@@ -448,7 +449,8 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
   // R^-1 = cho_solve(L, I) (:997) via potri on a copy of L
   const int ldr = h->ldr;
   if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * h->cap_ld * h->cap_ld * sizeof(double)));
-  HIPCHK(h, launch_uut(h->dU, h->dRinv, ldr, st));  // R^-1 = L^-T L^-1, lower triangle
+  int nparts = UUT_PARTS;
+  HIPCHK(h, launch_uut(h->dU, h->dRinv, ldr, st, &nparts));  // R^-1 = L^-T L^-1, lower triangle
   const int nblk = grad_contract_blocks(N);
   int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)nblk * (d + 1) + (d + 4));
   if (e) return e;
@@ -465,12 +467,12 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
     gv.cB[t] = 1.0 / o.s2t_t[t];
     gv.cA[t] = mode == BOGP_MODE_NOISY ? gv.cB[t] : inv_sum;
   }
-  HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, gv, nullptr, 0.0, h->dRinv, ldr, UUT_PARTS, (size_t)ldr * ldr, h->dgrad_partial, nblk, st));
+  HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, gv, nullptr, 0.0, h->dRinv, ldr, nparts, (size_t)ldr * ldr, h->dgrad_partial, nblk, st));
   double* dS = h->dgrad_partial + (size_t)nblk * (d + 1);
   HIPCHK(h, launch_grad_reduce(h->dgrad_partial, nblk, d + 1, dS, st));
   std::vector<double> S(d + 3);
   if (mode == BOGP_MODE_NOISY) {
-    HIPCHK(h, launch_trace_gg(h->dRinv, ldr, UUT_PARTS, (size_t)ldr * ldr, N, h->dgamma_base, nullptr, dS + d + 1, st));
+    HIPCHK(h, launch_trace_gg(h->dRinv, ldr, nparts, (size_t)ldr * ldr, N, h->dgamma_base, nullptr, dS + d + 1, st));
     if (n_t > 1) HIPCHK(h, launch_sumsq(h->dgamma_base, n_t * h->Np, dS + d + 2, st));  // sum_t gamma_t . gamma_t (zero padding)
   }
   HIPCHK(h, hipMemcpyAsync(S.data(), dS, (d + 3) * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -531,7 +533,8 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
     if (n_theta != d) FAIL(h, BOGP_ERR_UNSUPPORTED, "gradient with isotropic theta (len %d, d = %d) is not built", n_theta, d);
     hipStream_t st = h->stream;
     if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * h->cap_ld * h->cap_ld * sizeof(double)));
-    HIPCHK(h, launch_uut(h->dU, h->dRinv, ldr, st));
+    int nparts = UUT_PARTS;
+    HIPCHK(h, launch_uut(h->dU, h->dRinv, ldr, st, &nparts));
     const double* qv = nullptr;
     double c2 = 0.0;
     if (estimate_trend) {  // q = L^-T Q = (L^-T Ft) / G
@@ -545,11 +548,11 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
     if (e) return e;
     GradVecs gv;
     gv.v = h->dgamma; gv.stride = 0; gv.n = 1; gv.c0 = 1.0; gv.cA[0] = gv.cB[0] = 1.0 / tv;
-    HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, gv, qv, c2, h->dRinv, ldr, UUT_PARTS,
+    HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, gv, qv, c2, h->dRinv, ldr, nparts,
                                    (size_t)ldr * ldr, h->dgrad_partial, nblk, st));
     double* dS = h->dgrad_partial + (size_t)nblk * (d + 1);
     HIPCHK(h, launch_grad_reduce(h->dgrad_partial, nblk, d + 1, dS, st));
-    HIPCHK(h, launch_trace_gg(h->dRinv, ldr, UUT_PARTS, (size_t)ldr * ldr, N, h->dgamma, qv, dS + d + 1, st));
+    HIPCHK(h, launch_trace_gg(h->dRinv, ldr, nparts, (size_t)ldr * ldr, N, h->dgamma, qv, dS + d + 1, st));
     std::vector<double> S(d + 4);
     HIPCHK(h, hipMemcpyAsync(S.data(), dS, (d + 4) * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));

@@ -129,7 +129,7 @@ hipError_t launch_pad_identity(double* A, int N, int ld, hipStream_t st);
 hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStream_t st);
 hipError_t launch_tri_inverse(const double* L, const double* Winv, double* V, double* U, double* T, int ld, hipStream_t st);
 constexpr int UUT_PARTS = 4;  // R^-1 = U U^T is produced as this many K-slices (ld*ld doubles apart) that the consumers add
-hipError_t launch_uut(const double* U, double* Rinv, int ld, hipStream_t st);
+hipError_t launch_uut(const double* U, double* Rinv, int ld, hipStream_t st, int* nparts);
 hipError_t launch_copy_lower(const double* L, int N, int ld, double* dst, hipStream_t st);
 // the rank-1 terms of the likelihood gradient: vectors v + t * stride (t < n) with weights cA (theta contractions) and
 // cB (R0 contraction); c0 multiplies R^-1

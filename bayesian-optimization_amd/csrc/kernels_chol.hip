@@ -239,7 +239,10 @@ __device__ __forceinline__ void diag_store(double* __restrict__ Ad /* &A[i0 + i0
 // ---------------------------------------------------------------------------------------------------------------
 // First diagonal block (nothing to subtract yet).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol_first(double* __restrict__ A, int ld, double* __restrict__ W0, int* __restrict__ info) {
+// (base, reset): the two-level variant factors later diagonal blocks with this kernel too -- `base` = first row of the
+// block (LAPACK's info counts from the matrix origin), reset = 0 keeps an earlier failure.
+__global__ __launch_bounds__(256) void k_chol_first(double* __restrict__ A, int ld, double* __restrict__ W0, int* __restrict__ info,
+                                                    int base = 0, int reset = 1) {
   __shared__ __attribute__((aligned(16))) double cs[CB * (CB + 1)];
   __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
   const int tid = threadIdx.x;
@@ -251,7 +254,12 @@ __global__ __launch_bounds__(256) void k_chol_first(double* __restrict__ A, int 
   double a[4][4], w[4][4];
   const int bad = diag_factor_invert(cs, sb, a, w, tid);
   diag_store(A, ld, W0, a, w, tid);
-  if (tid == 0) *info = bad;  // also resets the flag of the previous factorisation
+  if (tid == 0) {
+    if (reset)
+      *info = bad;  // also resets the flag of the previous factorisation
+    else if (bad != 0 && *info == 0)
+      *info = base + bad;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -284,11 +292,12 @@ __global__ __launch_bounds__(256) void k_chol_panel(const double* __restrict__ W
 // next diagonal block.  Grid: m*m workgroups, m = nb - k - 1; workgroup (bi, bj) with bj > bi leaves at once.
 // Xc -> A[k0*ld] is its own read-only argument: that block column is disjoint from everything this kernel writes.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, const double* __restrict__ Xc, int ld, int k0, int m,
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, const double* __restrict__ Xc, int ld, int k0, int m, int nc,
                                                      double* __restrict__ Wn, int* __restrict__ info) {
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];  // 40 KB: A-side tile, then the 64 x 65 block staging
   __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
-  const int bi = blockIdx.x / m, bj = blockIdx.x % m;
+  // nc = block columns updated (m for the plain right-looking sweep; fewer inside a panel of the two-level variant)
+  const int bi = blockIdx.x / nc, bj = blockIdx.x % nc;
   if (bj > bi) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -437,25 +446,341 @@ __global__ __launch_bounds__(256) void k_tri_base(const double* __restrict__ Win
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Large matrices (ld >= 4096): the same products on 128 x 128 tiles.
+//
+// The 64 x 64 tile product above moves 64 KB of operands per 0.5 MFLOP (8 flop/B) and, at N = 8192, none of the 512 MB
+// matrices stays in a cache: the inverse ran at 39 TF/s and the rank-64 trailing updates of the factorisation at
+// 22 TF/s (profiles/r01_nll_n8192_kernel_stats.csv).  k_mm128 forms out(128 x 128) = alpha * Rside Cside^T (+ out):
+//   * BOTH operands go through LDS (k-major tiles of 16 x 128, pitch 144 doubles: the four k-rows of a fragment read fall
+//     into different 128-byte bank groups), register-staged global -> LDS one k-block ahead, two LDS buffers, one barrier
+//     per k-block; 4 waves x (64 x 64) outputs = 16 d4 accumulators per wave, two workgroups per CU;
+//   * the MFMA's A operand is the COLUMN side, so that D's lane index (lane & 15) runs along the rows of the column-major
+//     output: every store instruction writes 128-byte row segments;
+//   * workgroups are dealt to tiles XCD-aware (mm_tile_of): inside every 8 x 8 super tile each XCD owns a 2 x 4 block, so
+//     its workgroups share operand panels through that XCD's L2 and all XCDs carry the same mix of long and short K;
+//   * structure is exploited at tile level: tiles above the diagonal leave at once, K ranges follow the triangles.
+// Two-level Cholesky: 256-wide panels are factored by the 64-block kernels above (updates confined to the panel), the
+// trailing matrix then receives ONE rank-256 update from k_mm128 instead of four rank-64 ones.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int MB = 128;        // tile edge
+constexpr int MKB = 16;        // k rows per LDS stage
+constexpr int MPT = MB + 16;   // LDS pitch in doubles
+constexpr int BIG_LD = 4096;
+
+struct MmTile {
+  const double* Rs;  // row-side operand: element (row, k) at Rs[row + k * ldr]
+  const double* Cs;  // column-side operand: element (col, k) at Cs[col + k * ldc]
+  double* out;       // out(row, col) at out[row + col * ldo]
+  int ldr, ldc, ldo;
+  int k0, k1;        // K range, multiples of MKB
+  double alpha;
+  int beta;          // 1: out += alpha * product
+};
+
+__device__ __forceinline__ void mm128_tile(const MmTile& t, double* lds) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w & 1, wn = w >> 1;  // this wave: rows 64 wm .., columns 64 wn ..
+  const int lk = lane >> 4, li = lane & 15;
+  d4 acc[4][4];  // [column fragment][row fragment]
+  if (t.beta) {
+    // out += alpha * product with alpha = +-1: start from alpha * out (exact) and scale by alpha at the end.  All 64 loads
+    // of the tile are issued before anything waits on them (a read-modify-write in the epilogue serialises 64 round trips
+    // per thread: measured 100 us per workgroup)
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double* __restrict__ o = t.out + (size_t)(64 * wn + 16 * ci + 4 * r + lk) * t.ldo + 64 * wm + li;
+#pragma unroll
+        for (int rj = 0; rj < 4; ++rj) acc[ci][rj][r] = t.alpha * o[16 * rj];
+      }
+  } else {
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int rj = 0; rj < 4; ++rj) acc[ci][rj] = (d4){0.0, 0.0, 0.0, 0.0};
+  }
+  const int nkb = (t.k1 - t.k0) / MKB;
+  if (nkb > 0) {
+    const int srow = tid >> 6, scol = (tid & 63) * 2;
+    const double* __restrict__ rbase = t.Rs + (size_t)t.k0 * t.ldr + scol;
+    const double* __restrict__ cbase = t.Cs + (size_t)t.k0 * t.ldc + scol;
+    double2 r0, r1, r2, r3, c0, c1, c2, c3;
+#define BOGP_MM_LOAD(kb_)                                                                 \
+  do {                                                                                    \
+    const double* pr_ = rbase + (size_t)((kb_)*MKB + srow) * t.ldr;                       \
+    const double* pc_ = cbase + (size_t)((kb_)*MKB + srow) * t.ldc;                       \
+    r0 = *reinterpret_cast<const double2*>(pr_);                                          \
+    r1 = *reinterpret_cast<const double2*>(pr_ + (size_t)4 * t.ldr);                      \
+    r2 = *reinterpret_cast<const double2*>(pr_ + (size_t)8 * t.ldr);                      \
+    r3 = *reinterpret_cast<const double2*>(pr_ + (size_t)12 * t.ldr);                     \
+    c0 = *reinterpret_cast<const double2*>(pc_);                                          \
+    c1 = *reinterpret_cast<const double2*>(pc_ + (size_t)4 * t.ldc);                      \
+    c2 = *reinterpret_cast<const double2*>(pc_ + (size_t)8 * t.ldc);                      \
+    c3 = *reinterpret_cast<const double2*>(pc_ + (size_t)12 * t.ldc);                     \
+  } while (0)
+#define BOGP_MM_STORE(buf_)                                                               \
+  do {                                                                                    \
+    double* qr_ = lds + (buf_)*2 * MKB * MPT + srow * MPT + scol;                         \
+    double* qc_ = qr_ + MKB * MPT;                                                        \
+    *reinterpret_cast<double2*>(qr_) = r0;                                                \
+    *reinterpret_cast<double2*>(qr_ + 4 * MPT) = r1;                                      \
+    *reinterpret_cast<double2*>(qr_ + 8 * MPT) = r2;                                      \
+    *reinterpret_cast<double2*>(qr_ + 12 * MPT) = r3;                                     \
+    *reinterpret_cast<double2*>(qc_) = c0;                                                \
+    *reinterpret_cast<double2*>(qc_ + 4 * MPT) = c1;                                      \
+    *reinterpret_cast<double2*>(qc_ + 8 * MPT) = c2;                                      \
+    *reinterpret_cast<double2*>(qc_ + 12 * MPT) = c3;                                     \
+  } while (0)
+    const int roff = lk * MPT + 64 * wm + li, coff = MKB * MPT + lk * MPT + 64 * wn + li;
+    BOGP_MM_LOAD(0);
+    BOGP_MM_STORE(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+      __syncthreads();  // block kb is in buffer kb & 1; every wave is done with the other buffer
+      BOGP_MM_LOAD(min(kb + 1, nkb - 1));
+      // keep the loads HERE: left alone, the scheduler sinks them below the MFMAs, next to the LDS stores that consume them
+      // (fewer live registers), and every k-block then waits out the full global latency (measured: 20 TF/s)
+      __builtin_amdgcn_sched_barrier(0);
+      const double* tb = lds + (kb & 1) * 2 * MKB * MPT;
+      double rf[2][4], cf[2][4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        rf[0][f] = tb[roff + 16 * f];
+        cf[0][f] = tb[coff + 16 * f];
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) {
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            rf[(ks + 1) & 1][f] = tb[roff + 4 * (ks + 1) * MPT + 16 * f];
+            cf[(ks + 1) & 1][f] = tb[coff + 4 * (ks + 1) * MPT + 16 * f];
+          }
+        }
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+          for (int rj = 0; rj < 4; ++rj) mfma16(cf[ks & 1][ci], rf[ks & 1][rj], acc[ci][rj]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      BOGP_MM_STORE((kb + 1) & 1);
+    }
+#undef BOGP_MM_LOAD
+#undef BOGP_MM_STORE
+    BOGP_CHOL_DRAIN();
+  }
+  // D[i][j]: i = column (MFMA A side), j = row; lane 16 (i % 4) + j, register i / 4
+  // (out = alpha * acc: with beta the accumulators started from alpha * out, and alpha^2 = 1)
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double* __restrict__ o = t.out + (size_t)(64 * wn + 16 * ci + 4 * r + lk) * t.ldo + 64 * wm + li;
+#pragma unroll
+      for (int rj = 0; rj < 4; ++rj) o[16 * rj] = t.alpha * acc[ci][rj][r];
+    }
+}
+
+enum { MM_UUT = 0, MM_T = 1, MM_V = 2, MM_U = 3, MM_SYRK = 4 };
+struct MmArgs {
+  const double* L;
+  double* V;
+  double* U;
+  double* T;
+  double* Rinv;
+  double* A;   // MM_SYRK: the matrix being factored
+  int ld, nt;  // nt = ld / 128
+  int nb2;     // MM_T / V / U: 128-tiles per diagonal block of this level
+  int t0;      // MM_SYRK: first trailing tile;  kp0 / kp1: the panel's columns
+  int kp0, kp1;
+  int TI, TJ;  // logical tile grid of one z / y slice
+};
+
+// workgroup -> tile.  Hardware deals consecutive workgroups round-robin to the 8 XCDs, each with its own L2.  The grid is
+// walked in 8 x 8 SUPER tiles of 64 consecutive workgroups; inside one, XCD x = b % 8 gets the 2 x 4 block of tiles
+// (rows 2 (x >> 1) .., columns 4 (x & 1) ..): its 8 workgroups share 2 row panels and 4 column panels through that L2
+// (6 panel streams for 8 tiles), and EVERY XCD takes an eighth of every super tile -- the triangular products have rows
+// whose K differs by 64x, and a first version that gave whole super tiles to XCDs left one XCD with 2.5x the average
+// work (and small grids on a single XCD).
+__device__ __forceinline__ bool mm_tile_of(int TI, int TJ, int& ti, int& tj) {
+  const int SJ = (TJ + 7) / 8;
+  const int b = blockIdx.x;
+  const int s = b >> 6, r = b & 63;
+  const int x = r & 7, y = r >> 3;
+  const int si = s / SJ, sj = s - si * SJ;
+  ti = si * 8 + (x >> 1) * 2 + (y >> 2);
+  tj = sj * 8 + (x & 1) * 4 + (y & 3);
+  return ti < TI && tj < TJ;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void k_mm128(MmArgs a, int mode0) {
+  extern __shared__ __attribute__((aligned(16))) double mm_lds[];
+  const int mode = mode0 + (int)blockIdx.z;
+  int ti, tj;
+  if (!mm_tile_of(a.TI, a.TJ, ti, tj)) return;
+  const int ld = a.ld;
+  MmTile t;
+  t.ldr = t.ldc = t.ldo = ld;
+  t.alpha = 1.0;
+  t.beta = 0;
+  if (mode == MM_UUT) {  // R^-1(i, j) = sum_{k >= i} U(i, k) U(j, k), lower tiles
+    if (tj > ti) return;
+    t.Rs = a.U + (size_t)ti * MB;
+    t.Cs = a.U + (size_t)tj * MB;
+    t.out = a.Rinv + (size_t)ti * MB + (size_t)tj * MB * ld;
+    t.k0 = ti * MB;
+    t.k1 = ld;
+  } else if (mode == MM_SYRK) {  // A22(i, j) -= sum_{k in panel} P(i, k) P(j, k), lower tiles (diagonal tiles in full)
+    if (tj > ti) return;
+    t.Rs = a.A + (size_t)(a.t0 + ti) * MB;
+    t.Cs = a.A + (size_t)(a.t0 + tj) * MB;
+    t.out = a.A + (size_t)(a.t0 + ti) * MB + (size_t)(a.t0 + tj) * MB * ld;
+    t.k0 = a.kp0;
+    t.k1 = a.kp1;
+    t.alpha = -1.0;
+    t.beta = 1;
+  } else {
+    const int nb2 = a.nb2;
+    const int o11 = 2 * (int)blockIdx.y * nb2, o22 = o11 + nb2;
+    const int n22 = min(nb2, a.nt - o22);
+    if (mode == MM_T) {  // Tt(c, r) = sum_{k >= c} U11(c, k) L21(r, k): c in block 11 (ti), r in block 22 (tj)
+      if (tj >= n22) return;
+      t.Rs = a.U + (size_t)(o11 + ti) * MB;
+      t.Cs = a.L + (size_t)(o22 + tj) * MB;
+      t.out = a.T + (size_t)(o11 + ti) * MB + (size_t)(o22 + tj) * MB * ld;
+      t.k0 = (o11 + ti) * MB;
+      t.k1 = o22 * MB;
+    } else if (mode == MM_V) {  // V21(r, c) = -sum_{k <= r} V22(r, k) Tt(c, k): r in block 22 (ti), c in block 11 (tj)
+      ti = nb2 - 1 - ti;  // K grows with r: the long tiles are dispatched first
+      if (ti >= n22) return;
+      t.Rs = a.V + (size_t)(o22 + ti) * MB;
+      t.Cs = a.T + (size_t)(o11 + tj) * MB;
+      t.out = a.V + (size_t)(o22 + ti) * MB + (size_t)(o11 + tj) * MB * ld;
+      t.k0 = o22 * MB;
+      t.k1 = (o22 + ti + 1) * MB;
+      t.alpha = -1.0;
+    } else {  // MM_U: U12(c, r) = -sum_{k <= r} Tt(c, k) V22(r, k): c in block 11 (ti), r in block 22 (tj)
+      {  // K grows with r = the COLUMN here: walk the grid transposed and reversed so that the long tiles go first
+        const int a_ = nb2 - 1 - ti;
+        ti = tj;
+        tj = a_;
+      }
+      if (tj >= n22) return;
+      t.Rs = a.T + (size_t)(o11 + ti) * MB;
+      t.Cs = a.V + (size_t)(o22 + tj) * MB;
+      t.out = a.U + (size_t)(o11 + ti) * MB + (size_t)(o22 + tj) * MB * ld;
+      t.k0 = o22 * MB;
+      t.k1 = (o22 + tj + 1) * MB;
+      t.alpha = -1.0;
+    }
+  }
+  mm128_tile(t, mm_lds);
+}
+
+// U12 = V21^T for every pair of a level (the third product of the recursive doubling is a transposition of the second):
+// 64 x 64 tiles through LDS, both sides coalesced.  grid (tiles of r in block 22, tiles of c in block 11, pairs).
+__global__ __launch_bounds__(256) void k_transpose_v21(const double* __restrict__ V, double* __restrict__ U, int ld, int nt, int nb2) {
+  __shared__ double tl[64][65];
+  const int o11 = 2 * (int)blockIdx.z * nb2 * 2, o22 = o11 + nb2 * 2;  // in 64-blocks
+  const int n22 = min(nb2 * 2, 2 * nt - o22);
+  if ((int)blockIdx.x >= n22) return;
+  const int r0 = (o22 + blockIdx.x) * 64, c0 = (o11 + blockIdx.y) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int c = ty; c < 64; c += 4) tl[c][tx] = V[(size_t)(c0 + c) * ld + r0 + tx];  // V21(r0 + tx, c0 + c)
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) U[(size_t)(r0 + r) * ld + c0 + tx] = tl[tx][r];  // U12(c0 + tx, r0 + r)
+}
+
+static bool big_path(int ld) {
+  const char* e = getenv("BOGP_NO_BIG_FIT");
+  return ld >= BIG_LD && ld % MB == 0 && !(e && atoi(e) != 0);
+}
+
+static hipError_t launch_mm128(MmArgs a, int mode, int TI, int TJ, int ny, int nz, hipStream_t st) {
+  constexpr int shm = 2 * 2 * MKB * MPT * (int)sizeof(double);  // 73.7 KB: two stages of (row tile + column tile)
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm128), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  a.TI = TI;
+  a.TJ = TJ;
+  const int nsuper = ((TI + 7) / 8) * ((TJ + 7) / 8);
+  hipLaunchKernelGGL(k_mm128, dim3((unsigned)(nsuper * 64), ny, nz), 256, shm, st, a, mode);
+  return hipGetLastError();
+}
+
+// two-level right-looking Cholesky: panels of 4 block columns (256); inside a panel the 64-block kernels with their updates
+// confined to the panel; then one rank-256 update of the trailing matrix and the factorisation of its first block
+static hipError_t launch_chol_lower_big(double* A, int ld, double* Winv, int* info, hipStream_t st) {
+  const int nb = ld / CB;
+  hipLaunchKernelGGL(k_chol_first, dim3(1), 256, 0, st, A, ld, Winv, info, 0, 1);
+  for (int kbeg = 0; kbeg < nb; kbeg += 4) {
+    const int kend = min(nb, kbeg + 4);
+    for (int k = kbeg; k < kend; ++k) {
+      const int m = nb - k - 1, k0 = k * CB;
+      if (m == 0) break;
+      hipLaunchKernelGGL(k_chol_panel, dim3(m), 256, 0, st, Winv + (size_t)k * CB * CB, A + (size_t)k0 * ld + k0 + CB, ld);
+      const int nc = kend - 1 - k;  // block columns of this panel still to the right of k
+      if (nc > 0)
+        hipLaunchKernelGGL(k_chol_update, dim3(m * nc), 256, 0, st, A, A + (size_t)k0 * ld, ld, k0, m, nc,
+                           Winv + (size_t)(k + 1) * CB * CB, info);
+    }
+    if (kend < nb) {
+      MmArgs a{};
+      a.A = A; a.ld = ld; a.nt = ld / MB;
+      a.t0 = kend / 2; a.kp0 = kbeg * CB; a.kp1 = kend * CB;
+      const int TT = a.nt - a.t0;
+      hipError_t e = launch_mm128(a, MM_SYRK, TT, TT, 1, 1, st);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k_chol_first, dim3(1), 256, 0, st, A + (size_t)kend * CB * (ld + 1), ld, Winv + (size_t)kend * CB * CB, info,
+                         kend * CB, 0);
+    }
+  }
+  return hipGetLastError();
+}
+
 // V = L^-1 (lower) and U = V^T (upper), both ld x ld column-major; their other triangles must be zero on entry and stay
 // zero.  T: scratch of the same shape.
 hipError_t launch_tri_inverse(const double* L, const double* Winv, double* V, double* U, double* T, int ld, hipStream_t st) {
   const int nb = ld / CB;
   hipLaunchKernelGGL(k_tri_base, dim3(nb), 256, 0, st, Winv, V, U, ld);
   TriArgs a{L, V, U, T, nullptr, ld, nb, 0};
+  const bool big = big_path(ld);
   for (int level = 0; (1 << level) < nb; ++level) {
     const int nbb = 1 << level;
     const int pairs = (nb + 2 * nbb - 1) / (2 * nbb);
     a.level = level;
+    if (big && level >= 1) {  // blocks of >= 128: the 128 x 128 tile product
+      MmArgs m{};
+      m.L = L; m.V = V; m.U = U; m.T = T; m.ld = ld; m.nt = ld / MB; m.nb2 = nbb / 2;
+      hipError_t e = launch_mm128(m, MM_T, m.nb2, m.nb2, pairs, 1, st);
+      if (e != hipSuccess) return e;
+      if ((e = launch_mm128(m, MM_V, m.nb2, m.nb2, pairs, 1, st)) != hipSuccess) return e;
+      hipLaunchKernelGGL(k_transpose_v21, dim3(nbb, nbb, pairs), 256, 0, st, V, U, ld, m.nt, m.nb2);
+      continue;
+    }
     hipLaunchKernelGGL(k_tri_gemm, dim3(nbb * nbb, pairs, 1), 256, 0, st, a, (int)TG_TRTRI_T);
     hipLaunchKernelGGL(k_tri_gemm, dim3(nbb * nbb, pairs, 2), 256, 0, st, a, (int)TG_TRTRI_V);
   }
   return hipGetLastError();
 }
 
-// sum of the UUT_PARTS slices at Rinv + q*ld*ld (lower triangle, full diagonal tiles) = U U^T = L^-T L^-1
-hipError_t launch_uut(const double* U, double* Rinv, int ld, hipStream_t st) {
+// sum of the *nparts slices at Rinv + q*ld*ld (lower triangle, full diagonal tiles) = U U^T = L^-T L^-1
+hipError_t launch_uut(const double* U, double* Rinv, int ld, hipStream_t st, int* nparts) {
   const int nb = ld / CB;
+  if (big_path(ld)) {  // one slice: the long-K tiles are spread over the XCDs by the tile order instead of K-slicing
+    MmArgs m{};
+    m.U = const_cast<double*>(U); m.Rinv = Rinv; m.ld = ld; m.nt = ld / MB;
+    *nparts = 1;
+    return launch_mm128(m, MM_UUT, m.nt, m.nt, 1, 1, st);
+  }
+  *nparts = UUT_PARTS;
   TriArgs a{nullptr, nullptr, const_cast<double*>(U), nullptr, Rinv, ld, nb, 0};
   hipLaunchKernelGGL(k_tri_gemm, dim3(nb * nb, UUT_PARTS, 1), 256, 0, st, a, (int)TG_UUT);
   return hipGetLastError();
@@ -480,12 +805,13 @@ hipError_t launch_pad_identity(double* A, int N, int ld, hipStream_t st) {
 // pivot, as LAPACK reports it.
 hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStream_t st) {
   const int nb = ld / CB;
-  hipLaunchKernelGGL(k_chol_first, dim3(1), 256, 0, st, A, ld, Winv, info);
+  if (big_path(ld)) return launch_chol_lower_big(A, ld, Winv, info, st);
+  hipLaunchKernelGGL(k_chol_first, dim3(1), 256, 0, st, A, ld, Winv, info, 0, 1);
   for (int k = 0; k + 1 < nb; ++k) {
     const int k0 = k * CB;
     const int m = nb - k - 1;
     hipLaunchKernelGGL(k_chol_panel, dim3(m), 256, 0, st, Winv + (size_t)k * CB * CB, A + (size_t)k0 * ld + k0 + CB, ld);
-    hipLaunchKernelGGL(k_chol_update, dim3(m * m), 256, 0, st, A, A + (size_t)k0 * ld, ld, k0, m,
+    hipLaunchKernelGGL(k_chol_update, dim3(m * m), 256, 0, st, A, A + (size_t)k0 * ld, ld, k0, m, m,
                        Winv + (size_t)(k + 1) * CB * CB, info);
   }
   return hipGetLastError();

@@ -285,3 +285,50 @@ def test_library_exchange_with_a_one_rank_communicator():
         assert np.all(g >= 50) and np.array_equal(x, Xs[g - 50])
     eng.comm_destroy()
     assert eng.comm_info() == (0, 0)
+
+
+@pytest.mark.parametrize("N", [4096, 4100, 5000])
+def test_large_fit_path_equals_the_64_block_path(N):
+    """From ld = 4096 on the factorisation runs on 128 x 128 tiles (two-level Cholesky with rank-256 trailing updates,
+    recursive-doubling inverse and R^-1 = U U^T through k_mm128; kernels_chol.hip).  Same mathematics, other summation
+    order: likelihood, gradient, committed state and posterior against the 64-block path (BOGP_NO_BIG_FIT=1), incl. a
+    size whose tile count is not a power of two, and the -inf convention on a singular matrix."""
+    import os
+
+    d = 6
+    rng = np.random.default_rng(N)
+    X = rng.uniform(-5, 5, size=(N, d))
+    y = np.sum(X**2, axis=1)
+    y = ((y - y.mean()) / y.std() + 0.3 * rng.standard_normal(N)).reshape(-1, 1)
+    par = np.r_[np.full(d, 0.2) * rng.uniform(0.8, 1.2, size=d), 0.9]
+    Xs = rng.uniform(-5, 5, size=(300, d))
+    out = {}
+    for tag, flag in (("big", "0"), ("small", "1")):
+        os.environ["BOGP_NO_BIG_FIT"] = flag
+        try:
+            eng = _lib.Engine(0)
+            eng.set_train(X, y)
+            llf, grad = eng.nll(_lib.KERNEL_MATERN32, _lib.MODE_NOISY, par, 1e-6, True, 0.0, eval_grad=True)
+            llf_c = eng.commit(_lib.KERNEL_MATERN32, _lib.MODE_NOISY, par, 1e-6, True, 0.0)
+            st = eng.get_state()
+            eng.upload_candidates(Xs)
+            mu, mse = eng.predict()
+            out[tag] = (llf, grad, llf_c, st, mu, mse)
+            if tag == "big":  # duplicated rows without a nugget: not positive definite, reported as LAPACK would
+                Xd = X.copy()
+                Xd[N - 7] = Xd[3]
+                eng.set_train(Xd, y)
+                with pytest.raises(_lib.NotPositiveDefinite):
+                    eng.commit(_lib.KERNEL_SE, _lib.MODE_NOISELESS, par[:-1])
+            eng.close()
+        finally:
+            del os.environ["BOGP_NO_BIG_FIT"]
+    b, s = out["big"], out["small"]
+    np.testing.assert_allclose(b[0], s[0], rtol=1e-11)
+    np.testing.assert_allclose(b[2], s[2], rtol=1e-11)
+    np.testing.assert_allclose(b[1], s[1], rtol=1e-8, atol=1e-9 * np.abs(s[1]).max())
+    scale = np.abs(s[3]["C"]).max()
+    np.testing.assert_allclose(b[3]["C"], s[3]["C"], rtol=0, atol=1e-11 * scale)
+    np.testing.assert_allclose(b[3]["gamma"], s[3]["gamma"], rtol=1e-6, atol=1e-8 * np.abs(s[3]["gamma"]).max())
+    np.testing.assert_allclose(b[4], s[4], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(b[5], s[5], rtol=1e-6, atol=1e-11)

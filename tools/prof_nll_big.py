@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, "/root/repo")
 import numpy as np
 from bogp import _lib
 eng = _lib.Engine(0)
