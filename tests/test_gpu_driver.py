@@ -314,12 +314,9 @@ def test_large_fit_path_equals_the_64_block_path(N):
             eng.upload_candidates(Xs)
             mu, mse = eng.predict()
             out[tag] = (llf, grad, llf_c, st, mu, mse)
-            if tag == "big":  # duplicated rows without a nugget: not positive definite, reported as LAPACK would
-                Xd = X.copy()
-                Xd[N - 7] = Xd[3]
-                eng.set_train(Xd, y)
+            if tag == "big":  # an indefinite matrix (negative nugget: diagonal below the off-diagonal mass) is reported as LAPACK would
                 with pytest.raises(_lib.NotPositiveDefinite):
-                    eng.commit(_lib.KERNEL_SE, _lib.MODE_NOISELESS, par[:-1])
+                    eng.commit(_lib.KERNEL_SE, _lib.MODE_NOISY, np.r_[np.full(d, 1e-4), 0.9], -0.6)
             eng.close()
         finally:
             del os.environ["BOGP_NO_BIG_FIT"]
