@@ -60,6 +60,12 @@ extern "C" int bogp_create(int device, bogp_handle** out) {
     return BOGP_ERR_HIP;
   }
   rocblas_set_pointer_mode(h->blas, rocblas_pointer_mode_host);
+  if (hipEventCreateWithFlags(&h->ev_chol[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_chol[1], hipEventDisableTiming) != hipSuccess) {
+    g_create_error = "event creation failed";
+    delete h;
+    return BOGP_ERR_HIP;
+  }
   *out = h;
   return BOGP_OK;
 }
@@ -95,6 +101,8 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   dfree(h->dbest_val); dfree(h->dbest_idx); dfree(h->dtopk_val); dfree(h->dtopk_idx); dfree(h->dcounter); dfree(h->dinfo); dfree(h->dscal); dfree(h->dgrad_partial); dfree(h->dbatch);
   dfree(h->dTt); dfree(h->dCS); dfree(h->duu); dfree(h->dmtrend);
   for (auto e : h->ev) (void)hipEventDestroy(e);
+  for (int i = 0; i < 2; ++i)
+    if (h->ev_chol[i]) (void)hipEventDestroy(h->ev_chol[i]);
   if (h->blas) rocblas_destroy_handle(h->blas);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
@@ -118,8 +126,8 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
   if (d > BOGP_MAX_DIM) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_set_train: d = %d > %d: the sweep producer keeps a 64 x d candidate tile in the CU's 160 KB of LDS", d, BOGP_MAX_DIM);
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  // leading dimension: N rounded up to 64; to 128 from 4096 on, where the factorisation works on 128 x 128 tiles
-  const int ld_need = N > 4032 ? ((N + 127) / 128) * 128 : ((N + 63) / 64) * 64;
+  // leading dimension: N rounded up to 64; to 128 from 6144 on, where the inverse and R^-1 work on 128 x 128 tiles
+  const int ld_need = N > 6080 ? ((N + 127) / 128) * 128 : ((N + 63) / 64) * 64;
   const bool fits = h->dX && ld_need <= h->cap_ld && d <= h->cap_d && n_targets <= h->cap_nt;
   if (fits) {
     free_trend(h);  // N x p buffers of a polynomial basis: rebuilt on demand
@@ -337,7 +345,7 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   //   Yt = V y (:799), Ft = V 1 (:803)              one pass over V
   //   rho (:806 / :808), |Ft|, Ft.Yt, rho.rho       k_fit_rho
   //   gamma = U rho (:788 / :996)
-  HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st));
+  HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st, h->stream2, h->ev_chol));
   HIPCHK(h, launch_logdet(h->dR, N, ldr, h->dscal, st));
   HIPCHK(h, launch_tri_inverse(h->dR, h->ddinv, h->dV, h->dU, h->dT, ldr, st));
   const int n_t = h->n_t;

@@ -20,6 +20,7 @@ struct bogp_handle {
   int device = 0;
   int n_cu = 256;  // compute units of the device (launch planning of the fused small-N sweep)
   hipStream_t stream = nullptr;
+  hipEvent_t ev_chol[2] = {nullptr, nullptr};  // look-ahead of the large-matrix Cholesky (second stream)
   hipStream_t stream2 = nullptr;  // producer stream: k_corr_chunk of chunk c+1 runs beside k_contract of chunk c
   rocblas_handle blas = nullptr;
   std::string err;

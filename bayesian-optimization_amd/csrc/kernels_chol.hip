@@ -467,7 +467,7 @@ namespace {
 constexpr int MB = 128;        // tile edge
 constexpr int MKB = 16;        // k rows per LDS stage
 constexpr int MPT = MB + 16;   // LDS pitch in doubles
-constexpr int BIG_LD = 4096;
+constexpr int BIG_LD = 6144;  // measured cross-over (tools/time_fit_big.py): 4096 5.1 vs 4.8 ms, 6144 9.9 vs 10.2, 8192 17.6 vs 20.2
 
 struct MmTile {
   const double* Rs;  // row-side operand: element (row, k) at Rs[row + k * ldr]
@@ -594,8 +594,9 @@ struct MmArgs {
   double* A;   // MM_SYRK: the matrix being factored
   int ld, nt;  // nt = ld / 128
   int nb2;     // MM_T / V / U: 128-tiles per diagonal block of this level
-  int t0;      // MM_SYRK: first trailing tile;  kp0 / kp1: the panel's columns
+  int t0;      // MM_SYRK: first trailing tile;  kp0 / kp1: the panel's columns;  cj0 / cj1: column tiles updated
   int kp0, kp1;
+  int cj0, cj1;
   int TI, TJ;  // logical tile grid of one z / y slice
 };
 
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(256, 2) void k_mm128(MmArgs a, int mode0) {
     t.k0 = ti * MB;
     t.k1 = ld;
   } else if (mode == MM_SYRK) {  // A22(i, j) -= sum_{k in panel} P(i, k) P(j, k), lower tiles (diagonal tiles in full)
-    if (tj > ti) return;
+    if (tj > ti || tj < a.cj0 || tj >= a.cj1) return;
     t.Rs = a.A + (size_t)(a.t0 + ti) * MB;
     t.Cs = a.A + (size_t)(a.t0 + tj) * MB;
     t.out = a.A + (size_t)(a.t0 + ti) * MB + (size_t)(a.t0 + tj) * MB * ld;
@@ -700,6 +701,15 @@ static bool big_path(int ld) {
   return ld >= BIG_LD && ld % MB == 0 && !(e && atoi(e) != 0);
 }
 
+// The two-level factorisation is kept behind BOGP_BIG_CHOL=1: its panel chain (a k_chol_panel + k_chol_update pair per block
+// column, ~33 us each, bound by the 64-pivot diagonal block) runs beside the trailing update in the one-level variant
+// (workgroup 0 of k_chol_update) but ahead of it here, and the look-ahead on a second stream does not hide it (the small
+// chain kernels queue behind the update's workgroups): 9.5 ms against 8.9 ms at N = 8192.  The inverse and R^-1 do win.
+static bool big_chol(int ld) {
+  const char* e = getenv("BOGP_BIG_CHOL");
+  return big_path(ld) && e && atoi(e) != 0;
+}
+
 static hipError_t launch_mm128(MmArgs a, int mode, int TI, int TJ, int ny, int nz, hipStream_t st) {
   constexpr int shm = 2 * 2 * MKB * MPT * (int)sizeof(double);  // 73.7 KB: two stages of (row tile + column tile)
   static bool attr_set = false;
@@ -716,12 +726,23 @@ static hipError_t launch_mm128(MmArgs a, int mode, int TI, int TJ, int ny, int n
 }
 
 // two-level right-looking Cholesky: panels of 4 block columns (256); inside a panel the 64-block kernels with their updates
-// confined to the panel; then one rank-256 update of the trailing matrix and the factorisation of its first block
-static hipError_t launch_chol_lower_big(double* A, int ld, double* Winv, int* info, hipStream_t st) {
+// confined to the panel; then one rank-256 update of the trailing matrix and the factorisation of its first block.
+// With a second stream (st2 + two events) the update is split with LOOK-AHEAD: the two column tiles that form the NEXT
+// panel are updated on the main stream, which then goes on factoring that panel (a serial chain of ~33 us per block
+// column: 64 pivots each), while the rest of the trailing matrix is updated on st2 beside it.
+static hipError_t launch_chol_lower_big(double* A, int ld, double* Winv, int* info, hipStream_t st, hipStream_t st2,
+                                        hipEvent_t* ev) {
   const int nb = ld / CB;
+  const bool ahead = st2 != nullptr && ev != nullptr;
+  bool rest_pending = false;
   hipLaunchKernelGGL(k_chol_first, dim3(1), 256, 0, st, A, ld, Winv, info, 0, 1);
-  for (int kbeg = 0; kbeg < nb; kbeg += 4) {
-    const int kend = min(nb, kbeg + 4);
+  static const int PWB = [] {  // block columns per panel (8 = 512 wide: measured 18.3 ms per llf+gradient at N = 8192 against 18.8 with 4 and 20.0 with 2)
+    const char* e = getenv("BOGP_CHOL_PANEL");
+    const int v = e ? atoi(e) : 8;
+    return (v == 2 || v == 4 || v == 6 || v == 8) ? v : 4;
+  }();
+  for (int kbeg = 0; kbeg < nb; kbeg += PWB) {
+    const int kend = min(nb, kbeg + PWB);
     for (int k = kbeg; k < kend; ++k) {
       const int m = nb - k - 1, k0 = k * CB;
       if (m == 0) break;
@@ -736,11 +757,30 @@ static hipError_t launch_chol_lower_big(double* A, int ld, double* Winv, int* in
       a.A = A; a.ld = ld; a.nt = ld / MB;
       a.t0 = kend / 2; a.kp0 = kbeg * CB; a.kp1 = kend * CB;
       const int TT = a.nt - a.t0;
-      hipError_t e = launch_mm128(a, MM_SYRK, TT, TT, 1, 1, st);
-      if (e != hipSuccess) return e;
+      hipError_t e;
+      if (!ahead || TT <= PWB / 2) {
+        a.cj0 = 0; a.cj1 = TT;
+        if ((e = launch_mm128(a, MM_SYRK, TT, TT, 1, 1, st)) != hipSuccess) return e;
+      } else {
+        // the previous panel's remainder update (st2) writes the same trailing columns: it has to be through first
+        if (rest_pending && (e = hipStreamWaitEvent(st, ev[1], 0)) != hipSuccess) return e;
+        const int nstrip = min(TT, PWB / 2);
+        a.cj0 = 0; a.cj1 = nstrip;  // the next panel's column tiles
+        if ((e = launch_mm128(a, MM_SYRK, TT, nstrip, 1, 1, st)) != hipSuccess) return e;
+        if ((e = hipEventRecord(ev[0], st)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(st2, ev[0], 0)) != hipSuccess) return e;
+        a.cj0 = nstrip; a.cj1 = TT;
+        if ((e = launch_mm128(a, MM_SYRK, TT, TT, 1, 1, st2)) != hipSuccess) return e;
+        if ((e = hipEventRecord(ev[1], st2)) != hipSuccess) return e;
+        rest_pending = true;
+      }
       hipLaunchKernelGGL(k_chol_first, dim3(1), 256, 0, st, A + (size_t)kend * CB * (ld + 1), ld, Winv + (size_t)kend * CB * CB, info,
                          kend * CB, 0);
     }
+  }
+  if (rest_pending) {
+    hipError_t e = hipStreamWaitEvent(st, ev[1], 0);
+    if (e != hipSuccess) return e;
   }
   return hipGetLastError();
 }
@@ -803,9 +843,9 @@ hipError_t launch_pad_identity(double* A, int N, int ld, hipStream_t st) {
 // L = chol(A) in place (lower, column-major, ld a multiple of 64 with identity padding).  Winv: ld x 64 doubles; block
 // k holds L_kk^-1 (64 x 64 column-major) afterwards.  *info (device) = 0 or 1 + the first column with a non-positive
 // pivot, as LAPACK reports it.
-hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStream_t st) {
+hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStream_t st, hipStream_t st2, hipEvent_t* ev) {
   const int nb = ld / CB;
-  if (big_path(ld)) return launch_chol_lower_big(A, ld, Winv, info, st);
+  if (big_chol(ld)) return launch_chol_lower_big(A, ld, Winv, info, st, st2, ev);
   hipLaunchKernelGGL(k_chol_first, dim3(1), 256, 0, st, A, ld, Winv, info, 0, 1);
   for (int k = 0; k + 1 < nb; ++k) {
     const int k0 = k * CB;

@@ -287,12 +287,12 @@ def test_library_exchange_with_a_one_rank_communicator():
     assert eng.comm_info() == (0, 0)
 
 
-@pytest.mark.parametrize("N", [4096, 4100, 5000])
+@pytest.mark.parametrize("N", [6144, 6200, 7000])
 def test_large_fit_path_equals_the_64_block_path(N):
-    """From ld = 4096 on the factorisation runs on 128 x 128 tiles (two-level Cholesky with rank-256 trailing updates,
-    recursive-doubling inverse and R^-1 = U U^T through k_mm128; kernels_chol.hip).  Same mathematics, other summation
-    order: likelihood, gradient, committed state and posterior against the 64-block path (BOGP_NO_BIG_FIT=1), incl. a
-    size whose tile count is not a power of two, and the -inf convention on a singular matrix."""
+    """From ld = 6144 on the inverse and R^-1 = U U^T run on 128 x 128 tiles (k_mm128, kernels_chol.hip; with
+    BOGP_BIG_CHOL=1 also a two-level Cholesky with rank-512 trailing updates).  Same mathematics, other summation order:
+    likelihood, gradient, committed state and posterior against the 64-block path (BOGP_NO_BIG_FIT=1), incl. sizes whose
+    tile count is not a power of two, and the -inf convention on an indefinite matrix."""
     import os
 
     d = 6
@@ -303,8 +303,9 @@ def test_large_fit_path_equals_the_64_block_path(N):
     par = np.r_[np.full(d, 0.2) * rng.uniform(0.8, 1.2, size=d), 0.9]
     Xs = rng.uniform(-5, 5, size=(300, d))
     out = {}
-    for tag, flag in (("big", "0"), ("small", "1")):
+    for tag, flag in (("big", "0"), ("small", "1"), ("bigchol", "0")):
         os.environ["BOGP_NO_BIG_FIT"] = flag
+        os.environ["BOGP_BIG_CHOL"] = "1" if tag == "bigchol" else "0"
         try:
             eng = _lib.Engine(0)
             eng.set_train(X, y)
@@ -314,13 +315,17 @@ def test_large_fit_path_equals_the_64_block_path(N):
             eng.upload_candidates(Xs)
             mu, mse = eng.predict()
             out[tag] = (llf, grad, llf_c, st, mu, mse)
-            if tag == "big":  # an indefinite matrix (negative nugget: diagonal below the off-diagonal mass) is reported as LAPACK would
+            if tag in ("big", "bigchol"):  # an indefinite matrix (negative nugget: diagonal below the off-diagonal mass) is reported as LAPACK would
                 with pytest.raises(_lib.NotPositiveDefinite):
                     eng.commit(_lib.KERNEL_SE, _lib.MODE_NOISY, np.r_[np.full(d, 1e-4), 0.9], -0.6)
             eng.close()
         finally:
-            del os.environ["BOGP_NO_BIG_FIT"]
-    b, s = out["big"], out["small"]
+            del os.environ["BOGP_NO_BIG_FIT"], os.environ["BOGP_BIG_CHOL"]
+    for variant in ("big", "bigchol"):
+        _compare_fit_outputs(out[variant], out["small"])
+
+
+def _compare_fit_outputs(b, s):
     np.testing.assert_allclose(b[0], s[0], rtol=1e-11)
     np.testing.assert_allclose(b[2], s[2], rtol=1e-11)
     np.testing.assert_allclose(b[1], s[1], rtol=1e-8, atol=1e-9 * np.abs(s[1]).max())
