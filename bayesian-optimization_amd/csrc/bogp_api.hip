@@ -158,8 +158,8 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
     HIPCHK(h, hipMalloc((void**)&h->dtmp, cl * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->dgamma_base, ntc * cl * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->dw, cl * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->dtheta, d * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->dsqrt_theta, d * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dtheta, (d + 1) * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dsqrt_theta, (d + 1) * sizeof(double)));
   }
   h->N = N;
   h->d = d;
@@ -303,29 +303,44 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
                      int estimate_trend, double beta, bool want_gamma, FitOut* o, std::vector<double>* theta_out,
                      bool reject_positive = true) {
   if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "no training set: call bogp_set_train first");
-  if (kernel < 0 || kernel > BOGP_KERNEL_ABSEXP) FAIL(h, BOGP_ERR_INVALID, "unknown kernel id %d", kernel);
+  if (kernel < 0 || kernel > BOGP_KERNEL_GENEXP) FAIL(h, BOGP_ERR_INVALID, "unknown kernel id %d", kernel);
   if (mode < 0 || mode > 2) FAIL(h, BOGP_ERR_INVALID, "unknown estimation mode %d", mode);
   if (trend < BOGP_TREND_CONSTANT || trend > BOGP_TREND_QUADRATIC) FAIL(h, BOGP_ERR_INVALID, "unknown trend id %d", trend);
   const int ptrend = trend_size(trend, h->d);
   const int N = h->N, d = h->d, ldr = h->ldr;
-  const int n_theta = n_par - (mode == BOGP_MODE_NOISELESS ? 0 : 1);
+  int n_theta = n_par - (mode == BOGP_MODE_NOISELESS ? 0 : 1);
+  double pexp = 0.0;
+  if (kernel == BOGP_KERNEL_GENEXP) {  // theta = [theta_1 .. theta_d, p], or [theta, p] (kernel.py:369-373)
+    if (n_theta != d + 1 && n_theta != 2) FAIL(h, BOGP_ERR_INVALID, "generalized_exponential: len(theta) = %d must be 2 or d + 1 = %d", n_theta, d + 1);
+    pexp = par[n_theta - 1];
+    if (!(pexp > 0) || !std::isfinite(pexp)) FAIL(h, BOGP_ERR_INVALID, "generalized_exponential: exponent p = %g must be finite and > 0", pexp);
+    n_theta -= 1;
+  }
   if (n_theta != d && n_theta != 1) FAIL(h, BOGP_ERR_INVALID, "len(theta) = %d must be 1 or d = %d", n_theta, d);
   std::vector<double>& th = h->h_theta;  // handle-owned: the asynchronous uploads below outlive this scope
   std::vector<double>& sth = h->h_sqrt_theta;
-  th.resize(d);
-  sth.resize(d);
+  th.resize(d + 1);
+  sth.resize(d + 1);
   for (int k = 0; k < d; ++k) {
     th[k] = par[n_theta == 1 ? 0 : k];
     if (!(th[k] > 0) || !std::isfinite(th[k])) FAIL(h, BOGP_ERR_INVALID, "theta[%d] = %g must be finite and > 0", k, th[k]);
-    // coordinates are pre-scaled so that the producer forms (a - b)^2 (radial kernels) or |a - b| (absolute_exponential)
-    sth[k] = kernel == BOGP_KERNEL_ABSEXP ? th[k] : std::sqrt(th[k]);
+    // coordinates are pre-scaled so that the producer forms (a - b)^2 (radial kernels), |a - b| (absolute_exponential,
+    // cubic) or |a - b|^p (generalized_exponential: theta_k^(1/p))
+    sth[k] = (kernel == BOGP_KERNEL_ABSEXP || kernel == BOGP_KERNEL_CUBIC) ? th[k]
+             : kernel == BOGP_KERNEL_GENEXP ? std::pow(th[k], 1.0 / pexp) : std::sqrt(th[k]);
   }
-  if (theta_out) *theta_out = th;
+  th[d] = sth[d] = pexp;  // entry d of both device arrays: the exponent (read by the generalized_exponential kernels only)
+  if (theta_out) theta_out->assign(th.begin(), th.begin() + d);
   hipStream_t st = h->stream;
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipMemcpyAsync(h->dtheta, th.data(), d * sizeof(double), hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(h->dsqrt_theta, sth.data(), d * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(h->dtheta, th.data(), (d + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(h->dsqrt_theta, sth.data(), (d + 1) * sizeof(double), hipMemcpyHostToDevice, st));
 
+  // The identity padding is re-established for EVERY factorisation: a factorisation that broke down (pivots of rounding
+  // size -> overflowing inverses -> inf * 0) leaves NaN in the padding rows of the in-place factor, and R is only rebuilt
+  // inside its N x N block -- without this, one failed likelihood evaluation made every later one on the handle fail too
+  // (found with the near-singular noiseless cubic tables of G25).
+  HIPCHK(h, launch_pad_identity(h->dR, N, ldr, st));
   // correlation matrix with the per-mode normalisation (gpr.py:931-969)
   double s2t = 0, alpha = 0, sigma2_par = 0;
   if (mode == BOGP_MODE_NOISELESS) {
@@ -439,6 +454,8 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
                         int estimate_trend, double beta, double* llf, double* grad) {
   if (!h) return BOGP_ERR_INVALID;
   if (!par || !llf || n_par <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_nll: par/llf must be non-null");
+  if (grad && (kernel == BOGP_KERNEL_CUBIC || kernel == BOGP_KERNEL_GENEXP))
+    FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll: the cubic / generalized_exponential correlation has no theta-derivative (the reference's corr_grad_theta leaves it undefined, gpr.py:763-766: its own likelihood gradient raises UnboundLocalError)");
   h->committed = false;  // the factor buffers are about to be overwritten
   FitOut o;
   int rc = factorize(h, kernel, mode, par, n_par, noise_var, trend, estimate_trend, beta, grad != nullptr, &o, nullptr);
@@ -512,6 +529,7 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
                                    int trend, int estimate_trend, double beta, double* llf, double* grad) {
   if (!h) return BOGP_ERR_INVALID;
   if (!par || !llf || n_par <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_nll_restricted: par/llf must be non-null");
+  if (grad && (kernel == BOGP_KERNEL_CUBIC || kernel == BOGP_KERNEL_GENEXP)) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_restricted: the cubic / generalized_exponential correlation has no theta-derivative");
   if (mode < 0 || mode > 2) FAIL(h, BOGP_ERR_INVALID, "unknown estimation mode %d", mode);
   if (trend != BOGP_TREND_CONSTANT) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_restricted: only the constant trend basis is built (trend id %d)", trend);
   if (h->n_t != 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_restricted: single-target y only (have %d targets)", h->n_t);
@@ -1176,6 +1194,7 @@ extern "C" double bogp_flops_per_candidate(const bogp_handle* h) {
 extern "C" int bogp_gradient(bogp_handle* h, const double* x, double* dmu, double* dmse) {
   if (!h) return BOGP_ERR_INVALID;
   if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "bogp_gradient: no committed model");
+  if (h->kernel == BOGP_KERNEL_CUBIC || h->kernel == BOGP_KERNEL_GENEXP) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_gradient: the cubic correlation has no input-derivative (corr_dx leaves it undefined in the reference, gpr.py:655-658)");
   if (!x || !dmu || !dmse) FAIL(h, BOGP_ERR_INVALID, "bogp_gradient: null pointer");
   const int N = h->N, d = h->d;
   hipStream_t st = h->stream;
@@ -1253,6 +1272,7 @@ extern "C" int bogp_point_eval(bogp_handle* h, const double* x, int q, const int
                                int minimize, double* mu, double* mse, double* dmu, double* dmse, double* acq) {
   if (!h) return BOGP_ERR_INVALID;
   if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "bogp_point_eval: no committed model");
+  if (h->kernel == BOGP_KERNEL_CUBIC || h->kernel == BOGP_KERNEL_GENEXP) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_point_eval: the cubic correlation has no input-derivative (corr_dx leaves it undefined in the reference, gpr.py:655-658)");
   if (!x || !mu || !mse || !dmu || !dmse) FAIL(h, BOGP_ERR_INVALID, "bogp_point_eval: null pointer");
   if (q < 0 || q > BOGP_MAX_Q || (q > 0 && (!acq_id || !acq))) FAIL(h, BOGP_ERR_INVALID, "bogp_point_eval: 0 <= q <= %d with non-null acq_id / acq", BOGP_MAX_Q);
   if (h->p > 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_point_eval: constant trend basis only (use bogp_predict + bogp_gradient)");
@@ -1365,6 +1385,7 @@ extern "C" int bogp_prior_corr(bogp_handle* h, const double* X1, int n1, double*
 extern "C" int bogp_gradient_batch(bogp_handle* h, const double* Xb, int B, double* dmu, double* dmse) {
   if (!h) return BOGP_ERR_INVALID;
   if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "bogp_gradient_batch: no committed model");
+  if (h->kernel == BOGP_KERNEL_CUBIC || h->kernel == BOGP_KERNEL_GENEXP) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_gradient_batch: the cubic correlation has no input-derivative (corr_dx leaves it undefined in the reference, gpr.py:655-658)");
   if (!Xb || !dmu || !dmse || B <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_gradient_batch: null pointer or B <= 0");
   if (h->p > 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_gradient_batch: polynomial trends (p = %d) are served by bogp_gradient only", h->p);
   const int N = h->N, d = h->d;

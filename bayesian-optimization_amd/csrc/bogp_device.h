@@ -17,15 +17,44 @@ template <int KERNEL>
 __device__ __forceinline__ double dist_term(double theta_k, double diff) {
   return KERNEL == BOGP_KERNEL_ABSEXP ? theta_k * fabs(diff) : theta_k * (diff * diff);
 }
-// Same term when both points were pre-scaled (by sqrt(theta_k), or by theta_k for absolute_exponential).
+// cubic (kernel.py:419-466) is a PRODUCT over the dimensions, not a function of a summed distance:
+//   td = min(1, theta_k |d_k|);  factor = 1 - td^2 (3 - 2 td);  r = prod_k factor
+// so the per-pair accumulator starts at dist_init (1 for cubic, 0 otherwise), folds one dimension at a time and the
+// radial profile of cubic is the identity.
+__device__ __forceinline__ double cubic_factor(double td_abs) {
+  const double td = td_abs > 1.0 ? 1.0 : td_abs;
+  return 1.0 - (td * td) * (3.0 - 2.0 * td);
+}
 template <int KERNEL>
-__device__ __forceinline__ double dist_accumulate(double diff_scaled, double acc) {
+__device__ __forceinline__ double dist_init() {
+  return KERNEL == BOGP_KERNEL_CUBIC ? 1.0 : 0.0;
+}
+// generalized_exponential (kernel.py:332-379): exp(-sum_k theta_k |d_k|^p); the exponent p travels as entry d of the
+// device theta arrays (`pexp` below; unused by the other kernels)
+template <int KERNEL>
+__device__ __forceinline__ double kernel_exponent(const double* theta_like, int d) {
+  return KERNEL == BOGP_KERNEL_GENEXP ? theta_like[d] : 0.0;
+}
+// fold dimension k (unscaled coordinates, weight theta_k) into the accumulator
+template <int KERNEL>
+__device__ __forceinline__ double dist_fold(double theta_k, double diff, double acc, double pexp = 0.0) {
+  if (KERNEL == BOGP_KERNEL_CUBIC) return acc * cubic_factor(fabs(diff) * theta_k);
+  if (KERNEL == BOGP_KERNEL_GENEXP) return acc + theta_k * pow(fabs(diff), pexp);
+  return acc + dist_term<KERNEL>(theta_k, fabs(diff));
+}
+// the same when both points were pre-scaled (by sqrt(theta_k); by theta_k for absolute_exponential and cubic; by
+// theta_k^(1/p) for generalized_exponential)
+template <int KERNEL>
+__device__ __forceinline__ double dist_accumulate(double diff_scaled, double acc, double pexp = 0.0) {
+  if (KERNEL == BOGP_KERNEL_CUBIC) return acc * cubic_factor(fabs(diff_scaled));
+  if (KERNEL == BOGP_KERNEL_GENEXP) return acc + pow(fabs(diff_scaled), pexp);
   return KERNEL == BOGP_KERNEL_ABSEXP ? acc + fabs(diff_scaled) : __builtin_fma(diff_scaled, diff_scaled, acc);
 }
 
 template <int KERNEL>
 __device__ __forceinline__ double corr_profile(double s2) {
-  if (KERNEL == BOGP_KERNEL_SE || KERNEL == BOGP_KERNEL_ABSEXP) return exp(-s2);
+  if (KERNEL == BOGP_KERNEL_CUBIC) return s2;  // the accumulator already is the product
+  if (KERNEL == BOGP_KERNEL_SE || KERNEL == BOGP_KERNEL_ABSEXP || KERNEL == BOGP_KERNEL_GENEXP) return exp(-s2);
   const double dists = sqrt(s2);
   if (KERNEL == BOGP_KERNEL_MATERN12) return exp(-dists);
   if (KERNEL == BOGP_KERNEL_MATERN32) {

@@ -830,13 +830,15 @@ hipError_t launch_uut(const double* U, double* Rinv, int ld, hipStream_t st, int
 // identity padding of an ld x ld column-major matrix outside its leading N x N block
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void k_pad_identity(double* __restrict__ A, int N, int ld) {
-  const int i = blockIdx.x * 256 + threadIdx.x;  // row
-  const int j = blockIdx.y;                      // column
-  if (i >= ld || (i < N && j < N)) return;
-  A[(size_t)j * ld + i] = i == j ? 1.0 : 0.0;
+  const int i = blockIdx.x * 256 + threadIdx.x;  // runs over a whole row / column
+  const int j = N + blockIdx.y;                  // a padding row / column
+  if (i >= ld) return;
+  const double v = i == j ? 1.0 : 0.0;
+  A[(size_t)j * ld + i] = v;  // column j
+  A[(size_t)i * ld + j] = v;  // row j
 }
 hipError_t launch_pad_identity(double* A, int N, int ld, hipStream_t st) {
-  hipLaunchKernelGGL(k_pad_identity, dim3((ld + 255) / 256, ld), 256, 0, st, A, N, ld);
+  if (ld > N) hipLaunchKernelGGL(k_pad_identity, dim3((ld + 255) / 256, ld - N), 256, 0, st, A, N, ld);
   return hipGetLastError();
 }
 

@@ -375,8 +375,9 @@ __global__ __launch_bounds__(256) void k_batch_corr(const double* __restrict__ X
   const int n = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (n >= N) return;
-  double s2 = 0.0;
-  for (int k = 0; k < d; ++k) s2 += dist_term<KERNEL>(theta[k], fabs(Xb[(size_t)b * d + k] - X[(size_t)n * d + k]));
+  double s2 = dist_init<KERNEL>();
+  const double pexp = kernel_exponent<KERNEL>(theta, d);
+  for (int k = 0; k < d; ++k) s2 = dist_fold<KERNEL>(theta[k], Xb[(size_t)b * d + k] - X[(size_t)n * d + k], s2, pexp);
   r[(size_t)b * N + n] = corr_profile<KERNEL>(s2);
   s2out[(size_t)b * N + n] = s2;
 }
@@ -500,6 +501,14 @@ hipError_t launch_batch_corr(int kernel, const double* X, int N, int d, const do
                              double* r, double* s2, hipStream_t st) {
   dim3 grid((N + 255) / 256, B);
 #define CALL(K) hipLaunchKernelGGL(k_batch_corr<K>, grid, 256, 0, st, X, N, d, theta, Xb, r, s2)
+  if (kernel == BOGP_KERNEL_CUBIC || kernel == BOGP_KERNEL_GENEXP) {  // values only (small-batch posterior, prior correlation): no derivative kernels
+    if (kernel == BOGP_KERNEL_CUBIC) {
+      CALL(BOGP_KERNEL_CUBIC);
+    } else {
+      CALL(BOGP_KERNEL_GENEXP);
+    }
+    return hipGetLastError();
+  }
   BOGP_DISPATCH_KERNEL(kernel, CALL)
 #undef CALL
   return hipGetLastError();

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void k_build_R(const double* __restrict__ X, i
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) s2[r][c] = 0.0;
+    for (int c = 0; c < 4; ++c) s2[r][c] = dist_init<KERNEL>();
+  const double pexp = kernel_exponent<KERNEL>(theta, d);
   for (int kc = 0; kc < d; kc += KC) {
     __syncthreads();
     stage_points(xi, X, N, d, i0, kc, tid);
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void k_build_R(const double* __restrict__ X, i
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s2[r][c] += dist_term<KERNEL>(th, fabs(vi[r] - vj[c]));
+        for (int c = 0; c < 4; ++c) s2[r][c] = dist_fold<KERNEL>(th, vi[r] - vj[c], s2[r][c], pexp);
     }
   }
 #pragma unroll
@@ -102,13 +103,20 @@ __global__ __launch_bounds__(256) void k_build_R(const double* __restrict__ X, i
     case BOGP_KERNEL_ABSEXP: { CALL(BOGP_KERNEL_ABSEXP); } break;     \
     default: { CALL(BOGP_KERNEL_MATERN52); } break;                   \
   }
+// the correlation matrix itself also exists for cubic (no theta-derivative: k_grad_contract is not instantiated for it)
+#define BOGP_FOR_KERNEL_R(kernel, CALL)                    \
+  switch (kernel) {                                        \
+    case BOGP_KERNEL_CUBIC: { CALL(BOGP_KERNEL_CUBIC); } break; \
+    case BOGP_KERNEL_GENEXP: { CALL(BOGP_KERNEL_GENEXP); } break; \
+    default: BOGP_FOR_KERNEL(kernel, CALL)                 \
+  }
 
 hipError_t launch_build_R(int kernel, const double* X, int N, int d, const double* theta, double off_scale, double diag,
                           double* R, int ld, hipStream_t st) {
   const int nt = (N + PT - 1) / PT;
   const dim3 grid(nt, nt);
 #define CALL(K) hipLaunchKernelGGL((k_build_R<K, false>), grid, 256, 0, st, X, N, d, theta, off_scale, 1.0, diag, R, ld)
-  BOGP_FOR_KERNEL(kernel, CALL)
+  BOGP_FOR_KERNEL_R(kernel, CALL)
 #undef CALL
   return hipGetLastError();
 }
@@ -118,7 +126,7 @@ hipError_t launch_build_R_div(int kernel, const double* X, int N, int d, const d
   const int nt = (N + PT - 1) / PT;
   const dim3 grid(nt, nt);
 #define CALL(K) hipLaunchKernelGGL((k_build_R<K, true>), grid, 256, 0, st, X, N, d, theta, mul, div, diag, R, ld)
-  BOGP_FOR_KERNEL(kernel, CALL)
+  BOGP_FOR_KERNEL_R(kernel, CALL)
 #undef CALL
   return hipGetLastError();
 }

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void k_corr_chunk(const double* __restrict__ X
   }
   __syncthreads();
 
+  const double pexp = kernel_exponent<KERNEL>(sqrt_theta, d);
   const int nb0 = blockIdx.y * a.nblk_per_split * 32;
   const int nb1 = min(a.Np, nb0 + a.nblk_per_split * 32);
   double mu = 0.0, wd = 0.0;
@@ -71,14 +72,14 @@ __global__ __launch_bounds__(256) void k_corr_chunk(const double* __restrict__ X
     const int n0 = nb + g * 8;
     double acc[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+    for (int i = 0; i < 8; ++i) acc[i] = dist_init<KERNEL>();
 #pragma unroll 2
     for (int k = 0; k < d; ++k) {
       const double xk = xs[k * 64 + m];
       const double* __restrict__ xr = XthT + (size_t)k * a.Np + n0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        acc[i] = dist_accumulate<KERNEL>(xk - xr[i], acc[i]);
+        acc[i] = dist_accumulate<KERNEL>(xk - xr[i], acc[i], pexp);
       }
     }
 #pragma unroll
@@ -472,6 +473,8 @@ hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipS
     case BOGP_KERNEL_MATERN12: BOGP_LAUNCH_CORR(BOGP_KERNEL_MATERN12); break;
     case BOGP_KERNEL_MATERN32: BOGP_LAUNCH_CORR(BOGP_KERNEL_MATERN32); break;
     case BOGP_KERNEL_ABSEXP: BOGP_LAUNCH_CORR(BOGP_KERNEL_ABSEXP); break;
+    case BOGP_KERNEL_CUBIC: BOGP_LAUNCH_CORR(BOGP_KERNEL_CUBIC); break;
+    case BOGP_KERNEL_GENEXP: BOGP_LAUNCH_CORR(BOGP_KERNEL_GENEXP); break;
     default: BOGP_LAUNCH_CORR(BOGP_KERNEL_MATERN52); break;
   }
 #undef BOGP_LAUNCH_CORR

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
   constexpr int MT = 16 * SM_MR;  // candidates of this workgroup (lanes >= MT of the producer are idle)
   const int64_t mg0 = a.m_begin + (int64_t)blockIdx.x * MT;
 
+  const double pexp = kernel_exponent<KERNEL>(sqrt_theta, d);
   const int d3 = (d + 2) / 3 * 3;  // the producer walks the dimensions three at a time; the padding rows are zero
   for (int idx = tid; idx < SM_MT * d; idx += 512) {
     const int row = idx / d, k = idx - row * d;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
           const int n0 = nb + st * 8;
           double ac[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) ac[i] = 0.0;
+          for (int i = 0; i < 8; ++i) ac[i] = dist_init<KERNEL>();
           // three dimensions per trip: their 3 x 8 training values arrive through three scalar loads issued back to back and
           // waited for ONCE -- with two waves per SIMD a single 16-op trip per load would leave the SMEM latency exposed
           // (measured: 430 instead of ~250 cycles per pair).  Rows d .. d3-1 of xs / XthT are zero: they add (0 - 0)^2.
@@ -196,11 +197,11 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
             }
             const double xk0 = xs[k * SM_MT + lane], xk1 = xs[(k + 1) * SM_MT + lane], xk2 = xs[(k + 2) * SM_MT + lane];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ac[i] = dist_accumulate<KERNEL>(xk0 - t0[i], ac[i]);
+            for (int i = 0; i < 8; ++i) ac[i] = dist_accumulate<KERNEL>(xk0 - t0[i], ac[i], pexp);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ac[i] = dist_accumulate<KERNEL>(xk1 - t1[i], ac[i]);
+            for (int i = 0; i < 8; ++i) ac[i] = dist_accumulate<KERNEL>(xk1 - t1[i], ac[i], pexp);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ac[i] = dist_accumulate<KERNEL>(xk2 - t2[i], ac[i]);
+            for (int i = 0; i < 8; ++i) ac[i] = dist_accumulate<KERNEL>(xk2 - t2[i], ac[i], pexp);
           }
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
@@ -408,6 +409,8 @@ static hipError_t launch_small_mr(int kernel, const SmallArgs& a, unsigned nwg, 
     case BOGP_KERNEL_MATERN12: BOGP_LAUNCH_SMALL(BOGP_KERNEL_MATERN12); break;
     case BOGP_KERNEL_MATERN32: BOGP_LAUNCH_SMALL(BOGP_KERNEL_MATERN32); break;
     case BOGP_KERNEL_ABSEXP: BOGP_LAUNCH_SMALL(BOGP_KERNEL_ABSEXP); break;
+    case BOGP_KERNEL_CUBIC: BOGP_LAUNCH_SMALL(BOGP_KERNEL_CUBIC); break;
+    case BOGP_KERNEL_GENEXP: BOGP_LAUNCH_SMALL(BOGP_KERNEL_GENEXP); break;
     default: BOGP_LAUNCH_SMALL(BOGP_KERNEL_MATERN52); break;
   }
 #undef BOGP_LAUNCH_SMALL

@@ -34,10 +34,12 @@ _KERNEL_IDS = {
     "matern32": _lib.KERNEL_MATERN32,
     "matern52": _lib.KERNEL_MATERN52,
     "absolute_exponential": _lib.KERNEL_ABSEXP,
+    # values only (set_state / predict / sweep): `fit` needs d llf / d theta, which the reference defines for neither
+    "cubic": _lib.KERNEL_CUBIC,
+    "generalized_exponential": _lib.KERNEL_GENEXP,  # theta = [theta_1 .. theta_d, p]: thetaL / thetaU of length d + 1
 }
-# generalized_exponential / cubic cannot be fitted by the reference either (their theta-derivatives are `pass`,
-# gpr.py:763-766) and are not built; "linear" / "pure_nugget" are not in its correlation table at all (gpr.py:198-207)
-_UNBUILT_KERNELS = ("generalized_exponential", "cubic", "linear")
+# "linear" / "pure_nugget" are not in the reference's correlation table at all (gpr.py:198-207)
+_UNBUILT_KERNELS = ("linear",)
 _NU_IDS = {0.5: _lib.KERNEL_MATERN12, 1.5: _lib.KERNEL_MATERN32, 2.5: _lib.KERNEL_MATERN52}
 
 
@@ -55,6 +57,10 @@ def kernel_id_of(corr) -> int:
         return _lib.KERNEL_SE
     if name == "absolute_exponential":
         return _lib.KERNEL_ABSEXP
+    if name == "cubic":
+        return _lib.KERNEL_CUBIC
+    if name == "generalized_exponential":
+        return _lib.KERNEL_GENEXP
     if name == "matern":
         nu = (getattr(corr, "keywords", None) or {}).get("nu", 1.5)
         if nu in _NU_IDS:
@@ -211,7 +217,13 @@ class GaussianProcess:
             raise NotImplementedError("multi-target y needs a fixed constant trend (constant_trend(dim, beta=...)) and the concentrated likelihood")
         if y.shape[1] > _lib.MAX_TARGETS:
             raise NotImplementedError("at most %d targets" % _lib.MAX_TARGETS)
-        if self.thetaL.size not in (1, X.shape[1]):
+        if self.kernel_id == _lib.KERNEL_GENEXP:  # theta carries the exponent p as its last entry (kernel.py:369-373)
+            if self.thetaL.size not in (2, X.shape[1] + 1):
+                raise Exception("Length of theta must be 2 or %s" % (X.shape[1] + 1))
+            if getattr(self.mean, "n_feature", X.shape[1]) != X.shape[1]:
+                # the default trend is built from len(thetaU) = d + 1 (gpr.py:269-270): the reference then rejects X at trend.py:57
+                raise Exception("X does not have the right size!")
+        elif self.thetaL.size not in (1, X.shape[1]):
             raise ValueError("Length of theta must be 1 or %s" % X.shape[1])
         if self.estimate_trend:
             p = _lib.trend_size_of(self._trend_args()[0], X.shape[1])
@@ -440,6 +452,10 @@ class GaussianProcess:
 
     def fit(self, X, y):
         """gpr.py:355-417.  Returns self; sets `is_fitted`."""
+        if self.kernel_id in (_lib.KERNEL_CUBIC, _lib.KERNEL_GENEXP):
+            # the MLE needs d llf / d theta; for these two the reference's own fit raises UnboundLocalError at gpr.py:1001
+            # (corr_grad_theta :763-766 defines nothing).  Pinned hyper-parameters work: set_state / predict / sweep.
+            raise NotImplementedError("corr=%r has no theta-derivative (neither here nor in the reference): use set_state(par, X, y)" % (self.corr,))
         self._check_data(X, y)
         n_retry = 0
         while True:

@@ -46,6 +46,10 @@ typedef struct bogp_handle bogp_handle;
 #define BOGP_KERNEL_MATERN32 2
 #define BOGP_KERNEL_MATERN52 3
 #define BOGP_KERNEL_ABSEXP 4 /* absolute_exponential :247-286   exp(-sum_k theta_k |d_k|) */
+#define BOGP_KERNEL_GENEXP 6 /* exp(-sum_k theta_k |d_k|^p), kernel.py:332-379; theta = [theta_1 .. theta_d, p] (d + 1 entries, or [theta, p]):
+                                values only, like BOGP_KERNEL_CUBIC */
+#define BOGP_KERNEL_CUBIC 5 /* prod_k max(0, 1 - 3 (theta_k d_k)^2 + 2 (theta_k d_k)^3), kernel.py:419-466: likelihood VALUE, commit,
+                               predict, sweep -- no derivatives, like the reference (corr_grad_theta / corr_dx leave it undefined) */
 
 /* estimation modes: gpr.py:252-263; parameter layouts gpr.py:1073-1086
  *   NOISELESS   par = [theta]          sigma2 = sum(rho^2)/(N-k)

@@ -31,7 +31,10 @@ KERNEL_MATERN12 = 1
 KERNEL_MATERN32 = 2
 KERNEL_MATERN52 = 3
 KERNEL_ABSEXP = 4
-KERNEL_NAMES = {"squared_exponential": KERNEL_SE, "matern": KERNEL_MATERN32, "absolute_exponential": KERNEL_ABSEXP}
+KERNEL_CUBIC = 5
+KERNEL_GENEXP = 6  # theta = [theta_1 .. theta_d, p]
+KERNEL_NAMES = {"squared_exponential": KERNEL_SE, "matern": KERNEL_MATERN32, "absolute_exponential": KERNEL_ABSEXP,
+                "cubic": KERNEL_CUBIC, "generalized_exponential": KERNEL_GENEXP}
 
 # estimation modes (surrogate/gaussian_process/gpr.py:252-263)
 MODE_NOISELESS = 0
@@ -78,6 +81,26 @@ def corr(kernel: int, theta: np.ndarray, d: np.ndarray) -> np.ndarray:
     theta = np.asarray(theta, dtype=np.float64)
     d = np.asarray(d, dtype=np.float64)
     n_features = d.shape[1] if d.ndim > 1 else 1
+    if kernel == KERNEL_CUBIC:  # kernel.py:419-466: td = min(1, theta |d|); prod_k (1 - td^2 (3 - 2 td))
+        if theta.size == 1:
+            td = np.abs(d) * theta
+        elif theta.size != n_features:
+            raise Exception("Length of theta must be 1 or " + str(n_features))
+        else:
+            td = np.abs(d) * theta.reshape(1, n_features)
+        td[td > 1.0] = 1.0
+        ss = 1.0 - td**2.0 * (3.0 - 2.0 * td)
+        return np.prod(ss, 1)
+    if kernel == KERNEL_GENEXP:  # kernel.py:332-379: theta = [theta_1 .. theta_n, p]; exp(-sum_k theta_k |d_k|^p)
+        lth = theta.size
+        if n_features > 1 and lth == 2:
+            th = np.hstack([np.repeat(theta[0], n_features), theta[1]]).reshape(1, n_features + 1)
+        elif lth != n_features + 1:
+            raise Exception("Length of theta must be 2 or %s" % (n_features + 1))
+        else:
+            th = theta.reshape(1, lth)
+        td = th[:, 0:-1].reshape(1, n_features) * np.abs(d) ** th[:, -1]
+        return np.exp(-np.sum(td, 1))
     if kernel == KERNEL_ABSEXP:  # kernel.py:247-286: exp(-sum_k theta_k |d_k|)
         d = np.abs(d)
         if theta.size == 1:

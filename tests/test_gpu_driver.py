@@ -334,3 +334,107 @@ def _compare_fit_outputs(b, s):
     np.testing.assert_allclose(b[3]["gamma"], s[3]["gamma"], rtol=1e-6, atol=1e-8 * np.abs(s[3]["gamma"]).max())
     np.testing.assert_allclose(b[4], s[4], rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(b[5], s[5], rtol=1e-6, atol=1e-11)
+
+
+@pytest.mark.parametrize("name", ["G25_cubic_ok_noisy", "G26_genexp_sk_noisy"])
+def test_value_only_kernels_on_the_device(name):
+    """cubic / generalized_exponential against the reference's outputs (G25 / G26): committed state, posterior, the six
+    criteria with argmax, likelihood values incl. the -inf convention; derivatives are refused (the reference has none)."""
+    from conftest import load_golden, state_from_golden
+
+    g = load_golden(name)
+    st = state_from_golden(g)
+    kid, mode = int(g["kernel"]), int(g["mode"])
+    est = bool(g["estimate_trend"])
+    eng = _lib.Engine(0)
+    eng.set_train(g["X"], g["y"])
+    llf = eng.commit(kid, mode, g["par"], 1e-6, est, 0.0)
+    np.testing.assert_allclose(llf, float(g["llf"]), rtol=1e-10)
+    s = eng.get_state()
+    np.testing.assert_allclose(s["C"], g["C"], rtol=0, atol=1e-11 * np.abs(g["C"]).max())
+    np.testing.assert_allclose(s["gamma"], g["gamma"].ravel(), rtol=1e-6, atol=1e-9 * np.abs(g["gamma"]).max())
+    acq = [("EI", O.ACQ_EI, 0.0), ("EpsilonPI_1e-10", O.ACQ_EPSILON_PI, 1e-10), ("UCB_0.5", O.ACQ_UCB, 0.5),
+           ("MGFI_1", O.ACQ_MGFI, 1.0), ("MGFI_2", O.ACQ_MGFI, 2.0), ("MGFI_100", O.ACQ_MGFI, 100.0)]  # fmt: skip
+    pl = O.plugin_value(st.y, True)
+    import os
+
+    for fused in ("0", "1"):  # both schedules of the sweep (N = 70: the fused small-N kernel by default)
+        os.environ["BOGP_NO_FUSED_SMALL"] = fused
+        try:
+            eng.upload_candidates(g["Xs"])
+            mu, mse = eng.predict()
+            best, idx, vals = eng.sweep([(a, p) for _, a, p in acq], pl, True, return_values=True)
+            eng.upload_candidates(g["Xs"][:20])  # the small-batch path (M <= 32)
+            mu20, mse20 = eng.predict()
+        finally:
+            del os.environ["BOGP_NO_FUSED_SMALL"]
+        np.testing.assert_allclose(mu, g["mu"][:, 0], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(mse, g["mse"][:, 0], rtol=1e-6, atol=1e-12 * st.sigma2[0])
+        np.testing.assert_allclose(mu20, g["mu"][:20, 0], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(mse20, g["mse"][:20, 0], rtol=1e-6, atol=1e-12 * st.sigma2[0])
+        solid = g["mse"][:, 0] > 1e-9 * st.sigma2[0]
+        for c, (key, a, p) in enumerate(acq):
+            np.testing.assert_allclose(vals[c][solid], g[key][solid], rtol=1e-6, atol=1e-300)
+            if int(g["argmax_" + key][0]) != 5:
+                assert idx[c] == int(g["argmax_" + key][0])
+    for mid in (0, 1, 2):
+        for tname, e_ in (("sk", False), ("ok", True)):
+            P, L = g["t_m%d_%s_par" % (mid, tname)], g["t_m%d_%s_llf" % (mid, tname)]
+            for p_, l_ in zip(P, L):
+                if np.isfinite(l_):
+                    try:
+                        np.testing.assert_allclose(eng.nll(kid, mid, p_, 1e-6 if mid == 1 else 0.0, e_, 0.0), l_, rtol=1e-8)
+                    except _lib.NotPositiveDefinite:
+                        # only acceptable where the matrix is singular to working precision (the noiseless cubic tables hold
+                        # such cases: LAPACK got through on a pivot of rounding size, a different summation order does not)
+                        n_th = len(p_) - (0 if mid == 0 else 1)
+                        R0 = O.correlation_matrix(kid, p_[:n_th], g["X"])
+                        assert mid == 0 and np.linalg.cond(R0) > 1e13, (mid, tname, np.linalg.cond(R0))
+                else:
+                    with pytest.raises(_lib.NotPositiveDefinite):
+                        eng.nll(kid, mid, p_, 1e-6 if mid == 1 else 0.0, e_, 0.0)
+    eng.commit(kid, mode, g["par"], 1e-6, est, 0.0)
+    for call in (lambda: eng.nll(kid, mode, g["par"], 1e-6, est, 0.0, eval_grad=True), lambda: eng.gradient(g["Xs"][0]),
+                 lambda: eng.point_eval(g["Xs"][0]), lambda: eng.gradient_batch(g["Xs"][:3])):  # fmt: skip
+        with pytest.raises(_lib.BogpError) as ei:
+            call()
+        assert ei.value.code == _lib.ERR_UNSUPPORTED
+    # the drop-in class: pinned state, predictions and a sweep through the front end
+    d = g["X"].shape[1]
+    corr = {5: "cubic", 6: "generalized_exponential"}[kid]
+    n = len(g["par"]) - 1
+    gp = bogp.GaussianProcess(mean=bogp.trend.constant_trend(d, beta=None if est else 0.0), corr=corr, thetaL=[1e-5] * n, thetaU=[1e2] * n,
+                              nugget=1e-6)  # fmt: skip
+    gp.set_state(g["par"], g["X"], g["y"])
+    m2, s2 = gp.predict(g["Xs"], eval_MSE=True)
+    np.testing.assert_allclose(m2, g["mu"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(np.ravel(bogp.UCB(model=gp)(g["Xs"])), g["UCB_0.5"], rtol=1e-6)
+    eng.close()
+
+
+def test_a_failed_factorisation_does_not_poison_the_next_one():
+    """Regression (found with G25): a factorisation that breaks down (singular to working precision: pivots of rounding
+    size, overflowing block inverses, inf * 0) used to leave NaN in the identity padding of the in-place factor (N not a
+    multiple of 64), and every later likelihood on the handle then failed too -- inside an MLE that turned one bad
+    L-BFGS-B step into a dead restart."""
+    rng = np.random.default_rng(8)
+    N, d = 70, 3
+    X = rng.uniform(-5, 5, size=(N, d))
+    X[N - 1] = X[0] + 1e-13  # numerically duplicated rows: singular without a nugget
+    y = np.sum(X**2, axis=1, keepdims=True)
+    y = (y - y.mean()) / y.std() + 0.1 * rng.standard_normal((N, 1))
+    good = np.r_[np.full(d, 0.2), 0.9]
+    eng = _lib.Engine(0)
+    eng.set_train(X, y)
+    ref = eng.nll(_lib.KERNEL_SE, _lib.MODE_NOISY, good, 1e-3, False, 0.0, eval_grad=True)
+    for bad_call in (lambda: eng.nll(_lib.KERNEL_SE, _lib.MODE_NOISELESS, np.full(d, 1e-9), 0.0, False, 0.0),
+                     lambda: eng.nll(_lib.KERNEL_SE, _lib.MODE_NOISY, good, -0.95, False, 0.0),
+                     lambda: eng.nll(_lib.KERNEL_SE, _lib.MODE_NOISY, np.r_[np.full(d, 1e-12), 0.9], 0.0, False, 0.0)):  # fmt: skip
+        try:
+            bad_call()
+        except _lib.NotPositiveDefinite:
+            pass
+        again = eng.nll(_lib.KERNEL_SE, _lib.MODE_NOISY, good, 1e-3, False, 0.0, eval_grad=True)
+        assert again[0] == ref[0]
+        np.testing.assert_array_equal(again[1], ref[1])
+    eng.close()

@@ -21,8 +21,9 @@ def test_kernel_name_mapping_follows_the_reference():
     assert kernel_id_of(functools.partial(matern, nu=0.5)) == _lib.KERNEL_MATERN12
     assert kernel_id_of(matern) == _lib.KERNEL_MATERN32
     assert kernel_id_of("absolute_exponential") == _lib.KERNEL_ABSEXP
+    assert kernel_id_of("cubic") == _lib.KERNEL_CUBIC and kernel_id_of("generalized_exponential") == _lib.KERNEL_GENEXP
     with pytest.raises(NotImplementedError):
-        kernel_id_of("cubic")
+        kernel_id_of("linear")
     with pytest.raises(ValueError):
         kernel_id_of("no_such_kernel")
 
@@ -296,3 +297,19 @@ def test_bfgs_path_refuses_what_it_does_not_implement():
 
     with pytest.raises(NotImplementedError, match="continuous"):
         optim.argmax_restart(crit, Lattice(), optimizer="BFGS")
+
+
+def test_value_only_kernels_refuse_fit_like_the_reference():
+    """cubic / generalized_exponential (kernel.py:332-379, 419-466) have no theta-derivative in the reference (its fit dies
+    with UnboundLocalError at gpr.py:1001): `fit` refuses, pinned states are the supported use; generalized_exponential
+    takes theta of length d + 1 and, with the default trend (built from len(thetaU), gpr.py:269-270), rejects X as the
+    reference does (trend.py:57)."""
+    X = np.random.default_rng(0).uniform(-1, 1, size=(10, 3))
+    y = np.sum(X, axis=1, keepdims=True)
+    for corr, n in (("cubic", 3), ("generalized_exponential", 4)):
+        gp = bogp.GaussianProcess(mean=bogp.trend.constant_trend(3, beta=0), corr=corr, thetaL=[1e-3] * n, thetaU=[1e2] * n)
+        with pytest.raises(NotImplementedError, match="theta-derivative"):
+            gp.fit(X, y)
+    gp = bogp.GaussianProcess(corr="generalized_exponential", thetaL=[1e-3] * 4, thetaU=[1e2] * 4)
+    with pytest.raises(Exception, match="right size"):
+        gp._check_data(X, y)

@@ -378,3 +378,37 @@ def test_hessian_and_prior_cov_restatements():
         close(O.prior_cov(st, g[tag + "_P"]), g[tag + "_cov"], rtol=1e-9, atol=0)
     with pytest.raises(NotImplementedError):
         O.hessian(state_from_golden(load_golden("G2_m32_ok_noisy")), np.zeros(2))
+
+
+@pytest.mark.parametrize("name", ["G25_cubic_ok_noisy", "G26_genexp_sk_noisy"])
+def test_value_only_kernels_against_the_reference(name):
+    """cubic and generalized_exponential (round 2): state, posterior, criteria row by row, argmax and the likelihood VALUE
+    tables of the three modes (several entries are -inf: the llf > 0 rejection, gpr.py:981-982) -- the oracle against the
+    reference's own outputs."""
+    g = load_golden(name)
+    st = state_from_golden(g)
+    np.testing.assert_allclose(st.llf, float(g["llf"]), rtol=1e-12)
+    np.testing.assert_allclose(st.C, g["C"], rtol=0, atol=1e-12 * np.abs(g["C"]).max())
+    np.testing.assert_allclose(st.gamma, g["gamma"], rtol=1e-9, atol=1e-12 * np.abs(g["gamma"]).max())
+    mu, mse = O.predict(st, g["Xs"])
+    np.testing.assert_allclose(mu, g["mu"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(mse, g["mse"], rtol=1e-9, atol=1e-14)
+    pl = O.plugin_value(st.y, True)
+    solid = g["mse"][:, 0] > 1e-9 * st.sigma2[0]
+    for key, a, p in (("EI", O.ACQ_EI, 0.0), ("EpsilonPI_1e-10", O.ACQ_EPSILON_PI, 1e-10), ("UCB_0.5", O.ACQ_UCB, 0.5),
+                      ("MGFI_1", O.ACQ_MGFI, 1.0), ("MGFI_2", O.ACQ_MGFI, 2.0), ("MGFI_100", O.ACQ_MGFI, 100.0)):  # fmt: skip
+        v = O.acquisition(a, p, mu[:, 0], mse[:, 0], pl, st.sigma2[0], True)
+        np.testing.assert_allclose(v[solid], g[key][solid], rtol=1e-9, atol=1e-300)
+        if int(g["argmax_" + key][0]) != 5:  # (row 5 sits on a training point)
+            assert int(np.argmax(v)) == int(g["argmax_" + key][0])
+    kid = int(g["kernel"])
+    for mid in (0, 1, 2):
+        for tname, est in (("sk", False), ("ok", True)):
+            P, L = g["t_m%d_%s_par" % (mid, tname)], g["t_m%d_%s_llf" % (mid, tname)]
+            for p_, l_ in zip(P, L):
+                out = O.log_likelihood_concentrated(p_, g["X"], g["y"], kid, mid, noise_var=1e-6 if mid == 1 else 0.0,
+                                                    estimate_trend=est, beta=0.0)  # fmt: skip
+                if np.isfinite(l_):
+                    np.testing.assert_allclose(out, l_, rtol=1e-11)
+                else:
+                    assert out == l_
