@@ -20,6 +20,7 @@ TREND_CONSTANT, TREND_LINEAR, TREND_QUADRATIC = 0, 1, 2
 MAX_Q = 64
 MAX_TARGETS = 8
 COMM_ID_BYTES = 128
+SCALES = {"linear": 0, None: 0, "log": 1, "log10": 2, "logit": 3, "bilog": 4}  # Real.scale (variable.py:43-55)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -46,6 +47,7 @@ SIGNATURES = {
     "bogp_candidates_generate_lhs": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_uint64, C.c_int64, C.c_int64]),
     "bogp_candidates_generate_sobol": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int64, C.POINTER(C.c_uint64), C.c_int]),
     "bogp_candidates_read": (C.c_int, [C.c_void_p, _lp, C.c_int, _dp]),
+    "bogp_candidates_set_transform": (C.c_int, [C.c_void_p, _ip, _ip, _dp, _dp]),
     "bogp_predict": (C.c_int, [C.c_void_p, _dp, _dp]),
     "bogp_sweep": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, C.c_double, C.c_int, _dp, _lp, _dp]),
     "bogp_sweep_topk": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, C.c_double, C.c_int, C.c_int, _dp, _lp]),
@@ -344,6 +346,23 @@ class Engine:
         self._check(rc)
         self.M = int(M)
         self._keep = None
+
+    def set_candidate_transform(self, scales=None, precisions=None, lo=None, hi=None):
+        """Post-processing of device-generated candidates as RealSpace._sample does it (search_space.py:754): `scales` per
+        dimension ("linear" | "log" | "log10" | "logit" | "bilog": the design is drawn in the transformed box and mapped
+        back), `precisions` (decimals or None) with the variables' own bounds `lo`, `hi` for the clip.  No arguments:
+        plain designs again."""
+        if scales is None and precisions is None:
+            self._check(self._lib.bogp_candidates_set_transform(self._h, None, None, None, None))
+            return
+        d = self.d
+        sc = np.ascontiguousarray([SCALES[s] for s in (scales if scales is not None else [None] * d)], dtype=np.int32)
+        pr = np.ascontiguousarray([-1 if p is None else int(p) for p in (precisions if precisions is not None else [None] * d)], dtype=np.int32)
+        if len(sc) != d or len(pr) != d:
+            raise ValueError("scales / precisions must have %d entries" % d)
+        lo_ = _f64(lo).ravel() if lo is not None else None
+        hi_ = _f64(hi).ravel() if hi is not None else None
+        self._check(self._lib.bogp_candidates_set_transform(self._h, sc.ctypes.data_as(_ip), pr.ctypes.data_as(_ip), _ptr(lo_), _ptr(hi_)))
 
     def read_candidates(self, rows) -> np.ndarray:
         rows = np.ascontiguousarray(rows, dtype=np.int64).ravel()

@@ -95,7 +95,7 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   comm_release(h);
   free_train(h);
   (void)hipStreamSynchronize(h->stream2);
-  dfree(h->dXs_owned); dfree(h->dss_part); dfree(h->dbounds); dfree(h->dsobol);
+  dfree(h->dXs_owned); dfree(h->dss_part); dfree(h->dbounds); dfree(h->dsobol); dfree(h->dxform);
   for (int b = 0; b < 2; ++b) { dfree(h->drT[b]); dfree(h->dmu_part[b]); dfree(h->dw_part[b]); }
   dfree(h->dblk_val); dfree(h->dblk_idx); dfree(h->dmu_out); dfree(h->dmse_out); dfree(h->dacq_out);
   dfree(h->dbest_val); dfree(h->dbest_idx); dfree(h->dtopk_val); dfree(h->dtopk_idx); dfree(h->dcounter); dfree(h->dinfo); dfree(h->dscal); dfree(h->dgrad_partial); dfree(h->dbatch);
@@ -750,7 +750,40 @@ static int generate_prepare(bogp_handle* h, const char* who, const double* lo, c
   return BOGP_OK;
 }
 
+extern "C" int bogp_candidates_set_transform(bogp_handle* h, const int* scale, const int* precision, const double* lo,
+                                             const double* hi) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_set_transform: call bogp_set_train first (d is unknown)");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!scale && !precision) {  // back to plain designs
+    h->h_xform.clear();
+    return BOGP_OK;
+  }
+  const int d = h->d;
+  std::vector<double> spec((size_t)4 * d);
+  bool any = false;
+  for (int k = 0; k < d; ++k) {
+    const int sc = scale ? scale[k] : BOGP_SCALE_LINEAR, pr = precision ? precision[k] : -1;
+    if (sc < BOGP_SCALE_LINEAR || sc > BOGP_SCALE_BILOG) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_set_transform: unknown scale id %d in dimension %d", sc, k);
+    if (pr > 15) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_set_transform: precision %d in dimension %d (at most 15 decimals)", pr, k);
+    if (pr >= 0 && (!lo || !hi || !(lo[k] <= hi[k]))) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_set_transform: rounding needs the variable's bounds (dimension %d)", k);
+    spec[4 * k] = sc; spec[4 * k + 1] = pr < 0 ? -1 : pr;
+    spec[4 * k + 2] = lo ? lo[k] : 0.0; spec[4 * k + 3] = hi ? hi[k] : 0.0;
+    any = any || sc != BOGP_SCALE_LINEAR || pr >= 0;
+  }
+  if (!any) {
+    h->h_xform.clear();
+    return BOGP_OK;
+  }
+  if (!h->dxform) HIPCHK(h, hipMalloc((void**)&h->dxform, (size_t)4 * BOGP_MAX_DIM * sizeof(double)));
+  h->h_xform = spec;
+  HIPCHK(h, hipMemcpy(h->dxform, spec.data(), spec.size() * sizeof(double), hipMemcpyHostToDevice));
+  return BOGP_OK;
+}
+
 static int generate_finish(bogp_handle* h, int64_t M) {
+  if (!h->h_xform.empty() && (int)h->h_xform.size() == 4 * h->d)
+    HIPCHK(h, launch_candidates_transform(h->dXs_owned, M * h->d, h->d, h->dxform, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));  // lo / hi (and sv) are caller memory
   h->dXs = h->dXs_owned;
   h->M = M;

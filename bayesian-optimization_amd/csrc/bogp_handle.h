@@ -66,6 +66,8 @@ struct bogp_handle {
   size_t xs_cap = 0;
   double* dbounds = nullptr;
   size_t bounds_cap = 0;
+  double* dxform = nullptr;  // per dimension [scale id, precision, lo, hi] of bogp_candidates_set_transform, or null
+  std::vector<double> h_xform;
   double* dsobol = nullptr;  // d x bits direction numbers (uint64 bit patterns)
   size_t sobol_cap = 0;
   int64_t M = 0;

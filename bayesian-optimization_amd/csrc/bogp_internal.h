@@ -112,6 +112,7 @@ hipError_t launch_generate_uniform(double* Xs, int64_t n_elem, int d, const doub
                                    uint64_t first_elem, hipStream_t st);
 hipError_t launch_generate_lhs(double* Xs, int64_t n_elem, int d, const double* lo, const double* hi, uint64_t seed,
                                uint64_t first_elem, uint64_t n_strata, hipStream_t st);
+hipError_t launch_candidates_transform(double* Xs, int64_t n_elem, int d, const double* spec, hipStream_t st);
 hipError_t launch_generate_sobol(double* Xs, int64_t n_elem, int d, const double* lo, const double* hi, const uint64_t* sv,
                                  int bits, uint64_t first_elem, hipStream_t st);
 

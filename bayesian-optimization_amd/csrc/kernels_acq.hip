@@ -331,6 +331,45 @@ hipError_t launch_generate_sobol(double* Xs, int64_t n_elem, int d, const double
   return hipGetLastError();
 }
 
+// Post-processing of generated candidates exactly where RealSpace._sample does it (search_space.py:754:
+// `self.round(self.to_linear_scale(X))`): the designs above are drawn in the TRANSFORMED box (variable.py:246
+// `_bounds_transformed`), each coordinate then goes back to the linear scale with the variable's inverse transform
+// (variable.py:40-55: log -> exp, log10 -> 10^x, logit -> 1 / (1 + exp(-x)), bilog -> sign(x) (exp|x| - 1)) and, if the
+// variable has a precision, is rounded to that many decimals and clipped to its bounds (variable.py:250-257; np.round is
+// rint(x * 10^p) / 10^p).  spec per dimension k: [scale id, precision or -1, lo, hi] as four doubles.
+__global__ __launch_bounds__(256) void k_candidates_transform(double* __restrict__ Xs, int64_t n_elem, int d,
+                                                              const double* __restrict__ spec) {
+#pragma clang fp contract(off)
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_elem) return;
+  const int k = (int)(e % d);
+  const int scale = (int)spec[4 * k];
+  const int prec = (int)spec[4 * k + 1];
+  double x = Xs[e];
+  if (scale == BOGP_SCALE_LOG) {
+    x = exp(x);
+  } else if (scale == BOGP_SCALE_LOG10) {
+    x = pow(10.0, x);
+  } else if (scale == BOGP_SCALE_LOGIT) {
+    x = 1.0 / (1.0 + exp(-x));
+  } else if (scale == BOGP_SCALE_BILOG) {
+    const double a = exp(fabs(x)) - 1.0;
+    x = x > 0.0 ? a : (x < 0.0 ? -a : 0.0 * a);
+  }
+  if (prec >= 0) {
+    double mult = 1.0;
+    for (int i = 0; i < prec; ++i) mult *= 10.0;
+    const double scaled = x * mult;
+    x = rint(scaled) / mult;
+    x = fmin(fmax(x, spec[4 * k + 2]), spec[4 * k + 3]);
+  }
+  Xs[e] = x;
+}
+hipError_t launch_candidates_transform(double* Xs, int64_t n_elem, int d, const double* spec, hipStream_t st) {
+  hipLaunchKernelGGL(k_candidates_transform, dim3((unsigned)((n_elem + 255) / 256)), 256, 0, st, Xs, n_elem, d, spec);
+  return hipGetLastError();
+}
+
 hipError_t launch_acquisition(const AcqArgs& a, hipStream_t st) {
   const unsigned nblk = (unsigned)((a.mcount + 255) / 256);
   hipLaunchKernelGGL(k_acquisition, dim3(nblk), 256, 0, st, a);

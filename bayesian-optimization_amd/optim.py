@@ -22,19 +22,67 @@ from scipy.optimize import fmin_l_bfgs_b
 from . import distributed
 
 
-class Box:
-    """Minimal continuous search space with the three members of `RealSpace` the maximiser touches
-    (`search_space.py:724-769`: `bounds`, `dim`, `sample(N, method)`)."""
+_TRANS = {  # Real.scale -> (forward, inverse) (variable.py:22-55)
+    "linear": (lambda v: v, lambda v: v),
+    "log": (np.log, np.exp),
+    "log10": (np.log10, lambda v: np.power(10, v)),
+    "logit": (lambda v: np.log(v / (1 - v)), lambda v: 1 / (1 + np.exp(-v))),
+    "bilog": (lambda v: np.sign(v) * np.log(1 + np.abs(v)), lambda v: np.sign(v) * (np.exp(np.abs(v)) - 1)),
+}
 
-    def __init__(self, bounds, random_seed=None):
+
+class Box:
+    """Minimal continuous search space with the members of `RealSpace` the maximiser touches
+    (`search_space.py:724-769`: `bounds`, `dim`, `sample(N, method)`), incl. the per-variable `scale` and `precision` of
+    `Real` (variable.py:165-257): sampling is uniform on the transformed scale, then mapped back, rounded and clipped."""
+
+    def __init__(self, bounds, random_seed=None, precision=None, scale=None):
         self.bounds = [tuple(map(float, b)) for b in bounds]
         self.dim = len(self.bounds)
         self._rng = np.random.default_rng(random_seed)
+        self.precision = list(precision) if np.ndim(precision) else [precision] * self.dim
+        self.scale = [(s or "linear") for s in (list(scale) if np.ndim(scale) else [scale] * self.dim)]
 
     def sample(self, N=1, method="uniform"):
-        lo = np.array([b[0] for b in self.bounds])
-        hi = np.array([b[1] for b in self.bounds])
-        return self._rng.uniform(lo, hi, size=(int(N), self.dim))
+        lo_t, hi_t, scales, precs, lo, hi = design_of(self)
+        X = self._rng.uniform(lo_t, hi_t, size=(int(N), self.dim))
+        for k in range(self.dim):
+            X[:, k] = _TRANS[scales[k]][1](X[:, k])
+            if precs[k] is not None:
+                X[:, k] = np.clip(np.round(X[:, k], precs[k]), lo[k], hi[k])
+        return X
+
+
+def design_of(space):
+    """(lo_t, hi_t, scales, precisions, lo, hi) of a continuous search space: the box the design is DRAWN in (transformed
+    bounds, `Real._bounds_transformed`), the per-variable scale names and precisions, and the variables' own bounds.
+    Accepts a plain list of (lo, hi) pairs, a `Box`, or the reference's `RealSpace` (its `data` list of `Real`)."""
+    if isinstance(space, Box):
+        lo = np.array([b[0] for b in space.bounds], dtype=float)
+        hi = np.array([b[1] for b in space.bounds], dtype=float)
+        scales, precs = list(space.scale), list(space.precision)
+    elif hasattr(space, "data") and hasattr(space, "bounds"):  # bayes_optim.RealSpace
+        lo = np.array([v.bounds[0] for v in space.data], dtype=float)
+        hi = np.array([v.bounds[1] for v in space.data], dtype=float)
+        scales = [getattr(v, "scale", "linear") or "linear" for v in space.data]
+        precs = [getattr(v, "precision", None) for v in space.data]
+    else:
+        b = list(getattr(space, "bounds", space))
+        lo = np.array([x[0] for x in b], dtype=float)
+        hi = np.array([x[1] for x in b], dtype=float)
+        scales, precs = ["linear"] * len(b), [None] * len(b)
+    lo_t = np.array([_TRANS[s][0](np.float64(a)) for s, a in zip(scales, lo)], dtype=float)
+    hi_t = np.array([_TRANS[s][0](np.float64(a)) for s, a in zip(scales, hi)], dtype=float)
+    return lo_t, hi_t, scales, precs, lo, hi
+
+
+def _generate(eng, space, count, seed, first_row, method, n_total):
+    """Draw `count` rows of the design of `space` on the device, with RealSpace._sample's post-processing
+    (search_space.py:754: to_linear_scale, then round) applied there too."""
+    lo_t, hi_t, scales, precs, lo, hi = design_of(space)
+    plain = all(s == "linear" for s in scales) and all(p is None for p in precs)
+    eng.set_candidate_transform(None if plain else scales, None if plain else precs, lo, hi)
+    eng.generate_candidates(lo_t, hi_t, count, seed, first_row=first_row, method=method, n_total=n_total)
 
 
 def shard_bounds(M: int, rank: int, world: int):
@@ -75,7 +123,8 @@ def sweep_argmax(criteria: Sequence, Xs: np.ndarray, index_offset: int = 0, grou
 
 def sweep_generated(criteria: Sequence, bounds, M: int, seed: int, rank: int = 0, world: int = 1, group=None,
                     method: str = "uniform"):
-    """`sweep_argmax` over M candidates in `bounds` that never touch the host: rank r draws rows
+    """`sweep_argmax` over M candidates in `bounds` (a list of (lo, hi) pairs, a `Box`, or the reference's `RealSpace` -- scales
+    and precisions of its variables are honoured on the device) that never touch the host: rank r draws rows
     [r M / R, (r+1) M / R) of the design on its GPU, sweeps them, and the ranks exchange their winners (value, global
     row, point).  `method` names the design like `RealSpace._sample` does (search_space.py:742-754): "uniform" (Philox
     stream `seed`), "LHS" (an M-point Latin hypercube of stream `seed`), "sobol" (points 1..M of the unscrambled
@@ -84,11 +133,9 @@ def sweep_generated(criteria: Sequence, bounds, M: int, seed: int, rank: int = 0
     model = c0.model
     if getattr(model, "_committed_par", None) is None:
         raise Exception("The model is not fitted yet!")
-    lo = np.array([b[0] for b in bounds], dtype=float)
-    hi = np.array([b[1] for b in bounds], dtype=float)
     a, b_ = shard_bounds(int(M), rank, world)
     eng = model.engine
-    eng.generate_candidates(lo, hi, b_ - a, seed, first_row=a, method=method, n_total=int(M))
+    _generate(eng, bounds, b_ - a, seed, a, method, int(M))
     best, idx = eng.sweep([(c.acq_id, c.acq_par()) for c in criteria], c0.effective_plugin(), c0.minimize)
     if getattr(eng, "comm_world", 0):
         return eng.exchange_argmax(len(criteria), a, True)
@@ -121,16 +168,14 @@ def sweep_topk_generated(criteria: Sequence, bounds, M: int, k: int, seed: int, 
     model = c0.model
     if getattr(model, "_committed_par", None) is None:
         raise Exception("The model is not fitted yet!")
-    lo = np.array([b[0] for b in bounds], dtype=float)
-    hi = np.array([b[1] for b in bounds], dtype=float)
     a, b_ = shard_bounds(int(M), rank, world)
     eng = model.engine
-    eng.generate_candidates(lo, hi, b_ - a, seed, first_row=a, method=method, n_total=int(M))
+    _generate(eng, bounds, b_ - a, seed, a, method, int(M))
     best, idx = eng.sweep_topk([(c.acq_id, c.acq_par()) for c in criteria], c0.effective_plugin(), c0.minimize, k)
     if getattr(eng, "comm_world", 0):
         return eng.exchange_topk(len(criteria), k, a, True)
     flat = np.clip(idx, 0, b_ - a - 1).ravel()
-    xb = np.where((idx >= 0)[..., None], eng.read_candidates(flat).reshape(idx.shape + (len(lo),)), np.nan)
+    xb = np.where((idx >= 0)[..., None], eng.read_candidates(flat).reshape(idx.shape + (eng.d,)), np.nan)
     gidx = np.where(idx >= 0, idx + a, -1)
     return distributed.exchange_topk(best, gidx, xb, k, group=group)
 
@@ -154,7 +199,7 @@ def batch_argmax(criteria: Sequence, search_space, eval_budget: int, history: Op
         if masks is not None:
             raise NotImplementedError("device-generated designs take no fixed variables")
         seed = int(np.random.randint(0, 2**62)) if seed is None else int(seed)
-        vals, gidx, pts = sweep_topk_generated(criteria, search_space.bounds, int(eval_budget), k, seed, rank, world, group, design)
+        vals, gidx, pts = sweep_topk_generated(criteria, search_space, int(eval_budget), k, seed, rank, world, group, design)
     else:
         if Xs is None:
             Xs = np.asarray(search_space.sample(int(eval_budget), method="uniform"), dtype=float)
@@ -238,7 +283,7 @@ def argmax_restart(
         crit, masks, _ = unwrap_criterion(obj_func)
         if crit is None or masks is not None or h is not None or g is not None:
             raise NotImplementedError("optimizer=%r takes an unconstrained bogp criterion without fixed variables" % optimizer)
-        best, _, xb = sweep_generated([crit], search_space.bounds, int(eval_budget), int(np.random.randint(0, 2**62)),
+        best, _, xb = sweep_generated([crit], search_space, int(eval_budget), int(np.random.randint(0, 2**62)),
                                       method=DEVICE_DESIGNS[optimizer])  # fmt: skip
         return xb[0].tolist(), float(best[0])
     if optimizer == "sweep":

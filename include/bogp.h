@@ -171,6 +171,18 @@ int bogp_candidates_generate_lhs(bogp_handle* h, const double* lo, const double*
 int bogp_candidates_generate_sobol(bogp_handle* h, const double* lo, const double* hi, int64_t M, int64_t first_index,
                                    const uint64_t* sv, int bits);
 int bogp_candidates_read(bogp_handle* h, const int64_t* rows, int n, double* out);
+/* Per-variable post-processing of the three generators above, as RealSpace._sample applies it (search_space.py:754:
+ * `self.round(self.to_linear_scale(X))`): draw in the TRANSFORMED box (pass trans(lo), trans(hi) to the generator:
+ * Real._bounds_transformed, variable.py:246), map every coordinate back with the inverse of its scale (variable.py:40-55)
+ * and, where precision[k] >= 0, round to that many decimals and clip to [lo[k], hi[k]] (the variable's own bounds,
+ * variable.py:250-257).  scale / precision / lo / hi hold d entries; scale == NULL && precision == NULL switches the
+ * post-processing off again.  The setting persists on the handle until changed (it needs bogp_set_train for d).      */
+#define BOGP_SCALE_LINEAR 0
+#define BOGP_SCALE_LOG 1   /* x = exp(u)                      */
+#define BOGP_SCALE_LOG10 2 /* x = 10^u                        */
+#define BOGP_SCALE_LOGIT 3 /* x = 1 / (1 + exp(-u))           */
+#define BOGP_SCALE_BILOG 4 /* x = sign(u) (exp(|u|) - 1)      */
+int bogp_candidates_set_transform(bogp_handle* h, const int* scale, const int* precision, const double* lo, const double* hi);
 
 /* ---- posterior ------------------------------------------------------------------------------------
  * Replaces GaussianProcess.predict(X, eval_MSE) (gpr.py:486-510) on the current candidates:

@@ -131,3 +131,19 @@ def sobol_box(lo, hi, M, sv, first_index=1):
         sel = ((g >> np.uint64(b)) & np.uint64(1)).astype(bool)
         v[sel] ^= sv[:, b]
     return lo + (hi - lo) * (v.astype(np.float64) * 2.0**-bits)
+
+
+def transform(X, scales=None, precisions=None, lo=None, hi=None):
+    """RealSpace.round(RealSpace.to_linear_scale(X)) (search_space.py:754-770) for a design X drawn in the transformed box:
+    per column the inverse of the variable's scale (variable.py:40-55), then np.round to its precision and the clip to its
+    bounds (variable.py:250-257).  NumPy's own exp / power: the device's libm may differ from them in the last place."""
+    X = np.array(X, dtype=np.float64)
+    d = X.shape[1]
+    inv = {None: lambda v: v, "linear": lambda v: v, "log": np.exp, "log10": lambda v: np.power(10, v),
+           "logit": lambda v: 1 / (1 + np.exp(-v)), "bilog": lambda v: np.sign(v) * (np.exp(np.abs(v)) - 1)}  # fmt: skip
+    for k in range(d):
+        X[:, k] = inv[scales[k] if scales is not None else None](X[:, k])
+        p = precisions[k] if precisions is not None else None
+        if p is not None:
+            X[:, k] = np.clip(np.round(X[:, k], p), lo[k], hi[k])
+    return X

@@ -438,3 +438,51 @@ def test_a_failed_factorisation_does_not_poison_the_next_one():
         assert again[0] == ref[0]
         np.testing.assert_array_equal(again[1], ref[1])
     eng.close()
+
+
+def test_device_designs_apply_scale_and_precision_like_realspace_sample():
+    """search_space.py:754 `self.round(self.to_linear_scale(X))` on the device: the three designs drawn in the transformed
+    box, mapped back per variable (log10 / logit / bilog / log / linear) and rounded + clipped where a precision is set --
+    against the NumPy restatement (oracle/philox.py): exact where only rounding is involved, within 2 ulp through exp / pow
+    (the device's libm against NumPy's)."""
+    from bogp import optim
+    from oracle import philox as P
+
+    bounds = [(1e-3, 10.0), (-5.0, 5.0), (0.01, 0.99), (-100.0, 100.0), (0.5, 50.0), (-1.0, 1.0)]
+    scale = ["log10", "linear", "logit", "bilog", "log", None]
+    prec = [None, 2, None, 1, 3, None]
+    box = optim.Box(bounds, random_seed=0, precision=prec, scale=scale)
+    lo_t, hi_t, scales, precs, lo, hi = optim.design_of(box)
+    d = len(bounds)
+    eng = _lib.Engine(0)
+    eng.set_train(np.zeros((4, d)) + np.arange(4)[:, None], np.arange(4.0))
+    M = 20000
+    for method, ref in (("uniform", lambda: P.uniform_box(lo_t, hi_t, M, 77, first_row=123)),
+                        ("LHS", lambda: P.lhs_box(lo_t, hi_t, M, 77, first_row=123, n_strata=M + 123)),
+                        ("sobol", lambda: P.sobol_box(lo_t, hi_t, M, _lib.sobol_direction_numbers(d), first_index=124))):  # fmt: skip
+        eng.set_candidate_transform(scales, precs, lo, hi)
+        eng.generate_candidates(lo_t, hi_t, M, seed=77, first_row=123, method=method, n_total=M + 123)
+        got = eng.read_candidates(np.arange(M))
+        want = P.transform(ref(), scales, precs, lo, hi)
+        for k in range(d):
+            assert np.all(got[:, k] >= lo[k]) and np.all(got[:, k] <= hi[k])
+            if scales[k] == "linear":
+                np.testing.assert_array_equal(got[:, k], want[:, k])  # Philox integers + a separately rounded multiply-add + np.round
+            elif precs[k] is None:
+                np.testing.assert_allclose(got[:, k], want[:, k], rtol=5e-16, atol=0)
+            else:  # rounded after a transcendental: equal except where 2 ulp straddle a rounding boundary
+                differ = got[:, k] != want[:, k]
+                assert differ.mean() < 1e-3 and np.all(np.abs(got[differ, k] - want[differ, k]) <= 10.0 ** -precs[k] * 1.0000001)
+        # the setting is sticky until reset
+        eng.set_candidate_transform()
+        eng.generate_candidates(lo_t, hi_t, 16, seed=77, method=method)
+        plain = eng.read_candidates(np.arange(16))
+        assert np.all(plain >= lo_t - 1e-12) and np.all(plain <= hi_t + 1e-12)
+    eng.close()
+    # through the optimiser front end: the proposal honours precision and bounds of the space
+    gp, X, y = _fitted_model(N=120, d=3)
+    sp = optim.Box([(-5, 5)] * 3, random_seed=1, precision=[2, None, 0], scale=[None, None, None])
+    np.random.seed(3)
+    xopt, fopt = bogp.argmax_restart(bogp.EI(model=gp), sp, eval_budget=30000, optimizer="sweep-device-lhs")
+    assert np.round(xopt[0], 2) == xopt[0] and np.round(xopt[2], 0) == xopt[2] and all(abs(v) <= 5 for v in xopt)
+    np.testing.assert_allclose(float(np.ravel(bogp.EI(model=gp)(np.array(xopt).reshape(1, -1)))[0]), fopt, rtol=1e-9)
