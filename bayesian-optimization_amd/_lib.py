@@ -160,13 +160,26 @@ def trend_size_of(trend: int, d: int) -> int:
     return 1 if trend == TREND_CONSTANT else (d + 1 if trend == TREND_LINEAR else (d + 1) * (d + 2) // 2)
 
 
-def sobol_direction_numbers(d: int) -> np.ndarray:
-    """The (d, bits) direction numbers of scipy's unscrambled Sobol' generator (Joe & Kuo tables, bits = 30): what
-    the reference's `sobol_seq` call resolves to in this image.  Data for
-    `bogp_candidates_generate_sobol`, which carries no table of its own."""
+def sobol_direction_numbers(d: int, bits: int = 30) -> np.ndarray:
+    """The (d, bits) direction numbers of scipy's unscrambled Sobol' generator (Joe & Kuo tables): what the reference's
+    `sobol_seq` call resolves to in this image.  Data for `bogp_candidates_generate_sobol`, which
+    carries no table of its own.  Recovered through scipy's PUBLIC interface only: point n of the sequence is the XOR of
+    the direction numbers over the set bits of the Gray code of n, and gray(2^b) = 2^b ^ 2^(b-1), so
+    sv[b] = x_(2^b) ^ sv[b-1] with x_(2^b) read off `Sobol.fast_forward(2^b).random(1)` (exact multiples of 2^-bits)."""
     from scipy.stats import qmc
 
-    return np.ascontiguousarray(qmc.Sobol(d=int(d), scramble=False)._sv, dtype=np.uint64)
+    sv = np.zeros((int(d), int(bits)), dtype=np.uint64)
+    prev = np.zeros(int(d), dtype=np.uint64)
+    for b in range(int(bits)):
+        eng = qmc.Sobol(d=int(d), scramble=False, bits=int(bits))
+        if b:
+            eng.fast_forward(2**b)
+        else:
+            eng.fast_forward(1)
+        ints = np.round(eng.random(1)[0] * 2.0 ** int(bits)).astype(np.uint64)
+        sv[:, b] = ints ^ prev if b else ints
+        prev = sv[:, b]
+    return np.ascontiguousarray(sv)
 
 
 class Engine:

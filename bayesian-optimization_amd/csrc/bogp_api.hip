@@ -74,7 +74,7 @@ static void free_trend(bogp_handle* h) {
   dfree(h->dF); dfree(h->dFt); dfree(h->dQ1); dfree(h->dQ); dfree(h->dWp);
   for (int b = 0; b < 2; ++b) { dfree(h->dA[b]); dfree(h->dAV[b]); dfree(h->dAU[b]); }
   dfree(h->dAw); dfree(h->dAT); dfree(h->dGinv); dfree(h->dSinv); dfree(h->dbetav); dfree(h->dqty); dfree(h->dinfo2);
-  h->tr_built = -1; h->tr_p = 0; h->ldp = 0; h->trend = BOGP_TREND_CONSTANT; h->p = 1;
+  h->tr_built = -1; h->tr_p = 0; h->ldp = 0; h->trend = BOGP_TREND_CONSTANT; h->p = 1; h->reml_ftf_basis = -1;
 }
 
 static void free_train(bogp_handle* h) {
@@ -531,7 +531,7 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
   if (!par || !llf || n_par <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_nll_restricted: par/llf must be non-null");
   if (grad && (kernel == BOGP_KERNEL_CUBIC || kernel == BOGP_KERNEL_GENEXP)) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_restricted: the cubic / generalized_exponential correlation has no theta-derivative");
   if (mode < 0 || mode > 2) FAIL(h, BOGP_ERR_INVALID, "unknown estimation mode %d", mode);
-  if (trend != BOGP_TREND_CONSTANT) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_restricted: only the constant trend basis is built (trend id %d)", trend);
+  if (trend < BOGP_TREND_CONSTANT || trend > BOGP_TREND_QUADRATIC) FAIL(h, BOGP_ERR_INVALID, "unknown trend id %d", trend);
   if (h->n_t != 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_restricted: single-target y only (have %d targets)", h->n_t);
   h->committed = false;
   const int n_tail = mode == BOGP_MODE_NOISE_ESTIM ? 2 : 1;
@@ -547,8 +547,46 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
   if (rc != BOGP_OK) return rc;
   const int N = h->N, d = h->d, ldr = h->ldr;
   const double tv = sigma2 + nv, TWO_PI = 2.0 * 3.141592653589793;
+  const int ptrend = trend_size(trend, d);
   double v;
-  if (estimate_trend)  // p = 1: det(F^T F) = N, prod(diag G)^2 = |Ft|^2  (:850-860)
+  if (estimate_trend && ptrend > 1) {
+    // p > 1 (:850-860): (N - p) log(2 pi tv) - log det(F^T F) + 2 sum log diag L + log prod diag(G)^2 + rho.rho / tv
+    //   det(F^T F): a constant of (training set, basis) -- F^T F on the device, its p x p Cholesky on the host, cached;
+    //   diag(G) = diag(R2) diag(R1) of the two CholeskyQR passes (G = R2 R1, both upper triangular)
+    hipStream_t st = h->stream;
+    const int ldp = h->ldp;
+    if (h->reml_ftf_basis != h->tr_built) {
+      const double one = 1.0, zero = 0.0;
+      BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_transpose, rocblas_operation_none, ptrend, ptrend, N, &one, h->dF, N, h->dF, N, &zero, h->dAT, ldp));
+      std::vector<double> a((size_t)ldp * ptrend);
+      HIPCHK(h, hipMemcpyAsync(a.data(), h->dAT, a.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+      double ld2 = 0.0;  // log det by an unblocked host Cholesky of the p x p Gram matrix (column-major, lower)
+      for (int j = 0; j < ptrend; ++j) {
+        double dj = a[(size_t)j * ldp + j];
+        for (int k = 0; k < j; ++k) dj -= a[(size_t)k * ldp + j] * a[(size_t)k * ldp + j];
+        if (!(dj > 0)) FAIL(h, BOGP_ERR_NOT_POSDEF, "trend basis is rank deficient (F^T F not positive definite at column %d)", j);
+        const double ljj = std::sqrt(dj);
+        a[(size_t)j * ldp + j] = ljj;
+        ld2 += 2.0 * std::log(ljj);
+        for (int i = j + 1; i < ptrend; ++i) {
+          double s_ = a[(size_t)j * ldp + i];
+          for (int k = 0; k < j; ++k) s_ -= a[(size_t)k * ldp + i] * a[(size_t)k * ldp + j];
+          a[(size_t)j * ldp + i] = s_ / ljj;
+        }
+      }
+      h->reml_logdet_ftf = ld2;
+      h->reml_ftf_basis = h->tr_built;
+    }
+    std::vector<double> dg((size_t)2 * ptrend);
+    for (int pass = 0; pass < 2; ++pass)
+      HIPCHK(h, hipMemcpy2DAsync(dg.data() + (size_t)pass * ptrend, sizeof(double), h->dA[pass], (size_t)(ldp + 1) * sizeof(double),
+                                 sizeof(double), ptrend, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    double lg = 0.0;
+    for (double x : dg) lg += std::log(std::fabs(x));
+    v = -0.5 * ((N - ptrend) * std::log(TWO_PI * tv) - h->reml_logdet_ftf + 2.0 * o.logdet + 2.0 * lg + o.rho_ss / tv);
+  } else if (estimate_trend)  // p = 1: det(F^T F) = N, prod(diag G)^2 = |Ft|^2  (:850-860)
     v = -0.5 * ((N - 1) * std::log(TWO_PI * tv) - std::log((double)N) + 2.0 * o.logdet + std::log(o.ftft) + o.rho_ss / tv);
   else  // the reference SUBTRACTS the log-determinant here (:861-866)
     v = -0.5 * (N * std::log(TWO_PI * tv) - 2.0 * o.logdet + o.rho_ss / tv);
@@ -563,7 +601,15 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
     HIPCHK(h, launch_uut(h->dU, h->dRinv, ldr, st, &nparts));
     const double* qv = nullptr;
     double c2 = 0.0;
-    if (estimate_trend) {  // q = L^-T Q = (L^-T Ft) / G
+    if (estimate_trend && ptrend > 1) {
+      // term = (L^-T Q)(L^-T Q)^T = W S W^T with W = L^-T Ft (N x p) and S = (Ft^T Ft)^-1: folded into the first slice of
+      // R^-1 as R^-1 - tv W S W^T (two library GEMMs with inner dimension p), after which the p = 1 code below applies
+      // with no separate q vector: the contraction sees R^-1 - tv term, and its trace is tr(R^-1) - tv tr(term)
+      const double one = 1.0, zero = 0.0, mtv = -tv;
+      BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_none, N, ptrend, N, &one, h->dU, ldr, h->dFt, N, &zero, h->dQ1, N));
+      BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_none, N, ptrend, ptrend, &one, h->dQ1, N, h->dSinv, ptrend, &zero, h->dWp, N));
+      BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_transpose, N, N, ptrend, &mtv, h->dWp, N, h->dQ1, N, &one, h->dRinv, ldr));
+    } else if (estimate_trend) {  // q = L^-T Q = (L^-T Ft) / G
       HIPCHK(h, hipMemsetAsync(h->dw, 0, h->Np * sizeof(double), st));
       HIPCHK(h, launch_gemv2(h->dU, ldr, N, 2, h->dft, nullptr, h->dw, nullptr, h->dgemv_scratch, st));
       qv = h->dw;
@@ -582,7 +628,7 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
     std::vector<double> S(d + 4);
     HIPCHK(h, hipMemcpyAsync(S.data(), dS, (d + 4) * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
-    const double tr = S[d + 1], gg = S[d + 2], qq = estimate_trend ? S[d + 3] / o.ftft : 0.0;
+    const double tr = S[d + 1], gg = S[d + 2], qq = (estimate_trend && ptrend == 1) ? S[d + 3] / o.ftft : 0.0;
     const double diag = -0.5 * (tr / tv - gg / (tv * tv) - qq);  // sum over the diagonal of (Cinv - gamma_ gamma_^T - term)
     for (int k = 0; k < d; ++k) grad[k] = S[k];
     grad[d] = S[d] / tv + diag;                              // d / d sigma2: C_grad = R0 (:883)

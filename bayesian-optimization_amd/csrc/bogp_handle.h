@@ -86,6 +86,8 @@ struct bogp_handle {
 
   // polynomial trend bases with p > 1 columns (linear / quadratic; the constant basis keeps its scalar fast path)
   int trend = BOGP_TREND_CONSTANT, p = 1;  // committed
+  double reml_logdet_ftf = 0.0;  // log det(F^T F) of the basis `reml_ftf_basis` (REML value, p > 1); -1: none cached
+  int reml_ftf_basis = -1;
   int tr_built = -1, tr_p = 0, ldp = 0;    // basis currently held in dF / sizes of the buffers below
   std::vector<double> h_beta_fixed;        // bogp_set_trend_beta: simple-kriging coefficients
   std::vector<double> h_betav, h_Sinv;     // committed beta (p) and (Ft^T Ft)^-1 (p x p, column-major) for bogp_gradient

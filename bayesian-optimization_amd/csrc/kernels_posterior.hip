@@ -8,8 +8,10 @@
 //     1 - sum(rt^2) [+ sum(u^2)]                                     -> k_contract epilogue (+ acquisition kernel)
 //
 // Design constants come from measurements on the target (tools/ubench_f64*.hip, profiles/ubench_r01.txt):
-//   * v_mfma_f64_4x4x4_4b_f64 issues every 16 cycles (512 flop) = 32 flop/clk/SIMD = the 78.6 TF/s FP64 peak;
-//     v_mfma_f64_16x16x4_f64 needs ~137 cycles (2048 flop) = HALF that rate on gfx950 -> not used.
+//   * v_mfma_f64_4x4x4_4b_f64 issues every 16 cycles (512 flop) = 32 flop/clk/SIMD = the 78.6 TF/s FP64 peak (kernel B below);
+//     v_mfma_f64_16x16x4_f64 issues every 64 cycles (2048 flop) = the same rate -- but only with its accumulator in
+//     architectural VGPRs (with AGPR accumulators, where the builtin puts them: ~130 cycles).  Kernel B' below, the DEFAULT,
+//     is built on it: one A and one B register per 2048 flop instead of four rotated A registers.
 //   * FP64 VALU work does not hide beside FP64 MFMA (same DP pipe: times add), so the kernel-matrix
 //     producer must run ONCE per (candidate, training point) -- it is split into its own kernel and r is
 //     staged through HBM/L2 in candidate chunks instead of being recomputed per column tile.

@@ -194,8 +194,6 @@ class GaussianProcess:
             raise ValueError("optimizer should be one of %s" % self._optimizer_types)
         if self.optimizer == "CMA":
             raise NotImplementedError("optimizer='CMA' is out of scope (SURVEY.md 2 row 8); use 'BFGS'")
-        if self.likelihood == "restricted" and type(self.mean).__name__ != "constant_trend":
-            raise NotImplementedError("likelihood='restricted' is built for the constant trend basis only")
 
     def _check_data(self, X, y):
         """gpr.py:279-310 without the pair-distance list (never built on the device)."""
@@ -211,7 +209,7 @@ class GaussianProcess:
             raise ValueError("Found input variables with inconsistent numbers of samples: [%d, %d]" % (X.shape[0], y.shape[0]))
         if not (np.isfinite(X).all() and np.isfinite(y).all()):
             raise ValueError("Input contains NaN, infinity or a value too large for dtype('float64').")
-        if y.shape[1] > 1 and (self.estimate_trend or type(self.mean).__name__ != "constant_trend" or self.likelihood == "restricted"):
+        if y.shape[1] > 1 and (self.estimate_trend or type(self.mean).__name__ != "constant_trend" or self.likelihood == "restricted"):  # (REML: single target)
             # the reference gets through the MLE and then raises "Shapes of beta and F do not match." (gpr.py:787 assigns
             # a (p, n_targets) beta); only a fixed constant trend works there with several targets
             raise NotImplementedError("multi-target y needs a fixed constant trend (constant_trend(dim, beta=...)) and the concentrated likelihood")

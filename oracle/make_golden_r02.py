@@ -55,7 +55,44 @@ def one(name, corr, kid, d, n_theta, mean_pin, par, seed, theta_draw):
          **state_dict(gp, llf), **acq_rows(gp, Xs), **tabs)  # fmt: skip
 
 
+def golden_reml_trends():
+    """G27: the restricted likelihood (gpr.py:813-918) with the linear (p = d + 1) and quadratic (p = (d+1)(d+2)/2) trend
+    bases, value + gradient, three modes x {estimated, fixed coefficients} x {SE, Matern-3/2}: the p > 1 forms of
+    -log det(F^T F), log prod diag(G)^2 and the (L^-T Q)(L^-T Q)^T gradient term."""
+    X, y = make_data(27, 45, 3)
+    y = y + 0.2 * np.random.default_rng(327).standard_normal(y.shape)
+    d = 3
+    out = dict(X=X, y=y)
+    rng = np.random.default_rng(227)
+    n = 0
+    for tid, tcls in ((1, trend.linear_trend), (2, trend.quadratic_trend)):
+        p = d + 1 if tid == 1 else (d + 1) * (d + 2) // 2
+        beta_fixed = np.round(rng.uniform(-0.3, 0.3, size=p), 3)
+        out["t%d_beta" % tid] = beta_fixed
+        for kid, corr in ((0, "squared_exponential"), (2, "matern")):
+            for mid, kw in ((0, dict(nugget=0)), (1, dict(nugget=1e-6)), (2, dict(nugget=1e-6, noise_estim=True))):
+                for tname, mean in (("uk", lambda: tcls(d)), ("sk", lambda: tcls(d, beta=beta_fixed))):
+                    gp = GaussianProcess(mean=mean(), corr=corr, thetaL=[1e-4] * d, thetaU=[1e2] * d, likelihood="restricted", **kw)
+                    gp._check_data(X, y)
+                    pars, vals, grads = [], [], []
+                    for _ in range(3):
+                        th = 10 ** rng.uniform(-1.5, -0.6, size=d)
+                        pr = np.r_[th, rng.uniform(0.3, 1.2)]
+                        if mid == 2:
+                            pr = np.r_[pr, 10 ** rng.uniform(-4, -1)]
+                        v, g = gp.log_likelihood_restricted(pr, eval_grad=True)
+                        pars.append(pr)
+                        vals.append(float(v))
+                        grads.append(np.asarray(g, float).ravel())
+                        n += 1
+                    key = "t%d_k%d_m%d_%s" % (tid, kid, mid, tname)
+                    out[key + "_par"], out[key + "_llf"], out[key + "_grad"] = np.array(pars), np.array(vals), np.array(grads)
+    assert n == 72
+    save("G27_reml_trend_tables", **out)
+
+
 if __name__ == "__main__":
+    golden_reml_trends()
     d = 4
     one("G25_cubic_ok_noisy", "cubic", 5, d, d, lambda: trend.constant_trend(d), np.r_[0.06, 0.09, 0.05, 0.08, 0.85], 25,
         lambda r: 10 ** r.uniform(-1.5, -0.8, size=d))

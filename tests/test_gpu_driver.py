@@ -486,3 +486,42 @@ def test_device_designs_apply_scale_and_precision_like_realspace_sample():
     xopt, fopt = bogp.argmax_restart(bogp.EI(model=gp), sp, eval_budget=30000, optimizer="sweep-device-lhs")
     assert np.round(xopt[0], 2) == xopt[0] and np.round(xopt[2], 0) == xopt[2] and all(abs(v) <= 5 for v in xopt)
     np.testing.assert_allclose(float(np.ravel(bogp.EI(model=gp)(np.array(xopt).reshape(1, -1)))[0]), fopt, rtol=1e-9)
+
+
+def test_reml_with_polynomial_trends_on_the_device():
+    """bogp_nll_restricted with the linear (p = 4) and quadratic (p = 10) bases against the reference's tables (G27): value
+    1e-9, gradient 1e-6; then `fit(likelihood="restricted")` with a linear trend runs to a finite optimum whose value the
+    oracle reproduces."""
+    from conftest import load_golden
+
+    g = load_golden("G27_reml_trend_tables")
+    eng = _lib.Engine(0)
+    eng.set_train(g["X"], g["y"])
+    n = 0
+    for tid in (1, 2):
+        beta = g["t%d_beta" % tid]
+        for kid in (0, 2):
+            for mid in (0, 1, 2):
+                for tname in ("uk", "sk"):
+                    key = "t%d_k%d_m%d_%s" % (tid, kid, mid, tname)
+                    for p, v, gr in zip(g[key + "_par"], g[key + "_llf"], g[key + "_grad"]):
+                        llf, grad = eng.nll_restricted(kid, mid, p, 1e-6 if mid == 1 else 0.0, tname == "uk", beta, eval_grad=True, trend=tid)
+                        if np.isneginf(v):
+                            assert np.isneginf(llf)
+                        else:
+                            np.testing.assert_allclose(llf, v, rtol=1e-9, err_msg=key)
+                        np.testing.assert_allclose(grad, gr, rtol=1e-6, atol=1e-8 * np.abs(gr).max(), err_msg=key)
+                        assert eng.nll_restricted(kid, mid, p, 1e-6 if mid == 1 else 0.0, tname == "uk", beta, trend=tid) == llf
+                        n += 1
+    assert n == 72
+    eng.close()
+    X, y = g["X"], g["y"]
+    gp = bogp.GaussianProcess(mean=bogp.trend.linear_trend(3), corr="matern", thetaL=[1e-2] * 3, thetaU=[1e2] * 3, nugget=1e-6,
+                              likelihood="restricted", random_start=2, eval_budget=80)  # fmt: skip
+    np.random.seed(5)
+    assert gp.fit(X, y) is gp and gp.is_fitted and np.isfinite(gp.log_likelihood_)
+    par = np.concatenate([np.ravel(gp.par[k]) for k in ("theta", "sigma2")])
+    ref = O.log_likelihood_restricted(par, X, y, O.KERNEL_MATERN32, O.MODE_NOISY, noise_var=1e-6, trend=O.TREND_LINEAR, estimate_trend=True)
+    np.testing.assert_allclose(gp.log_likelihood_, ref, rtol=1e-9)
+    mu, mse = gp.predict(X[:5], eval_MSE=True)
+    assert mu.shape == (5, 1) and np.all(mse >= 0)

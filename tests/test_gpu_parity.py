@@ -443,7 +443,7 @@ def test_classes_follow_the_protocols():
         for i in range(8):
             v, dx = c(g["Xs"][i : i + 1], return_dx=True)
             np.testing.assert_allclose(np.ravel(v)[0], g["dx_val_" + key][i], rtol=1e-6)
-            np.testing.assert_allclose(np.ravel(dx), g["dx_" + key][i], rtol=1e-5, atol=1e-12)
+            np.testing.assert_allclose(np.ravel(dx), g["dx_" + key][i], rtol=1e-6, atol=1e-12)  # north_star: 1e-6
     pi = bogp.PI(model=gp)(x1)
     np.testing.assert_allclose(np.ravel(pi)[0], g["EpsilonPI_1e-10"][0], rtol=1e-6)
     # pickling: no device handles travel, predictions are reproduced after a lazy re-commit

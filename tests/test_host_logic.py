@@ -45,8 +45,8 @@ def test_constructor_contract():
     with pytest.raises(NotImplementedError):
         bogp.GaussianProcess(thetaL=[1e-3], thetaU=[1e2], optimizer="CMA")
     assert bogp.GaussianProcess(thetaL=[1e-3], thetaU=[1e2], likelihood="restricted").likelihood == "restricted"
-    with pytest.raises(NotImplementedError):  # REML is built for the constant basis
-        bogp.GaussianProcess(mean=bogp.trend.linear_trend(1), thetaL=[1e-3], thetaU=[1e2], likelihood="restricted")
+    # REML takes every trend basis (round 2: p > 1 forms of det(F^T F), diag(G) and the (L^-T Q)(L^-T Q)^T term)
+    assert bogp.GaussianProcess(mean=bogp.trend.linear_trend(1), thetaL=[1e-3], thetaU=[1e2], likelihood="restricted").likelihood == "restricted"
     assert hasattr(gp, "gradient")  # its presence selects the BFGS inner optimiser (base.py:201)
 
 

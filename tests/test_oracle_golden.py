@@ -412,3 +412,24 @@ def test_value_only_kernels_against_the_reference(name):
                     np.testing.assert_allclose(out, l_, rtol=1e-11)
                 else:
                     assert out == l_
+
+
+def test_reml_with_polynomial_trends_against_the_reference():
+    """G27: log_likelihood_restricted (gpr.py:813-918) with linear / quadratic bases (p > 1), value and gradient."""
+    g = load_golden("G27_reml_trend_tables")
+    n = 0
+    for tid in (1, 2):
+        for kid in (0, 2):
+            for mid in (0, 1, 2):
+                for tname in ("uk", "sk"):
+                    key = "t%d_k%d_m%d_%s" % (tid, kid, mid, tname)
+                    for p, v, gr in zip(g[key + "_par"], g[key + "_llf"], g[key + "_grad"]):
+                        out = O.log_likelihood_restricted(p, g["X"], g["y"], kid, mid, noise_var=1e-6 if mid == 1 else 0.0, trend=tid,
+                                                          estimate_trend=(tname == "uk"), beta=g["t%d_beta" % tid], eval_grad=True)  # fmt: skip
+                        if np.isneginf(v):
+                            assert np.isneginf(out[0])
+                        else:
+                            close(out[0], v, rtol=1e-10)
+                        close(out[1], gr, rtol=1e-7, atol=1e-8)
+                        n += 1
+    assert n == 72
