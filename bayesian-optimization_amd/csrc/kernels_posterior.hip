@@ -344,6 +344,10 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nMt = a.nMt;
+  // Column-group-major order, heaviest group first: concurrent workgroups then walk the SAME 256-column panel of V, which
+  // stays hot in every XCD's L2 (the B fragments feed the MFMAs straight from global loads).  Measured alternative (r02,
+  // tools/ab_contract_order.sh): the nJ groups of one candidate tile back to back on one XCD -- r tiles shared in L2, but the
+  // B reads then span all of V (16 MB against 4 MB of L2): 61.5 -> 85.4 ms per step.  r is re-read (nJ + 1) / 2 times instead.
   const int jg = a.nJ - 1 - (int)(blockIdx.x / nMt);
   const int mt = blockIdx.x % nMt;
   const int64_t mc0 = (int64_t)mt * 64;
@@ -376,22 +380,25 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
   const int scol = (tid & 31) * 2;
   const double* __restrict__ rbase = a.rT + mc0 + scol;
   const size_t Mc = (size_t)a.Mc;
-  double2 st0, st1, st2, st3;
-#define BOGP_STAGE_LOAD(kb_)                                                                         \
+  // Two register sets for the staged r tiles: tile kb + 2 is requested while tile kb is contracted and tile kb + 1 (requested one
+  // block earlier) is written to LDS at the END of the block -- every load has TWO blocks of MFMA work to arrive.  With one
+  // set (one block of cover) the half-empty blocks of the diagonal zone no longer hid the ~2 us round trip to HBM.
+  double2 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+#define BOGP_STAGE_LOAD(S, kb_)                                                                      \
   do {                                                                                               \
     const double* p_ = rbase + (size_t)((kb_)*KB + srow) * Mc;                                       \
-    st0 = *reinterpret_cast<const double2*>(p_);                                                     \
-    st1 = *reinterpret_cast<const double2*>(p_ + 8 * Mc);                                            \
-    st2 = *reinterpret_cast<const double2*>(p_ + 16 * Mc);                                           \
-    st3 = *reinterpret_cast<const double2*>(p_ + 24 * Mc);                                           \
+    S##0 = *reinterpret_cast<const double2*>(p_);                                                    \
+    S##1 = *reinterpret_cast<const double2*>(p_ + 8 * Mc);                                           \
+    S##2 = *reinterpret_cast<const double2*>(p_ + 16 * Mc);                                          \
+    S##3 = *reinterpret_cast<const double2*>(p_ + 24 * Mc);                                          \
   } while (0)
-#define BOGP_STAGE_STORE(buf_)                                                                       \
+#define BOGP_STAGE_STORE(S, buf_)                                                                    \
   do {                                                                                               \
     double* q_ = &lds[(buf_)*KB * PITCH + srow * PITCH + scol];                                      \
-    *reinterpret_cast<double2*>(q_) = st0;                                                           \
-    *reinterpret_cast<double2*>(q_ + 8 * PITCH) = st1;                                               \
-    *reinterpret_cast<double2*>(q_ + 16 * PITCH) = st2;                                              \
-    *reinterpret_cast<double2*>(q_ + 24 * PITCH) = st3;                                              \
+    *reinterpret_cast<double2*>(q_) = S##0;                                                          \
+    *reinterpret_cast<double2*>(q_ + 8 * PITCH) = S##1;                                              \
+    *reinterpret_cast<double2*>(q_ + 16 * PITCH) = S##2;                                             \
+    *reinterpret_cast<double2*>(q_ + 24 * PITCH) = S##3;                                             \
   } while (0)
 
   const double2* __restrict__ vp = a.Vp + lane;
@@ -406,15 +413,20 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
   // different 128-byte bank groups
   const int aoff = (lane >> 4) * PITCH + (lane & 15);
 
-  BOGP_STAGE_LOAD(0);
-  BOGP_STAGE_STORE(0);
+  BOGP_STAGE_LOAD(sa, 0);
+  BOGP_STAGE_STORE(sa, 0);
+  BOGP_STAGE_LOAD(sa, min(1, nkb - 1));  // tile 1 -> set A (stored at the end of block 0)
 
-  for (int kb = 0; kb < nkb; ++kb) {
-    __syncthreads();
-    BOGP_STAGE_LOAD(min(kb + 1, nkb - 1));
-    const double* tile = &lds[(kb & 1) * KB * PITCH];
-    contract_block16<NR>(kb >= nkb_full, tile, vp, boff, jt, aoff, kb, kp_last, bq, acc);
-    BOGP_STAGE_STORE((kb + 1) & 1);
+  for (int kb = 0; kb < nkb; kb += 2) {
+    __syncthreads();  // tile kb is in lds[0]; every wave is done with lds[1]
+    BOGP_STAGE_LOAD(sb, min(kb + 2, nkb - 1));
+    contract_block16<NR>(kb >= nkb_full, &lds[0], vp, boff, jt, aoff, kb, kp_last, bq, acc);
+    BOGP_STAGE_STORE(sa, 1);  // tile kb + 1
+    if (kb + 1 >= nkb) break;
+    __syncthreads();  // tile kb + 1 is in lds[1]; every wave is done with lds[0]
+    BOGP_STAGE_LOAD(sa, min(kb + 3, nkb - 1));
+    contract_block16<NR>(kb + 1 >= nkb_full, &lds[KB * PITCH], vp, boff, jt, aoff, kb + 1, kp_last, bq, acc);
+    BOGP_STAGE_STORE(sb, 0);  // tile kb + 2
   }
 #undef BOGP_STAGE_LOAD
 #undef BOGP_STAGE_STORE

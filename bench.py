@@ -17,6 +17,7 @@ flops / HIP-event duration on the library's stream) + "cpu_baseline" (the NumPy 
 cores on a bounded sample of the same workload; also used as a parity check of the timed run).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -142,7 +143,16 @@ def main():
     torch.cuda.synchronize()
     eng.bind_candidates(Xs.data_ptr(), M, owner=Xs)
     # the library's own RCCL communicator over the ranks (a one-rank communicator at N = 1: the collective still runs)
-    distributed.init_engine_comm(eng)
+    # (RCCL announces itself on C stdout: send that to stderr so that stdout carries the JSON line and nothing else)
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        distributed.init_engine_comm(eng)
+        ctypes.CDLL(None).fflush(None)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
     q = len(w["acq"])
 
     def step():
@@ -246,7 +256,10 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(w, X, y, par, plugin, Xs[: args.cpu_sample].cpu().numpy(), args.cpu_sample, eng)
-        print(json.dumps(res))
+        # RCCL prints a banner through C stdio, whose buffer would otherwise drain AFTER this line at exit: flush it first so
+        # the JSON line is the LAST line of stdout
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()
 
