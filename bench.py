@@ -218,6 +218,13 @@ def main():
         traffic, traffic_source = measured_traffic(args.workload, ((1 << 30) // (((N + 31) // 32 * 32) * 8)) // 64 * 64)
         flops_contract = (float(N) * N + 3.0 * N) * M * args.steps  # k_contract: forward substitution + sum of squares
         achieved = flops_contract / (tim["contract_ms"] * 1e-3) / 1e12
+        if tim["corr_ms"] == 0.0 and tim["acquisition_ms"] == 0.0:  # the fused small-N sweep: ONE kernel, its whole time
+            kernel_label = ("k_sweep_small (N <= 512: correlation producer + v_mfma_f64_16x16x4_f64 contraction + acquisition + "
+                            "argmax in ONE kernel; `achieved` counts the contraction's flops over the whole kernel's time)")
+        elif os.environ.get("BOGP_CONTRACT_MFMA", "16")[0] != "4":
+            kernel_label = "k_contract16 (v_mfma_f64_16x16x4_f64, VGPR accumulators)"
+        else:
+            kernel_label = "k_contract (v_mfma_f64_4x4x4_4b_f64)"
         res = {
             "metric": "candidates/sec (GP posterior+EI) at N=2048,d=20 and ask() wall-time, 1/2/4/8 GPU",
             "value": value,
@@ -234,7 +241,7 @@ def main():
             "config": {"workload": w["name"], "N": N, "d": d, "M_per_gpu": M, "M_total": M_total, "q": len(w["acq"]),
                        "parallelism": "candidate shards x%d, 1 ncclAllGather of q*(val,idx,x) per step (bogp_exchange_argmax)" % world},
             "roofline": (lambda r: dict(r, hbm_GBps=(r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) if r["traffic"] else None))({
-                "bound": "mfma", "kernel": "k_contract16 (v_mfma_f64_16x16x4_f64, VGPR accumulators)" if os.environ.get("BOGP_CONTRACT_MFMA", "16")[0] != "4" else "k_contract (v_mfma_f64_4x4x4_4b_f64)", "achieved": achieved, "peak": PEAK_FP64_TFLOPS,
+                "bound": "mfma", "kernel": kernel_label, "achieved": achieved, "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_TFLOPS,
                 "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": tim["contract_ms"] / max(1, tim["n_chunks"]), "launches": tim["n_chunks"],
