@@ -241,10 +241,10 @@ __device__ __forceinline__ void diag_store(double* __restrict__ Ad /* &A[i0 + i0
 // ---------------------------------------------------------------------------------------------------------------
 // (base, reset): the two-level variant factors later diagonal blocks with this kernel too -- `base` = first row of the
 // block (LAPACK's info counts from the matrix origin), reset = 0 keeps an earlier failure.
-__global__ __launch_bounds__(256) void k_chol_first(double* __restrict__ A, int ld, double* __restrict__ W0, int* __restrict__ info,
-                                                    int base = 0, int reset = 1) {
-  __shared__ __attribute__((aligned(16))) double cs[CB * (CB + 1)];
-  __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
+// Factor + invert the 64 x 64 block at A (global, column-major) with the calling 256-thread workgroup; cs / sb: LDS scratch of
+// CB * (CB + 1) and DIAG_SB doubles.
+__device__ __forceinline__ void diag_from_global(double* __restrict__ A, int ld, double* __restrict__ W0, int* __restrict__ info, int base,
+                                                 int reset, double* cs, double* sb) {
   const int tid = threadIdx.x;
   for (int e = tid; e < CB * CB; e += 256) {
     const int r = e & 63, c = e >> 6;
@@ -260,6 +260,13 @@ __global__ __launch_bounds__(256) void k_chol_first(double* __restrict__ A, int 
     else if (bad != 0 && *info == 0)
       *info = base + bad;
   }
+}
+
+__global__ __launch_bounds__(256) void k_chol_first(double* __restrict__ A, int ld, double* __restrict__ W0, int* __restrict__ info,
+                                                    int base = 0, int reset = 1) {
+  __shared__ __attribute__((aligned(16))) double cs[CB * (CB + 1)];
+  __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
+  diag_from_global(A, ld, W0, info, base, reset, cs, sb);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -288,21 +295,25 @@ __global__ __launch_bounds__(256) void k_chol_panel(const double* __restrict__ W
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Trailing update with block column k (X = A[k0+64:, k0:k0+64], already solved) + factorisation / inversion of the
-// next diagonal block.  Grid: m*m workgroups, m = nb - k - 1; workgroup (bi, bj) with bj > bi leaves at once.
-// Xc -> A[k0*ld] is its own read-only argument: that block column is disjoint from everything this kernel writes.
+// Update with `np` consecutive, already solved block columns (panels) starting at column kp0: for every 64 x 64 output
+// block (bi, bj), bj <= bi, of the region whose first row / column is o0:  A_ij -= sum_p X_p(i) X_p(j)^T, X_p = A[:, kp0 +
+// 64 p ..].  The output block is read and written ONCE for the np rank-64 terms: at N = 8192 the plain right-looking sweep
+// (np = 1) is bound by exactly that read-modify-write of a 512 MB trailing matrix.  Workgroup 0 also FACTORS and INVERTS
+// the region's first diagonal block, so the serial chain of the factorisation runs beside the update.
+// Grid: m * nc workgroups (m block rows, nc block columns; nc = m: the whole trailing triangle, nc = 1: only the next
+// block column -- what a pair step applies first).  The panels are read-only here: disjoint from everything written.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, const double* __restrict__ Xc, int ld, int k0, int m, int nc,
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int ld, int kp0, int np, int o0, int m, int nc,
                                                      double* __restrict__ Wn, int* __restrict__ info) {
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];  // 40 KB: A-side tile, then the 64 x 65 block staging
   __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
-  // nc = block columns updated (m for the plain right-looking sweep; fewer inside a panel of the two-level variant)
   const int bi = blockIdx.x / nc, bj = blockIdx.x % nc;
   if (bj > bi) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i0 = k0 + CB * (1 + bi), j0 = k0 + CB * (1 + bj);  // first row / column of the output block
+  const int i0 = o0 + CB * bi, j0 = o0 + CB * bj;  // first row / column of the output block
   const int lk = lane >> 4;
+  const double* __restrict__ Xc = A + (size_t)kp0 * ld;
 
   stage_aside(lds, Xc + j0, ld, tid);  // tile[kk][c] = X(j0 + c, kk)
   double bv[16];
@@ -314,6 +325,18 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, con
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[mi][t] = -Ab[(size_t)(16 * mi + 4 * t + lk) * ld + 16 * w + (lane & 15)];
   __syncthreads();
+  for (int p = 1; p < np; ++p) {
+    // the next panel's B side is requested before this panel's MFMAs, its A side restaged after them
+    double bn[16];
+    const double* __restrict__ Xn = Xc + (size_t)p * CB * ld;
+    load_bside(bn, Xn + i0, ld, w, lane);
+    mma_64(lds, bv, acc, lane);
+    __syncthreads();  // every wave is done reading the A-side tile
+    stage_aside(lds, Xn + j0, ld, tid);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) bv[ks] = bn[ks];
+    __syncthreads();
+  }
   mma_64(lds, bv, acc, lane);
 
   if (bi != 0) {
@@ -598,6 +621,8 @@ struct MmArgs {
   int kp0, kp1;
   int cj0, cj1;
   int TI, TJ;  // logical tile grid of one z / y slice
+  double* Wn;  // MM_SYRK: if set, the workgroup of tile (0, 0) goes on to factor + invert the region's first 64 x 64 block
+  int* info;
 };
 
 // workgroup -> tile.  Hardware deals consecutive workgroups round-robin to the 8 XCDs, each with its own L2.  The grid is
@@ -680,6 +705,12 @@ __global__ __launch_bounds__(256, 2) void k_mm128(MmArgs a, int mode0) {
     }
   }
   mm128_tile(t, mm_lds);
+  if (mode == MM_SYRK && a.Wn != nullptr && ti == 0 && tj == 0) {
+    // the next diagonal block of the factorisation is the top-left quarter of this tile: factored here, beside the rest of
+    // the update, like workgroup 0 of k_chol_update does
+    __syncthreads();  // the tile's stores (this workgroup's own) are visible; every wave is done with the staging buffers
+    diag_from_global(t.out, ld, a.Wn, a.info, a.t0 * MB, 0, mm_lds, mm_lds + CB * (CB + 1));
+  }
 }
 
 // U12 = V21^T for every pair of a level (the third product of the recursive doubling is a transposition of the second):
@@ -749,7 +780,7 @@ static hipError_t launch_chol_lower_big(double* A, int ld, double* Winv, int* in
       hipLaunchKernelGGL(k_chol_panel, dim3(m), 256, 0, st, Winv + (size_t)k * CB * CB, A + (size_t)k0 * ld + k0 + CB, ld);
       const int nc = kend - 1 - k;  // block columns of this panel still to the right of k
       if (nc > 0)
-        hipLaunchKernelGGL(k_chol_update, dim3(m * nc), 256, 0, st, A, A + (size_t)k0 * ld, ld, k0, m, nc,
+        hipLaunchKernelGGL(k_chol_update, dim3(m * nc), 256, 0, st, A, ld, k0, 1, k0 + CB, m, nc,
                            Winv + (size_t)(k + 1) * CB * CB, info);
     }
     if (kend < nb) {
@@ -849,12 +880,55 @@ hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStre
   const int nb = ld / CB;
   if (big_chol(ld)) return launch_chol_lower_big(A, ld, Winv, info, st, st2, ev);
   hipLaunchKernelGGL(k_chol_first, dim3(1), 256, 0, st, A, ld, Winv, info, 0, 1);
-  for (int k = 0; k + 1 < nb; ++k) {
-    const int k0 = k * CB;
-    const int m = nb - k - 1;
-    hipLaunchKernelGGL(k_chol_panel, dim3(m), 256, 0, st, Winv + (size_t)k * CB * CB, A + (size_t)k0 * ld + k0 + CB, ld);
-    hipLaunchKernelGGL(k_chol_update, dim3(m * m), 256, 0, st, A, A + (size_t)k0 * ld, ld, k0, m, m,
-                       Winv + (size_t)(k + 1) * CB * CB, info);
+  // Block columns are taken in GROUPS of G: inside a group the update after panel k touches only block column k + 1 (with
+  // all the group's panels so far), and the group's LAST panel triggers ONE rank-64 G update of everything to the right.
+  // The chain (panel -> diagonal block, ~38 us per block column) is the same as in the plain sweep (G = 1), the trailing
+  // matrix is read and written nb / G times instead of nb times.  (With the 64 x 64 tile kernel alone G > 1 does not pay --
+  // measured 13.0 -> 13.0 / 13.2 / 13.4 ms per likelihood at N = 8192 for G = 2 / 3 / 4: that kernel is bound by its
+  // un-pipelined operand loads, not by the read-modify-write of the trailing matrix.)
+  static const int Gset = [] {
+    const char* e = getenv("BOGP_CHOL_GROUP");
+    const int v = e ? atoi(e) : 0;
+    return (v >= 1 && v <= 8) ? v : 0;
+  }();
+  // Experimental (BOGP_CHOL_SYRK_MIN=m > 0, big_path only; OFF by default): while the trailing matrix has at least m block
+  // rows the group's trailing update is ONE k_mm128 SYRK over K = 64 G (G = 2 or 4) whose tile (0, 0) workgroup factors the
+  // next diagonal block.  Measured at N = 8192 (tools/ab_chol_group.sh, timelines by tools/trace_big_chol.sh): the SYRK runs
+  // at 38-43 TF/s at K = 128 (the C tile's read-modify-write and the pipeline prologue weigh on 8 k-blocks) against 28-33 for
+  // two passes of the 64 x 64 kernel, but the pair step pays an extra block-column update (27 us) and tile (0, 0)'s
+  // workgroup now carries a 128 x 128 x K product before the 64-pivot chain: per block column 127 vs 156 us at m = 127, 96
+  // vs 87 at m = 104, 80 vs 66 at m = 88 -- a win only for the first ~20 of 128 block columns; 13.5-13.8 ms per likelihood
+  // against 13.0 for every threshold tried (24 / 40 / 56, G = 2 / 4).
+  static const int syrk_min = [] {
+    const char* e = getenv("BOGP_CHOL_SYRK_MIN");
+    return e ? atoi(e) : 0;
+  }();
+  const bool syrk = big_path(ld) && syrk_min > 0;
+  int kbeg = 0;
+  while (kbeg + 1 < nb) {
+    const int Gs = Gset ? Gset : 2;
+    const bool grouped = syrk && (Gs == 2 || Gs == 4) && kbeg % 2 == 0 && nb - kbeg - Gs >= syrk_min;
+    const int G = grouped ? Gs : (syrk ? 1 : (Gset ? Gset : 1));
+    for (int k = kbeg; k < kbeg + G && k + 1 < nb; ++k) {
+      const int k0 = k * CB;
+      const int m = nb - k - 1;
+      hipLaunchKernelGGL(k_chol_panel, dim3(m), 256, 0, st, Winv + (size_t)k * CB * CB, A + (size_t)k0 * ld + k0 + CB, ld);
+      const bool last = k == kbeg + G - 1;
+      if (last && grouped) {
+        MmArgs a{};
+        a.A = A; a.ld = ld; a.nt = ld / MB;
+        a.t0 = (kbeg + G) / 2; a.kp0 = kbeg * CB; a.kp1 = (kbeg + G) * CB;
+        const int TT = a.nt - a.t0;
+        a.cj0 = 0; a.cj1 = TT;
+        a.Wn = Winv + (size_t)(k + 1) * CB * CB; a.info = info;
+        hipError_t e = launch_mm128(a, MM_SYRK, TT, TT, 1, 1, st);
+        if (e != hipSuccess) return e;
+      } else {
+        hipLaunchKernelGGL(k_chol_update, dim3(last ? m * m : m), 256, 0, st, A, ld, kbeg * CB, k - kbeg + 1, k0 + CB, m, last ? m : 1,
+                           Winv + (size_t)(k + 1) * CB * CB, info);
+      }
+    }
+    kbeg += G;
   }
   return hipGetLastError();
 }
