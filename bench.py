@@ -147,17 +147,32 @@ def main():
     sys.stdout.flush()
     saved = os.dup(1)
     os.dup2(2, 1)
+    comm_error = None
     try:
         distributed.init_engine_comm(eng)
-        ctypes.CDLL(None).fflush(None)
+    except Exception as e:  # noqa: BLE001 -- reported in the JSON line, never silent
+        comm_error = "%s: %s" % (type(e).__name__, e)
     finally:
+        ctypes.CDLL(None).fflush(None)
         os.dup2(saved, 1)
         os.close(saved)
+    if use_dist:  # every rank takes the same path: the library exchange only if EVERY rank has its communicator
+        ok = torch.tensor([0.0 if comm_error else 1.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 0.0 and comm_error is None:
+            comm_error = "another rank could not create the library communicator"
+    if comm_error and eng.comm_world:
+        eng.comm_destroy()
     q = len(w["acq"])
 
     def step():
-        eng.sweep(w["acq"], plugin, True, local_result=False)  # queued; the exchange below is the step's one host wait
-        return eng.exchange_argmax(q, offset, True)  # (values, GLOBAL indices, points), identical on every rank
+        if comm_error is None:
+            eng.sweep(w["acq"], plugin, True, local_result=False)  # queued; the exchange below is the step's one host wait
+            return eng.exchange_argmax(q, offset, True)  # (values, GLOBAL indices, points), identical on every rank
+        # the library communicator could not be built (reported as `exchange` in the JSON line): same sweep, the q winners
+        # exchanged through torch.distributed instead (one all-gather of the same records)
+        bv, bi = eng.sweep(w["acq"], plugin, True)
+        return distributed.exchange_argmax(bv, bi + offset, eng.read_candidates(bi))
 
     def fence():
         if use_dist:
@@ -259,7 +274,8 @@ def main():
             "fit": fit_ms,
             "llf": llf,
             "argmax": [int(i) for i in out[1]],
-            "exchange": "bogp_exchange_argmax over RCCL, world %d (executed inside every timed step)" % eng.comm_world,
+            "exchange": ("bogp_exchange_argmax over RCCL, world %d (executed inside every timed step)" % eng.comm_world) if comm_error is None
+            else "torch.distributed all-gather (library communicator failed: %s)" % comm_error,
         }
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(w, X, y, par, plugin, Xs[: args.cpu_sample].cpu().numpy(), args.cpu_sample, eng)
