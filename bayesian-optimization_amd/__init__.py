@@ -17,6 +17,6 @@ __version__ = "0.1.0"
 from . import _lib, acquisition, distributed, integration, optim  # noqa: E402,F401
 from . import prior_mean as trend  # noqa: E402,F401
 from .acquisition import EI, MGFI, PI, UCB, EpsilonPI  # noqa: E402,F401
-from .optim import argmax_restart, batch_argmax, sweep_argmax, sweep_generated, sweep_topk, sweep_topk_generated  # noqa: E402,F401
+from .optim import argmax_restart, batch_argmax, device_sample, sweep_argmax, sweep_generated, sweep_topk, sweep_topk_generated  # noqa: E402,F401
 from .integration import install, uninstall  # noqa: E402,F401
 from .surrogate import GaussianProcess  # noqa: E402,F401

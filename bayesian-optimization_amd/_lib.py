@@ -45,6 +45,8 @@ SIGNATURES = {
     "bogp_candidates_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "bogp_candidates_generate": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_uint64, C.c_int64]),
     "bogp_candidates_generate_lhs": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_uint64, C.c_int64, C.c_int64]),
+    "bogp_candidates_generate_lhs_maximin": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_uint64, C.c_int, _dp, _ip]),
+    "bogp_candidates_min_pdist2": (C.c_int, [C.c_void_p, _dp]),
     "bogp_candidates_generate_sobol": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int64, C.POINTER(C.c_uint64), C.c_int]),
     "bogp_candidates_read": (C.c_int, [C.c_void_p, _lp, C.c_int, _dp]),
     "bogp_candidates_set_transform": (C.c_int, [C.c_void_p, _ip, _ip, _dp, _dp]),
@@ -332,12 +334,13 @@ class Engine:
         self._keep = owner
 
     def generate_candidates(self, lo, hi, M: int, seed: int = 0, first_row: int = 0, method: str = "uniform",
-                            n_total: Optional[int] = None, sobol_sv: Optional[np.ndarray] = None):
+                            n_total: Optional[int] = None, sobol_sv: Optional[np.ndarray] = None, maximin: int = 5):
         """M points in the box [lo, hi] drawn ON the device -- no host sampling, no H2D copy.  `method` follows
         RealSpace._sample (search_space.py:742-754): "uniform" (Philox4x32-10 stream `seed`, rows [first_row,
         first_row + M)); "LHS" (rows [first_row, first_row + M) of an `n_total`-point Latin hypercube, default M);
         "sobol" (points first_row + 1 ... of the unscrambled sequence -- the reference skips point 0 -- for the
-        direction numbers `sobol_sv` (d x bits), default scipy's)."""
+        direction numbers `sobol_sv` (d x bits), default scipy's); "LHS-maximin" (the best of `maximin` hypercubes by
+        minimum pairwise distance, pyDOE's criterion; (distance, trial) left in `self.last_maximin`)."""
         lo, hi = _f64(lo).ravel(), _f64(hi).ravel()
         if len(lo) != self.d or len(hi) != self.d:
             raise ValueError("bounds must have %d entries" % self.d)
@@ -347,6 +350,13 @@ class Engine:
         elif method == "LHS":
             n_total = int(M) + int(first_row) if n_total is None else int(n_total)
             rc = self._lib.bogp_candidates_generate_lhs(self._h, _ptr(lo), _ptr(hi), int(M), useed, int(first_row), n_total)
+        elif method == "LHS-maximin":  # pyDOE's criterion="maximin": the reference's own "LHS" (search_space.py:751)
+            if int(first_row) != 0 or (n_total is not None and int(n_total) != int(M)):
+                raise NotImplementedError("the maximin criterion needs the whole design on one device (no row shards)")
+            dist, it = C.c_double(), C.c_int()
+            rc = self._lib.bogp_candidates_generate_lhs_maximin(self._h, _ptr(lo), _ptr(hi), int(M), useed, int(maximin),
+                                                                 C.cast(C.byref(dist), _dp), C.cast(C.byref(it), _ip))  # fmt: skip
+            self.last_maximin = (dist.value, it.value)
         elif method == "sobol":
             sv = sobol_direction_numbers(self.d) if sobol_sv is None else sobol_sv
             sv = np.ascontiguousarray(sv, dtype=np.uint64)
@@ -376,6 +386,12 @@ class Engine:
         lo_ = _f64(lo).ravel() if lo is not None else None
         hi_ = _f64(hi).ravel() if hi is not None else None
         self._check(self._lib.bogp_candidates_set_transform(self._h, sc.ctypes.data_as(_ip), pr.ctypes.data_as(_ip), _ptr(lo_), _ptr(hi_)))
+
+    def min_pairwise_distance(self) -> float:
+        """min over pairs of the Euclidean distance between the current candidates (scipy's pdist(...).min())."""
+        out = C.c_double()
+        self._check(self._lib.bogp_candidates_min_pdist2(self._h, C.cast(C.byref(out), _dp)))
+        return float(np.sqrt(out.value))
 
     def read_candidates(self, rows) -> np.ndarray:
         rows = np.ascontiguousarray(rows, dtype=np.int64).ravel()

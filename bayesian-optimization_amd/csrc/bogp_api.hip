@@ -863,6 +863,66 @@ extern "C" int bogp_candidates_generate_lhs(bogp_handle* h, const double* lo, co
   return generate_finish(h, M);
 }
 
+// largest design the maximin criterion accepts: M^2 d / 2 pair terms per trial design (2^18 points, d = 20: ~0.1 s each)
+static constexpr int64_t BOGP_MAXIMIN_MAX_POINTS = (int64_t)1 << 18;
+
+extern "C" int bogp_candidates_min_pdist2(bogp_handle* h, double* min_sq) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!h->dXs || h->M <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_min_pdist2: no candidates");
+  if (!min_sq) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_min_pdist2: null output");
+  if (h->M > BOGP_MAXIMIN_MAX_POINTS) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_candidates_min_pdist2: %lld points exceed the %lld-point limit of the O(M^2 d) pair sweep", (long long)h->M, (long long)BOGP_MAXIMIN_MAX_POINTS);
+  HIPCHK(h, hipSetDevice(h->device));
+  unsigned long long* dout = (unsigned long long*)h->dscal;
+  HIPCHK(h, launch_min_pdist2(h->dXs, (int)h->M, h->d, dout, h->stream));
+  unsigned long long bits = 0;
+  HIPCHK(h, hipMemcpyAsync(&bits, dout, sizeof(bits), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (bits == ~0ull) {
+    *min_sq = INFINITY;  // fewer than two points
+  } else {
+    memcpy(min_sq, &bits, sizeof(double));
+  }
+  return BOGP_OK;
+}
+
+extern "C" int bogp_candidates_generate_lhs_maximin(bogp_handle* h, const double* lo, const double* hi, int64_t M, uint64_t seed,
+                                                    int iterations, double* best_min_dist, int* best_iteration) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (iterations < 1 || iterations > 64) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_generate_lhs_maximin: iterations = %d outside [1, 64]", iterations);
+  if (M > BOGP_MAXIMIN_MAX_POINTS) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_candidates_generate_lhs_maximin: %lld points exceed the %lld-point limit of the O(M^2 d) pair sweep", (long long)M, (long long)BOGP_MAXIMIN_MAX_POINTS);
+  int e = generate_prepare(h, "bogp_candidates_generate_lhs_maximin", lo, hi, M, 0);
+  if (e) return e;
+  const int d = h->d;
+  // trial designs live in the unit cube, un-transformed (pyDOE measures the design before the caller scales it)
+  if ((e = ensure(h, &h->dbatch, &h->batch_cap, (size_t)2 * d))) return e;
+  std::vector<double> unit((size_t)2 * d, 0.0);
+  for (int k = 0; k < d; ++k) unit[d + k] = 1.0;
+  HIPCHK(h, hipMemcpyAsync(h->dbatch, unit.data(), (size_t)2 * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  unsigned long long* dout = (unsigned long long*)h->dscal;
+  double best = -1.0;
+  int best_it = 0;
+  for (int it = 0; it < iterations; ++it) {
+    const uint64_t s_it = seed + 0x9E3779B97F4A7C15ull * (uint64_t)it;
+    HIPCHK(h, launch_generate_lhs(h->dXs_owned, M * d, d, h->dbatch, h->dbatch + d, s_it, 0, (uint64_t)M, h->stream));
+    HIPCHK(h, launch_min_pdist2(h->dXs_owned, (int)M, d, dout, h->stream));
+    unsigned long long bits = 0;
+    HIPCHK(h, hipMemcpyAsync(&bits, dout, sizeof(bits), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double msq = INFINITY;
+    if (bits != ~0ull) memcpy(&msq, &bits, sizeof(double));
+    const double dist = std::sqrt(msq);  // pyDOE compares the distances: `if maxdist < np.min(d)` keeps the EARLIER design on ties
+    if (best < dist) {
+      best = dist;
+      best_it = it;
+    }
+  }
+  const uint64_t s_best = seed + 0x9E3779B97F4A7C15ull * (uint64_t)best_it;
+  HIPCHK(h, launch_generate_lhs(h->dXs_owned, M * d, d, h->dbounds, h->dbounds + d, s_best, 0, (uint64_t)M, h->stream));
+  if (best_min_dist) *best_min_dist = best;
+  if (best_iteration) *best_iteration = best_it;
+  return generate_finish(h, M);
+}
+
 extern "C" int bogp_candidates_generate_sobol(bogp_handle* h, const double* lo, const double* hi, int64_t M,
                                               int64_t first_index, const uint64_t* sv, int bits) {
   if (!h) return BOGP_ERR_INVALID;

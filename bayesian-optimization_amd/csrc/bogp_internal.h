@@ -117,6 +117,7 @@ hipError_t launch_generate_sobol(double* Xs, int64_t n_elem, int d, const double
                                  int bits, uint64_t first_elem, hipStream_t st);
 
 // fit-path kernels (kernels_fit.hip)
+hipError_t launch_min_pdist2(const double* X, int M, int d, unsigned long long* out, hipStream_t st);
 hipError_t launch_build_R(int kernel, const double* X, int N, int d, const double* theta, double off_scale, double diag,
                           double* R, int ld, hipStream_t st);
 hipError_t launch_build_R_div(int kernel, const double* X, int N, int d, const double* theta, double mul, double div,

@@ -95,6 +95,81 @@ __global__ __launch_bounds__(256) void k_build_R(const double* __restrict__ X, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// min over all pairs i < j of |x_i - x_j|^2 for M points (row-major, d columns): what pyDOE's `maximin` criterion computes
+// with scipy's pdist for each of its candidate Latin hypercubes (the reference's DoE call, search_space.py:751:
+// lhs(dim, samples=N, criterion="maximin")).  Same 64 x 64 pair tiles as k_build_R.  The sum over the dimensions is
+// sequential and NOT contracted into FMAs (s = s + diff * diff, the arithmetic of pdist's C loop and of oracle/philox.py),
+// and a minimum does not depend on the order of its operands: the result is bit-reproducible.  out: bit pattern of the
+// minimum as an unsigned integer (non-negative doubles order like their bit patterns), initialised to all ones.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_min_pdist2(const double* __restrict__ X, int M, int d, unsigned long long* __restrict__ out) {
+#pragma clang fp contract(off)
+  __shared__ double xi[KC * PP], xj[KC * PP];
+  __shared__ unsigned long long wmin[4];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int i0 = bi * PT, j0 = bj * PT;
+  double s2[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s2[r][c] = 0.0;
+  for (int kc = 0; kc < d; kc += KC) {
+    __syncthreads();
+    stage_points(xi, X, M, d, i0, kc, tid);
+    stage_points(xj, X, M, d, j0, kc, tid);
+    __syncthreads();
+    const int kn = min(KC, d - kc);
+    for (int kk = 0; kk < kn; ++kk) {
+      double vi[4], vj[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vi[r] = xi[kk * PP + 4 * ty + r];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vj[c] = xj[kk * PP + 4 * tx + c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double diff = vi[r] - vj[c];
+          const double sq = diff * diff;
+          s2[r][c] = s2[r][c] + sq;
+        }
+    }
+  }
+  unsigned long long best = ~0ull;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = i0 + 4 * ty + r, j = j0 + 4 * tx + c;
+      if (i < M && j < i) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(s2[r][c]);
+        best = b < best ? b : best;
+      }
+    }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned long long ob = (unsigned long long)shfl_xor_i64((int64_t)best, o);
+    best = ob < best ? ob : best;
+  }
+  if ((tid & 63) == 0) wmin[tid >> 6] = best;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w) best = wmin[w] < best ? wmin[w] : best;
+    if (best != ~0ull) atomicMin(out, best);
+  }
+}
+
+hipError_t launch_min_pdist2(const double* X, int M, int d, unsigned long long* out, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(out, 0xFF, sizeof(unsigned long long), st);
+  if (e != hipSuccess) return e;
+  const unsigned nt = (unsigned)((M + PT - 1) / PT);
+  hipLaunchKernelGGL(k_min_pdist2, dim3(nt, nt), 256, 0, st, X, M, d, out);
+  return hipGetLastError();
+}
+
 #define BOGP_FOR_KERNEL(kernel, CALL)                      \
   switch (kernel) {                                        \
     case BOGP_KERNEL_SE: { CALL(BOGP_KERNEL_SE); } break;             \

@@ -85,6 +85,18 @@ def _generate(eng, space, count, seed, first_row, method, n_total):
     eng.generate_candidates(lo_t, hi_t, count, seed, first_row=first_row, method=method, n_total=n_total)
 
 
+def device_sample(engine, space, N: int, method: str = "LHS-maximin", seed: int = 0, maximin: int = 5) -> np.ndarray:
+    """`space.sample(N, method)` of the reference (search_space.py:742-754) drawn on the device and read back: (N, d).
+    `method`: "uniform" | "LHS" | "LHS-maximin" | "sobol" -- the reference's own "LHS" is pyDOE's maximin criterion over
+    five hypercubes, i.e. "LHS-maximin" here (the plain "LHS" is one hypercube, the only flavour that can be drawn in
+    row shards).  The engine must know d (a training set has been set); its candidate buffer is overwritten."""
+    lo_t, hi_t, scales, precs, lo, hi = design_of(space)
+    plain = all(s == "linear" for s in scales) and all(p is None for p in precs)
+    engine.set_candidate_transform(None if plain else scales, None if plain else precs, lo, hi)
+    engine.generate_candidates(lo_t, hi_t, int(N), seed, method=method, maximin=maximin)
+    return engine.read_candidates(np.arange(int(N)))
+
+
 def shard_bounds(M: int, rank: int, world: int):
     """Contiguous block of rank r: rows [r M / R, (r+1) M / R)."""
     return (rank * M) // world, ((rank + 1) * M) // world
@@ -127,7 +139,8 @@ def sweep_generated(criteria: Sequence, bounds, M: int, seed: int, rank: int = 0
     and precisions of its variables are honoured on the device) that never touch the host: rank r draws rows
     [r M / R, (r+1) M / R) of the design on its GPU, sweeps them, and the ranks exchange their winners (value, global
     row, point).  `method` names the design like `RealSpace._sample` does (search_space.py:742-754): "uniform" (Philox
-    stream `seed`), "LHS" (an M-point Latin hypercube of stream `seed`), "sobol" (points 1..M of the unscrambled
+    stream `seed`), "LHS" (an M-point Latin hypercube of stream `seed`; "LHS-maximin": pyDOE's criterion, one rank only),
+    "sobol" (points 1..M of the unscrambled
     sequence; `seed` unused).  The union of the shards is the same M-point set for every world size."""
     c0 = criteria[0]
     model = c0.model

@@ -160,8 +160,15 @@ int bogp_candidates_generate(bogp_handle* h, const double* lo, const double* hi,
 /* `generate_lhs`: rows [first_row, first_row + M) of an n_strata-point Latin hypercube (method "LHS",
  * search_space.py:747-751 -> pyDOE.lhs): per dimension one point in each of n_strata equal strata, the strata
  * visited in a keyed pseudo-random permutation (Feistel network + cycle walking, evaluated per element, so no sort
- * and no exchange between ranks), jitter inside the stratum from the uniform stream.  pyDOE's "maximin" selection
- * among 5 such designs costs O(n^2 d) per design and is not reproduced.
+ * and no exchange between ranks), jitter inside the stratum from the uniform stream.
+ * `generate_lhs_maximin`: what the reference's DoE call actually asks pyDOE for (search_space.py:751: lhs(dim, samples=N,
+ * criterion="maximin"), pyDOE's _lhsmaximin): `iterations` (pyDOE: 5) independent M-point hypercubes in the UNIT cube --
+ * trial t is stream seed + 0x9E3779B97F4A7C15 * t -- are measured by the minimum pairwise Euclidean distance (the O(M^2 d)
+ * pair sweep of `min_pdist2`; M <= 2^18) and the FIRST design with the largest minimum (pyDOE's `if maxdist < min(d)`) is
+ * generated into the box [lo, hi] (+ the transform below); its minimum distance and trial number are returned.  Whole
+ * designs only (no row shards: the criterion needs every pair).
+ * `min_pdist2`: min over i < j of |x_i - x_j|^2 of the current candidates (sequential, un-fused sum over the dimensions:
+ * bit-reproducible), +inf for fewer than two points.
  * `generate_sobol`: points [first_index, first_index + M) of the unscrambled Sobol' sequence (method "sobol",
  * search_space.py:752-753 -> sobol_seq.i4_sobol_generate, whose skip = 1 is first_index = 1) for caller-supplied
  * direction numbers sv (d x bits, row-major, sv[k][b] is XORed in when bit b of the Gray code of the index is set --
@@ -170,6 +177,9 @@ int bogp_candidates_generate_lhs(bogp_handle* h, const double* lo, const double*
                                  int64_t first_row, int64_t n_strata);
 int bogp_candidates_generate_sobol(bogp_handle* h, const double* lo, const double* hi, int64_t M, int64_t first_index,
                                    const uint64_t* sv, int bits);
+int bogp_candidates_generate_lhs_maximin(bogp_handle* h, const double* lo, const double* hi, int64_t M, uint64_t seed,
+                                         int iterations, double* best_min_dist, int* best_iteration);
+int bogp_candidates_min_pdist2(bogp_handle* h, double* min_sq);
 int bogp_candidates_read(bogp_handle* h, const int64_t* rows, int n, double* out);
 /* Per-variable post-processing of the three generators above, as RealSpace._sample applies it (search_space.py:754:
  * `self.round(self.to_linear_scale(X))`): draw in the TRANSFORMED box (pass trans(lo), trans(hi) to the generator:

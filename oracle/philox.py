@@ -117,6 +117,36 @@ def lhs_box(lo, hi, M, seed, first_row=0, n_strata=None):
     return (lo[k] + (hi[k] - lo[k]) * t).reshape(M, d)
 
 
+def min_pdist(X):
+    """scipy.spatial.distance.pdist(X).min() with the arithmetic spelled out: per pair the squared differences are added
+    one dimension after the other (no FMA), the minimum taken over the squares and rooted once (sqrt is monotone)."""
+    X = np.asarray(X, dtype=np.float64)
+    n, d = X.shape
+    best = np.inf
+    for i in range(1, n):
+        s = np.zeros(i)
+        for k in range(d):
+            diff = X[i, k] - X[:i, k]
+            s = s + diff * diff
+        best = min(best, float(s.min()))
+    return float(np.sqrt(best))
+
+
+def lhs_maximin_box(lo, hi, M, seed, iterations=5):
+    """pyDOE's _lhsmaximin on libbogp's hypercubes (bogp_candidates_generate_lhs_maximin): trial t = stream seed +
+    0x9E3779B97F4A7C15 t in the unit cube, keep the first trial with the largest minimum pairwise distance, return that
+    design in the box [lo, hi] with (distance, trial)."""
+    d = len(lo)
+    best, best_t = -1.0, 0
+    for t in range(iterations):
+        s_t = (seed + 0x9E3779B97F4A7C15 * t) & 0xFFFFFFFFFFFFFFFF
+        dist = min_pdist(lhs_box(np.zeros(d), np.ones(d), M, s_t))
+        if best < dist:
+            best, best_t = dist, t
+    s_b = (seed + 0x9E3779B97F4A7C15 * best_t) & 0xFFFFFFFFFFFFFFFF
+    return lhs_box(lo, hi, M, s_b), best, best_t
+
+
 def sobol_box(lo, hi, M, sv, first_index=1):
     """Points [first_index, first_index + M) of the unscrambled Sobol' sequence with direction numbers sv (d, bits) in
     the box [lo, hi] (k_generate_sobol): XOR of sv[:, b] over the set bits b of the index's Gray code."""

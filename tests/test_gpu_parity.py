@@ -521,6 +521,44 @@ def test_device_candidate_generation_is_bit_exact_and_shardable(eng):
     np.testing.assert_array_equal(eng.read_candidates(idx), Xs[oidx])
 
 
+def test_device_maximin_latin_hypercube_matches_the_restatement(eng):
+    """f4, the criterion the reference's own "LHS" uses (search_space.py:751 -> pyDOE criterion="maximin"): the pair sweep's
+    minimum distance, the chosen trial and the design itself, bit for bit against oracle/philox.py (which is held to scipy's
+    pdist on the CPU side)."""
+    from oracle import philox as P
+
+    g = load_golden("G1_se_sk_noisy")
+    commit_golden(eng, g)
+    d = g["X"].shape[1]
+    lo, hi = np.full(d, -5.0), np.linspace(1.0, 5.0, d)
+    for M, seed, iters in ((2, 1, 5), (37, 99, 5), (64, 5, 3), (65, 5, 5), (300, 0xABCDEF, 5), (1000, 7, 2)):
+        eng.generate_candidates(lo, hi, M, seed=seed, method="LHS-maximin", maximin=iters)
+        X, dist, t = P.lhs_maximin_box(lo, hi, M, seed, iters)
+        assert eng.last_maximin == (dist, t), (M, seed)
+        np.testing.assert_array_equal(eng.read_candidates(np.arange(M)), X)
+    # the pair sweep on its own, on arbitrary (uploaded) points incl. a duplicate pair and ragged tile edges
+    rng = np.random.default_rng(0)
+    for M in (2, 63, 64, 129, 1500):
+        Xs = rng.uniform(-3, 3, size=(M, d))
+        eng.upload_candidates(Xs)
+        assert eng.min_pairwise_distance() == P.min_pdist(Xs), M
+    Xs[700] = Xs[3]
+    eng.upload_candidates(Xs)
+    assert eng.min_pairwise_distance() == 0.0
+    eng.upload_candidates(Xs[:1])
+    assert eng.min_pairwise_distance() == np.inf
+    # at a design size the CPU could not sweep (2e5 points = 2e10 pairs): never below the plain design of the same stream
+    M = 200_000
+    eng.generate_candidates(lo, hi, M, seed=5, method="LHS")
+    plain = eng.min_pairwise_distance()
+    eng.generate_candidates(np.zeros(d), np.ones(d), M, seed=5, method="LHS")
+    plain_unit = eng.min_pairwise_distance()
+    eng.generate_candidates(lo, hi, M, seed=5, method="LHS-maximin", maximin=3)
+    assert eng.last_maximin[0] >= plain_unit and plain > 0
+    with pytest.raises(NotImplementedError):
+        eng.generate_candidates(lo, hi, 100, seed=5, first_row=10, method="LHS-maximin")
+
+
 def test_device_latin_hypercube_and_sobol_are_bit_exact_and_shardable(eng):
     """f4: the two other designs of RealSpace._sample (search_space.py:742-754) drawn on the device."""
     from oracle import philox as P

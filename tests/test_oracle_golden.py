@@ -232,6 +232,26 @@ def test_latin_hypercube_restatement_properties():
         assert sorted(pi.tolist()) == list(range(n))
 
 
+def test_maximin_restatement_follows_pydoe():
+    """pyDOE's _lhsmaximin (what the reference's "LHS" asks for, search_space.py:751): of `iterations` hypercubes keep the
+    FIRST with the largest scipy pdist minimum.  The restatement's distance equals scipy's pdist bit for bit."""
+    from scipy.spatial.distance import pdist
+
+    from oracle import philox as P
+
+    rng = np.random.default_rng(3)
+    for n, d in ((2, 1), (5, 3), (64, 7), (257, 20)):
+        X = rng.random((n, d))
+        assert P.min_pdist(X) == float(pdist(X).min()), (n, d)
+    lo, hi = np.array([-5.0, 0.0, 2.0]), np.array([5.0, 1.0, 2.5])
+    X, dist, t = P.lhs_maximin_box(lo, hi, 40, seed=11, iterations=5)
+    trials = [P.lhs_box(np.zeros(3), np.ones(3), 40, (11 + 0x9E3779B97F4A7C15 * i) & (2**64 - 1)) for i in range(5)]
+    dists = [float(pdist(T).min()) for T in trials]
+    assert t == int(np.argmax(dists)) and dist == max(dists)  # np.argmax: first maximum, like `if maxdist < min(d)`
+    np.testing.assert_array_equal(X, lo + (hi - lo) * trials[t])
+    assert dist >= dists[0]  # never worse than the plain design of the same stream
+
+
 def test_sobol_restatement_equals_the_reference_generator():
     """RealSpace._sample(method="sobol") (search_space.py:752-753) = (ub - lb) * i4_sobol_generate(dim, N) + lb; in
     this image `sobol_seq` resolves to scipy's unscrambled generator minus its first point."""
