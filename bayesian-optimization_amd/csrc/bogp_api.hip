@@ -366,7 +366,7 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   //   Yt = V y (:799), Ft = V 1 (:803)              one pass over V
   //   rho (:806 / :808), |Ft|, Ft.Yt, rho.rho       k_fit_rho
   //   gamma = U rho (:788 / :996)
-  HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st, h->stream2, h->ev_chol));
+  HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st, h->stream2, h->ev_chol, h->dT));  // dT: free until the inverse
   HIPCHK(h, launch_logdet(h->dR, N, ldr, h->dscal, st));
   HIPCHK(h, launch_tri_inverse(h->dR, h->ddinv, h->dV, h->dU, h->dT, ldr, st));
   const int n_t = h->n_t;

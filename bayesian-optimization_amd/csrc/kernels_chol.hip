@@ -37,14 +37,17 @@ __device__ __forceinline__ void mfma16(double a, double b, d4& c) {
 // 16 passes: nothing may read the last results before they have left the pipe
 #define BOGP_CHOL_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
 
-// 1/sqrt(x): hardware estimate + two Newton-Raphson steps (FMA form), ~1 ulp
+// 1/sqrt(x): hardware estimate + ONE third-order (Halley) step, e = 1 - x y^2, y' = y (1 + e/2 + 3 e^2/8): five dependent
+// operations after v_rsq_f64 instead of the eight of two Newton steps.  A dependent FP64 operation costs ~26 cycles on
+// the 64-pivot chain of the diagonal block (tools/ubench_diag.hip: 21.7 -> 19.5 us per 64 x 64 block together with the
+// merged phases below); relative error ~ e0^3 (e0 ~ 2^-26) + one rounding, the same 2.2e-16 against LAPACK's factor.
 __device__ __forceinline__ double rsqrt_nr(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  double e = __builtin_fma(-x * y, y, 1.0);
-  y = __builtin_fma(y * 0.5, e, y);
-  e = __builtin_fma(-x * y, y, 1.0);
-  y = __builtin_fma(y * 0.5, e, y);
-  return y;
+  const double y = __builtin_amdgcn_rsq(x);
+  const double t = x * y;
+  const double e = __builtin_fma(-t, y, 1.0);
+  double p = __builtin_fma(0.375, e, 0.5);
+  p = p * e;
+  return __builtin_fma(y, p, y);
 }
 
 // ---- 64x64x64 product on the matrix cores ---------------------------------------------------------------------
@@ -97,13 +100,13 @@ __device__ __forceinline__ void mma_64(const double* lds, const double (&bv)[16]
 // diagonal, the final block row of W = L^-1 -- so every thread below applies the SAME update z -= lr yc with
 // lr[i][k] = Y[k][4 tr + i], yc[k][c] = Y[k][4 tc + c], whether its tile still belongs to the trailing block (tc > jb) or
 // already accumulates W (tc <= jb; the tile switches role at jb == tc, where lr is its final piece of L).
-// Two barriers per 4 columns; the serial part is the diagonal thread's 4x4 potf2 + inverse.
+// Two barriers per 4 columns; the serial part is the 4x4 potf2 + inverse (done redundantly by the 16 threads of the block row).
 // cs: 64 x 65 staging of the input block; sb: DIAG_SB doubles.  On return `lo` holds the L tile (tc <= tr) and z the
 // W tile (tc <= tr).  Returns 0 or 1 + the first column with a non-positive pivot (LAPACK's info), workgroup-uniform.
 constexpr int DIAG_SB = 16 + 4 * CB + 2;
 __device__ __forceinline__ int diag_factor_invert(const double* cs, double* sb, double (&lo)[4][4], double (&z)[4][4], int tid) {
   const int tr = tid >> 4, tc = tid & 15;
-  double* mini = sb;            // [4][4] row-major, lower
+  double* dtile = sb;           // [4][4] the diagonal tile of the current step (lower part used)
   double* Y = sb + 16;          // [4][64]
   double* flag = sb + 16 + 256; // 1 + first bad column (as a double), 0 if none
 #pragma unroll
@@ -113,30 +116,42 @@ __device__ __forceinline__ int diag_factor_invert(const double* cs, double* sb, 
       z[i][c] = cs[(4 * tr + i) * (CB + 1) + 4 * tc + c];
       lo[i][c] = 0.0;
     }
-  if (tid == 0) flag[0] = 0.0;
+  if (tid == 0) {
+    flag[0] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dtile[4 * i + c] = z[i][c];
+  }
+  __syncthreads();
   for (int jb = 0; jb < 16; ++jb) {
-    // ---- A: 4x4 potf2 + inverse by the diagonal thread ---------------------------------------------------
-    if (tr == jb && tc == jb) {
-      double l[4][4], iv[4];
+    // ---- A + B: the 16 threads of block row jb ALL factor and invert the 4x4 diagonal tile (published by its owner at the
+    // end of the previous step) and go straight on to their own piece of the block row Y = M z(jb, :): one barrier and
+    // one LDS round trip less per step than handing M from the diagonal thread to the others
+    if (tr == jb) {
+      double a[4][4], l[4][4], iv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c <= i; ++c) a[i][c] = dtile[4 * i + c];
       int bad = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        double piv = z[j][j];
-        if (!(piv > 0.0)) {
-          if (bad == 0) bad = 4 * jb + j + 1;
-          piv = 1.0;
-        }
+        double piv = a[j][j];
+        const bool okp = piv > 0.0;
+        bad = (!okp && bad == 0) ? 4 * jb + j + 1 : bad;
+        piv = okp ? piv : 1.0;
         const double inv = rsqrt_nr(piv);
-        double sq = piv * inv;
-        sq = __builtin_fma(__builtin_fma(-sq, sq, piv), 0.5 * inv, sq);  // sqrt(piv) to ~1 ulp
-        l[j][j] = sq;
         iv[j] = inv;
 #pragma unroll
-        for (int i = j + 1; i < 4; ++i) l[i][j] = z[i][j] * inv;
+        for (int i = j + 1; i < 4; ++i) l[i][j] = a[i][j] * inv;
 #pragma unroll
         for (int i = j + 1; i < 4; ++i)
 #pragma unroll
-          for (int c = j + 1; c <= i; ++c) z[i][c] = __builtin_fma(-l[i][j], l[c][j], z[i][c]);
+          for (int c = j + 1; c <= i; ++c) a[i][c] = __builtin_fma(-l[i][j], l[c][j], a[i][c]);
+        double sq = piv * inv;  // sqrt(piv) to ~1 ulp, off the pivot chain
+        sq = __builtin_fma(__builtin_fma(-sq, sq, piv), 0.5 * inv, sq);
+        l[j][j] = sq;
       }
       // M = l^-1 (lower), by forward substitution on the identity
       double mm[4][4];
@@ -156,37 +171,35 @@ __device__ __forceinline__ int diag_factor_invert(const double* cs, double* sb, 
           }
         }
       }
+      if (tc == jb) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          lo[i][c] = c <= i ? l[i][c] : 0.0;
-          z[i][c] = mm[i][c];
-          mini[4 * i + c] = mm[i][c];
-          Y[i * CB + 4 * tc + c] = mm[i][c];
-        }
-      if (bad != 0 && flag[0] == 0.0) flag[0] = (double)bad;
-    }
-    __syncthreads();
-    // ---- B: block row Y = M z(jb, :) ---------------------------------------------------------------------
-    if (tr == jb && tc != jb) {
-      double y[4][4];
+          for (int c = 0; c < 4; ++c) {
+            lo[i][c] = c <= i ? l[i][c] : 0.0;
+            z[i][c] = mm[i][c];
+            Y[i * CB + 4 * tc + c] = mm[i][c];
+          }
+        if (bad != 0 && flag[0] == 0.0) flag[0] = (double)bad;
+      } else {
+        double y[4][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          double sacc = 0.0;
+          for (int c = 0; c < 4; ++c) {
+            double sacc = 0.0;
 #pragma unroll
-          for (int k = 0; k <= i; ++k) sacc = __builtin_fma(mini[4 * i + k], z[k][c], sacc);
-          y[i][c] = sacc;
-        }
+            for (int k = 0; k <= i; ++k) sacc = __builtin_fma(mm[i][k], z[k][c], sacc);
+            y[i][c] = sacc;
+          }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          z[i][c] = y[i][c];
-          Y[i * CB + 4 * tc + c] = y[i][c];
-        }
+          for (int c = 0; c < 4; ++c) {
+            z[i][c] = y[i][c];
+            Y[i * CB + 4 * tc + c] = y[i][c];
+          }
+      }
     }
     __syncthreads();
     // ---- C: rank-4 update of every tile below the block row ----------------------------------------------
@@ -214,9 +227,15 @@ __device__ __forceinline__ int diag_factor_invert(const double* cs, double* sb, 
         for (int c = 0; c < 4; ++c)
 #pragma unroll
           for (int k = 0; k < 4; ++k) z[i][c] = __builtin_fma(-lr[i][k], yc[k][c], z[i][c]);
+      if (tr == jb + 1 && tc == jb + 1) {  // the next diagonal tile is final: publish it for its block row
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) dtile[4 * i + c] = z[i][c];
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
   return (int)flag[0];
 }
 
@@ -304,7 +323,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(const double* __restrict__ W
 // block column -- what a pair step applies first).  The panels are read-only here: disjoint from everything written.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int ld, int kp0, int np, int o0, int m, int nc,
-                                                     double* __restrict__ Wn, int* __restrict__ info) {
+                                                     double* __restrict__ Wn, int* __restrict__ info, double* __restrict__ Pnext) {
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];  // 40 KB: A-side tile, then the 64 x 65 block staging
   __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
   const int bi = blockIdx.x / nc, bj = blockIdx.x % nc;
@@ -344,10 +363,112 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int t = 0; t < 4; ++t) Ab[(size_t)(16 * mi + 4 * t + lk) * ld + 16 * w + (lane & 15)] = -acc[mi][t];
+    if (Pnext != nullptr && bj == 0) {  // a copy of the next (still unsolved) panel for k_chol_step
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Pnext[(size_t)(16 * mi + 4 * t + lk) * ld + i0 + 16 * w + (lane & 15)] = -acc[mi][t];
+    }
     return;
   }
   // ---- next diagonal block: stage the updated block in LDS (row-major, pitch 65), factor, invert -------------
   __syncthreads();  // every wave is done reading the A-side tile
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) lds[(16 * w + (lane & 15)) * (CB + 1) + 16 * mi + 4 * t + lk] = -acc[mi][t];
+  __syncthreads();
+  double a[4][4], ww[4][4];
+  const int bad = diag_factor_invert(lds, sb, a, ww, tid);
+  diag_store(Ab, ld, Wn, a, ww, tid);
+  if (tid == 0 && bad != 0 && *info == 0) *info = i0 + bad;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One block column in ONE launch (small trailing matrices): panel solve + trailing update + next diagonal block.
+// Every workgroup (bi, bj) recomputes the two panel tiles it needs, X_i = A[i, k] W_k^T and X_j, from the UNSOLVED panel
+// (three 64^3 products per workgroup instead of one -- free while the trailing matrix has fewer tiles than the GPU has
+// workgroup slots) and k_chol_panel with its launch boundary disappears from the serial chain (~6 of ~33 us per block column).
+// The unsolved panel is read from a scratch copy Pcur (element (row, kk) at Pcur[row + kk * ld]): the workgroups of block
+// column bj = 0 store the solved X_i into A (the final L) while others still read the unsolved tile, and they write the
+// NEXT unsolved panel twice, into A and into Pnext (two scratch panels alternate between steps).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int ld, int k0, int m, const double* __restrict__ Wk,
+                                                   const double* __restrict__ Pcur, double* __restrict__ Pnext,
+                                                   double* __restrict__ Wn, int* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
+  __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
+  const int bi = blockIdx.x / m, bj = blockIdx.x % m;
+  if (bj > bi) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i0 = k0 + CB * (1 + bi), j0 = k0 + CB * (1 + bj);
+  const int lk = lane >> 4;
+
+  stage_aside(lds, Wk, CB, tid);  // tile[kk][c] = W(c, kk)
+  double bv[16], bvi[16];
+  load_bside(bv, Pcur + j0, ld, w, lane);
+  if (bi != bj) load_bside(bvi, Pcur + i0, ld, w, lane);
+  double xj[4][4], xi[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xj[mi][t] = xi[mi][t] = 0.0;
+  double acc[4][4];  // negated output tile, requested early
+  double* __restrict__ Ab = A + (size_t)j0 * ld + i0;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[mi][t] = -Ab[(size_t)(16 * mi + 4 * t + lk) * ld + 16 * w + (lane & 15)];
+  __syncthreads();
+  mma_64(lds, bv, xj, lane);  // X_j: rows 16 w .. of block j, element (row, col 16 mi + 4 t + lk)
+  if (bi != bj) {
+    mma_64(lds, bvi, xi, lane);
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xi[mi][t] = xj[mi][t];
+  }
+  __syncthreads();  // every wave is done with the W tile
+  // A side of the update: tile[kk][c] = X_j(c, kk)
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) lds[(16 * mi + 4 * t + lk) * CPITCH + 16 * w + (lane & 15)] = xj[mi][t];
+  if (bj == 0) {  // the solved panel tile of block row i is final: store L
+    double* __restrict__ Lb = A + (size_t)k0 * ld + i0;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Lb[(size_t)(16 * mi + 4 * t + lk) * ld + 16 * w + (lane & 15)] = xi[mi][t];
+  }
+  // B side: X_i(row 16 w + (lane & 15), kk = 4 ks + lk) is exactly xi[ks / 4][ks % 4] of this lane
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bv[4 * mi + t] = xi[mi][t];
+  // (register moves feeding inline-asm MFMAs: the hazard recogniser does not see the consumer)
+  asm volatile("s_nop 7\n\ts_nop 7"
+               : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7]), "+v"(bv[8]),
+                 "+v"(bv[9]), "+v"(bv[10]), "+v"(bv[11]), "+v"(bv[12]), "+v"(bv[13]), "+v"(bv[14]), "+v"(bv[15]));
+  __syncthreads();
+  mma_64(lds, bv, acc, lane);
+
+  if (bi != 0) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Ab[(size_t)(16 * mi + 4 * t + lk) * ld + 16 * w + (lane & 15)] = -acc[mi][t];
+    if (bj == 0) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Pnext[(size_t)(16 * mi + 4 * t + lk) * ld + i0 + 16 * w + (lane & 15)] = -acc[mi][t];
+    }
+    return;
+  }
+  __syncthreads();
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -621,8 +742,6 @@ struct MmArgs {
   int kp0, kp1;
   int cj0, cj1;
   int TI, TJ;  // logical tile grid of one z / y slice
-  double* Wn;  // MM_SYRK: if set, the workgroup of tile (0, 0) goes on to factor + invert the region's first 64 x 64 block
-  int* info;
 };
 
 // workgroup -> tile.  Hardware deals consecutive workgroups round-robin to the 8 XCDs, each with its own L2.  The grid is
@@ -705,12 +824,6 @@ __global__ __launch_bounds__(256, 2) void k_mm128(MmArgs a, int mode0) {
     }
   }
   mm128_tile(t, mm_lds);
-  if (mode == MM_SYRK && a.Wn != nullptr && ti == 0 && tj == 0) {
-    // the next diagonal block of the factorisation is the top-left quarter of this tile: factored here, beside the rest of
-    // the update, like workgroup 0 of k_chol_update does
-    __syncthreads();  // the tile's stores (this workgroup's own) are visible; every wave is done with the staging buffers
-    diag_from_global(t.out, ld, a.Wn, a.info, a.t0 * MB, 0, mm_lds, mm_lds + CB * (CB + 1));
-  }
 }
 
 // U12 = V21^T for every pair of a level (the third product of the recursive doubling is a transposition of the second):
@@ -781,7 +894,7 @@ static hipError_t launch_chol_lower_big(double* A, int ld, double* Winv, int* in
       const int nc = kend - 1 - k;  // block columns of this panel still to the right of k
       if (nc > 0)
         hipLaunchKernelGGL(k_chol_update, dim3(m * nc), 256, 0, st, A, ld, k0, 1, k0 + CB, m, nc,
-                           Winv + (size_t)(k + 1) * CB * CB, info);
+                           Winv + (size_t)(k + 1) * CB * CB, info, (double*)nullptr);
     }
     if (kend < nb) {
       MmArgs a{};
@@ -876,59 +989,51 @@ hipError_t launch_pad_identity(double* A, int N, int ld, hipStream_t st) {
 // L = chol(A) in place (lower, column-major, ld a multiple of 64 with identity padding).  Winv: ld x 64 doubles; block
 // k holds L_kk^-1 (64 x 64 column-major) afterwards.  *info (device) = 0 or 1 + the first column with a non-positive
 // pivot, as LAPACK reports it.
-hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStream_t st, hipStream_t st2, hipEvent_t* ev) {
+hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStream_t st, hipStream_t st2, hipEvent_t* ev,
+                             double* scratch) {
   const int nb = ld / CB;
   if (big_chol(ld)) return launch_chol_lower_big(A, ld, Winv, info, st, st2, ev);
   hipLaunchKernelGGL(k_chol_first, dim3(1), 256, 0, st, A, ld, Winv, info, 0, 1);
-  // Block columns are taken in GROUPS of G: inside a group the update after panel k touches only block column k + 1 (with
-  // all the group's panels so far), and the group's LAST panel triggers ONE rank-64 G update of everything to the right.
-  // The chain (panel -> diagonal block, ~38 us per block column) is the same as in the plain sweep (G = 1), the trailing
-  // matrix is read and written nb / G times instead of nb times.  (With the 64 x 64 tile kernel alone G > 1 does not pay --
-  // measured 13.0 -> 13.0 / 13.2 / 13.4 ms per likelihood at N = 8192 for G = 2 / 3 / 4: that kernel is bound by its
-  // un-pipelined operand loads, not by the read-modify-write of the trailing matrix.)
-  static const int Gset = [] {
+  // BOGP_CHOL_GROUP=G > 1 (experiment, default 1): block columns in groups of G -- inside a group the update after panel k
+  // touches only block column k + 1 (with all the group's panels so far), the group's LAST panel triggers ONE rank-64 G
+  // update of everything to the right, so the trailing matrix is read and written nb / G times instead of nb times.
+  // Measured 13.0 -> 13.0 / 13.2 / 13.4 ms per likelihood at N = 8192 for G = 2 / 3 / 4: the 64 x 64 tile kernel is bound
+  // by its un-pipelined operand loads, not by that read-modify-write.  (Also measured, and removed again: the group's
+  // trailing update as ONE k_mm128 SYRK with the diagonal duty in its tile (0, 0): 38-43 TF/s at K = 128 against 28-33,
+  // but a longer chain per block column -- 13.5-13.8 ms for every threshold tried; tools/ab_chol_group.sh.)
+  static const int G = [] {
     const char* e = getenv("BOGP_CHOL_GROUP");
-    const int v = e ? atoi(e) : 0;
-    return (v >= 1 && v <= 8) ? v : 0;
+    const int v = e ? atoi(e) : 1;
+    return (v >= 1 && v <= 8) ? v : 1;
   }();
-  // Experimental (BOGP_CHOL_SYRK_MIN=m > 0, big_path only; OFF by default): while the trailing matrix has at least m block
-  // rows the group's trailing update is ONE k_mm128 SYRK over K = 64 G (G = 2 or 4) whose tile (0, 0) workgroup factors the
-  // next diagonal block.  Measured at N = 8192 (tools/ab_chol_group.sh, timelines by tools/trace_big_chol.sh): the SYRK runs
-  // at 38-43 TF/s at K = 128 (the C tile's read-modify-write and the pipeline prologue weigh on 8 k-blocks) against 28-33 for
-  // two passes of the 64 x 64 kernel, but the pair step pays an extra block-column update (27 us) and tile (0, 0)'s
-  // workgroup now carries a 128 x 128 x K product before the 64-pivot chain: per block column 127 vs 156 us at m = 127, 96
-  // vs 87 at m = 104, 80 vs 66 at m = 88 -- a win only for the first ~20 of 128 block columns; 13.5-13.8 ms per likelihood
-  // against 13.0 for every threshold tried (24 / 40 / 56, G = 2 / 4).
-  static const int syrk_min = [] {
-    const char* e = getenv("BOGP_CHOL_SYRK_MIN");
-    return e ? atoi(e) : 0;
+  // Block columns whose trailing matrix has at most `fuse_max` block rows run as ONE launch (k_chol_step: panel solve
+  // recomputed per workgroup); needs `scratch` (2 * ld * 64 doubles) for the copies of the unsolved panels.
+  static const int fuse_max = [] {
+    const char* e = getenv("BOGP_CHOL_FUSE_MAX");
+    return e ? atoi(e) : 32;
   }();
-  const bool syrk = big_path(ld) && syrk_min > 0;
-  int kbeg = 0;
-  while (kbeg + 1 < nb) {
-    const int Gs = Gset ? Gset : 2;
-    const bool grouped = syrk && (Gs == 2 || Gs == 4) && kbeg % 2 == 0 && nb - kbeg - Gs >= syrk_min;
-    const int G = grouped ? Gs : (syrk ? 1 : (Gset ? Gset : 1));
+  const bool can_fuse = G == 1 && scratch != nullptr && fuse_max > 0;
+  auto panel_copy = [&](int k) { return scratch + (size_t)(k & 1) * ld * CB; };
+  if (can_fuse && nb - 1 >= 1 && nb - 1 <= fuse_max) {  // step 0 is fused already: prime its panel copy from A
+    hipError_t e = hipMemcpy2DAsync(panel_copy(0) + CB, (size_t)ld * sizeof(double), A + CB, (size_t)ld * sizeof(double),
+                                    (size_t)(ld - CB) * sizeof(double), CB, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return e;
+  }
+  for (int kbeg = 0; kbeg + 1 < nb; kbeg += G) {
     for (int k = kbeg; k < kbeg + G && k + 1 < nb; ++k) {
       const int k0 = k * CB;
       const int m = nb - k - 1;
+      const bool next_fused = can_fuse && m - 1 >= 1 && m - 1 <= fuse_max;
+      if (can_fuse && m <= fuse_max) {
+        hipLaunchKernelGGL(k_chol_step, dim3(m * m), 256, 0, st, A, ld, k0, m, Winv + (size_t)k * CB * CB, panel_copy(k),
+                           panel_copy(k + 1), Winv + (size_t)(k + 1) * CB * CB, info);
+        continue;
+      }
       hipLaunchKernelGGL(k_chol_panel, dim3(m), 256, 0, st, Winv + (size_t)k * CB * CB, A + (size_t)k0 * ld + k0 + CB, ld);
       const bool last = k == kbeg + G - 1;
-      if (last && grouped) {
-        MmArgs a{};
-        a.A = A; a.ld = ld; a.nt = ld / MB;
-        a.t0 = (kbeg + G) / 2; a.kp0 = kbeg * CB; a.kp1 = (kbeg + G) * CB;
-        const int TT = a.nt - a.t0;
-        a.cj0 = 0; a.cj1 = TT;
-        a.Wn = Winv + (size_t)(k + 1) * CB * CB; a.info = info;
-        hipError_t e = launch_mm128(a, MM_SYRK, TT, TT, 1, 1, st);
-        if (e != hipSuccess) return e;
-      } else {
-        hipLaunchKernelGGL(k_chol_update, dim3(last ? m * m : m), 256, 0, st, A, ld, kbeg * CB, k - kbeg + 1, k0 + CB, m, last ? m : 1,
-                           Winv + (size_t)(k + 1) * CB * CB, info);
-      }
+      hipLaunchKernelGGL(k_chol_update, dim3(last ? m * m : m), 256, 0, st, A, ld, kbeg * CB, k - kbeg + 1, k0 + CB, m, last ? m : 1,
+                         Winv + (size_t)(k + 1) * CB * CB, info, next_fused ? panel_copy(k + 1) : (double*)nullptr);
     }
-    kbeg += G;
   }
   return hipGetLastError();
 }

@@ -939,19 +939,26 @@ def test_factorisation_block_boundaries(eng, N):
 
 
 def test_singular_matrix_is_reported_like_lapack(eng):
-    """Duplicate training points without a nugget: the pivot of the second copy is <= 0 -> BOGP_ERR_NOT_POSDEF, which the
-    host maps to the reference's -inf (gpr.py:946-947), wherever in the matrix (first block, later block) it happens."""
+    """Duplicate training points under a slightly NEGATIVE noise variance (noisy mode: R = (sigma2 R0 + tau2 I) / (sigma2 +
+    tau2), gpr.py:966-967): the two copies then correlate by 1 + 1e-9 > 1 and the second one's pivot is -2e-9 whatever the
+    rounding (with tau2 = 0 it is +-1e-16, positive or not by luck -- in LAPACK as well) -> BOGP_ERR_NOT_POSDEF, which the
+    host maps to the reference's -inf (gpr.py:946-947), wherever in the matrix (first block, later block, last row)."""
     rng = np.random.default_rng(0)
-    for N, dup in ((40, (3, 17)), (200, (150, 199)), (130, (5, 129))):
+    for N, dup in ((40, (3, 17)), (200, (150, 199)), (130, (5, 129)), (64, (0, 63)), (65, (63, 64))):
         X = rng.uniform(-5, 5, size=(N, 2))
         X[dup[1]] = X[dup[0]]
         y = rng.standard_normal((N, 1))
         eng.set_train(X, y)
         with pytest.raises(_lib.NotPositiveDefinite):
-            eng.nll(O.KERNEL_SE, O.MODE_NOISELESS, np.r_[0.3, 0.2], 0.0, False, 0.0, eval_grad=True)
-        gp = bogp.GaussianProcess(corr="squared_exponential", thetaL=[1e-2] * 2, thetaU=[1e1] * 2, nugget=0)
+            eng.nll(O.KERNEL_SE, O.MODE_NOISY, np.r_[0.3, 0.2, 1.0], -1e-9, False, 0.0, eval_grad=True)
+        gp = bogp.GaussianProcess(corr="squared_exponential", thetaL=[1e-2] * 2, thetaU=[1e1] * 2, nugget=1e-9)
         gp._check_data(X, y)
-        assert gp.log_likelihood_concentrated(np.r_[0.3, 0.2]) == -np.inf
+        gp.noise_var = np.atleast_1d(-1e-9)
+        assert gp.estimation_mode == "noisy" and gp.log_likelihood_concentrated(np.r_[0.3, 0.2, 1.0]) == -np.inf
+        # and the very same matrix fails in LAPACK
+        R = (O.correlation_matrix(O.KERNEL_SE, np.r_[0.3, 0.2], X) - 1e-9 * np.eye(N)) / (1.0 - 1e-9)
+        with pytest.raises(np.linalg.LinAlgError):
+            np.linalg.cholesky(R)
 
 
 MT_NV = {0: 0.0, 1: 1e-3, 2: 0.0}
