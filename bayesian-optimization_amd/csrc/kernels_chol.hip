@@ -940,7 +940,15 @@ hipError_t launch_tri_inverse(const double* L, const double* Winv, double* V, do
     const int nbb = 1 << level;
     const int pairs = (nb + 2 * nbb - 1) / (2 * nbb);
     a.level = level;
-    if (big && level >= 1) {  // blocks of >= 128: the 128 x 128 tile product
+    // Levels that merge blocks of >= 1024 use the 128 x 128 tile product; below that a level is too few 128-tiles to fill
+    // the GPU and the 64 x 64 kernel wins -- measured per level at N = 8192 (merging blocks of 128 / 256 / 512 / 1024 / 2048 /
+    // 4096): k_tri_gemm 25 / 50 / 134 / 439 / 1272 / 4432 us against k_mm128 153 / 273 / 278 / 322 / 1075 / 2683 us.
+    static const int mm_min_level = [] {
+      const char* e = getenv("BOGP_MM128_MIN_LEVEL");
+      const int v = e ? atoi(e) : 4;
+      return v < 1 ? 1 : v;
+    }();
+    if (big && level >= mm_min_level) {
       MmArgs m{};
       m.L = L; m.V = V; m.U = U; m.T = T; m.ld = ld; m.nt = ld / MB; m.nb2 = nbb / 2;
       hipError_t e = launch_mm128(m, MM_T, m.nb2, m.nb2, pairs, 1, st);
