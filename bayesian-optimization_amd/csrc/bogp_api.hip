@@ -59,12 +59,13 @@ extern "C" int bogp_create(int device, bogp_handle** out) {
       hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_least) != hipSuccess ||
       rocblas_create_handle(&h->blas) != rocblas_status_success ||
       rocblas_set_stream(h->blas, h->stream) != rocblas_status_success ||
-      hipMalloc((void**)&h->dinfo, sizeof(rocblas_int)) != hipSuccess ||
       hipMalloc((void**)&h->dscal, 64 * sizeof(double)) != hipSuccess) {
     g_create_error = "stream / rocBLAS handle creation failed";
     delete h;
     return BOGP_ERR_HIP;
   }
+  // the factorisation's info word lives in the same block as its scalars (doubles 62-63): ONE read-back fetches both
+  h->dinfo = reinterpret_cast<rocblas_int*>(h->dscal + 62);
   rocblas_set_pointer_mode(h->blas, rocblas_pointer_mode_host);
   if (hipEventCreateWithFlags(&h->ev_chol[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_chol[1], hipEventDisableTiming) != hipSuccess) {
@@ -88,7 +89,7 @@ static void free_train(bogp_handle* h) {
   dfree(h->dyt_base); dfree(h->dft); dfree(h->drho_base); dfree(h->dtmp); dfree(h->dgamma_base); dfree(h->dw);
   h->dyt = h->drho = h->dgamma = nullptr;
   h->n_t = 1; h->target = 0;
-  dfree(h->dtheta); dfree(h->dsqrt_theta); dfree(h->dXthT); dfree(h->dVp);
+  dfree(h->dtheta); h->dsqrt_theta = nullptr; dfree(h->dXthT); dfree(h->dVp);
   free_trend(h);
   h->committed = false;
   h->cap_ld = h->cap_d = h->cap_nt = 0;
@@ -104,7 +105,7 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   dfree(h->dXs_owned); dfree(h->dss_part); dfree(h->dbounds); dfree(h->dsobol); dfree(h->dxform);
   for (int b = 0; b < 2; ++b) { dfree(h->drT[b]); dfree(h->dmu_part[b]); dfree(h->dw_part[b]); }
   dfree(h->dblk_val); dfree(h->dblk_idx); dfree(h->dmu_out); dfree(h->dmse_out); dfree(h->dacq_out);
-  dfree(h->dbest_val); dfree(h->dbest_idx); dfree(h->dtopk_val); dfree(h->dtopk_idx); dfree(h->dcounter); dfree(h->dinfo); dfree(h->dscal); dfree(h->dgrad_partial); dfree(h->dbatch);
+  dfree(h->dbest_val); dfree(h->dbest_idx); dfree(h->dtopk_val); dfree(h->dtopk_idx); dfree(h->dcounter); h->dinfo = nullptr; dfree(h->dscal); dfree(h->dgrad_partial); dfree(h->dbatch);
   dfree(h->dTt); dfree(h->dCS); dfree(h->duu); dfree(h->dmtrend);
   for (auto e : h->ev) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; ++i)
@@ -164,8 +165,8 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
     HIPCHK(h, hipMalloc((void**)&h->dtmp, cl * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->dgamma_base, ntc * cl * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->dw, cl * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->dtheta, (d + 1) * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->dsqrt_theta, (d + 1) * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dtheta, 2 * (d + 1) * sizeof(double)));  // [theta (d + 1) | sqrt_theta (d + 1)]: one upload
+    h->dsqrt_theta = h->dtheta + (d + 1);
   }
   h->N = N;
   h->d = d;
@@ -305,9 +306,20 @@ static int trend_solve(bogp_handle* h, int trend, int estimate_trend) {
   return BOGP_OK;
 }
 
+// what the host half of a factorisation (factorize_finish) needs once info / the device scalars have been read back
+struct FitPending {
+  int mode = 0, estimate_trend = 0, ptrend = 1, n_t = 1, N = 0;
+  double beta = 0, alpha = 0, sigma2_par = 0, noise_var = 0, s2t = 0;
+};
+static int factorize_finish(bogp_handle* h, const FitPending& fp, int info, const double* sc, const int* info2,
+                            bool reject_positive, FitOut* o);
+
+// pend == nullptr: queue the device work, read info + scalars back, finish (ONE host synchronisation).
+// pend != nullptr: queue only -- the caller appends its own device work (the likelihood gradient), reads everything back in ONE
+// synchronisation and calls factorize_finish itself.
 static int factorize(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
                      int estimate_trend, double beta, bool want_gamma, FitOut* o, std::vector<double>* theta_out,
-                     bool reject_positive = true) {
+                     bool reject_positive = true, FitPending* pend = nullptr) {
   if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "no training set: call bogp_set_train first");
   if (kernel < 0 || kernel > BOGP_KERNEL_GENEXP) FAIL(h, BOGP_ERR_INVALID, "unknown kernel id %d", kernel);
   if (mode < 0 || mode > 2) FAIL(h, BOGP_ERR_INVALID, "unknown estimation mode %d", mode);
@@ -323,10 +335,9 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
     n_theta -= 1;
   }
   if (n_theta != d && n_theta != 1) FAIL(h, BOGP_ERR_INVALID, "len(theta) = %d must be 1 or d = %d", n_theta, d);
-  std::vector<double>& th = h->h_theta;  // handle-owned: the asynchronous uploads below outlive this scope
-  std::vector<double>& sth = h->h_sqrt_theta;
-  th.resize(d + 1);
-  sth.resize(d + 1);
+  h->h_theta.resize(2 * (size_t)(d + 1));  // handle-owned: the asynchronous upload below outlives this scope
+  double* th = h->h_theta.data();          // [theta (d + 1) | sqrt_theta (d + 1)], uploaded in one copy
+  double* sth = th + (d + 1);
   for (int k = 0; k < d; ++k) {
     th[k] = par[n_theta == 1 ? 0 : k];
     if (!(th[k] > 0) || !std::isfinite(th[k])) FAIL(h, BOGP_ERR_INVALID, "theta[%d] = %g must be finite and > 0", k, th[k]);
@@ -336,11 +347,11 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
              : kernel == BOGP_KERNEL_GENEXP ? std::pow(th[k], 1.0 / pexp) : std::sqrt(th[k]);
   }
   th[d] = sth[d] = pexp;  // entry d of both device arrays: the exponent (read by the generalized_exponential kernels only)
-  if (theta_out) theta_out->assign(th.begin(), th.begin() + d);
+  if (theta_out) theta_out->assign(th, th + d);
   hipStream_t st = h->stream;
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipMemcpyAsync(h->dtheta, th.data(), (d + 1) * sizeof(double), hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(h->dsqrt_theta, sth.data(), (d + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+  h->dsqrt_theta = h->dtheta + (d + 1);  // (the block holds 2 (cap_d + 1) doubles; d may be below the capacity)
+  HIPCHK(h, hipMemcpyAsync(h->dtheta, th, 2 * (size_t)(d + 1) * sizeof(double), hipMemcpyHostToDevice, st));
 
   // The identity padding is re-established for EVERY factorisation: a factorisation that broke down (pivots of rounding
   // size -> overflowing inverses -> inf * 0) leaves NaN in the padding rows of the in-place factor, and R is only rebuilt
@@ -388,13 +399,29 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
     for (int t = 0; t < n_t; ++t)
       HIPCHK(h, launch_gemv2(h->dU, ldr, N, 2, h->drho_base + (size_t)t * N, nullptr, h->dgamma_base + (size_t)t * h->Np, nullptr, h->dgemv_scratch, st));
   }
-  rocblas_int info = 0;
-  double sc[4 * BOGP_MAX_TARGETS] = {0, 0, 0, 0};  // sum(log diag L), |Ft|, Ft.Yt, rho.rho (the last three per target)
-  HIPCHK(h, hipMemcpyAsync(&info, h->dinfo, sizeof(info), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipMemcpyAsync(sc, h->dscal, 4 * n_t * sizeof(double), hipMemcpyDeviceToHost, st));
+  FitPending fp;
+  fp.mode = mode; fp.estimate_trend = estimate_trend; fp.ptrend = ptrend; fp.n_t = n_t; fp.N = N;
+  fp.beta = beta; fp.alpha = alpha; fp.sigma2_par = sigma2_par; fp.noise_var = noise_var; fp.s2t = s2t;
+  if (pend) {
+    *pend = fp;
+    return BOGP_OK;
+  }
+  double blk[64];  // [0 .. 4 n_t): sum(log diag L), |Ft|, Ft.Yt, rho.rho (the last three per target); [62]: the info word
+  HIPCHK(h, hipMemcpyAsync(blk, h->dscal, sizeof(blk), hipMemcpyDeviceToHost, st));
+  const double* sc = blk;
   rocblas_int info2[2] = {0, 0};
   if (ptrend > 1 && estimate_trend) HIPCHK(h, hipMemcpyAsync(info2, h->dinfo2, sizeof(info2), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
+  rocblas_int info = 0;
+  memcpy(&info, blk + 62, sizeof(info));
+  return factorize_finish(h, fp, (int)info, sc, info2, reject_positive, o);
+}
+
+static int factorize_finish(bogp_handle* h, const FitPending& fp, int info, const double* sc, const int* info2,
+                            bool reject_positive, FitOut* o) {
+  const int mode = fp.mode, estimate_trend = fp.estimate_trend, ptrend = fp.ptrend, n_t = fp.n_t, N = fp.N;
+  const double beta = fp.beta, alpha = fp.alpha, sigma2_par = fp.sigma2_par, noise_var = fp.noise_var;
+  double s2t = fp.s2t;
   if (info != 0) FAIL(h, BOGP_ERR_NOT_POSDEF, "correlation matrix is not positive definite (potrf info = %d)", (int)info);
   if (info2[0] != 0 || info2[1] != 0) FAIL(h, BOGP_ERR_NOT_POSDEF, "trend basis is rank deficient after whitening (Ft^T Ft not positive definite, info = %d / %d)", (int)info2[0], (int)info2[1]);
 
@@ -464,8 +491,15 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
     FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll: the cubic / generalized_exponential correlation has no theta-derivative (the reference's corr_grad_theta leaves it undefined, gpr.py:763-766: its own likelihood gradient raises UnboundLocalError)");
   h->committed = false;  // the factor buffers are about to be overwritten
   FitOut o;
-  int rc = factorize(h, kernel, mode, par, n_par, noise_var, trend, estimate_trend, beta, grad != nullptr, &o, nullptr);
-  *llf = o.llf;
+  // With the constant basis the gradient kernels are queued straight behind the factorisation (their only host-dependent
+  // inputs, the per-target weights, are formed on the device by k_grad_coef) and info, the likelihood scalars and the d + 1
+  // contractions come back in ONE synchronisation: ~60 us less per evaluation than reading the scalars first (the whole
+  // evaluation is 0.15 ms at N <= 64).  A failed factorisation then wastes the queued gradient work -- the rare case.
+  const bool deferred = grad != nullptr && trend == BOGP_TREND_CONSTANT && !(getenv("BOGP_NLL_TWO_SYNCS") && atoi(getenv("BOGP_NLL_TWO_SYNCS")) != 0);
+  FitPending fp;
+  int rc = factorize(h, kernel, mode, par, n_par, noise_var, trend, estimate_trend, beta, grad != nullptr, &o, nullptr, true,
+                     deferred ? &fp : nullptr);
+  if (!deferred) *llf = o.llf;
   if (rc != BOGP_OK) return rc;
   if (!grad) return BOGP_OK;
 
@@ -492,11 +526,19 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
   const int n_t = h->n_t;
   GradVecs gv;
   gv.v = h->dgamma_base; gv.stride = (size_t)h->Np; gv.n = n_t; gv.c0 = (double)n_t;
-  double inv_sum = 0.0;
-  for (int t = 0; t < n_t; ++t) inv_sum += 1.0 / (mode == BOGP_MODE_NOISELESS ? o.sigma2_t[t] : o.s2t_t[t]);
-  for (int t = 0; t < n_t; ++t) {
-    gv.cB[t] = 1.0 / o.s2t_t[t];
-    gv.cA[t] = mode == BOGP_MODE_NOISY ? gv.cB[t] : inv_sum;
+  if (deferred) {
+    // scal[4 n_t ..]: 16 doubles of weights behind the per-target scalars (dscal holds 64 doubles)
+    double* dcoef = h->dscal + 4 * BOGP_MAX_TARGETS;
+    HIPCHK(h, launch_grad_coef(h->dscal, n_t, mode, N, estimate_trend ? 1 : 0, fp.s2t, dcoef, st));
+    gv.dcoef = dcoef;
+    for (int t = 0; t < BOGP_MAX_TARGETS; ++t) gv.cA[t] = gv.cB[t] = 0.0;
+  } else {
+    double inv_sum = 0.0;
+    for (int t = 0; t < n_t; ++t) inv_sum += 1.0 / (mode == BOGP_MODE_NOISELESS ? o.sigma2_t[t] : o.s2t_t[t]);
+    for (int t = 0; t < n_t; ++t) {
+      gv.cB[t] = 1.0 / o.s2t_t[t];
+      gv.cA[t] = mode == BOGP_MODE_NOISY ? gv.cB[t] : inv_sum;
+    }
   }
   HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, gv, nullptr, 0.0, h->dRinv, ldr, nparts, (size_t)ldr * ldr, h->dgrad_partial, nblk, st));
   double* dS = h->dgrad_partial + (size_t)nblk * (d + 1);
@@ -507,7 +549,19 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
     if (n_t > 1) HIPCHK(h, launch_sumsq(h->dgamma_base, n_t * h->Np, dS + d + 2, st));  // sum_t gamma_t . gamma_t (zero padding)
   }
   HIPCHK(h, hipMemcpyAsync(S.data(), dS, (d + 3) * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
+  if (deferred) {
+    double blk[64];
+    const int info2[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(blk, h->dscal, sizeof(blk), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    rocblas_int info = 0;
+    memcpy(&info, blk + 62, sizeof(info));
+    rc = factorize_finish(h, fp, (int)info, blk, info2, true, &o);
+    *llf = o.llf;
+    if (rc != BOGP_OK) return rc;
+  } else {
+    HIPCHK(h, hipStreamSynchronize(st));
+  }
   const double tr = n_t * S[d + 1], gg = S[d + 2];
   if (iso) {
     grad[0] = mode == BOGP_MODE_NOISE_ESTIM ? par[n_par - 1] * S[0] : S[0];

@@ -143,6 +143,7 @@ struct GradVecs {
   int n;
   double c0;
   double cA[BOGP_MAX_TARGETS], cB[BOGP_MAX_TARGETS];
+  const double* dcoef = nullptr;  // if set: cA = dcoef[0..7], cB = dcoef[8..15] read on the device (k_grad_coef) instead
 };
 hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const double* theta, const GradVecs& gv,
                                 const double* qv, double c2, const double* Rinv, int ld, int nparts,
@@ -156,6 +157,7 @@ hipError_t launch_trend_terms(int trend, const double* Xs, int64_t m0, int64_t m
                               double* T, double* mtrend, hipStream_t st);
 hipError_t launch_rowdot(const double* Cm, const double* CS, int64_t Mc, int64_t mcount, int p, double* uu, hipStream_t st);
 hipError_t launch_sumsq(const double* v, int N, double* out, hipStream_t st);
+hipError_t launch_grad_coef(const double* scal, int n_t, int mode, int N, int krank, double s2t_host, double* coef, hipStream_t st);
 hipError_t launch_gemv2(const double* M, int ld, int N, int tri, const double* x0, const double* x1, double* y0, double* y1,
                         double* scratch, hipStream_t st);
 hipError_t launch_fit_rho(const double* Yt, const double* Ft, int N, int estimate_trend, double beta, double* rho, double* scal,

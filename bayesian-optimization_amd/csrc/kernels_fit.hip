@@ -163,6 +163,28 @@ hipError_t launch_fit_rho(const double* Yt, const double* Ft, int N, int estimat
   return hipGetLastError();
 }
 
+// Per-target weights of gamma_t gamma_t^T in the likelihood gradient (bogp_nll), formed ON the device from the scalars of
+// k_fit_rho so that the gradient kernels can be queued behind the factorisation without a host round trip in between:
+//   s2t_t = rho_t.rho_t / (N - k)  [noiseless, target 0; / N for further targets and in noise_estim mode],  s2t_host [noisy]
+//   cB[t] = 1 / s2t_t;  cA[t] = cB[t] [noisy]  or  sum_t 1 / s2t_t [otherwise]          (same IEEE operations as the host's)
+// coef: cA[0..7], cB[8..15].
+__global__ void k_grad_coef(const double* __restrict__ scal, int n_t, int mode, int N, int krank, double s2t_host,
+                            double* __restrict__ coef) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double inv_sum = 0.0;
+  for (int t = 0; t < n_t; ++t) {
+    const double rss = scal[4 * t + 3];
+    const double s2t = mode == BOGP_MODE_NOISY ? s2t_host : (mode == BOGP_MODE_NOISELESS && t == 0 ? rss / (N - krank) : rss / N);
+    coef[8 + t] = 1.0 / s2t;
+    inv_sum += 1.0 / s2t;
+  }
+  for (int t = 0; t < n_t; ++t) coef[t] = mode == BOGP_MODE_NOISY ? coef[8 + t] : inv_sum;
+}
+hipError_t launch_grad_coef(const double* scal, int n_t, int mode, int N, int krank, double s2t_host, double* coef, hipStream_t st) {
+  hipLaunchKernelGGL(k_grad_coef, dim3(1), 64, 0, st, scal, n_t, mode, N, krank, s2t_host, coef);
+  return hipGetLastError();
+}
+
 // out[0] = v . v
 __global__ __launch_bounds__(1024) void k_sumsq(const double* __restrict__ v, int N, double* __restrict__ out) {
   __shared__ double red[16];

@@ -268,8 +268,8 @@ __global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict_
         double gA = 0.0, gB = 0.0;
         for (int t = 0; t < gv.n; ++t) {
           const double gg = gv.v[t * gv.stride + i] * gv.v[t * gv.stride + j];
-          gA = __builtin_fma(gg, gv.cA[t], gA);
-          gB = __builtin_fma(gg, gv.cB[t], gB);
+          gA = __builtin_fma(gg, gv.dcoef ? gv.dcoef[t] : gv.cA[t], gA);
+          gB = __builtin_fma(gg, gv.dcoef ? gv.dcoef[8 + t] : gv.cB[t], gB);
         }
         double A = gA - gv.c0 * rinv, A2 = gB - gv.c0 * rinv;
         if (qv) {  // REML: the (L^-T Q)(L^-T Q)^T term of gpr.py:876-878, 896-898
