@@ -143,6 +143,40 @@ def test_install_fuses_the_parallelbo_batch_into_one_posterior_pass(ref):
     assert not any(np.any(np.all(np.isclose(hist, x), axis=1)) for x in Xf)
 
 
+def test_install_reroutes_the_default_bfgs_to_one_sweep(ref):
+    """A driver built WITHOUT `acquisition_optimization` gets the reference's default inner optimiser "BFGS" with 100 dim point
+    evaluations (base.py:200-214): `install(reroute_bfgs="sweep", sweep_budget=...)` turns its ask() into one sweep -- same
+    constructor call, one posterior pass for the 4 proposals; `uninstall()` clears the reroute."""
+    bayes_optim, bogp, OracleEngine = ref
+    from bayes_optim import ParallelBO, RealSpace
+
+    from bogp import integration
+
+    dim, q = 2, 4
+    f = lambda x: float(np.sum(np.asarray(x) ** 2))  # noqa: E731
+    undo = bogp.install(bayes_optim, reroute_bfgs="sweep", sweep_budget=2500)
+    try:
+        np.random.seed(3)
+        model = _model(bogp, OracleEngine, dim)
+        model._engine = _CountingEngine()
+        opt = ParallelBO(search_space=RealSpace([-5, 5]) * dim, obj_fun=f, model=model, DoE_size=8, max_FEs=30, verbose=False,
+                         n_point=q, acquisition_fun="MGFI", acquisition_par={"t": 2}, random_seed=3)  # fmt: skip
+        assert opt._optimizer == "BFGS"  # the reference's own default: nothing was passed
+        X0 = opt.ask()
+        opt.tell(X0, [f(x) for x in X0])
+        before = type(model._engine).passes
+        X = opt.ask()
+        assert type(model._engine).passes - before == 1
+        assert np.asarray(X, dtype=float).shape == (q, dim)
+        assert model._engine.M == 2500  # the sweep's own budget, not BFGS's 100 dim
+    finally:
+        undo()
+    assert not integration._REROUTE
+    with pytest.raises(ValueError):
+        bogp.install(bayes_optim, reroute_bfgs="CMA")
+    bogp.uninstall()
+
+
 @pytest.mark.timeout(600)
 def test_fused_batch_with_fixed_variables_and_ucb(ref):
     """ask(fixed=...) through the fused batch (the free variables are swept, the fixed one is filled in for the model and
