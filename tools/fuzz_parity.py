@@ -1,0 +1,158 @@
+"""Differential fuzz: the device engine against the oracle engine (tests/support/oracle_engine.py = oracle/gp_oracle.py
+behind the same methods) on random problems for a given number of seconds -- sizes around every block boundary of the
+kernels (N mod 16 / 32 / 64, the 512 limit of the fused sweep, M mod 64), every kernel / mode / trend the path builds,
+random criteria.  Prints one line per failure with the seed that reproduces it; exits non-zero if any.
+usage: python tools/fuzz_parity.py [seconds] [first_seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from bogp import _lib  # noqa: E402
+from oracle import gp_oracle as O  # noqa: E402
+from support.oracle_engine import OracleEngine  # noqa: E402
+
+KERNELS = [O.KERNEL_SE, O.KERNEL_MATERN12, O.KERNEL_MATERN32, O.KERNEL_MATERN52, O.KERNEL_ABSEXP, O.KERNEL_CUBIC, O.KERNEL_GENEXP]
+NO_GRAD = (O.KERNEL_CUBIC, O.KERNEL_GENEXP)
+EDGE_N = [2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 640, 1023, 1025]
+
+
+def close(a, b, rtol=1e-6, atol=0.0):
+    return np.allclose(np.asarray(a, float), np.asarray(b, float), rtol=rtol, atol=atol, equal_nan=True)
+
+
+def one(seed, eng, orc):
+    rng = np.random.default_rng(seed)
+    d = int(rng.integers(1, 13))
+    N = int(rng.choice(EDGE_N)) if rng.random() < 0.6 else int(rng.integers(2, 700))
+    N = max(N, 2)
+    kernel = int(rng.choice(KERNELS))
+    mode = int(rng.integers(0, 3))
+    trend = int(rng.choice([0, 0, 0, 1, 2])) if d <= 4 and N > 40 else 0
+    est = bool(rng.integers(0, 2))
+    X = rng.uniform(-5, 5, (N, d))
+    y = np.sum(np.sin(X), axis=1) + 0.3 * np.sum(X**2, axis=1) / d
+    y = ((y - y.mean()) / (y.std() + 1e-12) + 0.05 * rng.standard_normal(N)).reshape(-1, 1)
+    theta = np.exp(rng.uniform(np.log(0.02), np.log(0.5), d)) / d
+    if kernel == O.KERNEL_GENEXP:
+        theta = np.r_[theta, rng.uniform(1.0, 2.0)]
+    nv = 0.0
+    if mode == O.MODE_NOISELESS:
+        par = theta
+        if kernel in (O.KERNEL_SE, O.KERNEL_MATERN52, O.KERNEL_CUBIC) and N > 64:  # smooth kernels without a nugget: singular
+            mode, par, nv = O.MODE_NOISY, np.r_[theta, 0.9], 1e-4
+    elif mode == O.MODE_NOISY:
+        par, nv = np.r_[theta, rng.uniform(0.5, 1.5)], 10.0 ** rng.uniform(-6, -2)
+    else:
+        par = np.r_[theta, rng.uniform(0.7, 0.999)]
+    p = 1 if trend == 0 else (d + 1 if trend == 1 else (d + 1) * (d + 2) // 2)
+    beta = 0.0 if est else (0.1 if trend == 0 else np.linspace(-0.1, 0.1, p))
+    tag = "seed %d: N=%d d=%d kernel=%d mode=%d trend=%d est=%d" % (seed, N, d, kernel, mode, trend, est)
+    # both sides lose cond(R) eps of accuracy: compare only where that is below the tolerances (the estimate: squared ratio of
+    # the extreme diagonal entries of the Cholesky factor, a lower bound of cond(R)); the rest still runs, for crashes
+    Rm = O.correlation_matrix(kernel, np.asarray(theta), X)
+    if mode == O.MODE_NOISY:
+        Rm = (par[-1] * Rm + nv * np.eye(N)) / (par[-1] + nv)
+    elif mode == O.MODE_NOISE_ESTIM:
+        Rm = par[-1] * Rm + (1 - par[-1]) * np.eye(N)
+    try:
+        dl = np.diag(np.linalg.cholesky(Rm))
+        cond = float((dl.max() / dl.min()) ** 2)
+    except np.linalg.LinAlgError:
+        cond = np.inf
+    compare = cond < 1e8
+    tol = max(1e-8, 100.0 * cond * 2.2e-16)  # likelihood tolerance: both sides carry cond(R) eps
+    eng.set_train(X, y)
+    orc.set_train(X, y)
+    fails = []
+    grad = kernel not in NO_GRAD
+    try:
+        ref = orc.nll(kernel, mode, par, nv, est, beta, eval_grad=grad, trend=trend)
+        ref_err = None
+    except Exception as e:  # noqa: BLE001
+        ref, ref_err = None, type(e).__name__
+    try:
+        got = eng.nll(kernel, mode, par, nv, est, beta, eval_grad=grad, trend=trend)
+        got_err = None
+    except _lib.BogpError as e:
+        got, got_err = None, type(e).__name__
+    if (ref_err is None) != (got_err is None):
+        # a likelihood at the edge of positive definiteness may fail on one side only; count, do not fail
+        return [], tag + " -- one-sided failure (%s / %s)" % (ref_err, got_err)
+    if ref is None:
+        return [], None
+    if not compare:
+        try:
+            eng.commit(kernel, mode, par, nv, est, beta, trend=trend)
+            eng.upload_candidates(rng.uniform(-5, 5, (100, d)))
+            eng.sweep([(0, 0.0)], float(y.min()), True)
+        except _lib.BogpError:
+            pass
+        return [], tag + " -- ill-conditioned (cond >= %.1e): ran, not compared" % cond
+    if grad:
+        if not close(got[0], ref[0], tol, tol):
+            fails.append("llf %r vs %r" % (got[0], ref[0]))
+        if not close(np.ravel(got[1]), np.ravel(ref[1]), 1e-5, 1e-6 * (1 + np.abs(ref[1]).max())):
+            fails.append("grad max diff %g" % np.abs(np.ravel(got[1]) - np.ravel(ref[1])).max())
+    elif not close(got, ref, tol, tol):
+        fails.append("llf %r vs %r" % (got, ref))
+    try:
+        orc.commit(kernel, mode, par, nv, est, beta, trend=trend)
+        eng.commit(kernel, mode, par, nv, est, beta, trend=trend)
+    except Exception as e:  # noqa: BLE001
+        return fails, tag + " -- commit failed (%s)" % type(e).__name__
+    M = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 1000, 4097])) if rng.random() < 0.7 else int(rng.integers(1, 6000))
+    Xs = rng.uniform(-5, 5, (M, d))
+    if M > 3:
+        Xs[1] = X[0]  # a training point among the candidates
+    eng.upload_candidates(Xs)
+    orc.upload_candidates(Xs)
+    mu, mse = eng.predict()
+    rmu, rmse = orc.predict()
+    s2 = float(np.atleast_1d(orc.get_state(False)["sigma2"])[0]) if hasattr(orc, "get_state") else 1.0
+    if not close(mu, rmu, 1e-6, 1e-7):
+        fails.append("mu max diff %g" % np.abs(np.ravel(mu) - np.ravel(rmu)).max())
+    if not close(mse, rmse, 1e-6, 1e-7 * s2):
+        fails.append("mse max diff %g (sigma2 %g)" % (np.abs(np.ravel(mse) - np.ravel(rmse)).max(), s2))
+    q = int(rng.integers(1, 5))
+    acq = [(int(rng.integers(0, 4)), float(rng.uniform(0.1, 3.0))) for _ in range(q)]
+    plugin = float(y.min())
+    b, i = eng.sweep(acq, plugin, True)
+    rb, ri, rv = orc.sweep(acq, plugin, True, return_values=True)
+    for c in range(q):
+        if int(i[c]) != int(ri[c]):
+            # a different index is a failure only if the oracle's values separate the two candidates
+            v = rv[c]
+            if not (np.isnan(v[int(i[c])]) or abs(v[int(i[c])] - v[int(ri[c])]) <= 1e-9 * (abs(v[int(ri[c])]) + 1e-300)):
+                fails.append("argmax[%d] %d vs %d (values %r / %r)" % (c, i[c], ri[c], v[int(i[c])], v[int(ri[c])]))
+        elif not close(b[c], rb[c], 1e-6, 1e-300):
+            fails.append("best[%d] %r vs %r" % (c, b[c], rb[c]))
+    return [tag + ": " + f for f in fails], None
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    eng, orc = _lib.Engine(0), OracleEngine()
+    t0 = time.time()
+    n = nfail = nskip = 0
+    while time.time() - t0 < seconds:
+        fails, note = one(seed, eng, orc)
+        for f in fails:
+            print("FAIL", f, flush=True)
+        if note:
+            nskip += 1
+            print("note", note, flush=True)
+        nfail += bool(fails)
+        n += 1
+        seed += 1
+    print("fuzz: %d problems in %.0f s, %d with failures, %d notes (next seed %d)" % (n, time.time() - t0, nfail, nskip, seed))
+    sys.exit(1 if nfail else 0)
+
+
+if __name__ == "__main__":
+    main()
