@@ -2,7 +2,7 @@
 behind the same methods) on random problems for a given number of seconds -- sizes around every block boundary of the
 kernels (N mod 16 / 32 / 64, the 512 limit of the fused sweep, M mod 64), every kernel / mode / trend the path builds,
 random criteria.  Prints one line per failure with the seed that reproduces it; exits non-zero if any.
-usage: python tools/fuzz_parity.py [seconds] [first_seed]"""
+usage: python tools/fuzz_parity.py [--wide] [seconds] [first_seed]"""
 import os
 import sys
 import time
@@ -25,10 +25,17 @@ def close(a, b, rtol=1e-6, atol=0.0):
     return np.allclose(np.asarray(a, float), np.asarray(b, float), rtol=rtol, atol=atol, equal_nan=True)
 
 
+WIDE = False  # --wide: d up to 60 (the fused sweep's limit), N up to 2200, + the restricted likelihood and input gradients
+
+
 def one(seed, eng, orc):
     rng = np.random.default_rng(seed)
     d = int(rng.integers(1, 13))
     N = int(rng.choice(EDGE_N)) if rng.random() < 0.6 else int(rng.integers(2, 700))
+    if WIDE:
+        d = int(rng.choice([1, 2, 3, 5, 10, 16, 17, 20, 33, 48, 59, 60]))
+        if rng.random() < 0.25:
+            N = int(rng.choice([1536, 2047, 2048, 2049, 2200]))
     N = max(N, 2)
     kernel = int(rng.choice(KERNELS))
     mode = int(rng.integers(0, 3))
@@ -118,6 +125,35 @@ def one(seed, eng, orc):
         fails.append("mu max diff %g" % np.abs(np.ravel(mu) - np.ravel(rmu)).max())
     if not close(mse, rmse, 1e-6, 1e-7 * s2):
         fails.append("mse max diff %g (sigma2 %g)" % (np.abs(np.ravel(mse) - np.ravel(rmse)).max(), s2))
+    if WIDE and trend == 0 and kernel in (O.KERNEL_SE, O.KERNEL_MATERN32, O.KERNEL_ABSEXP):
+        # input gradients of the posterior at a random point (gpr.py:537-576) ...
+        x = rng.uniform(-5, 5, d)
+        try:
+            gm, gv = eng.gradient(x)
+            rm, rv_ = orc.gradient(x)
+            if not close(gm, rm, 1e-6, 1e-8) or not close(gv, rv_, 1e-6, 1e-8 * s2):
+                fails.append("input gradient max diff %g / %g" % (np.abs(np.ravel(gm) - np.ravel(rm)).max(), np.abs(np.ravel(gv) - np.ravel(rv_)).max()))
+        except (_lib.BogpError, NotImplementedError) as e:
+            fails.append("gradient raised %s" % type(e).__name__)
+        # ... and the restricted likelihood (gpr.py:813-918) at [theta, sigma2(, noise_var)]
+        if len(theta) == d:
+            rpar = np.r_[theta, 0.8] if mode != O.MODE_NOISE_ESTIM else np.r_[theta, 0.8, 1e-3]
+            rnv = nv if mode == O.MODE_NOISY else 0.0
+            try:
+                rr = orc.nll_restricted(kernel, mode, rpar, rnv, est, beta, eval_grad=True, trend=trend)
+            except Exception:  # noqa: BLE001
+                rr = None
+            try:
+                gr = eng.nll_restricted(kernel, mode, rpar, rnv, est, beta, eval_grad=True, trend=trend)
+            except _lib.BogpError:
+                gr = None
+            if rr is not None and gr is not None and np.isfinite(rr[0]):
+                if not close(gr[0], rr[0], tol, tol):
+                    fails.append("REML %r vs %r" % (gr[0], rr[0]))
+                if not close(np.ravel(gr[1]), np.ravel(rr[1]), 1e-5, 1e-6 * (1 + np.abs(rr[1]).max())):
+                    fails.append("REML grad max diff %g" % np.abs(np.ravel(gr[1]) - np.ravel(rr[1])).max())
+            eng.commit(kernel, mode, par, nv, est, beta, trend=trend)  # (the likelihood call dropped the committed state)
+            eng.upload_candidates(Xs)
     q = int(rng.integers(1, 5))
     acq = [(int(rng.integers(0, 4)), float(rng.uniform(0.1, 3.0))) for _ in range(q)]
     plugin = float(y.min())
@@ -135,6 +171,10 @@ def one(seed, eng, orc):
 
 
 def main():
+    global WIDE
+    if "--wide" in sys.argv:
+        WIDE = True
+        sys.argv.remove("--wide")
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     eng, orc = _lib.Engine(0), OracleEngine()
