@@ -41,7 +41,7 @@ struct bogp_handle {
   double *dR = nullptr, *dV = nullptr, *dU = nullptr, *dT = nullptr, *dRinv = nullptr;  // L, L^-1, L^-T, scratch, R^-1
   double* dones = nullptr;  // N ones (the constant trend basis)
   double* dgemv_scratch = nullptr;  // segment partials of launch_gemv2
-  std::vector<double> h_theta, h_sqrt_theta;
+  std::vector<double> h_theta;  // [theta (d + 1) | sqrt_theta (d + 1)]: the block uploaded by factorize
   double* ddinv = nullptr;  // ldr x 64: inverses of the diagonal blocks of the running factorisation (kernels_chol.hip)
   double *dyt = nullptr, *dft = nullptr, *drho = nullptr, *dtmp = nullptr;  // N each
   double *dgamma = nullptr, *dw = nullptr;                                  // Np each (zero padded)
