@@ -313,3 +313,31 @@ def test_value_only_kernels_refuse_fit_like_the_reference():
     gp = bogp.GaussianProcess(corr="generalized_exponential", thetaL=[1e-3] * 4, thetaU=[1e2] * 4)
     with pytest.raises(Exception, match="right size"):
         gp._check_data(X, y)
+
+
+def test_driver_trace_fixture_replays_on_the_oracle_engine():
+    """G28 (oracle/make_driver_trace.py: every engine call of a real `ParallelBO` run with its answer) decodes, and the
+    oracle-backed engine reproduces its own recorded answers bit for bit -- the CPU half of
+    tests/test_gpu_driver.py::test_replay_of_the_real_driver_trace."""
+    import json
+
+    from conftest import load_golden
+    from support.oracle_engine import OracleEngine
+    from support.trace_codec import decode
+
+    g = load_golden("G28_driver_trace")
+    index = json.loads(str(g["index"]))
+    eng = OracleEngine()
+    n_nll = n_top = 0
+    for node in index:
+        c = decode(node, g)
+        out = getattr(eng, c["name"])(*c["args"], **c["kwargs"])
+        if c["name"] == "nll":
+            got = out[0] if isinstance(out, tuple) else out
+            ref = c["out"][0] if isinstance(c["out"], (tuple, list)) else c["out"]
+            assert got == ref
+            n_nll += 1
+        elif c["name"] == "sweep_topk":
+            np.testing.assert_array_equal(out[1], c["out"][1])
+            n_top += 1
+    assert n_nll >= 100 and n_top == 3
