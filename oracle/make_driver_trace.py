@@ -1,6 +1,6 @@
 """G28: every engine call the REAL `bayes_optim.ParallelBO` makes during a short run, with its result (build container only).
 
-    python oracle/make_driver_trace.py      ->  tests/golden/G28_driver_trace.npz
+    python oracle/make_driver_trace.py      ->  tests/golden/G28_driver_trace.npz, G29_driver_trace_bfgs.npz
 
 VERDICT r01 (weak 4): the drop-in tests with the real drivers run on the oracle-backed engine stand-in (no GPU here), the GPU
 suite runs the device classes without the real drivers (no reference tree there) -- joined only by inspection.  This fixture
@@ -67,6 +67,39 @@ class RecordingEngine(OracleEngine):
         return attr
 
 
+def trace_bo_bfgs():
+    """G29: the plain `BO` driver with its DEFAULT-style inner optimiser (multi-restart L-BFGS-B on `EI(x, return_dx=True)`:
+    one-point posterior + input-gradient calls) for a DoE and 2 iterations."""
+    from bayes_optim import BO
+
+    dim = 2
+    f = lambda x: float(np.sum(np.asarray(x) ** 2) + np.sin(3 * np.asarray(x)[0]))  # noqa: E731
+    undo = bogp.install(bayes_optim)
+    try:
+        np.random.seed(7)
+        model = bogp.GaussianProcess(mean=bogp.trend.constant_trend(dim), corr="squared_exponential", thetaL=[1e-3] * dim,
+                                     thetaU=[1e2] * dim, nugget=1e-6, optimizer="BFGS", random_start=2, wait_iter=2, eval_budget=40)  # fmt: skip
+        eng = RecordingEngine()
+        model._engine = eng
+        opt = BO(search_space=RealSpace([-5, 5]) * dim, obj_fun=f, model=model, DoE_size=6, max_FEs=20, verbose=False,
+                 acquisition_fun="EI", acquisition_optimization={"optimizer": "BFGS", "max_FEs": 40, "n_restart": 2}, random_seed=7)  # fmt: skip
+        for it in range(3):
+            X = opt.ask()
+            opt.tell(X, [f(x) for x in X])
+    finally:
+        undo()
+    arrs = {}
+    index = [encode(c, arrs) for c in eng.calls]
+    arrs["index"] = np.array(json.dumps(index))
+    arrs["n_calls"] = np.array(len(index))
+    out = OUT.replace("G28_driver_trace", "G29_driver_trace_bfgs")
+    np.savez_compressed(out, **arrs)
+    kinds = {}
+    for c in eng.calls:
+        kinds[c["name"]] = kinds.get(c["name"], 0) + 1
+    print("recorded %d engine calls: %s -> %s (%.1f KB)" % (len(index), kinds, out, os.path.getsize(out) / 1024))
+
+
 def main():
     dim, q = 2, 3
     f = lambda x: float(np.sum(np.asarray(x) ** 2) + np.sin(3 * np.asarray(x)[0]))  # noqa: E731
@@ -98,6 +131,7 @@ def main():
     for c in eng.calls:
         kinds[c["name"]] = kinds.get(c["name"], 0) + 1
     print("recorded %d engine calls: %s -> %s (%.1f KB)" % (len(index), kinds, OUT, os.path.getsize(OUT) / 1024))
+    trace_bo_bfgs()
 
 
 if __name__ == "__main__":

@@ -315,7 +315,8 @@ def test_value_only_kernels_refuse_fit_like_the_reference():
         gp._check_data(X, y)
 
 
-def test_driver_trace_fixture_replays_on_the_oracle_engine():
+@pytest.mark.parametrize("fixture", ["G28_driver_trace", "G29_driver_trace_bfgs"])
+def test_driver_trace_fixture_replays_on_the_oracle_engine(fixture):
     """G28 (oracle/make_driver_trace.py: every engine call of a real `ParallelBO` run with its answer) decodes, and the
     oracle-backed engine reproduces its own recorded answers bit for bit -- the CPU half of
     tests/test_gpu_driver.py::test_replay_of_the_real_driver_trace."""
@@ -325,7 +326,7 @@ def test_driver_trace_fixture_replays_on_the_oracle_engine():
     from support.oracle_engine import OracleEngine
     from support.trace_codec import decode
 
-    g = load_golden("G28_driver_trace")
+    g = load_golden(fixture)
     index = json.loads(str(g["index"]))
     eng = OracleEngine()
     n_nll = n_top = 0
@@ -340,4 +341,4 @@ def test_driver_trace_fixture_replays_on_the_oracle_engine():
         elif c["name"] == "sweep_topk":
             np.testing.assert_array_equal(out[1], c["out"][1])
             n_top += 1
-    assert n_nll >= 100 and n_top == 3
+    assert n_nll >= 50 and n_top == (3 if fixture == "G28_driver_trace" else 0)
