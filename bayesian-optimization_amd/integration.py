@@ -1,30 +1,53 @@
 """`bogp.install(bayes_optim)`: route the reference's own drivers through the device engine, without editing them.
 
-Three module attributes and one method are re-pointed (INTEGRATION.md sections 3-4; all undone by the returned callable):
+What is re-pointed (INTEGRATION.md sections 3-4; all undone by the returned callable):
 
-  bayes_optim.base.argmax_restart              -> bogp.argmax_restart      (same signature; adds optimizer="sweep" ...)
-  bayes_optim.base.AcquisitionFunction         -> bogp.acquisition         (classes looked up by name, base.py:485-488)
-  bayes_optim.bayes_opt.AcquisitionFunction    -> bogp.acquisition         (`hasattr(cls, "plugin")`, bayes_opt.py:21-23)
-  ParallelBO._batch_arg_max_acquisition        -> fused_batch_arg_max_acquisition (below)
+  bayes_optim.base.argmax_restart               -> routed_argmax_restart    (same signature; serves the sweep family,
+                                                                             hands everything else to the original)
+  bayes_optim.{base,bayes_opt,extension}.AcquisitionFunction -> a per-MODEL dispatching namespace (below)
+  ParallelBO._batch_arg_max_acquisition         -> fused_batch_arg_max_acquisition
+  bayes_optim.GaussianProcess, bayes_optim.surrogate.GaussianProcess -> a dispatching class that builds
+                                                   `bogp.GaussianProcess` (so `bayes_optim.fmin` -- which resolves the
+                                                   name at call time, `__init__.py:147-160` -- runs on the device)
 
-The last one is SURVEY.md row f1.  The reference maximises its q criteria one after the other (`bayes_opt.py:100-115`:
-q calls of `_argmax_restart`, i.e. q host samplings, q uploads and q posterior passes although the criteria differ only
-in t / alpha), de-duplicates afterwards (`BO.pre_eval_check`, `:27-55`) and pads what is left with random points
-(`base.py:282-289`).  The fused method draws the q parameters with the reference's own sampler IN THE SAME ORDER (so the
-global np.random stream advances exactly as in the reference), then makes ONE call of `optim.batch_argmax`: one candidate
-design, one posterior pass, q criteria, top-k per criterion; a criterion whose best candidate is already taken by an
-earlier criterion, or `np.isclose` to an evaluated point, falls back through its own top-k.  With any other inner
-optimiser ("BFGS", ...) the reference's method runs unchanged.
+The contract of install() is that NOTHING the reference could do before stops working afterwards:
+
+  * the acquisition namespace decides per model: `EI(model=<a bogp GaussianProcess>)` builds this package's criterion,
+    any other model (the reference's CPU GaussianProcess, RandomForest, ...) gets the reference's own class
+    (`acquisition_fun.py:107-310`); every other attribute of the namespace is the reference module's;
+  * `routed_argmax_restart` serves optimizer = "sweep", "sweep-device[-lhs|-sobol]", "sweep-BFGS" (and a rerouted
+    default "BFGS", see `install(reroute_bfgs=...)`) for this package's criteria; "BFGS" on a real space, constraints
+    under BFGS / "OnePlusOne_Cholesky_CMA" / "MIES", non-real spaces and criteria that are not this package's all go
+    to the saved original (`acquisition/optim/__init__.py:55-153`) -- our criteria are plain callables to it;
+  * the GaussianProcess name builds the reference's own class for configurations the device does not serve
+    (`optimizer="CMA"`, a callable correlation it does not know), with a warning.
+
+Row f1: the reference maximises its q criteria one after the other (`bayes_opt.py:100-115`: q calls of
+`_argmax_restart`, i.e. q host samplings, q uploads and q posterior passes although the criteria differ only in
+t / alpha), de-duplicates afterwards (`BO.pre_eval_check`, `:27-55`) and pads what is left with random points
+(`base.py:282-289`).  The fused method draws the q parameters with the reference's own sampler IN THE SAME ORDER (so
+the global np.random stream advances exactly as in the reference), then makes ONE call of `optim.batch_argmax`: one
+candidate design, one posterior pass, q criteria, top-k per criterion; a criterion whose best candidate is already
+taken by an earlier criterion, or `np.isclose` to an evaluated point, falls back through its own top-k.  With any
+other inner optimiser ("BFGS", ...) the reference's method runs unchanged.
 """
 from __future__ import annotations
 
+import warnings
 from copy import copy
 
 import numpy as np
 
 from . import acquisition, optim
+from .surrogate import GaussianProcess as _DeviceGP
 
 _SWEEPS = ("sweep",) + tuple(optim.DEVICE_DESIGNS)
+_OURS = _SWEEPS + ("sweep-BFGS",)  # inner optimisers only this package knows
+
+
+def is_device_model(model) -> bool:
+    """True for a surrogate whose posterior lives in a libbogp engine (this package's GaussianProcess or a subclass)."""
+    return isinstance(model, _DeviceGP)
 
 
 def _history_of(bo):
@@ -40,8 +63,11 @@ def fused_batch_arg_max_acquisition(self, n_point: int, return_dx: bool, fixed=N
     """Drop-in body for `ParallelBO._batch_arg_max_acquisition` (bayes_opt.py:100-115): same arguments, same
     `(candidates, values)` return (two q-tuples)."""
     optimizer, budget = _effective(getattr(self, "_optimizer", None), None)
-    if optimizer not in _SWEEPS:
+    kw = getattr(getattr(self, "_argmax_restart", None), "keywords", None) or {}  # bound by BaseBO.__set_argmax (base.py:231-243)
+    if optimizer not in _SWEEPS or not is_device_model(getattr(self, "model", None)) or not optim.is_continuous(kw.get("search_space")):
         return _ORIGINAL["batch"](self, n_point, return_dx, fixed)
+    if optimizer in optim.DEVICE_DESIGNS and (kw.get("h") is not None or kw.get("g") is not None or fixed):
+        return _ORIGINAL["batch"](self, n_point, return_dx, fixed)  # one criterion at a time through routed_argmax_restart
     wrapped = []
     for _ in range(n_point):  # bayes_opt.py:101-106 verbatim in effect: same draws, same order
         _par = self._sampler(self._acquisition_par)
@@ -55,13 +81,10 @@ def fused_batch_arg_max_acquisition(self, n_point: int, return_dx: bool, fixed=N
             return tuple(zip(*[list(self._argmax_restart(w, logger=self.logger)) for w in wrapped]))
         crits.append(c)
         masks, values = m, v
-    kw = self._argmax_restart.keywords  # bound by BaseBO.__set_argmax (base.py:231-243)
-    if kw.get("h") is not None or kw.get("g") is not None:
-        raise NotImplementedError("constraints are handled by the reference's penalised optimisers, not the sweep")
     design = optim.DEVICE_DESIGNS.get(optimizer)
     k = int(min(32, n_point + 8))  # fall-backs: at most n_point - 1 taken by earlier criteria + a few history hits
     xs, fs = optim.batch_argmax(crits, kw["search_space"], int(budget or kw["eval_budget"]), history=_history_of(self), k=k,
-                                design=design, masks=masks, values=values)  # fmt: skip
+                                design=design, masks=masks, values=values, h=kw.get("h"), g=kw.get("g"))  # fmt: skip
     return tuple(xs), tuple(fs)
 
 
@@ -78,50 +101,162 @@ def _effective(optimizer, eval_budget):
     return optimizer, eval_budget
 
 
-def _rerouting_argmax_restart(obj_func, search_space, h=None, g=None, eval_budget=100, n_restart=10, wait_iter=3,
-                              optimizer="BFGS", logger=None):
-    """`optim.argmax_restart` behind the reroute of `install(reroute_bfgs=...)`: constrained problems and criteria that are not
-    this package's keep the optimiser the caller asked for."""
-    opt2, budget2 = _effective(optimizer, eval_budget)
-    if opt2 != optimizer and (h is not None or g is not None or optim.unwrap_criterion(obj_func)[0] is None):
-        opt2, budget2 = optimizer, eval_budget
-    return optim.argmax_restart(obj_func, search_space, h=h, g=g, eval_budget=budget2, n_restart=n_restart, wait_iter=wait_iter,
-                                optimizer=opt2, logger=logger)
+def routed_argmax_restart(obj_func, search_space, h=None, g=None, eval_budget=100, n_restart=10, wait_iter=3,
+                          optimizer="BFGS", logger=None):
+    """`bayes_optim.base.argmax_restart` after `install()`.
+
+    This package's inner optimisers (the sweep family) are served by `optim.argmax_restart` when `obj_func` wraps one
+    of this package's criteria over a continuous space; every other call -- the reference's "BFGS" /
+    "OnePlusOne_Cholesky_CMA" / "MIES", constraints under them, mixed / integer / discrete spaces, foreign criteria or
+    models -- goes to the reference's own function with the arguments untouched (optim/__init__.py:55-153), for which a
+    bogp criterion is an ordinary callable.  A reroute (`install(reroute_bfgs=...)`) only ever applies to an
+    unconstrained "BFGS" call on a continuous space whose criterion is this package's."""
+    original = _ORIGINAL["argmax"]
+    mine = optim.unwrap_criterion(obj_func)[0] is not None and optim.is_continuous(search_space)
+    opt2, budget2 = optimizer, eval_budget
+    if mine and optimizer == "BFGS" and h is None and g is None:
+        opt2, budget2 = _effective(optimizer, eval_budget)
+    if mine and opt2 in _OURS:
+        return optim.argmax_restart(obj_func, search_space, h=h, g=g, eval_budget=budget2, n_restart=n_restart,
+                                    wait_iter=wait_iter, optimizer=opt2, logger=logger)  # fmt: skip
+    if optimizer in _OURS:  # asked for by name, but not servable: say why instead of a KeyError deep in the reference
+        raise TypeError("optimizer=%r needs one of this package's criteria (a bogp.GaussianProcess as model=) on a "
+                        "continuous search space" % optimizer)  # fmt: skip
+    return original(obj_func, search_space, h=h, g=g, eval_budget=eval_budget, n_restart=n_restart, wait_iter=wait_iter,
+                    optimizer=optimizer, logger=logger)  # fmt: skip
 
 
-def install(bayes_optim=None, fuse_batch: bool = True, reroute_bfgs: str = None, sweep_budget: int = 1_000_000):
+# ----------------------------------------------------------------------------------------------------------------------
+# per-model dispatch: one name, two implementations
+# ----------------------------------------------------------------------------------------------------------------------
+class _Dispatch(type):
+    """Metaclass of the names install() re-points: calling the class builds `_device` or `_host` (decided by
+    `_pick(args, kwargs)`), `isinstance` / `issubclass` accept instances of either, attribute look-ups that the
+    dispatching class does not define fall through to the device class and then the host class (so that
+    `hasattr(cls, "plugin")`, bayes_opt.py:21-23, answers as both originals do)."""
+
+    def __call__(cls, *args, **kwargs):
+        return cls._pick(args, kwargs)(*args, **kwargs)
+
+    def __instancecheck__(cls, obj):
+        return isinstance(obj, tuple(t for t in (cls._device, cls._host) if t is not None))
+
+    def __subclasscheck__(cls, sub):
+        return sub is cls or issubclass(sub, tuple(t for t in (cls._device, cls._host) if t is not None))
+
+    def __getattr__(cls, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        for t in (cls.__dict__.get("_device"), cls.__dict__.get("_host")):
+            if t is not None and hasattr(t, name):
+                return getattr(t, name)
+        raise AttributeError("%s has no attribute %r" % (cls.__name__, name))
+
+
+def _dispatching_criterion(name, device_cls, host_cls):
+    def _pick(args, kwargs):
+        model = kwargs.get("model", next((a for a in args if hasattr(a, "predict")), None))
+        if device_cls is not None and (is_device_model(model) or host_cls is None):
+            return device_cls
+        return host_cls
+
+    return _Dispatch(name, (), {"_device": device_cls, "_host": host_cls, "_pick": staticmethod(_pick),
+                                "__doc__": "dispatches on `model`: %s on a bogp.GaussianProcess, the reference's otherwise" % name})  # fmt: skip
+
+
+class _AcquisitionNamespace:
+    """Stands in for the module `bayes_optim.acquisition.acquisition_fun` under the name `AcquisitionFunction`
+    (`base.py:14,250,488`, `bayes_opt.py:8,21,96,187`, `extension.py:13,327`): criteria this package implements dispatch
+    per model, every other attribute is the reference module's own."""
+
+    def __init__(self, reference_module):
+        self._ref = reference_module
+        self._classes = {}
+        for name in ("EI", "PI", "EpsilonPI", "UCB", "MGFI"):
+            ours, theirs = getattr(acquisition, name, None), getattr(reference_module, name, None)
+            if ours is not None:
+                self._classes[name] = _dispatching_criterion(name, ours, theirs)
+
+    def __getattr__(self, name):
+        classes = self.__dict__.get("_classes", {})
+        if name in classes:
+            return classes[name]
+        return getattr(self.__dict__["_ref"], name)
+
+    def __dir__(self):
+        return sorted(set(dir(self._ref)) | set(self._classes))
+
+
+def _dispatching_surrogate(host_cls):
+    def _pick(args, kwargs):
+        try:  # validate on a throw-away instance: the constructor touches no device
+            _DeviceGP(*args, **kwargs)
+            return _DeviceGP
+        except NotImplementedError as e:
+            warnings.warn("bogp: this GaussianProcess configuration stays on the reference's CPU class (%s)" % e, stacklevel=3)
+            return host_cls
+
+    return _Dispatch("GaussianProcess", (), {"_device": _DeviceGP, "_host": host_cls, "_pick": staticmethod(_pick),
+                                             "__doc__": "bogp.GaussianProcess where the device serves the configuration, "
+                                                        "else bayes_optim's CPU class"})  # fmt: skip
+
+
+def install(bayes_optim=None, fuse_batch: bool = True, reroute_bfgs: str = None, sweep_budget: int = 1_000_000, surrogate: bool = True):
     """Re-point the reference's extension points at this package (see the module docstring).  `bayes_optim` is the
     imported reference package (default: `import bayes_optim`).  Returns `uninstall()`.  Idempotent.
+
+    `surrogate=True`: `bayes_optim.GaussianProcess` and `bayes_optim.surrogate.GaussianProcess` build
+    `bogp.GaussianProcess`, hence `bayes_optim.fmin(...)` fits, predicts and maximises on the device (the defining module
+    `bayes_optim.surrogate.gaussian_process` keeps the CPU class; names imported BEFORE install() keep what they had).
+
     `reroute_bfgs` = "sweep" | "sweep-device" | "sweep-device-lhs" | "sweep-device-sobol" | "sweep-BFGS": drivers constructed
     WITHOUT `acquisition_optimization` fall to the reference's default "BFGS" (one device round trip per point); with a
     reroute their inner maximisation becomes one sweep of `sweep_budget` candidates instead -- no change to the driver's
-    constructor call."""
+    constructor call.  Constrained problems, foreign models and non-real spaces are never rerouted."""
     if reroute_bfgs is not None:
-        if reroute_bfgs not in _SWEEPS + ("sweep-BFGS",):
-            raise ValueError("reroute_bfgs must be one of %s" % (_SWEEPS + ("sweep-BFGS",),))
+        if reroute_bfgs not in _OURS:
+            raise ValueError("reroute_bfgs must be one of %s" % (_OURS,))
         _REROUTE.update(optimizer=reroute_bfgs, budget=int(sweep_budget))
     if bayes_optim is None:
         import bayes_optim  # noqa: PLC0415
-    import bayes_optim.base as rbase
-    import bayes_optim.bayes_opt as ropt
+    import importlib
+
+    rbase = importlib.import_module(bayes_optim.__name__ + ".base")
+    ropt = importlib.import_module(bayes_optim.__name__ + ".bayes_opt")
+    racq = importlib.import_module(bayes_optim.__name__ + ".acquisition.acquisition_fun")
+    rsur = importlib.import_module(bayes_optim.__name__ + ".surrogate")
+    try:
+        rext = importlib.import_module(bayes_optim.__name__ + ".extension")
+    except Exception:  # optional module with heavier dependencies
+        rext = None
 
     if _ORIGINAL:
         return uninstall
-    _ORIGINAL.update(argmax=rbase.argmax_restart, acq_base=rbase.AcquisitionFunction, acq_opt=ropt.AcquisitionFunction,
-                     batch=ropt.ParallelBO._batch_arg_max_acquisition, mods=(rbase, ropt))  # fmt: skip
-    rbase.argmax_restart = _rerouting_argmax_restart
-    rbase.AcquisitionFunction = ropt.AcquisitionFunction = acquisition
+    holders = [m for m in (rbase, ropt, rext) if m is not None and getattr(m, "AcquisitionFunction", None) is racq]
+    _ORIGINAL.update(argmax=rbase.argmax_restart, acq_holders=holders, acq=racq, batch=ropt.ParallelBO._batch_arg_max_acquisition,
+                     mods=(bayes_optim, rbase, ropt, rsur), gp=(getattr(bayes_optim, "GaussianProcess", None), rsur.GaussianProcess),
+                     surrogate=bool(surrogate))  # fmt: skip
+    rbase.argmax_restart = routed_argmax_restart
+    ns = _AcquisitionNamespace(racq)
+    for m in holders:
+        m.AcquisitionFunction = ns
     if fuse_batch:
         ropt.ParallelBO._batch_arg_max_acquisition = fused_batch_arg_max_acquisition
+    if surrogate:
+        gp = _dispatching_surrogate(rsur.GaussianProcess)
+        bayes_optim.GaussianProcess = rsur.GaussianProcess = gp
     return uninstall
 
 
 def uninstall():
     if not _ORIGINAL:
         return
-    rbase, ropt = _ORIGINAL["mods"]
+    pkg, rbase, ropt, rsur = _ORIGINAL["mods"]
     rbase.argmax_restart = _ORIGINAL["argmax"]
-    rbase.AcquisitionFunction, ropt.AcquisitionFunction = _ORIGINAL["acq_base"], _ORIGINAL["acq_opt"]
+    for m in _ORIGINAL["acq_holders"]:
+        m.AcquisitionFunction = _ORIGINAL["acq"]
     ropt.ParallelBO._batch_arg_max_acquisition = _ORIGINAL["batch"]
+    if _ORIGINAL["surrogate"]:
+        pkg.GaussianProcess, rsur.GaussianProcess = _ORIGINAL["gp"]
     _ORIGINAL.clear()
     _REROUTE.clear()

@@ -102,6 +102,44 @@ def shard_bounds(M: int, rank: int, world: int):
     return (rank * M) // world, ((rank + 1) * M) // world
 
 
+def is_continuous(space) -> bool:
+    """True for the spaces the sweep and L-BFGS-B serve: a `Box`, the reference's `RealSpace` (recognised by class name
+    through the MRO -- `isinstance(search_space, RealSpace)` is the reference's own test, optim/__init__.py:71), or a
+    plain sequence of (lo, hi) pairs."""
+    if space is None:
+        return False
+    if isinstance(space, Box) or "RealSpace" in [c.__name__ for c in type(space).__mro__]:
+        return True
+    if any(c.__name__ == "SearchSpace" for c in type(space).__mro__):
+        return False
+    try:
+        return all(len(b) == 2 for b in space)
+    except TypeError:
+        return False
+
+
+def engine_rank_world(eng, group=None):
+    """(rank, world) a sweep shards by: the engine's own communicator when it has one (`bogp_comm_init` with an id that
+    travelled out of band, or `bogp_comm_attach`: no torch process group need exist), else the torch process group."""
+    if getattr(eng, "comm_world", 0):
+        return int(eng.comm_rank), int(eng.comm_world)
+    return distributed.rank_world(group)
+
+
+def feasible_rows(X: np.ndarray, h: Optional[Callable], g: Optional[Callable]) -> np.ndarray:
+    """Boolean mask of the rows of X the reference would ACCEPT as the outcome of a restart (optim/__init__.py:125-127):
+    |h(x)| within 1e-1 of zero for every equality constraint and g(x) <= 0 for every inequality constraint.  `h` / `g`
+    take one point as a list, like the wrappers `BaseBO` binds (base.py:224-229, 236-237)."""
+    keep = np.ones(len(X), dtype=bool)
+    for i in range(len(X)):
+        x = X[i].tolist()
+        if h is not None:
+            keep[i] = bool(np.all(np.isclose(np.abs(h(x)), 0, atol=1e-1)))
+        if keep[i] and g is not None:
+            keep[i] = bool(np.all(np.asarray(g(x)) <= 0))
+    return keep
+
+
 def candidate_block(bounds, M: int, seed: int, rank: int = 0, world: int = 1) -> np.ndarray:
     """This rank's block of M uniform candidates in the box: a deterministic function of (seed, rank, world)."""
     lo = np.array([b[0] for b in bounds], dtype=float)
@@ -195,7 +233,8 @@ def sweep_topk_generated(criteria: Sequence, bounds, M: int, k: int, seed: int, 
 
 def batch_argmax(criteria: Sequence, search_space, eval_budget: int, history: Optional[np.ndarray] = None, k: int = 8,
                  index_offset: Optional[int] = None, group=None, Xs: Optional[np.ndarray] = None, design: Optional[str] = None,
-                 seed: Optional[int] = None, rank: Optional[int] = None, world: Optional[int] = None, masks=None, values=None):
+                 seed: Optional[int] = None, rank: Optional[int] = None, world: Optional[int] = None, masks=None, values=None,
+                 h: Optional[Callable] = None, g: Optional[Callable] = None):
     """The q-point proposal of `ParallelBO._batch_arg_max_acquisition` (bayes_opt.py:100-115) in ONE posterior pass:
     q criteria (same model; they differ only in t / alpha) share (mu, MSE); each takes its best candidate that is
     neither already taken by an earlier criterion nor `np.isclose` to an evaluated point in `history`
@@ -205,17 +244,27 @@ def batch_argmax(criteria: Sequence, search_space, eval_budget: int, history: Op
     of ONE design); otherwise every rank sweeps its own host sample (`search_space.sample`, or `Xs`) and the union of the
     world x eval_budget points competes.  `masks` / `values` (ask(fixed=...), utils.py:184-213): `search_space` spans the
     free variables only, the fixed columns are filled in for the model, `history` holds full points, and the returned
-    points hold the free variables (the caller's `fillin_fixed_value` completes them, base.py:476)."""
+    points hold the free variables (the caller's `fillin_fixed_value` completes them, base.py:476).  `h` / `g` (constraints
+    over the free variables, one point as a list): only host-sampled candidates the reference would accept as a restart's
+    outcome (`feasible_rows`) enter the sweep; with none, `((), ())` -- the reference's "no feasible restart" answer."""
     if rank is None or world is None:
-        rank, world = distributed.rank_world(group)
+        rank, world = engine_rank_world(criteria[0].model.engine, group)
+    if int(eval_budget) < world:
+        raise ValueError("%d candidates cannot be sharded over %d ranks (every rank must own at least one)" % (eval_budget, world))
     if design is not None:  # "uniform" | "LHS" | "sobol": the candidates are drawn on the GPU(s) and never touch the host
-        if masks is not None:
-            raise NotImplementedError("device-generated designs take no fixed variables")
+        if masks is not None or h is not None or g is not None:
+            raise NotImplementedError("device-generated designs take neither fixed variables nor constraints")
         seed = int(np.random.randint(0, 2**62)) if seed is None else int(seed)
         vals, gidx, pts = sweep_topk_generated(criteria, search_space, int(eval_budget), k, seed, rank, world, group, design)
     else:
         if Xs is None:
             Xs = np.asarray(search_space.sample(int(eval_budget), method="uniform"), dtype=float)
+        if h is not None or g is not None:
+            if world > 1:
+                raise NotImplementedError("a constrained sweep runs on one rank (a shard without feasible rows cannot join the exchange)")
+            Xs = np.asarray(Xs, dtype=float)[feasible_rows(np.asarray(Xs, dtype=float), h, g)]
+            if len(Xs) == 0:
+                return (), ()
         full = np.asarray(Xs, dtype=float)
         if masks is not None:
             full = np.empty((len(Xs), len(masks)))
@@ -272,6 +321,17 @@ def unwrap_criterion(obj):
 DEVICE_DESIGNS = {"sweep-device": "uniform", "sweep-device-lhs": "LHS", "sweep-device-sobol": "sobol"}
 
 
+def _reference_argmax_restart():
+    """The reference's own `argmax_restart` when `bayes_optim` is importable in this process (it is whenever a reference
+    driver is the caller), read from its DEFINING module -- which no integration route re-points -- else None."""
+    try:
+        import importlib
+
+        return importlib.import_module("bayes_optim.acquisition.optim").argmax_restart
+    except Exception:
+        return None
+
+
 def argmax_restart(
     obj_func: Callable,
     search_space,
@@ -286,64 +346,73 @@ def argmax_restart(
     """Same signature and return convention as the reference's `argmax_restart` (optim/__init__.py:55-153).
 
     optimizer="sweep": `obj_func` must be one of this package's acquisition objects; `eval_budget` candidates are
-    drawn with `search_space.sample(N, "uniform")` and swept on the GPU.
+    drawn with `search_space.sample(N, "uniform")` and swept on the GPU.  With constraints `h` / `g`, only the sampled
+    candidates the reference would accept as a restart's outcome (`feasible_rows`) are swept; `([], [])` when there is none.
     optimizer="sweep-device" / "sweep-device-lhs" / "sweep-device-sobol": the candidates (uniform / Latin hypercube /
     Sobol') are generated on the GPU and never touch the host.
+    optimizer="sweep-BFGS": the sweep's best `n_restart` candidates are polished together on the device
+    (`polish_topk`: lock-step projected L-BFGS, one batched value + gradient call per iteration).
     optimizer="BFGS": the reference's multi-restart L-BFGS-B loop on `obj_func(x) -> (value, dx)` (host; every
     evaluation is one device call through the acquisition object).
+    Anything else ("MIES", "OnePlusOne_Cholesky_CMA", constraints under "BFGS", a non-continuous space) is the
+    reference's own business: the call is handed to its `argmax_restart` when `bayes_optim` is importable, for which a
+    bogp criterion is an ordinary callable; without the reference, NotImplementedError.
     """
+    ours = optimizer in DEVICE_DESIGNS or optimizer in ("sweep", "sweep-BFGS")
+    if not ours and (optimizer != "BFGS" or h is not None or g is not None or not is_continuous(search_space)):
+        ref = _reference_argmax_restart()
+        if ref is None:
+            raise NotImplementedError(
+                "optimizer %r / constraints / non-continuous spaces are served by the reference's own argmax_restart "
+                "(bayes_optim is not importable here); this package serves 'BFGS', 'sweep', 'sweep-device[-lhs|-sobol]' "
+                "and 'sweep-BFGS' on continuous spaces" % optimizer)  # fmt: skip
+        return ref(obj_func, search_space, h=h, g=g, eval_budget=eval_budget, n_restart=n_restart, wait_iter=wait_iter,
+                   optimizer=optimizer, logger=logger)  # fmt: skip
     if optimizer in DEVICE_DESIGNS:  # candidates drawn on the GPU; the stream is seeded from the global np.random
         crit, masks, _ = unwrap_criterion(obj_func)
         if crit is None or masks is not None or h is not None or g is not None:
             raise NotImplementedError("optimizer=%r takes an unconstrained bogp criterion without fixed variables" % optimizer)
-        best, _, xb = sweep_generated([crit], search_space, int(eval_budget), int(np.random.randint(0, 2**62)),
+        rank, world = engine_rank_world(crit.model.engine)
+        if int(eval_budget) < world:
+            raise ValueError("%d candidates cannot be sharded over %d ranks" % (eval_budget, world))
+        best, _, xb = sweep_generated([crit], search_space, int(eval_budget), int(np.random.randint(0, 2**62)), rank, world,
                                       method=DEVICE_DESIGNS[optimizer])  # fmt: skip
         return xb[0].tolist(), float(best[0])
-    if optimizer == "sweep":
-        if h is not None or g is not None:
-            raise NotImplementedError("constraints are handled by the reference's penalised optimisers, not the sweep")
+    if ours:  # "sweep" | "sweep-BFGS": host-sampled candidates
         crit, masks, values = unwrap_criterion(obj_func)
         if crit is None:
-            raise TypeError("optimizer='sweep' needs a bogp acquisition object (or the reference's wrapper around one)")
+            raise TypeError("optimizer=%r needs a bogp acquisition object (or the reference's wrapper around one)" % optimizer)
         Xs = np.asarray(search_space.sample(int(eval_budget), method="uniform"), dtype=float)
+        # Under a communicator / process group every rank sweeps ITS OWN draw of `eval_budget` candidates (the union is
+        # world x eval_budget points; global row = rank x eval_budget + local row) and the winner's POINT comes out of the
+        # exchange, so that every rank returns the same (xopt, fopt) whatever its local sample was.
+        rank, world = engine_rank_world(crit.model.engine)
+        if h is not None or g is not None:
+            if world > 1:
+                raise NotImplementedError("a constrained sweep runs on one rank (a shard without feasible rows cannot join the exchange)")
+            Xs = Xs[feasible_rows(Xs, h, g)]
+            if len(Xs) == 0:
+                return [], []  # what the reference returns when no restart ends feasible (optim/__init__.py:148-149)
         full = Xs
         if masks is not None:  # ask(fixed=...): the free columns are swept, the fixed ones are filled in
             full = np.empty((len(Xs), len(masks)))
             full[:, ~masks] = Xs
             full[:, masks] = np.asarray(values, dtype=float)
-        # Under an initialised process group every rank sweeps ITS OWN draw of `eval_budget` candidates (the union is
-        # world x eval_budget points; global row = rank x eval_budget + local row) and the winner's POINT comes out of the
-        # exchange, so that every rank returns the same (xopt, fopt) whatever its local sample was.
-        rank, world = distributed.rank_world()
-        best, _, xb = sweep_argmax([crit], full, index_offset=rank * len(full), return_points=True)
-        x = np.asarray(xb[0], dtype=float)
-        return (x[~masks] if masks is not None else x).tolist(), float(best[0])
-    starts = None
-    if optimizer == "sweep-BFGS":
-        # hybrid (SURVEY.md 8 f2): the sweep picks the n_restart most promising candidates, the reference's L-BFGS-B
-        # loop then polishes each of them instead of starting from uniform random points
-        crit, masks, _ = unwrap_criterion(obj_func)
-        if crit is None or masks is not None or h is not None or g is not None:
+        if optimizer == "sweep":
+            best, _, xb = sweep_argmax([crit], full, index_offset=rank * int(eval_budget), return_points=True)
+            x = np.asarray(xb[0], dtype=float)
+            return (x[~masks] if masks is not None else x).tolist(), float(best[0])
+        # hybrid (SURVEY.md 8 f2): the sweep picks the n_restart most promising candidates, which are then polished
+        if masks is not None or h is not None or g is not None:
             raise NotImplementedError("optimizer='sweep-BFGS' takes an unconstrained bogp criterion without fixed variables")
-        Xs = np.asarray(search_space.sample(int(eval_budget), method="uniform"), dtype=float)
         k = int(max(1, min(n_restart, 32, len(Xs))))
-        rank, world = distributed.rank_world()  # as above: per-rank draws, points travel with the exchange
-        tv, _, tx = sweep_topk([crit], Xs, k, index_offset=rank * len(Xs))
-        starts = [tx[0, r] for r in range(k) if np.isfinite(tv[0, r])]
-        n_restart, eval_budget, wait_iter = len(starts), 50 * len(starts), len(starts) + 1
-        obj_func, optimizer = crit, "BFGS"
-    if optimizer != "BFGS":
-        raise NotImplementedError(
-            "optimizer %r is out of scope here (SURVEY.md 2 rows 6-7); use 'BFGS', 'sweep', 'sweep-device[-lhs|-sobol]' or 'sweep-BFGS'" % optimizer
-        )
-    if h is not None or g is not None:
-        # the reference wraps the objective in Penalized(obj_func, h, g) and keeps a restart only if the constraints hold
-        # (optim/__init__.py:33-52, 125-140); that wrapper is out of scope, and returning constraint-violating points
-        # silently is worse than refusing
-        raise NotImplementedError("constraints (h, g) are handled by the reference's penalised optimisers, not here")
-    if not (isinstance(search_space, Box) or "RealSpace" in [c.__name__ for c in type(search_space).__mro__]):
-        # optim/__init__.py:71-73 reroutes every other space to MIES, which is out of scope here
-        raise NotImplementedError("optimizer='BFGS' needs a continuous space (RealSpace / Box); the reference reroutes others to MIES")
+        tv, _, tx = sweep_topk([crit], Xs, k, index_offset=rank * int(eval_budget))
+        ok = np.isfinite(tv[0])
+        if not ok.any():
+            return [], []
+        xp, fp = polish_topk(crit, tx[0][ok], np.array(search_space.bounds, dtype=float))
+        j = int(np.argmax(fp))
+        return xp[j].tolist(), float(fp[j])
 
     xopt, fopt = [], []
     best = -np.inf
@@ -358,12 +427,8 @@ def argmax_restart(
         return -1.0 * float(np.asarray(f, float).ravel()[0]), -1.0 * np.asarray(fg, float).ravel()
 
     for iteration in range(n_restart):
-        if starts is None:
-            x0 = np.asarray(search_space.sample(N=1, method="uniform")[0], dtype=float)
-        else:
-            x0 = np.asarray(starts[iteration], dtype=float)
-        maxfun = eval_budget if starts is None else 50
-        xopt_, fopt_, stop_dict = fmin_l_bfgs_b(neg, x0, pgtol=1e-8, factr=1e6, bounds=bounds, maxfun=maxfun)
+        x0 = np.asarray(search_space.sample(N=1, method="uniform")[0], dtype=float)
+        xopt_, fopt_, stop_dict = fmin_l_bfgs_b(neg, x0, pgtol=1e-8, factr=1e6, bounds=bounds, maxfun=eval_budget)
         xopt_ = xopt_.flatten().tolist()
         fopt_ = -float(fopt_)
         if fopt_ > best:
@@ -380,3 +445,22 @@ def argmax_restart(
         return [], []
     idx = np.argsort(fopt)[::-1]
     return xopt[idx[0]], fopt[idx[0]]
+
+
+def polish_topk(crit, starts: np.ndarray, bounds: np.ndarray, max_iter: int = 50, sequential: bool = False):
+    """Local refinement of `starts` (k, d) inside the box `bounds` (d, 2); returns (points (k, d), values (k,)) with
+    values[i] >= the criterion at starts[i].  Placeholder until the batched device call lands: one L-BFGS-B run per start
+    through the one-point call (the r02 behaviour)."""
+    xs, fs = [], []
+    for x0 in np.asarray(starts, dtype=float):
+        def neg(x):
+            f, fg = crit(np.asarray(x, dtype=float).reshape(1, -1), return_dx=True)
+            return -1.0 * float(np.asarray(f, float).ravel()[0]), -1.0 * np.asarray(fg, float).ravel()
+
+        f0 = -neg(x0)[0]
+        x1, f1, _ = fmin_l_bfgs_b(neg, x0, pgtol=1e-8, factr=1e6, bounds=bounds, maxfun=max_iter)
+        if -float(f1) >= f0:
+            xs.append(np.asarray(x1, dtype=float).ravel()), fs.append(-float(f1))
+        else:
+            xs.append(x0), fs.append(f0)
+    return np.array(xs), np.array(fs)

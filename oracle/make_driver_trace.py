@@ -1,6 +1,6 @@
 """G28: every engine call the REAL `bayes_optim.ParallelBO` makes during a short run, with its result (build container only).
 
-    python oracle/make_driver_trace.py      ->  tests/golden/G28_driver_trace.npz, G29_driver_trace_bfgs.npz
+    python oracle/make_driver_trace.py      ->  tests/golden/G28_driver_trace.npz, G29_driver_trace_bfgs.npz, G30_fmin_trace.npz
 
 VERDICT r01 (weak 4): the drop-in tests with the real drivers run on the oracle-backed engine stand-in (no GPU here), the GPU
 suite runs the device classes without the real drivers (no reference tree there) -- joined only by inspection.  This fixture
@@ -100,7 +100,43 @@ def trace_bo_bfgs():
     print("recorded %d engine calls: %s -> %s (%.1f KB)" % (len(index), kinds, out, os.path.getsize(out) / 1024))
 
 
+def trace_fmin():
+    """G30: `bayes_optim.fmin` itself after `bogp.install()`: fmin builds its model through the re-pointed
+    `GaussianProcess` name (Matern-3/2, ordinary kriging, nugget 1e-6), drives `BO` with EI and the reference's own BFGS loop
+    (delegated by `routed_argmax_restart`).  The inner budget is cut through fmin's **kwargs to keep the fixture small."""
+    engines = []
+
+    def engine(device=0):
+        engines.append(RecordingEngine())
+        return engines[-1]
+
+    saved = bogp._lib.Engine
+    bogp._lib.Engine = engine
+    undo = bogp.install(bayes_optim)
+    try:
+        f = lambda x: float(np.sum(np.asarray(x) ** 2))  # noqa: E731
+        xopt, fopt, n_iter, n_eval, _ = bayes_optim.fmin(f, [-5] * 2, [5] * 2, seed=42, max_FEs=13, verbose=False,
+                                                         acquisition_optimization={"max_FEs": 30, "n_restart": 2})  # fmt: skip
+    finally:
+        undo()
+        bogp._lib.Engine = saved
+    assert len(engines) == 1 and n_eval == 13
+    arrs = {}
+    index = [encode(c, arrs) for c in engines[0].calls]
+    arrs["index"] = np.array(json.dumps(index))
+    arrs["n_calls"] = np.array(len(index))
+    arrs["xopt"], arrs["fopt"] = np.asarray(xopt, dtype=float), np.asarray(fopt, dtype=float)
+    out = OUT.replace("G28_driver_trace", "G30_fmin_trace")
+    np.savez_compressed(out, **arrs)
+    kinds = {}
+    for c in engines[0].calls:
+        kinds[c["name"]] = kinds.get(c["name"], 0) + 1
+    print("recorded %d engine calls: %s -> %s (%.1f KB)" % (len(index), kinds, out, os.path.getsize(out) / 1024))
+
+
 def main():
+    if "--fmin-only" in sys.argv:
+        return trace_fmin()
     dim, q = 2, 3
     f = lambda x: float(np.sum(np.asarray(x) ** 2) + np.sin(3 * np.asarray(x)[0]))  # noqa: E731
     undo = bogp.install(bayes_optim)
@@ -132,6 +168,7 @@ def main():
         kinds[c["name"]] = kinds.get(c["name"], 0) + 1
     print("recorded %d engine calls: %s -> %s (%.1f KB)" % (len(index), kinds, OUT, os.path.getsize(OUT) / 1024))
     trace_bo_bfgs()
+    trace_fmin()
 
 
 if __name__ == "__main__":

@@ -279,11 +279,18 @@ def test_likelihood_calls_leave_the_fitted_model_alone():
     assert gp2._committed_par is None
 
 
-def test_bfgs_path_refuses_what_it_does_not_implement():
+def test_bfgs_path_hands_over_what_it_does_not_implement(monkeypatch):
     """optim/__init__.py:71-73, 125-140: constraints go through `Penalized` + a feasibility filter and non-continuous
-    spaces through MIES in the reference; both are out of scope and must not be silently ignored."""
+    spaces through MIES in the reference; both are the reference's business: handed to ITS `argmax_restart` when
+    `bayes_optim` is importable, refused -- never silently ignored -- when it is not."""
     box = optim.Box([(-1, 1)] * 2, random_seed=0)
     crit = lambda x: (0.0, np.zeros(2))  # noqa: E731
+    handed = []
+    monkeypatch.setattr(optim, "_reference_argmax_restart", lambda: (lambda *a, **kw: handed.append(kw) or ([0.0, 0.0], 1.0)))
+    assert optim.argmax_restart(crit, box, h=lambda x: [0.0], optimizer="BFGS", eval_budget=7) == ([0.0, 0.0], 1.0)
+    assert optim.argmax_restart(crit, box, optimizer="MIES", n_restart=2) == ([0.0, 0.0], 1.0)
+    assert [k["optimizer"] for k in handed] == ["BFGS", "MIES"] and handed[0]["eval_budget"] == 7 and handed[0]["h"] is not None
+    monkeypatch.setattr(optim, "_reference_argmax_restart", lambda: None)
     with pytest.raises(NotImplementedError, match="constraints"):
         optim.argmax_restart(crit, box, h=lambda x: [0.0], optimizer="BFGS")
     with pytest.raises(NotImplementedError, match="constraints"):
@@ -315,7 +322,7 @@ def test_value_only_kernels_refuse_fit_like_the_reference():
         gp._check_data(X, y)
 
 
-@pytest.mark.parametrize("fixture", ["G28_driver_trace", "G29_driver_trace_bfgs"])
+@pytest.mark.parametrize("fixture", ["G28_driver_trace", "G29_driver_trace_bfgs", "G30_fmin_trace"])
 def test_driver_trace_fixture_replays_on_the_oracle_engine(fixture):
     """G28 (oracle/make_driver_trace.py: every engine call of a real `ParallelBO` run with its answer) decodes, and the
     oracle-backed engine reproduces its own recorded answers bit for bit -- the CPU half of

@@ -1,0 +1,250 @@
+"""`bogp.install()` must not take anything away from the reference: the scenarios of the
+reference's own `unittest/test_fmin.py:9-28`, `unittest/test_constraint.py:31-90` and a CMA-inner-optimiser driver run
+UNDER install(), next to drivers whose model is the reference's CPU GaussianProcess / RandomForest.
+
+Build container only (`/root/reference` is absent on the GPU box); no GPU here, so the engine under `bogp.GaussianProcess`
+is the oracle-backed stand-in of tests/support/oracle_engine.py, injected by monkeypatching `bogp._lib.Engine`.  The device
+twin is `tests/test_gpu_driver.py::test_fmin_engine_trace_replays_on_the_device` (a recorded `fmin` engine trace)."""
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "bayes_optim")), reason="reference tree not present")
+
+
+@pytest.fixture()
+def installed(monkeypatch):
+    for p in (REF, os.path.join(ROOT, "oracle", "shims")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    warnings.filterwarnings("ignore")
+    import bayes_optim
+
+    import bogp
+    from support.oracle_engine import OracleEngine
+
+    created = []
+
+    class Recording(OracleEngine):
+        """remembers the size of every candidate upload (a sweep shows up as one upload of its budget)"""
+
+        def upload_candidates(self, Xs):
+            self.__dict__.setdefault("uploads", []).append(len(Xs))
+            return super().upload_candidates(Xs)
+
+    def engine(device=0):
+        created.append(Recording(device))
+        return created[-1]
+
+    monkeypatch.setattr(bogp._lib, "Engine", engine)
+    undo = bogp.install(bayes_optim)
+    yield bayes_optim, bogp, created
+    undo()
+
+
+def _criterion_behind(w):
+    """the acquisition object inside `partial_argument(functools.partial(criterion, return_dx=...))` (base.py:489-494)"""
+    import functools
+
+    for _ in range(8):
+        if isinstance(w, functools.partial):
+            w = w.func
+        elif hasattr(w, "__wrapped__"):
+            w = w.__wrapped__
+        else:
+            break
+    return w
+
+
+def _sphere(x):
+    x = np.asarray(x)
+    return np.sum(x**2)
+
+
+@pytest.mark.timeout(900)
+def test_fmin_runs_on_the_device_classes_after_install(installed):
+    """unittest/test_fmin.py:9-28 verbatim in effect; the model `fmin` builds is bogp's (so is its EI), the default inner
+    optimiser stays the reference's "BFGS" loop, now delegated to the reference's own function."""
+    bayes_optim, bogp, created = installed
+    seen = []
+    orig_fit = bogp.GaussianProcess.fit
+
+    def spy(self, X, y):
+        seen.append(type(self))
+        return orig_fit(self, X, y)
+
+    bogp.GaussianProcess.fit = spy
+    try:
+        minimum = bayes_optim.fmin(_sphere, [-5] * 2, [5] * 2, seed=42, max_FEs=30, verbose=False)
+    finally:
+        bogp.GaussianProcess.fit = orig_fit
+    assert len(minimum) == 5 and len(minimum[0]) == 2
+    assert minimum[3] == 30  # function evaluations
+    assert len(seen) == 21 and all(t is bogp.GaussianProcess for t in seen) and len(created) == 1
+    assert minimum[1] < 1.0  # 30 evaluations of a 2-d sphere: the BO loop did optimise
+
+    # warm starting (test_fmin.py:21-27)
+    X = np.random.rand(10, 2) * 10 - 5
+    y = [_sphere(x) for x in X]
+    minimum = bayes_optim.fmin(_sphere, [-5] * 2, [5] * 2, x0=X, y0=y, max_FEs=20, verbose=False)
+    assert minimum[2] == 20
+    minimum = bayes_optim.fmin(_sphere, [-5] * 2, [5] * 2, x0=X, max_FEs=5, verbose=False)
+    assert minimum[2] == 5
+
+
+@pytest.mark.timeout(900)
+def test_fmin_batch_mode_uses_the_fused_sweep(installed):
+    """fmin(n_point=3) -> ParallelBO(MGFI) on the device classes; with the default-BFGS reroute the three proposals of an
+    iteration come from one sweep."""
+    bayes_optim, bogp, created = installed
+    bogp.uninstall()
+    bogp.install(bayes_optim, reroute_bfgs="sweep", sweep_budget=2000)
+    minimum = bayes_optim.fmin(_sphere, [-5] * 2, [5] * 2, seed=1, max_FEs=19, n_point=3, verbose=False)
+    assert minimum[3] == 19 and len(created) == 1 and created[0].uploads.count(2000) == 3  # 3 asks after the DoE, one sweep each
+
+
+def _h(x):
+    return np.sum(x) - 1
+
+
+@pytest.mark.timeout(900)
+def test_equality_constrained_BO_after_install(installed):
+    """unittest/test_constraint.py:31-60 with the model built through the re-pointed name: BFGS + eq_fun -> the reference
+    switches to OnePlusOne_Cholesky_CMA (base.py:208-209), which install() must hand to the reference's own optimiser."""
+    bayes_optim, bogp, created = installed
+    from bayes_optim import BO, RealSpace
+    from bayes_optim.surrogate import GaussianProcess
+
+    dim = 2
+    thetaL, thetaU = 1e-5 * np.ones(dim), np.ones(dim)
+    np.random.seed(42)
+    theta0 = np.random.rand(dim) * (thetaU - thetaL) + thetaL
+    model = GaussianProcess(corr="squared_exponential", theta0=theta0, thetaL=thetaL, thetaU=thetaU, nugget=1e-1, random_state=42)
+    assert type(model) is bogp.GaussianProcess and isinstance(model, GaussianProcess)
+    opt = BO(search_space=RealSpace([0, 1]) * dim, obj_fun=lambda x: np.sum(np.array(x) ** 2) + 5 * np.sum(np.array(x)) + 10,
+             eq_fun=_h, model=model, max_FEs=12, DoE_size=3, acquisition_fun="MGFI", acquisition_par={"t": 2},
+             acquisition_optimization={"optimizer": "BFGS"}, verbose=False, random_seed=42)  # fmt: skip
+    assert opt._optimizer == "OnePlusOne_Cholesky_CMA"
+    xopt, _, __ = opt.run()
+    assert opt.eval_count == 12 and np.isclose(_h(xopt), 0, atol=1e-1)
+
+
+@pytest.mark.timeout(900)
+def test_equality_constrained_sweep(installed):
+    """The sweep with constraints: only sampled candidates the reference would accept (|h| <= 1e-1) compete."""
+    bayes_optim, bogp, created = installed
+    from bayes_optim import BO, ParallelBO, RealSpace
+
+    dim = 2
+    f = lambda x: float(np.sum(np.array(x) ** 2) + 5 * np.sum(np.array(x)) + 10)  # noqa: E731
+    gp = bogp.GaussianProcess(corr="squared_exponential", thetaL=1e-3 * np.ones(dim), thetaU=10 * np.ones(dim), nugget=1e-3, random_start=3)
+    opt = BO(search_space=RealSpace([0, 1]) * dim, obj_fun=f, eq_fun=_h, model=gp, max_FEs=10, DoE_size=4, acquisition_fun="EI",
+             acquisition_optimization={"optimizer": "sweep", "max_FEs": 3000}, verbose=False, random_seed=1)  # fmt: skip
+    X = opt.ask()
+    opt.tell(X, [f(x) for x in X])
+    for _ in range(3):
+        X = opt.ask()
+        assert len(X) == 1 and abs(_h(X[0])) <= 1e-1
+        opt.tell(X, [f(x) for x in X])
+    gp2 = bogp.GaussianProcess(corr="squared_exponential", thetaL=1e-3 * np.ones(dim), thetaU=10 * np.ones(dim), nugget=1e-3, random_start=3)
+    popt = ParallelBO(search_space=RealSpace([0, 1]) * dim, obj_fun=f, eq_fun=_h, model=gp2, max_FEs=20, DoE_size=5, n_point=3,
+                      acquisition_fun="MGFI", acquisition_par={"t": 2}, acquisition_optimization={"optimizer": "sweep", "max_FEs": 3000},
+                      verbose=False, random_seed=2)  # fmt: skip
+    X = popt.ask()
+    popt.tell(X, [f(x) for x in X])
+    X = popt.ask()
+    assert len(X) == 3 and all(abs(_h(x)) <= 1e-1 for x in X)
+
+
+@pytest.mark.timeout(900)
+def test_inequality_constraints_mixed_space_random_forest_after_install(installed):
+    """unittest/test_constraint.py:63-90: mixed space + RandomForest + ineq_fun -> MIES on the reference's own MGFI; none of
+    it is this package's business and all of it must still run."""
+    bayes_optim, bogp, created = installed
+    from bayes_optim import BO, IntegerSpace, RealSpace
+    from bayes_optim.surrogate import RandomForest
+
+    space = (IntegerSpace([1, 10], var_name="mu") + IntegerSpace([1, 10], var_name="lambda") + RealSpace([0, 1], var_name="pc")
+             + RealSpace([0.005, 0.5], var_name="p"))  # fmt: skip
+    g = lambda x: [-x["pc"], x["mu"] - 1.9]  # noqa: E731
+    opt = BO(search_space=space, obj_fun=lambda x: (x["pc"] - 0.2) ** 2 + x["mu"] + x["lambda"] + np.abs(x["p"] - 0.7), ineq_fun=g,
+             model=RandomForest(levels=space.levels), max_FEs=8, DoE_size=3, eval_type="dict", acquisition_fun="MGFI",
+             acquisition_par={"t": 2}, n_job=1, n_point=1, verbose=False, random_seed=42)  # fmt: skip
+    assert opt._optimizer == "MIES"
+    xopt, _, __ = opt.run()
+    assert isinstance(xopt, dict) and all(np.array(g(xopt)) <= 0) and not created
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("inner", ["OnePlusOne_Cholesky_CMA", "MIES"])
+def test_cma_and_mies_inner_optimisers_on_a_device_model(installed, inner):
+    bayes_optim, bogp, created = installed
+    from bayes_optim import BO, RealSpace
+
+    dim = 2
+    gp = bogp.GaussianProcess(mean=bogp.trend.constant_trend(dim), corr="matern", thetaL=[1e-2] * dim, thetaU=[1e2] * dim, nugget=1e-6,
+                              random_start=3, eval_budget=100)  # fmt: skip
+    opt = BO(search_space=RealSpace([-5, 5]) * dim, obj_fun=lambda x: float(_sphere(x)), model=gp, DoE_size=5, max_FEs=9, verbose=False,
+             n_point=1, acquisition_fun="EI", acquisition_optimization={"optimizer": inner, "max_FEs": 60, "n_restart": 2}, random_seed=5)  # fmt: skip
+    opt.run()
+    assert opt.eval_count == 9 and gp.is_fitted and type(_criterion_behind(opt._create_acquisition())).__module__.startswith("bogp")
+
+
+@pytest.mark.timeout(900)
+def test_reference_cpu_gp_as_model_after_install(installed):
+    """A driver whose model is the reference's own CPU GaussianProcess gets the reference's own EI (the namespace
+    dispatches per model) and its own BFGS loop -- the "model is not fitted yet" regression of r02."""
+    bayes_optim, bogp, created = installed
+    from bayes_optim import BO, RealSpace
+    from bayes_optim.surrogate.gaussian_process import GaussianProcess as CpuGP
+
+    dim = 2
+    new = lambda: CpuGP(mean=bayes_optim.trend.constant_trend(dim), corr="matern", thetaL=[1e-2] * dim, thetaU=[1e2] * dim,  # noqa: E731
+                        nugget=1e-6, random_start=3, eval_budget=100)  # fmt: skip
+    model = new()
+    opt = BO(search_space=RealSpace([-5, 5]) * dim, obj_fun=lambda x: float(_sphere(x)), model=model, DoE_size=5, max_FEs=9,
+             verbose=False, n_point=1, acquisition_fun="EI", random_seed=5)  # fmt: skip
+    opt.run()
+    crit = _criterion_behind(opt._create_acquisition())
+    assert opt.eval_count == 9 and type(crit).__module__.startswith("bayes_optim") and not created
+    import bayes_optim.base as rbase
+
+    assert isinstance(crit, rbase.AcquisitionFunction.EI) and hasattr(rbase.AcquisitionFunction.EI, "plugin")
+    assert not hasattr(rbase.AcquisitionFunction.UCB, "plugin") and rbase.AcquisitionFunction.norm is not None
+    with pytest.raises(TypeError):  # a sweep was asked for BY NAME on a model that has no engine
+        BO(search_space=RealSpace([-5, 5]) * dim, obj_fun=lambda x: float(_sphere(x)), model=new(), DoE_size=5, max_FEs=9, verbose=False,
+           acquisition_fun="EI", acquisition_optimization={"optimizer": "sweep", "max_FEs": 100}, random_seed=5).run()  # fmt: skip
+
+
+def test_unserved_gp_configuration_falls_back_to_the_cpu_class(installed):
+    bayes_optim, bogp, created = installed
+    from bayes_optim.surrogate.gaussian_process import GaussianProcess as CpuGP
+
+    with pytest.warns(UserWarning, match="stays on the reference's CPU class"):
+        gp = bayes_optim.GaussianProcess(corr="matern", thetaL=[1e-2] * 2, thetaU=[1e2] * 2, optimizer="CMA")
+    assert type(gp) is CpuGP and isinstance(gp, bayes_optim.GaussianProcess)
+    with pytest.raises(ValueError):  # genuine argument errors surface as they would without install()
+        bayes_optim.GaussianProcess(corr="matern", thetaL=[1e-2] * 2, thetaU=[1e2] * 3)
+
+
+def test_uninstall_restores_every_name(installed):
+    bayes_optim, bogp, created = installed
+    import bayes_optim.acquisition.acquisition_fun as racq
+    import bayes_optim.acquisition.optim as roptim
+    import bayes_optim.base as rbase
+    import bayes_optim.bayes_opt as ropt
+    from bayes_optim.surrogate.gaussian_process import GaussianProcess as CpuGP
+
+    assert rbase.argmax_restart is not roptim.argmax_restart and bayes_optim.GaussianProcess is not CpuGP
+    bogp.uninstall()
+    assert rbase.argmax_restart is roptim.argmax_restart
+    assert rbase.AcquisitionFunction is racq and ropt.AcquisitionFunction is racq
+    assert bayes_optim.GaussianProcess is CpuGP and bayes_optim.surrogate.GaussianProcess is CpuGP
+    bogp.install(bayes_optim, surrogate=False)
+    assert bayes_optim.GaussianProcess is CpuGP
