@@ -1,7 +1,11 @@
 """bench.py -- candidates/sec of the GP posterior + acquisition + argmax sweep on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]                      (N = 1)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no torch.distributed.run environment (RANK / WORLD_SIZE unset) the script launches its own N ranks
+(`launch_command`: one process per GPU on 127.0.0.1, a free port) and rank 0's JSON line is the last line of stdout,
+so `python bench.py --gpus 8` works the way `--gpus 1` does.
 
 A "step" is one pass of the hot path over one batch of synthetic candidates already resident in HBM: posterior
 (mu, MSE) of M candidates per GPU + q = 2 criteria (MGFI t=2, EI) + argmax, then the one cross-rank exchange of the
@@ -72,6 +76,40 @@ def measured_traffic(workload, n_per_launch):
     return float(p["traffic_bytes_per_launch"]), "committed PMC passes of commit %s (%s); not collected in this run" % (p.get("commit", "?"), PMC_FILE)
 
 
+def launch_command(n_gpus, argv, port=None):
+    """argv of the self-launch: `python -m torch.distributed.run` with one rank per GPU of this node, rendezvous on
+    127.0.0.1 (the container hostname may not resolve) at a free port, and bench.py's own arguments forwarded untouched."""
+    if port is None:
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)), "--master-addr", "127.0.0.1",
+            "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)  # fmt: skip
+
+
+def plumbing_check(args):
+    """`--plumbing-check` (CPU, gloo): what a rank sees after the (self-)launch -- its rank / world / local rank, that a
+    collective over the N ranks works, and the arguments as forwarded.  Rank 0 prints one JSON line.  Exercised by
+    tests/test_dist_gloo.py so that the first multi-GPU driver run cannot die in the launch plumbing."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" in os.environ:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        got = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(got, torch.tensor([rank, local], dtype=torch.int64))
+        ranks = [[int(v) for v in t] for t in got]
+        dist.destroy_process_group()
+    else:
+        ranks = [[0, 0]]
+    if rank == 0:
+        print(json.dumps({"plumbing": True, "n_gpus": world, "gpus_arg": args.gpus, "ranks": ranks, "steps": args.steps, "warmup": args.warmup,
+                          "workload": args.workload, "scaling": args.scaling, "master_addr": os.environ.get("MASTER_ADDR")}), flush=True)  # fmt: skip
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,7 +120,16 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: M candidates per GPU (default); strong: the workload's total (C3 1e6, C4 8e6, C5 4e6) split over the ranks")
+    ap.add_argument("--plumbing-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        import subprocess
+
+        sys.stdout.flush()
+        raise SystemExit(subprocess.call(launch_command(args.gpus, sys.argv[1:])))
+    if args.plumbing_check:
+        return plumbing_check(args)
 
     import torch
     import torch.distributed as dist
@@ -191,10 +238,12 @@ def main():
             tim[k] += lt[k]
     fence()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        each = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(each, torch.tensor([elapsed], dtype=torch.float64, device="cuda"))
+        per_rank_ms = [float(e.item()) / args.steps * 1e3 for e in each]
+        elapsed = max(float(e.item()) for e in each)  # MAX over ranks
 
     # PCIe-inclusive ask(): H2D of the shard + one step (noted, never `value`)
     h2d_ms = gen_ms = full_ms = None
@@ -248,6 +297,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_per_rank": per_rank_ms,
+            "rccl_world": int(eng.comm_world) if comm_error is None else (world if use_dist else 0),
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
