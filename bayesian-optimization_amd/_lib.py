@@ -17,6 +17,7 @@ KERNEL_SE, KERNEL_MATERN12, KERNEL_MATERN32, KERNEL_MATERN52, KERNEL_ABSEXP, KER
 MODE_NOISELESS, MODE_NOISY, MODE_NOISE_ESTIM = 0, 1, 2
 ACQ_EI, ACQ_EPSILON_PI, ACQ_UCB, ACQ_MGFI = 0, 1, 2, 3
 TREND_CONSTANT, TREND_LINEAR, TREND_QUADRATIC = 0, 1, 2
+ABI_VERSION = 4  # BOGP_ABI_VERSION of include/bogp.h this binding table was written for
 MAX_Q = 64
 MAX_TARGETS = 8
 COMM_ID_BYTES = 128
@@ -58,6 +59,9 @@ SIGNATURES = {
     "bogp_hessian": (C.c_int, [C.c_void_p, _dp, _dp]),
     "bogp_prior_corr": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp]),
     "bogp_point_eval": (C.c_int, [C.c_void_p, _dp, C.c_int, _ip, _dp, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "bogp_point_eval_batch": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _ip, _dp, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "bogp_polish": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double,
+                              C.c_double, _dp, _dp, _ip]),
     "bogp_comm_unique_id": (C.c_int, [C.c_char_p]),
     "bogp_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "bogp_comm_attach": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -107,6 +111,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI and this table drift apart
         fn.restype = res
         fn.argtypes = args
+    if lib.bogp_abi_version() != ABI_VERSION:
+        raise ImportError("libbogp.so is at ABI %d, this binding at %d: rebuild it (make -C %s)"
+                          % (lib.bogp_abi_version(), ABI_VERSION, os.path.join(os.path.dirname(LIB_PATH), "csrc")))
     _lib = lib
     return lib
 
@@ -449,21 +456,72 @@ class Engine:
 
     def point_eval(self, x, acq: Sequence[Tuple[int, float]] = (), plugin: float = 0.0, minimize: bool = True):
         """mu, mse, dmu (d,), dmse (d,), criterion values (q,) at ONE point with one device round trip
-        (bogp_point_eval: what `criterion(x, return_dx=True)` needs).  Constant trend basis."""
-        x = _f64(x).ravel()
-        if len(x) != self.d:
+        (bogp_point_eval: what `criterion(x, return_dx=True)` needs).  Constant trend basis.
+        This is the call the reference's L-BFGS-B loop makes thousands of times per ask(): the ctypes argument objects are
+        built once per (d, criteria) and re-used, so that the host side of a call is a few microseconds."""
+        key = (self.d, tuple(acq))
+        c = self.__dict__.get("_pe_cache")
+        if c is None or c[0] != key:
+            q = len(acq)
+            ids = np.ascontiguousarray([a for a, _ in acq], dtype=np.int32)
+            pars = np.ascontiguousarray([p for _, p in acq], dtype=np.float64)
+            xb, out = np.empty(self.d), np.empty(2 + 2 * self.d + max(q, 1))
+            po = out.ctypes.data
+            c = (key, q, xb, out, ids, pars, _ptr(xb), ids.ctypes.data_as(_ip) if q else None, _ptr(pars) if q else None,
+                 C.cast(po, _dp), C.cast(po + 8, _dp), C.cast(po + 16, _dp), C.cast(po + 16 + 8 * self.d, _dp),
+                 C.cast(po + 16 + 16 * self.d, _dp) if q else None)  # fmt: skip
+            self._pe_cache = c
+        _, q, xb, out, _, _, px, pids, ppars, pmu, pmse, pdmu, pdmse, pvals = c
+        x = np.asarray(x, dtype=np.float64)
+        if x.size != self.d:
             raise Exception("x does not have the right size!")
-        q = len(acq)
+        xb[:] = x.ravel()
+        rc = self._lib.bogp_point_eval(self._h, px, q, pids, ppars, float(plugin), 1 if minimize else 0, pmu, pmse, pdmu, pdmse, pvals)
+        if rc:
+            self._check(rc)
+        d = self.d
+        return float(out[0]), float(out[1]), out[2 : 2 + d].copy(), out[2 + d : 2 + 2 * d].copy(), out[2 + 2 * d : 2 + 2 * d + q].copy()
+
+    def point_eval_batch(self, Xb, acq: Sequence[Tuple[int, float]] = (), plugin: float = 0.0, minimize: bool = True,
+                         return_dx: bool = True):
+        """(mu (B,), mse (B,), dmu (B, d), dmse (B, d), values (B, q), dvalues (B, q, d) or None) at the B rows of `Xb` in ONE
+        device round trip (bogp_point_eval_batch): the criteria's input-gradients are the reference's `return_dx` chain rule
+        evaluated on the device.  Constant trend basis."""
+        Xb = _f64(Xb)
+        if Xb.ndim != 2 or Xb.shape[1] != self.d:
+            raise Exception("x does not have the right size!")
+        B, q = Xb.shape[0], len(acq)
         ids = np.ascontiguousarray([a for a, _ in acq], dtype=np.int32)
         pars = np.ascontiguousarray([p for _, p in acq], dtype=np.float64)
-        mu, mse = C.c_double(), C.c_double()
-        dmu, dmse, vals = np.empty(self.d), np.empty(self.d), np.empty(max(q, 1))
+        mu, mse = np.empty(B), np.empty(B)
+        dmu, dmse = np.empty((B, self.d)), np.empty((B, self.d))
+        vals = np.empty((B, max(q, 1)))
+        dvals = np.empty((B, max(q, 1), self.d)) if (return_dx and q) else None
         self._check(
-            self._lib.bogp_point_eval(self._h, _ptr(x), q, ids.ctypes.data_as(_ip) if q else None, _ptr(pars) if q else None,
-                                      float(plugin), int(bool(minimize)), C.cast(C.byref(mu), _dp), C.cast(C.byref(mse), _dp),
-                                      _ptr(dmu), _ptr(dmse), _ptr(vals) if q else None)
+            self._lib.bogp_point_eval_batch(self._h, _ptr(Xb), B, q, ids.ctypes.data_as(_ip) if q else None, _ptr(pars) if q else None,
+                                            float(plugin), int(bool(minimize)), _ptr(mu), _ptr(mse), _ptr(dmu), _ptr(dmse),
+                                            _ptr(vals) if q else None, _ptr(dvals))
         )  # fmt: skip
-        return mu.value, mse.value, dmu, dmse, vals[:q]
+        return mu, mse, dmu, dmse, vals[:, :q], (dvals[:, :q] if dvals is not None else None)
+
+    def polish(self, X0, lo, hi, acq: Tuple[int, float], plugin: float = 0.0, minimize: bool = True, max_evals: int = 50,
+               pgtol: float = 1e-8, factr: float = 1e6):
+        """Lock-step multi-start local maximisation of one criterion inside the box (bogp_polish): (points (B, d), values (B,),
+        evaluations used (B,)); values[i] >= the criterion at X0[i]."""
+        X0 = _f64(X0)
+        if X0.ndim != 2 or X0.shape[1] != self.d:
+            raise Exception("x does not have the right size!")
+        lo, hi = _f64(lo).ravel(), _f64(hi).ravel()
+        if len(lo) != self.d or len(hi) != self.d:
+            raise ValueError("lo / hi must have d entries")
+        B = X0.shape[0]
+        Xo, fo, ne = np.empty((B, self.d)), np.empty(B), np.zeros(B, dtype=np.int32)
+        self._check(
+            self._lib.bogp_polish(self._h, _ptr(X0), B, _ptr(lo), _ptr(hi), int(acq[0]), float(acq[1]), float(plugin),
+                                  int(bool(minimize)), int(max_evals), float(pgtol), float(factr), _ptr(Xo), _ptr(fo),
+                                  ne.ctypes.data_as(_ip))
+        )  # fmt: skip
+        return Xo, fo, ne
 
     def hessian(self, x) -> np.ndarray:
         """(d, d) Hessian of the posterior mean at x (squared exponential; constant / linear trend)."""

@@ -20,7 +20,7 @@ using namespace bogp;
 
 static std::string g_create_error;
 
-extern "C" int bogp_abi_version(void) { return 3; }
+extern "C" int bogp_abi_version(void) { return BOGP_ABI_VERSION; }
 
 extern "C" const char* bogp_last_error(const bogp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -100,6 +100,7 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   comm_release(h);
+  point_release(h);
   free_train(h);
   (void)hipStreamSynchronize(h->stream2);
   dfree(h->dXs_owned); dfree(h->dss_part); dfree(h->dbounds); dfree(h->dsobol); dfree(h->dxform);
@@ -1399,6 +1400,8 @@ extern "C" int bogp_gradient(bogp_handle* h, const double* x, double* dmu, doubl
   hipStream_t st = h->stream;
   HIPCHK(h, hipSetDevice(h->device));
   const int pt = h->p;
+  if (pt == 1)  // constant basis: k_point_rhs + k_point_tri, no library call (kernels_point.hip)
+    return point_eval_host(h, "bogp_gradient", x, 1, 0, nullptr, nullptr, 0.0, 1, nullptr, nullptr, dmu, dmse, nullptr, nullptr);
   if (pt > 1 && h->trend == BOGP_TREND_QUADRATIC)
     FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_gradient: the quadratic trend has no Jacobian in the reference either (trend.py:138-139)");
   int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)N * (d + 2) + 4 * d + 8 + (size_t)pt * (d + 1));
@@ -1462,76 +1465,6 @@ extern "C" int bogp_gradient(bogp_handle* h, const double* x, double* dmu, doubl
   return BOGP_OK;
 }
 
-// Everything the reference's default inner optimiser asks for at ONE point -- criterion(x, return_dx=True) =
-// predict (gpr.py:486-510) + gradient (:537-576) + the closed form (acquisition_fun.py) -- in one call with one host
-// synchronisation: the intermediates of bogp_gradient (r, V r, V^T V r) also give mu = beta + r.gamma and
-// MSE = sigma2 (1 - |V r|^2 + u^2), and the q criteria run through the same k_acquisition as a sweep row.
-// Constant trend basis only (polynomial bases: BOGP_ERR_UNSUPPORTED, callers use the separate entry points).
-extern "C" int bogp_point_eval(bogp_handle* h, const double* x, int q, const int* acq_id, const double* acq_par, double plugin,
-                               int minimize, double* mu, double* mse, double* dmu, double* dmse, double* acq) {
-  if (!h) return BOGP_ERR_INVALID;
-  if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "bogp_point_eval: no committed model");
-  if (h->kernel == BOGP_KERNEL_CUBIC || h->kernel == BOGP_KERNEL_GENEXP) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_point_eval: the cubic correlation has no input-derivative (corr_dx leaves it undefined in the reference, gpr.py:655-658)");
-  if (!x || !mu || !mse || !dmu || !dmse) FAIL(h, BOGP_ERR_INVALID, "bogp_point_eval: null pointer");
-  if (q < 0 || q > BOGP_MAX_Q || (q > 0 && (!acq_id || !acq))) FAIL(h, BOGP_ERR_INVALID, "bogp_point_eval: 0 <= q <= %d with non-null acq_id / acq", BOGP_MAX_Q);
-  if (h->p > 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_point_eval: constant trend basis only (use bogp_predict + bogp_gradient)");
-  for (int i = 0; i < q; ++i) {
-    if (acq_id[i] < 0 || acq_id[i] > 3) FAIL(h, BOGP_ERR_INVALID, "unknown acquisition id %d", acq_id[i]);
-    const bool zero_ok = acq_id[i] == BOGP_ACQ_EPSILON_PI;
-    if (acq_id[i] != BOGP_ACQ_EI && (!acq_par || !(acq_par[i] > 0 || (zero_ok && acq_par[i] == 0))))
-      FAIL(h, BOGP_ERR_INVALID, "acquisition parameter %d must be > 0 (the reference asserts alpha/epsilon/t > 0)", i);
-  }
-  const int N = h->N, d = h->d;
-  hipStream_t st = h->stream;
-  HIPCHK(h, hipSetDevice(h->device));
-  int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)N * (d + 2) + 4 * d + 16 + BOGP_MAX_Q);
-  if (e) return e;
-  if ((e = ensure(h, &h->dblk_val, &h->blk_val_cap, (size_t)BOGP_MAX_Q * 2))) return e;
-  if ((e = ensure(h, &h->dblk_idx, &h->blk_idx_cap, (size_t)BOGP_MAX_Q * 2))) return e;
-  double* dr = h->dgrad_partial;      // N
-  double* drdx = dr + N;              // d x N (column k = dr/dx_k)
-  double* dz = drdx + (size_t)N * d;  // N
-  double* dx = dz + N;                // d
-  double* dout = dx + d;              // 3 d: gamma^T r_dx, z^T r_dx, w^T r_dx
-  double* dred = dout + 3 * d;        // r.gamma, r.w, |V r|^2, mu, mse
-  double* dacq = dred + 8;            // q
-  HIPCHK(h, hipMemcpyAsync(dx, x, d * sizeof(double), hipMemcpyHostToDevice, st));
-  HIPCHK(h, launch_point_corr(h->kernel, h->dX, N, d, h->dtheta, dx, dr, drdx, st));
-  HIPCHK(h, hipMemcpyAsync(dz, dr, N * sizeof(double), hipMemcpyDeviceToDevice, st));
-  BLASCHK(h, rocblas_dtrmv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, h->dV, h->ldr, dz, 1));
-  HIPCHK(h, launch_col_reduce(dr, dz, N, 1, h->dgamma, h->dw, dred, dred + 1, dred + 2, st));  // before dz becomes V^T V r
-  BLASCHK(h, rocblas_dtrmv(h->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, h->dV, h->ldr, dz, 1));
-  const double one = 1.0, zero = 0.0;
-  BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, h->dgamma, 1, &zero, dout, 1));
-  BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, dz, 1, &zero, dout + d, 1));
-  if (h->estimate_trend)
-    BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, h->dw, 1, &zero, dout + 2 * d, 1));
-  AcqArgs aa;
-  memset(&aa, 0, sizeof(aa));
-  aa.mu_part = dred; aa.w_part = dred + 1; aa.ss_part = dred + 2; aa.S = 1; aa.nJ = 1; aa.Mc = 1;
-  aa.mcount = 1; aa.m0 = 0; aa.beta = h->beta; aa.G = h->G; aa.estimate_trend = h->estimate_trend;
-  aa.sigma2 = h->sigma2; aa.mu_out = dred + 3; aa.mse_out = dred + 4;
-  aa.q = q;
-  for (int i = 0; i < q; ++i) { aa.acq_id[i] = acq_id[i]; aa.acq_par[i] = acq_par ? acq_par[i] : 0.0; }
-  aa.plugin = plugin; aa.minimize = minimize; aa.acq_out = q > 0 ? dacq : nullptr; aa.M = 1;
-  aa.blk_val = h->dblk_val; aa.blk_idx = h->dblk_idx; aa.blk_offset = 0; aa.nblk_total = 1;
-  HIPCHK(h, launch_acquisition(aa, st));
-  std::vector<double> out((size_t)3 * d + 8 + (q > 0 ? q : 0), 0.0);  // dout | dred | dacq are contiguous
-  HIPCHK(h, hipMemcpyAsync(out.data(), dout, out.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
-  const double wr = out[3 * d + 1];
-  *mu = out[3 * d + 3];
-  *mse = out[3 * d + 4];
-  for (int i = 0; i < q; ++i) acq[i] = out[3 * d + 8 + i];
-  for (int k = 0; k < d; ++k) {
-    dmu[k] = out[k];  // beta^T f_dx = 0 for the constant basis
-    double m = -1.0 * out[d + k];
-    if (h->estimate_trend) m += (wr - 1.0) * (1.0 / h->ftft) * out[2 * d + k];
-    dmse[k] = 2.0 * h->sigma2 * m;
-  }
-  return BOGP_OK;
-}
-
 // Hessian of the posterior mean at x (GaussianProcess.Hessian, gpr.py:578-598): f_dx2 . beta + r_dx2 . gamma.  The trend
 // part is zero for the constant and linear bases (trend.py:88-91, 113-116; the quadratic one raises); the correlation part
 // exists for the squared exponential only (corr_Hessian, :663-734, leaves H undefined for every other kernel).
@@ -1578,46 +1511,3 @@ extern "C" int bogp_prior_corr(bogp_handle* h, const double* X1, int n1, double*
   HIPCHK(h, hipStreamSynchronize(st));
   return BOGP_OK;
 }
-
-// Batched flavour: B points, one pair of triangular solves with B right-hand sides
-// (rocBLAS dtrsm = the reference's solve_triangular twice) and one reduction kernel; dmu, dmse are B x d row-major.
-extern "C" int bogp_gradient_batch(bogp_handle* h, const double* Xb, int B, double* dmu, double* dmse) {
-  if (!h) return BOGP_ERR_INVALID;
-  if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "bogp_gradient_batch: no committed model");
-  if (h->kernel == BOGP_KERNEL_CUBIC || h->kernel == BOGP_KERNEL_GENEXP) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_gradient_batch: the cubic correlation has no input-derivative (corr_dx leaves it undefined in the reference, gpr.py:655-658)");
-  if (!Xb || !dmu || !dmse || B <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_gradient_batch: null pointer or B <= 0");
-  if (h->p > 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_gradient_batch: polynomial trends (p = %d) are served by bogp_gradient only", h->p);
-  const int N = h->N, d = h->d;
-  hipStream_t st = h->stream;
-  HIPCHK(h, hipSetDevice(h->device));
-  const size_t nout = (size_t)B * (3 * d + 1);
-  int e = ensure(h, &h->dbatch, &h->batch_cap, (size_t)3 * N * B + (size_t)B * d + nout);
-  if (e) return e;
-  double* dr = h->dbatch;               // N x B (column b = r of point b)
-  double* ds2 = dr + (size_t)N * B;     // N x B
-  double* dZ = ds2 + (size_t)N * B;     // N x B
-  double* dXb = dZ + (size_t)N * B;     // B x d
-  double* dout = dXb + (size_t)B * d;   // B x (3d + 1)
-  HIPCHK(h, hipMemcpyAsync(dXb, Xb, (size_t)B * d * sizeof(double), hipMemcpyHostToDevice, st));
-  HIPCHK(h, launch_batch_corr(h->kernel, h->dX, N, d, h->dtheta, dXb, B, dr, ds2, st));
-  HIPCHK(h, hipMemcpyAsync(dZ, dr, (size_t)N * B * sizeof(double), hipMemcpyDeviceToDevice, st));
-  const double one = 1.0;
-  BLASCHK(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, B, &one, h->dR, h->ldr, dZ, N));
-  BLASCHK(h, rocblas_dtrsm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, B, &one, h->dR, h->ldr, dZ, N));
-  HIPCHK(h, launch_batch_grad(h->kernel, h->dX, N, d, h->dtheta, dXb, B, dr, ds2, dZ, h->dgamma, h->dw, dout, st));
-  std::vector<double> out(nout);
-  HIPCHK(h, hipMemcpyAsync(out.data(), dout, nout * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
-  for (int b = 0; b < B; ++b) {
-    const double* o = &out[(size_t)b * (3 * d + 1)];
-    const double wr = o[3 * d];
-    for (int k = 0; k < d; ++k) {
-      dmu[(size_t)b * d + k] = o[k];
-      double m = -1.0 * o[d + k];
-      if (h->estimate_trend) m += (wr - 1.0) * (1.0 / h->ftft) * o[2 * d + k];
-      dmse[(size_t)b * d + k] = 2.0 * h->sigma2 * m;
-    }
-  }
-  return BOGP_OK;
-}
-

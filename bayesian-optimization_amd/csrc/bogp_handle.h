@@ -13,7 +13,12 @@
 
 struct bogp_handle;
 namespace bogp {
-void comm_release(bogp_handle* h);  // bogp_comm.hip: destroys an owned communicator, frees the exchange buffers
+void comm_release(bogp_handle* h);   // bogp_comm.hip: destroys an owned communicator, frees the exchange buffers
+void point_release(bogp_handle* h);  // bogp_point.hip: frees the point-evaluation buffers
+// bogp_point.hip: posterior, input-gradients and q criteria of B points through k_point_rhs + k_point_tri.  `Xb` is a HOST
+// array (B x d).  Outputs (host, any may be null): mu, mse (B), dmu, dmse (B x d), acq (B x q), dacq (B x q x d).
+int point_eval_host(bogp_handle* h, const char* who, const double* Xb, int B, int q, const int* acq_id, const double* acq_par,
+                    double plugin, int minimize, double* mu, double* mse, double* dmu, double* dmse, double* acq, double* dacq);
 }
 
 struct bogp_handle {
@@ -108,6 +113,18 @@ struct bogp_handle {
   double *dxchg_send = nullptr, *dxchg_recv = nullptr;
   size_t xchg_send_cap = 0, xchg_recv_cap = 0;
   int last_q = 0, last_topk_q = 0, last_topk_k = 0;
+
+  // one-point / B-point evaluation and the lock-step polish (kernels_point.hip, bogp_point.hip)
+  double *dpt_rhs = nullptr, *dpt_part = nullptr, *dpt_out = nullptr, *dpt_Xb = nullptr, *dpt_state = nullptr, *dpt_box = nullptr;
+  size_t pt_rhs_cap = 0, pt_part_cap = 0, pt_out_cap = 0, pt_Xb_cap = 0, pt_state_cap = 0, pt_box_cap = 0;
+  unsigned int* dpt_counter = nullptr;  // [cap] arrival tickets (zero between launches) + 1 word: finished starts of the polish
+  size_t pt_counter_cap = 0;
+  double* dpt_split = nullptr;  // partial tiles of split row blocks (one-point latency mode of k_point_tri)
+  unsigned int* dpt_splitc = nullptr;
+  size_t pt_split_cap = 0, pt_splitc_cap = 0;
+  double* hpin = nullptr;  // pinned host buffer the finishing workgroup writes its records into (device-mapped)
+  double* hpin_dev = nullptr;
+  size_t hpin_cap = 0;
 
   // timing of the last sweep/predict
   std::vector<hipEvent_t> ev;

@@ -177,4 +177,51 @@ hipError_t launch_batch_grad(int kernel, const double* X, int N, int d, const do
                              const double* r, const double* s2, const double* Z, const double* gamma,
                              const double* wvec, double* out, hipStream_t st);
 
+
+// ---- one-point / B-point evaluation and the lock-step polish (kernels_point.hip) -------------------------------------
+constexpr int BOGP_POINT_MAX_D = 320;   // = BOGP_MAX_DIM: input dimensions the finishing workgroup stages in LDS
+constexpr int BOGP_POINT_ARG_D = 64;    // a single point of at most this many dimensions travels as a kernel argument
+constexpr int POLISH_M = 8;             // curvature pairs of the lock-step L-BFGS
+struct PointRhsArgs {
+  const double* X;      // N x d training points, row-major
+  const double* theta;  // d
+  const double* Xb;     // B x d points (device), or null: ONE point in `x`
+  double x[BOGP_POINT_ARG_D];
+  double* rhs;          // [B][npass][Npp][NC]
+  int N, d, Npp, npass;
+};
+struct PointTriArgs {
+  const double* V;      // L^-1, column-major, leading dimension ld, exact zeros above the diagonal
+  const double* gamma;  // Np
+  const double* wvec;   // Np (zeros under simple kriging)
+  const double* rhs;
+  double* part;         // [B][npass][nRB + 1][2 NC] block records
+  double* split_scratch;        // [B][npass][nRB + 1][nsplit][rb x NC] partial tiles of a split row block (nsplit > 1)
+  unsigned int* split_counter;  // [B][npass][nRB + 1] arrival tickets of the splits, zero between launches
+  int rb, nsplit;               // rows of V per workgroup (16 / 32 / 64); workgroups per row block
+  unsigned int* counter;  // [B] arrival tickets, zero between launches
+  double* out;          // [B][rec_stride]: mu, mse, acq (q), dmu (d), dmse (d), dacq (q x d)
+  int ld, Npp, Nr32, nRB, npass, d;
+  int rec_stride, q, want_dacq, estimate_trend, minimize;
+  int acq_id[64];
+  double acq_par[64];
+  double plugin, beta, G, ftft, sigma2;
+};
+struct PolishArgs {
+  double* state;        // [B][state_stride]
+  const double* rec;    // the records k_point_tri wrote for the current trial points
+  double* Xt;           // [B][d] trial points (read: the evaluated ones; written: the next ones)
+  const double *lo, *hi;  // d each
+  unsigned int* n_done;
+  int d, q, rec_stride, state_stride, max_evals;
+  double pgtol, factr_eps, first_step;
+};
+int point_columns_per_pass(int d);
+int point_passes(int d);
+void point_tri_geometry(int N, int d, int B, int* rb, int* nsplit);
+hipError_t launch_point_rhs(int kernel, const PointRhsArgs& a, int B, hipStream_t st);
+hipError_t launch_point_tri(const PointTriArgs& a, int B, hipStream_t st);
+size_t polish_state_doubles();
+hipError_t launch_polish_step(const PolishArgs& a, int B, hipStream_t st);
+
 }  // namespace bogp

@@ -1,0 +1,517 @@
+// kernels_point.hip -- the ONE-POINT (and B-point) consumption path of the reference's inner optimisers.
+//
+// The reference maximises its acquisition function with L-BFGS-B on `criterion(x, return_dx=True)` one point per call
+// (acquisition/optim/__init__.py:74-153): predict (gpr.py:486-510) + gradient (:537-576, corr_dx :600-661) + the closed
+// form and its chain rule (acquisition_fun.py:139-146, 181-188, 220-227, 292-309).  r02 served that call with
+// k_point_corr + two rocBLAS dtrmv + three dgemv + k_acquisition (177 us at N = 2048, the data movement is ~10 us).
+//
+// Here it is three launches for B >= 1 points, no library call:
+//
+//   k_point_rhs<KERNEL, NC>   one thread per training row n: r_n = corr(x, X_n) and dr_n/dx_k, written as the n-major
+//                             right-hand sides  rhs[b][pass][n][NC] = [ r_n | dr_n/dx_k for the pass's <= NC-1 dimensions ]
+//   k_point_tri<NC>           C = V rhs with V = L^-1 (column-major, lower): ONE pass over V serves all d + 1 columns,
+//                             because  (V^T V r) . dr/dx_k = (V r) . (V dr/dx_k)  -- no second triangular product, no
+//                             grid-wide dependency.  A workgroup owns 16 rows of V; lane = (row pair, 1 of 8 n-phases),
+//                             4 waves = 32 columns of V per step, 16-B loads (8 x 128-B segments per wave-load); FP64 VALU
+//                             FMAs against the rhs row of the lane's n (16-B loads, L1/L2 resident: 8 N NC bytes).  The
+//                             n-phases are folded by 3 shuffle steps, the waves through LDS in fixed order; the block
+//                             then forms  sum_rows C_0 C_c  (c = 0: |V r|^2; c = 1 + k: z . dr/dx_k).  One extra
+//                             workgroup treats (gamma, w) as two more rows: gamma . rhs_c and w . rhs_c.
+//   k_point_finish<NC>        one workgroup per point adds the block records in fixed order and finishes: mu, MSE
+//                             (gpr.py:490, 496-510), dmu, dMSE (:561-576), the q criteria (acq_value) and their
+//                             input-gradients -- one record per point.
+//   k_polish_step             lock-step projected L-BFGS over B starts: consumes the records of the
+//                             current trial points, accepts / backtracks per start, writes the next trial points.
+//
+// Work per point: N^2 (d + 1) / 2 FMAs + N (2 d + profile) for the rhs -- 4.4e7 at C3, FP64-VALU; V is read once
+// (4 N^2 bytes, L2 / MALL resident between calls): the call is bound by launch + synchronisation latency, not by either.
+// Everything is deterministic (no floating-point atomics): identical inputs give identical bits.
+#include <algorithm>
+#include <cstdlib>
+
+#include "bogp_device.h"
+#include "bogp_internal.h"
+
+namespace bogp {
+
+namespace {
+
+template <int KERNEL>
+__device__ __forceinline__ double point_dx_entry(double rv, double D, double e5, double theta_k, double diff) {
+  // d r / d x_k (corr_dx, gpr.py:600-661); the same expressions as k_point_corr (kernels_fit.hip)
+  if (KERNEL == BOGP_KERNEL_ABSEXP) return -1.0 * rv * theta_k * (diff > 0.0 ? 1.0 : (diff < 0.0 ? -1.0 : 0.0));
+  if (KERNEL == BOGP_KERNEL_SE) return -2 * rv * (theta_k * diff);
+  if (KERNEL == BOGP_KERNEL_MATERN32) return D > 0.0 ? (diff * theta_k / D) * (-3.0 * D * e5) : 0.0;
+  if (KERNEL == BOGP_KERNEL_MATERN52) return (-(5.0 / 3.0) * (1.0 + 2.23606797749979 * D) * e5) * (theta_k * diff);
+  return D > 0.0 ? -diff * theta_k / D * rv : 0.0;
+}
+
+// 64 training rows x 4 column slices per workgroup: every thread forms the weighted distance of its row (d terms, redundant
+// across the 4 slices -- cheaper than a shuffle), then its quarter of the row's NC entries for every pass.
+template <int KERNEL, int NC>
+__global__ __launch_bounds__(256) void k_point_rhs(PointRhsArgs a) {
+  constexpr int CPS = ((NC / 2 + 3) / 4) * 2;  // columns per slice (even: 16-B stores)
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  if (n >= a.Npp) return;
+  const int d = a.d;
+  const bool from_args = a.Xb == nullptr;  // one point, carried by the kernel arguments (no upload)
+#define XB(k) (from_args ? a.x[k] : a.Xb[(size_t)b * d + (k)])
+  double rv = 0.0, D = 0.0, e5 = 0.0;
+  const bool live = n < a.N;
+  if (live) {
+    double s2 = 0.0;
+    for (int k = 0; k < d; ++k) s2 += dist_term<KERNEL>(a.theta[k], fabs(XB(k) - a.X[(size_t)n * d + k]));
+    rv = corr_profile<KERNEL>(s2);
+    D = sqrt(s2);
+    if (KERNEL == BOGP_KERNEL_MATERN32) e5 = exp(-1.7320508075688772 * D);
+    if (KERNEL == BOGP_KERNEL_MATERN52) e5 = exp(-2.23606797749979 * D);
+  }
+  const int c0 = slice * CPS, c1 = min(NC, c0 + CPS);
+  for (int g = 0; g < a.npass; ++g) {
+    double* row = a.rhs + (((size_t)b * a.npass + g) * a.Npp + n) * NC;
+    for (int c = c0; c < c1; c += 2) {
+      double v[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int cc = c + i;
+        const int k = g * (NC - 1) + (cc - 1);
+        v[i] = cc == 0 ? rv : ((live && k < d) ? point_dx_entry<KERNEL>(rv, D, e5, a.theta[k], XB(k) - a.X[(size_t)n * d + k]) : 0.0);
+      }
+      *(double2*)(row + c) = make_double2(v[0], v[1]);
+    }
+  }
+#undef XB
+}
+
+// d acq / d x_k = a_dy * dy_k + a_dsd * dsd_k   (acquisition_fun.py:139-146, 181-188, 220-227, 292-309); the guards of
+// the reference return a zero gradient, its FloatingPointError path (np.errstate(all="raise")) likewise
+__device__ __forceinline__ void acq_grad_coef(int id, double par, double y, double sd, double plugin, double sigma2, double& a_dy,
+                                              double& a_dsd) {
+  a_dy = 0.0;
+  a_dsd = 0.0;
+  switch (id) {
+    case BOGP_ACQ_UCB:
+      a_dy = 1.0;
+      a_dsd = par;
+      return;
+    case BOGP_ACQ_EI: {
+      if (sd / sqrt(sigma2) < 1e-6) return;
+      const double z = (plugin - y) / sd;
+      a_dsd = norm_pdf(z);
+      a_dy = -ndtr(z);
+      return;
+    }
+    case BOGP_ACQ_EPSILON_PI: {
+      const double shrink = y > 0 ? 1 - par : 1 + par;
+      const double z = (plugin - shrink * y) / sd;
+      const double f = norm_pdf(z) / sd;
+      a_dy = -shrink * f;
+      a_dsd = -z * f;
+      return;
+    }
+    default: {  // MGFI
+      if (fabs(sd) <= 1e-8) return;
+      const double t = fmin(par, 22.36);
+      const double var = sd * sd;
+      const double z = (plugin - (y - t * var)) / sd;
+      const double scale = exp(t * (plugin + t * var / 2 - y - 1));
+      const double pdf = norm_pdf(z), cdf = ndtr(z);
+      const double c_dy = scale * (-pdf / sd - cdf * t);
+      const double c_dsd = scale * (pdf * (2.0 * t * sd - z) / sd + cdf * (t * t) * sd);
+      if (isfinite(c_dy) && isfinite(c_dsd) && isfinite(scale)) {
+        a_dy = c_dy;
+        a_dsd = c_dsd;
+      }
+      return;
+    }
+  }
+}
+
+// NC columns per pass.  A workgroup owns RB = 64 rows of V -- one row per lane, so that every lane of a wave works on the
+// SAME column n and the right-hand-side row of that column is a wave-uniform (scalar, SMEM) load: rhs values sit in SGPRs
+// and feed the FMAs as scalar operands, V arrives as one coalesced 512-B load per wave and column.  (The first version
+// gave each lane its own n and loaded the rhs row per lane: 8 lanes per address, so the L1 -> VGPR path moved every rhs
+// byte 8 times and bounded the kernel; profiles/r03_point_tri_ab.txt.)  The 4 waves take every 4th column; `nsplit` > 1
+// deals the columns to that many workgroups per row block as well (latency of ONE point: chains nsplit times shorter,
+// more waves per CU); their partial C tiles meet in a scratch slab and the last arriver of the row block (a per-row-block
+// ticket) adds them in fixed order -- still deterministic.  Few VGPRs (the accumulators: 2 NC) => 8 waves per SIMD.
+template <int NC>
+__global__ __launch_bounds__(256) void k_point_tri(const double* __restrict__ V, const double* __restrict__ gamma,
+                                                   const double* __restrict__ wvec, const double* __restrict__ rhs_all,
+                                                   PointTriArgs a) {
+  constexpr int RB = 64;
+  __shared__ double Cs[RB][NC];
+  __shared__ bool s_last;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = a.nsplit;
+  const int wg = blockIdx.x / S, sp = blockIdx.x - wg * S;
+  const int g = blockIdx.y, b = blockIdx.z;
+  const bool special = wg == 0;            // (gamma, w) as two extra rows; scheduled first, it is as long as the longest
+  const int j0 = special ? 0 : (a.nRB - wg) * RB;  // wg = 1 owns the LAST (longest) rows of V
+  const int nend = special ? a.Nr32 : min(j0 + RB, a.ld);  // columns [0, nend): V is exactly zero above its diagonal
+  const double* __restrict__ rhs = rhs_all + ((size_t)b * a.npass + g) * (size_t)a.Npp * NC;
+
+  double acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+  const double* __restrict__ vcol = V + j0 + lane;
+  if (special) {
+#pragma unroll 2
+    for (int n = 4 * sp + wv; n < nend; n += 4 * S) {
+      const double v = lane == 0 ? gamma[n] : (lane == 1 ? wvec[n] : 0.0);
+      const double* __restrict__ rr = rhs + (size_t)n * NC;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = __builtin_fma(v, rr[c], acc[c]);
+    }
+  } else {
+#pragma unroll 2
+    for (int n = 4 * sp + wv; n < nend; n += 4 * S) {
+      const double v = vcol[(size_t)n * a.ld];
+      const double* __restrict__ rr = rhs + (size_t)n * NC;  // wave-uniform: scalar loads, SGPR operands
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = __builtin_fma(v, rr[c], acc[c]);
+    }
+  }
+  // the 4 waves add their tiles in fixed order ((w0 + w1) + w2) + w3 in LDS
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (wv == w) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) Cs[lane][c] = w == 0 ? acc[c] : Cs[lane][c] + acc[c];
+    }
+    __syncthreads();
+  }
+  const size_t rb_slot = ((size_t)b * a.npass + g) * (a.nRB + 1) + wg;  // this row block of this pass of this point
+  if (S > 1) {
+    // the split's partial tile -> scratch; the last of the S splits adds them (s = 0 .. S-1) and carries on alone
+    double* mine = a.split_scratch + (rb_slot * S + sp) * (size_t)(RB * NC);
+    // write-through (sc1) stores drained by every storing wave, then ONE relaxed agent-scope ticket: no release fence
+    // (a `buffer_wbl2` per workgroup serialises on the XCD's L2: 1000 of them cost 130 us, profiles/r03_point_tri_ab.txt)
+    for (int t = tid; t < RB * NC; t += 256) __hip_atomic_store(mine + t, (&Cs[0][0])[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned int ticket = __hip_atomic_fetch_add(a.split_counter + rb_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = ticket == (unsigned int)S - 1;
+      if (s_last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(a.split_counter + rb_slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+      }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const double* all = a.split_scratch + rb_slot * S * (size_t)(RB * NC);
+    for (int t = tid; t < RB * NC; t += 256) {
+      double s = 0.0;
+#pragma unroll 4
+      for (int k = 0; k < S; ++k) s += __builtin_nontemporal_load(all + (size_t)k * (RB * NC) + t);
+      (&Cs[0][0])[t] = s;
+    }
+  }
+  __syncthreads();
+  // the block's record: [0][c] = sum_rows C_0 C_c (special: gamma . rhs_c), [1][c] = 0 (special: w . rhs_c)
+  double* rec = a.part + rb_slot * (2 * NC);
+  if (tid < NC) {
+    double r0, r1 = 0.0;
+    if (special) {
+      r0 = Cs[0][tid];
+      r1 = Cs[1][tid];
+    } else {
+      r0 = 0.0;
+#pragma unroll 8
+      for (int row = 0; row < RB; ++row) r0 = __builtin_fma(Cs[row][0], Cs[row][tid], r0);
+    }
+    rec[tid] = r0;
+    rec[NC + tid] = r1;
+  }
+}
+
+// One workgroup per point, after k_point_tri (stream order: no ticket, no fence): adds the row-block records in fixed order
+// and finishes the point -- mu, MSE (gpr.py:490, 496-510), dmu, dMSE (:561-576), the q criteria (acq_value) and their
+// input-gradients.  Its own kernel so that the erf / exp code of the criteria does not set the register budget of
+// k_point_tri's loop (132 -> 58 VGPRs: 8 waves per SIMD instead of 3).
+template <int NC>
+__global__ __launch_bounds__(256) void k_point_finish(PointTriArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.x;
+  __shared__ double fin[4][NC];
+  __shared__ double zdr[BOGP_POINT_MAX_D], gdr[BOGP_POINT_MAX_D], wdr[BOGP_POINT_MAX_D];
+  __shared__ double sc[4];  // |V r|^2, gamma . r, w . r
+  const int d = a.d;
+  for (int gg = 0; gg < a.npass; ++gg) {
+    const double* base = a.part + ((size_t)b * a.npass + gg) * (a.nRB + 1) * (2 * NC);
+    if (lane < NC) {
+      double s = 0.0;
+      for (int w2 = 1 + wv; w2 <= a.nRB; w2 += 4) s += base[(size_t)w2 * (2 * NC) + lane];
+      fin[wv][lane] = s;
+    }
+    __syncthreads();
+    if (tid < NC) {
+      const double tot = ((fin[0][tid] + fin[1][tid]) + fin[2][tid]) + fin[3][tid];
+      const double gv = base[tid], wv2 = base[NC + tid];
+      if (tid == 0) {
+        if (gg == 0) {
+          sc[0] = tot;
+          sc[1] = gv;
+          sc[2] = wv2;
+        }
+      } else {
+        const int k = gg * (NC - 1) + tid - 1;
+        if (k < d) {
+          zdr[k] = tot;
+          gdr[k] = gv;
+          wdr[k] = wv2;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // posterior of the point and its input-gradients (constant trend basis)
+  double mu, mse;
+  posterior_of_sums(sc[1], sc[2], sc[0], a.beta, a.G, a.estimate_trend, a.sigma2, mu, mse);
+  const double sign = a.minimize ? 1.0 : -1.0;
+  const double y = sign * mu, sd = sqrt(mse);
+  double* out = a.out + (size_t)b * a.rec_stride;  // [mu, mse, acq (q), dmu (d), dmse (d), dacq (q x d)]
+  const int q = a.q;
+  if (tid == 0) {
+    out[0] = mu;
+    out[1] = mse;
+  }
+  if (tid < q) out[2 + tid] = acq_value(a.acq_id[tid], a.acq_par[tid], y, sd, a.plugin, a.sigma2);
+  for (int k = tid; k < d; k += 256) {
+    const double dmu = gdr[k];  // beta^T f_dx = 0 for the constant basis (gpr.py:561)
+    double m = -1.0 * zdr[k];
+    if (a.estimate_trend) m += (sc[2] - 1.0) * (1.0 / a.ftft) * wdr[k];
+    const double dmse = 2.0 * a.sigma2 * m;  // gpr.py:573-576
+    out[2 + q + k] = dmu;
+    out[2 + q + d + k] = dmse;
+    if (a.want_dacq) {
+      const double dy = sign * dmu, dsd = dmse / (2.0 * sd);
+      for (int i = 0; i < q; ++i) {
+        double c_dy, c_dsd;
+        acq_grad_coef(a.acq_id[i], a.acq_par[i], y, sd, a.plugin, a.sigma2, c_dy, c_dsd);
+        // a zero coefficient is the reference's guard path (a zero gradient), whatever dsd is (0 / 0 at sd = 0)
+        const double t1 = c_dy != 0.0 ? c_dy * dy : 0.0, t2 = c_dsd != 0.0 ? c_dsd * dsd : 0.0;
+        out[2 + q + 2 * d + (size_t)i * d + k] = t1 + t2;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Lock-step projected L-BFGS (maximisation inside a box), one 64-thread block per start.  Every call consumes the record of
+// the start's current TRIAL point (criterion 0: value and input-gradient) and writes the next trial point:
+//   * Armijo test  f_t >= f + 1e-4 g . (x_t - x): accept (x, f, g <- trial; curvature pair into the history when
+//     s . y > 0; step length back to 1) or halve the step from the same x;
+//   * stop rules of scipy's L-BFGS-B as the reference configures it (pgtol = 1e-8 on the projected gradient, factr = 1e6
+//     on the relative improvement; optim/__init__.py:94-101), or 30 consecutive rejected trials, or max evaluations;
+//   * direction: two-loop recursion over the last POLISH_M pairs applied to the gradient with the coordinates that sit on
+//     a bound and point outward removed; not an ascent direction -> steepest ascent and the history is dropped.
+// A finished start keeps proposing its own x (the evaluation is wasted, the state never moves).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmax(v, shfl_xor_f64(v, m));
+  return v;
+}
+
+__global__ __launch_bounds__(64) void k_polish_step(PolishArgs a) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int d = a.d;  // d <= 64: one coordinate per lane
+  const bool on = lane < d;
+  double* st = a.state + (size_t)b * a.state_stride;
+  // state layout: [f, alpha, nhist, head, nfail, done, nevals, first] (8) | x (64) | g (64) | S (M x 64) | Y (M x 64) | rho (M)
+  double* sx = st + 8;
+  double* sg = sx + 64;
+  double* sS = sg + 64;
+  double* sY = sS + POLISH_M * 64;
+  double* srho = sY + POLISH_M * 64;
+  const double* rec = a.rec + (size_t)b * a.rec_stride;
+  const double ft = rec[2];                                           // criterion 0 at the trial point
+  const double gt = on ? rec[2 + a.q + 2 * d + lane] : 0.0;           // its gradient
+  const double xt = on ? a.Xt[(size_t)b * d + lane] : 0.0;
+  const double lo = on ? a.lo[lane] : 0.0, hi = on ? a.hi[lane] : 0.0;
+  double f = st[0], alpha = st[1];
+  int nhist = (int)st[2], head = (int)st[3], nfail = (int)st[4], done = (int)st[5], nevals = (int)st[6];
+  const int first = (int)st[7];
+  double x = on ? sx[lane] : 0.0, gcur = on ? sg[lane] : 0.0;
+  if (done) return;  // the trial buffer already holds x
+  nevals += 1;
+  bool accepted = false;
+  if (first) {
+    x = xt;
+    gcur = gt;
+    f = ft;
+    accepted = true;
+    if (!(ft == ft) || !isfinite(ft)) done = 1;  // nothing to climb from
+  } else {
+    const double slope = wave_sum(gcur * (xt - x));
+    const bool finite = (ft == ft) && isfinite(ft) && isfinite(wave_sum(fabs(gt)));
+    if (finite && ft >= f + 1e-4 * slope && ft > f) {
+      const double s = xt - x, yv = gcur - gt;  // pair of the equivalent minimisation of -f
+      const double sy = wave_sum(s * yv), yy = wave_sum(yv * yv);
+      if (sy > 2.2e-16 * yy) {
+        if (on) {
+          sS[head * 64 + lane] = s;
+          sY[head * 64 + lane] = yv;
+        }
+        if (lane == 0) srho[head] = 1.0 / sy;
+        head = (head + 1) % POLISH_M;
+        nhist = nhist < POLISH_M ? nhist + 1 : POLISH_M;
+      }
+      const double gain = ft - f;
+      const double scale_f = fmax(fmax(fabs(f), fabs(ft)), 1.0);
+      x = xt;
+      gcur = gt;
+      f = ft;
+      alpha = 1.0;
+      nfail = 0;
+      accepted = true;
+      if (gain <= a.factr_eps * scale_f) done = 1;  // scipy: (f_k - f_{k+1}) / max(|f_k|, |f_{k+1}|, 1) <= factr * eps
+    } else {
+      alpha *= 0.5;
+      nfail += 1;
+      if (nfail >= 30) done = 1;
+    }
+  }
+  if (accepted && !done) {
+    const double pg = on ? fmin(fmax(x + gcur, lo), hi) - x : 0.0;  // projected gradient of the ascent
+    if (wave_max(fabs(pg)) < a.pgtol) done = 1;
+  }
+  if (nevals >= a.max_evals) done = 1;
+  // next trial point
+  double xn = x;
+  if (!done) {
+    __syncthreads();  // history written above is read below (one wave: a compiler barrier is all this is)
+    const bool blocked = on && ((x <= lo && gcur < 0.0) || (x >= hi && gcur > 0.0));
+    const double gf = (on && !blocked) ? gcur : 0.0;
+    double p = gf;
+    const double gnorm = sqrt(wave_sum(gf * gf));
+    if (nhist > 0) {
+      double qv = gf;
+      double al[POLISH_M];
+#pragma unroll
+      for (int i = 0; i < POLISH_M; ++i) {
+        al[i] = 0.0;
+        if (i < nhist) {
+          const int h = (head - 1 - i + 2 * POLISH_M) % POLISH_M;
+          al[i] = srho[h] * wave_sum((on ? sS[h * 64 + lane] : 0.0) * qv);
+          qv -= al[i] * (on ? sY[h * 64 + lane] : 0.0);
+        }
+      }
+      const int hl = (head - 1 + POLISH_M) % POLISH_M;
+      const double yl = on ? sY[hl * 64 + lane] : 0.0;
+      const double gam = 1.0 / (srho[hl] * wave_sum(yl * yl));
+      qv *= gam;
+#pragma unroll
+      for (int i = POLISH_M - 1; i >= 0; --i) {
+        if (i < nhist) {
+          const int h = (head - 1 - i + 2 * POLISH_M) % POLISH_M;
+          const double be = srho[h] * wave_sum((on ? sY[h * 64 + lane] : 0.0) * qv);
+          qv += (al[i] - be) * (on ? sS[h * 64 + lane] : 0.0);
+        }
+      }
+      p = blocked ? 0.0 : qv;
+      const double asc = wave_sum(p * gf);
+      if (!(asc > 0.0) || !isfinite(asc)) {  // not an ascent direction: steepest ascent, history dropped
+        p = gf;
+        nhist = 0;
+        head = 0;
+      }
+    }
+    if (nhist == 0 && gnorm > 0.0) p = gf * (a.first_step / gnorm);  // first move: a fixed length along the gradient
+    xn = on ? fmin(fmax(x + alpha * p, lo), hi) : 0.0;
+    if (wave_max(fabs(xn - x)) == 0.0) done = 1;  // the step no longer moves any coordinate
+  }
+  if (done) xn = x;
+  if (on) {
+    sx[lane] = x;
+    sg[lane] = gcur;
+    a.Xt[(size_t)b * d + lane] = xn;
+  }
+  if (lane == 0) {
+    st[0] = f;
+    st[1] = alpha;
+    st[2] = (double)nhist;
+    st[3] = (double)head;
+    st[4] = (double)nfail;
+    st[5] = (double)done;
+    st[6] = (double)nevals;
+    st[7] = 0.0;
+    if (done) atomicAdd(a.n_done, 1u);
+  }
+}
+
+}  // namespace
+
+int point_columns_per_pass(int d) {
+  static const int forced = [] {
+    const char* e = getenv("BOGP_POINT_NC");  // A/B switch (profiles/r03_point_tri_ab.txt)
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 12 || forced == 22) return forced;
+  return d + 1 <= 12 ? 12 : 22;
+}
+int point_passes(int d) {
+  const int nc = point_columns_per_pass(d);
+  return (d + nc - 2) / (nc - 1);
+}
+
+hipError_t launch_point_rhs(int kernel, const PointRhsArgs& a, int B, hipStream_t st) {
+  dim3 grid((a.Npp + 63) / 64, B);
+  const int nc = point_columns_per_pass(a.d);
+#define CALL(K)                                                                  \
+  if (nc == 12) hipLaunchKernelGGL((k_point_rhs<K, 12>), grid, 256, 0, st, a);    \
+  else hipLaunchKernelGGL((k_point_rhs<K, 22>), grid, 256, 0, st, a)
+  switch (kernel) {
+    case BOGP_KERNEL_SE: CALL(BOGP_KERNEL_SE); break;
+    case BOGP_KERNEL_MATERN12: CALL(BOGP_KERNEL_MATERN12); break;
+    case BOGP_KERNEL_MATERN32: CALL(BOGP_KERNEL_MATERN32); break;
+    case BOGP_KERNEL_ABSEXP: CALL(BOGP_KERNEL_ABSEXP); break;
+    default: CALL(BOGP_KERNEL_MATERN52); break;
+  }
+#undef CALL
+  return hipGetLastError();
+}
+
+// splits of a 64-row block for B points.  Measured at C3 size (profiles/r03_point_tri_ab.txt): the loop is a chain of
+// dependent (scalar load -> FMA) steps, so shorter chains win well beyond the point where the row blocks alone fill the
+// chip -- 16 splits for one point (47 vs 168 us unsplit), 8 for 8 points, 4 from 32 points up (179 vs 283 us at B = 32).
+void point_tri_geometry(int N, int d, int B, int* rb, int* nsplit) {
+  const int npass = point_passes(d);
+  const long long wgs = (long long)((N + 63) / 64 + 1) * npass * B;
+  int s = wgs < 128 ? 16 : (wgs < 512 ? 8 : 4);
+  if (const char* e = getenv("BOGP_POINT_SPLIT")) s = std::max(1, atoi(e));  // A/B switch
+  s = std::max(1, std::min(s, (N + 15) / 16));  // at least ~4 columns per wave and split
+  *rb = 64;
+  *nsplit = s;
+}
+
+hipError_t launch_point_tri(const PointTriArgs& a, int B, hipStream_t st) {
+  dim3 grid((a.nRB + 1) * a.nsplit, a.npass, B);
+  if (point_columns_per_pass(a.d) == 12) {
+    hipLaunchKernelGGL(k_point_tri<12>, grid, 256, 0, st, a.V, a.gamma, a.wvec, a.rhs, a);
+    hipLaunchKernelGGL(k_point_finish<12>, dim3(B), 256, 0, st, a);
+  } else {
+    hipLaunchKernelGGL(k_point_tri<22>, grid, 256, 0, st, a.V, a.gamma, a.wvec, a.rhs, a);
+    hipLaunchKernelGGL(k_point_finish<22>, dim3(B), 256, 0, st, a);
+  }
+  return hipGetLastError();
+}
+
+size_t polish_state_doubles() { return 8 + 64 + 64 + 2 * (size_t)POLISH_M * 64 + POLISH_M; }
+
+hipError_t launch_polish_step(const PolishArgs& a, int B, hipStream_t st) {
+  hipLaunchKernelGGL(k_polish_step, dim3(B), 64, 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace bogp

@@ -447,12 +447,26 @@ def argmax_restart(
     return xopt[idx[0]], fopt[idx[0]]
 
 
-def polish_topk(crit, starts: np.ndarray, bounds: np.ndarray, max_iter: int = 50, sequential: bool = False):
+def polish_topk(crit, starts: np.ndarray, bounds: np.ndarray, max_iter: int = 50):
     """Local refinement of `starts` (k, d) inside the box `bounds` (d, 2); returns (points (k, d), values (k,)) with
-    values[i] >= the criterion at starts[i].  Placeholder until the batched device call lands: one L-BFGS-B run per start
-    through the one-point call (the r02 behaviour)."""
+    values[i] >= the criterion at starts[i].  On the device engine all k starts advance in lock step (`bogp_polish`:
+    one batched value + gradient evaluation per iteration, the optimiser state never leaves the GPU) -- the reference
+    runs its restarts one after the other, one point per call (optim/__init__.py:74-153).  An engine without `polish`
+    (the test stand-ins) or a model the fused call does not serve (polynomial trend basis) gets the reference-style
+    sequential L-BFGS-B through the one-point call."""
+    starts = np.atleast_2d(np.asarray(starts, dtype=float))
+    bounds = np.asarray(bounds, dtype=float)
+    model = crit.model
+    eng = getattr(model, "engine", None)
+    fused = getattr(model, "_fused_point_ok", None)
+    if eng is not None and hasattr(eng, "polish") and fused is not None and fused() and starts.shape[1] <= 64:
+        if getattr(model, "_committed_par", None) is None:
+            raise Exception("The model is not fitted yet!")
+        xs, fs, _ = eng.polish(model._check_X(starts), bounds[:, 0], bounds[:, 1], (crit.acq_id, crit.acq_par()), crit.effective_plugin(),
+                               crit.minimize, max_evals=int(max_iter))  # fmt: skip
+        return xs, fs
     xs, fs = [], []
-    for x0 in np.asarray(starts, dtype=float):
+    for x0 in starts:
         def neg(x):
             f, fg = crit(np.asarray(x, dtype=float).reshape(1, -1), return_dx=True)
             return -1.0 * float(np.asarray(f, float).ravel()[0]), -1.0 * np.asarray(fg, float).ravel()

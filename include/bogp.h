@@ -28,6 +28,7 @@ extern "C" {
 typedef struct bogp_handle bogp_handle;
 
 /* error codes */
+#define BOGP_ABI_VERSION 4 /* what bogp_abi_version() of a matching library returns */
 #define BOGP_OK 0
 #define BOGP_ERR_INVALID (-1)      /* bad argument / call order                                           */
 #define BOGP_ERR_HIP (-2)          /* HIP runtime / rocBLAS failure                                        */
@@ -225,8 +226,8 @@ int bogp_sweep_topk(bogp_handle* h, int q, const int* acq_id, const double* acq_
 /* ---- input-gradient of the posterior at ONE point ---------------------------------------------------
  * Replaces GaussianProcess.gradient(x) (gpr.py:537-576, corr_dx :600-661): dmu (d), dmse (d).            */
 int bogp_gradient(bogp_handle* h, const double* x, double* dmu, double* dmse);
-/* The same for B points at once (Xb: B x d; dmu, dmse: B x d row-major): one pair of triangular solves with B
- * right-hand sides + one reduction kernel.  Feeds multi-start local refinement of the sweep's top-k.      */
+/* The same for B points at once (Xb: B x d; dmu, dmse: B x d row-major); constant trend basis.  r03: k_point_rhs +
+ * k_point_tri (csrc/kernels_point.hip) -- ONE pass over L^-1 per point serves all d + 1 right-hand sides.     */
 int bogp_gradient_batch(bogp_handle* h, const double* Xb, int B, double* dmu, double* dmse);
 /* Hessian of the posterior mean at x (GaussianProcess.Hessian, gpr.py:578-598), d x d row-major.  Squared exponential
  * only, like the reference's corr_Hessian (:663-734); constant / linear trend (their Hessians are zero, trend.py:88-116). */
@@ -240,6 +241,26 @@ int bogp_prior_corr(bogp_handle* h, const double* X1, int n1, double* R);
  * L-BFGS-B, base.py:201-243) makes thousands of times per ask().  Constant trend basis; q may be 0.            */
 int bogp_point_eval(bogp_handle* h, const double* x, int q, const int* acq_id, const double* acq_par, double plugin,
                     int minimize, double* mu, double* mse, double* dmu, double* dmse, double* acq);
+/* The same for B points (Xb: B x d, host) in ONE device round trip, plus the criteria's own input-gradients -- the
+ * `return_dx` chain rule of acquisition_fun.py:139-146 (UCB), 181-188 (EI), 220-227 (EpsilonPI), 292-309 (MGFI) evaluated
+ * on the device, guards (zero gradient) included.  Outputs, row-major, any may be NULL: mu, mse (B), dmu, dmse (B x d),
+ * acq (B x q), dacq (B x q x d).  The reference raises for more than one row (gpr.py:548-549); row b here is what its
+ * one-row call returns for row b.  Constant trend basis.                                                      */
+int bogp_point_eval_batch(bogp_handle* h, const double* Xb, int B, int q, const int* acq_id, const double* acq_par,
+                          double plugin, int minimize, double* mu, double* mse, double* dmu, double* dmse, double* acq,
+                          double* dacq);
+/* Multi-start local maximisation of ONE criterion inside the box [lo, hi] (d each), all B starts in lock step on the
+ * device: every iteration is one batched value + gradient evaluation of the B trial points (as bogp_point_eval_batch,
+ * records stay on the device) and one optimiser step per start (projected L-BFGS, 8 curvature pairs, Armijo
+ * backtracking; a start never moves to a worse point).  Replaces the restart loop of acquisition/optim/__init__.py:74-153
+ * when it is started from the sweep's top-k -- the reference runs its restarts one after the other, one
+ * point per call.  Stop rules per start as the reference configures scipy's L-BFGS-B (:94-101): projected gradient
+ * below pgtol (1e-8), relative improvement below factr (1e6) x machine epsilon, or max_evals evaluations.
+ * X0: B x d starting points (clipped into the box); Xout: B x d; fout: B (criterion value at Xout, >= the value at
+ * X0); n_evals: B evaluations used, may be NULL.  d <= 64; constant trend basis.                              */
+int bogp_polish(bogp_handle* h, const double* X0, int B, const double* lo, const double* hi, int acq_id, double acq_par,
+                double plugin, int minimize, int max_evals, double pgtol, double factr, double* Xout, double* fout,
+                int* n_evals);
 
 /* ---- multi-GPU: the one exchange step per sweep ------------------------------------------
  * Nothing like it exists in the reference (its only parallelism is joblib over the q criteria, bayes_opt.py:108-111);

@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
     fprintf(stderr, "bogp_create: %s\n", bogp_last_error(NULL));
     return 3;
   }
-  if (bogp_abi_version() != 3) return 4;
+  if (bogp_abi_version() != BOGP_ABI_VERSION) return 4;
   double llf = 0.0;
   CHECK(bogp_set_train(h, X, y, N, d, 1));
   CHECK(bogp_commit(h, BOGP_KERNEL_MATERN32, BOGP_MODE_NOISY, par, d + 1, 1e-6, BOGP_TREND_CONSTANT, 0, 0.0, &llf));
