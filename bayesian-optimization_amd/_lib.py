@@ -3,6 +3,7 @@ gfx950 device is usable, every entry point raises -- the product path never comp
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
 from typing import Optional, Sequence, Tuple
 
@@ -169,8 +170,11 @@ def trend_size_of(trend: int, d: int) -> int:
     return 1 if trend == TREND_CONSTANT else (d + 1 if trend == TREND_LINEAR else (d + 1) * (d + 2) // 2)
 
 
+@functools.lru_cache(maxsize=32)
 def sobol_direction_numbers(d: int, bits: int = 30) -> np.ndarray:
-    """The (d, bits) direction numbers of scipy's unscrambled Sobol' generator (Joe & Kuo tables): what the reference's
+    """(Cached per (d, bits): building the table costs 30 scipy engines, and generate_candidates(method="sobol") asks for it on
+    every ask().  Needs scipy >= 1.9 for the `bits=` keyword of `qmc.Sobol`.  The returned array is shared: do not write to it.)
+    The (d, bits) direction numbers of scipy's unscrambled Sobol' generator (Joe & Kuo tables): what the reference's
     `sobol_seq` call resolves to in this image.  Data for `bogp_candidates_generate_sobol`, which
     carries no table of its own.  Recovered through scipy's PUBLIC interface only: point n of the sequence is the XOR of
     the direction numbers over the set bits of the Gray code of n, and gray(2^b) = 2^b ^ 2^(b-1), so
@@ -332,12 +336,14 @@ class Engine:
             raise ValueError("candidates must have shape (M, %d)" % self.d)
         self._check(self._lib.bogp_candidates_upload(self._h, _ptr(Xs), Xs.shape[0]))
         self.M = Xs.shape[0]
+        self._last_q, self._last_topk = -1, (-1, -1)  # winners of an earlier sweep refer to other rows
         self._keep = None
 
     def bind_candidates(self, device_ptr: int, M: int, owner=None):
         """Adopt caller-owned device memory (M x d float64 row-major), e.g. a torch tensor's data_ptr()."""
         self._check(self._lib.bogp_candidates_bind(self._h, C.c_void_p(int(device_ptr)), int(M)))
         self.M = int(M)
+        self._last_q, self._last_topk = -1, (-1, -1)
         self._keep = owner
 
     def generate_candidates(self, lo, hi, M: int, seed: int = 0, first_row: int = 0, method: str = "uniform",
@@ -375,6 +381,7 @@ class Engine:
             raise ValueError("method must be 'uniform', 'LHS' or 'sobol'")
         self._check(rc)
         self.M = int(M)
+        self._last_q, self._last_topk = -1, (-1, -1)
         self._keep = None
 
     def set_candidate_transform(self, scales=None, precisions=None, lo=None, hi=None):
@@ -420,9 +427,11 @@ class Engine:
         q = len(acq)
         ids = np.ascontiguousarray([a for a, _ in acq], dtype=np.int32)
         pars = _f64([float(p) if p is not None else 0.0 for _, p in acq])
+        self._last_q, self._last_topk = -1, (-1, -1)
         if not local_result:
             self._check(self._lib.bogp_sweep(self._h, q, ids.ctypes.data_as(_ip), _ptr(pars), float(plugin), int(bool(minimize)),
                                              None, None, None))  # fmt: skip
+            self._last_q = q
             return None
         best = np.empty(q)
         idx = np.empty(q, dtype=np.int64)
@@ -431,6 +440,7 @@ class Engine:
             self._lib.bogp_sweep(self._h, q, ids.ctypes.data_as(_ip), _ptr(pars), float(plugin), int(bool(minimize)),
                                  _ptr(best), idx.ctypes.data_as(_lp), _ptr(vals))
         )  # fmt: skip
+        self._last_q = q
         return (best, idx, vals) if return_values else (best, idx)
 
     def sweep_topk(self, acq: Sequence[Tuple[int, float]], plugin: float, minimize=True, k: int = 1):
@@ -440,10 +450,12 @@ class Engine:
         pars = _f64([float(p) if p is not None else 0.0 for _, p in acq])
         best = np.empty((q, k))
         idx = np.empty((q, k), dtype=np.int64)
+        self._last_q, self._last_topk = -1, (-1, -1)
         self._check(
             self._lib.bogp_sweep_topk(self._h, q, ids.ctypes.data_as(_ip), _ptr(pars), float(plugin), int(bool(minimize)),
                                       int(k), _ptr(best), idx.ctypes.data_as(_lp))
         )  # fmt: skip
+        self._last_topk = (q, int(k))
         return best, idx
 
     def gradient(self, x):
@@ -576,6 +588,8 @@ class Engine:
     def exchange_argmax(self, q: int, index_offset: int = 0, with_points: bool = True):
         """After sweep(): the global winners over all ranks' shards, identical on every rank:
         (best_val (q,), best_global_idx (q,), best_x (q, d) or None).  ONE ncclAllGather on device records."""
+        if int(q) != self.__dict__.get("_last_q", -1):  # the C side packs ITS q records: a mismatch would under- or overrun these buffers
+            raise ValueError("exchange_argmax(q=%d) does not follow a sweep of q = %d criteria on the current candidates" % (q, self.__dict__.get("_last_q", 0)))
         best, gidx = np.empty(q), np.empty(q, dtype=np.int64)
         x = np.empty((q, self.d)) if with_points else None
         self._check(self._lib.bogp_exchange_argmax(self._h, int(index_offset), _ptr(best), gidx.ctypes.data_as(_lp), _ptr(x)))
@@ -583,6 +597,8 @@ class Engine:
 
     def exchange_topk(self, q: int, k: int, index_offset: int = 0, with_points: bool = True):
         """After sweep_topk(): (values (q, k), global indices (q, k), points (q, k, d) or None), identical on every rank."""
+        if (int(q), int(k)) != self.__dict__.get("_last_topk", (-1, -1)):
+            raise ValueError("exchange_topk(q=%d, k=%d) does not follow a sweep_topk of that shape on the current candidates" % (q, k))
         best, gidx = np.empty((q, k)), np.empty((q, k), dtype=np.int64)
         x = np.empty((q, k, self.d)) if with_points else None
         self._check(self._lib.bogp_exchange_topk(self._h, int(index_offset), _ptr(best), gidx.ctypes.data_as(_lp), _ptr(x)))

@@ -136,17 +136,16 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
   HIPCHK(h, hipStreamSynchronize(h->stream));
   // leading dimension: N rounded up to 64; to 128 from 6144 on, where the inverse and R^-1 work on 128 x 128 tiles
   const int ld_need = N > 6080 ? ((N + 127) / 128) * 128 : ((N + 63) / 64) * 64;
-  const bool fits = h->dX && ld_need <= h->cap_ld && d <= h->cap_d && n_targets <= h->cap_nt;
+  const bool fits = h->dX && h->dtheta && ld_need <= h->cap_ld && d <= h->cap_d && n_targets <= h->cap_nt;
   if (fits) {
     free_trend(h);  // N x p buffers of a polynomial basis: rebuilt on demand
     h->committed = false;
   } else {
-    free_train(h);
+    free_train(h);  // also zeroes cap_*: they are set again only after EVERY allocation below has succeeded, so a failure
+                    // half way (HIPCHK returns) can never leave a "fits" state with null buffers behind
     // grow in steps of 256 rows once the set is larger than a block, so that a BO loop reallocates every 256 tell()s
-    h->cap_ld = ld_need <= 256 ? ld_need : ((ld_need + 255) / 256) * 256;
-    h->cap_d = d;
-    h->cap_nt = n_targets;
-    const size_t cl = (size_t)h->cap_ld, NNc = cl * cl, ntc = (size_t)n_targets;
+    const int new_cap_ld = ld_need <= 256 ? ld_need : ((ld_need + 255) / 256) * 256;
+    const size_t cl = (size_t)new_cap_ld, NNc = cl * cl, ntc = (size_t)n_targets;
     HIPCHK(h, hipMalloc((void**)&h->dX, cl * d * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->dy_base, ntc * cl * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->dR, NNc * sizeof(double)));
@@ -168,6 +167,9 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
     HIPCHK(h, hipMalloc((void**)&h->dw, cl * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->dtheta, 2 * (d + 1) * sizeof(double)));  // [theta (d + 1) | sqrt_theta (d + 1)]: one upload
     h->dsqrt_theta = h->dtheta + (d + 1);
+    h->cap_ld = new_cap_ld;
+    h->cap_d = d;
+    h->cap_nt = n_targets;
   }
   h->N = N;
   h->d = d;
@@ -827,8 +829,14 @@ extern "C" int bogp_get_trend_state(bogp_handle* h, double* Ft, double* Q, doubl
 // ------------------------------------------------------------------------------------------------------
 // candidates
 // ------------------------------------------------------------------------------------------------------
+// The winners a sweep left on the device (dbest_* / dtopk_*) refer to rows of the candidate set they were computed on: any
+// change of that set -- and a sweep of the other flavour, which overwrites dbest_* -- makes them unusable for
+// bogp_exchange_* (stale or out-of-range rows would be packed otherwise).
+static void invalidate_sweep_results(bogp_handle* h) { h->last_q = h->last_topk_q = h->last_topk_k = 0; }
+
 extern "C" int bogp_candidates_upload(bogp_handle* h, const double* Xs, int64_t M) {
   if (!h) return BOGP_ERR_INVALID;
+  invalidate_sweep_results(h);
   if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_upload: call bogp_set_train first (d is unknown)");
   if (!Xs || M <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_upload: Xs must be non-null and M > 0");
   HIPCHK(h, hipSetDevice(h->device));
@@ -843,6 +851,7 @@ extern "C" int bogp_candidates_upload(bogp_handle* h, const double* Xs, int64_t 
 
 // shared front end of the three on-device generators: validates the box, sizes the candidate buffer, stages lo / hi
 static int generate_prepare(bogp_handle* h, const char* who, const double* lo, const double* hi, int64_t M, int64_t first) {
+  invalidate_sweep_results(h);
   if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "%s: call bogp_set_train first (d is unknown)", who);
   if (!lo || !hi || M <= 0 || first < 0) FAIL(h, BOGP_ERR_INVALID, "%s: bounds must be non-null, M > 0, first row/index >= 0", who);
   const int d = h->d;
@@ -1014,6 +1023,7 @@ extern "C" int bogp_candidates_read(bogp_handle* h, const int64_t* rows, int n, 
 extern "C" int bogp_candidates_bind(bogp_handle* h, const void* d_Xs, int64_t M) {
   if (!h) return BOGP_ERR_INVALID;
   if (!d_Xs || M <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_bind: pointer must be non-null and M > 0");
+  invalidate_sweep_results(h);
   h->dXs = (const double*)d_Xs;
   h->M = M;
   return BOGP_OK;
@@ -1323,7 +1333,7 @@ extern "C" int bogp_sweep(bogp_handle* h, int q, const int* acq_id, const double
     if (acq_id[i] != BOGP_ACQ_EI && (!acq_par || !(acq_par[i] > 0 || (zero_ok && acq_par[i] == 0))))
       FAIL(h, BOGP_ERR_INVALID, "acquisition parameter %d must be > 0 (the reference asserts alpha/epsilon/t > 0)", i);
   }
-  h->last_q = 0;
+  invalidate_sweep_results(h);
   int rc = run_sweep(h, false, q, acq_id, acq_par, plugin, minimize, acq_out != nullptr, true, local);
   if (rc) return rc;
   h->last_q = q;  // dbest_val / dbest_idx hold this sweep's winners for bogp_exchange_argmax
@@ -1345,7 +1355,7 @@ extern "C" int bogp_sweep_topk(bogp_handle* h, int q, const int* acq_id, const d
     if (acq_id[i] != BOGP_ACQ_EI && (!acq_par || !(acq_par[i] > 0 || (zero_ok && acq_par[i] == 0))))
       FAIL(h, BOGP_ERR_INVALID, "acquisition parameter %d must be > 0", i);
   }
-  h->last_topk_q = h->last_topk_k = 0;
+  invalidate_sweep_results(h);  // run_sweep below overwrites dbest_* as well
   int rc = run_sweep(h, false, q, acq_id, acq_par, plugin, minimize, true);  // keeps the q x M values on the device
   if (rc) return rc;
   // rank 0 is the sweep's own argmax; ranks 1..k-1 repeat the argmax with the winners so far masked out -- all q criteria

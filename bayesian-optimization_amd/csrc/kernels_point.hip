@@ -51,18 +51,27 @@ __device__ __forceinline__ double point_dx_entry(double rv, double D, double e5,
 template <int KERNEL, int NC>
 __global__ __launch_bounds__(256) void k_point_rhs(PointRhsArgs a) {
   constexpr int CPS = ((NC / 2 + 3) / 4) * 2;  // columns per slice (even: 16-B stores)
+  __shared__ double xs[BOGP_POINT_MAX_D], ths[BOGP_POINT_MAX_D];
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   const int slice = threadIdx.x >> 6;
   const int b = blockIdx.y;
-  if (n >= a.Npp) return;
   const int d = a.d;
-  const bool from_args = a.Xb == nullptr;  // one point, carried by the kernel arguments (no upload)
-#define XB(k) (from_args ? a.x[k] : a.Xb[(size_t)b * d + (k)])
+  // the point (from the kernel arguments when it is the only one: no upload) and theta, once per workgroup: the distance
+  // loop below then has ONE global load per term, and unrolled they are all in flight together (the first version
+  // selected between the argument segment and memory per term: 20 dependent round trips, 8 us)
+  for (int k = threadIdx.x; k < d; k += 256) {
+    xs[k] = a.Xb ? a.Xb[(size_t)b * d + k] : a.x[k];
+    ths[k] = a.theta[k];
+  }
+  __syncthreads();
+  if (n >= a.Npp) return;
   double rv = 0.0, D = 0.0, e5 = 0.0;
   const bool live = n < a.N;
+  const double* __restrict__ xr = a.X + (size_t)(live ? n : 0) * d;
   if (live) {
     double s2 = 0.0;
-    for (int k = 0; k < d; ++k) s2 += dist_term<KERNEL>(a.theta[k], fabs(XB(k) - a.X[(size_t)n * d + k]));
+#pragma unroll 8
+    for (int k = 0; k < d; ++k) s2 += dist_term<KERNEL>(ths[k], fabs(xs[k] - xr[k]));
     rv = corr_profile<KERNEL>(s2);
     D = sqrt(s2);
     if (KERNEL == BOGP_KERNEL_MATERN32) e5 = exp(-1.7320508075688772 * D);
@@ -77,12 +86,11 @@ __global__ __launch_bounds__(256) void k_point_rhs(PointRhsArgs a) {
       for (int i = 0; i < 2; ++i) {
         const int cc = c + i;
         const int k = g * (NC - 1) + (cc - 1);
-        v[i] = cc == 0 ? rv : ((live && k < d) ? point_dx_entry<KERNEL>(rv, D, e5, a.theta[k], XB(k) - a.X[(size_t)n * d + k]) : 0.0);
+        v[i] = cc == 0 ? rv : ((live && k < d) ? point_dx_entry<KERNEL>(rv, D, e5, ths[k], xs[k] - xr[k]) : 0.0);
       }
       *(double2*)(row + c) = make_double2(v[0], v[1]);
     }
   }
-#undef XB
 }
 
 // d acq / d x_k = a_dy * dy_k + a_dsd * dsd_k   (acquisition_fun.py:139-146, 181-188, 220-227, 292-309); the guards of
@@ -245,6 +253,7 @@ __global__ __launch_bounds__(256) void k_point_finish(PointTriArgs a) {
     const double* base = a.part + ((size_t)b * a.npass + gg) * (a.nRB + 1) * (2 * NC);
     if (lane < NC) {
       double s = 0.0;
+#pragma unroll 8
       for (int w2 = 1 + wv; w2 <= a.nRB; w2 += 4) s += base[(size_t)w2 * (2 * NC) + lane];
       fin[wv][lane] = s;
     }

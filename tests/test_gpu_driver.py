@@ -279,6 +279,19 @@ def test_library_exchange_with_a_one_rank_communicator():
         np.testing.assert_array_equal(ev, tv)
         np.testing.assert_array_equal(ei, ti + 123)
         np.testing.assert_array_equal(ex, Xs[ti])
+        # stale winners are refused: a top-k sweep overwrites the argmax buffers; new candidates change the rows
+        with pytest.raises(ValueError):
+            eng.exchange_argmax(len(acq), 0, True)
+        with pytest.raises(ValueError):
+            eng.exchange_topk(len(acq), 5, 0, True)  # not the shape the last sweep_topk produced
+        eng.upload_candidates(Xs[:100])
+        with pytest.raises(ValueError):
+            eng.exchange_topk(len(acq), 7, 0, True)
+        bv, bi = np.empty(256), np.empty(256, dtype=np.int64)
+        for fn in (eng._lib.bogp_exchange_argmax, eng._lib.bogp_exchange_topk):  # and by the C side itself
+            assert fn(eng._h, 0, _lib._ptr(bv), bi.ctypes.data_as(_lib._lp), None) == _lib.ERR_INVALID
+            assert b"no " in eng._lib.bogp_last_error(eng._h)
+        eng.upload_candidates(Xs)
         # the optimiser front ends pick the library transport up by themselves
         crit = [bogp.MGFI(model=gp if n_train == 700 else gp2, t=1.0), bogp.MGFI(model=gp if n_train == 700 else gp2, t=3.0)]
         v, g, x = bogp.sweep_argmax(crit, Xs, index_offset=50)
