@@ -314,6 +314,26 @@ struct FitPending {
   int mode = 0, estimate_trend = 0, ptrend = 1, n_t = 1, N = 0;
   double beta = 0, alpha = 0, sigma2_par = 0, noise_var = 0, s2t = 0;
 };
+// One Newton-Schulz step V <- V (2 I - L V) on the explicit inverse (opt-in: BOGP_REFINE_V=1).  The
+// recursive-doubling inverse carries a residual L V - I of order cond(L) eps; one step squares it.  Two library
+// triangular products (this is an accuracy experiment off the sweep path, see profiles/r03_refine_inverse.txt), results
+// into V (lower) and U = V^T.  Scratch: dT and the first slice of dRinv.
+static bool refine_wanted() {
+  static const bool on = [] { const char* e = getenv("BOGP_REFINE_V"); return e && atoi(e) != 0; }();
+  return on;
+}
+static int refine_inverse(bogp_handle* h, int N, int ldr, hipStream_t st) {
+  const double one = 1.0;
+  if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * h->cap_ld * h->cap_ld * sizeof(double)));
+  BLASCHK(h, rocblas_dtrmm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, N, &one,
+                           h->dR, ldr, h->dV, ldr, h->dT, ldr));  // T = L V
+  HIPCHK(h, launch_two_i_minus(h->dT, N, ldr, st));                // T = 2 I - L V
+  BLASCHK(h, rocblas_dtrmm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, N, &one,
+                           h->dV, ldr, h->dT, ldr, h->dRinv, ldr));  // W = V (2 I - L V)
+  HIPCHK(h, launch_refine_store(h->dRinv, h->dV, h->dU, N, ldr, st));
+  return BOGP_OK;
+}
+
 static int factorize_finish(bogp_handle* h, const FitPending& fp, int info, const double* sc, const int* info2,
                             bool reject_positive, FitOut* o);
 
@@ -383,6 +403,10 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st, h->stream2, h->ev_chol, h->dT));  // dT: free until the inverse
   HIPCHK(h, launch_logdet(h->dR, N, ldr, h->dscal, st));
   HIPCHK(h, launch_tri_inverse(h->dR, h->ddinv, h->dV, h->dU, h->dT, ldr, st));
+  if (refine_wanted()) {
+    int er = refine_inverse(h, N, ldr, st);
+    if (er) return er;
+  }
   const int n_t = h->n_t;
   if (n_t > 1 && (ptrend != 1 || estimate_trend))
     FAIL(h, BOGP_ERR_UNSUPPORTED, "multi-target y (%d targets) is built for a FIXED constant trend only: with estimated coefficients the reference raises at gpr.py:787 (beta gets one row per target)", n_t);

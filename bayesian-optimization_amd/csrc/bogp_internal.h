@@ -126,6 +126,8 @@ hipError_t launch_scale_transpose(const double* X, int N, int d, int Np, const d
                                   hipStream_t st);
 hipError_t launch_pack_V(const double* Vcm, int N, int ld, int Np, double2* Vp, hipStream_t st);
 hipError_t launch_logdet(const double* L, int N, int ld, double* out, hipStream_t st);
+hipError_t launch_two_i_minus(double* T, int N, int ld, hipStream_t st);
+hipError_t launch_refine_store(const double* W, double* V, double* U, int N, int ld, hipStream_t st);
 // kernels_chol.hip: in-place lower Cholesky of a column-major matrix whose ld is a multiple of 64 (identity padded)
 hipError_t launch_pad_identity(double* A, int N, int ld, hipStream_t st);
 // st2 + ev[2] (optional): a second stream and two events for the look-ahead of the large-matrix path

@@ -846,7 +846,7 @@ def test_trend_classes_end_to_end():
     ei = bogp.EI(model=gp, minimize=True)
     v, dx = ei(g["Xs"][:1], return_dx=True)
     np.testing.assert_allclose(np.ravel(v)[0], g["dx_val_EI"][0], rtol=1e-6)
-    np.testing.assert_allclose(np.ravel(dx), g["dx_EI"][0], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(np.ravel(dx), g["dx_EI"][0], rtol=1e-6, atol=1e-9 * float(np.max(np.abs(g["dx_EI"][0]))))
     gb = gp.gradient_batch(g["Xs"][:3])
     np.testing.assert_allclose(gb[0][2], g["grad_mu"][2].ravel(), rtol=1e-6, atol=1e-9)
     # a real fit with the GLS trend (MLE on the device, universal kriging)
@@ -1222,7 +1222,7 @@ def test_randomised_configurations_match_the_oracle(eng):
             oi = O.nan_first_argmax(ov)
             # the winner may differ only between candidates whose values agree to rounding
             assert idx[c] == oi or np.isclose(ov[idx[c]], ov[oi], rtol=1e-9, atol=1e-300), tag
-            np.testing.assert_allclose(vals[c], ov, rtol=1e-5, atol=1e-12, err_msg=tag)
+            np.testing.assert_allclose(vals[c], ov, rtol=1e-6, atol=1e-12, err_msg=tag)
         if kernel in (O.KERNEL_SE, O.KERNEL_MATERN32, O.KERNEL_ABSEXP) and trend == O.TREND_CONSTANT:
             ollf, ograd = O.log_likelihood_concentrated(par, X, y, kernel, mode, nv, trend, est, beta, eval_grad=True)
             if np.isfinite(ollf):

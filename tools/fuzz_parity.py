@@ -71,8 +71,12 @@ def one(seed, eng, orc):
         cond = float((dl.max() / dl.min()) ** 2)
     except np.linalg.LinAlgError:
         cond = np.inf
-    compare = cond < 1e8
+    # r03: up to cond 1e12 the comparison is MADE, at the tolerance both sides can honour -- each carries
+    # cond(R) eps of error (the LAPACK solve of the oracle included), so the posterior is compared at max(1e-6, 100 cond eps);
+    # beyond 1e12 the problem still runs, for crashes
+    compare = cond <= 1e12
     tol = max(1e-8, 100.0 * cond * 2.2e-16)  # likelihood tolerance: both sides carry cond(R) eps
+    ptol = max(1e-6, 100.0 * cond * 2.2e-16)  # posterior / criterion tolerance
     eng.set_train(X, y)
     orc.set_train(X, y)
     fails = []
@@ -99,7 +103,7 @@ def one(seed, eng, orc):
             eng.sweep([(0, 0.0)], float(y.min()), True)
         except _lib.BogpError:
             pass
-        return [], tag + " -- ill-conditioned (cond >= %.1e): ran, not compared" % cond
+        return [], tag + " -- ill-conditioned (cond %.1e > 1e12): ran, not compared" % cond
     if grad:
         if not close(got[0], ref[0], tol, tol):
             fails.append("llf %r vs %r" % (got[0], ref[0]))
@@ -121,17 +125,18 @@ def one(seed, eng, orc):
     mu, mse = eng.predict()
     rmu, rmse = orc.predict()
     s2 = float(np.atleast_1d(orc.get_state(False)["sigma2"])[0]) if hasattr(orc, "get_state") else 1.0
-    if not close(mu, rmu, 1e-6, 1e-7):
-        fails.append("mu max diff %g" % np.abs(np.ravel(mu) - np.ravel(rmu)).max())
-    if not close(mse, rmse, 1e-6, 1e-7 * s2):
-        fails.append("mse max diff %g (sigma2 %g)" % (np.abs(np.ravel(mse) - np.ravel(rmse)).max(), s2))
+    mscale = max(1.0, float(np.max(np.abs(rmu))))
+    if not close(mu, rmu, ptol, 1e-7 * ptol / 1e-6 * mscale):
+        fails.append("mu max diff %g (cond %.1e)" % (np.abs(np.ravel(mu) - np.ravel(rmu)).max(), cond))
+    if not close(mse, rmse, ptol, 1e-7 * ptol / 1e-6 * s2):
+        fails.append("mse max diff %g (sigma2 %g, cond %.1e)" % (np.abs(np.ravel(mse) - np.ravel(rmse)).max(), s2, cond))
     if WIDE and trend == 0 and kernel in (O.KERNEL_SE, O.KERNEL_MATERN32, O.KERNEL_ABSEXP):
         # input gradients of the posterior at a random point (gpr.py:537-576) ...
         x = rng.uniform(-5, 5, d)
         try:
             gm, gv = eng.gradient(x)
             rm, rv_ = orc.gradient(x)
-            if not close(gm, rm, 1e-6, 1e-8) or not close(gv, rv_, 1e-6, 1e-8 * s2):
+            if not close(gm, rm, ptol, 1e-8 * ptol / 1e-6) or not close(gv, rv_, ptol, 1e-8 * ptol / 1e-6 * s2):
                 fails.append("input gradient max diff %g / %g" % (np.abs(np.ravel(gm) - np.ravel(rm)).max(), np.abs(np.ravel(gv) - np.ravel(rv_)).max()))
         except (_lib.BogpError, NotImplementedError) as e:
             fails.append("gradient raised %s" % type(e).__name__)
@@ -163,9 +168,14 @@ def one(seed, eng, orc):
         if int(i[c]) != int(ri[c]):
             # a different index is a failure only if the oracle's values separate the two candidates
             v = rv[c]
-            if not (np.isnan(v[int(i[c])]) or abs(v[int(i[c])] - v[int(ri[c])]) <= 1e-9 * (abs(v[int(ri[c])]) + 1e-300)):
+            if not (np.isnan(v[int(i[c])]) or abs(v[int(i[c])] - v[int(ri[c])]) <= max(1e-9, 1e-3 * ptol) * (abs(v[int(ri[c])]) + 1e-300)):
                 fails.append("argmax[%d] %d vs %d (values %r / %r)" % (c, i[c], ri[c], v[int(i[c])], v[int(ri[c])]))
-        elif not close(b[c], rb[c], 1e-6, 1e-300):
+        elif abs(rb[c]) > 1e50 and abs(b[c]) > 1e50 and np.sign(b[c]) == np.sign(rb[c]):
+            # MGFI far out on its exponential (exp of several hundred): a relative error e in the exponent is e |exponent| in the
+            # value, so the exponents are what can be compared at the posterior's tolerance
+            if not close(np.log(abs(b[c])), np.log(abs(rb[c])), ptol, 0.0):
+                fails.append("best[%d] %r vs %r (exponents differ)" % (c, b[c], rb[c]))
+        elif not close(b[c], rb[c], 10 * ptol if ptol > 1e-6 else 1e-6, 1e-300):
             fails.append("best[%d] %r vs %r" % (c, b[c], rb[c]))
     return [tag + ": " + f for f in fails], None
 
