@@ -1166,7 +1166,7 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
 
   // Small training sets (Np <= 512, d <= 60, constant trend): the whole sweep is ONE launch of k_sweep_small -- producer,
   // triangular contraction, posterior, criteria and argmax fused, r never leaves LDS (kernels_small.hip).
-  if (h->p == 1 && sweep_small_supported(Np, d)) {
+  if (h->p == 1 && sweep_small_supported(Np, d, h->kernel)) {
     const int64_t nblk = std::max<int64_t>(sweep_small_blocks(M, h->n_cu), (M + 15) / 16);
     int e2;
     if (q > 0) {

@@ -94,7 +94,7 @@ struct SmallArgs {
   int64_t blk_begin;         // first partial-argmax slot of this launch
   int final_launch;          // the launch whose last workgroup reduces the partial winners
 };
-bool sweep_small_supported(int Np, int d);
+bool sweep_small_supported(int Np, int d, int kernel);
 int64_t sweep_small_blocks(int64_t M, int n_cu);
 hipError_t launch_sweep_small(int kernel, const SmallArgs& a, int n_cu, hipStream_t st);
 

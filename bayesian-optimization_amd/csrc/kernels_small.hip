@@ -104,14 +104,14 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
   const int64_t mg0 = a.m_begin + (int64_t)blockIdx.x * MT;
 
   const double pexp = kernel_exponent<KERNEL>(sqrt_theta, d);
-  const int d3 = (d + 2) / 3 * 3;  // the producer walks the dimensions three at a time; the padding rows are zero
+  const int d2 = (d + 1) & ~1;  // the producer walks the dimensions two at a time; xs is sized for d2 rows, row d (if any) is zero
   for (int idx = tid; idx < SM_MT * d; idx += 512) {
     const int row = idx / d, k = idx - row * d;
     const int64_t gm = mg0 + row;
     const double v = (row < MT && gm < a.M) ? Xs[gm * d + k] : 0.0;
     xs[k * SM_MT + row] = v * sqrt_theta[k];
   }
-  for (int idx = tid; idx < SM_MT * (d3 - d); idx += 512) xs[d * SM_MT + idx] = 0.0;
+  for (int idx = tid; idx < SM_MT * (d2 - d); idx += 512) xs[d * SM_MT + idx] = 0.0;
 
   // column tiles of this wave: serpentine over the (up to) 32 tiles, so that in every panel every wave carries the same
   // number of sixteen-row groups: tiles {w, 15 - w} end inside panel 0, {16 + w, 31 - w} inside panel 1
@@ -180,28 +180,42 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
           double ac[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) ac[i] = dist_init<KERNEL>();
-          // three dimensions per trip: their 3 x 8 training values arrive through three scalar loads issued back to back and
-          // waited for ONCE -- with two waves per SIMD a single 16-op trip per load would leave the SMEM latency exposed
-          // (measured: 430 instead of ~250 cycles per pair).  Rows d .. d3-1 of xs / XthT are zero: they add (0 - 0)^2.
+          // Software-pipelined, two dimensions per trip (r03): the 2 x 8 training values of trip t + 1 (two scalar loads) and the
+          // lane's two candidate coordinates (LDS) are REQUESTED before trip t is computed and waited for at the top of
+          // trip t + 1 -- one lgkmcnt(0) per trip, with 32 DP instructions of cover.  (r02 issued three loads, waited, computed:
+          // with two waves per SIMD the SMEM round trip was exposed -- 430 instead of ~250 cycles per row of 64 pairs.)
+          // Rows d .. d2-1 of xs / XthT are zero: they add (0 - 0)^2.  Same operations in the same order as before.
+          const double* __restrict__ xp = XthT + n0;
+          double c0[8], c1[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            c0[i] = xp[i];
+            c1[i] = xp[(size_t)Np + i];
+          }
+          double xa0 = xs[lane], xa1 = xs[SM_MT + lane];
 #pragma unroll 1
-          for (int k = 0; k < d3; k += 3) {
-            const double* __restrict__ x0 = XthT + (size_t)k * Np + n0;
-            const double* __restrict__ x1 = x0 + Np;
-            const double* __restrict__ x2 = x1 + Np;
-            double t0[8], t1[8], t2[8];
+          for (int k = 0; k < d2; k += 2) {
+            const int kn = k + 2 < d2 ? k + 2 : k;  // the last trip re-requests its own rows (never used)
+            const double* __restrict__ y0 = xp + (size_t)kn * Np;
+            const double* __restrict__ y1 = y0 + Np;
+            double e0[8], e1[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-              t0[i] = x0[i];
-              t1[i] = x1[i];
-              t2[i] = x2[i];
+              e0[i] = y0[i];
+              e1[i] = y1[i];
             }
-            const double xk0 = xs[k * SM_MT + lane], xk1 = xs[(k + 1) * SM_MT + lane], xk2 = xs[(k + 2) * SM_MT + lane];
+            const double xb0 = xs[kn * SM_MT + lane], xb1 = xs[(kn + 1) * SM_MT + lane];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ac[i] = dist_accumulate<KERNEL>(xk0 - t0[i], ac[i], pexp);
+            for (int i = 0; i < 8; ++i) ac[i] = dist_accumulate<KERNEL>(xa0 - c0[i], ac[i], pexp);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ac[i] = dist_accumulate<KERNEL>(xk1 - t1[i], ac[i], pexp);
+            for (int i = 0; i < 8; ++i) ac[i] = dist_accumulate<KERNEL>(xa1 - c1[i], ac[i], pexp);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ac[i] = dist_accumulate<KERNEL>(xk2 - t2[i], ac[i], pexp);
+            for (int i = 0; i < 8; ++i) {
+              c0[i] = e0[i];
+              c1[i] = e1[i];
+            }
+            xa0 = xb0;
+            xa1 = xb1;
           }
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
@@ -360,10 +374,13 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
   if (tid == 0) *a.counter = 0u;  // ready for the next launch on this stream
 }
 
-bool sweep_small_supported(int Np, int d) {
+bool sweep_small_supported(int Np, int d, int kernel) {
+  // generalized_exponential calls pow() per pair and dimension: inlined 16 times per producer trip it spills > 1000 VGPRs
+  // next to the resident accumulators -- that kernel (values only, never fitted) keeps the chunked schedule
+  if (kernel == BOGP_KERNEL_GENEXP) return false;
   const char* e = getenv("BOGP_NO_FUSED_SMALL");  // read per call: the tests run both schedules in one process
   const bool off = e && atoi(e) != 0;
-  return !off && Np <= 2 * SM_PANEL && d <= 60;  // LDS: 128 KB panel + 64 x roundup(d, 3) doubles <= 160 KB
+  return !off && Np <= 2 * SM_PANEL && d <= 60;  // LDS: 128 KB panel + 64 x roundup(d, 2) doubles <= 160 KB
 }
 
 // How a sweep over M candidates is cut into launches on a device with n_cu compute units: `bulk` 64-candidate workgroups
@@ -396,7 +413,7 @@ int64_t sweep_small_blocks(int64_t M, int n_cu) {
 
 template <int MR>
 static hipError_t launch_small_mr(int kernel, const SmallArgs& a, unsigned nwg, hipStream_t st) {
-  const size_t shm = ((size_t)SM_PANEL * SM_MT + (size_t)SM_MT * ((a.d + 2) / 3 * 3)) * sizeof(double);
+  const size_t shm = ((size_t)SM_PANEL * SM_MT + (size_t)SM_MT * ((a.d + 1) & ~1)) * sizeof(double);
 #define BOGP_LAUNCH_SMALL(K)                                                                                             \
   do {                                                                                                                   \
     hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_small<K, MR>),                            \
@@ -410,7 +427,7 @@ static hipError_t launch_small_mr(int kernel, const SmallArgs& a, unsigned nwg, 
     case BOGP_KERNEL_MATERN32: BOGP_LAUNCH_SMALL(BOGP_KERNEL_MATERN32); break;
     case BOGP_KERNEL_ABSEXP: BOGP_LAUNCH_SMALL(BOGP_KERNEL_ABSEXP); break;
     case BOGP_KERNEL_CUBIC: BOGP_LAUNCH_SMALL(BOGP_KERNEL_CUBIC); break;
-    case BOGP_KERNEL_GENEXP: BOGP_LAUNCH_SMALL(BOGP_KERNEL_GENEXP); break;
+    case BOGP_KERNEL_GENEXP: return hipErrorInvalidValue;  // sweep_small_supported() excludes it
     default: BOGP_LAUNCH_SMALL(BOGP_KERNEL_MATERN52); break;
   }
 #undef BOGP_LAUNCH_SMALL
@@ -427,11 +444,11 @@ hipError_t launch_sweep_small(int kernel, const SmallArgs& a0, int n_cu, hipStre
   a.blk_begin = 0;
   if (const char* f = getenv("BOGP_SMALL_FORCE_MR")) {  // measurement aid: every workgroup with 16 * MR candidates
     const int mr = atoi(f);
-    if (mr >= 1 && mr <= 3) {
+    if (mr >= 2 && mr <= 3) {  // (MR = 1 is gone: one accumulator per tile, every MFMA waiting for its predecessor, 21 spilled VGPRs)
       const unsigned nwg = (unsigned)((a0.M + 16 * mr - 1) / (16 * mr));
       a.final_launch = 1;
       if ((int64_t)nwg > a0.nblk) return hipErrorInvalidValue;
-      return mr == 1 ? launch_small_mr<1>(kernel, a, nwg, st) : mr == 2 ? launch_small_mr<2>(kernel, a, nwg, st) : launch_small_mr<3>(kernel, a, nwg, st);
+      return mr == 2 ? launch_small_mr<2>(kernel, a, nwg, st) : launch_small_mr<3>(kernel, a, nwg, st);
     }
   }
   a.final_launch = tail_wg == 0;
