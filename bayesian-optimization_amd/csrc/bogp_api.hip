@@ -384,13 +384,16 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   // correlation matrix with the per-mode normalisation (gpr.py:931-969)
   double s2t = 0, alpha = 0, sigma2_par = 0;
   if (mode == BOGP_MODE_NOISELESS) {
+    h->R_div = false; h->R_a = 1.0; h->R_b = 1.0; h->R_diag = 1.0;
     HIPCHK(h, launch_build_R(kernel, h->dX, N, d, h->dtheta, 1.0, 1.0, h->dR, ldr, st));
   } else if (mode == BOGP_MODE_NOISE_ESTIM) {
     alpha = par[n_par - 1];
+    h->R_div = false; h->R_a = alpha; h->R_b = 1.0; h->R_diag = alpha * 1.0 + (1 - alpha) * 1.0;
     HIPCHK(h, launch_build_R(kernel, h->dX, N, d, h->dtheta, alpha, alpha * 1.0 + (1 - alpha) * 1.0, h->dR, ldr, st));
   } else {
     sigma2_par = par[n_par - 1];
     s2t = sigma2_par + noise_var;
+    h->R_div = true; h->R_a = sigma2_par; h->R_b = s2t; h->R_diag = (sigma2_par * 1.0 + noise_var * 1.0) / s2t;
     HIPCHK(h, launch_build_R_div(kernel, h->dX, N, d, h->dtheta, sigma2_par, s2t, (sigma2_par * 1.0 + noise_var * 1.0) / s2t,
                                  h->dR, ldr, st));
   }
@@ -739,8 +742,31 @@ extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* p
   if (rc != BOGP_OK) return rc;
   const int N = h->N, d = h->d, Np = h->Np;
   hipStream_t st = h->stream;
-  // V = L^-1 (the triangular solve of gpr.py:494 becomes a triangular GEMM against V)
   const int ldr = h->ldr;
+  // One step of iterative refinement of gamma = R^-1 (y - beta 1) (gpr.py:787-788) against R recomputed from X: the factor of
+  // the blocked Cholesky applies explicit inverses of its diagonal blocks (conditionally backward stable), which at
+  // cond(R) ~ 1e12 left the posterior mean ~100x further from the exact one than a LAPACK solve (profiles/r03_refine_inverse.txt,
+  // r03_refine_gamma.txt).  gamma += L^-T L^-1 (b - R gamma): one N^2 d pass + two triangular matrix-vector products, at
+  // commit only.  Constant basis (estimated or fixed beta); BOGP_REFINE_GAMMA=0 switches it off.
+  {
+    static const int steps = [] { const char* e = getenv("BOGP_REFINE_GAMMA"); return e ? atoi(e) : 1; }();
+    if (steps > 0 && trend_size(trend, d) == 1) {
+      int e = ensure(h, &h->dbatch, &h->batch_cap, (size_t)3 * N);
+      if (e) return e;
+      double *dres = h->dbatch, *dt1 = dres + N, *dt2 = dt1 + N;
+      for (int t = 0; t < h->n_t; ++t) {
+        double* g = h->dgamma_base + (size_t)t * Np;
+        for (int it = 0; it < steps; ++it) {
+          HIPCHK(h, launch_resid_gamma(kernel, h->R_div, h->dX, N, d, h->dtheta, h->R_a, h->R_b, h->R_diag, h->dy_base + (size_t)t * N,
+                                       o.beta, g, dres, st));
+          HIPCHK(h, launch_gemv2(h->dV, ldr, N, 1, dres, nullptr, dt1, nullptr, h->dgemv_scratch, st));
+          HIPCHK(h, launch_gemv2(h->dU, ldr, N, 2, dt1, nullptr, dt2, nullptr, h->dgemv_scratch, st));
+          HIPCHK(h, launch_add_vec(g, dt2, N, st));
+        }
+      }
+    }
+  }
+  // V = L^-1 (the triangular solve of gpr.py:494 becomes a triangular GEMM against V)
   if (!h->dVp) HIPCHK(h, hipMalloc((void**)&h->dVp, (size_t)h->cap_ld * h->cap_ld * sizeof(double)));
   HIPCHK(h, launch_pack_V(h->dV, N, ldr, Np, h->dVp, st));
   // w = L^-T Ft  (so that Ft^T L^-1 r = w . r, gpr.py:496-498)

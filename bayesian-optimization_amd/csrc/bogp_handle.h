@@ -58,6 +58,11 @@ struct bogp_handle {
   double* dbatch = nullptr;
   size_t batch_cap = 0;
 
+  // how the last factorisation formed R from the correlations (k_build_R's arguments): what bogp_commit's refinement of
+  // gamma recomputes R with
+  bool R_div = false;
+  double R_a = 1.0, R_b = 1.0, R_diag = 1.0;
+
   // committed state
   bool committed = false;
   int kernel = 0, mode = 0, estimate_trend = 0;

@@ -207,6 +207,100 @@ hipError_t launch_build_R_div(int kernel, const double* X, int N, int d, const d
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// res_i = (y_i - beta) - sum_j R_ij gamma_j  with R recomputed from X exactly as k_build_R formed it (same expressions, so
+// the residual is taken against the matrix that was factorised): the right-hand side of one step of iterative refinement
+// of gamma = R^-1 (y - beta 1) at commit (bogp_api.hip: refine_gamma).  One workgroup per 64 rows walks all column tiles;
+// the sum over j runs in a fixed order (tile by tile, then the 16 thread columns): deterministic.
+// ---------------------------------------------------------------------------------------------------------------
+template <int KERNEL, bool DIV>
+__global__ __launch_bounds__(256) void k_resid_gamma(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
+                                                     double a, double b, double diag, const double* __restrict__ y, double beta,
+                                                     const double* __restrict__ gamma, double* __restrict__ res) {
+  __shared__ double xi[KC * PP], xj[KC * PP];
+  __shared__ double red[16][PT + 1];
+  const int bi = blockIdx.x;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int i0 = bi * PT, nt = (N + PT - 1) / PT;
+  const double pexp = kernel_exponent<KERNEL>(theta, d);
+  double rowacc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int bj = 0; bj < nt; ++bj) {
+    const int j0 = bj * PT;
+    double s2[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s2[r][c] = dist_init<KERNEL>();
+    for (int kc = 0; kc < d; kc += KC) {
+      __syncthreads();
+      stage_points(xi, X, N, d, i0, kc, tid);
+      stage_points(xj, X, N, d, j0, kc, tid);
+      __syncthreads();
+      const int kn = min(KC, d - kc);
+      for (int kk = 0; kk < kn; ++kk) {
+        const double th = theta[kc + kk];
+        double vi[4], vj[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vi[r] = xi[kk * PP + 4 * ty + r];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) vj[c] = xj[kk * PP + 4 * tx + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) s2[r][c] = dist_fold<KERNEL>(th, vi[r] - vj[c], s2[r][c], pexp);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = j0 + 4 * tx + c;
+      const double gj = j < N ? gamma[j] : 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 4 * ty + r;
+        if (i >= N || j >= N) continue;
+        double v;
+        if (i == j)
+          v = diag;
+        else if (DIV)
+          v = (a * corr_profile<KERNEL>(s2[r][c])) / b;
+        else
+          v = a * corr_profile<KERNEL>(s2[r][c]);
+        rowacc[r] = __builtin_fma(v, gj, rowacc[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[tx][4 * ty + r] = rowacc[r];
+  __syncthreads();
+  if (tid < PT) {
+    double s = 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += red[t][tid];
+    const int i = i0 + tid;
+    if (i < N) res[i] = (y[i] - beta) - s;
+  }
+}
+
+hipError_t launch_resid_gamma(int kernel, bool div, const double* X, int N, int d, const double* theta, double a, double b,
+                              double diag, const double* y, double beta, const double* gamma, double* res, hipStream_t st) {
+  const int nt = (N + PT - 1) / PT;
+#define CALL(K)                                                                                                          \
+  if (div) hipLaunchKernelGGL((k_resid_gamma<K, true>), dim3(nt), 256, 0, st, X, N, d, theta, a, b, diag, y, beta, gamma, res); \
+  else hipLaunchKernelGGL((k_resid_gamma<K, false>), dim3(nt), 256, 0, st, X, N, d, theta, a, b, diag, y, beta, gamma, res)
+  BOGP_FOR_KERNEL_R(kernel, CALL)
+#undef CALL
+  return hipGetLastError();
+}
+
+__global__ void k_add_vec(double* __restrict__ y, const double* __restrict__ x, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) y[i] += x[i];
+}
+hipError_t launch_add_vec(double* y, const double* x, int N, hipStream_t st) {
+  hipLaunchKernelGGL(k_add_vec, dim3((N + 255) / 256), 256, 0, st, y, x, N);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // partial[blk][k] = sum over the tile's pairs i < j of A_ij * dR0_ij/dtheta_k  (k < d),  partial[blk][d] = sum A_ij R0_ij
 // Rinv arrives as `nparts` K-slices (lower triangles, part_stride doubles apart) that are added here.
 // Tile (bi <= bj): i in tile bi (thread columns), j in tile bj (thread rows); blk = bj (bj + 1) / 2 + bi.

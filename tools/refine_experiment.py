@@ -35,7 +35,7 @@ X = rng.uniform(-5, 5, size=(N, d))
 y = np.sin(X[:, :1]) + 0.1 * X[:, 1:] ** 2
 y = (y - y.mean()) / y.std()
 Xs = rng.uniform(-5, 5, size=(400, d))
-print("BOGP_REFINE_V=%s" % os.environ.get("BOGP_REFINE_V", "0"))
+print("BOGP_REFINE_V=%s BOGP_REFINE_GAMMA=%s" % (os.environ.get("BOGP_REFINE_V", "0"), os.environ.get("BOGP_REFINE_GAMMA", "1 (default)")))
 for nug in (1e-6, 1e-8, 1e-10, 1e-11):
     par = np.r_[np.full(d, 0.02), 0.9]
     try:
