@@ -118,18 +118,14 @@ void point_release(bogp_handle* h) {
   h->hpin_cap = 0;
 }
 
-int point_eval_host(bogp_handle* h, const char* who, const double* Xb, int B, int q, const int* acq_id, const double* acq_par,
-                    double plugin, int minimize, double* mu, double* mse, double* dmu, double* dmse, double* acq, double* dacq) {
-  int e = check_common(h, who, q, acq_id, acq_par);
-  if (e) return e;
-  if (!Xb || B <= 0) FAIL(h, BOGP_ERR_INVALID, "%s: null points or B <= 0", who);
-  if (q > 0 && !acq && !dacq) FAIL(h, BOGP_ERR_INVALID, "%s: q > 0 needs acq or dacq", who);
-  HIPCHK(h, hipSetDevice(h->device));
+static int point_eval_chunk(bogp_handle* h, const double* Xb, int B, int q, const int* acq_id, const double* acq_par, double plugin,
+                            int minimize, double* mu, double* mse, double* dmu, double* dmse, double* acq, double* dacq) {
   hipStream_t st = h->stream;
   const int d = h->d;
   const bool want_dacq = dacq != nullptr && q > 0;
   const PointPlan pl = plan_of(h, B, q, want_dacq);
   const size_t nrec = (size_t)B * pl.rec_stride;
+  int e;
   // the finishing workgroups write straight into pinned host memory: one stream synchronisation, no copy command
   if ((e = ensure_pinned(h, std::max<size_t>(nrec, 1024)))) return e;
   const double* dXb = nullptr;
@@ -148,6 +144,27 @@ int point_eval_host(bogp_handle* h, const char* who, const double* Xb, int B, in
     if (dmu) memcpy(dmu + (size_t)b * d, o + 2 + q, (size_t)d * sizeof(double));
     if (dmse) memcpy(dmse + (size_t)b * d, o + 2 + q + d, (size_t)d * sizeof(double));
     if (want_dacq) memcpy(dacq + (size_t)b * q * d, o + 2 + q + 2 * d, (size_t)q * d * sizeof(double));
+  }
+  return BOGP_OK;
+}
+
+int point_eval_host(bogp_handle* h, const char* who, const double* Xb, int B, int q, const int* acq_id, const double* acq_par,
+                    double plugin, int minimize, double* mu, double* mse, double* dmu, double* dmse, double* acq, double* dacq) {
+  int e = check_common(h, who, q, acq_id, acq_par);
+  if (e) return e;
+  if (!Xb || B <= 0) FAIL(h, BOGP_ERR_INVALID, "%s: null points or B <= 0", who);
+  if (q > 0 && !acq && !dacq) FAIL(h, BOGP_ERR_INVALID, "%s: q > 0 needs acq or dacq", who);
+  HIPCHK(h, hipSetDevice(h->device));
+  const int d = h->d;
+  // points are served in chunks whose right-hand sides (8 ld NC bytes per point and pass) stay below 256 MB
+  const size_t per_point = (size_t)point_passes(d) * h->ldr * point_columns_per_pass(d) * sizeof(double);
+  const int chunk = (int)std::max<size_t>(1, std::min<size_t>(4096, ((size_t)256 << 20) / per_point));
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int nb = std::min(chunk, B - b0);
+    e = point_eval_chunk(h, Xb + (size_t)b0 * d, nb, q, acq_id, acq_par, plugin, minimize, mu ? mu + b0 : nullptr, mse ? mse + b0 : nullptr,
+                         dmu ? dmu + (size_t)b0 * d : nullptr, dmse ? dmse + (size_t)b0 * d : nullptr, acq ? acq + (size_t)b0 * q : nullptr,
+                         dacq ? dacq + (size_t)b0 * q * d : nullptr);
+    if (e) return e;
   }
   return BOGP_OK;
 }

@@ -7,7 +7,8 @@
 //     rt = solve_triangular(L, r.T)      N^2 flops per candidate     -> k_contract     (FP64 MFMA)
 //     1 - sum(rt^2) [+ sum(u^2)]                                     -> k_contract epilogue (+ acquisition kernel)
 //
-// Design constants come from measurements on the target (tools/ubench_f64*.hip, profiles/ubench_r01.txt):
+// Design constants come from measurements on the target (tools/ubench_f64*.hip, tools/ubench_mfma16.hip; profiles/r01_ubench_f64.txt,
+// r01_ubench_mfma16.txt, r01_ubench_mfma_stream.txt):
 //   * v_mfma_f64_4x4x4_4b_f64 issues every 16 cycles (512 flop) = 32 flop/clk/SIMD = the 78.6 TF/s FP64 peak (kernel B below);
 //     v_mfma_f64_16x16x4_f64 issues every 64 cycles (2048 flop) = the same rate -- but only with its accumulator in
 //     architectural VGPRs (with AGPR accumulators, where the builtin puts them: ~130 cycles).  Kernel B' below, the DEFAULT,

@@ -42,7 +42,7 @@ from . import acquisition, optim
 from .surrogate import GaussianProcess as _DeviceGP
 
 _SWEEPS = ("sweep",) + tuple(optim.DEVICE_DESIGNS)
-_OURS = _SWEEPS + ("sweep-BFGS",)  # inner optimisers only this package knows
+_OURS = _SWEEPS + ("sweep-BFGS", "sweep-device-BFGS")  # inner optimisers only this package knows
 
 
 def is_device_model(model) -> bool:
@@ -209,7 +209,7 @@ def install(bayes_optim=None, fuse_batch: bool = True, reroute_bfgs: str = None,
     `bogp.GaussianProcess`, hence `bayes_optim.fmin(...)` fits, predicts and maximises on the device (the defining module
     `bayes_optim.surrogate.gaussian_process` keeps the CPU class; names imported BEFORE install() keep what they had).
 
-    `reroute_bfgs` = "sweep" | "sweep-device" | "sweep-device-lhs" | "sweep-device-sobol" | "sweep-BFGS": drivers constructed
+    `reroute_bfgs` = "sweep" | "sweep-device" | "sweep-device-lhs" | "sweep-device-sobol" | "sweep-BFGS" | "sweep-device-BFGS": drivers constructed
     WITHOUT `acquisition_optimization` fall to the reference's default "BFGS" (one device round trip per point); with a
     reroute their inner maximisation becomes one sweep of `sweep_budget` candidates instead -- no change to the driver's
     constructor call.  Constrained problems, foreign models and non-real spaces are never rerouted."""

@@ -350,15 +350,16 @@ def argmax_restart(
     candidates the reference would accept as a restart's outcome (`feasible_rows`) are swept; `([], [])` when there is none.
     optimizer="sweep-device" / "sweep-device-lhs" / "sweep-device-sobol": the candidates (uniform / Latin hypercube /
     Sobol') are generated on the GPU and never touch the host.
-    optimizer="sweep-BFGS": the sweep's best `n_restart` candidates are polished together on the device
-    (`polish_topk`: lock-step projected L-BFGS, one batched value + gradient call per iteration).
+    optimizer="sweep-BFGS" / "sweep-device-BFGS": the sweep's best `n_restart` candidates (host-sampled / drawn on the GPU)
+    are polished together on the device (`polish_topk`: lock-step projected L-BFGS, one batched value + gradient call
+    per iteration).
     optimizer="BFGS": the reference's multi-restart L-BFGS-B loop on `obj_func(x) -> (value, dx)` (host; every
     evaluation is one device call through the acquisition object).
     Anything else ("MIES", "OnePlusOne_Cholesky_CMA", constraints under "BFGS", a non-continuous space) is the
     reference's own business: the call is handed to its `argmax_restart` when `bayes_optim` is importable, for which a
     bogp criterion is an ordinary callable; without the reference, NotImplementedError.
     """
-    ours = optimizer in DEVICE_DESIGNS or optimizer in ("sweep", "sweep-BFGS")
+    ours = optimizer in DEVICE_DESIGNS or optimizer in ("sweep", "sweep-BFGS", "sweep-device-BFGS")
     if not ours and (optimizer != "BFGS" or h is not None or g is not None or not is_continuous(search_space)):
         ref = _reference_argmax_restart()
         if ref is None:
@@ -368,6 +369,21 @@ def argmax_restart(
                 "and 'sweep-BFGS' on continuous spaces" % optimizer)  # fmt: skip
         return ref(obj_func, search_space, h=h, g=g, eval_budget=eval_budget, n_restart=n_restart, wait_iter=wait_iter,
                    optimizer=optimizer, logger=logger)  # fmt: skip
+    if optimizer == "sweep-device-BFGS":  # as "sweep-BFGS" with the candidates drawn on the GPU: nothing of size M on the host
+        crit, masks, _ = unwrap_criterion(obj_func)
+        if crit is None or masks is not None or h is not None or g is not None:
+            raise NotImplementedError("optimizer=%r takes an unconstrained bogp criterion without fixed variables" % optimizer)
+        rank, world = engine_rank_world(crit.model.engine)
+        if int(eval_budget) < world:
+            raise ValueError("%d candidates cannot be sharded over %d ranks" % (eval_budget, world))
+        k = int(max(1, min(n_restart, 32, int(eval_budget))))
+        tv, _, tx = sweep_topk_generated([crit], search_space, int(eval_budget), k, int(np.random.randint(0, 2**62)), rank, world)
+        ok = np.isfinite(tv[0])
+        if not ok.any():
+            return [], []
+        xp, fp = polish_topk(crit, tx[0][ok], np.array(search_space.bounds, dtype=float))
+        j = int(np.argmax(fp))
+        return xp[j].tolist(), float(fp[j])
     if optimizer in DEVICE_DESIGNS:  # candidates drawn on the GPU; the stream is seeded from the global np.random
         crit, masks, _ = unwrap_criterion(obj_func)
         if crit is None or masks is not None or h is not None or g is not None:

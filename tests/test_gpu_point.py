@@ -180,3 +180,30 @@ def test_sweep_bfgs_optimizer_uses_the_device_polish(eng):
     x2, f2 = bogp.argmax_restart(ei, box, eval_budget=20000, n_restart=16, optimizer="sweep-BFGS")
     assert len(x2) == d and f2 >= f1 and np.all(np.abs(x2) <= 5.0)
     np.testing.assert_allclose(np.ravel(ei(np.array([x2])))[0], f2, rtol=1e-9)
+
+
+def test_large_batches_are_served_in_chunks(eng):
+    """More rows than one launch takes (the right-hand sides of a chunk are capped at 256 MB / 4096 points): every row
+    still equals its one-row answer, whatever chunk it fell into."""
+    rng = np.random.default_rng(5)
+    N, d, B = 300, 4, 5000
+    X = rng.uniform(-5, 5, size=(N, d))
+    y = np.sum(np.sin(X), axis=1).reshape(-1, 1)
+    y = (y - y.mean()) / y.std()
+    par = np.r_[np.full(d, 0.1), 0.9]
+    eng.set_train(X, y)
+    eng.commit(O.KERNEL_MATERN32, O.MODE_NOISY, par, 1e-5, True, 0.0)
+    Xb = rng.uniform(-5, 5, size=(B, d))
+    acq = [(O.ACQ_EI, 0.0), (O.ACQ_UCB, 0.5)]
+    pl = float(y.min())
+    mu, mse, dmu, dmse, vals, dvals = eng.point_eval_batch(Xb, acq, pl, True)
+    assert mu.shape == (B,) and dvals.shape == (B, 2, d)
+    for i in (0, 1, 4095, 4096, 4097, B - 1):
+        m1, s1, a1, b1, v1 = eng.point_eval(Xb[i], acq, pl, True)
+        np.testing.assert_allclose([m1, s1], [mu[i], mse[i]], rtol=1e-11, atol=1e-14)
+        np.testing.assert_allclose(a1, dmu[i], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(v1, vals[i], rtol=1e-9, atol=1e-300)
+    st = O.make_state(par, X, y, O.KERNEL_MATERN32, O.MODE_NOISY, 1e-5, estimate_trend=True)
+    omu, omse = O.predict(st, Xb)
+    np.testing.assert_allclose(mu, omu.ravel(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(mse, omse.ravel(), rtol=1e-6, atol=1e-12 * float(st.sigma2[0]))

@@ -107,8 +107,9 @@ def one(seed, eng, orc):
     if grad:
         if not close(got[0], ref[0], tol, tol):
             fails.append("llf %r vs %r" % (got[0], ref[0]))
-        if not close(np.ravel(got[1]), np.ravel(ref[1]), 1e-5, 1e-6 * (1 + np.abs(ref[1]).max())):
-            fails.append("grad max diff %g" % np.abs(np.ravel(got[1]) - np.ravel(ref[1])).max())
+        gtol = 1e-5 * max(1.0, ptol / 1e-6)  # the gradient's traces go through R^-1: cond(R) eps on both sides, like the posterior
+        if not close(np.ravel(got[1]), np.ravel(ref[1]), gtol, 0.1 * gtol * (1 + np.abs(ref[1]).max())):
+            fails.append("grad max diff %g (|grad| %.3g, cond %.1e)" % (np.abs(np.ravel(got[1]) - np.ravel(ref[1])).max(), np.abs(ref[1]).max(), cond))
     elif not close(got, ref, tol, tol):
         fails.append("llf %r vs %r" % (got, ref))
     try:
@@ -140,6 +141,33 @@ def one(seed, eng, orc):
                 fails.append("input gradient max diff %g / %g" % (np.abs(np.ravel(gm) - np.ravel(rm)).max(), np.abs(np.ravel(gv) - np.ravel(rv_)).max()))
         except (_lib.BogpError, NotImplementedError) as e:
             fails.append("gradient raised %s" % type(e).__name__)
+        # ... the batched one-point path (r03: k_point_rhs / k_point_tri / k_point_finish) at B random rows: posterior, input
+        # gradients, and the criteria's own values against the sweep kernel's
+        if True:
+            B = int(rng.choice([1, 2, 3, 17, 40]))
+            Xb = rng.uniform(-5, 5, (B, d))
+            pacq = [(int(rng.integers(0, 4)), float(rng.uniform(0.1, 3.0))) for _ in range(int(rng.integers(1, 4)))]
+            try:
+                pm, ps, pdm, pds, pv, pdv = eng.point_eval_batch(Xb, pacq, float(y.min()), True)
+                eng.upload_candidates(Xb)
+                orc.upload_candidates(Xb)
+                rm2, rs2 = orc.predict()
+                if not close(pm, rm2, ptol, 1e-7 * ptol / 1e-6 * mscale) or not close(ps, rs2, ptol, 1e-7 * ptol / 1e-6 * s2):
+                    fails.append("point batch B=%d: mu / mse max diff %g / %g" % (B, np.abs(pm - np.ravel(rm2)).max(), np.abs(ps - np.ravel(rs2)).max()))
+                for bb in range(min(B, 3)):
+                    rm, rv_ = orc.gradient(Xb[bb])
+                    if not close(pdm[bb], rm, ptol, 1e-8 * ptol / 1e-6) or not close(pds[bb], rv_, ptol, 1e-8 * ptol / 1e-6 * s2):
+                        fails.append("point batch B=%d row %d: gradient max diff %g / %g" % (B, bb, np.abs(pdm[bb] - np.ravel(rm)).max(), np.abs(pds[bb] - np.ravel(rv_)).max()))
+                _, _, sv = eng.sweep(pacq, float(y.min()), True, return_values=True)
+                solid = np.ravel(rs2) > 1e-9 * s2
+                if not close(pv[solid], sv.T[solid], 1e-6, 1e-300):
+                    fails.append("point batch B=%d: criteria differ from the sweep's by %g" % (B, np.nanmax(np.abs(pv[solid] - sv.T[solid]))))
+                if not np.all(np.isfinite(pdv[solid])):
+                    fails.append("point batch B=%d: non-finite criterion gradient" % B)
+            except (_lib.BogpError, NotImplementedError) as e:
+                fails.append("point_eval_batch raised %s" % type(e).__name__)
+            eng.upload_candidates(Xs)
+            orc.upload_candidates(Xs)
         # ... and the restricted likelihood (gpr.py:813-918) at [theta, sigma2(, noise_var)]
         if len(theta) == d:
             rpar = np.r_[theta, 0.8] if mode != O.MODE_NOISE_ESTIM else np.r_[theta, 0.8, 1e-3]
@@ -170,8 +198,8 @@ def one(seed, eng, orc):
             v = rv[c]
             if not (np.isnan(v[int(i[c])]) or abs(v[int(i[c])] - v[int(ri[c])]) <= max(1e-9, 1e-3 * ptol) * (abs(v[int(ri[c])]) + 1e-300)):
                 fails.append("argmax[%d] %d vs %d (values %r / %r)" % (c, i[c], ri[c], v[int(i[c])], v[int(ri[c])]))
-        elif abs(rb[c]) > 1e50 and abs(b[c]) > 1e50 and np.sign(b[c]) == np.sign(rb[c]):
-            # MGFI far out on its exponential (exp of several hundred): a relative error e in the exponent is e |exponent| in the
+        elif abs(rb[c]) > 1e10 and abs(b[c]) > 1e10 and np.sign(b[c]) == np.sign(rb[c]):
+            # MGFI far out on its exponential (exp of tens to hundreds): a relative error e in the exponent is e |exponent| in the
             # value, so the exponents are what can be compared at the posterior's tolerance
             if not close(np.log(abs(b[c])), np.log(abs(rb[c])), ptol, 0.0):
                 fails.append("best[%d] %r vs %r (exponents differ)" % (c, b[c], rb[c]))

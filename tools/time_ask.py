@@ -43,3 +43,22 @@ for opt in ("sweep", "sweep-device"):
             ts.append(time.perf_counter() - t0)
         assert len(xs) == q and len({tuple(x) for x in xs}) == q
         print("ask(): optimizer=%-12s n_point=%d  M=%d: %.1f ms (min of 3; %s)" % (opt, q, M, min(ts) * 1e3, ", ".join("%.1f" % (t * 1e3) for t in ts)))
+
+# r03: the single-proposal inner maximisers behind `argmax_restart`'s signature, as BO.ask() (n_point = 1) reaches them:
+#   "BFGS"        the reference's DEFAULT for a GP on a real space (base.py:200-214): 100 d = 2000 one-point evaluations of
+#                 EI(x, return_dx=True), each one bogp_point_eval round trip
+#   "sweep-BFGS"  one sweep of M candidates, its top-32 polished in lock step on the device (bogp_polish)
+ei = bogp.EI(model=gp, minimize=True)
+box = bogp.optim.Box([(-5.0, 5.0)] * d, random_seed=5)
+for opt, kw in (("BFGS", dict(eval_budget=100 * d, n_restart=10, wait_iter=3)), ("sweep-BFGS", dict(eval_budget=M, n_restart=32)),
+                ("sweep-device-BFGS", dict(eval_budget=M, n_restart=32)), ("sweep-device-BFGS", dict(eval_budget=100_000, n_restart=32)),
+                ("sweep-device", dict(eval_budget=M))):
+    np.random.seed(2)
+    bogp.argmax_restart(ei, box, optimizer=opt, **kw)  # warm-up
+    ts, fs = [], []
+    for rep in range(3):
+        t0 = time.perf_counter()
+        x, f = bogp.argmax_restart(ei, box, optimizer=opt, **kw)
+        ts.append(time.perf_counter() - t0)
+        fs.append(f)
+    print("ask(): argmax_restart(EI, optimizer=%-10s %s): %.1f ms (min of 3; best EI found %.4g)" % (opt + ",", ", ".join("%s=%s" % kv for kv in kw.items()), min(ts) * 1e3, max(fs)))
