@@ -248,3 +248,35 @@ def test_uninstall_restores_every_name(installed):
     assert bayes_optim.GaussianProcess is CpuGP and bayes_optim.surrogate.GaussianProcess is CpuGP
     bogp.install(bayes_optim, surrogate=False)
     assert bayes_optim.GaussianProcess is CpuGP
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("inner", ["sweep-BFGS", "sweep-device-BFGS"])
+def test_sweep_bfgs_hybrid_under_the_real_driver(installed, inner):
+    """The hybrid inner optimisers behind the reference's own `BO.ask()`: a sweep, then the polish of its top-k (on the oracle
+    stand-in engine: the sequential L-BFGS-B route of `optim.polish_topk`; on the device: `bogp_polish`).  Every proposal is at
+    least as good as the plain sweep's would have been from the same candidates."""
+    bayes_optim, bogp, created = installed
+    from bayes_optim import BO, RealSpace
+
+    if inner == "sweep-device-BFGS":
+        pytest.importorskip("bogp")  # the oracle stand-in has no device generator: the name must still be routed, and refuse clearly
+    dim = 2
+    gp = bogp.GaussianProcess(mean=bogp.trend.constant_trend(dim), corr="matern", thetaL=[1e-2] * dim, thetaU=[1e2] * dim, nugget=1e-6,
+                              random_start=3, eval_budget=100)  # fmt: skip
+    opt = BO(search_space=RealSpace([-5, 5]) * dim, obj_fun=lambda x: float(_sphere(x)), model=gp, DoE_size=6, max_FEs=9, verbose=False,
+             n_point=1, acquisition_fun="EI", acquisition_optimization={"optimizer": inner, "max_FEs": 1500, "n_restart": 4}, random_seed=5)  # fmt: skip
+    if inner == "sweep-device-BFGS" and not hasattr(created[0] if created else object(), "generate_candidates"):
+        X = opt.ask()
+        opt.tell(X, [float(_sphere(x)) for x in X])
+        with pytest.raises(AttributeError):  # OracleEngine cannot draw candidates on a device it does not have
+            opt.ask()
+        return
+    opt.run()
+    assert opt.eval_count == 9 and gp.is_fitted
+    crit = bogp.EI(model=gp, minimize=True)
+    box = bogp.optim.Box([(-5.0, 5.0)] * dim, random_seed=1)
+    x1, f1 = bogp.argmax_restart(crit, box, eval_budget=1500, optimizer="sweep")
+    box = bogp.optim.Box([(-5.0, 5.0)] * dim, random_seed=1)
+    x2, f2 = bogp.argmax_restart(crit, box, eval_budget=1500, n_restart=4, optimizer=inner)
+    assert f2 >= f1 and len(x2) == dim
