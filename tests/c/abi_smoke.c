@@ -82,6 +82,21 @@ int main(int argc, char** argv) {
       free(xb);
       free(xr);
     }
+    { /* the consumption path of the reference's inner optimisers through the same boundary (r03): one point with the moments
+         and the criterion's input-gradient; then the sweep's winner polished on the device */
+      double* x0 = (double*)malloc(sizeof(double) * d);
+      double* xo = (double*)malloc(sizeof(double) * d);
+      double* dmu = (double*)malloc(sizeof(double) * d);
+      double* dms = (double*)malloc(sizeof(double) * d);
+      double* dei = (double*)malloc(sizeof(double) * d);
+      double pmu = 0.0, pms = 0.0, pei = 0.0, fo = 0.0;
+      int ne = 0;
+      CHECK(bogp_candidates_read(h, &idx, 1, x0));
+      CHECK(bogp_point_eval_batch(h, x0, 1, 1, acq_id, acq_par, ymin, 1, &pmu, &pms, dmu, dms, &pei, dei));
+      CHECK(bogp_polish(h, x0, 1, lo, hi, BOGP_ACQ_EI, 0.0, ymin, 1, 50, 1e-8, 1e6, xo, &fo, &ne));
+      printf("point %.17g %.17g %.17g %.17g %.17g\npolish %.17g %d %.17g\n", pmu, pms, pei, dmu[0], dei[d - 1], fo, ne, xo[0]);
+      free(x0); free(xo); free(dmu); free(dms); free(dei);
+    }
     free(mu);
     free(mse);
   }

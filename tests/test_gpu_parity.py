@@ -1106,7 +1106,7 @@ def test_plain_c_client_gets_the_same_numbers(tmp_path):
     exe = _build_c_client(tmp_path)
     res = subprocess.run([exe, str(N), str(d), str(M), str(seed)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr
-    keys = ("llf", "best", "mu0", "mse0", "exchange")  # (librccl prints a version banner on stdout when it initialises)
+    keys = ("llf", "best", "mu0", "mse0", "exchange", "point", "polish")  # (librccl prints a version banner on stdout when it initialises)
     got = {ln.split()[0]: [float(v) for v in ln.split()[1:]] for ln in res.stdout.strip().splitlines() if ln.split() and ln.split()[0] in keys}
     s = seed
     X = np.empty((N, d))
@@ -1135,6 +1135,13 @@ def test_plain_c_client_gets_the_same_numbers(tmp_path):
     assert got["exchange"][0] == got["best"][0] and int(got["exchange"][1]) == int(idx[0]) + 1000
     assert (int(got["exchange"][2]), int(got["exchange"][3])) == (0, 1)
     assert got["exchange"][4] == got["exchange"][5] == e.read_candidates(idx)[0, d - 1]
+    # the r03 entry points through the same boundary: one point (sweep's winner) and its polish
+    x0 = e.read_candidates(idx)[0]
+    pm, ps, pdm, pds, pv, pdv = e.point_eval_batch(x0[None, :], [(O.ACQ_EI, 0.0)], float(y.min()), True)
+    np.testing.assert_allclose(got["point"], [pm[0], ps[0], pv[0, 0], pdm[0, 0], pdv[0, 0, d - 1]], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(pv[0, 0], best[0], rtol=1e-9)  # the one-point kernels and the sweep agree on the winner's EI
+    xo, fo, ne = e.polish(x0[None, :], np.full(d, -5.0), np.full(d, 5.0), (O.ACQ_EI, 0.0), float(y.min()), True, max_evals=50)
+    assert got["polish"][0] == fo[0] and int(got["polish"][1]) == int(ne[0]) and got["polish"][2] == xo[0, 0] and fo[0] >= best[0] * (1 - 1e-12)
     # and the oracle agrees with both
     st = O.make_state(par, X, y.reshape(-1, 1), O.KERNEL_MATERN32, O.MODE_NOISY, 1e-6)
     from oracle import philox as P
