@@ -747,18 +747,26 @@ extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* p
   // the blocked Cholesky applies explicit inverses of its diagonal blocks (conditionally backward stable), which at
   // cond(R) ~ 1e12 left the posterior mean ~100x further from the exact one than a LAPACK solve (profiles/r03_refine_inverse.txt,
   // r03_refine_gamma.txt).  gamma += L^-T L^-1 (b - R gamma): one N^2 d pass + two triangular matrix-vector products, at
-  // commit only.  Constant basis (estimated or fixed beta); BOGP_REFINE_GAMMA=0 switches it off.
+  // commit only, every trend basis (b = y - F beta with the committed coefficients); BOGP_REFINE_GAMMA=0 switches it off.
   {
     static const int steps = [] { const char* e = getenv("BOGP_REFINE_GAMMA"); return e ? atoi(e) : 1; }();
-    if (steps > 0 && trend_size(trend, d) == 1) {
-      int e = ensure(h, &h->dbatch, &h->batch_cap, (size_t)3 * N);
+    const int pt = trend_size(trend, d);
+    if (steps > 0) {
+      int e = ensure(h, &h->dbatch, &h->batch_cap, (size_t)4 * N);
       if (e) return e;
-      double *dres = h->dbatch, *dt1 = dres + N, *dt2 = dt1 + N;
+      double *dres = h->dbatch, *dt1 = dres + N, *dt2 = dt1 + N, *db = dt2 + N;
       for (int t = 0; t < h->n_t; ++t) {
         double* g = h->dgamma_base + (size_t)t * Np;
+        const double* yt_ = h->dy_base + (size_t)t * N;
+        if (pt == 1) {
+          HIPCHK(h, launch_sub_const(yt_, o.beta, db, N, st));  // b = y - beta 1
+        } else {  // b = y - F beta with the committed coefficients (fixed, or the GLS estimate of trend_solve)
+          const double one = 1.0, mone = -1.0;
+          HIPCHK(h, hipMemcpyAsync(db, yt_, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st));
+          BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, N, pt, &mone, h->dF, N, h->dbetav, 1, &one, db, 1));
+        }
         for (int it = 0; it < steps; ++it) {
-          HIPCHK(h, launch_resid_gamma(kernel, h->R_div, h->dX, N, d, h->dtheta, h->R_a, h->R_b, h->R_diag, h->dy_base + (size_t)t * N,
-                                       o.beta, g, dres, st));
+          HIPCHK(h, launch_resid_gamma(kernel, h->R_div, h->dX, N, d, h->dtheta, h->R_a, h->R_b, h->R_diag, db, g, dres, st));
           HIPCHK(h, launch_gemv2(h->dV, ldr, N, 1, dres, nullptr, dt1, nullptr, h->dgemv_scratch, st));
           HIPCHK(h, launch_gemv2(h->dU, ldr, N, 2, dt1, nullptr, dt2, nullptr, h->dgemv_scratch, st));
           HIPCHK(h, launch_add_vec(g, dt2, N, st));

@@ -123,7 +123,8 @@ hipError_t launch_build_R(int kernel, const double* X, int N, int d, const doubl
 hipError_t launch_build_R_div(int kernel, const double* X, int N, int d, const double* theta, double mul, double div,
                               double diag, double* R, int ld, hipStream_t st);
 hipError_t launch_resid_gamma(int kernel, bool div, const double* X, int N, int d, const double* theta, double a, double b,
-                              double diag, const double* y, double beta, const double* gamma, double* res, hipStream_t st);
+                              double diag, const double* bvec, const double* gamma, double* res, hipStream_t st);
+hipError_t launch_sub_const(const double* y, double c, double* out, int N, hipStream_t st);
 hipError_t launch_add_vec(double* y, const double* x, int N, hipStream_t st);
 hipError_t launch_scale_transpose(const double* X, int N, int d, int Np, const double* sqrt_theta, double* XthT,
                                   hipStream_t st);

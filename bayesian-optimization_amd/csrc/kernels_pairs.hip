@@ -207,14 +207,14 @@ hipError_t launch_build_R_div(int kernel, const double* X, int N, int d, const d
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// res_i = (y_i - beta) - sum_j R_ij gamma_j  with R recomputed from X exactly as k_build_R formed it (same expressions, so
+// res_i = b_i - sum_j R_ij gamma_j (b = y - F beta, formed by the caller) with R recomputed from X exactly as k_build_R formed it (same expressions, so
 // the residual is taken against the matrix that was factorised): the right-hand side of one step of iterative refinement
 // of gamma = R^-1 (y - beta 1) at commit (bogp_api.hip: refine_gamma).  One workgroup per 64 rows walks all column tiles;
 // the sum over j runs in a fixed order (tile by tile, then the 16 thread columns): deterministic.
 // ---------------------------------------------------------------------------------------------------------------
 template <int KERNEL, bool DIV>
 __global__ __launch_bounds__(256) void k_resid_gamma(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
-                                                     double a, double b, double diag, const double* __restrict__ y, double beta,
+                                                     double a, double b, double diag, const double* __restrict__ bvec,
                                                      const double* __restrict__ gamma, double* __restrict__ res) {
   __shared__ double xi[KC * PP], xj[KC * PP];
   __shared__ double red[16][PT + 1];
@@ -276,21 +276,29 @@ __global__ __launch_bounds__(256) void k_resid_gamma(const double* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 16; ++t) s += red[t][tid];
     const int i = i0 + tid;
-    if (i < N) res[i] = (y[i] - beta) - s;
+    if (i < N) res[i] = bvec[i] - s;
   }
 }
 
 hipError_t launch_resid_gamma(int kernel, bool div, const double* X, int N, int d, const double* theta, double a, double b,
-                              double diag, const double* y, double beta, const double* gamma, double* res, hipStream_t st) {
+                              double diag, const double* bvec, const double* gamma, double* res, hipStream_t st) {
   const int nt = (N + PT - 1) / PT;
 #define CALL(K)                                                                                                          \
-  if (div) hipLaunchKernelGGL((k_resid_gamma<K, true>), dim3(nt), 256, 0, st, X, N, d, theta, a, b, diag, y, beta, gamma, res); \
-  else hipLaunchKernelGGL((k_resid_gamma<K, false>), dim3(nt), 256, 0, st, X, N, d, theta, a, b, diag, y, beta, gamma, res)
+  if (div) hipLaunchKernelGGL((k_resid_gamma<K, true>), dim3(nt), 256, 0, st, X, N, d, theta, a, b, diag, bvec, gamma, res); \
+  else hipLaunchKernelGGL((k_resid_gamma<K, false>), dim3(nt), 256, 0, st, X, N, d, theta, a, b, diag, bvec, gamma, res)
   BOGP_FOR_KERNEL_R(kernel, CALL)
 #undef CALL
   return hipGetLastError();
 }
 
+__global__ void k_sub_const(const double* __restrict__ y, double c, double* __restrict__ out, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) out[i] = y[i] - c;
+}
+hipError_t launch_sub_const(const double* y, double c, double* out, int N, hipStream_t st) {
+  hipLaunchKernelGGL(k_sub_const, dim3((N + 255) / 256), 256, 0, st, y, c, out, N);
+  return hipGetLastError();
+}
 __global__ void k_add_vec(double* __restrict__ y, const double* __restrict__ x, int N) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) y[i] += x[i];
