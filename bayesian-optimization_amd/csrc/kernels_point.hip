@@ -145,11 +145,13 @@ __device__ __forceinline__ void acq_grad_coef(int id, double par, double y, doub
 // deals the columns to that many workgroups per row block as well (latency of ONE point: chains nsplit times shorter,
 // more waves per CU); their partial C tiles meet in a scratch slab and the last arriver of the row block (a per-row-block
 // ticket) adds them in fixed order -- still deterministic.  Few VGPRs (the accumulators: 2 NC) => 8 waves per SIMD.
-template <int NC>
+// ROWS = rows of V per lane (1 or 2): with two, a scalar rhs row feeds 44 FMAs instead of 22.  Built to test whether the scalar
+// loads bound the batched rate: they do not (neutral, profiles/r03_point_tri_ab.txt); the default is ROWS = 1.
+template <int NC, int ROWS>
 __global__ __launch_bounds__(256) void k_point_tri(const double* __restrict__ V, const double* __restrict__ gamma,
                                                    const double* __restrict__ wvec, const double* __restrict__ rhs_all,
                                                    PointTriArgs a) {
-  constexpr int RB = 64;
+  constexpr int RB = 64 * ROWS;
   __shared__ double Cs[RB][NC];
   __shared__ bool s_last;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -162,25 +164,34 @@ __global__ __launch_bounds__(256) void k_point_tri(const double* __restrict__ V,
   const int nend = special ? a.Nr32 : min(j0 + RB, a.ld);  // columns [0, nend): V is exactly zero above its diagonal
   const double* __restrict__ rhs = rhs_all + ((size_t)b * a.npass + g) * (size_t)a.Npp * NC;
 
-  double acc[NC];
+  double acc[ROWS][NC];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
   const double* __restrict__ vcol = V + j0 + lane;
+  const bool second = ROWS > 1 && j0 + 64 + lane < a.ld;  // (ld is a multiple of 64, not of 128: the last block may be half)
   if (special) {
 #pragma unroll 2
     for (int n = 4 * sp + wv; n < nend; n += 4 * S) {
       const double v = lane == 0 ? gamma[n] : (lane == 1 ? wvec[n] : 0.0);
       const double* __restrict__ rr = rhs + (size_t)n * NC;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) acc[c] = __builtin_fma(v, rr[c], acc[c]);
+      for (int c = 0; c < NC; ++c) acc[0][c] = __builtin_fma(v, rr[c], acc[0][c]);
     }
   } else {
 #pragma unroll 2
     for (int n = 4 * sp + wv; n < nend; n += 4 * S) {
-      const double v = vcol[(size_t)n * a.ld];
+      double v[ROWS];
+      v[0] = vcol[(size_t)n * a.ld];
+      if (ROWS > 1) v[ROWS - 1] = second ? vcol[(size_t)n * a.ld + 64] : 0.0;
       const double* __restrict__ rr = rhs + (size_t)n * NC;  // wave-uniform: scalar loads, SGPR operands
 #pragma unroll
-      for (int c = 0; c < NC; ++c) acc[c] = __builtin_fma(v, rr[c], acc[c]);
+      for (int c = 0; c < NC; ++c) {
+        const double rc = rr[c];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) acc[r][c] = __builtin_fma(v[r], rc, acc[r][c]);
+      }
     }
   }
   // the 4 waves add their tiles in fixed order ((w0 + w1) + w2) + w3 in LDS
@@ -188,7 +199,9 @@ __global__ __launch_bounds__(256) void k_point_tri(const double* __restrict__ V,
   for (int w = 0; w < 4; ++w) {
     if (wv == w) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) Cs[lane][c] = w == 0 ? acc[c] : Cs[lane][c] + acc[c];
+      for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) Cs[64 * r + lane][c] = w == 0 ? acc[r][c] : Cs[64 * r + lane][c] + acc[r][c];
     }
     __syncthreads();
   }
@@ -496,21 +509,28 @@ hipError_t launch_point_rhs(int kernel, const PointRhsArgs& a, int B, hipStream_
 // chip -- 16 splits for one point (47 vs 168 us unsplit), 8 for 8 points, 4 from 32 points up (179 vs 283 us at B = 32).
 void point_tri_geometry(int N, int d, int B, int* rb, int* nsplit) {
   const int npass = point_passes(d);
-  const long long wgs = (long long)((N + 63) / 64 + 1) * npass * B;
+  // rows of V per lane: 2 halves the scalar rhs traffic per FMA -- measured NEUTRAL (524 vs 525 us at B = 128): what bounds the
+  // batched rate is the V stream from L2 (8 bytes per 22 FMAs, ~4 TB/s at B = 128), not the rhs (profiles/r03_point_tri_ab.txt)
+  int rows = 1;
+  if (const char* e = getenv("BOGP_POINT_ROWS")) rows = atoi(e) == 2 ? 2 : 1;  // A/B switch
+  const int r = 64 * rows;
+  const long long wgs = (long long)((N + r - 1) / r + 1) * npass * B;
   int s = wgs < 128 ? 16 : (wgs < 512 ? 8 : 4);
   if (const char* e = getenv("BOGP_POINT_SPLIT")) s = std::max(1, atoi(e));  // A/B switch
   s = std::max(1, std::min(s, (N + 15) / 16));  // at least ~4 columns per wave and split
-  *rb = 64;
+  *rb = r;
   *nsplit = s;
 }
 
 hipError_t launch_point_tri(const PointTriArgs& a, int B, hipStream_t st) {
   dim3 grid((a.nRB + 1) * a.nsplit, a.npass, B);
   if (point_columns_per_pass(a.d) == 12) {
-    hipLaunchKernelGGL(k_point_tri<12>, grid, 256, 0, st, a.V, a.gamma, a.wvec, a.rhs, a);
+    if (a.rb == 128) hipLaunchKernelGGL((k_point_tri<12, 2>), grid, 256, 0, st, a.V, a.gamma, a.wvec, a.rhs, a);
+    else hipLaunchKernelGGL((k_point_tri<12, 1>), grid, 256, 0, st, a.V, a.gamma, a.wvec, a.rhs, a);
     hipLaunchKernelGGL(k_point_finish<12>, dim3(B), 256, 0, st, a);
   } else {
-    hipLaunchKernelGGL(k_point_tri<22>, grid, 256, 0, st, a.V, a.gamma, a.wvec, a.rhs, a);
+    if (a.rb == 128) hipLaunchKernelGGL((k_point_tri<22, 2>), grid, 256, 0, st, a.V, a.gamma, a.wvec, a.rhs, a);
+    else hipLaunchKernelGGL((k_point_tri<22, 1>), grid, 256, 0, st, a.V, a.gamma, a.wvec, a.rhs, a);
     hipLaunchKernelGGL(k_point_finish<22>, dim3(B), 256, 0, st, a);
   }
   return hipGetLastError();
