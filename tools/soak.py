@@ -45,6 +45,13 @@ def main():
         if trend == 0 and n_t == 1:
             mu, mse, dmu, dmse, v = eng.point_eval(X[0] + 0.1, [(0, 0.0)], float(y.min()), True)
             assert np.isfinite(mu) and mse >= 0 and np.all(np.isfinite(dmu))
+            B = int(rng.integers(1, 70))  # r03: the batched flavour and the lock-step polish, sizes changing every cycle
+            Xb = rng.uniform(-5, 5, (B, d))
+            out = eng.point_eval_batch(Xb, [(0, 0.0), (2, 0.5)], float(y.min()), True)
+            assert np.all(np.isfinite(out[0])) and np.all(out[1] >= 0) and out[5].shape == (B, 2, d)
+            if d <= 64 and it % 3 == 0:
+                Xp, fp, ne = eng.polish(Xb[: min(B, 16)], [-5.0] * d, [5.0] * d, (2, 0.5), float(y.min()), True, max_evals=12)
+                assert np.all(np.isfinite(fp)) and np.all(Xp >= -5) and np.all(Xp <= 5)
         if it == 20:
             base = used_mb()
     mid = used_mb()
