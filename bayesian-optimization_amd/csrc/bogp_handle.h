@@ -130,6 +130,7 @@ struct bogp_handle {
   double* hpin = nullptr;  // pinned host buffer the finishing workgroup writes its records into (device-mapped)
   double* hpin_dev = nullptr;
   size_t hpin_cap = 0;
+  unsigned long long pt_seq = 0;  // sequence number of the last one-point call (completion word behind its record)
 
   // timing of the last sweep/predict
   std::vector<hipEvent_t> ev;

@@ -212,6 +212,8 @@ struct PointTriArgs {
   int acq_id[64];
   double acq_par[64];
   double plugin, beta, G, ftft, sigma2;
+  unsigned long long* done_flag;  // device-mapped pinned word k_point_finish stores `done_seq` into last (one-point calls), or null
+  unsigned long long done_seq;
 };
 struct PolishArgs {
   double* state;        // [B][state_stride]

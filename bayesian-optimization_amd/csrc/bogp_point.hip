@@ -1,6 +1,8 @@
 // bogp_point.hip -- C ABI of the one-point / B-point consumption path (kernels_point.hip): bogp_point_eval,
 // bogp_point_eval_batch, bogp_gradient_batch, bogp_polish.  See include/bogp.h for the contracts.
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -66,7 +68,8 @@ int ensure_pinned(bogp_handle* h, size_t n) {
 
 // queue k_point_rhs + k_point_tri for B points; the records land in `out` (device or device-mapped host memory)
 int queue_point_eval(bogp_handle* h, const PointPlan& pl, const double* dXb, const double* x_host, int B, int q, const int* acq_id,
-                     const double* acq_par, double plugin, int minimize, bool want_dacq, double* out) {
+                     const double* acq_par, double plugin, int minimize, bool want_dacq, double* out,
+                     unsigned long long* done_flag = nullptr, unsigned long long done_seq = 0) {
   hipStream_t st = h->stream;
   int e;
   if ((e = ensure(h, &h->dpt_rhs, &h->pt_rhs_cap, (size_t)B * pl.npass * pl.Npp * pl.NC))) return e;
@@ -100,6 +103,7 @@ int queue_point_eval(bogp_handle* h, const PointPlan& pl, const double* dXb, con
   ta.minimize = minimize;
   for (int i = 0; i < q; ++i) { ta.acq_id[i] = acq_id[i]; ta.acq_par[i] = acq_par ? acq_par[i] : 0.0; }
   ta.plugin = plugin; ta.beta = h->beta; ta.G = h->G; ta.ftft = h->ftft; ta.sigma2 = h->sigma2;
+  ta.done_flag = done_flag; ta.done_seq = done_seq;
   HIPCHK(h, launch_point_tri(ta, B, st));
   return BOGP_OK;
 }
@@ -127,15 +131,33 @@ static int point_eval_chunk(bogp_handle* h, const double* Xb, int B, int q, cons
   const size_t nrec = (size_t)B * pl.rec_stride;
   int e;
   // the finishing workgroups write straight into pinned host memory: one stream synchronisation, no copy command
-  if ((e = ensure_pinned(h, std::max<size_t>(nrec, 1024)))) return e;
+  if ((e = ensure_pinned(h, std::max<size_t>(nrec + 8, 1024)))) return e;
   const double* dXb = nullptr;
   if (B > 1 || d > BOGP_POINT_ARG_D) {
     if ((e = ensure(h, &h->dpt_Xb, &h->pt_Xb_cap, (size_t)B * d))) return e;
     HIPCHK(h, hipMemcpyAsync(h->dpt_Xb, Xb, (size_t)B * d * sizeof(double), hipMemcpyHostToDevice, st));
     dXb = h->dpt_Xb;
   }
-  if ((e = queue_point_eval(h, pl, dXb, Xb, B, q, acq_id, acq_par, plugin, minimize, want_dacq, h->hpin_dev))) return e;
-  HIPCHK(h, hipStreamSynchronize(st));
+  // One point (the BFGS loop's call): completion is read off a sequence word the finishing workgroup stores behind the record
+  // (pinned memory, system-scope release) -- polling it costs less than a stream synchronisation (profiles/r03_point_call_latency.txt);
+  // bounded: after ~2 ms of polling the ordinary synchronisation takes over.  BOGP_POINT_POLL=0 disables.
+  static const bool poll = [] { const char* e_ = getenv("BOGP_POINT_POLL"); return !(e_ && atoi(e_) == 0); }();
+  if (B == 1 && poll) {
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->hpin + nrec);
+    const unsigned long long seq = ++h->pt_seq;
+    unsigned long long* dflag = reinterpret_cast<unsigned long long*>(h->hpin_dev + nrec);
+    if ((e = queue_point_eval(h, pl, dXb, Xb, B, q, acq_id, acq_par, plugin, minimize, want_dacq, h->hpin_dev, dflag, seq))) return e;
+    bool seen = false;
+    for (int spin = 0; spin < 400000; ++spin) {
+      if (*flag == seq) { seen = true; break; }
+      __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen) HIPCHK(h, hipStreamSynchronize(st));
+  } else {
+    if ((e = queue_point_eval(h, pl, dXb, Xb, B, q, acq_id, acq_par, plugin, minimize, want_dacq, h->hpin_dev))) return e;
+    HIPCHK(h, hipStreamSynchronize(st));
+  }
   for (int b = 0; b < B; ++b) {
     const double* o = h->hpin + (size_t)b * pl.rec_stride;
     if (mu) mu[b] = o[0];

@@ -321,6 +321,15 @@ __global__ __launch_bounds__(256) void k_point_finish(PointTriArgs a) {
       }
     }
   }
+  // one-point calls: the record went straight into pinned host memory; a sequence word behind it (written after every
+  // storing thread's system-scope fence) lets the host see completion by polling that word instead of waiting for the stream
+  if (a.done_flag) {
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
