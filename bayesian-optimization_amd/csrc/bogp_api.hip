@@ -67,6 +67,20 @@ extern "C" int bogp_create(int device, bogp_handle** out) {
   // the factorisation's info word lives in the same block as its scalars (doubles 62-63): ONE read-back fetches both
   h->dinfo = reinterpret_cast<rocblas_int*>(h->dscal + 62);
   rocblas_set_pointer_mode(h->blas, rocblas_pointer_mode_host);
+  if (const char* e = getenv("BOGP_CHOL_RESERVE_CU")) {
+    // experiment (tools/ab_big_chol_cumask.sh): the look-ahead update of the two-level factorisation on a stream that may
+    // not use the last n CUs (mask bit i -> XCD i % 8, so n / 8 CUs per XCD stay free for the panel chain on the main stream)
+    const int n = atoi(e);
+    if (n > 0 && n < h->n_cu) {
+      uint32_t mask[16] = {0};
+      for (int i = 0; i < h->n_cu - n && i < 512; ++i) mask[i >> 5] |= 1u << (i & 31);
+      if (hipExtStreamCreateWithCUMask(&h->stream_upd, (uint32_t)((h->n_cu + 31) / 32), mask) != hipSuccess) {
+        g_create_error = "hipExtStreamCreateWithCUMask failed";
+        delete h;
+        return BOGP_ERR_HIP;
+      }
+    }
+  }
   if (hipEventCreateWithFlags(&h->ev_chol[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_chol[1], hipEventDisableTiming) != hipSuccess) {
     g_create_error = "event creation failed";
@@ -103,6 +117,7 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   point_release(h);
   free_train(h);
   (void)hipStreamSynchronize(h->stream2);
+  if (h->stream_upd) (void)hipStreamSynchronize(h->stream_upd);
   dfree(h->dXs_owned); dfree(h->dss_part); dfree(h->dbounds); dfree(h->dsobol); dfree(h->dxform);
   for (int b = 0; b < 2; ++b) { dfree(h->drT[b]); dfree(h->dmu_part[b]); dfree(h->dw_part[b]); }
   dfree(h->dblk_val); dfree(h->dblk_idx); dfree(h->dmu_out); dfree(h->dmse_out); dfree(h->dacq_out);
@@ -114,6 +129,7 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   if (h->blas) rocblas_destroy_handle(h->blas);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
+  if (h->stream_upd) (void)hipStreamDestroy(h->stream_upd);
   delete h;
 }
 
@@ -403,7 +419,7 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   //   Yt = V y (:799), Ft = V 1 (:803)              one pass over V
   //   rho (:806 / :808), |Ft|, Ft.Yt, rho.rho       k_fit_rho
   //   gamma = U rho (:788 / :996)
-  HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st, h->stream2, h->ev_chol, h->dT));  // dT: free until the inverse
+  HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st, h->stream_upd ? h->stream_upd : h->stream2, h->ev_chol, h->dT));  // dT: free until the inverse
   HIPCHK(h, launch_logdet(h->dR, N, ldr, h->dscal, st));
   HIPCHK(h, launch_tri_inverse(h->dR, h->ddinv, h->dV, h->dU, h->dT, ldr, st));
   if (refine_wanted()) {

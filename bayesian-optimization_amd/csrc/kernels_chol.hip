@@ -742,6 +742,9 @@ struct MmArgs {
   int kp0, kp1;
   int cj0, cj1;
   int TI, TJ;  // logical tile grid of one z / y slice
+  int fixed;   // experiment BOGP_MM128_FIXED=1
+  int order;   // 1: workgroups walk the live tiles in order of decreasing K (pairs flattened into x)
+  int fp, nl;  // MM_T / V / U with order: full pairs of the level, live 128-tiles of block 22 in the partial last pair (0: none)
 };
 
 // workgroup -> tile.  Hardware deals consecutive workgroups round-robin to the 8 XCDs, each with its own L2.  The grid is
@@ -765,8 +768,36 @@ __device__ __forceinline__ bool mm_tile_of(int TI, int TJ, int& ti, int& tj) {
 __global__ __launch_bounds__(256, 2) void k_mm128(MmArgs a, int mode0) {
   extern __shared__ __attribute__((aligned(16))) double mm_lds[];
   const int mode = mode0 + (int)blockIdx.z;
-  int ti, tj;
-  if (!mm_tile_of(a.TI, a.TJ, ti, tj)) return;
+  int ti, tj, pair = (int)blockIdx.y;
+  if (a.order && mode != MM_SYRK) {
+    // Longest K first, only tiles that exist: the dispatcher hands out workgroups in index order as slots free up, and
+    // consecutive indices go to different XCDs -- every XCD sees the same mix of long and short tiles.  (The products are not
+    // bound by operand traffic -- identical times with every k-row at one address -- so the XCD-local super tiles of
+    // mm_tile_of bought nothing and cost balance: profiles/r03_mm128_order_ab.txt.)  Empty workgroups in the queue would
+    // steer the real ones onto a subset of the CUs (measured at N = 6144), hence the compaction over the partial last pair:
+    // fp full pairs, and nl < nb2 live tile rows / columns of block 22 in one more pair.
+    const int q = (int)blockIdx.x, nb2 = a.nb2, fp = a.fp, nl = a.nl;
+    if (mode == MM_UUT) {  // row ti has ti + 1 tiles, K shrinks with ti
+      ti = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
+      while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
+      while (ti * (ti + 1) / 2 > q) --ti;
+      tj = q - ti * (ti + 1) / 2;
+    } else if (mode == MM_T) {  // K = (nb2 - ti) tiles; tj runs over the live columns of block 22
+      const int per = fp * nb2 + nl;
+      ti = q / per;
+      const int rem = q - ti * per;
+      if (rem < fp * nb2) { pair = rem / nb2; tj = rem - pair * nb2; }
+      else { pair = fp; tj = rem - fp * nb2; }
+    } else {  // MM_V (MM_U): K = (nb2 - prim) tiles with row (column) nb2 - 1 - prim of block 22, live in the last pair from prim >= nb2 - nl
+      const int p0 = nb2 - nl, perA = fp * nb2, perB = perA + (nl > 0 ? nb2 : 0);
+      const int cntA = p0 * perA;
+      int rem;
+      if (q < cntA) { ti = q / perA; rem = q - ti * perA; }
+      else { const int q2 = q - cntA; ti = p0 + q2 / perB; rem = q2 - (ti - p0) * perB; }
+      pair = rem / nb2;
+      tj = rem - pair * nb2;
+    }
+  } else if (!mm_tile_of(a.TI, a.TJ, ti, tj)) return;
   const int ld = a.ld;
   MmTile t;
   t.ldr = t.ldc = t.ldo = ld;
@@ -790,7 +821,7 @@ __global__ __launch_bounds__(256, 2) void k_mm128(MmArgs a, int mode0) {
     t.beta = 1;
   } else {
     const int nb2 = a.nb2;
-    const int o11 = 2 * (int)blockIdx.y * nb2, o22 = o11 + nb2;
+    const int o11 = 2 * pair * nb2, o22 = o11 + nb2;
     const int n22 = min(nb2, a.nt - o22);
     if (mode == MM_T) {  // Tt(c, r) = sum_{k >= c} U11(c, k) L21(r, k): c in block 11 (ti), r in block 22 (tj)
       if (tj >= n22) return;
@@ -823,6 +854,7 @@ __global__ __launch_bounds__(256, 2) void k_mm128(MmArgs a, int mode0) {
       t.alpha = -1.0;
     }
   }
+  if (a.fixed) t.ldr = t.ldc = 0;  // experiment: every k-row of the operands at one address (no L2 / HBM traffic)
   mm128_tile(t, mm_lds);
 }
 
@@ -864,6 +896,27 @@ static hipError_t launch_mm128(MmArgs a, int mode, int TI, int TJ, int ny, int n
   }
   a.TI = TI;
   a.TJ = TJ;
+  static const int fixed = [] { const char* e = getenv("BOGP_MM128_FIXED"); return e ? atoi(e) : 0; }();
+  a.fixed = fixed;
+  static const int order = [] { const char* e = getenv("BOGP_MM128_ORDER"); return e ? atoi(e) : 1; }();
+  a.order = order;
+  if (order && mode != MM_SYRK && nz == 1) {
+    unsigned count;
+    if (mode == MM_UUT) {
+      count = (unsigned)(TI * (TI + 1) / 2);
+    } else {  // ny pairs of diagonal blocks of nb2 tiles each; block 22 of the last pair may be cut by the matrix edge
+      const int nb2 = a.nb2;
+      const int n22_last = max(0, min(nb2, a.nt - (2 * (ny - 1) * nb2 + nb2)));
+      a.fp = n22_last == nb2 ? ny : ny - 1;
+      a.nl = n22_last == nb2 ? 0 : n22_last;
+      count = mode == MM_T ? (unsigned)(nb2 * (a.fp * nb2 + a.nl))
+                           : (unsigned)((nb2 - a.nl) * a.fp * nb2 + a.nl * (a.fp + (a.nl > 0 ? 1 : 0)) * nb2);
+    }
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mm128, dim3(count, 1, 1), 256, shm, st, a, mode);
+    return hipGetLastError();
+  }
+  a.order = 0;
   const int nsuper = ((TI + 7) / 8) * ((TJ + 7) / 8);
   hipLaunchKernelGGL(k_mm128, dim3((unsigned)(nsuper * 64), ny, nz), 256, shm, st, a, mode);
   return hipGetLastError();
