@@ -298,7 +298,7 @@ __device__ __forceinline__ void mfma16_acc(double a, double b, d4& c) {
 // 16 passes: the result of the last MFMA must not be read by the VALU before it has left the pipe
 #define BOGP_MFMA16_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
 
-template <int NR, int TP = PITCH>
+template <int NR>
 __device__ __forceinline__ void contract_block16(const bool GUARDED, const double* __restrict__ tile, const double2* __restrict__ vp,
                                                  const size_t (&boff)[NR], const int (&jt)[NR], int aoff, int kb, int kp_last,
                                                  double2 (&bq)[4][NR], d4 (&acc)[MR][NR]) {
@@ -320,7 +320,7 @@ __device__ __forceinline__ void contract_block16(const bool GUARDED, const doubl
     for (int h = 0; h < 2; ++h) {
       const int sub = 2 * s + h;
       if (sub < 7) {
-        const double* trow = tile + (4 * (sub + 1)) * TP;
+        const double* trow = tile + (4 * (sub + 1)) * PITCH;
 #pragma unroll
         for (int mi = 0; mi < MR; ++mi) af[(sub + 1) & 1][mi] = trow[aoff + 16 * mi];
       }
@@ -464,134 +464,6 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Kernel B'': k_contract16 with 64-row stages (two 32-row blocks per barrier; BOGP_CONTRACT_STAGE=2).  Same tiles, same
-// MFMA order per accumulator (bit-identical sums); the r tile of a stage is 64 x 80 doubles = 40 KB, two buffers = 80 KB of
-// dynamic LDS per workgroup -- two workgroups still fit the CU's 160 KB.  One register set of eight 16-byte loads per
-// thread, requested at the top of stage s for stage s + 1 (one stage = the same cover as the two-blocks-ahead scheme above).
-// ---------------------------------------------------------------------------------------------------
-template <int NR, int WP>
-__global__ __launch_bounds__(256, 2) void k_contract16w(ContractArgs a) {
-  constexpr int JT16 = NWJ * NR;
-  constexpr int SR = 2 * KB;  // rows per stage
-  extern __shared__ __attribute__((aligned(16))) double ldsw[];  // [2][SR][WP]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nMt = a.nMt;
-  const int jg = a.nJ - 1 - (int)(blockIdx.x / nMt);
-  const int mt = blockIdx.x % nMt;
-  const int64_t mc0 = (int64_t)mt * 64;
-  const int NJ16 = a.NJ16, NKP = a.NKP;
-  const int kmax16 = min((jg + 1) * JT16, NJ16);
-  const int nkb = kmax16 >> 1;
-  const int nkb_full = jg * (JT16 / 2);
-  const int kp_last = 2 * kmax16 - 1;
-  const int nst = (nkb + 1) >> 1;
-
-  int jt[NR];
-  size_t boff[NR];
-  bool valid[NR];
-#pragma unroll
-  for (int ni = 0; ni < NR; ++ni) {
-    const int j = jg * JT16 + ((ni & 1) ? NWJ * (ni + 1) - 1 - w : NWJ * ni + w);
-    valid[ni] = j < NJ16;
-    jt[ni] = valid[ni] ? j : -1;
-    boff[ni] = (size_t)min(j, NJ16 - 1) * NKP * 64;
-  }
-
-  d4 acc[MR][NR];
-#pragma unroll
-  for (int mi = 0; mi < MR; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NR; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
-
-  const int srow = tid >> 5;
-  const int scol = (tid & 31) * 2;
-  const double* __restrict__ rbase = a.rT + mc0 + scol;
-  const size_t Mc = (size_t)a.Mc;
-  const int last_row0 = (nkb - 1) * KB;  // first row of the last valid 32-row block
-  double2 s0, s1, s2, s3, s4, s5, s6, s7;
-  // rows of the second half of an odd last stage are clamped into the last valid block (loaded twice, never contracted)
-#define BOGP_STAGEW_LOAD(st_)                                                                        \
-  do {                                                                                               \
-    const int r0_ = (st_)*SR;                                                                        \
-    const int r1_ = min(r0_ + KB, last_row0);                                                        \
-    const double* p_ = rbase + (size_t)(r0_ + srow) * Mc;                                            \
-    const double* q_ = rbase + (size_t)(r1_ + srow) * Mc;                                            \
-    s0 = *reinterpret_cast<const double2*>(p_);                                                      \
-    s1 = *reinterpret_cast<const double2*>(p_ + 8 * Mc);                                             \
-    s2 = *reinterpret_cast<const double2*>(p_ + 16 * Mc);                                            \
-    s3 = *reinterpret_cast<const double2*>(p_ + 24 * Mc);                                            \
-    s4 = *reinterpret_cast<const double2*>(q_);                                                      \
-    s5 = *reinterpret_cast<const double2*>(q_ + 8 * Mc);                                             \
-    s6 = *reinterpret_cast<const double2*>(q_ + 16 * Mc);                                            \
-    s7 = *reinterpret_cast<const double2*>(q_ + 24 * Mc);                                            \
-  } while (0)
-#define BOGP_STAGEW_STORE(buf_)                                                                      \
-  do {                                                                                               \
-    double* q_ = &ldsw[(buf_)*SR * WP + srow * WP + scol];                                           \
-    *reinterpret_cast<double2*>(q_) = s0;                                                            \
-    *reinterpret_cast<double2*>(q_ + 8 * WP) = s1;                                                   \
-    *reinterpret_cast<double2*>(q_ + 16 * WP) = s2;                                                  \
-    *reinterpret_cast<double2*>(q_ + 24 * WP) = s3;                                                  \
-    *reinterpret_cast<double2*>(q_ + 32 * WP) = s4;                                                  \
-    *reinterpret_cast<double2*>(q_ + 40 * WP) = s5;                                                  \
-    *reinterpret_cast<double2*>(q_ + 48 * WP) = s6;                                                  \
-    *reinterpret_cast<double2*>(q_ + 56 * WP) = s7;                                                  \
-  } while (0)
-
-  const double2* __restrict__ vp = a.Vp + lane;
-  double2 bq[4][NR];
-#pragma unroll
-  for (int ni = 0; ni < NR; ++ni) {
-    bq[0][ni] = vp[boff[ni]];
-    bq[1][ni] = vp[boff[ni] + (size_t)min(1, kp_last) * 64];
-  }
-  const int aoff = (lane >> 4) * WP + (lane & 15);
-
-  BOGP_STAGEW_LOAD(0);
-  BOGP_STAGEW_STORE(0);
-  for (int s = 0; s < nst; ++s) {
-    __syncthreads();  // stage s is in buffer s & 1; every wave is done with the other buffer
-    BOGP_STAGEW_LOAD(min(s + 1, nst - 1));
-    const double* tile = &ldsw[(s & 1) * SR * WP];
-    contract_block16<NR, WP>(2 * s >= nkb_full, tile, vp, boff, jt, aoff, 2 * s, kp_last, bq, acc);
-    if (2 * s + 1 < nkb)
-      contract_block16<NR, WP>(2 * s + 1 >= nkb_full, tile + KB * WP, vp, boff, jt, aoff, 2 * s + 1, kp_last, bq, acc);
-    BOGP_STAGEW_STORE((s + 1) & 1);
-  }
-#undef BOGP_STAGEW_LOAD
-#undef BOGP_STAGEW_STORE
-
-  BOGP_MFMA16_DRAIN();
-  __syncthreads();
-  constexpr int RP = 65;
-  double* red = ldsw;
-  double* red2 = ldsw + 16 * NWJ * RP;
-  const int q = lane >> 4, jc = lane & 15;
-#pragma unroll
-  for (int mi = 0; mi < MR; ++mi)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double s = 0.0;
-#pragma unroll
-      for (int ni = 0; ni < NR; ++ni)
-        if (valid[ni]) s = __builtin_fma(acc[mi][ni][r], acc[mi][ni][r], s);
-      red[(jc * NWJ + w) * RP + 16 * mi + 4 * r + q] = s;
-    }
-  __syncthreads();
-  {
-    double s = 0.0;
-#pragma unroll
-    for (int sl = 0; sl < 16; ++sl) s += red[(sl * NWJ + w) * RP + lane];
-    red2[w * 64 + lane] = s;
-  }
-  __syncthreads();
-  if (tid < 64) a.ss_part[(size_t)jg * a.Mc + mc0 + tid] = ((red2[tid] + red2[64 + tid]) + red2[128 + tid]) + red2[192 + tid];
-}
-
-// ---------------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------------
 hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipStream_t st) {
@@ -640,30 +512,7 @@ static bool contract_use_16x16() {
   return v;
 }
 
-static int contract_stage() {
-  static int v = [] {
-    const char* e = getenv("BOGP_CONTRACT_STAGE");  // 2: 64-row stages, pitch 80; 3: 64-row stages, pitch 72
-    return e ? atoi(e) : 1;
-  }();
-  return v;
-}
-
-template <int WP>
-static hipError_t launch_contract16w(const ContractArgs& a, hipStream_t st) {
-  constexpr int shm = 2 * 2 * KB * WP * (int)sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_contract16w<4, WP>), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((k_contract16w<4, WP>), dim3((unsigned)(a.nMt * a.nJ)), 256, shm, st, a);
-  return hipGetLastError();
-}
-
 hipError_t launch_contract(const ContractArgs& a, hipStream_t st) {
-  if (contract_use_16x16() && contract_nr() == 4 && contract_stage() == 2) return launch_contract16w<PITCH>(a, st);
-  if (contract_use_16x16() && contract_nr() == 4 && contract_stage() == 3) return launch_contract16w<72>(a, st);
   if (contract_use_16x16() && contract_nr() == 4) {
     hipLaunchKernelGGL(k_contract16<4>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
     return hipGetLastError();

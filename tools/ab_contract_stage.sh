@@ -1,4 +1,4 @@
-# A/B of the stage depth of the triangular contraction at C3 and C5-size (r03): BOGP_CONTRACT_STAGE=1 (32-row stages, k_contract16),
+# A/B of the stage depth of the triangular contraction at C3 and C5-size (r03; the k_contract16w variant it switched on was removed after the measurement: profiles/r03_contract_stage_ab.txt, git babf07a):
 # 2 (64-row stages, pitch 80, k_contract16w), 3 (64-row stages, pitch 72).
 for st in 1 2 3 1 2 3; do
 echo "== stage $st"
