@@ -703,6 +703,8 @@ __device__ __forceinline__ void mm128_tile(const MmTile& t, double* lds) {
             rf[(ks + 1) & 1][f] = tb[roff + 4 * (ks + 1) * MPT + 16 * f];
             cf[(ks + 1) & 1][f] = tb[coff + 4 * (ks + 1) * MPT + 16 * f];
           }
+          // (pinning these reads ahead of the MFMAs of k-step ks with sched_barrier / sched_group_barrier measured -1 %:
+          // the second wave of the SIMD already covers the LDS round trips -- profiles/r03_mm128_order_ab.txt)
         }
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci)
@@ -888,9 +890,10 @@ static bool big_chol(int ld) {
 
 static hipError_t launch_mm128(MmArgs a, int mode, int TI, int TJ, int ny, int nz, hipStream_t st) {
   constexpr int shm = 2 * 2 * MKB * MPT * (int)sizeof(double);  // 73.7 KB: two stages of (row tile + column tile)
+  auto kern = &k_mm128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm128), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
@@ -913,12 +916,12 @@ static hipError_t launch_mm128(MmArgs a, int mode, int TI, int TJ, int ny, int n
                            : (unsigned)((nb2 - a.nl) * a.fp * nb2 + a.nl * (a.fp + (a.nl > 0 ? 1 : 0)) * nb2);
     }
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_mm128, dim3(count, 1, 1), 256, shm, st, a, mode);
+    hipLaunchKernelGGL(kern, dim3(count, 1, 1), 256, shm, st, a, mode);
     return hipGetLastError();
   }
   a.order = 0;
   const int nsuper = ((TI + 7) / 8) * ((TJ + 7) / 8);
-  hipLaunchKernelGGL(k_mm128, dim3((unsigned)(nsuper * 64), ny, nz), 256, shm, st, a, mode);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nsuper * 64), ny, nz), 256, shm, st, a, mode);
   return hipGetLastError();
 }
 
