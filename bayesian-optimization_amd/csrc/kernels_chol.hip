@@ -313,6 +313,15 @@ __global__ __launch_bounds__(256) void k_chol_panel(const double* __restrict__ W
     for (int t = 0; t < 4; ++t) Pb[(size_t)(16 * mi + 4 * t + lk) * ld + 16 * w + (lane & 15)] = acc[mi][t];
 }
 
+// q -> (bi, bj), bj <= bi, row by row: only live tiles are launched (an m x m grid whose upper half exits at once costs
+// dispatch time and skews the placement of the live workgroups over the CUs)
+__device__ __forceinline__ void tri_index(int q, int& bi, int& bj) {
+  bi = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
+  while ((bi + 1) * (bi + 2) / 2 <= q) ++bi;
+  while (bi * (bi + 1) / 2 > q) --bi;
+  bj = q - bi * (bi + 1) / 2;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Update with `np` consecutive, already solved block columns (panels) starting at column kp0: for every 64 x 64 output
 // block (bi, bj), bj <= bi, of the region whose first row / column is o0:  A_ij -= sum_p X_p(i) X_p(j)^T, X_p = A[:, kp0 +
@@ -323,11 +332,18 @@ __global__ __launch_bounds__(256) void k_chol_panel(const double* __restrict__ W
 // block column -- what a pair step applies first).  The panels are read-only here: disjoint from everything written.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int ld, int kp0, int np, int o0, int m, int nc,
-                                                     double* __restrict__ Wn, int* __restrict__ info, double* __restrict__ Pnext) {
+                                                     double* __restrict__ Wn, int* __restrict__ info, double* __restrict__ Pnext,
+                                                     int tri_grid) {
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];  // 40 KB: A-side tile, then the 64 x 65 block staging
   __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
-  const int bi = blockIdx.x / nc, bj = blockIdx.x % nc;
-  if (bj > bi) return;
+  int bi, bj;
+  if (nc == m && tri_grid) {
+    tri_index((int)blockIdx.x, bi, bj);
+  } else {
+    bi = blockIdx.x / nc;
+    bj = blockIdx.x % nc;
+    if (bj > bi) return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i0 = o0 + CB * bi, j0 = o0 + CB * bj;  // first row / column of the output block
@@ -395,11 +411,17 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int ld, int k0, int m, const double* __restrict__ Wk,
                                                    const double* __restrict__ Pcur, double* __restrict__ Pnext,
-                                                   double* __restrict__ Wn, int* __restrict__ info) {
+                                                   double* __restrict__ Wn, int* __restrict__ info, int tri_grid) {
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
   __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
-  const int bi = blockIdx.x / m, bj = blockIdx.x % m;
-  if (bj > bi) return;
+  int bi, bj;
+  if (tri_grid) {
+    tri_index((int)blockIdx.x, bi, bj);
+  } else {
+    bi = blockIdx.x / m;
+    bj = blockIdx.x % m;
+    if (bj > bi) return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i0 = k0 + CB * (1 + bi), j0 = k0 + CB * (1 + bj);
@@ -950,7 +972,7 @@ static hipError_t launch_chol_lower_big(double* A, int ld, double* Winv, int* in
       const int nc = kend - 1 - k;  // block columns of this panel still to the right of k
       if (nc > 0)
         hipLaunchKernelGGL(k_chol_update, dim3(m * nc), 256, 0, st, A, ld, k0, 1, k0 + CB, m, nc,
-                           Winv + (size_t)(k + 1) * CB * CB, info, (double*)nullptr);
+                           Winv + (size_t)(k + 1) * CB * CB, info, (double*)nullptr, 0);
     }
     if (kend < nb) {
       MmArgs a{};
@@ -1083,20 +1105,25 @@ hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStre
                                     (size_t)(ld - CB) * sizeof(double), CB, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return e;
   }
+  static const int tri = [] {  // 0: the r02 m x m grids whose upper half exits at once (A/B: tools/ab_chol_tri.sh)
+    const char* e = getenv("BOGP_CHOL_TRI_GRID");
+    return e ? atoi(e) : 1;
+  }();
   for (int kbeg = 0; kbeg + 1 < nb; kbeg += G) {
     for (int k = kbeg; k < kbeg + G && k + 1 < nb; ++k) {
       const int k0 = k * CB;
       const int m = nb - k - 1;
       const bool next_fused = can_fuse && m - 1 >= 1 && m - 1 <= fuse_max;
       if (can_fuse && m <= fuse_max) {
-        hipLaunchKernelGGL(k_chol_step, dim3(m * m), 256, 0, st, A, ld, k0, m, Winv + (size_t)k * CB * CB, panel_copy(k),
-                           panel_copy(k + 1), Winv + (size_t)(k + 1) * CB * CB, info);
+        hipLaunchKernelGGL(k_chol_step, dim3(tri ? m * (m + 1) / 2 : m * m), 256, 0, st, A, ld, k0, m, Winv + (size_t)k * CB * CB,
+                           panel_copy(k), panel_copy(k + 1), Winv + (size_t)(k + 1) * CB * CB, info, tri);
         continue;
       }
       hipLaunchKernelGGL(k_chol_panel, dim3(m), 256, 0, st, Winv + (size_t)k * CB * CB, A + (size_t)k0 * ld + k0 + CB, ld);
       const bool last = k == kbeg + G - 1;
-      hipLaunchKernelGGL(k_chol_update, dim3(last ? m * m : m), 256, 0, st, A, ld, kbeg * CB, k - kbeg + 1, k0 + CB, m, last ? m : 1,
-                         Winv + (size_t)(k + 1) * CB * CB, info, next_fused ? panel_copy(k + 1) : (double*)nullptr);
+      hipLaunchKernelGGL(k_chol_update, dim3(last ? (tri ? m * (m + 1) / 2 : m * m) : m), 256, 0, st, A, ld, kbeg * CB, k - kbeg + 1,
+                         k0 + CB, m, last ? m : 1, Winv + (size_t)(k + 1) * CB * CB, info,
+                         next_fused ? panel_copy(k + 1) : (double*)nullptr, tri);
     }
   }
   return hipGetLastError();

@@ -13,7 +13,7 @@ from bogp import _lib  # noqa: E402
 def main():
     eng = _lib.Engine(0)
     print("%6s %4s %9s %10s %14s %8s" % ("N", "d", "M", "ms/sweep", "candidates/s", "TFLOP/s"))
-    for N, d in ((128, 5), (512, 10), (2048, 20), (8192, 50)):
+    for N, d in ((128, 5), (256, 10), (384, 10), (512, 10), (2048, 20), (8192, 50)):
         rng = np.random.default_rng(0)
         X = rng.uniform(-5, 5, size=(N, d))
         y = np.sum(X**2, axis=1)
