@@ -99,10 +99,10 @@ def load():
             "libbogp.so not found at %s -- build it with `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH
         )
-    # Load order matters: the PyTorch wheel bundles its own libamdhip64 / librocblas / librocsolver with the SAME
-    # sonames as /opt/rocm's.  The dynamic loader keeps whichever copy comes first, and torch crashes when it is
-    # handed the system copies; the other way round (libbogp on torch's copies) works.  So torch goes first
-    # whenever it is installed (it provides torch.distributed for the multi-GPU exchange anyway).
+    # Load order matters: the PyTorch wheel bundles its own libamdhip64 (the only ROCm library libbogp.so needs; it links
+    # no BLAS) with the SAME soname as /opt/rocm's.  The dynamic loader keeps whichever copy comes first, and torch
+    # crashes when it is handed the system copy; the other way round (libbogp on torch's copy) works.  So torch goes
+    # first whenever it is installed (it provides torch.distributed for the multi-GPU exchange anyway).
     try:
         import torch  # noqa: F401
     except ImportError:

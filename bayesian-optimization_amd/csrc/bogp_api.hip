@@ -2,7 +2,6 @@
 // fit path, and the chunked posterior/acquisition sweep.  No host fallback exists: every numerical step runs on
 // the gfx950 device, and every failure is reported as an error code + message.
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
 
 #include <algorithm>
 #include <cmath>
@@ -57,16 +56,13 @@ extern "C" int bogp_create(int device, bogp_handle** out) {
   if (hipSetDevice(device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess ||
       hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
       hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_least) != hipSuccess ||
-      rocblas_create_handle(&h->blas) != rocblas_status_success ||
-      rocblas_set_stream(h->blas, h->stream) != rocblas_status_success ||
       hipMalloc((void**)&h->dscal, 64 * sizeof(double)) != hipSuccess) {
-    g_create_error = "stream / rocBLAS handle creation failed";
+    g_create_error = "stream creation failed";
     delete h;
     return BOGP_ERR_HIP;
   }
   // the factorisation's info word lives in the same block as its scalars (doubles 62-63): ONE read-back fetches both
-  h->dinfo = reinterpret_cast<rocblas_int*>(h->dscal + 62);
-  rocblas_set_pointer_mode(h->blas, rocblas_pointer_mode_host);
+  h->dinfo = reinterpret_cast<int*>(h->dscal + 62);
   if (const char* e = getenv("BOGP_CHOL_RESERVE_CU")) {
     // experiment (tools/ab_big_chol_cumask.sh): the look-ahead update of the two-level factorisation on a stream that may
     // not use the last n CUs (mask bit i -> XCD i % 8, so n / 8 CUs per XCD stay free for the panel chain on the main stream)
@@ -92,7 +88,8 @@ extern "C" int bogp_create(int device, bogp_handle** out) {
 }
 
 static void free_trend(bogp_handle* h) {
-  dfree(h->dF); dfree(h->dFt); dfree(h->dQ1); dfree(h->dQ); dfree(h->dWp);
+  dfree(h->dF); dfree(h->dFt); dfree(h->dQ1); dfree(h->dQ); dfree(h->dWp); dfree(h->dWpT); dfree(h->dSinvP);
+  dfree(h->gsplit.scratch); dfree(h->gsplit.tickets); h->gsplit.cap = 0; h->gsplit.max_tiles = 0;
   for (int b = 0; b < 2; ++b) { dfree(h->dA[b]); dfree(h->dAV[b]); dfree(h->dAU[b]); }
   dfree(h->dAw); dfree(h->dAT); dfree(h->dGinv); dfree(h->dSinv); dfree(h->dbetav); dfree(h->dqty); dfree(h->dinfo2);
   h->tr_built = -1; h->tr_p = 0; h->ldp = 0; h->trend = BOGP_TREND_CONSTANT; h->p = 1; h->reml_ftf_basis = -1;
@@ -126,7 +123,6 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   for (auto e : h->ev) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; ++i)
     if (h->ev_chol[i]) (void)hipEventDestroy(h->ev_chol[i]);
-  if (h->blas) rocblas_destroy_handle(h->blas);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream_upd) (void)hipStreamDestroy(h->stream_upd);
@@ -261,6 +257,8 @@ static int ensure_trend(bogp_handle* h, int trend) {
     HIPCHK(h, hipMalloc((void**)&h->dQ1, np_ * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->dQ, np_ * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->dWp, (size_t)Np * p * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dWpT, (size_t)Np * ((p + 127) / 128 * 128) * sizeof(double)));
+    HIPCHK(h, hipMalloc((void**)&h->dSinvP, (size_t)((p + 127) / 128 * 128) * ((p + 127) / 128 * 128) * sizeof(double)));
     for (int b = 0; b < 2; ++b) {
       HIPCHK(h, hipMalloc((void**)&h->dA[b], pp * sizeof(double)));
       HIPCHK(h, hipMalloc((void**)&h->dAV[b], pp * sizeof(double)));
@@ -274,8 +272,15 @@ static int ensure_trend(bogp_handle* h, int trend) {
     HIPCHK(h, hipMalloc((void**)&h->dSinv, (size_t)p * p * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->dbetav, p * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->dqty, p * sizeof(double)));
-    HIPCHK(h, hipMalloc((void**)&h->dinfo2, 2 * sizeof(rocblas_int)));
-    HIPCHK(h, hipMemsetAsync(h->dinfo2, 0, 2 * sizeof(rocblas_int), st));
+    HIPCHK(h, hipMalloc((void**)&h->dinfo2, 2 * sizeof(int)));
+    if (!h->gsplit.scratch) {  // split-K scratch of k_gemm64: tiles x slices <= 512 partial tiles of 64 x 64 (16 MB), 128 ticket words
+      h->gsplit.max_tiles = 128;
+      h->gsplit.cap = (size_t)512 * 64 * 64;
+      HIPCHK(h, hipMalloc((void**)&h->gsplit.scratch, h->gsplit.cap * sizeof(double)));
+      HIPCHK(h, hipMalloc((void**)&h->gsplit.tickets, 128 * sizeof(unsigned int)));
+      HIPCHK(h, hipMemsetAsync(h->gsplit.tickets, 0, 128 * sizeof(unsigned int), st));
+    }
+    HIPCHK(h, hipMemsetAsync(h->dinfo2, 0, 2 * sizeof(int), st));
     h->tr_p = p;
     h->ldp = ldp;
     h->tr_built = -1;
@@ -299,29 +304,29 @@ static int trend_solve(bogp_handle* h, int trend, int estimate_trend) {
   const int N = h->N, p = h->tr_p, ldp = h->ldp, ldr = h->ldr;
   hipStream_t st = h->stream;
   const double one = 1.0, zero = 0.0, mone = -1.0;
-  BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_none, N, p, N, &one, h->dV, ldr, h->dF, N, &zero, h->dFt, N));
+  HIPCHK(h, launch_gemm(0, 0, N, p, N, one, h->dV, ldr, h->dF, N, zero, h->dFt, N, st, 1, &h->gsplit));  // V lower, zero upper triangle
   HIPCHK(h, hipMemcpyAsync(h->drho, h->dyt, N * sizeof(double), hipMemcpyDeviceToDevice, st));
   if (!estimate_trend) {
     if ((int)h->h_beta_fixed.size() != p) FAIL(h, BOGP_ERR_INVALID, "trend with p = %d fixed coefficients: call bogp_set_trend_beta first (have %d)", p, (int)h->h_beta_fixed.size());
     HIPCHK(h, hipMemcpyAsync(h->dbetav, h->h_beta_fixed.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
-    BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, N, p, &mone, h->dFt, N, h->dbetav, 1, &one, h->drho, 1));  // :808
+    HIPCHK(h, launch_gemm(0, 0, N, 1, p, mone, h->dFt, N, h->dbetav, p, one, h->drho, N, st, 0, &h->gsplit));  // :808
     return BOGP_OK;
   }
   const double* src = h->dFt;
   for (int pass = 0; pass < 2; ++pass) {
     double* dst = pass == 0 ? h->dQ1 : h->dQ;
-    BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_transpose, rocblas_operation_none, p, p, N, &one, src, N, src, N, &zero, h->dA[pass], ldp));
+    HIPCHK(h, launch_gemm(1, 0, p, p, N, one, src, N, src, N, zero, h->dA[pass], ldp, st, 0, &h->gsplit));
     HIPCHK(h, launch_pad_identity(h->dA[pass], p, ldp, st));
     HIPCHK(h, launch_chol_lower(h->dA[pass], ldp, h->dAw, h->dinfo2 + pass, st));
     HIPCHK(h, launch_tri_inverse(h->dA[pass], h->dAw, h->dAV[pass], h->dAU[pass], h->dAT, ldp, st));
-    BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_none, N, p, p, &one, src, N, h->dAU[pass], ldp, &zero, dst, N));
+    HIPCHK(h, launch_gemm(0, 0, N, p, p, one, src, N, h->dAU[pass], ldp, zero, dst, N, st, 0, &h->gsplit));
     src = dst;
   }
-  BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_none, p, p, p, &one, h->dAU[0], ldp, h->dAU[1], ldp, &zero, h->dGinv, p));
-  BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, p, &one, h->dQ, N, h->dyt, 1, &zero, h->dqty, 1));
-  BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, N, p, &mone, h->dQ, N, h->dqty, 1, &one, h->drho, 1));  // :806
-  BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, p, p, &one, h->dGinv, p, h->dqty, 1, &zero, h->dbetav, 1));  // :785-787
-  BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_transpose, p, p, p, &one, h->dGinv, p, h->dGinv, p, &zero, h->dSinv, p));
+  HIPCHK(h, launch_gemm(0, 0, p, p, p, one, h->dAU[0], ldp, h->dAU[1], ldp, zero, h->dGinv, p, st, 0, &h->gsplit));
+  HIPCHK(h, launch_gemm(1, 0, p, 1, N, one, h->dQ, N, h->dyt, N, zero, h->dqty, p, st, 0, &h->gsplit));
+  HIPCHK(h, launch_gemm(0, 0, N, 1, p, mone, h->dQ, N, h->dqty, p, one, h->drho, N, st, 0, &h->gsplit));  // :806
+  HIPCHK(h, launch_gemm(0, 0, p, 1, p, one, h->dGinv, p, h->dqty, p, zero, h->dbetav, p, st, 0, &h->gsplit));  // :785-787
+  HIPCHK(h, launch_gemm(0, 1, p, p, p, one, h->dGinv, p, h->dGinv, p, zero, h->dSinv, p, st, 0, &h->gsplit));
   return BOGP_OK;
 }
 
@@ -330,26 +335,6 @@ struct FitPending {
   int mode = 0, estimate_trend = 0, ptrend = 1, n_t = 1, N = 0;
   double beta = 0, alpha = 0, sigma2_par = 0, noise_var = 0, s2t = 0;
 };
-// One Newton-Schulz step V <- V (2 I - L V) on the explicit inverse (opt-in: BOGP_REFINE_V=1).  The
-// recursive-doubling inverse carries a residual L V - I of order cond(L) eps; one step squares it.  Two library
-// triangular products (this is an accuracy experiment off the sweep path, see profiles/r03_refine_inverse.txt), results
-// into V (lower) and U = V^T.  Scratch: dT and the first slice of dRinv.
-static bool refine_wanted() {
-  static const bool on = [] { const char* e = getenv("BOGP_REFINE_V"); return e && atoi(e) != 0; }();
-  return on;
-}
-static int refine_inverse(bogp_handle* h, int N, int ldr, hipStream_t st) {
-  const double one = 1.0;
-  if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * h->cap_ld * h->cap_ld * sizeof(double)));
-  BLASCHK(h, rocblas_dtrmm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, N, &one,
-                           h->dR, ldr, h->dV, ldr, h->dT, ldr));  // T = L V
-  HIPCHK(h, launch_two_i_minus(h->dT, N, ldr, st));                // T = 2 I - L V
-  BLASCHK(h, rocblas_dtrmm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, N, &one,
-                           h->dV, ldr, h->dT, ldr, h->dRinv, ldr));  // W = V (2 I - L V)
-  HIPCHK(h, launch_refine_store(h->dRinv, h->dV, h->dU, N, ldr, st));
-  return BOGP_OK;
-}
-
 static int factorize_finish(bogp_handle* h, const FitPending& fp, int info, const double* sc, const int* info2,
                             bool reject_positive, FitOut* o);
 
@@ -422,10 +407,6 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st, h->stream_upd ? h->stream_upd : h->stream2, h->ev_chol, h->dT));  // dT: free until the inverse
   HIPCHK(h, launch_logdet(h->dR, N, ldr, h->dscal, st));
   HIPCHK(h, launch_tri_inverse(h->dR, h->ddinv, h->dV, h->dU, h->dT, ldr, st));
-  if (refine_wanted()) {
-    int er = refine_inverse(h, N, ldr, st);
-    if (er) return er;
-  }
   const int n_t = h->n_t;
   if (n_t > 1 && (ptrend != 1 || estimate_trend))
     FAIL(h, BOGP_ERR_UNSUPPORTED, "multi-target y (%d targets) is built for a FIXED constant trend only: with estimated coefficients the reference raises at gpr.py:787 (beta gets one row per target)", n_t);
@@ -455,10 +436,10 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   double blk[64];  // [0 .. 4 n_t): sum(log diag L), |Ft|, Ft.Yt, rho.rho (the last three per target); [62]: the info word
   HIPCHK(h, hipMemcpyAsync(blk, h->dscal, sizeof(blk), hipMemcpyDeviceToHost, st));
   const double* sc = blk;
-  rocblas_int info2[2] = {0, 0};
+  int info2[2] = {0, 0};
   if (ptrend > 1 && estimate_trend) HIPCHK(h, hipMemcpyAsync(info2, h->dinfo2, sizeof(info2), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
-  rocblas_int info = 0;
+  int info = 0;
   memcpy(&info, blk + 62, sizeof(info));
   return factorize_finish(h, fp, (int)info, sc, info2, reject_positive, o);
 }
@@ -600,7 +581,7 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
     const int info2[2] = {0, 0};
     HIPCHK(h, hipMemcpyAsync(blk, h->dscal, sizeof(blk), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
-    rocblas_int info = 0;
+    int info = 0;
     memcpy(&info, blk + 62, sizeof(info));
     rc = factorize_finish(h, fp, (int)info, blk, info2, true, &o);
     *llf = o.llf;
@@ -663,7 +644,7 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
     const int ldp = h->ldp;
     if (h->reml_ftf_basis != h->tr_built) {
       const double one = 1.0, zero = 0.0;
-      BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_transpose, rocblas_operation_none, ptrend, ptrend, N, &one, h->dF, N, h->dF, N, &zero, h->dAT, ldp));
+      HIPCHK(h, launch_gemm(1, 0, ptrend, ptrend, N, one, h->dF, N, h->dF, N, zero, h->dAT, ldp, st, 0, &h->gsplit));
       std::vector<double> a((size_t)ldp * ptrend);
       HIPCHK(h, hipMemcpyAsync(a.data(), h->dAT, a.size() * sizeof(double), hipMemcpyDeviceToHost, st));
       HIPCHK(h, hipStreamSynchronize(st));
@@ -712,9 +693,9 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
       // R^-1 as R^-1 - tv W S W^T (two library GEMMs with inner dimension p), after which the p = 1 code below applies
       // with no separate q vector: the contraction sees R^-1 - tv term, and its trace is tr(R^-1) - tv tr(term)
       const double one = 1.0, zero = 0.0, mtv = -tv;
-      BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_none, N, ptrend, N, &one, h->dU, ldr, h->dFt, N, &zero, h->dQ1, N));
-      BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_none, N, ptrend, ptrend, &one, h->dQ1, N, h->dSinv, ptrend, &zero, h->dWp, N));
-      BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_transpose, N, N, ptrend, &mtv, h->dWp, N, h->dQ1, N, &one, h->dRinv, ldr));
+      HIPCHK(h, launch_gemm(0, 0, N, ptrend, N, one, h->dU, ldr, h->dFt, N, zero, h->dQ1, N, st, 0, &h->gsplit));
+      HIPCHK(h, launch_gemm(0, 0, N, ptrend, ptrend, one, h->dQ1, N, h->dSinv, ptrend, zero, h->dWp, N, st, 0, &h->gsplit));
+      HIPCHK(h, launch_gemm(0, 1, N, N, ptrend, mtv, h->dWp, N, h->dQ1, N, one, h->dRinv, ldr, st, 0, &h->gsplit));
     } else if (estimate_trend) {  // q = L^-T Q = (L^-T Ft) / G
       HIPCHK(h, hipMemsetAsync(h->dw, 0, h->Np * sizeof(double), st));
       HIPCHK(h, launch_gemv2(h->dU, ldr, N, 2, h->dft, nullptr, h->dw, nullptr, h->dgemv_scratch, st));
@@ -779,7 +760,7 @@ extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* p
         } else {  // b = y - F beta with the committed coefficients (fixed, or the GLS estimate of trend_solve)
           const double one = 1.0, mone = -1.0;
           HIPCHK(h, hipMemcpyAsync(db, yt_, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st));
-          BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_none, N, pt, &mone, h->dF, N, h->dbetav, 1, &one, db, 1));
+          HIPCHK(h, launch_gemm(0, 0, N, 1, pt, mone, h->dF, N, h->dbetav, pt, one, db, N, st, 0, &h->gsplit));
         }
         for (int it = 0; it < steps; ++it) {
           HIPCHK(h, launch_resid_gamma(kernel, h->R_div, h->dX, N, d, h->dtheta, h->R_a, h->R_b, h->R_diag, db, g, dres, st));
@@ -806,7 +787,12 @@ extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* p
     if (estimate_trend) {  // W = L^-T Ft (N x p), zero rows in the padding
       const double one = 1.0, zero = 0.0;
       HIPCHK(h, hipMemsetAsync(h->dWp, 0, (size_t)Np * ptrend * sizeof(double), st));
-      BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_none, N, ptrend, N, &one, h->dU, ldr, h->dFt, N, &zero, h->dWp, Np));
+      HIPCHK(h, launch_gemm(0, 0, N, ptrend, N, one, h->dU, ldr, h->dFt, N, zero, h->dWp, Np, st, 0, &h->gsplit));
+      // the column sides of the two per-chunk trend products on k_mm128 (run_sweep): W^T and (Ft^T Ft)^-1, zero padded to 128 columns
+      const int pp = (ptrend + 127) / 128 * 128;
+      HIPCHK(h, launch_transpose_pad(h->dWp, Np, Np, ptrend, h->dWpT, pp, st));
+      HIPCHK(h, hipMemsetAsync(h->dSinvP, 0, (size_t)pp * pp * sizeof(double), st));
+      HIPCHK(h, launch_transpose_pad(h->dSinv, ptrend, ptrend, ptrend, h->dSinvP, pp, st));
       HIPCHK(h, hipMemcpyAsync(h->h_Sinv.data(), h->dSinv, (size_t)ptrend * ptrend * sizeof(double), hipMemcpyDeviceToHost, st));
     }
   }
@@ -1169,7 +1155,7 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
 
   // Small batches (the reference's one-point-per-call usage through L-BFGS-B): the tiled contraction would leave one
   // workgroup walking all N columns alone (~0.3 ms at N = 2048).  For M <= BOGP_SMALL_M the posterior is instead
-  // r -> rt = V r (rocBLAS dtrmm with M right-hand sides) -> column reductions, feeding the same acquisition kernel.
+  // r -> rt = V r (k_gemm64 with M right-hand sides) -> column reductions, feeding the same acquisition kernel.
   int small_m = 32;
   if (const char* env = getenv("BOGP_SMALL_M")) small_m = atoi(env);
   if (M <= small_m && h->p == 1) {
@@ -1193,8 +1179,7 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     if (want_acq_out)
       if ((e2 = ensure(h, &h->dacq_out, &h->acq_out_cap, (size_t)q * M))) return e2;
     HIPCHK(h, launch_batch_corr(h->kernel, h->dX, N, d, h->dtheta, h->dXs, B, dr, ds2, st));
-    const double one = 1.0;
-    BLASCHK(h, rocblas_dtrmm(h->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, B, &one, h->dV, h->ldr, dr, N, drt, N));
+    HIPCHK(h, launch_gemm(0, 0, N, B, N, 1.0, h->dV, h->ldr, dr, N, 0.0, drt, N, st, 1));  // rt = V r, V lower with a zero upper triangle
     HIPCHK(h, launch_col_reduce(dr, drt, N, B, h->dgamma, h->dw, dred, dred + B, dred + 2 * B, st));
     AcqArgs aa;
     memset(&aa, 0, sizeof(aa));
@@ -1288,8 +1273,8 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
   if ((e = ensure(h, &h->dss_part, &h->ss_part_cap, (size_t)nJ * Mc))) return e;
   if (h->p > 1) {
     if (Mc > 0x7fffffff / 2) FAIL(h, BOGP_ERR_UNSUPPORTED, "chunk of %lld candidates is too large for the trend GEMM (lower BOGP_CHUNK_MB)", (long long)Mc);
-    if ((e = ensure(h, &h->dTt, &h->Tt_cap, (size_t)Mc * h->p))) return e;
-    if ((e = ensure(h, &h->dCS, &h->CS_cap, (size_t)Mc * h->p))) return e;
+    if ((e = ensure(h, &h->dTt, &h->Tt_cap, (size_t)Mc * ((h->p + 127) / 128 * 128)))) return e;  // whole 128-column tiles (k_mm128)
+    if ((e = ensure(h, &h->dCS, &h->CS_cap, (size_t)Mc * ((h->p + 127) / 128 * 128)))) return e;
     if ((e = ensure(h, &h->duu, &h->uu_cap, (size_t)Mc))) return e;
     if ((e = ensure(h, &h->dmtrend, &h->mtrend_cap, (size_t)Mc))) return e;
   }
@@ -1355,17 +1340,28 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     aa.blk_val = h->dblk_val; aa.blk_idx = h->dblk_idx; aa.blk_offset = blk_offset; aa.nblk_total = nblk_total;
     if (h->p > 1) {
       // polynomial trend: mean f(x*) . beta, and under universal kriging u = G^-T (Ft^T L^-1 r - f(x*)) (gpr.py:496-498):
-      // T = r W (Mc x p, library GEMM on the chunk that k_contract has just read), c = T - f(x*), u^T u = c^T (Ft^T Ft)^-1 c
-      const int pt = h->p;
+      // T = r W (Mc x p, a tile product on the chunk that k_contract has just read), c = T - f(x*), u^T u = c^T (Ft^T Ft)^-1 c
+      // The two products run on k_mm128 (128 x 128 tiles, kernels_chol.hip) when the chunk is whole tiles -- the default
+      // chunk sizes are; rows past Mc_eff of the last tile are computed on stale chunk data and never read -- and on the
+      // generic k_gemm64 otherwise.
+      const int pt = h->p, pp = (pt + 127) / 128 * 128;
+      const bool tiles128 = Mc % 128 == 0 && !(getenv("BOGP_TREND_GEMM64") && atoi(getenv("BOGP_TREND_GEMM64")) != 0);
+      const int TI = (int)((Mc_eff + 127) / 128);
       const double one = 1.0, zero = 0.0;
       double* Tt = nullptr;
       if (h->estimate_trend) {
-        BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_none, (int)Mc_eff, pt, Np, &one, h->drT[b], (int)Mc, h->dWp, Np, &zero, h->dTt, (int)Mc));
+        if (tiles128)
+          HIPCHK(h, launch_mm128_gen(h->drT[b], (int)Mc, h->dWpT, pp, h->dTt, (int)Mc, TI, pp / 128, Np, st));
+        else
+          HIPCHK(h, launch_gemm(0, 0, (int)Mc_eff, pt, Np, one, h->drT[b], (int)Mc, h->dWp, Np, zero, h->dTt, (int)Mc, st, 0, &h->gsplit));
         Tt = h->dTt;
       }
       HIPCHK(h, launch_trend_terms(h->trend, h->dXs, m0, mcount, d, Mc, h->dbetav, Tt, h->dmtrend, st));
       if (h->estimate_trend) {
-        BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_none, rocblas_operation_none, (int)Mc_eff, pt, pt, &one, h->dTt, (int)Mc, h->dSinv, pt, &zero, h->dCS, (int)Mc));
+        if (tiles128)
+          HIPCHK(h, launch_mm128_gen(h->dTt, (int)Mc, h->dSinvP, pp, h->dCS, (int)Mc, TI, pp / 128, pp, st));
+        else
+          HIPCHK(h, launch_gemm(0, 0, (int)Mc_eff, pt, pt, one, h->dTt, (int)Mc, h->dSinv, pt, zero, h->dCS, (int)Mc, st, 0, &h->gsplit));
         HIPCHK(h, launch_rowdot(h->dTt, h->dCS, Mc, mcount, pt, h->duu, st));
         aa.uu = h->duu;
       }
@@ -1488,7 +1484,7 @@ extern "C" int bogp_gradient(bogp_handle* h, const double* x, double* dmu, doubl
     return point_eval_host(h, "bogp_gradient", x, 1, 0, nullptr, nullptr, 0.0, 1, nullptr, nullptr, dmu, dmse, nullptr, nullptr);
   if (pt > 1 && h->trend == BOGP_TREND_QUADRATIC)
     FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_gradient: the quadratic trend has no Jacobian in the reference either (trend.py:138-139)");
-  int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)N * (d + 2) + 4 * d + 8 + (size_t)pt * (d + 1));
+  int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)N * (d + 3) + 4 * d + 8 + (size_t)pt * (d + 1));
   if (e) return e;
   double* dr = h->dgrad_partial;            // N
   double* drdx = dr + N;                    // d x N (column k = dr/dx_k); [r | dr/dx] is one N x (d+1) column-major matrix
@@ -1496,30 +1492,25 @@ extern "C" int bogp_gradient(bogp_handle* h, const double* x, double* dmu, doubl
   double* dx = dz + N;                      // d
   double* dout = dx + d;                    // 3 d
   double* dtw = dout + 3 * d + 8;           // p x (d+1): W^T [r | dr/dx]
+  double* dvr = dtw + (size_t)pt * (d + 1);  // N: V r
   HIPCHK(h, hipMemcpyAsync(dx, x, d * sizeof(double), hipMemcpyHostToDevice, st));
   HIPCHK(h, launch_point_corr(h->kernel, h->dX, N, d, h->dtheta, dx, dr, drdx, st));
   // z = L^-T L^-1 r = V^T (V r) with the explicit V = L^-1 kept from the commit: two triangular matrix-vector
   // products (bandwidth bound, ~50 us at N = 2048) instead of two dependent triangular solves (~350 us each)
-  HIPCHK(h, hipMemcpyAsync(dz, dr, N * sizeof(double), hipMemcpyDeviceToDevice, st));
-  BLASCHK(h, rocblas_dtrmv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, h->dV, h->ldr, dz, 1));
-  BLASCHK(h, rocblas_dtrmv(h->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, h->dV, h->ldr, dz, 1));
+  HIPCHK(h, launch_gemm(0, 0, N, 1, N, 1.0, h->dV, h->ldr, dr, N, 0.0, dvr, N, st, 1));  // V r
+  HIPCHK(h, launch_gemm(1, 0, N, 1, N, 1.0, h->dV, h->ldr, dvr, N, 0.0, dz, N, st, 2));  // V^T (V r)
   const double one = 1.0, zero = 0.0;
-  BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, h->dgamma, 1, &zero, dout, 1));
-  BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, dz, 1, &zero, dout + d, 1));
-  double wr = 0;
-  if (h->estimate_trend && pt == 1) {
-    BLASCHK(h, rocblas_dgemv(h->blas, rocblas_operation_transpose, N, d, &one, drdx, N, h->dw, 1, &zero, dout + 2 * d, 1));
-    BLASCHK(h, rocblas_ddot(h->blas, N, h->dw, 1, dr, 1, &wr));
-  }
+  HIPCHK(h, launch_gemm(1, 0, d, 1, N, one, drdx, N, h->dgamma, N, zero, dout, d, st, 0, &h->gsplit));
+  HIPCHK(h, launch_gemm(1, 0, d, 1, N, one, drdx, N, dz, N, zero, dout + d, d, st, 0, &h->gsplit));
   std::vector<double> out(3 * d, 0.0), tw;
   if (h->estimate_trend && pt > 1) {  // (Ft^T L^-1) [r | dr/dx] = W^T [r | dr/dx]   (gpr.py:570-571)
-    BLASCHK(h, rocblas_dgemm(h->blas, rocblas_operation_transpose, rocblas_operation_none, pt, d + 1, N, &one, h->dWp, h->Np, dr, N, &zero, dtw, pt));
+    HIPCHK(h, launch_gemm(1, 0, pt, d + 1, N, one, h->dWp, h->Np, dr, N, zero, dtw, pt, st, 0, &h->gsplit));
     tw.resize((size_t)pt * (d + 1));
     HIPCHK(h, hipMemcpyAsync(tw.data(), dtw, tw.size() * sizeof(double), hipMemcpyDeviceToHost, st));
   }
-  HIPCHK(h, hipMemcpyAsync(out.data(), dout, (h->estimate_trend && pt == 1 ? 3 : 2) * d * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(out.data(), dout, 2 * d * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
-  if (pt > 1) {  // linear basis: f = [1, x], Jacobian rows 1..d = identity (trend.py:104-112)
+  {  // linear basis (the constant one returned above): f = [1, x], Jacobian rows 1..d = identity (trend.py:104-112)
     std::vector<double> su;  // S u with u = Ft^T rt - f and S = (Ft^T Ft)^-1 (:570-573)
     if (h->estimate_trend) {
       std::vector<double> u(pt);
@@ -1538,13 +1529,6 @@ extern "C" int bogp_gradient(bogp_handle* h, const double* x, double* dmu, doubl
       }
       dmse[k] = 2.0 * h->sigma2 * m;
     }
-    return BOGP_OK;
-  }
-  for (int k = 0; k < d; ++k) {
-    dmu[k] = out[k];  // beta^T f_dx = 0 for the constant basis
-    double m = -1.0 * out[d + k];
-    if (h->estimate_trend) m += (wr - 1.0) * (1.0 / h->ftft) * out[2 * d + k];
-    dmse[k] = 2.0 * h->sigma2 * m;
   }
   return BOGP_OK;
 }

@@ -2,7 +2,6 @@
 // translation units that implement the C ABI (bogp_api.hip, bogp_comm.hip).
 #pragma once
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
 
 #include <cstdio>
 #include <string>
@@ -28,7 +27,6 @@ struct bogp_handle {
   hipEvent_t ev_chol[2] = {nullptr, nullptr};  // look-ahead of the large-matrix Cholesky (second stream)
   hipStream_t stream_upd = nullptr;  // BOGP_CHOL_RESERVE_CU=n: a stream whose CU mask leaves n CUs to the factorisation's chain (two-level Cholesky)
   hipStream_t stream2 = nullptr;  // producer stream: k_corr_chunk of chunk c+1 runs beside k_contract of chunk c
-  rocblas_handle blas = nullptr;
   std::string err;
 
   // training set.  The buffers are sized for cap_ld rows / cap_d columns / cap_nt targets and re-used by every
@@ -53,7 +51,7 @@ struct bogp_handle {
   double *dgamma = nullptr, *dw = nullptr;                                  // Np each (zero padded)
   double *dtheta = nullptr, *dsqrt_theta = nullptr;                         // d each
   double* dscal = nullptr;                                                  // small scalar scratch
-  rocblas_int* dinfo = nullptr;
+  int* dinfo = nullptr;
   double* dgrad_partial = nullptr;
   size_t grad_partial_cap = 0;
   double* dbatch = nullptr;
@@ -104,10 +102,13 @@ struct bogp_handle {
   std::vector<double> h_betav, h_Sinv;     // committed beta (p) and (Ft^T Ft)^-1 (p x p, column-major) for bogp_gradient
   double *dF = nullptr, *dFt = nullptr, *dQ1 = nullptr, *dQ = nullptr;  // N x p, column-major, ld = N
   double* dWp = nullptr;                                                // Np x p: L^-T Ft, zero-padded rows
+  bogp::GemmSplit gsplit = {nullptr, 0, nullptr, 0};  // split-K scratch of the small products (kernels_gemm.hip), allocated with the trend buffers
+  double* dWpT = nullptr;    // pp x Np (pp = p rounded up to 128): W^T, zero rows in the padding -- column side of the k_mm128 trend product
+  double* dSinvP = nullptr;  // pp x pp: (Ft^T Ft)^-1, zero padded
   double *dA[2] = {nullptr, nullptr}, *dAV[2] = {nullptr, nullptr}, *dAU[2] = {nullptr, nullptr};  // ldp x ldp (CholeskyQR2)
   double *dAw = nullptr, *dAT = nullptr;                                // ldp x 64, ldp x ldp scratch
   double *dGinv = nullptr, *dSinv = nullptr, *dbetav = nullptr, *dqty = nullptr;  // p x p, p x p, p, p
-  rocblas_int* dinfo2 = nullptr;
+  int* dinfo2 = nullptr;
   double *dTt = nullptr, *dCS = nullptr, *duu = nullptr, *dmtrend = nullptr;  // per sweep chunk: Mc x p, Mc x p, Mc, Mc
   size_t Tt_cap = 0, CS_cap = 0, uu_cap = 0, mtrend_cap = 0;
 
@@ -152,13 +153,6 @@ struct bogp_handle {
     hipError_t _e = (expr);                                                                              \
     if (_e != hipSuccess) FAIL(h, BOGP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
   } while (0)
-#define BLASCHK(h, expr)                                                                          \
-  do {                                                                                            \
-    rocblas_status _s = (expr);                                                                   \
-    if (_s != rocblas_status_success)                                                             \
-      FAIL(h, BOGP_ERR_HIP, "%s failed: rocblas_status %d (%s:%d)", #expr, (int)_s, __FILE__, __LINE__); \
-  } while (0)
-
 template <typename T>
 static inline int ensure(bogp_handle* h, T** p, size_t* cap, size_t n) {
   if (*cap >= n && *p) return BOGP_OK;

@@ -130,9 +130,35 @@ hipError_t launch_scale_transpose(const double* X, int N, int d, int Np, const d
                                   hipStream_t st);
 hipError_t launch_pack_V(const double* Vcm, int N, int ld, int Np, double2* Vp, hipStream_t st);
 hipError_t launch_logdet(const double* L, int N, int ld, double* out, hipStream_t st);
-hipError_t launch_two_i_minus(double* T, int N, int ld, hipStream_t st);
-hipError_t launch_refine_store(const double* W, double* V, double* U, int N, int ld, hipStream_t st);
 // kernels_chol.hip: in-place lower Cholesky of a column-major matrix whose ld is a multiple of 64 (identity padded)
+// ---- kernels_gemm.hip: the small dense products that used to be library calls ------------------------------------
+struct GemmArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  int m, n, k, ldc;
+  long sai, sak;  // op(A)(i, kk) at A[i * sai + kk * sak]
+  long sbj, sbk;  // op(B)(kk, j) at B[j * sbj + kk * sbk]
+  double alpha, beta;
+  int tri;  // 1 / 2: op(A) square lower / upper triangular (zeros stored): the k range of a row tile shrinks
+  double* scratch;        // split K (gridDim.z > 1): [tile][slice][64 x 64] partial tiles
+  unsigned int* tickets;  // one zeroed word per tile
+};
+struct GemmSplit {  // what launch_gemm needs to split K: scratch of `cap` doubles, `max_tiles` zeroed ticket words
+  double* scratch;
+  size_t cap;
+  unsigned int* tickets;
+  int max_tiles;
+};
+// C (m x n) = alpha op(A) op(B) + beta C, column-major; ta / tb != 0: the stored matrix is the transpose (any shape)
+hipError_t launch_gemm(int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda, const double* B, int ldb,
+                       double beta, double* C, int ldc, hipStream_t st, int tri = 0, const GemmSplit* sp = nullptr);
+// out[c + r * ldo] = in[r + c * ldi], r < rows, c < cols, zero for cols <= c < ldo
+hipError_t launch_transpose_pad(const double* in, int ldi, int rows, int cols, double* out, int ldo, hipStream_t st);
+// kernels_chol.hip, k_mm128 on a plain product: out (128 TI x 128 TJ, ldo) = sum_{k < K} Rs(row, k) Cs(col, k), element (row, k)
+// at Rs[row + k * ldr], (col, k) at Cs[col + k * ldc]; K a multiple of 16, every tile complete
+hipError_t launch_mm128_gen(const double* Rs, int ldr, const double* Cs, int ldc, double* out, int ldo, int TI, int TJ, int K,
+                            hipStream_t st);
 hipError_t launch_pad_identity(double* A, int N, int ld, hipStream_t st);
 // st2 + ev[2] (optional): a second stream and two events for the look-ahead of the large-matrix path
 hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStream_t st, hipStream_t st2 = nullptr,

@@ -752,7 +752,7 @@ __device__ __forceinline__ void mm128_tile(const MmTile& t, double* lds) {
     }
 }
 
-enum { MM_UUT = 0, MM_T = 1, MM_V = 2, MM_U = 3, MM_SYRK = 4 };
+enum { MM_UUT = 0, MM_T = 1, MM_V = 2, MM_U = 3, MM_SYRK = 4, MM_GEN = 5 };
 struct MmArgs {
   const double* L;
   double* V;
@@ -767,6 +767,10 @@ struct MmArgs {
   int cj0, cj1;
   int TI, TJ;  // logical tile grid of one z / y slice
   int fixed;   // experiment BOGP_MM128_FIXED=1
+  const double* gR;  // MM_GEN: plain product out = Rs Cs^T over k < gK (launch_mm128_gen)
+  const double* gC;
+  double* gO;
+  int gldr, gldc, gldo, gK;
   int order;   // 1: workgroups walk the live tiles in order of decreasing K (pairs flattened into x)
   int fp, nl;  // MM_T / V / U with order: full pairs of the level, live 128-tiles of block 22 in the partial last pair (0: none)
 };
@@ -793,6 +797,19 @@ __global__ __launch_bounds__(256, 2) void k_mm128(MmArgs a, int mode0) {
   extern __shared__ __attribute__((aligned(16))) double mm_lds[];
   const int mode = mode0 + (int)blockIdx.z;
   int ti, tj, pair = (int)blockIdx.y;
+  if (mode == MM_GEN) {  // every tile is live and equally long; consecutive workgroups share the row panel
+    MmTile g;
+    ti = (int)blockIdx.x / a.TJ;
+    tj = (int)blockIdx.x - ti * a.TJ;
+    g.Rs = a.gR + (size_t)ti * MB;
+    g.Cs = a.gC + (size_t)tj * MB;
+    g.out = a.gO + (size_t)ti * MB + (size_t)tj * MB * a.gldo;
+    g.ldr = a.gldr; g.ldc = a.gldc; g.ldo = a.gldo;
+    g.k0 = 0; g.k1 = a.gK;
+    g.alpha = 1.0; g.beta = 0;
+    mm128_tile(g, mm_lds);
+    return;
+  }
   if (a.order && mode != MM_SYRK) {
     // Longest K first, only tiles that exist: the dispatcher hands out workgroups in index order as slots free up, and
     // consecutive indices go to different XCDs -- every XCD sees the same mix of long and short tiles.  (The products are not
@@ -944,6 +961,24 @@ static hipError_t launch_mm128(MmArgs a, int mode, int TI, int TJ, int ny, int n
   a.order = 0;
   const int nsuper = ((TI + 7) / 8) * ((TJ + 7) / 8);
   hipLaunchKernelGGL(kern, dim3((unsigned)(nsuper * 64), ny, nz), 256, shm, st, a, mode);
+  return hipGetLastError();
+}
+
+hipError_t launch_mm128_gen(const double* Rs, int ldr, const double* Cs, int ldc, double* out, int ldo, int TI, int TJ, int K,
+                            hipStream_t st) {
+  if (TI <= 0 || TJ <= 0) return hipSuccess;
+  constexpr int shm = 2 * 2 * MKB * MPT * (int)sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm128), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  MmArgs a{};
+  a.gR = Rs; a.gC = Cs; a.gO = out;
+  a.gldr = ldr; a.gldc = ldc; a.gldo = ldo; a.gK = K;
+  a.TI = TI; a.TJ = TJ;
+  hipLaunchKernelGGL(k_mm128, dim3((unsigned)(TI * TJ), 1, 1), 256, shm, st, a, (int)MM_GEN);
   return hipGetLastError();
 }
 

@@ -52,30 +52,6 @@ __global__ __launch_bounds__(256) void k_logdet(const double* __restrict__ L, in
   }
   if (threadIdx.x == 0) out[0] = red[0];
 }
-// ---- one Newton-Schulz step on the explicit inverse (bogp_api.hip: refine_inverse) -------------------------------------
-// k_two_i_minus: T <- 2 I - T on the N x N leading block;  k_refine_store: V <- lower(W), U <- lower(W)^T
-__global__ __launch_bounds__(256) void k_two_i_minus(double* __restrict__ T, int N, int ld) {
-  const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
-  if (i < N) T[(size_t)j * ld + i] = (i == j ? 2.0 : 0.0) - T[(size_t)j * ld + i];
-}
-__global__ __launch_bounds__(256) void k_refine_store(const double* __restrict__ W, double* __restrict__ V, double* __restrict__ U,
-                                                      int N, int ld) {
-  const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
-  if (i < N && i >= j) {
-    const double w = W[(size_t)j * ld + i];
-    V[(size_t)j * ld + i] = w;
-    U[(size_t)i * ld + j] = w;
-  }
-}
-hipError_t launch_two_i_minus(double* T, int N, int ld, hipStream_t st) {
-  hipLaunchKernelGGL(k_two_i_minus, dim3((N + 255) / 256, N), 256, 0, st, T, N, ld);
-  return hipGetLastError();
-}
-hipError_t launch_refine_store(const double* W, double* V, double* U, int N, int ld, hipStream_t st) {
-  hipLaunchKernelGGL(k_refine_store, dim3((N + 255) / 256, N), 256, 0, st, W, V, U, N, ld);
-  return hipGetLastError();
-}
-
 hipError_t launch_logdet(const double* L, int N, int ld, double* out, hipStream_t st) {
   hipLaunchKernelGGL(k_logdet, dim3(1), 256, 0, st, L, N, ld, out);
   return hipGetLastError();
