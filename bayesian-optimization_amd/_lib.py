@@ -18,7 +18,7 @@ KERNEL_SE, KERNEL_MATERN12, KERNEL_MATERN32, KERNEL_MATERN52, KERNEL_ABSEXP, KER
 MODE_NOISELESS, MODE_NOISY, MODE_NOISE_ESTIM = 0, 1, 2
 ACQ_EI, ACQ_EPSILON_PI, ACQ_UCB, ACQ_MGFI = 0, 1, 2, 3
 TREND_CONSTANT, TREND_LINEAR, TREND_QUADRATIC = 0, 1, 2
-ABI_VERSION = 4  # BOGP_ABI_VERSION of include/bogp.h this binding table was written for
+ABI_VERSION = 5  # BOGP_ABI_VERSION of include/bogp.h this binding table was written for
 MAX_Q = 64
 MAX_TARGETS = 8
 COMM_ID_BYTES = 128
@@ -74,6 +74,7 @@ SIGNATURES = {
     "bogp_merge_topk": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _lp, _dp]),
     "bogp_last_timing": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip]),
     "bogp_flops_per_candidate": (C.c_double, [C.c_void_p]),
+    "bogp_selftest_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, C.c_int, C.c_double, _dp, C.c_int, C.c_int, C.c_int]),
 }
 
 _lib = None
@@ -610,6 +611,19 @@ class Engine:
         cast = lambda x: C.cast(C.byref(x), _dp)  # noqa: E731
         self._check(self._lib.bogp_last_timing(self._h, cast(a), cast(b), cast(c), C.cast(C.byref(n), _ip)))
         return dict(corr_ms=a.value, contract_ms=b.value, acquisition_ms=c.value, n_chunks=n.value)
+
+    def selftest_gemm(self, A, B, C_in=None, ta=False, tb=False, alpha=1.0, beta=0.0, tri=0, split=True):
+        """alpha op(A) op(B) + beta C through k_gemm64 (kernels_gemm.hip); A, B, C_in Fortran-ordered 2-D float64 arrays."""
+        A = np.asfortranarray(A, dtype=np.float64)
+        B = np.asfortranarray(B, dtype=np.float64)
+        m, k = (A.shape[1], A.shape[0]) if ta else A.shape
+        k2, n = (B.shape[1], B.shape[0]) if tb else B.shape
+        if k != k2:
+            raise ValueError("inner dimensions differ: %d vs %d" % (k, k2))
+        out = np.zeros((m, n), order="F") if C_in is None else np.asfortranarray(C_in, dtype=np.float64).copy(order="F")
+        self._check(self._lib.bogp_selftest_gemm(self._h, int(ta), int(tb), m, n, k, float(alpha), _ptr(A), A.shape[0], _ptr(B), B.shape[0],
+                                                 float(beta), _ptr(out), out.shape[0], int(tri), int(split)))
+        return out
 
     def flops_per_candidate(self) -> float:
         return float(self._lib.bogp_flops_per_candidate(self._h))

@@ -238,6 +238,17 @@ extern "C" int bogp_set_trend_beta(bogp_handle* h, const double* beta, int p) {
 }
 
 // buffers of the p > 1 path, (re)allocated when p changes; F is rebuilt when the basis id changes
+// split-K scratch of k_gemm64: tiles x slices <= 512 partial tiles of 64 x 64 (16 MB), 128 zeroed ticket words
+static int ensure_gsplit(bogp_handle* h) {
+  if (h->gsplit.scratch) return BOGP_OK;
+  h->gsplit.max_tiles = 128;
+  h->gsplit.cap = (size_t)512 * 64 * 64;
+  HIPCHK(h, hipMalloc((void**)&h->gsplit.scratch, h->gsplit.cap * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->gsplit.tickets, 128 * sizeof(unsigned int)));
+  HIPCHK(h, hipMemsetAsync(h->gsplit.tickets, 0, 128 * sizeof(unsigned int), h->stream));
+  return BOGP_OK;
+}
+
 static int ensure_trend(bogp_handle* h, int trend) {
   const int N = h->N, d = h->d, Np = h->Np;
   const int p = trend_size(trend, d);
@@ -273,13 +284,7 @@ static int ensure_trend(bogp_handle* h, int trend) {
     HIPCHK(h, hipMalloc((void**)&h->dbetav, p * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->dqty, p * sizeof(double)));
     HIPCHK(h, hipMalloc((void**)&h->dinfo2, 2 * sizeof(int)));
-    if (!h->gsplit.scratch) {  // split-K scratch of k_gemm64: tiles x slices <= 512 partial tiles of 64 x 64 (16 MB), 128 ticket words
-      h->gsplit.max_tiles = 128;
-      h->gsplit.cap = (size_t)512 * 64 * 64;
-      HIPCHK(h, hipMalloc((void**)&h->gsplit.scratch, h->gsplit.cap * sizeof(double)));
-      HIPCHK(h, hipMalloc((void**)&h->gsplit.tickets, 128 * sizeof(unsigned int)));
-      HIPCHK(h, hipMemsetAsync(h->gsplit.tickets, 0, 128 * sizeof(unsigned int), st));
-    }
+    { const int eg = ensure_gsplit(h); if (eg) return eg; }
     HIPCHK(h, hipMemsetAsync(h->dinfo2, 0, 2 * sizeof(int), st));
     h->tr_p = p;
     h->ldp = ldp;
@@ -317,7 +322,7 @@ static int trend_solve(bogp_handle* h, int trend, int estimate_trend) {
     double* dst = pass == 0 ? h->dQ1 : h->dQ;
     HIPCHK(h, launch_gemm(1, 0, p, p, N, one, src, N, src, N, zero, h->dA[pass], ldp, st, 0, &h->gsplit));
     HIPCHK(h, launch_pad_identity(h->dA[pass], p, ldp, st));
-    HIPCHK(h, launch_chol_lower(h->dA[pass], ldp, h->dAw, h->dinfo2 + pass, st));
+    HIPCHK(h, launch_chol_lower(h->dA[pass], ldp, h->dAw, h->dinfo2 + pass, st, nullptr, nullptr, nullptr, p));
     HIPCHK(h, launch_tri_inverse(h->dA[pass], h->dAw, h->dAV[pass], h->dAU[pass], h->dAT, ldp, st));
     HIPCHK(h, launch_gemm(0, 0, N, p, p, one, src, N, h->dAU[pass], ldp, zero, dst, N, st, 0, &h->gsplit));
     src = dst;
@@ -404,7 +409,7 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   //   Yt = V y (:799), Ft = V 1 (:803)              one pass over V
   //   rho (:806 / :808), |Ft|, Ft.Yt, rho.rho       k_fit_rho
   //   gamma = U rho (:788 / :996)
-  HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st, h->stream_upd ? h->stream_upd : h->stream2, h->ev_chol, h->dT));  // dT: free until the inverse
+  HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st, h->stream_upd ? h->stream_upd : h->stream2, h->ev_chol, h->dT, N));  // dT: free until the inverse
   HIPCHK(h, launch_logdet(h->dR, N, ldr, h->dscal, st));
   HIPCHK(h, launch_tri_inverse(h->dR, h->ddinv, h->dV, h->dU, h->dT, ldr, st));
   const int n_t = h->n_t;
@@ -1577,5 +1582,36 @@ extern "C" int bogp_prior_corr(bogp_handle* h, const double* X1, int n1, double*
   HIPCHK(h, launch_batch_corr(h->kernel, dX1, n1, d, h->dtheta, dX1, n1, dr, ds2, st));
   HIPCHK(h, hipMemcpyAsync(R, dr, (size_t)n1 * n1 * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
+  return BOGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// self test of kernels_gemm.hip on host buffers (include/bogp.h)
+// ------------------------------------------------------------------------------------------------------
+extern "C" int bogp_selftest_gemm(bogp_handle* h, int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda,
+                                  const double* B, int ldb, double beta, double* C, int ldc, int tri, int split) {
+  if (!h) return BOGP_ERR_INVALID;
+  if (!A || !B || !C || m <= 0 || n <= 0 || k <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_selftest_gemm: null pointer or empty shape");
+  if (lda < (ta ? k : m) || ldb < (tb ? n : k) || ldc < m) FAIL(h, BOGP_ERR_INVALID, "bogp_selftest_gemm: leading dimension below the stored rows");
+  if (tri && m != k) FAIL(h, BOGP_ERR_INVALID, "bogp_selftest_gemm: a triangular op(A) is square");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = h->stream;
+  const size_t na = (size_t)lda * (ta ? m : k), nb = (size_t)ldb * (tb ? k : n), nc = (size_t)ldc * n;
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  int rc = BOGP_OK;
+  if (split && (rc = ensure_gsplit(h))) return rc;
+  if (hipMalloc((void**)&dA, na * sizeof(double)) != hipSuccess || hipMalloc((void**)&dB, nb * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&dC, nc * sizeof(double)) != hipSuccess) {
+    dfree(dA); dfree(dB); dfree(dC);
+    FAIL(h, BOGP_ERR_HIP, "bogp_selftest_gemm: hipMalloc failed");
+  }
+  hipError_t e = hipMemcpyAsync(dA, A, na * sizeof(double), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(dB, B, nb * sizeof(double), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(dC, C, nc * sizeof(double), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = launch_gemm(ta, tb, m, n, k, alpha, dA, lda, dB, ldb, beta, dC, ldc, st, tri, split ? &h->gsplit : nullptr);
+  if (e == hipSuccess) e = hipMemcpyAsync(C, dC, nc * sizeof(double), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  dfree(dA); dfree(dB); dfree(dC);
+  if (e != hipSuccess) FAIL(h, BOGP_ERR_HIP, "bogp_selftest_gemm: %s", hipGetErrorString(e));
   return BOGP_OK;
 }

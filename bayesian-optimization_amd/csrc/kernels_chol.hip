@@ -104,7 +104,10 @@ __device__ __forceinline__ void mma_64(const double* lds, const double (&bv)[16]
 // cs: 64 x 65 staging of the input block; sb: DIAG_SB doubles.  On return `lo` holds the L tile (tc <= tr) and z the
 // W tile (tc <= tr).  Returns 0 or 1 + the first column with a non-positive pivot (LAPACK's info), workgroup-uniform.
 constexpr int DIAG_SB = 16 + 4 * CB + 2;
-__device__ __forceinline__ int diag_factor_invert(const double* cs, double* sb, double (&lo)[4][4], double (&z)[4][4], int tid) {
+// nlive: leading columns of the block that hold data -- the rest is the identity padding of the matrix, whose factor and
+// inverse are the identity: the block steps past it are skipped (a block with 16 live columns takes 4 of the 16 steps).
+__device__ __forceinline__ int diag_factor_invert(const double* cs, double* sb, double (&lo)[4][4], double (&z)[4][4], int tid,
+                                                  int nlive = CB) {
   const int tr = tid >> 4, tc = tid & 15;
   double* dtile = sb;           // [4][4] the diagonal tile of the current step (lower part used)
   double* Y = sb + 16;          // [4][64]
@@ -124,7 +127,8 @@ __device__ __forceinline__ int diag_factor_invert(const double* cs, double* sb, 
       for (int c = 0; c < 4; ++c) dtile[4 * i + c] = z[i][c];
   }
   __syncthreads();
-  for (int jb = 0; jb < 16; ++jb) {
+  const int nsteps = min(16, (nlive + 3) >> 2);
+  for (int jb = 0; jb < nsteps; ++jb) {
     // ---- A + B: the 16 threads of block row jb ALL factor and invert the 4x4 diagonal tile (published by its owner at the
     // end of the previous step) and go straight on to their own piece of the block row Y = M z(jb, :): one barrier and
     // one LDS round trip less per step than handing M from the diagonal thread to the others
@@ -236,6 +240,12 @@ __device__ __forceinline__ int diag_factor_invert(const double* cs, double* sb, 
     }
     __syncthreads();
   }
+  if (tr == tc && tr >= nsteps) {  // skipped identity blocks: z is still exactly the identity tile = its own factor and inverse
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) lo[i][c] = z[i][c];
+  }
   return (int)flag[0];
 }
 
@@ -263,7 +273,7 @@ __device__ __forceinline__ void diag_store(double* __restrict__ Ad /* &A[i0 + i0
 // Factor + invert the 64 x 64 block at A (global, column-major) with the calling 256-thread workgroup; cs / sb: LDS scratch of
 // CB * (CB + 1) and DIAG_SB doubles.
 __device__ __forceinline__ void diag_from_global(double* __restrict__ A, int ld, double* __restrict__ W0, int* __restrict__ info, int base,
-                                                 int reset, double* cs, double* sb) {
+                                                 int reset, double* cs, double* sb, int nlive) {
   const int tid = threadIdx.x;
   for (int e = tid; e < CB * CB; e += 256) {
     const int r = e & 63, c = e >> 6;
@@ -271,7 +281,7 @@ __device__ __forceinline__ void diag_from_global(double* __restrict__ A, int ld,
   }
   __syncthreads();
   double a[4][4], w[4][4];
-  const int bad = diag_factor_invert(cs, sb, a, w, tid);
+  const int bad = diag_factor_invert(cs, sb, a, w, tid, nlive);
   diag_store(A, ld, W0, a, w, tid);
   if (tid == 0) {
     if (reset)
@@ -282,10 +292,10 @@ __device__ __forceinline__ void diag_from_global(double* __restrict__ A, int ld,
 }
 
 __global__ __launch_bounds__(256) void k_chol_first(double* __restrict__ A, int ld, double* __restrict__ W0, int* __restrict__ info,
-                                                    int base = 0, int reset = 1) {
+                                                    int base = 0, int reset = 1, int nlive = CB) {
   __shared__ __attribute__((aligned(16))) double cs[CB * (CB + 1)];
   __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
-  diag_from_global(A, ld, W0, info, base, reset, cs, sb);
+  diag_from_global(A, ld, W0, info, base, reset, cs, sb, nlive);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -333,7 +343,7 @@ __device__ __forceinline__ void tri_index(int q, int& bi, int& bj) {
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int ld, int kp0, int np, int o0, int m, int nc,
                                                      double* __restrict__ Wn, int* __restrict__ info, double* __restrict__ Pnext,
-                                                     int tri_grid) {
+                                                     int tri_grid, int nlive) {
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];  // 40 KB: A-side tile, then the 64 x 65 block staging
   __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
   int bi, bj;
@@ -395,7 +405,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
     for (int t = 0; t < 4; ++t) lds[(16 * w + (lane & 15)) * (CB + 1) + 16 * mi + 4 * t + lk] = -acc[mi][t];
   __syncthreads();
   double a[4][4], ww[4][4];
-  const int bad = diag_factor_invert(lds, sb, a, ww, tid);
+  const int bad = diag_factor_invert(lds, sb, a, ww, tid, nlive);
   diag_store(Ab, ld, Wn, a, ww, tid);
   if (tid == 0 && bad != 0 && *info == 0) *info = i0 + bad;
 }
@@ -411,7 +421,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int ld, int k0, int m, const double* __restrict__ Wk,
                                                    const double* __restrict__ Pcur, double* __restrict__ Pnext,
-                                                   double* __restrict__ Wn, int* __restrict__ info, int tri_grid) {
+                                                   double* __restrict__ Wn, int* __restrict__ info, int tri_grid, int nlive) {
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
   __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
   int bi, bj;
@@ -497,7 +507,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int l
     for (int t = 0; t < 4; ++t) lds[(16 * w + (lane & 15)) * (CB + 1) + 16 * mi + 4 * t + lk] = -acc[mi][t];
   __syncthreads();
   double a[4][4], ww[4][4];
-  const int bad = diag_factor_invert(lds, sb, a, ww, tid);
+  const int bad = diag_factor_invert(lds, sb, a, ww, tid, nlive);
   diag_store(Ab, ld, Wn, a, ww, tid);
   if (tid == 0 && bad != 0 && *info == 0) *info = i0 + bad;
 }
@@ -1007,7 +1017,7 @@ static hipError_t launch_chol_lower_big(double* A, int ld, double* Winv, int* in
       const int nc = kend - 1 - k;  // block columns of this panel still to the right of k
       if (nc > 0)
         hipLaunchKernelGGL(k_chol_update, dim3(m * nc), 256, 0, st, A, ld, k0, 1, k0 + CB, m, nc,
-                           Winv + (size_t)(k + 1) * CB * CB, info, (double*)nullptr, 0);
+                           Winv + (size_t)(k + 1) * CB * CB, info, (double*)nullptr, 0, CB);
     }
     if (kend < nb) {
       MmArgs a{};
@@ -1111,10 +1121,12 @@ hipError_t launch_pad_identity(double* A, int N, int ld, hipStream_t st) {
 // k holds L_kk^-1 (64 x 64 column-major) afterwards.  *info (device) = 0 or 1 + the first column with a non-positive
 // pivot, as LAPACK reports it.
 hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStream_t st, hipStream_t st2, hipEvent_t* ev,
-                             double* scratch) {
+                             double* scratch, int N) {
+  if (N <= 0 || N > ld) N = ld;
+  auto live = [&](int col0) { return max(0, min(CB, N - col0)); };  // data columns of the 64-block that starts at col0
   const int nb = ld / CB;
   if (big_chol(ld)) return launch_chol_lower_big(A, ld, Winv, info, st, st2, ev);
-  hipLaunchKernelGGL(k_chol_first, dim3(1), 256, 0, st, A, ld, Winv, info, 0, 1);
+  hipLaunchKernelGGL(k_chol_first, dim3(1), 256, 0, st, A, ld, Winv, info, 0, 1, live(0));
   // BOGP_CHOL_GROUP=G > 1 (experiment, default 1): block columns in groups of G -- inside a group the update after panel k
   // touches only block column k + 1 (with all the group's panels so far), the group's LAST panel triggers ONE rank-64 G
   // update of everything to the right, so the trailing matrix is read and written nb / G times instead of nb times.
@@ -1151,14 +1163,14 @@ hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStre
       const bool next_fused = can_fuse && m - 1 >= 1 && m - 1 <= fuse_max;
       if (can_fuse && m <= fuse_max) {
         hipLaunchKernelGGL(k_chol_step, dim3(tri ? m * (m + 1) / 2 : m * m), 256, 0, st, A, ld, k0, m, Winv + (size_t)k * CB * CB,
-                           panel_copy(k), panel_copy(k + 1), Winv + (size_t)(k + 1) * CB * CB, info, tri);
+                           panel_copy(k), panel_copy(k + 1), Winv + (size_t)(k + 1) * CB * CB, info, tri, live(k0 + CB));
         continue;
       }
       hipLaunchKernelGGL(k_chol_panel, dim3(m), 256, 0, st, Winv + (size_t)k * CB * CB, A + (size_t)k0 * ld + k0 + CB, ld);
       const bool last = k == kbeg + G - 1;
       hipLaunchKernelGGL(k_chol_update, dim3(last ? (tri ? m * (m + 1) / 2 : m * m) : m), 256, 0, st, A, ld, kbeg * CB, k - kbeg + 1,
                          k0 + CB, m, last ? m : 1, Winv + (size_t)(k + 1) * CB * CB, info,
-                         next_fused ? panel_copy(k + 1) : (double*)nullptr, tri);
+                         next_fused ? panel_copy(k + 1) : (double*)nullptr, tri, live(k0 + CB));
     }
   }
   return hipGetLastError();

@@ -28,7 +28,7 @@ extern "C" {
 typedef struct bogp_handle bogp_handle;
 
 /* error codes */
-#define BOGP_ABI_VERSION 4 /* what bogp_abi_version() of a matching library returns */
+#define BOGP_ABI_VERSION 5 /* what bogp_abi_version() of a matching library returns */
 #define BOGP_OK 0
 #define BOGP_ERR_INVALID (-1)      /* bad argument / call order                                           */
 #define BOGP_ERR_HIP (-2)          /* HIP runtime / rocBLAS failure                                        */
@@ -300,6 +300,15 @@ int bogp_last_timing(bogp_handle* h, double* corr_ms, double* contract_ms, doubl
 /* Algorithmic FP64 flops per candidate of the posterior for the committed model:
  * N^2 + N (3d + 5 + 2p)  (SURVEY.md section 8d).                                                        */
 double bogp_flops_per_candidate(const bogp_handle* h);
+
+/* ---- self test -------------------------------------------------------------------------------------
+ * The in-tree dense product behind the polynomial-trend, REML and small-batch paths (kernels_gemm.hip; the library links no
+ * BLAS), on host buffers: C (m x n, ldc) = alpha op(A) (m x k) op(B) (k x n) + beta C, column-major; ta / tb != 0: the stored
+ * matrix is the transpose; tri = 1 / 2: op(A) is square lower / upper triangular with explicit zeros in the other triangle
+ * (the kernel then shortens its k range); split != 0: the deterministic split-K path may be taken (small C, long k).
+ * What the reference gets from numpy.dot / scipy.linalg (gpr.py:799-808, 850-918); used by tests/test_gpu_gemm.py.        */
+int bogp_selftest_gemm(bogp_handle* h, int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda,
+                       const double* B, int ldb, double beta, double* C, int ldc, int tri, int split);
 
 #ifdef __cplusplus
 }

@@ -2,7 +2,11 @@
 behind the same methods) on random problems for a given number of seconds -- sizes around every block boundary of the
 kernels (N mod 16 / 32 / 64, the 512 limit of the fused sweep, M mod 64), every kernel / mode / trend the path builds,
 random criteria.  Prints one line per failure with the seed that reproduces it; exits non-zero if any.
-usage: python tools/fuzz_parity.py [--wide] [seconds] [first_seed]"""
+--trend (r03, after the library GEMMs were replaced by kernels_gemm.hip): every problem has a linear or quadratic basis with up
+to 91 columns, N from 3 p to 1500 -- the shapes k_gemm64's bounds checks, triangular k ranges and split K have to get right --
+plus the restricted likelihood with its three trend products; candidates up to 70 000 rows so that the k_mm128 chunk products
+run on whole and on ragged chunks.
+usage: python tools/fuzz_parity.py [--wide | --trend] [seconds] [first_seed]"""
 import os
 import sys
 import time
@@ -25,6 +29,7 @@ def close(a, b, rtol=1e-6, atol=0.0):
     return np.allclose(np.asarray(a, float), np.asarray(b, float), rtol=rtol, atol=atol, equal_nan=True)
 
 
+TREND = False  # --trend: polynomial bases with many columns (see the module docstring)
 WIDE = False  # --wide: d up to 60 (the fused sweep's limit), N up to 2200, + the restricted likelihood and input gradients
 
 
@@ -40,6 +45,13 @@ def one(seed, eng, orc):
     kernel = int(rng.choice(KERNELS))
     mode = int(rng.integers(0, 3))
     trend = int(rng.choice([0, 0, 0, 1, 2])) if d <= 4 and N > 40 else 0
+    if TREND:
+        d = int(rng.choice([1, 2, 3, 5, 8, 12]))
+        trend = int(rng.choice([1, 2]))
+        pcols = d + 1 if trend == 1 else (d + 1) * (d + 2) // 2
+        N = int(rng.choice([3 * pcols, 3 * pcols + 1, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1500])) if rng.random() < 0.7 else int(rng.integers(3 * pcols, 1500))
+        N = max(N, 3 * pcols)
+        kernel = int(rng.choice([O.KERNEL_SE, O.KERNEL_MATERN32, O.KERNEL_MATERN52, O.KERNEL_ABSEXP]))
     est = bool(rng.integers(0, 2))
     X = rng.uniform(-5, 5, (N, d))
     y = np.sum(np.sin(X), axis=1) + 0.3 * np.sum(X**2, axis=1) / d
@@ -69,6 +81,9 @@ def one(seed, eng, orc):
     try:
         dl = np.diag(np.linalg.cholesky(Rm))
         cond = float((dl.max() / dl.min()) ** 2)
+        if TREND:  # the 2-norm condition number itself: the diagonal ratio is only a lower bound (seed 70229: a 1-D exponential
+            w = np.linalg.eigvalsh(Rm)  # kernel on 1500 points, 5e7 by the ratio and 1.1e11 by the spectrum -- both builds,
+            cond = max(cond, float(w[-1] / max(w[0], 1e-300)))  # with and without rocBLAS, sat 2.4e-5 from the oracle's gradient)
     except np.linalg.LinAlgError:
         cond = np.inf
     # r03: up to cond 1e12 the comparison is MADE, at the tolerance both sides can honour -- each carries
@@ -118,6 +133,8 @@ def one(seed, eng, orc):
     except Exception as e:  # noqa: BLE001
         return fails, tag + " -- commit failed (%s)" % type(e).__name__
     M = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 1000, 4097])) if rng.random() < 0.7 else int(rng.integers(1, 6000))
+    if TREND and rng.random() < 0.15:
+        M = int(rng.choice([16384, 20000, 70000]))
     Xs = rng.uniform(-5, 5, (M, d))
     if M > 3:
         Xs[1] = X[0]  # a training point among the candidates
@@ -131,6 +148,35 @@ def one(seed, eng, orc):
         fails.append("mu max diff %g (cond %.1e)" % (np.abs(np.ravel(mu) - np.ravel(rmu)).max(), cond))
     if not close(mse, rmse, ptol, 1e-7 * ptol / 1e-6 * s2):
         fails.append("mse max diff %g (sigma2 %g, cond %.1e)" % (np.abs(np.ravel(mse) - np.ravel(rmse)).max(), s2, cond))
+    if TREND and trend == 1 and kernel in (O.KERNEL_SE, O.KERNEL_MATERN32, O.KERNEL_ABSEXP):  # linear basis: the r01 gradient route (k_gemm64 against V, V^T, W^T)
+        x = rng.uniform(-5, 5, d)
+        try:
+            gm, gv = eng.gradient(x)
+            rm, rv_ = orc.gradient(x)
+            if not close(gm, rm, ptol, 1e-8 * ptol / 1e-6) or not close(gv, rv_, ptol, 1e-8 * ptol / 1e-6 * s2):
+                fails.append("input gradient (linear basis) max diff %g / %g" % (np.abs(np.ravel(gm) - np.ravel(rm)).max(), np.abs(np.ravel(gv) - np.ravel(rv_)).max()))
+        except (_lib.BogpError, NotImplementedError) as e:
+            fails.append("gradient raised %s" % type(e).__name__)
+        eng.upload_candidates(Xs)
+        orc.upload_candidates(Xs)
+    if TREND and len(theta) == d:  # the restricted likelihood with the basis' three trend products
+        rpar = np.r_[theta, 0.8] if mode != O.MODE_NOISE_ESTIM else np.r_[theta, 0.8, 1e-3]
+        rnv = nv if mode == O.MODE_NOISY else 0.0
+        try:
+            rr = orc.nll_restricted(kernel, mode, rpar, rnv, est, beta, eval_grad=True, trend=trend)
+        except Exception:  # noqa: BLE001
+            rr = None
+        try:
+            gr = eng.nll_restricted(kernel, mode, rpar, rnv, est, beta, eval_grad=True, trend=trend)
+        except _lib.BogpError:
+            gr = None
+        if rr is not None and gr is not None and np.isfinite(rr[0]):
+            if not close(gr[0], rr[0], tol, tol):
+                fails.append("REML %r vs %r" % (gr[0], rr[0]))
+            if not close(np.ravel(gr[1]), np.ravel(rr[1]), 1e-5 * max(1.0, ptol / 1e-6), 1e-6 * max(1.0, ptol / 1e-6) * (1 + np.abs(rr[1]).max())):
+                fails.append("REML grad max diff %g" % np.abs(np.ravel(gr[1]) - np.ravel(rr[1])).max())
+        eng.commit(kernel, mode, par, nv, est, beta, trend=trend)
+        eng.upload_candidates(Xs)
     if WIDE and trend == 0 and kernel in (O.KERNEL_SE, O.KERNEL_MATERN32, O.KERNEL_ABSEXP):
         # input gradients of the posterior at a random point (gpr.py:537-576) ...
         x = rng.uniform(-5, 5, d)
@@ -209,10 +255,13 @@ def one(seed, eng, orc):
 
 
 def main():
-    global WIDE
+    global WIDE, TREND
     if "--wide" in sys.argv:
         WIDE = True
         sys.argv.remove("--wide")
+    if "--trend" in sys.argv:
+        TREND = True
+        sys.argv.remove("--trend")
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     eng, orc = _lib.Engine(0), OracleEngine()
