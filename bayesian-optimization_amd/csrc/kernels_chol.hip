@@ -749,6 +749,10 @@ __device__ __forceinline__ void mm128_tile(const MmTile& t, double* lds) {
 #undef BOGP_MM_LOAD
 #undef BOGP_MM_STORE
     BOGP_CHOL_DRAIN();
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int rj = 0; rj < 4; ++rj) asm volatile("" : "+v"(acc[ci][rj]));  // the stores' reads of the accumulators stay behind the drain
   }
   // D[i][j]: i = column (MFMA A side), j = row; lane 16 (i % 4) + j, register i / 4
   // (out = alpha * acc: with beta the accumulators started from alpha * out, and alpha^2 = 1)

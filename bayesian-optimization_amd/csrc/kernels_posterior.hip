@@ -256,6 +256,12 @@ __global__ __launch_bounds__(256, 2) void k_contract(ContractArgs a) {
 
   // ---- epilogue: sum of squares over this group's columns, per candidate row -----------------------
   BOGP_MFMA_DRAIN();
+#pragma unroll
+  for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) asm volatile("" : "+a"(acc[mi][ni][t]));  // reads of the accumulators stay behind the drain
   __syncthreads();
   double* red = lds;  // [NWJ][64 rows][16 slots]
 #pragma unroll
@@ -434,6 +440,12 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
 
   // ---- epilogue: D[i][j] sits in lane 16 (i % 4) + j, register i / 4 ---------------------------------
   BOGP_MFMA16_DRAIN();
+  // (the drain has no register operands: an empty volatile asm per accumulator behind it keeps the epilogue's reads from being
+  // scheduled above it -- the MFMAs are inline asm whose results look ready at once to the compiler; kernels_small.hip)
+#pragma unroll
+  for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
   __syncthreads();
   // red[slot][wave][row] with a row pitch of 65 doubles: the writes (lanes = 4 rows x 16 slots) fall on (4 slot + row)
   // mod 32 = every bank pair twice, the reads (lanes = 64 consecutive rows) are conflict free.  (The first layout,

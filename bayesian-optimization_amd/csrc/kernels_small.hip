@@ -31,8 +31,7 @@ namespace bogp {
 namespace {
 constexpr int SM_MT = 64;        // candidates per workgroup
 constexpr int SM_PANEL = 256;    // training rows resident in LDS at a time
-constexpr int SM_WAVES = 8;      // 512 threads: two waves per SIMD
-constexpr int SM_NR = 4;         // column tiles per wave (32 tiles = 512 columns)
+constexpr int SM_WAVES = 8;      // 512 threads: two waves per SIMD; each owns 4 / 2 sixteen-column tiles (SM_NR: Np <= 512 / 256)
 
 typedef double d4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void mfma16s(double a, double b, d4s& c) {
@@ -45,10 +44,15 @@ __device__ __forceinline__ void mfma16s(double a, double b, d4s& c) {
 // is this lane's offset for fragment mi inside a 4-row k-step (the swizzle is folded in: the row parity of a lane is fixed).
 // A tile is active while kb16 <= jt[ni] (wave-uniform); GUARDED (a run-time, wave-uniform flag: ONE inlined copy of this
 // body keeps the kernel inside 256 VGPRs) = false when all four tiles are active for the whole block.
-template <int SM_MR>
+// SM_NR column tiles per wave and a RING of B-fragment slots (one k-pair each) per tile: fragments are requested RING - 2
+// k-pairs ahead.  With four tiles per wave (Np > 256) RING = 4 as before; with two tiles per wave (Np <= 256) the registers the
+// absent tiles would have taken carry an 8-slot ring instead: the wave has half the MFMAs per k-pair to cover each round trip
+// to L2 (+7 % at N = 256; profiles/r03_sweep_scaling.txt).  PH = this block's position inside the RING / 4 blocks the caller
+// unrolls, so that every slot index is a compile-time constant.
+template <int SM_MR, int SM_NR, int RING, int PH>
 __device__ __forceinline__ void small_block16(const bool GUARDED, const double* __restrict__ tile, const double2* __restrict__ vp,
                                               const size_t (&boff)[SM_NR], const int (&jt)[SM_NR], const int (&aoffm)[SM_MR],
-                                              int kb, int kp_clamp, double2 (&bq)[4][SM_NR], d4s (&acc)[SM_MR][SM_NR]) {
+                                              int kb, int kp_clamp, double2 (&bq)[RING][SM_NR], d4s (&acc)[SM_MR][SM_NR]) {
   double af[2][SM_MR];
 #pragma unroll
   for (int mi = 0; mi < SM_MR; ++mi) af[0][mi] = tile[aoffm[mi]];
@@ -56,10 +60,11 @@ __device__ __forceinline__ void small_block16(const bool GUARDED, const double* 
   for (int s = 0; s < 4; ++s) {
     const int kp = kb * 4 + s;
     const int kb16 = kp >> 1;
+    constexpr int AHEAD = RING - 2;
     {
-      const int kpn = min(kp + 2, kp_clamp);
+      const int kpn = min(kp + AHEAD, kp_clamp);
 #pragma unroll
-      for (int ni = 0; ni < SM_NR; ++ni) bq[(s + 2) & 3][ni] = vp[boff[ni] + (size_t)kpn * 64];
+      for (int ni = 0; ni < SM_NR; ++ni) bq[(4 * PH + s + AHEAD) & (RING - 1)][ni] = vp[boff[ni] + (size_t)kpn * 64];
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -72,7 +77,7 @@ __device__ __forceinline__ void small_block16(const bool GUARDED, const double* 
 #pragma unroll
       for (int ni = 0; ni < SM_NR; ++ni) {
         if (!GUARDED || kb16 <= jt[ni]) {
-          const double bv = h == 0 ? bq[s][ni].x : bq[s][ni].y;
+          const double bv = h == 0 ? bq[(4 * PH + s) & (RING - 1)][ni].x : bq[(4 * PH + s) & (RING - 1)][ni].y;
 #pragma unroll
           for (int mi = 0; mi < SM_MR; ++mi) mfma16s(af[sub & 1][mi], bv, acc[mi][ni]);
         }
@@ -86,7 +91,7 @@ __device__ __forceinline__ void small_block16(const bool GUARDED, const double* 
 // SM_MR = sixteen-candidate A fragments per workgroup: 4 (64 candidates) for the bulk; 2 or 3 for the TAIL launch that
 // spreads the last, incomplete round of 64-candidate workgroups over all CUs (the producer's lanes beyond 16 SM_MR idle,
 // the contraction shrinks with SM_MR).
-template <int KERNEL, int SM_MR>
+template <int KERNEL, int SM_MR, int SM_NR>
 __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict__ Xs, const double* __restrict__ sqrt_theta,
                                                         const double* __restrict__ XthT, const double* __restrict__ gamma,
                                                         const double* __restrict__ wvec, const double2* __restrict__ Vp,
@@ -157,16 +162,17 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
   for (int ni = 0; ni < SM_NR; ++ni) jmax = max(jmax, jt[ni]);
   const int nkb_all = Np / 32;                                   // 32-row blocks of the training set
   const int nkb_w = a.need_var ? min(nkb_all, (jmax >> 1) + 1) : 0;  // ... that this wave's tiles need
-  double2 bq[4][SM_NR];
+  constexpr int RING = 16 / SM_NR;  // B-fragment slots per tile: 4 / 8 for 4 / 2 tiles per wave (64 VGPRs either way)
+  constexpr int UNR = RING / 4;     // 32-row blocks per trip of the loop below (slot indices stay compile-time constants)
+  double2 bq[RING][SM_NR];
 #pragma unroll
-  for (int ni = 0; ni < SM_NR; ++ni) {
-    bq[0][ni] = vp[boff[ni]];
-    bq[1][ni] = vp[boff[ni] + (size_t)min(1, kp_clamp) * 64];
-  }
+  for (int kp0 = 0; kp0 < RING - 2; ++kp0)  // in flight while the first panel is produced
+#pragma unroll
+    for (int ni = 0; ni < SM_NR; ++ni) bq[kp0][ni] = vp[boff[ni] + (size_t)min(kp0, kp_clamp) * 64];
   // ONE loop over the 32-row blocks; at every panel boundary all waves meet, produce the next 256 rows of r into LDS and
   // meet again.  Between two boundaries a wave runs its blocks with no barrier; a wave whose tiles are finished idles at
   // the next boundary only (every wave carries the same MFMA count per panel, so they arrive together).
-  for (int kb = 0; kb < nkb_all; ++kb) {
+  for (int kb = 0; kb < nkb_all; kb += UNR) {
     if ((kb & (SM_PANEL / 32 - 1)) == 0) {
       const int p = kb / (SM_PANEL / 32);
       BOGP_STAMP(t_mfma);
@@ -231,17 +237,30 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
       __syncthreads();
       BOGP_STAMP(t_pro);
     }
-    if (kb < nkb_w) {
-      bool full = true;
-#pragma unroll
-      for (int ni = 0; ni < SM_NR; ++ni) full = full && (jt[ni] >= 2 * kb + 1);
-      const double* tile = rs + (kb & (SM_PANEL / 32 - 1)) * 32 * 64;
-      small_block16<SM_MR>(!full, tile, vp, boff, jt, aoffm, kb, kp_clamp, bq, acc);
+#define BOGP_SMALL_BLOCK(PH_)                                                                                            \
+    if (PH_ < UNR && kb + PH_ < nkb_w) {                                                                               \
+      bool full = true;                                                                                                \
+      _Pragma("unroll") for (int ni = 0; ni < SM_NR; ++ni) full = full && (jt[ni] >= 2 * (kb + PH_) + 1);               \
+      const double* tile = rs + ((kb + PH_) & (SM_PANEL / 32 - 1)) * 32 * 64;                                          \
+      small_block16<SM_MR, SM_NR, RING, (PH_ < UNR ? PH_ : 0)>(!full, tile, vp, boff, jt, aoffm, kb + PH_, kp_clamp, bq, acc); \
     }
+    BOGP_SMALL_BLOCK(0)
+    BOGP_SMALL_BLOCK(1)
+    BOGP_SMALL_BLOCK(2)
+    BOGP_SMALL_BLOCK(3)
+#undef BOGP_SMALL_BLOCK
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------------
   BOGP_SM_DRAIN();
+  // The MFMAs are inline asm: to the compiler their results are ready at once, and the drain above (no register operands) does
+  // not keep the epilogue's reads of the accumulators behind it.  With ONE tile per wave the scheduler did hoist the read of
+  // the last-written component of the last accumulator above the drain (rows 60-63 of every workgroup wrong: found by
+  // tests/test_gpu_driver.py at N = 100).  Naming every accumulator in an (empty) volatile asm behind the drain pins the order.
+#pragma unroll
+  for (int mi = 0; mi < SM_MR; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < SM_NR; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
   BOGP_STAMP(t_mfma);
   __syncthreads();
   BOGP_STAMP(t_pro);
@@ -411,15 +430,15 @@ int64_t sweep_small_blocks(int64_t M, int n_cu) {
   return bulk + tw;
 }
 
-template <int MR>
+template <int MR, int NR>
 static hipError_t launch_small_mr(int kernel, const SmallArgs& a, unsigned nwg, hipStream_t st) {
   const size_t shm = ((size_t)SM_PANEL * SM_MT + (size_t)SM_MT * ((a.d + 1) & ~1)) * sizeof(double);
 #define BOGP_LAUNCH_SMALL(K)                                                                                             \
   do {                                                                                                                   \
-    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_small<K, MR>),                            \
+    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_small<K, MR, NR>),                        \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                           \
     if (e_ != hipSuccess) return e_;                                                                                     \
-    hipLaunchKernelGGL((k_sweep_small<K, MR>), dim3(nwg), 512, shm, st, a.Xs, a.sqrt_theta, a.XthT, a.gamma, a.wvec, a.Vp, a); \
+    hipLaunchKernelGGL((k_sweep_small<K, MR, NR>), dim3(nwg), 512, shm, st, a.Xs, a.sqrt_theta, a.XthT, a.gamma, a.wvec, a.Vp, a); \
   } while (0)
   switch (kernel) {
     case BOGP_KERNEL_SE: BOGP_LAUNCH_SMALL(BOGP_KERNEL_SE); break;
@@ -432,6 +451,21 @@ static hipError_t launch_small_mr(int kernel, const SmallArgs& a, unsigned nwg, 
   }
 #undef BOGP_LAUNCH_SMALL
   return hipGetLastError();
+}
+
+// Tiles per wave by training-set size: two for Np <= 256 (measured +7 % at N = 256, profiles/r03_sweep_scaling.txt; one tile per
+// wave with a 16-slot ring was built too and measured the same as two at N = 128 -- below ~200 training points the kernel is
+// bound by the latencies of a workgroup that has the CU to itself, not by the contraction -- so it is not instantiated).  The
+// results are bit-identical whichever is taken: same tiles, same k order, same summation order in the epilogue
+// (test_fused_small_sweep_tiles_per_wave_variants_are_bit_identical); BOGP_SMALL_NR=4 forces the r02 schedule for A/B runs.
+static int small_nr(int Np) {
+  const char* e = getenv("BOGP_SMALL_NR");
+  return (Np <= 256 && !(e && atoi(e) == 4)) ? 2 : 4;
+}
+template <int MR>
+static hipError_t launch_small_nr(int kernel, const SmallArgs& a, unsigned nwg, hipStream_t st) {
+  if (small_nr(a.Np) == 2) return launch_small_mr<MR, 2>(kernel, a, nwg, st);
+  return launch_small_mr<MR, 4>(kernel, a, nwg, st);
 }
 
 // `a` describes the whole sweep (M candidates, a.nblk = sweep_small_blocks(M, n_cu) partial-argmax slots)
@@ -448,16 +482,16 @@ hipError_t launch_sweep_small(int kernel, const SmallArgs& a0, int n_cu, hipStre
       const unsigned nwg = (unsigned)((a0.M + 16 * mr - 1) / (16 * mr));
       a.final_launch = 1;
       if ((int64_t)nwg > a0.nblk) return hipErrorInvalidValue;
-      return mr == 2 ? launch_small_mr<2>(kernel, a, nwg, st) : launch_small_mr<3>(kernel, a, nwg, st);
+      return mr == 2 ? launch_small_nr<2>(kernel, a, nwg, st) : launch_small_nr<3>(kernel, a, nwg, st);
     }
   }
   a.final_launch = tail_wg == 0;
-  hipError_t e = launch_small_mr<4>(kernel, a, (unsigned)bulk, st);
+  hipError_t e = launch_small_nr<4>(kernel, a, (unsigned)bulk, st);
   if (e != hipSuccess || tail_wg == 0) return e;
   a.m_begin = bulk * SM_MT;
   a.blk_begin = bulk;
   a.final_launch = 1;
-  return tail_mr == 3 ? launch_small_mr<3>(kernel, a, (unsigned)tail_wg, st) : launch_small_mr<2>(kernel, a, (unsigned)tail_wg, st);
+  return tail_mr == 3 ? launch_small_nr<3>(kernel, a, (unsigned)tail_wg, st) : launch_small_nr<2>(kernel, a, (unsigned)tail_wg, st);
 }
 
 }  // namespace bogp

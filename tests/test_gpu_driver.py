@@ -188,7 +188,8 @@ def test_set_train_reuses_its_buffers_across_a_growing_training_set():
 
 
 @pytest.mark.parametrize("N,d,kernel,mode,est", [
-    (33, 1, O.KERNEL_SE, O.MODE_NOISY, False), (200, 6, O.KERNEL_MATERN52, O.MODE_NOISY, True),
+    (33, 1, O.KERNEL_SE, O.MODE_NOISY, False), (100, 5, O.KERNEL_MATERN32, O.MODE_NOISY, True), (128, 4, O.KERNEL_MATERN52, O.MODE_NOISY, False),
+    (129, 7, O.KERNEL_SE, O.MODE_NOISY, True), (200, 6, O.KERNEL_MATERN52, O.MODE_NOISY, True),
     (256, 10, O.KERNEL_SE, O.MODE_NOISY, False), (257, 3, O.KERNEL_MATERN32, O.MODE_NOISY, True),
     (500, 20, O.KERNEL_ABSEXP, O.MODE_NOISY, False), (512, 10, O.KERNEL_SE, O.MODE_NOISY, True),
     (480, 64, O.KERNEL_MATERN12, O.MODE_NOISY, False),
@@ -298,6 +299,39 @@ def test_library_exchange_with_a_one_rank_communicator():
         assert np.all(g >= 50) and np.array_equal(x, Xs[g - 50])
     eng.comm_destroy()
     assert eng.comm_info() == (0, 0)
+
+
+@pytest.mark.parametrize("N,d", [(17, 2), (64, 3), (128, 5), (130, 5), (256, 10)])
+def test_fused_small_sweep_tiles_per_wave_variants_are_bit_identical(N, d):
+    """r03: up to N = 256 a wave of k_sweep_small owns two column tiles of V instead of four and spends the registers of the absent
+    ones on a deeper B-fragment prefetch ring.  Same tiles, same k order, same summation order: the outputs must be the SAME BITS as
+    with the four-tile schedule (BOGP_SMALL_NR=4), values and argmax alike."""
+    import os
+
+    rng = np.random.default_rng(1000 * N + d)
+    X = rng.uniform(-5, 5, size=(N, d))
+    y = np.sum(np.cos(X), axis=1)
+    y = ((y - y.mean()) / y.std() + 0.05 * rng.standard_normal(N)).reshape(-1, 1)
+    par = np.r_[np.full(d, 0.3 / d), 0.9]
+    eng = _lib.Engine(0)
+    eng.set_train(X, y)
+    eng.commit(O.KERNEL_MATERN52, O.MODE_NOISY, par, 1e-6, True, 0.0)
+    acq = [(_lib.ACQ_EI, 0.0), (_lib.ACQ_MGFI, 2.0)]
+    for M in (64, 1000, 16384 + 700):
+        eng.upload_candidates(rng.uniform(-5, 5, size=(M, d)))
+        out = []
+        for forced in (None, "4"):
+            if forced:
+                os.environ["BOGP_SMALL_NR"] = forced
+            try:
+                mu, mse = eng.predict()
+                best, idx, vals = eng.sweep(acq, float(y.min()), True, return_values=True)
+            finally:
+                os.environ.pop("BOGP_SMALL_NR", None)
+            out.append((mu, mse, best, idx, vals))
+        for a, b in zip(out[0], out[1]):
+            np.testing.assert_array_equal(a, b)
+    eng.close()
 
 
 @pytest.mark.parametrize("N", [6144, 6200, 7000])
