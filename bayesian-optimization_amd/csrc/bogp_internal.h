@@ -34,6 +34,7 @@ struct ContractArgs {
   int nJ;    // column groups
   int NJ16;  // Np / 16
   int NKP;   // Np / 8
+  int64_t cross_B;  // launch_contract_cross: points (ss_part is then their record array, see k_contract16<NR, NCP>)
 };
 
 struct AcqArgs {
@@ -100,6 +101,7 @@ hipError_t launch_sweep_small(int kernel, const SmallArgs& a, int n_cu, hipStrea
 
 hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipStream_t st);
 hipError_t launch_contract(const ContractArgs& a, hipStream_t st);
+hipError_t launch_contract_cross(const ContractArgs& a, int ncp, hipStream_t st);
 int contract_cols_per_group();
 hipError_t launch_acquisition(const AcqArgs& a, hipStream_t st);
 hipError_t launch_argmax_final(const double* blk_val, const int64_t* blk_idx, int64_t nblk, int64_t stride, int q,
@@ -256,6 +258,12 @@ int point_passes(int d);
 void point_tri_geometry(int N, int d, int B, int* rb, int* nsplit);
 hipError_t launch_point_rhs(int kernel, const PointRhsArgs& a, int B, hipStream_t st);
 hipError_t launch_point_tri(const PointTriArgs& a, int B, hipStream_t st);
+// MFMA flavour of the B-point path (kernels_point.hip): ncp = point_mfma_columns(d) right-hand-side columns per point (0: d too large)
+int point_mfma_columns(int d);
+hipError_t launch_point_rhs_T(int kernel, const PointRhsArgs& a, int ncp, double* rT, long long Mc, int Np, int B, hipStream_t st);
+hipError_t launch_point_gw(int ncp, const double* rT, long long Mc, const double* gamma, const double* wvec, int Nr32, int B, int nJ,
+                           double* part, hipStream_t st);
+hipError_t launch_point_finish_mfma(const PointTriArgs& a, int ncp, int B, hipStream_t st);
 size_t polish_state_doubles();
 hipError_t launch_polish_step(const PolishArgs& a, int B, hipStream_t st);
 

@@ -72,6 +72,41 @@ int queue_point_eval(bogp_handle* h, const PointPlan& pl, const double* dXb, con
                      unsigned long long* done_flag = nullptr, unsigned long long done_seq = 0) {
   hipStream_t st = h->stream;
   int e;
+  // Enough right-hand sides: C = V rhs is the candidate sweep's triangular product -- FP64 MFMA through k_contract16's
+  // cross-product epilogue against the packed V of the commit (kernels_point.hip, "MFMA flavour") instead of k_point_tri's
+  // FP64-VALU loop.  "Enough" = the (64-column tile, 256-column group of V) workgroups fill the GPU's 512 slots one and a half
+  // times: a workgroup of the last group walks all N rows whatever B is (220 us at N = 2048), so below that the VALU path's
+  // finer split is faster -- C3: 128 points 515 us (VALU) vs 582 (MFMA); C5: 32 points 6.1 ms vs 3.0, 128 points 24.7 vs 11.0
+  // (profiles/r03_point_call_latency.txt).  BOGP_POINT_MFMA_MIN = that workgroup count (default 768; 0 = never).
+  const int ncp = point_mfma_columns(h->d);
+  const char* e_min = getenv("BOGP_POINT_MFMA_MIN");  // read per call: the tests run both flavours in one process
+  const long long mfma_min = e_min ? atoll(e_min) : 768LL;
+  if (dXb && ncp > 0 && h->dVp && mfma_min > 0 && (((long long)B * ncp + 63) / 64) * ((h->Np + 255) / 256) >= mfma_min) {
+    const int Np = h->Np, nJ = (Np + 255) / 256;
+    const long long Mc = ((long long)B * ncp + 63) / 64 * 64;
+    if ((e = ensure(h, &h->drT[0], &h->rT_cap[0], (size_t)Np * Mc))) return e;
+    if ((e = ensure(h, &h->dpt_part, &h->pt_part_cap, (size_t)B * (nJ + 1) * 2 * ncp))) return e;
+    PointRhsArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.X = h->dX; ra.theta = h->dtheta; ra.Xb = dXb; ra.N = h->N; ra.d = h->d;
+    HIPCHK(h, launch_point_rhs_T(h->kernel, ra, ncp, h->drT[0], Mc, Np, B, st));
+    HIPCHK(h, launch_point_gw(ncp, h->drT[0], Mc, h->dgamma, h->dw, pl.Nr32, B, nJ, h->dpt_part, st));
+    ContractArgs ka;
+    memset(&ka, 0, sizeof(ka));
+    ka.rT = h->drT[0]; ka.Vp = h->dVp; ka.ss_part = h->dpt_part; ka.Mc = Mc; ka.nMt = (int)(Mc / 64); ka.nJ = nJ;
+    ka.NJ16 = Np / 16; ka.NKP = Np / 8; ka.cross_B = B;
+    HIPCHK(h, launch_contract_cross(ka, ncp, st));
+    PointTriArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.part = h->dpt_part; fa.out = out; fa.nRB = nJ; fa.npass = 1; fa.d = h->d;
+    fa.rec_stride = pl.rec_stride; fa.q = q; fa.want_dacq = want_dacq ? 1 : 0; fa.estimate_trend = h->estimate_trend;
+    fa.minimize = minimize;
+    for (int i = 0; i < q; ++i) { fa.acq_id[i] = acq_id[i]; fa.acq_par[i] = acq_par ? acq_par[i] : 0.0; }
+    fa.plugin = plugin; fa.beta = h->beta; fa.G = h->G; fa.ftft = h->ftft; fa.sigma2 = h->sigma2;
+    fa.done_flag = done_flag; fa.done_seq = done_seq;
+    HIPCHK(h, launch_point_finish_mfma(fa, ncp, B, st));
+    return BOGP_OK;
+  }
   if ((e = ensure(h, &h->dpt_rhs, &h->pt_rhs_cap, (size_t)B * pl.npass * pl.Npp * pl.NC))) return e;
   if ((e = ensure(h, &h->dpt_part, &h->pt_part_cap, (size_t)B * pl.npass * (pl.nRB + 1) * 2 * pl.NC))) return e;
   const size_t nslots = (size_t)B * pl.npass * (pl.nRB + 1);

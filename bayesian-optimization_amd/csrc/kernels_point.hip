@@ -93,6 +93,84 @@ __global__ __launch_bounds__(256) void k_point_rhs(PointRhsArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// MFMA flavour of the B-point path (r03, SURVEY.md 8 f2: "another MFMA GEMM L^-1 r_dx").  With enough right-hand sides --
+// B (d + 1) columns -- C = V rhs is the SAME triangular product the candidate sweep runs, so it goes through k_contract16
+// (kernels_posterior.hip, its cross-product epilogue <4, NCP>) against the packed V of the commit instead of k_point_tri's
+// FP64-VALU loop:
+//   k_point_rhs_T<KERNEL, NCP>  the right-hand sides in the contraction's layout rT[n][m], m = b NCP + c, c = 0: r_n,
+//                               c = 1 + k: dr_n / dx_k, zero beyond d + 1 (NCP = 16 / 32 / 64 columns per point, ONE pass)
+//   k_point_gw<NCP>             gamma . rhs_c and w . rhs_c (what k_point_tri's extra workgroup does) -> record 0 of the point
+//   k_contract16<4, NCP>        sum_j C_0[j] C_c[j] per 256-column group of V                        -> records 1 .. nJ
+//   k_point_finish<NCP>         unchanged (npass = 1, nRB = nJ)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KERNEL, int NCP>
+__global__ __launch_bounds__(256) void k_point_rhs_T(PointRhsArgs a, double* __restrict__ rT, long long Mc, int Np, int B) {
+  constexpr int CPS = NCP / 4;  // columns per slice
+  __shared__ double xs[BOGP_POINT_MAX_D], ths[BOGP_POINT_MAX_D];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;
+  const int b = blockIdx.y;  // b >= B: the padding columns up to Mc (zeros)
+  const int d = a.d;
+  if (b < B) {
+    for (int k = threadIdx.x; k < d; k += 256) {
+      xs[k] = a.Xb[(size_t)b * d + k];
+      ths[k] = a.theta[k];
+    }
+  }
+  __syncthreads();
+  if (n >= Np) return;
+  const bool live = n < a.N && b < B;
+  double rv = 0.0, D = 0.0, e5 = 0.0;
+  const double* __restrict__ xr = a.X + (size_t)(live ? n : 0) * d;
+  if (live) {
+    double s2 = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < d; ++k) s2 += dist_term<KERNEL>(ths[k], fabs(xs[k] - xr[k]));
+    rv = corr_profile<KERNEL>(s2);
+    D = sqrt(s2);
+    if (KERNEL == BOGP_KERNEL_MATERN32) e5 = exp(-1.7320508075688772 * D);
+    if (KERNEL == BOGP_KERNEL_MATERN52) e5 = exp(-2.23606797749979 * D);
+  }
+  double* row = rT + (size_t)n * Mc + (size_t)b * NCP;
+  const int c0 = slice * CPS;
+  if ((long long)b * NCP + c0 >= Mc) return;
+#pragma unroll
+  for (int c = c0; c < c0 + CPS; c += 2) {
+    double v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int cc = c + i, k = cc - 1;
+      v[i] = cc == 0 ? rv : ((live && k < d) ? point_dx_entry<KERNEL>(rv, D, e5, ths[k], xs[k] - xr[k]) : 0.0);
+    }
+    *(double2*)(row + c) = make_double2(v[0], v[1]);
+  }
+}
+
+// one thread per right-hand-side column m: g = gamma . rhs_m, w = wvec . rhs_m over the Nr32 live rows (four interleaved
+// partial sums added in a fixed order); record 0 of point b = m / NCP
+template <int NCP>
+__global__ __launch_bounds__(256) void k_point_gw(const double* __restrict__ rT, long long Mc, const double* __restrict__ gamma,
+                                                  const double* __restrict__ wvec, int Nr32, int B, int nJ, double* __restrict__ part) {
+  const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (m >= (long long)B * NCP) return;
+  double g[4] = {0.0, 0.0, 0.0, 0.0}, w[4] = {0.0, 0.0, 0.0, 0.0};
+  const double* __restrict__ col = rT + m;
+  for (int n = 0; n < Nr32; n += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double v = col[(size_t)(n + u) * Mc];
+      g[u] = __builtin_fma(gamma[n + u], v, g[u]);
+      w[u] = __builtin_fma(wvec[n + u], v, w[u]);
+    }
+  }
+  const long long b = m / NCP;
+  const int c = (int)(m - b * NCP);
+  double* rec = part + (size_t)b * (nJ + 1) * (2 * NCP);
+  rec[c] = (g[0] + g[1]) + (g[2] + g[3]);
+  rec[NCP + c] = (w[0] + w[1]) + (w[2] + w[3]);
+}
+
 // d acq / d x_k = a_dy * dy_k + a_dsd * dsd_k   (acquisition_fun.py:139-146, 181-188, 220-227, 292-309); the guards of
 // the reference return a zero gradient, its FloatingPointError path (np.errstate(all="raise")) likewise
 __device__ __forceinline__ void acq_grad_coef(int id, double par, double y, double sd, double plugin, double sigma2, double& a_dy,
@@ -542,6 +620,44 @@ hipError_t launch_point_tri(const PointTriArgs& a, int B, hipStream_t st) {
     else hipLaunchKernelGGL((k_point_tri<22, 1>), grid, 256, 0, st, a.V, a.gamma, a.wvec, a.rhs, a);
     hipLaunchKernelGGL(k_point_finish<22>, dim3(B), 256, 0, st, a);
   }
+  return hipGetLastError();
+}
+
+int point_mfma_columns(int d) { return d + 1 <= 16 ? 16 : (d + 1 <= 32 ? 32 : (d + 1 <= 64 ? 64 : 0)); }
+
+hipError_t launch_point_rhs_T(int kernel, const PointRhsArgs& a, int ncp, double* rT, long long Mc, int Np, int B, hipStream_t st) {
+  dim3 grid((Np + 63) / 64, (unsigned)(Mc / ncp));
+#define CALLN(K, N_) hipLaunchKernelGGL((k_point_rhs_T<K, N_>), grid, 256, 0, st, a, rT, Mc, Np, B)
+#define CALL(K)                                  \
+  if (ncp == 16) CALLN(K, 16);                   \
+  else if (ncp == 32) CALLN(K, 32);              \
+  else CALLN(K, 64)
+  switch (kernel) {
+    case BOGP_KERNEL_SE: CALL(BOGP_KERNEL_SE); break;
+    case BOGP_KERNEL_MATERN12: CALL(BOGP_KERNEL_MATERN12); break;
+    case BOGP_KERNEL_MATERN32: CALL(BOGP_KERNEL_MATERN32); break;
+    case BOGP_KERNEL_ABSEXP: CALL(BOGP_KERNEL_ABSEXP); break;
+    default: CALL(BOGP_KERNEL_MATERN52); break;
+  }
+#undef CALL
+#undef CALLN
+  return hipGetLastError();
+}
+
+hipError_t launch_point_gw(int ncp, const double* rT, long long Mc, const double* gamma, const double* wvec, int Nr32, int B, int nJ,
+                           double* part, hipStream_t st) {
+  const dim3 grid((unsigned)(((long long)B * ncp + 255) / 256));
+  if (ncp == 16) hipLaunchKernelGGL(k_point_gw<16>, grid, 256, 0, st, rT, Mc, gamma, wvec, Nr32, B, nJ, part);
+  else if (ncp == 32) hipLaunchKernelGGL(k_point_gw<32>, grid, 256, 0, st, rT, Mc, gamma, wvec, Nr32, B, nJ, part);
+  else hipLaunchKernelGGL(k_point_gw<64>, grid, 256, 0, st, rT, Mc, gamma, wvec, Nr32, B, nJ, part);
+  return hipGetLastError();
+}
+
+// a.npass = 1, a.nRB = column groups, a.part = the records of k_point_gw + k_contract16<4, NCP>
+hipError_t launch_point_finish_mfma(const PointTriArgs& a, int ncp, int B, hipStream_t st) {
+  if (ncp == 16) hipLaunchKernelGGL(k_point_finish<16>, dim3(B), 256, 0, st, a);
+  else if (ncp == 32) hipLaunchKernelGGL(k_point_finish<32>, dim3(B), 256, 0, st, a);
+  else hipLaunchKernelGGL(k_point_finish<64>, dim3(B), 256, 0, st, a);
   return hipGetLastError();
 }
 

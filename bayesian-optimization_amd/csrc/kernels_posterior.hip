@@ -342,7 +342,13 @@ __device__ __forceinline__ void contract_block16(const bool GUARDED, const doubl
   }
 }
 
-template <int NR>
+// NCP != 0 (16 / 32 / 64): the batched one-point path (kernels_point.hip, k_point_rhs_T).  The 64 "candidates" of a workgroup are
+// then the right-hand-side columns [r | dr/dx_1 .. dr/dx_d | 0 ..] of 64 / NCP points, NCP columns each, and what a point needs
+// from C = V rhs is not |C_c|^2 but the cross products  sum_j C_0[j] C_c[j]  with its FIRST column ((V^T V r) . dr/dx_k =
+// (V r) . (V dr/dx_k): one pass over V serves the posterior AND its d input-derivatives, gpr.py:537-576).  Only the epilogue
+// differs: the first row of every NCP-row group (fragment head, register 0, lane quarter 0) is broadcast to the other quarters
+// and multiplies instead of the square; the sums land as the row-block records k_point_finish reads.
+template <int NR, int NCP = 0>
 __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArgs a) {
   constexpr int JT16 = NWJ * NR;
   __shared__ __attribute__((aligned(16))) double lds[2 * KB * PITCH];
@@ -454,16 +460,35 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
   double* red = lds;                    // [16 slots][NWJ][RP]
   double* red2 = lds + 16 * NWJ * RP;   // [NWJ][64]: per-wave partial sums
   const int q = lane >> 4, jc = lane & 15;
+  if constexpr (NCP == 0) {
 #pragma unroll
-  for (int mi = 0; mi < MR; ++mi)
+    for (int mi = 0; mi < MR; ++mi)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double s = 0.0;
+      for (int r = 0; r < 4; ++r) {
+        double s = 0.0;
 #pragma unroll
-      for (int ni = 0; ni < NR; ++ni)
-        if (valid[ni]) s = __builtin_fma(acc[mi][ni][r], acc[mi][ni][r], s);
-      red[(jc * NWJ + w) * RP + 16 * mi + 4 * r + q] = s;  // slot = column inside the 16-tile
-    }
+        for (int ni = 0; ni < NR; ++ni)
+          if (valid[ni]) s = __builtin_fma(acc[mi][ni][r], acc[mi][ni][r], s);
+        red[(jc * NWJ + w) * RP + 16 * mi + 4 * r + q] = s;  // slot = column inside the 16-tile
+      }
+  } else {
+    constexpr int FPG = NCP / 16;  // fragments per point
+    double head[MR / FPG][NR];     // row 0 of each point, for this lane's column jc: D[16 mi0][jc] = lane jc, register 0
+#pragma unroll
+    for (int g = 0; g < MR / FPG; ++g)
+#pragma unroll
+      for (int ni = 0; ni < NR; ++ni) head[g][ni] = __shfl(acc[g * FPG][ni][0], jc);
+#pragma unroll
+    for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double s = 0.0;
+#pragma unroll
+        for (int ni = 0; ni < NR; ++ni)
+          if (valid[ni]) s = __builtin_fma(acc[mi][ni][r], head[mi / FPG][ni], s);
+        red[(jc * NWJ + w) * RP + 16 * mi + 4 * r + q] = s;
+      }
+  }
   __syncthreads();
   {  // every thread adds the 16 slots of one (wave, row) in a fixed order, then 64 threads add the four waves
     double s = 0.0;
@@ -472,7 +497,17 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
     red2[w * 64 + lane] = s;
   }
   __syncthreads();
-  if (tid < 64) a.ss_part[(size_t)jg * a.Mc + mc0 + tid] = ((red2[tid] + red2[64 + tid]) + red2[128 + tid]) + red2[192 + tid];
+  if (tid < 64) {
+    const double tot = ((red2[tid] + red2[64 + tid]) + red2[128 + tid]) + red2[192 + tid];
+    if constexpr (NCP == 0) {
+      a.ss_part[(size_t)jg * a.Mc + mc0 + tid] = tot;
+    } else {  // record 1 + jg of point b: [0][c] = sum over this column group of C_0 C_c  (k_point_finish adds the groups)
+      const int64_t m = mc0 + tid;
+      const int64_t b = m / NCP;
+      const int c = (int)(m - b * NCP);
+      if (b < a.cross_B) a.ss_part[((size_t)b * (a.nJ + 1) + 1 + jg) * (2 * NCP) + c] = tot;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -541,5 +576,16 @@ hipError_t launch_contract(const ContractArgs& a, hipStream_t st) {
 }
 
 int contract_cols_per_group() { return NWJ * contract_nr() * 16; }
+
+// the cross-product flavour for the batched one-point path: ncp = 16 / 32 / 64 right-hand-side columns per point; always the
+// 256-column workgroups (a.nJ must be ceil(Np / 256)); a.ss_part = the points' record array, a.cross_B = points
+hipError_t launch_contract_cross(const ContractArgs& a, int ncp, hipStream_t st) {
+  const dim3 grid((unsigned)(a.nMt * a.nJ));
+  if (ncp == 16) hipLaunchKernelGGL((k_contract16<4, 16>), grid, 256, 0, st, a);
+  else if (ncp == 32) hipLaunchKernelGGL((k_contract16<4, 32>), grid, 256, 0, st, a);
+  else if (ncp == 64) hipLaunchKernelGGL((k_contract16<4, 64>), grid, 256, 0, st, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
 
 }  // namespace bogp

@@ -107,6 +107,52 @@ def test_point_batch_against_the_oracle_at_other_shapes(eng, N, d, kernel, est):
                 np.testing.assert_allclose(dvals[i, c], np.ravel(odx), rtol=2e-6, atol=1e-9 * scale, err_msg="acq %d row %d" % (aid, i))
 
 
+@pytest.mark.parametrize("N,d,kernel,est,B", [(300, 3, O.KERNEL_SE, False, 37), (700, 25, O.KERNEL_MATERN32, True, 9), (1100, 11, O.KERNEL_ABSEXP, True, 64),
+                                              (2048, 20, O.KERNEL_MATERN52, False, 130), (97, 47, O.KERNEL_SE, True, 3), (513, 63, O.KERNEL_MATERN12, True, 5),
+                                              (260, 15, O.KERNEL_SE, False, 4), (260, 16, O.KERNEL_SE, True, 4), (64, 31, O.KERNEL_MATERN32, False, 2)])  # fmt: skip
+def test_mfma_flavour_of_the_point_batch_equals_the_valu_flavour_and_the_oracle(eng, N, d, kernel, est, B):
+    """r03: with enough right-hand sides the B-point path runs C = V rhs through k_contract16's cross-product epilogue (FP64 MFMA
+    against the packed V; 16 / 32 / 64 columns per point) instead of k_point_tri.  Both flavours on the same points
+    (BOGP_POINT_MFMA_MIN = 1 / 0 forces one or the other): the same numbers up to the order of the sums, the oracle's at 1e-6 --
+    shapes on both sides of every column count (d + 1 = 16, 17, 32, 64), ragged N, one and many 64-column tiles, padding points."""
+    import os
+
+    rng = np.random.default_rng(31 * N + d)
+    X = rng.uniform(-5, 5, size=(N, d))
+    y = np.sum(np.sin(X), axis=1) + 0.1 * rng.standard_normal(N)
+    y = ((y - y.mean()) / y.std()).reshape(-1, 1)
+    par = np.r_[np.full(d, 0.5 / d), 0.85]
+    eng.set_train(X, y)
+    eng.commit(kernel, O.MODE_NOISY, par, 1e-5, est, 0.0)
+    st = O.make_state(par, X, y, kernel, O.MODE_NOISY, 1e-5, estimate_trend=est, beta=None if est else 0.0)
+    Xb = rng.uniform(-5, 5, size=(B, d))
+    Xb[B // 2] = X[1] + 1e-3 * rng.standard_normal(d)
+    pl = O.plugin_value(st.y, True)
+    acq = [(O.ACQ_EI, 0.0), (O.ACQ_MGFI, 2.0), (O.ACQ_UCB, 0.5)]
+    out = {}
+    for tag, v in (("mfma", "1"), ("valu", "0")):
+        os.environ["BOGP_POINT_MFMA_MIN"] = v
+        try:
+            out[tag] = eng.point_eval_batch(Xb, acq, pl, True)
+            again = eng.point_eval_batch(Xb, acq, pl, True)
+        finally:
+            del os.environ["BOGP_POINT_MFMA_MIN"]
+        for a, b in zip(out[tag], again):
+            np.testing.assert_array_equal(a, b)  # deterministic
+    s2 = float(st.sigma2[0])
+    names = ("mu", "mse", "dmu", "dmse", "values", "dvalues")
+    for name, a, b in zip(names, out["mfma"], out["valu"]):
+        scale = max(1e-300, float(np.max(np.abs(b))))
+        np.testing.assert_allclose(a, b, rtol=1e-7, atol=1e-9 * scale, err_msg=name)  # two summation orders of the same sums
+    omu, omse = O.predict(st, Xb)
+    np.testing.assert_allclose(out["mfma"][0], omu.ravel(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(out["mfma"][1], omse.ravel(), rtol=1e-6, atol=1e-12 * s2)
+    for i in range(min(B, 4)):
+        odmu, odmse = O.gradient(st, Xb[i])
+        np.testing.assert_allclose(out["mfma"][2][i], np.ravel(odmu), rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(out["mfma"][3][i], np.ravel(odmse), rtol=1e-6, atol=1e-9 * s2)
+
+
 def test_acquisition_call_with_many_rows_and_return_dx(eng):
     """`criterion(X, return_dx=True)` with several rows (the reference raises, gpr.py:548-549): row i = its one-row answer."""
     g = load_golden("G1_se_sk_noisy")

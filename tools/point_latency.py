@@ -45,7 +45,7 @@ def main():
         ei = bogp.EI(model=gp, minimize=True)
         x1 = x[None, :]
         print("bogp.EI(x, return_dx=True) (the reference's BFGS call)       : %8.1f us" % timeit(lambda: ei(x1, return_dx=True), 2000))
-        for B in (8, 32, 128):
+        for B in (8, 32, 128, 512):
             Xb = rng.uniform(-5, 5, size=(B, d))
             t = timeit(lambda: eng.point_eval_batch(Xb, acq, pl, True), 300)
             print("engine.point_eval_batch B = %3d                               : %8.1f us  (%.2f us per point)" % (B, t, t / B))
