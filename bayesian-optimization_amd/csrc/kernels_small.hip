@@ -21,6 +21,7 @@
 // Algorithmic work per candidate: N^2 + N (3d + 5 + 2p) flop; compulsory HBM bytes: 8 d per candidate
 // + V (2 MB at N = 512, L2-resident) -- the kernel is bound by the FP64 pipe (MFMA + the producer's VALU work, which
 // share it and therefore add).
+#include <algorithm>
 #include <cstdlib>
 
 #include "bogp_device.h"
@@ -91,14 +92,25 @@ __device__ __forceinline__ void small_block16(const bool GUARDED, const double* 
 // SM_MR = sixteen-candidate A fragments per workgroup: 4 (64 candidates) for the bulk; 2 or 3 for the TAIL launch that
 // spreads the last, incomplete round of 64-candidate workgroups over all CUs (the producer's lanes beyond 16 SM_MR idle,
 // the contraction shrinks with SM_MR).
-template <int KERNEL, int SM_MR, int SM_NR>
-__global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict__ Xs, const double* __restrict__ sqrt_theta,
+// NW = waves per workgroup.  8 (512 threads, 256-row panels, one workgroup per CU) up to Np = 512.  NW = 4 (r03; 256 threads,
+// 128-row panels of 64 KB, four tiles {w, 7 - w, 8 + w, 15 - w} per wave) serves Np <= 256 with TWO workgroups per CU: below
+// ~250 training points a workgroup that has the CU to itself is bound by its own latencies (load -> barrier -> produce ->
+// barrier -> contract -> epilogue: 53 k cycles at N = 128 for < 10 k cycles of DP-pipe work), and a second, independent
+// workgroup fills them.  A 4-wave workgroup carries each of its waves' sums as the two "virtual" waves of the 8-wave
+// schedule they are made of (wave w = virtual waves w and 7 - w of the contraction, w and w + 4 of the producer), in the same
+// order: the outputs are the SAME BITS as with NW = 8 (test_fused_small_sweep_tiles_per_wave_variants_are_bit_identical).
+template <int KERNEL, int SM_MR, int SM_NR, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_sweep_small(const double* __restrict__ Xs, const double* __restrict__ sqrt_theta,
                                                         const double* __restrict__ XthT, const double* __restrict__ gamma,
                                                         const double* __restrict__ wvec, const double2* __restrict__ Vp,
                                                         SmallArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* rs = smem;                       // [256][64] resident panel of r, swizzled
-  double* xs = smem + SM_PANEL * SM_MT;    // [d][64] theta-scaled candidate tile, k-major
+  constexpr int NT = 64 * NW;      // threads
+  constexpr int PANEL = 32 * NW;   // training rows resident in LDS at a time: every wave produces 32 of them
+  constexpr int HW = 2 * NW;       // tiles per serpentine half
+  static_assert(NW == 8 || (NW == 4 && SM_NR == 4), "4-wave workgroups carry four tiles per wave (Np <= 256)");
+  double* rs = smem;                       // [PANEL][64] resident panel of r, swizzled
+  double* xs = smem + PANEL * SM_MT;       // [d][64] theta-scaled candidate tile, k-major
   __shared__ int s_last;
 
   const int tid = threadIdx.x;
@@ -110,13 +122,13 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
 
   const double pexp = kernel_exponent<KERNEL>(sqrt_theta, d);
   const int d2 = (d + 1) & ~1;  // the producer walks the dimensions two at a time; xs is sized for d2 rows, row d (if any) is zero
-  for (int idx = tid; idx < SM_MT * d; idx += 512) {
+  for (int idx = tid; idx < SM_MT * d; idx += NT) {
     const int row = idx / d, k = idx - row * d;
     const int64_t gm = mg0 + row;
     const double v = (row < MT && gm < a.M) ? Xs[gm * d + k] : 0.0;
     xs[k * SM_MT + row] = v * sqrt_theta[k];
   }
-  for (int idx = tid; idx < SM_MT * (d2 - d); idx += 512) xs[d * SM_MT + idx] = 0.0;
+  for (int idx = tid; idx < SM_MT * (d2 - d); idx += NT) xs[d * SM_MT + idx] = 0.0;
 
   // column tiles of this wave: serpentine over the (up to) 32 tiles, so that in every panel every wave carries the same
   // number of sixteen-row groups: tiles {w, 15 - w} end inside panel 0, {16 + w, 31 - w} inside panel 1
@@ -125,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
   bool valid[SM_NR];
 #pragma unroll
   for (int ni = 0; ni < SM_NR; ++ni) {
-    const int j = (ni >> 1) * 16 + ((ni & 1) ? 15 - w : w);
+    const int j = (ni >> 1) * HW + ((ni & 1) ? HW - 1 - w : w);
     valid[ni] = j < NJ16;
     jt[ni] = valid[ni] ? j : -1;
     boff[ni] = (size_t)min(j, NJ16 - 1) * NKP * 64;
@@ -156,7 +168,8 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
     t_mark = now_;                        \
   }
   long long t_pro = 0;
-  double mu = 0.0, wd = 0.0;
+  double mu = 0.0, wd = 0.0;    // partial sums r . gamma, r . w over the rows this wave produces ...
+  double mu1 = 0.0, wd1 = 0.0;  // ... NW = 4: those of the ODD panels (the rows of virtual wave w + 4), kept apart
   int jmax = -1;
 #pragma unroll
   for (int ni = 0; ni < SM_NR; ++ni) jmax = max(jmax, jt[ni]);
@@ -173,12 +186,12 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
   // meet again.  Between two boundaries a wave runs its blocks with no barrier; a wave whose tiles are finished idles at
   // the next boundary only (every wave carries the same MFMA count per panel, so they arrive together).
   for (int kb = 0; kb < nkb_all; kb += UNR) {
-    if ((kb & (SM_PANEL / 32 - 1)) == 0) {
-      const int p = kb / (SM_PANEL / 32);
+    if ((kb & (PANEL / 32 - 1)) == 0) {
+      const int p = kb / (PANEL / 32);
       BOGP_STAMP(t_mfma);
       __syncthreads();  // every wave is done with the previous panel (and, for p = 0, the candidate tile is staged)
       BOGP_STAMP(t_pro);  // time spent waiting for the other waves
-      const int nb = p * SM_PANEL + w * 32;
+      const int nb = p * PANEL + w * 32;
       if (nb < Np) {
 #pragma unroll 1
         for (int st = 0; st < 4; ++st) {
@@ -226,10 +239,15 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const double r = corr_profile<KERNEL>(ac[i]);
-            const int nl = n0 + i - p * SM_PANEL;
+            const int nl = n0 + i - p * PANEL;
             rs[nl * 64 + (lane ^ ((nl & 1) << 4))] = r;
-            mu = __builtin_fma(r, gamma[n0 + i], mu);
-            wd = __builtin_fma(r, wvec[n0 + i], wd);
+            if (NW == 8 || (p & 1) == 0) {
+              mu = __builtin_fma(r, gamma[n0 + i], mu);
+              wd = __builtin_fma(r, wvec[n0 + i], wd);
+            } else {
+              mu1 = __builtin_fma(r, gamma[n0 + i], mu1);
+              wd1 = __builtin_fma(r, wvec[n0 + i], wd1);
+            }
           }
         }
       }
@@ -241,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
     if (PH_ < UNR && kb + PH_ < nkb_w) {                                                                               \
       bool full = true;                                                                                                \
       _Pragma("unroll") for (int ni = 0; ni < SM_NR; ++ni) full = full && (jt[ni] >= 2 * (kb + PH_) + 1);               \
-      const double* tile = rs + ((kb + PH_) & (SM_PANEL / 32 - 1)) * 32 * 64;                                          \
+      const double* tile = rs + ((kb + PH_) & (PANEL / 32 - 1)) * 32 * 64;                                          \
       small_block16<SM_MR, SM_NR, RING, (PH_ < UNR ? PH_ : 0)>(!full, tile, vp, boff, jt, aoffm, kb + PH_, kp_clamp, bq, acc); \
     }
     BOGP_SMALL_BLOCK(0)
@@ -267,29 +285,50 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
   // D[i][j] of a 16 x 16 tile sits in lane 16 (i % 4) + j, register i / 4.  red[slot j][wave][row], row pitch 65: writes
   // and reads conflict free (as in k_contract16); then per (wave, row) the 16 slots in a fixed order, then the 8 waves
   constexpr int RP = 65;
-  double* red = rs;                              // [16][8][RP]
-  double* red2 = rs + 16 * SM_WAVES * RP;        // [3][8][64]: ss, r.gamma, r.w per wave
+  double* red = rs;                              // [16][8][RP]  (8 = the waves of the 8-wave schedule, real or virtual)
+  double* red2 = rs + 16 * SM_WAVES * RP;        // [3][8][64]: ss, r.gamma, r.w per (virtual) wave
   {
     const int qd = lane >> 4, jc = lane & 15;
 #pragma unroll
     for (int mi = 0; mi < SM_MR; ++mi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        double s = 0.0;
+        if constexpr (NW == 8) {
+          double s = 0.0;
 #pragma unroll
-        for (int ni = 0; ni < SM_NR; ++ni)
-          if (valid[ni]) s = __builtin_fma(acc[mi][ni][r], acc[mi][ni][r], s);
-        red[(jc * SM_WAVES + w) * RP + 16 * mi + 4 * r + qd] = s;
+          for (int ni = 0; ni < SM_NR; ++ni)
+            if (valid[ni]) s = __builtin_fma(acc[mi][ni][r], acc[mi][ni][r], s);
+          red[(jc * SM_WAVES + w) * RP + 16 * mi + 4 * r + qd] = s;
+        } else {  // tiles {w, 15 - w} = virtual wave w (ni 0, 3), {7 - w, 8 + w} = virtual wave 7 - w (ni 1, 2)
+          double sa = 0.0, sb = 0.0;
+          if (valid[0]) sa = __builtin_fma(acc[mi][0][r], acc[mi][0][r], sa);
+          if (valid[3]) sa = __builtin_fma(acc[mi][3][r], acc[mi][3][r], sa);
+          if (valid[1]) sb = __builtin_fma(acc[mi][1][r], acc[mi][1][r], sb);
+          if (valid[2]) sb = __builtin_fma(acc[mi][2][r], acc[mi][2][r], sb);
+          red[(jc * SM_WAVES + w) * RP + 16 * mi + 4 * r + qd] = sa;
+          red[(jc * SM_WAVES + (7 - w)) * RP + 16 * mi + 4 * r + qd] = sb;
+        }
       }
   }
   __syncthreads();
-  {
+  if constexpr (NW == 8) {
     double s = 0.0;
 #pragma unroll
     for (int sl = 0; sl < 16; ++sl) s += red[(sl * SM_WAVES + w) * RP + lane];
     red2[w * 64 + lane] = s;
     red2[(SM_WAVES + w) * 64 + lane] = mu;
     red2[(2 * SM_WAVES + w) * 64 + lane] = wd;
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int v = w + 4 * h;
+      double s = 0.0;
+#pragma unroll
+      for (int sl = 0; sl < 16; ++sl) s += red[(sl * SM_WAVES + v) * RP + lane];
+      red2[v * 64 + lane] = s;
+      red2[(SM_WAVES + v) * 64 + lane] = h == 0 ? mu : mu1;
+      red2[(2 * SM_WAVES + v) * 64 + lane] = h == 0 ? wd : wd1;
+    }
   }
   __syncthreads();
   if (tid < 64) {
@@ -351,13 +390,13 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
   }
   __syncthreads();
   if (!s_last) return;
-  __shared__ double fv[SM_WAVES];
-  __shared__ int64_t fi[SM_WAVES];
+  __shared__ double fv[NW];
+  __shared__ int64_t fi[NW];
   const int64_t nslots = a.blk_begin + gridDim.x;  // slots written by the bulk launch (if any) + by this one
   for (int c = 0; c < a.q; ++c) {
     double v = -INFINITY;
     int64_t idx = INT64_MAX;
-    for (int64_t k = tid; k < nslots; k += 512) {
+    for (int64_t k = tid; k < nslots; k += NT) {
       const double ov = __builtin_nontemporal_load(&a.blk_val[(size_t)c * a.nblk + k]);
       const int64_t oi = __builtin_nontemporal_load(&a.blk_idx[(size_t)c * a.nblk + k]);
       if (better(ov, oi, v, idx)) {
@@ -380,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep_small(const double* __restrict
     }
     __syncthreads();
     if (tid == 0) {
-      for (int k = 1; k < SM_WAVES; ++k)
+      for (int k = 1; k < NW; ++k)
         if (better(fv[k], fi[k], v, idx)) {
           v = fv[k];
           idx = fi[k];
@@ -430,15 +469,18 @@ int64_t sweep_small_blocks(int64_t M, int n_cu) {
   return bulk + tw;
 }
 
-template <int MR, int NR>
+template <int MR, int NR, int NW>
 static hipError_t launch_small_mr(int kernel, const SmallArgs& a, unsigned nwg, hipStream_t st) {
-  const size_t shm = ((size_t)SM_PANEL * SM_MT + (size_t)SM_MT * ((a.d + 1) & ~1)) * sizeof(double);
+  // the panel + the candidate tile; the epilogue's reduction arrays ([16][8][65] + [3][8][64] doubles = 78 848 B) overlay them
+  const size_t shm = std::max(((size_t)(32 * NW) * SM_MT + (size_t)SM_MT * ((a.d + 1) & ~1)) * sizeof(double),
+                              (size_t)(16 * SM_WAVES * 65 + 3 * SM_WAVES * 64) * sizeof(double));
 #define BOGP_LAUNCH_SMALL(K)                                                                                             \
   do {                                                                                                                   \
-    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_small<K, MR, NR>),                        \
+    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_small<K, MR, NR, NW>),                    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                           \
     if (e_ != hipSuccess) return e_;                                                                                     \
-    hipLaunchKernelGGL((k_sweep_small<K, MR, NR>), dim3(nwg), 512, shm, st, a.Xs, a.sqrt_theta, a.XthT, a.gamma, a.wvec, a.Vp, a); \
+    hipLaunchKernelGGL((k_sweep_small<K, MR, NR, NW>), dim3(nwg), 64 * NW, shm, st, a.Xs, a.sqrt_theta, a.XthT, a.gamma, a.wvec, \
+                       a.Vp, a);                                                                                         \
   } while (0)
   switch (kernel) {
     case BOGP_KERNEL_SE: BOGP_LAUNCH_SMALL(BOGP_KERNEL_SE); break;
@@ -453,6 +495,13 @@ static hipError_t launch_small_mr(int kernel, const SmallArgs& a, unsigned nwg, 
   return hipGetLastError();
 }
 
+// Four-wave workgroups, two per CU (k_sweep_small's NW = 4): Np <= 256, and a candidate tile of at most 16 KB (d <= 32) so that
+// two 80-KB workgroups fit the CU's 160 KB of LDS.  BOGP_SMALL_NW=8 forces the one-workgroup-per-CU schedule for A/B runs.
+static bool small_four_waves(int Np, int d) {
+  const char* e = getenv("BOGP_SMALL_NW");
+  return Np <= 256 && d <= 32 && !(e && atoi(e) == 8);
+}
+
 // Tiles per wave by training-set size: two for Np <= 256 (measured +7 % at N = 256, profiles/r03_sweep_scaling.txt; one tile per
 // wave with a 16-slot ring was built too and measured the same as two at N = 128 -- below ~200 training points the kernel is
 // bound by the latencies of a workgroup that has the CU to itself, not by the contraction -- so it is not instantiated).  The
@@ -464,8 +513,8 @@ static int small_nr(int Np) {
 }
 template <int MR>
 static hipError_t launch_small_nr(int kernel, const SmallArgs& a, unsigned nwg, hipStream_t st) {
-  if (small_nr(a.Np) == 2) return launch_small_mr<MR, 2>(kernel, a, nwg, st);
-  return launch_small_mr<MR, 4>(kernel, a, nwg, st);
+  if (small_nr(a.Np) == 2) return launch_small_mr<MR, 2, 8>(kernel, a, nwg, st);
+  return launch_small_mr<MR, 4, 8>(kernel, a, nwg, st);
 }
 
 // `a` describes the whole sweep (M candidates, a.nblk = sweep_small_blocks(M, n_cu) partial-argmax slots)
@@ -476,6 +525,13 @@ hipError_t launch_sweep_small(int kernel, const SmallArgs& a0, int n_cu, hipStre
   SmallArgs a = a0;
   a.m_begin = 0;
   a.blk_begin = 0;
+  // (with fewer workgroups than CUs nobody shares a CU and the eight-wave workgroup is the shorter one: 87 vs 100 us at N = 256, M = 1e4)
+  const int64_t g64 = (a0.M + SM_MT - 1) / SM_MT;
+  if (small_four_waves(a0.Np, a0.d) && g64 > n_cu) {  // one launch of 64-candidate workgroups (two per CU: no tail planning)
+    if (g64 > a0.nblk) return hipErrorInvalidValue;
+    a.final_launch = 1;
+    return launch_small_mr<4, 4, 4>(kernel, a, (unsigned)g64, st);
+  }
   if (const char* f = getenv("BOGP_SMALL_FORCE_MR")) {  // measurement aid: every workgroup with 16 * MR candidates
     const int mr = atoi(f);
     if (mr >= 2 && mr <= 3) {  // (MR = 1 is gone: one accumulator per tile, every MFMA waiting for its predecessor, 21 spilled VGPRs)
