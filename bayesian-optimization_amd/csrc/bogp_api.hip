@@ -96,7 +96,7 @@ static void free_trend(bogp_handle* h) {
 }
 
 static void free_train(bogp_handle* h) {
-  dfree(h->dX); dfree(h->dy_base); h->dy = nullptr; dfree(h->dR); dfree(h->dV); dfree(h->dU); dfree(h->dT); dfree(h->dRinv); dfree(h->ddinv); dfree(h->dones); dfree(h->dgemv_scratch);
+  dfree(h->dX); dfree(h->dy_base); h->dy = nullptr; dfree(h->dR); dfree(h->dV); dfree(h->dU); dfree(h->dT); dfree(h->dRinv); dfree(h->ddinv); dfree(h->dchain_flags); dfree(h->dones); dfree(h->dgemv_scratch);
   dfree(h->dyt_base); dfree(h->dft); dfree(h->drho_base); dfree(h->dtmp); dfree(h->dgamma_base); dfree(h->dw);
   h->dyt = h->drho = h->dgamma = nullptr;
   h->n_t = 1; h->target = 0;
@@ -409,7 +409,8 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   //   Yt = V y (:799), Ft = V 1 (:803)              one pass over V
   //   rho (:806 / :808), |Ft|, Ft.Yt, rho.rho       k_fit_rho
   //   gamma = U rho (:788 / :996)
-  HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st, h->stream_upd ? h->stream_upd : h->stream2, h->ev_chol, h->dT, N));  // dT: free until the inverse
+  if (!h->dchain_flags) HIPCHK(h, hipMalloc((void**)&h->dchain_flags, (size_t)2 * (h->cap_ld / 64 + 1) * sizeof(unsigned int)));
+  HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st, h->stream_upd ? h->stream_upd : h->stream2, h->ev_chol, h->dT, N, h->dchain_flags));  // dT: free until the inverse
   HIPCHK(h, launch_logdet(h->dR, N, ldr, h->dscal, st));
   HIPCHK(h, launch_tri_inverse(h->dR, h->ddinv, h->dV, h->dU, h->dT, ldr, st));
   const int n_t = h->n_t;
@@ -454,6 +455,7 @@ static int factorize_finish(bogp_handle* h, const FitPending& fp, int info, cons
   const int mode = fp.mode, estimate_trend = fp.estimate_trend, ptrend = fp.ptrend, n_t = fp.n_t, N = fp.N;
   const double beta = fp.beta, alpha = fp.alpha, sigma2_par = fp.sigma2_par, noise_var = fp.noise_var;
   double s2t = fp.s2t;
+  if (info < 0) FAIL(h, BOGP_ERR_HIP, "factorisation: a hand-over between the diagonal chain and the block-column kernels timed out (info = %d)", (int)info);
   if (info != 0) FAIL(h, BOGP_ERR_NOT_POSDEF, "correlation matrix is not positive definite (potrf info = %d)", (int)info);
   if (info2[0] != 0 || info2[1] != 0) FAIL(h, BOGP_ERR_NOT_POSDEF, "trend basis is rank deficient after whitening (Ft^T Ft not positive definite, info = %d / %d)", (int)info2[0], (int)info2[1]);
 

@@ -411,6 +411,110 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The diagonal chain as ONE resident workgroup beside the block-column kernels (r03; BOGP_CHOL_CHAIN=1).
+//
+// With k_chol_step a block column costs ~31.6 us of which the 64-pivot diagonal routine is 19.5: the rest is the launch
+// boundary and workgroup (0, 0)'s way to its tile (stage W_k, load the panel tile, two 64^3 products, stores).  Here the
+// critical path of the factorisation -- factor(k) -> X = A(k+1, k) W_k^T -> A(k+1, k+1) -= X X^T -> factor(k+1) -- never leaves
+// ONE workgroup: W_k stays in LDS between steps, the two tiles a step needs from the previous block column's kernel arrive
+// through a counter (flagT[t] == 2: tiles (1, 0) and (1, 1) of k_chol_step(t - 1) stored), and W_{t+1} goes out to the next
+// block-column kernel through flagW[t + 1].  The block-column kernels (k_chol_step with flags) are launched back to back on
+// the main stream and wait for their W inside; they no longer touch tile (0, 0).  No circular wait: k_chol_step(t) needs only
+// flagW[t] (published before the chain starts step t), step t needs only k_chol_step(t - 1), which ran on flagW[t - 1].
+// Every wait is bounded (chain_wait): on expiry *info = -7 and the work goes on with whatever is there -- a launch can fail, not hang.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool chain_wait(const unsigned int* flag, unsigned int target) {
+  for (int spin = 0; spin < (1 << 18); ++spin) {  // ~0.3 s; a legitimate wait is below a millisecond
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      return true;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return false;
+}
+
+__global__ void k_chain_init(unsigned int* __restrict__ flags, int nb, int kf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * nb) flags[i] = i == kf ? 1u : (i == nb + kf ? 2u : 0u);  // flagW[kf] = 1, flagT[kf] = 2: step kf finds everything in place
+}
+
+__global__ __launch_bounds__(256) void k_chol_chain(double* __restrict__ A, int ld, int kf, int nb, double* __restrict__ Winv,
+                                                    const double* __restrict__ scratch, int* __restrict__ info,
+                                                    unsigned int* __restrict__ flags, int N) {
+  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
+  __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
+  unsigned int* flagW = flags;
+  unsigned int* flagT = flags + nb;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lk = lane >> 4;
+  const int tr = tid >> 4, tc = tid & 15;
+  stage_aside(lds, Winv + (size_t)kf * CB * CB, CB, tid);  // W_kf comes from the step before the chain (or k_chol_first)
+  for (int t = kf; t + 1 < nb; ++t) {
+    const int i0 = (t + 1) * CB;
+    if (tid == 0 && !chain_wait(flagT + t, 2u) && *info == 0) *info = -7;
+    __syncthreads();  // ... and W_t is staged
+    const double* __restrict__ Pcur = scratch + (size_t)(t & 1) * ld * CB;
+    double bv[16];
+    load_bside(bv, Pcur + i0, ld, w, lane);  // the unsolved tile A(t + 1, t)
+    double* __restrict__ Ab = A + (size_t)i0 * ld + i0;
+    double acc[4][4], x[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[mi][q] = -Ab[(size_t)(16 * mi + 4 * q + lk) * ld + 16 * w + (lane & 15)];
+        x[mi][q] = 0.0;
+      }
+    mma_64(lds, bv, x, lane);  // X = A(t + 1, t) W_t^T
+    __syncthreads();           // every wave is done with the W tile
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        lds[(16 * mi + 4 * q + lk) * CPITCH + 16 * w + (lane & 15)] = x[mi][q];
+        bv[4 * mi + q] = x[mi][q];
+      }
+    asm volatile("s_nop 7\n\ts_nop 7"
+                 : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7]), "+v"(bv[8]),
+                   "+v"(bv[9]), "+v"(bv[10]), "+v"(bv[11]), "+v"(bv[12]), "+v"(bv[13]), "+v"(bv[14]), "+v"(bv[15]));
+    __syncthreads();
+    mma_64(lds, bv, acc, lane);  // -(A(t + 1, t + 1) - X X^T)
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) lds[(16 * w + (lane & 15)) * (CB + 1) + 16 * mi + 4 * q + lk] = -acc[mi][q];
+    __syncthreads();
+    double a[4][4], ww[4][4];
+    const int bad = diag_factor_invert(lds, sb, a, ww, tid, max(0, min(CB, N - i0)));
+    // L's diagonal tile and W_{t+1} go out with write-through (agent-scope) stores drained by every storing wave, then ONE relaxed
+    // flag: an agent-scope release fence here is a write-back of the XCD's L2 (several us) on the critical path of every step
+    {
+      double* __restrict__ Wn = Winv + (size_t)(t + 1) * CB * CB;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * tr + i, col = 4 * tc + c;
+          if (r >= col) __hip_atomic_store(Ab + (size_t)col * ld + r, a[i][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(Wn + col * CB + r, tc <= tr ? ww[i][c] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (tid == 0 && bad != 0 && *info == 0) *info = i0 + bad;
+    // W_{t+1} for the next step straight from the registers (tile[kk][c] = W(c, kk), zeros above the diagonal)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) lds[(4 * tc + cc) * CPITCH + 4 * tr + i] = tc <= tr ? ww[i][cc] : 0.0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flagW + t + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // One block column in ONE launch (small trailing matrices): panel solve + trailing update + next diagonal block.
 // Every workgroup (bi, bj) recomputes the two panel tiles it needs, X_i = A[i, k] W_k^T and X_j, from the UNSOLVED panel
 // (three 64^3 products per workgroup instead of one -- free while the trailing matrix has fewer tiles than the GPU has
@@ -421,7 +525,8 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int ld, int k0, int m, const double* __restrict__ Wk,
                                                    const double* __restrict__ Pcur, double* __restrict__ Pnext,
-                                                   double* __restrict__ Wn, int* __restrict__ info, int tri_grid, int nlive) {
+                                                   double* __restrict__ Wn, int* __restrict__ info, int tri_grid, int nlive,
+                                                   unsigned int* __restrict__ flagW, unsigned int* __restrict__ flagT) {
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
   __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
   int bi, bj;
@@ -436,6 +541,11 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int l
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i0 = k0 + CB * (1 + bi), j0 = k0 + CB * (1 + bj);
   const int lk = lane >> 4;
+  const bool chained = flagW != nullptr;  // the diagonal chain runs in k_chol_chain: W_k arrives through a flag (see there)
+  if (chained) {
+    if (tid == 0 && !chain_wait(flagW + k0 / CB, 1u) && *info == 0) *info = -7;
+    __syncthreads();
+  }
 
   stage_aside(lds, Wk, CB, tid);  // tile[kk][c] = W(c, kk)
   double bv[16], bvi[16];
@@ -475,6 +585,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int l
 #pragma unroll
       for (int t = 0; t < 4; ++t) Lb[(size_t)(16 * mi + 4 * t + lk) * ld + 16 * w + (lane & 15)] = xi[mi][t];
   }
+  if (chained && bi == 0) return;  // the chain workgroup updates and factors A(k + 1, k + 1) itself
   // B side: X_i(row 16 w + (lane & 15), kk = 4 ks + lk) is exactly xi[ks / 4][ks % 4] of this lane
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
@@ -497,6 +608,11 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int l
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int t = 0; t < 4; ++t) Pnext[(size_t)(16 * mi + 4 * t + lk) * ld + i0 + 16 * w + (lane & 15)] = -acc[mi][t];
+    }
+    if (chained && bi == 1) {  // tiles (1, 0) and (1, 1) are what the chain's next step consumes: hand them over
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(flagT + k0 / CB + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     return;
   }
@@ -1125,7 +1241,7 @@ hipError_t launch_pad_identity(double* A, int N, int ld, hipStream_t st) {
 // k holds L_kk^-1 (64 x 64 column-major) afterwards.  *info (device) = 0 or 1 + the first column with a non-positive
 // pivot, as LAPACK reports it.
 hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStream_t st, hipStream_t st2, hipEvent_t* ev,
-                             double* scratch, int N) {
+                             double* scratch, int N, unsigned int* chain_flags) {
   if (N <= 0 || N > ld) N = ld;
   auto live = [&](int col0) { return max(0, min(CB, N - col0)); };  // data columns of the 64-block that starts at col0
   const int nb = ld / CB;
@@ -1160,14 +1276,36 @@ hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStre
     const char* e = getenv("BOGP_CHOL_TRI_GRID");
     return e ? atoi(e) : 1;
   }();
+  // BOGP_CHOL_CHAIN=1 (off by default; read per call so that the tests can run both): the fused block columns with their diagonal
+  // chain in ONE resident workgroup (k_chol_chain) on the second stream instead of workgroup (0, 0) of every k_chol_step.
+  // Measured (tools/ab_chol_chain.sh, profiles/r03_chol_chain_ab.txt): with agent-scope release fences at the hand-overs every
+  // block column got 1.3-2.4 us SLOWER (a fence is a write-back of the XCD's L2: what a kernel boundary costs anyway); with
+  // write-through stores + relaxed flags the per-column time equals k_chol_step's (31 us: flag poll + acquire + two tile
+  // loads + two 64^3 products + staging + stores are the same ~11 us around the 19.5-us diagonal routine whoever runs them)
+  // and the two events + init kernel + second-stream launch add ~30 us per factorisation: N = 128 132 -> 165 us,
+  // N = 2048 1.42 -> 1.44 ms, N = 4096 3.60 -> 3.69 ms per likelihood.  Same bits as the default path.
+  const char* e_chain = getenv("BOGP_CHOL_CHAIN");
+  const int chain_on = e_chain ? atoi(e_chain) : 0;
+  const int kf = can_fuse ? max(0, nb - 1 - fuse_max) : nb;  // first fused block column
+  const bool chain = chain_on && chain_flags != nullptr && st2 != nullptr && ev != nullptr && can_fuse && tri && kf + 1 < nb;
+  unsigned int* flagW = chain ? chain_flags : nullptr;
+  unsigned int* flagT = chain ? chain_flags + nb : nullptr;
   for (int kbeg = 0; kbeg + 1 < nb; kbeg += G) {
     for (int k = kbeg; k < kbeg + G && k + 1 < nb; ++k) {
       const int k0 = k * CB;
       const int m = nb - k - 1;
       const bool next_fused = can_fuse && m - 1 >= 1 && m - 1 <= fuse_max;
+      if (chain && k == kf) {  // everything before column kf is queued on st: start the chain behind it
+        hipError_t e;
+        hipLaunchKernelGGL(k_chain_init, dim3((2 * nb + 255) / 256), 256, 0, st, chain_flags, nb, kf);
+        if ((e = hipEventRecord(ev[0], st)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(st2, ev[0], 0)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_chol_chain, dim3(1), 256, 0, st2, A, ld, kf, nb, Winv, scratch, info, chain_flags, N);
+        if ((e = hipEventRecord(ev[1], st2)) != hipSuccess) return e;
+      }
       if (can_fuse && m <= fuse_max) {
         hipLaunchKernelGGL(k_chol_step, dim3(tri ? m * (m + 1) / 2 : m * m), 256, 0, st, A, ld, k0, m, Winv + (size_t)k * CB * CB,
-                           panel_copy(k), panel_copy(k + 1), Winv + (size_t)(k + 1) * CB * CB, info, tri, live(k0 + CB));
+                           panel_copy(k), panel_copy(k + 1), Winv + (size_t)(k + 1) * CB * CB, info, tri, live(k0 + CB), flagW, flagT);
         continue;
       }
       hipLaunchKernelGGL(k_chol_panel, dim3(m), 256, 0, st, Winv + (size_t)k * CB * CB, A + (size_t)k0 * ld + k0 + CB, ld);
@@ -1176,6 +1314,10 @@ hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStre
                          k0 + CB, m, last ? m : 1, Winv + (size_t)(k + 1) * CB * CB, info,
                          next_fused ? panel_copy(k + 1) : (double*)nullptr, tri, live(k0 + CB));
     }
+  }
+  if (chain) {  // the factor is complete when the chain has left its last step
+    hipError_t e = hipStreamWaitEvent(st, ev[1], 0);
+    if (e != hipSuccess) return e;
   }
   return hipGetLastError();
 }

@@ -341,6 +341,39 @@ def test_fused_small_sweep_tiles_per_wave_variants_are_bit_identical(N, d):
     eng.close()
 
 
+@pytest.mark.parametrize("N,d", [(130, 3), (700, 6), (2048, 20), (2500, 4)])
+def test_resident_diagonal_chain_gives_the_same_bits(N, d):
+    """BOGP_CHOL_CHAIN=1: the diagonal chain of the fused block columns runs in ONE resident workgroup beside the block-column kernels
+    (flag hand-overs, bounded waits; kernels_chol.hip k_chol_chain) -- an experiment kept off by default because it measured no
+    faster.  Same products on the same inputs in the same order: likelihood, gradient and committed factor must be the SAME BITS
+    (sizes: two block columns; all fused; exactly 32 fused columns; unfused columns first, then the chain)."""
+    import os
+
+    rng = np.random.default_rng(7 * N + d)
+    X = rng.uniform(-5, 5, size=(N, d))
+    y = np.sum(np.sin(X), axis=1)
+    y = ((y - y.mean()) / y.std() + 0.5 * rng.standard_normal(N)).reshape(-1, 1)  # (noisy: a dense smooth sample has llf > 0, which is rejected)
+    par = np.r_[np.full(d, 0.4 / d), 0.9]
+    out = []
+    for flag in ("0", "1", "1"):
+        os.environ["BOGP_CHOL_CHAIN"] = flag
+        try:
+            eng = _lib.Engine(0)
+            eng.set_train(X, y)
+            llf, grad = eng.nll(O.KERNEL_MATERN32, O.MODE_NOISY, par, 1e-2, True, 0.0, eval_grad=True)
+            eng.commit(O.KERNEL_MATERN32, O.MODE_NOISY, par, 1e-2, True, 0.0)
+            st = eng.get_state()
+            eng.close()
+        finally:
+            del os.environ["BOGP_CHOL_CHAIN"]
+        out.append((llf, grad, st["C"], st["gamma"]))
+    for other in out[1:]:
+        assert other[0] == out[0][0]
+        np.testing.assert_array_equal(other[1], out[0][1])
+        np.testing.assert_array_equal(np.tril(other[2]), np.tril(out[0][2]))
+        np.testing.assert_array_equal(other[3], out[0][3])
+
+
 @pytest.mark.parametrize("N", [6144, 6200, 7000])
 def test_large_fit_path_equals_the_64_block_path(N):
     """From ld = 6144 on the inverse and R^-1 = U U^T run on 128 x 128 tiles (k_mm128, kernels_chol.hip; with
