@@ -1,5 +1,5 @@
-// bogp_api.hip -- the C ABI of libbogp.so (include/bogp.h): device state, rocSOLVER/rocBLAS orchestration of the
-// fit path, and the chunked posterior/acquisition sweep.  No host fallback exists: every numerical step runs on
+// bogp_api.hip -- the C ABI of libbogp.so (include/bogp.h): device state, orchestration of the fit path (in-tree kernels
+// only: kernels_chol / kernels_fit / kernels_pairs / kernels_gemm -- no rocSOLVER, no rocBLAS), and the chunked posterior / acquisition sweep.  No host fallback exists: every numerical step runs on
 // the gfx950 device, and every failure is reported as an error code + message.
 #include <hip/hip_runtime.h>
 
@@ -697,7 +697,7 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
     double c2 = 0.0;
     if (estimate_trend && ptrend > 1) {
       // term = (L^-T Q)(L^-T Q)^T = W S W^T with W = L^-T Ft (N x p) and S = (Ft^T Ft)^-1: folded into the first slice of
-      // R^-1 as R^-1 - tv W S W^T (two library GEMMs with inner dimension p), after which the p = 1 code below applies
+      // R^-1 as R^-1 - tv W S W^T (two k_gemm64 products with inner dimension p), after which the p = 1 code below applies
       // with no separate q vector: the contraction sees R^-1 - tv term, and its trace is tr(R^-1) - tv tr(term)
       const double one = 1.0, zero = 0.0, mtv = -tv;
       HIPCHK(h, launch_gemm(0, 0, N, ptrend, N, one, h->dU, ldr, h->dFt, N, zero, h->dQ1, N, st, 0, &h->gsplit));

@@ -3,7 +3,8 @@
 // The reference maximises its acquisition function with L-BFGS-B on `criterion(x, return_dx=True)` one point per call
 // (acquisition/optim/__init__.py:74-153): predict (gpr.py:486-510) + gradient (:537-576, corr_dx :600-661) + the closed
 // form and its chain rule (acquisition_fun.py:139-146, 181-188, 220-227, 292-309).  r02 served that call with
-// k_point_corr + two rocBLAS dtrmv + three dgemv + k_acquisition (177 us at N = 2048, the data movement is ~10 us).
+// k_point_corr + two rocBLAS dtrmv + three dgemv + k_acquisition (177 us at N = 2048, the data movement is ~10 us); the
+// library is gone altogether since r03 (kernels_gemm.hip serves what is left of that route: the linear trend basis).
 //
 // Here it is three launches for B >= 1 points, no library call:
 //

@@ -31,7 +31,7 @@ typedef struct bogp_handle bogp_handle;
 #define BOGP_ABI_VERSION 5 /* what bogp_abi_version() of a matching library returns */
 #define BOGP_OK 0
 #define BOGP_ERR_INVALID (-1)      /* bad argument / call order                                           */
-#define BOGP_ERR_HIP (-2)          /* HIP runtime / rocBLAS failure                                        */
+#define BOGP_ERR_HIP (-2)          /* HIP runtime failure (or an in-kernel hand-over that timed out)       */
 #define BOGP_ERR_NOT_POSDEF (-3)   /* correlation matrix not positive definite (potrf info > 0)            */
 #define BOGP_ERR_UNSUPPORTED (-4)  /* valid in the reference but not built yet (see DESIGN.md "out of scope") */
 #define BOGP_ERR_NO_DEVICE (-5)    /* no usable gfx950 device                                              */
