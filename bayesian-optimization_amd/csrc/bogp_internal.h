@@ -196,8 +196,9 @@ hipError_t launch_sumsq(const double* v, int N, double* out, hipStream_t st);
 hipError_t launch_grad_coef(const double* scal, int n_t, int mode, int N, int krank, double s2t_host, double* coef, hipStream_t st);
 hipError_t launch_gemv2(const double* M, int ld, int N, int tri, const double* x0, const double* x1, double* y0, double* y1,
                         double* scratch, hipStream_t st);
+// Lfac != null: also scal[0] = sum(log(diag(Lfac))) (what launch_logdet writes, in the same launch)
 hipError_t launch_fit_rho(const double* Yt, const double* Ft, int N, int estimate_trend, double beta, double* rho, double* scal,
-                          hipStream_t st);
+                          hipStream_t st, const double* Lfac = nullptr, int ldL = 0);
 hipError_t launch_trace_gg(const double* Rinv, int ld, int nparts, size_t part_stride, int N, const double* gamma,
                            const double* qv, double* out, hipStream_t st);
 hipError_t launch_point_hessian(const double* X, int N, int d, const double* theta, const double* x, const double* r,

@@ -64,7 +64,7 @@ hipError_t launch_logdet(const double* L, int N, int ld, double* out, hipStream_
 constexpr int GV_SEG = 256;
 __global__ __launch_bounds__(256) void k_gemv2_part(const double* __restrict__ M, int ld, int N, int Nr, int tri,
                                                     const double* __restrict__ x0, const double* __restrict__ x1,
-                                                    double* __restrict__ part) {
+                                                    double* __restrict__ part, double* __restrict__ y0, double* __restrict__ y1) {
   __shared__ double red[2][4][64];
   const int tid = threadIdx.x, rl = tid & 63, cg = tid >> 6;
   const int rb = blockIdx.x * 64, seg = blockIdx.y;
@@ -86,7 +86,13 @@ __global__ __launch_bounds__(256) void k_gemv2_part(const double* __restrict__ M
   __syncthreads();
   if (tid < 128) {
     const int r = tid >> 6, q = tid & 63;
-    part[((size_t)seg * 2 + r) * Nr + rb + q] = ((red[r][0][q] + red[r][1][q]) + red[r][2][q]) + red[r][3][q];
+    const double v = ((red[r][0][q] + red[r][1][q]) + red[r][2][q]) + red[r][3][q];
+    if (y0 == nullptr) {
+      part[((size_t)seg * 2 + r) * Nr + rb + q] = v;
+    } else if (rb + q < N) {  // one column segment (N <= 256): the result itself, no k_gemv2_sum launch -- the same `0.0 + v` it would form
+      double* y = r == 0 ? y0 : y1;
+      if (y) y[rb + q] = 0.0 + v;
+    }
   }
 }
 __global__ void k_gemv2_sum(const double* __restrict__ part, int nseg, int Nr, int N, double* __restrict__ y0, double* __restrict__ y1) {
@@ -107,7 +113,11 @@ size_t gemv2_scratch_doubles(int N) {
 hipError_t launch_gemv2(const double* M, int ld, int N, int tri, const double* x0, const double* x1, double* y0, double* y1,
                         double* scratch, hipStream_t st) {
   const int nrb = (N + 63) / 64, nseg = (N + GV_SEG - 1) / GV_SEG, Nr = nrb * 64;
-  hipLaunchKernelGGL(k_gemv2_part, dim3(nrb, nseg), 256, 0, st, M, ld, N, Nr, tri, x0, x1, scratch);
+  if (nseg == 1) {  // N <= 256: one launch (a likelihood evaluation at these sizes is launch-latency bound: ~6 us per launch)
+    hipLaunchKernelGGL(k_gemv2_part, dim3(nrb, 1), 256, 0, st, M, ld, N, Nr, tri, x0, x1, scratch, y0, y1);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(k_gemv2_part, dim3(nrb, nseg), 256, 0, st, M, ld, N, Nr, tri, x0, x1, scratch, (double*)nullptr, (double*)nullptr);
   hipLaunchKernelGGL(k_gemv2_sum, dim3((N + 255) / 256), 256, 0, st, scratch, nseg, Nr, N, y0, y1);
   return hipGetLastError();
 }
@@ -126,8 +136,22 @@ __device__ __forceinline__ double block_sum_1024(double v, double* red /* [16] *
 }
 __global__ __launch_bounds__(1024) void k_fit_rho(const double* __restrict__ Yt, const double* __restrict__ Ft, int N,
                                                   int estimate_trend, double beta, double* __restrict__ rho,
-                                                  double* __restrict__ scal) {
+                                                  double* __restrict__ scal, const double* __restrict__ Lfac, int ldL) {
   __shared__ double red[16];
+  if (Lfac != nullptr) {  // sum(log(diag(L))) into scal[0]: k_logdet's partial sums and tree, by the first 256 threads (one launch less)
+    __shared__ double red256[256];
+    if (threadIdx.x < 256) {
+      double s = 0.0;
+      for (int i = threadIdx.x; i < N; i += 256) s += log(Lfac[(size_t)i * ldL + i]);
+      red256[threadIdx.x] = s;
+    }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red256[threadIdx.x] += red256[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) scal[0] = red256[0];
+  }
   double sff = 0.0, sfy = 0.0;
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
     const double f = Ft[i];
@@ -158,8 +182,8 @@ __global__ __launch_bounds__(1024) void k_fit_rho(const double* __restrict__ Yt,
   }
 }
 hipError_t launch_fit_rho(const double* Yt, const double* Ft, int N, int estimate_trend, double beta, double* rho, double* scal,
-                          hipStream_t st) {
-  hipLaunchKernelGGL(k_fit_rho, dim3(1), 1024, 0, st, Yt, Ft, N, estimate_trend, beta, rho, scal);
+                          hipStream_t st, const double* Lfac, int ldL) {
+  hipLaunchKernelGGL(k_fit_rho, dim3(1), 1024, 0, st, Yt, Ft, N, estimate_trend, beta, rho, scal, Lfac, ldL);
   return hipGetLastError();
 }
 
