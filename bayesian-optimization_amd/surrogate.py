@@ -19,6 +19,7 @@ Differences from the reference, all deliberate and listed in DESIGN.md:
 """
 from __future__ import annotations
 
+import os
 import warnings
 
 import numpy as np
@@ -94,6 +95,7 @@ class GaussianProcess:
         verbose=False,
         device=0,
         distribute_restarts=False,
+        restart_streams=None,
     ):
         self.mean = mean
         self.corr = corr
@@ -104,6 +106,9 @@ class GaussianProcess:
         self.is_fitted = False
         self.device = int(device)
         self.distribute_restarts = bool(distribute_restarts)
+        # MLE restarts on `restart_streams` engines (= HIP streams) of the SAME GPU at once (opt-in; None: BOGP_RESTART_STREAMS or 1)
+        self.restart_streams = int(restart_streams if restart_streams is not None else os.environ.get("BOGP_RESTART_STREAMS", "1"))
+        self._worker_engines = []
 
         self.theta0 = np.array(theta0, dtype=float).flatten() if theta0 is not None else None
         if thetaL is None or thetaU is None:
@@ -159,6 +164,7 @@ class GaussianProcess:
     def __getstate__(self):
         st = dict(self.__dict__)
         st["_engine"] = None  # device handles never travel; re-created lazily from (X, y, par)
+        st["_worker_engines"] = []
         return st
 
     def __setstate__(self, st):
@@ -413,6 +419,17 @@ class GaussianProcess:
         if dist is not None:
             rank, world = dist.get_rank(), dist.get_world_size()
             eval_budget = max(1, -(-eval_budget // world))
+        streams = min(int(getattr(self, "restart_streams", 1) or 1), self.random_start)
+        if streams > 1 and dist is None and not restricted:
+            param_opt, llf_opt = self._restarts_on_streams(streams, log10param, log10bounds, eval_budget)
+            optimal_param = 10.0**param_opt
+            env = {}
+            optimal_llf_value = llf_fun(optimal_param, env, _adopt=True)
+            param, i = {}, 0
+            for name, len_ in zip(par_list, par_len):
+                param[name] = optimal_param[i : i + len_]
+                i += len_
+            return param, optimal_llf_value, env, optimal_param
         wait_count = 0
         param_opt, llf_opt = np.array(log10param, dtype=float), np.inf
         first = True
@@ -447,6 +464,66 @@ class GaussianProcess:
             param[name] = optimal_param[i : i + len_]
             i += len_
         return param, optimal_llf_value, env, optimal_param
+
+    def _restarts_on_streams(self, streams, log10param0, log10bounds, eval_budget):
+        """The MLE restarts of gpr.py:1127-1162 on `streams` engines of ONE GPU at once (the single-device flavour of
+        `distribute_restarts`): at the training-set sizes of an ordinary BO run a likelihood evaluation is a chain of ~15 small
+        launches (0.1-0.3 ms) that leaves the GPU idle, and `tell()` is several hundred of them -- 98 % of a 200-evaluation run's wall
+        time (profiles/r03_bo_loop.txt).  Restart i runs on worker i % streams (its own engine = its own HIP stream and factor buffers;
+        ctypes releases the GIL during every call) with 1 / streams of the budget and its own stagnation counter; ALL starting points
+        come from the global np.random stream in the sequential loop's order, so the union of starts is the sequential run's; the best
+        (-llf, parameters) wins, ties to the lowest worker.  Opt-in: it relaxes the shared budget exactly as `distribute_restarts` does."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        starts = [np.array(log10param0, dtype=float)]
+        for _ in range(1, self.random_start):
+            starts.append(np.random.uniform(log10bounds[:, 0], log10bounds[:, 1]))
+        budget = max(1, -(-int(eval_budget) // streams))
+        tid, est, beta = self._trend_args()
+        mode, nv, kid = self._MODE[self.estimation_mode], self._nv(), self.kernel_id
+        while len(self._worker_engines) < streams:
+            self._worker_engines.append(_lib.Engine(self.device))
+        for eng in self._worker_engines[:streams]:
+            eng.set_train(self.X, self.y)
+
+        def worker(w):
+            eng = self._worker_engines[w]
+            calls = [0]
+
+            def obj(log10param):
+                calls[0] += 1
+                par = 10.0 ** np.array(log10param)
+                if not (np.all(np.isfinite(par)) and np.all(par > 0)):
+                    return np.inf, np.zeros(len(par))
+                try:
+                    llf, grad = eng.nll(kid, mode, par, nv, est, beta, eval_grad=True, trend=tid)
+                except _lib.NotPositiveDefinite:
+                    return np.inf, np.zeros(len(par))
+                return -1.0 * llf, -1.0 * np.asarray(grad, dtype=float).ravel()
+
+            best_p, best_l, first, wait, left = None, np.inf, True, 0, budget
+            for it in range(w, self.random_start, streams):
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    p_, l_, info = fmin_l_bfgs_b(obj, starts[it], bounds=log10bounds, maxfun=left)
+                if first:
+                    best_p, best_l, first = p_, l_, False
+                elif l_ <= best_l:
+                    best_p, best_l, wait = p_, l_, 0
+                else:
+                    wait += 1
+                left -= info["funcalls"]
+                if left <= 0 or wait >= self.wait_iter:
+                    break
+            return best_p, float(best_l), calls[0]
+
+        with ThreadPoolExecutor(max_workers=streams) as pool:
+            results = list(pool.map(worker, range(streams)))
+        self.eval_count = sum(r[2] for r in results)
+        best = min(range(streams), key=lambda w: (results[w][1], w))
+        if self.verbose:
+            print("MLE on %d streams: %d likelihood evaluations, best llf %.10g (worker %d)" % (streams, self.eval_count, -results[best][1], best))
+        return np.asarray(results[best][0], dtype=float), results[best][1]
 
     def fit(self, X, y):
         """gpr.py:355-417.  Returns self; sets `is_fitted`."""

@@ -341,6 +341,45 @@ def test_fused_small_sweep_tiles_per_wave_variants_are_bit_identical(N, d):
     eng.close()
 
 
+def test_mle_restarts_on_several_streams_of_one_gpu():
+    """GaussianProcess(restart_streams=T): the restarts of the MLE (gpr.py:1127-1162) run on T engines (= HIP streams) of the same GPU
+    at once, every worker with 1 / T of the budget, all starting points from the global np.random stream in the sequential order
+    (the one-device flavour of distribute_restarts).  Opt-in because it relaxes the shared budget / stagnation counter.
+    Checked: same starting points as the sequential run (the first restart's result is reproduced exactly by worker 0), a likelihood at
+    least as good as the sequential run's first restart, a valid committed state (posterior against the oracle at the fitted
+    parameters), deterministic results, and the evaluation count within the budget."""
+    rng = np.random.default_rng(5)
+    N, d = 90, 4
+    X = rng.uniform(-5, 5, size=(N, d))
+    y = np.sum(np.sin(X), axis=1) + 0.1 * rng.standard_normal(N)
+    y = ((y - y.mean()) / y.std()).reshape(-1, 1)
+    width = np.full(d, 10.0)
+
+    def make(streams, random_start):
+        return bogp.GaussianProcess(mean=bogp.trend.constant_trend(d), corr="matern", thetaL=1e-3 * width, thetaU=1e2 * width, nugget=1e-6,
+                                    optimizer="BFGS", wait_iter=3, random_start=random_start, eval_budget=400, restart_streams=streams)
+
+    np.random.seed(11)
+    one = make(1, 1).fit(X, y)  # one restart from the first starting point
+    llf_first = float(one.log_likelihood_concentrated(np.r_[one.theta_, one.sigma2]))
+    fits = []
+    for _ in range(2):
+        np.random.seed(11)
+        gp = make(4, 8).fit(X, y)
+        fits.append(gp)
+    a, b = fits
+    np.testing.assert_array_equal(a.theta_, b.theta_)
+    assert a.eval_count == b.eval_count and 0 < a.eval_count <= 400 + 4 * 8  # (L-BFGS-B may overshoot maxfun by a line search)
+    llf_multi = float(a.log_likelihood_concentrated(np.r_[a.theta_, a.sigma2]))
+    assert llf_multi >= llf_first - 1e-9 * abs(llf_first)  # worker 0 ran exactly that restart with a quarter of the budget... or found better
+    Xs = rng.uniform(-5, 5, size=(300, d))
+    mu, mse = a.predict(Xs, eval_MSE=True)
+    st = O.make_state(np.r_[a.theta_, a.sigma2], X, y, O.KERNEL_MATERN32, O.MODE_NOISY, 1e-6, estimate_trend=True)
+    omu, omse = O.predict(st, Xs)
+    np.testing.assert_allclose(mu, omu, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(mse, omse, rtol=1e-6, atol=1e-12 * float(st.sigma2[0]))
+
+
 @pytest.mark.parametrize("N,d", [(130, 3), (700, 6), (2048, 20), (2500, 4)])
 def test_resident_diagonal_chain_gives_the_same_bits(N, d):
     """BOGP_CHOL_CHAIN=1: the diagonal chain of the fused block columns runs in ONE resident workgroup beside the block-column kernels
