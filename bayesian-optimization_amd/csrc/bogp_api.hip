@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -61,6 +62,13 @@ extern "C" int bogp_create(int device, bogp_handle** out) {
     delete h;
     return BOGP_ERR_HIP;
   }
+  if (hipHostMalloc((void**)&h->hfit, 4096 * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&h->hfit_dev, h->hfit, 0) != hipSuccess) {
+    g_create_error = "pinned host buffer allocation failed";
+    delete h;
+    return BOGP_ERR_HIP;
+  }
+  memset(h->hfit, 0, 4096 * sizeof(double));
   // the factorisation's info word lives in the same block as its scalars (doubles 62-63): ONE read-back fetches both
   h->dinfo = reinterpret_cast<int*>(h->dscal + 62);
   if (const char* e = getenv("BOGP_CHOL_RESERVE_CU")) {
@@ -126,6 +134,7 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream_upd) (void)hipStreamDestroy(h->stream_upd);
+  if (h->hfit) (void)hipHostFree(h->hfit);
   delete h;
 }
 
@@ -340,15 +349,56 @@ struct FitPending {
   int mode = 0, estimate_trend = 0, ptrend = 1, n_t = 1, N = 0;
   double beta = 0, alpha = 0, sigma2_par = 0, noise_var = 0, s2t = 0;
 };
+static int fit_wait(bogp_handle* h, unsigned long long seq) {
+  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->hfit + 3000);
+  bool seen = false;
+  for (int spin = 0; spin < 400000; ++spin) {
+    if (*flag == seq) { seen = true; break; }
+    __builtin_ia32_pause();
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  if (!seen) HIPCHK(h, hipStreamSynchronize(h->stream));
+  return BOGP_OK;
+}
+// The 64 scalars of the evaluation (and nS gradient sums from dS, or none) back on the host: one gather launch into the mapped
+// pinned block + a polled sequence word instead of two copy commands into pageable memory + a stream synchronisation (the
+// host's API calls, not the GPU, bound an evaluation at the sizes of an ordinary BO run: profiles/r03_bo_loop.txt).
+// BOGP_FIT_POLL=0 restores the copies.  Bounded: after ~2 ms of polling the ordinary synchronisation takes over.
+static int fit_readback(bogp_handle* h, const double* dS, int nS, double* blk /* 64 */, double* S_out) {
+  hipStream_t st = h->stream;
+  static const bool poll = [] { const char* e_ = getenv("BOGP_FIT_POLL"); return !(e_ && atoi(e_) == 0); }();
+  if (!poll || nS > 512) {
+    if (nS > 0) HIPCHK(h, hipMemcpyAsync(S_out, dS, (size_t)nS * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(blk, h->dscal, 64 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return BOGP_OK;
+  }
+  const unsigned long long seq = ++h->fit_seq;
+  HIPCHK(h, launch_fit_gather(h->dscal, dS, nS, h->hfit_dev + 2048, h->hfit_dev + 2112,
+                              reinterpret_cast<unsigned long long*>(h->hfit_dev + 3000), seq, st));
+  const int ew = fit_wait(h, seq);
+  if (ew) return ew;
+  memcpy(blk, h->hfit + 2048, 64 * sizeof(double));
+  if (nS > 0) memcpy(S_out, h->hfit + 2112, (size_t)nS * sizeof(double));
+  return BOGP_OK;
+}
+
 static int factorize_finish(bogp_handle* h, const FitPending& fp, int info, const double* sc, const int* info2,
                             bool reject_positive, FitOut* o);
 
 // pend == nullptr: queue the device work, read info + scalars back, finish (ONE host synchronisation).
 // pend != nullptr: queue only -- the caller appends its own device work (the likelihood gradient), reads everything back in ONE
 // synchronisation and calls factorize_finish itself.
+// fz != nullptr: the caller only wants the likelihood (and its gradient sums), not the factor buffers -- a training set of at most
+// 128 points with the constant basis and one target is then evaluated by ONE launch (kernels_nllsmall.hip), `done` says so.
+struct FusedNll {
+  bool want_grad = false;
+  bool done = false;
+  double S[64 + 3];
+};
 static int factorize(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
                      int estimate_trend, double beta, bool want_gamma, FitOut* o, std::vector<double>* theta_out,
-                     bool reject_positive = true, FitPending* pend = nullptr) {
+                     bool reject_positive = true, FitPending* pend = nullptr, FusedNll* fz = nullptr) {
   if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "no training set: call bogp_set_train first");
   if (kernel < 0 || kernel > BOGP_KERNEL_GENEXP) FAIL(h, BOGP_ERR_INVALID, "unknown kernel id %d", kernel);
   if (mode < 0 || mode > 2) FAIL(h, BOGP_ERR_INVALID, "unknown estimation mode %d", mode);
@@ -379,8 +429,50 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   if (theta_out) theta_out->assign(th, th + d);
   hipStream_t st = h->stream;
   HIPCHK(h, hipSetDevice(h->device));
+  if (fz && N <= nll_small_max_n() && d <= 64 && trend == BOGP_TREND_CONSTANT && h->n_t == 1 &&
+      !(getenv("BOGP_NLL_FUSED") && atoi(getenv("BOGP_NLL_FUSED")) == 0)) {
+    NllSmallArgs na;
+    na.X = h->dX; na.y = h->dy_base; na.N = N; na.d = d;
+    for (int k = 0; k < d; ++k) na.theta[k] = th[k];
+    na.pexp = pexp;
+    FitPending fp;
+    fp.mode = mode; fp.estimate_trend = estimate_trend; fp.ptrend = 1; fp.n_t = 1; fp.N = N;
+    fp.beta = beta; fp.alpha = 0; fp.sigma2_par = 0; fp.noise_var = noise_var; fp.s2t = 0;
+    if (mode == BOGP_MODE_NOISELESS) {
+      h->R_div = false; h->R_a = 1.0; h->R_b = 1.0; h->R_diag = 1.0;
+    } else if (mode == BOGP_MODE_NOISE_ESTIM) {
+      fp.alpha = par[n_par - 1];
+      h->R_div = false; h->R_a = fp.alpha; h->R_b = 1.0; h->R_diag = fp.alpha * 1.0 + (1 - fp.alpha) * 1.0;
+    } else {
+      fp.sigma2_par = par[n_par - 1];
+      fp.s2t = fp.sigma2_par + noise_var;
+      h->R_div = true; h->R_a = fp.sigma2_par; h->R_b = fp.s2t; h->R_diag = (fp.sigma2_par * 1.0 + noise_var * 1.0) / fp.s2t;
+    }
+    na.a = h->R_a; na.b = h->R_b; na.diag = h->R_diag; na.div = h->R_div ? 1 : 0;
+    na.estimate_trend = estimate_trend; na.mode = mode; na.beta = beta; na.s2t_host = fp.s2t;
+    na.out_scal = h->hfit_dev + 2048; na.out_S = h->hfit_dev + 2112;
+    na.flag = reinterpret_cast<unsigned long long*>(h->hfit_dev + 3000);
+    na.seq = ++h->fit_seq;
+    HIPCHK(h, launch_nll_small(kernel, fz->want_grad, na, st));
+    const int ew = fit_wait(h, na.seq);
+    if (ew) return ew;
+    double blk[64];
+    memcpy(blk, h->hfit + 2048, sizeof(blk));
+    if (fz->want_grad) memcpy(fz->S, h->hfit + 2112, (size_t)(d + 3) * sizeof(double));
+    fz->done = true;
+    int info = 0;
+    memcpy(&info, blk + 62, sizeof(info));
+    const int info2[2] = {0, 0};
+    return factorize_finish(h, fp, info, blk, info2, reject_positive, o);
+  }
   h->dsqrt_theta = h->dtheta + (d + 1);  // (the block holds 2 (cap_d + 1) doubles; d may be below the capacity)
-  HIPCHK(h, hipMemcpyAsync(h->dtheta, th, 2 * (size_t)(d + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+  // (through the pinned staging block when it fits: a copy from pageable memory is staged by the runtime, synchronously)
+  const double* th_src = th;
+  if (2 * (size_t)(d + 1) <= 2048) {
+    memcpy(h->hfit, th, 2 * (size_t)(d + 1) * sizeof(double));
+    th_src = h->hfit;
+  }
+  HIPCHK(h, hipMemcpyAsync(h->dtheta, th_src, 2 * (size_t)(d + 1) * sizeof(double), hipMemcpyHostToDevice, st));
 
   // The identity padding is re-established for EVERY factorisation: a factorisation that broke down (pivots of rounding
   // size -> overflowing inverses -> inf * 0) leaves NaN in the padding rows of the in-place factor, and R is only rebuilt
@@ -442,11 +534,16 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
     return BOGP_OK;
   }
   double blk[64];  // [0 .. 4 n_t): sum(log diag L), |Ft|, Ft.Yt, rho.rho (the last three per target); [62]: the info word
-  HIPCHK(h, hipMemcpyAsync(blk, h->dscal, sizeof(blk), hipMemcpyDeviceToHost, st));
   const double* sc = blk;
   int info2[2] = {0, 0};
-  if (ptrend > 1 && estimate_trend) HIPCHK(h, hipMemcpyAsync(info2, h->dinfo2, sizeof(info2), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
+  if (ptrend > 1 && estimate_trend) {
+    HIPCHK(h, hipMemcpyAsync(blk, h->dscal, sizeof(blk), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(info2, h->dinfo2, sizeof(info2), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+  } else {
+    const int er = fit_readback(h, nullptr, 0, blk, nullptr);
+    if (er) return er;
+  }
   int info = 0;
   memcpy(&info, blk + 62, sizeof(info));
   return factorize_finish(h, fp, (int)info, sc, info2, reject_positive, o);
@@ -519,6 +616,26 @@ static int factorize_finish(bogp_handle* h, const FitPending& fp, int info, cons
   return BOGP_OK;
 }
 
+// the likelihood gradient from the d + 1 contractions, trace(R^-1) and gamma.gamma (gpr.py:1001-1038)
+static void nll_gradient_from_sums(int mode, bool iso, int d, const double* par, int n_par, int n_t, const double* S, double s2t,
+                                   double* grad) {
+  const double tr = n_t * S[d + 1], gg = S[d + 2];
+  if (iso) {
+    grad[0] = mode == BOGP_MODE_NOISE_ESTIM ? par[n_par - 1] * S[0] : S[0];
+    if (mode == BOGP_MODE_NOISE_ESTIM) grad[1] = S[d];
+    if (mode == BOGP_MODE_NOISY) grad[1] = S[1];
+  } else if (mode == BOGP_MODE_NOISELESS) {
+    for (int k = 0; k < d; ++k) grad[k] = S[k];
+  } else if (mode == BOGP_MODE_NOISE_ESTIM) {
+    const double alpha = par[n_par - 1];
+    for (int k = 0; k < d; ++k) grad[k] = alpha * S[k];
+    grad[d] = S[d];
+  } else {
+    for (int k = 0; k < d; ++k) grad[k] = S[k];
+    grad[d] = -0.5 * (tr / s2t - gg / (s2t * s2t)) + S[d] / s2t;
+  }
+}
+
 extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
                         int estimate_trend, double beta, double* llf, double* grad) {
   if (!h) return BOGP_ERR_INVALID;
@@ -533,14 +650,20 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
   // evaluation is 0.15 ms at N <= 64).  A failed factorisation then wastes the queued gradient work -- the rare case.
   const bool deferred = grad != nullptr && trend == BOGP_TREND_CONSTANT && !(getenv("BOGP_NLL_TWO_SYNCS") && atoi(getenv("BOGP_NLL_TWO_SYNCS")) != 0);
   FitPending fp;
+  FusedNll fz;
+  fz.want_grad = grad != nullptr;
   int rc = factorize(h, kernel, mode, par, n_par, noise_var, trend, estimate_trend, beta, grad != nullptr, &o, nullptr, true,
-                     deferred ? &fp : nullptr);
-  if (!deferred) *llf = o.llf;
+                     deferred ? &fp : nullptr, &fz);
+  if (!deferred || fz.done) *llf = o.llf;
   if (rc != BOGP_OK) return rc;
   if (!grad) return BOGP_OK;
 
   const int N = h->N, d = h->d;
   const int n_theta = n_par - (mode == BOGP_MODE_NOISELESS ? 0 : 1);
+  if (fz.done) {
+    nll_gradient_from_sums(mode, n_theta != d, d, par, n_par, 1, fz.S, o.s2t, grad);
+    return BOGP_OK;
+  }
   // Isotropic theta (len 1, d > 1): corr_grad_theta still returns the (N, N, d) per-dimension tensor (gpr.py:745-770) and the
   // loops of :1001-1037 index it BY PARAMETER, so row 0 is the derivative along dimension 0 only and, in the noisy mode,
   // the "sigma2" row is the derivative along dimension 1 (slice 1 of the d + 1 slices).  That is what the reference's MLE
@@ -584,35 +707,23 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
     HIPCHK(h, launch_trace_gg(h->dRinv, ldr, nparts, (size_t)ldr * ldr, N, h->dgamma_base, nullptr, dS + d + 1, st));
     if (n_t > 1) HIPCHK(h, launch_sumsq(h->dgamma_base, n_t * h->Np, dS + d + 2, st));  // sum_t gamma_t . gamma_t (zero padding)
   }
-  HIPCHK(h, hipMemcpyAsync(S.data(), dS, (d + 3) * sizeof(double), hipMemcpyDeviceToHost, st));
   if (deferred) {
     double blk[64];
     const int info2[2] = {0, 0};
-    HIPCHK(h, hipMemcpyAsync(blk, h->dscal, sizeof(blk), hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
+    {
+      const int er = fit_readback(h, dS, d + 3, blk, S.data());
+      if (er) return er;
+    }
     int info = 0;
     memcpy(&info, blk + 62, sizeof(info));
     rc = factorize_finish(h, fp, (int)info, blk, info2, true, &o);
     *llf = o.llf;
     if (rc != BOGP_OK) return rc;
   } else {
+    HIPCHK(h, hipMemcpyAsync(S.data(), dS, (d + 3) * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
   }
-  const double tr = n_t * S[d + 1], gg = S[d + 2];
-  if (iso) {
-    grad[0] = mode == BOGP_MODE_NOISE_ESTIM ? par[n_par - 1] * S[0] : S[0];
-    if (mode == BOGP_MODE_NOISE_ESTIM) grad[1] = S[d];
-    if (mode == BOGP_MODE_NOISY) grad[1] = S[1];
-  } else if (mode == BOGP_MODE_NOISELESS) {
-    for (int k = 0; k < d; ++k) grad[k] = S[k];
-  } else if (mode == BOGP_MODE_NOISE_ESTIM) {
-    const double alpha = par[n_par - 1];
-    for (int k = 0; k < d; ++k) grad[k] = alpha * S[k];
-    grad[d] = S[d];
-  } else {
-    for (int k = 0; k < d; ++k) grad[k] = S[k];
-    grad[d] = -0.5 * (tr / o.s2t - gg / (o.s2t * o.s2t)) + S[d] / o.s2t;
-  }
+  nll_gradient_from_sums(mode, iso, d, par, n_par, n_t, S.data(), o.s2t, grad);
   return BOGP_OK;
 }
 

@@ -130,6 +130,11 @@ struct bogp_handle {
   double* dpt_split = nullptr;  // partial tiles of split row blocks (one-point latency mode of k_point_tri)
   unsigned int* dpt_splitc = nullptr;
   size_t pt_split_cap = 0, pt_splitc_cap = 0;
+  // the likelihood's host traffic (r03): theta travels through a pinned staging block, the scalars / gradient sums come back through
+  // a device-mapped pinned block that one gather kernel fills, completion read off a sequence word (bogp_api.hip: fit_readback)
+  double* hfit = nullptr;      // pinned: [0, 2048) theta staging | [2048, 2112) the 64 scalars | [2112, 2112 + 512) gradient sums | [3000] sequence word
+  double* hfit_dev = nullptr;  // its device address
+  unsigned long long fit_seq = 0;
   double* hpin = nullptr;  // pinned host buffer the finishing workgroup writes its records into (device-mapped)
   double* hpin_dev = nullptr;
   size_t hpin_cap = 0;

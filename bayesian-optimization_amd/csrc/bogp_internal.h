@@ -193,6 +193,25 @@ hipError_t launch_trend_terms(int trend, const double* Xs, int64_t m0, int64_t m
                               double* T, double* mtrend, hipStream_t st);
 hipError_t launch_rowdot(const double* Cm, const double* CS, int64_t Mc, int64_t mcount, int p, double* uu, hipStream_t st);
 hipError_t launch_sumsq(const double* v, int N, double* out, hipStream_t st);
+// the one-launch likelihood of a small training set (kernels_nllsmall.hip)
+struct NllSmallArgs {
+  const double* X;  // N x d, row-major
+  const double* y;  // N
+  int N, d;
+  double theta[64];  // d entries
+  double pexp;       // generalized_exponential's exponent
+  double a, b, diag;  // off-diagonal = a corr (/ b if div), diagonal = diag: k_build_R's arguments
+  int div, estimate_trend, mode;
+  double beta, s2t_host;
+  double* out_scal;  // 64 doubles (device address of pinned host memory)
+  double* out_S;     // d + 3 doubles
+  unsigned long long* flag;
+  unsigned long long seq;
+};
+int nll_small_max_n();
+hipError_t launch_nll_small(int kernel, bool grad, const NllSmallArgs& a, hipStream_t st);
+hipError_t launch_fit_gather(const double* scal, const double* S, int nS, double* out_scal, double* out_S, unsigned long long* flag,
+                             unsigned long long seq, hipStream_t st);
 hipError_t launch_grad_coef(const double* scal, int n_t, int mode, int N, int krank, double s2t_host, double* coef, hipStream_t st);
 hipError_t launch_gemv2(const double* M, int ld, int N, int tri, const double* x0, const double* x1, double* y0, double* y1,
                         double* scratch, hipStream_t st);

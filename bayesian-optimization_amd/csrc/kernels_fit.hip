@@ -209,6 +209,23 @@ hipError_t launch_grad_coef(const double* scal, int n_t, int mode, int N, int kr
   return hipGetLastError();
 }
 
+// The likelihood's read-back in ONE launch instead of two copy commands: the 64 scalars (incl. the factorisation's info word) and
+// the nS gradient sums into device-mapped pinned host memory, then a sequence word the host polls (as k_point_finish does).
+__global__ void k_fit_gather(const double* __restrict__ scal, const double* __restrict__ S, int nS, double* __restrict__ out_scal,
+                             double* __restrict__ out_S, unsigned long long* __restrict__ flag, unsigned long long seq) {
+  const int i = threadIdx.x;
+  if (i < 64) out_scal[i] = scal[i];
+  for (int k = i; k < nS; k += blockDim.x) out_S[k] = S[k];
+  __threadfence_system();
+  __syncthreads();
+  if (i == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_fit_gather(const double* scal, const double* S, int nS, double* out_scal, double* out_S, unsigned long long* flag,
+                             unsigned long long seq, hipStream_t st) {
+  hipLaunchKernelGGL(k_fit_gather, dim3(1), 128, 0, st, scal, S, nS, out_scal, out_S, flag, seq);
+  return hipGetLastError();
+}
+
 // out[0] = v . v
 __global__ __launch_bounds__(1024) void k_sumsq(const double* __restrict__ v, int N, double* __restrict__ out) {
   __shared__ double red[16];
