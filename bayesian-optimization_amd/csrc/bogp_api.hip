@@ -394,6 +394,7 @@ static int factorize_finish(bogp_handle* h, const FitPending& fp, int info, cons
 struct FusedNll {
   bool want_grad = false;
   bool done = false;
+  bool mid = false;  // 128 < N <= 252: k_build_R + ONE workgroup for factor / inverse / scalars / gamma (k_spd_mid); the caller's tail follows
   double S[64 + 3];
 };
 static int factorize(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
@@ -429,8 +430,11 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   if (theta_out) theta_out->assign(th, th + d);
   hipStream_t st = h->stream;
   HIPCHK(h, hipSetDevice(h->device));
-  if (fz && N <= nll_small_max_n() && d <= 64 && trend == BOGP_TREND_CONSTANT && h->n_t == 1 &&
-      !(getenv("BOGP_NLL_FUSED") && atoi(getenv("BOGP_NLL_FUSED")) == 0)) {
+  const bool fused_ok = fz && trend == BOGP_TREND_CONSTANT && h->n_t == 1 && !(getenv("BOGP_NLL_FUSED") && atoi(getenv("BOGP_NLL_FUSED")) == 0);
+  const bool mid = fused_ok && N > nll_small_max_n() && N <= spd_mid_max_n() && (!fz->want_grad || pend) &&
+                   (getenv("BOGP_NLL_MID") && atoi(getenv("BOGP_NLL_MID")) != 0);  // opt-in: measured SLOWER than the general path
+                                                                                     // (profiles/r03_nll_small.txt), kept for the record
+  if (fused_ok && N <= nll_small_max_n() && d <= 64) {
     NllSmallArgs na;
     na.X = h->dX; na.y = h->dy_base; na.N = N; na.d = d;
     for (int k = 0; k < d; ++k) na.theta[k] = th[k];
@@ -478,7 +482,7 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   // size -> overflowing inverses -> inf * 0) leaves NaN in the padding rows of the in-place factor, and R is only rebuilt
   // inside its N x N block -- without this, one failed likelihood evaluation made every later one on the handle fail too
   // (found with the near-singular noiseless cubic tables of G25).
-  HIPCHK(h, launch_pad_identity(h->dR, N, ldr, st));
+  if (!mid) HIPCHK(h, launch_pad_identity(h->dR, N, ldr, st));  // (k_spd_mid pads in its registers)
   // correlation matrix with the per-mode normalisation (gpr.py:931-969)
   double s2t = 0, alpha = 0, sigma2_par = 0;
   if (mode == BOGP_MODE_NOISELESS) {
@@ -501,12 +505,21 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   //   Yt = V y (:799), Ft = V 1 (:803)              one pass over V
   //   rho (:806 / :808), |Ft|, Ft.Yt, rho.rho       k_fit_rho
   //   gamma = U rho (:788 / :996)
+  const int n_t = h->n_t;
+  if (mid) {
+    if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * h->cap_ld * h->cap_ld * sizeof(double)));
+    SpdMidArgs ma;
+    ma.R = h->dR; ma.ldr = ldr; ma.y = h->dy_base; ma.N = N; ma.estimate_trend = estimate_trend; ma.mode = mode;
+    ma.beta = beta; ma.s2t_host = s2t; ma.Rinv = h->dRinv; ma.ldi = ldr; ma.gamma = h->dgamma_base;
+    ma.scal = h->dscal; ma.coef = h->dscal + 4 * BOGP_MAX_TARGETS;
+    HIPCHK(h, launch_spd_mid(fz->want_grad, ma, st));
+    fz->mid = true;
+  } else {
   if (!h->dchain_flags) HIPCHK(h, hipMalloc((void**)&h->dchain_flags, (size_t)2 * (h->cap_ld / 64 + 1) * sizeof(unsigned int)));
   HIPCHK(h, launch_chol_lower(h->dR, ldr, h->ddinv, h->dinfo, st, h->stream_upd ? h->stream_upd : h->stream2, h->ev_chol, h->dT, N, h->dchain_flags));  // dT: free until the inverse
   const bool logdet_in_rho = trend_size(trend, h->d) == 1;  // constant basis: k_fit_rho of target 0 forms sum(log diag L) too (one launch less)
   if (!logdet_in_rho) HIPCHK(h, launch_logdet(h->dR, N, ldr, h->dscal, st));
   HIPCHK(h, launch_tri_inverse(h->dR, h->ddinv, h->dV, h->dU, h->dT, ldr, st));
-  const int n_t = h->n_t;
   if (n_t > 1 && (ptrend != 1 || estimate_trend))
     FAIL(h, BOGP_ERR_UNSUPPORTED, "multi-target y (%d targets) is built for a FIXED constant trend only: with estimated coefficients the reference raises at gpr.py:787 (beta gets one row per target)", n_t);
   if (ptrend == 1) {
@@ -526,6 +539,7 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
     for (int t = 0; t < n_t; ++t)
       HIPCHK(h, launch_gemv2(h->dU, ldr, N, 2, h->drho_base + (size_t)t * N, nullptr, h->dgamma_base + (size_t)t * h->Np, nullptr, h->dgemv_scratch, st));
   }
+  }  // !mid
   FitPending fp;
   fp.mode = mode; fp.estimate_trend = estimate_trend; fp.ptrend = ptrend; fp.n_t = n_t; fp.N = N;
   fp.beta = beta; fp.alpha = alpha; fp.sigma2_par = sigma2_par; fp.noise_var = noise_var; fp.s2t = s2t;
@@ -674,7 +688,8 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
   const int ldr = h->ldr;
   if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * h->cap_ld * h->cap_ld * sizeof(double)));
   int nparts = UUT_PARTS;
-  HIPCHK(h, launch_uut(h->dU, h->dRinv, ldr, st, &nparts));  // R^-1 = L^-T L^-1, lower triangle
+  if (fz.mid) nparts = 1;  // (k_spd_mid left R^-1 itself)
+  else HIPCHK(h, launch_uut(h->dU, h->dRinv, ldr, st, &nparts));  // R^-1 = L^-T L^-1, lower triangle
   const int nblk = grad_contract_blocks(N);
   int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)nblk * (d + 1) + (d + 4));
   if (e) return e;
@@ -688,7 +703,7 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
   if (deferred) {
     // scal[4 n_t ..]: 16 doubles of weights behind the per-target scalars (dscal holds 64 doubles)
     double* dcoef = h->dscal + 4 * BOGP_MAX_TARGETS;
-    HIPCHK(h, launch_grad_coef(h->dscal, n_t, mode, N, estimate_trend ? 1 : 0, fp.s2t, dcoef, st));
+    if (!fz.mid) HIPCHK(h, launch_grad_coef(h->dscal, n_t, mode, N, estimate_trend ? 1 : 0, fp.s2t, dcoef, st));
     gv.dcoef = dcoef;
     for (int t = 0; t < BOGP_MAX_TARGETS; ++t) gv.cA[t] = gv.cB[t] = 0.0;
   } else {
@@ -1703,6 +1718,22 @@ extern "C" int bogp_prior_corr(bogp_handle* h, const double* X1, int n1, double*
 // ------------------------------------------------------------------------------------------------------
 // self test of kernels_gemm.hip on host buffers (include/bogp.h)
 // ------------------------------------------------------------------------------------------------------
+#ifdef NS_PROFILE
+// (profiling builds only, `make EXTRA=-DNS_PROFILE`: the 64 scalars of the last polled read-back / of the device block, incl. the
+// clock words a profiled kernel leaves -- tools/prof_nll_small_phases.py)
+extern "C" int bogp_debug_fit_scalars(bogp_handle* h, double* out) {
+  if (!h || !out) return BOGP_ERR_INVALID;
+  memcpy(out, h->hfit + 2048, 64 * sizeof(double));
+  return BOGP_OK;
+}
+
+extern "C" int bogp_debug_dscal(bogp_handle* h, double* out) {
+  if (!h || !out) return BOGP_ERR_INVALID;
+  HIPCHK(h, hipMemcpy(out, h->dscal, 64 * sizeof(double), hipMemcpyDeviceToHost));
+  return BOGP_OK;
+}
+#endif
+
 extern "C" int bogp_selftest_gemm(bogp_handle* h, int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda,
                                   const double* B, int ldb, double beta, double* C, int ldc, int tri, int split) {
   if (!h) return BOGP_ERR_INVALID;

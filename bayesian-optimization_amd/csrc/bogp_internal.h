@@ -209,6 +209,21 @@ struct NllSmallArgs {
   unsigned long long seq;
 };
 int nll_small_max_n();
+// 128 < N <= 252: factor + inverse + the likelihood's scalars + gamma of a matrix k_build_R left in global memory, one workgroup
+struct SpdMidArgs {
+  const double* R;  // column-major, lower triangle (diagonal 64-tiles complete), leading dimension ldr
+  int ldr;
+  const double* y;
+  int N, estimate_trend, mode;
+  double beta, s2t_host;
+  double* Rinv;  // lower triangle, column-major, leading dimension ldi
+  int ldi;
+  double* gamma;  // N
+  double* scal;   // the 64-double scalar block (dscal layout)
+  double* coef;   // k_grad_coef's output block
+};
+int spd_mid_max_n();
+hipError_t launch_spd_mid(bool grad, const SpdMidArgs& a, hipStream_t st);
 hipError_t launch_nll_small(int kernel, bool grad, const NllSmallArgs& a, hipStream_t st);
 hipError_t launch_fit_gather(const double* scal, const double* S, int nS, double* out_scal, double* out_S, unsigned long long* flag,
                              unsigned long long seq, hipStream_t st);

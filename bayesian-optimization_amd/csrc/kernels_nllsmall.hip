@@ -30,7 +30,7 @@ namespace {
 constexpr int NS_BS = 4;           // block size
 constexpr int NS_MAXNB = 32;       // N <= 128
 constexpr int NS_PITCH = NS_MAXNB + 2;
-constexpr int NS_THREADS = 576;    // (nb + 1)(nb + 2) / 2 = 561 at nb = 32
+constexpr int NS_THREADS = 768;    // 4 (nb + 1) = 132 panel threads (3 waves) + (nb + 1)(nb + 2) / 2 - 1 = 560 owners (9 waves) at nb = 32
 constexpr int NS_WAVES = NS_THREADS / 64;
 
 __device__ __forceinline__ double ns_wave_sum(double v) {
@@ -50,23 +50,46 @@ __device__ __forceinline__ double ns_block_sum(double v, double* red /* [NS_WAVE
 }
 
 // sqrt(p) and 1 / sqrt(p) of a pivot 0 < p (no range scaling: pivots of a correlation matrix lie in (1e-300, 4)): the hardware's
-// reciprocal square root estimate + two coupled Goldschmidt steps -- a dependent chain of 8 operations where sqrt() followed by a
-// division is 45, and that chain is on the critical path of EVERY step
+// reciprocal square root estimate + ONE third-order (Halley) step -- five dependent operations where sqrt() followed by a
+// division is ~45; a dependent FP64 operation costs ~26 cycles in a lone wave and this chain is on the critical path of EVERY
+// step (kernels_chol.hip: rsqrt_nr, same arithmetic)
 __device__ __forceinline__ void ns_sqrt_rsqrt(double p, double& root, double& inv) {
   const double y = __builtin_amdgcn_rsq(p);
-  double g = p * y, hh = 0.5 * y;
-  double r = __builtin_fma(-g, hh, 0.5);
-  g = __builtin_fma(g, r, g);
-  hh = __builtin_fma(hh, r, hh);
-  r = __builtin_fma(-g, hh, 0.5);
-  g = __builtin_fma(g, r, g);
-  hh = __builtin_fma(hh, r, hh);
-  // one correction of the root against p itself
-  const double e = __builtin_fma(-g, g, p);
-  root = __builtin_fma(e, hh, g);
-  inv = hh + hh;
+  const double t = p * y;
+  const double e = __builtin_fma(-t, y, 1.0);
+  double q = __builtin_fma(0.375, e, 0.5);
+  q = q * e;
+  inv = __builtin_fma(y, q, y);
+  root = p * inv;
 }
 
+// 4 x 4 Cholesky of the lower triangle of a: l (strict lower part) and inv[c] = 1 / l_cc -- the panel's rows are then solved by
+// substitution, o = M L^-T, column c of o as soon as pivot c is known: off the pivots' dependent chain except for one product
+__device__ __forceinline__ int ns_factor4_sub(const double (&a)[4][4], double (&l)[4][4], double (&inv)[4], double& pivprod) {
+  int bad = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double p = a[c][c];
+#pragma unroll
+    for (int m = 0; m < c; ++m) p = __builtin_fma(-l[c][m], l[c][m], p);
+    if (!(p > 0.0) || !(p < 1e300)) {
+      if (!bad) bad = c + 1;
+      p = 1.0;
+    }
+    double lc;
+    ns_sqrt_rsqrt(p, lc, inv[c]);
+    l[c][c] = lc;
+    pivprod *= lc;
+#pragma unroll
+    for (int r = c + 1; r < 4; ++r) {
+      double v = a[r][c];
+#pragma unroll
+      for (int m = 0; m < c; ++m) v = __builtin_fma(-l[r][m], l[c][m], v);
+      l[r][c] = v * inv[c];
+    }
+  }
+  return bad;
+}
 // 4 x 4 Cholesky of the lower triangle of a, then W = L^-1 (lower); returns the 1-based index of the first non-positive
 // pivot (0: none); pivprod *= l_00 l_11 l_22 l_33 (its logarithm is taken once, after the last step)
 __device__ __forceinline__ int ns_factor4(const double (&a)[4][4], double (&w)[4][4], double& pivprod) {
@@ -113,168 +136,279 @@ __device__ __forceinline__ int ns_factor4(const double (&a)[4][4], double (&w)[4
   return bad;
 }
 
+// r0 = corr_profile(s2) and h = corr_dtheta_profile(s2, r0) with the square root and the exponential they share evaluated once
+// (the same operations on the same values: bit-identical to the two calls)
+template <int KERNEL>
+__device__ __forceinline__ void ns_corr_pair(double s2, double& r0, double& h) {
+  if (KERNEL == BOGP_KERNEL_SE || KERNEL == BOGP_KERNEL_ABSEXP) {
+    r0 = exp(-s2);
+    h = r0;
+    return;
+  }
+  const double D = sqrt(s2);
+  if (KERNEL == BOGP_KERNEL_MATERN12) {
+    r0 = exp(-D);
+    h = D > 0.0 ? 0.5 * r0 / D : 0.0;
+  } else if (KERNEL == BOGP_KERNEL_MATERN32) {
+    const double K = D * 1.7320508075688772;
+    const double E = exp(-K);
+    r0 = (1.0 + K) * E;
+    h = 1.5 * E;
+  } else {
+    const double K = D * 2.23606797749979;
+    const double E = exp(-K);
+    r0 = (1.0 + K + (K * K) * 0.3333333333333333) * E;
+    h = (5.0 / 6.0) * (1.0 + K) * E;
+  }
+}
+
 }  // namespace
 
 // out_scal: [0] sum(log diag L), [1] |Ft|, [2] Ft.Yt, [3] rho.rho, [62] the info word (int); out_S: the d + 1 contractions,
 // [d + 1] trace(R^-1), [d + 2] gamma.gamma  (the layout the general path's read-back has, bogp_api.hip: fit_readback)
+//
+// Threads: the first 4 (nb + 1) are the PANEL threads, one a ROW of a block row's block of the current panel (1 - 3 waves); the
+// others own the blocks.  Software pipeline, one barrier a step -- phase p:
+//   owners: T -= P_p[bi] P_p[bj]^T; then those of column / row p + 1 restart from 0 (GRAD) and those of column / row p + 2 copy
+//           their block (state after update p) to `Raw`;
+//   panel threads, at the same time: take the copies of column / row p + 1 (state after update p - 1), apply update p themselves,
+//           factor the diagonal block (every thread, the same instructions: no hand-over inside the panel), solve their row
+//           against it and store P_{p+1}.
+// The dependent chain of the 4 x 4 factorisation (~26 cycles an FP64 operation in a lone wave) sets the pace of a step,
+// ~2000 cycles; the owners' 64 FMAs + 32 LDS reads a block hide behind it.
+// The pair work before and after the loop (the correlation matrix; the gradient contractions) is spread over ALL threads in
+// strips of 1 x 4 entries through an LDS image of the blocks, whatever the number of owners (15 at N = 16): it is bound by the
+// exp / sqrt of each pair, ~100 instructions an entry.
 template <int KERNEL, bool GRAD>
 __global__ __launch_bounds__(NS_THREADS) void k_nll_small(const NllSmallArgs a) {
-  __shared__ double P[16 * NS_PITCH];  // P[e * NS_PITCH + i]: element e = 4 r + c of block row i's panel block
-  __shared__ double Wb[2][16];
+  extern __shared__ double dyn[];      // Xs[N][dP] | Rst[16][nbR]: the blocks of R, later of R^-1, element-major
+  __shared__ double P[2][16 * NS_PITCH];  // P[step & 1][e * NS_PITCH + i]: element e = 4 r + c of block row i's panel block
+  __shared__ double Raw[2][16 * NS_PITCH];
   __shared__ double yt[NS_BS * NS_MAXNB], ft[NS_BS * NS_MAXNB], gam[NS_BS * NS_MAXNB];
   __shared__ double red[NS_WAVES];
-  __shared__ double logpart[NS_MAXNB];
   __shared__ double redk[NS_WAVES][65];
+  __shared__ unsigned short blkmap[NS_MAXNB * (NS_MAXNB + 1) / 2];
+  __shared__ double s_logdet;
   __shared__ int s_info;
 
+#ifdef NS_PROFILE
+  const long long tstart = clock64();
+#endif
   const int N = a.N, d = a.d, nb = (N + NS_BS - 1) / NS_BS;
-  const int tid = threadIdx.x;
-  const int nthreads = (nb + 1) * (nb + 2) / 2 - 1;  // block (nb, nb) does not exist
-  const int nwaves = blockDim.x >> 6;
-  // thread -> block (bi, bj), bi >= bj, row-major over the triangle
-  int bi = (int)((sqrt(8.0 * tid + 1.0) - 1.0) * 0.5);
-  while ((bi + 1) * (bi + 2) / 2 <= tid) ++bi;
-  while (bi * (bi + 1) / 2 > tid) --bi;
-  const int bj = tid - bi * (bi + 1) / 2;
-  const bool live = tid < nthreads;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int nbR = nb * (nb + 1) / 2;              // blocks of R
+  const int nown = (nb + 1) * (nb + 2) / 2 - 1;   // + block row nb; block (nb, nb) does not exist
+  const int nwaves = nthr >> 6;
+  const int dP = d | 1;
+  double* Xs = dyn;
+  double* Rst = dyn + (((size_t)N * dP + 1) & ~(size_t)1);
+  // owner -> block (bi, bj), bi >= bj, row-major over the triangle
+  const int npanel = ((4 * (nb + 1) + 63) / 64) * 64;  // panel threads: one a row of the (nb + 1) panel blocks, whole waves
+  const int ot = tid - npanel;
+  int bi = 0, bj = 0;
+  if (ot >= 0) {
+    bi = (int)((sqrt(8.0 * ot + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= ot) ++bi;
+    while (bi * (bi + 1) / 2 > ot) --bi;
+    bj = ot - bi * (bi + 1) / 2;
+  }
+  const bool live = ot >= 0 && ot < nown;
   const bool border = bi == nb;
+  if (live && !border) blkmap[ot] = (unsigned short)((bi << 8) | bj);
   if (tid == 0) s_info = 0;
+  for (int e = tid; e < N * d; e += nthr) Xs[(e / d) * dP + (e % d)] = a.X[e];
+  __syncthreads();
 
-  // ---- the thread's block of [R; y; 1] ---------------------------------------------------------------------------
-  double T[4][4];
-  {
-    double s2[4][4];
+  // ---- R, strip by strip, into the LDS image ---------------------------------------------------------------------
+  for (int s = tid; s < 4 * nbR; s += nthr) {
+    const int t = s >> 2, r = s & 3;
+    const int sbi = blkmap[t] >> 8, sbj = blkmap[t] & 255;
+    const int i = 4 * sbi + r;
+    double s2[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) s2[r][c] = dist_init<KERNEL>();
-    if (live && !border) {
+    for (int c = 0; c < 4; ++c) s2[c] = dist_init<KERNEL>();
+    if (i < N) {
       const double pexp = a.pexp;
+      const double* xi = Xs + i * dP;
+      const double* xj = Xs + min(4 * sbj, N - 1) * dP;  // (columns j <= i < N; the clamp only keeps padding reads in range)
       for (int k = 0; k < d; ++k) {
-        const double th = a.theta[k];
-        double vi[4], vj[4];
+        const double th = a.theta[k], vi = xi[k];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vi[r] = (4 * bi + r < N) ? a.X[(size_t)(4 * bi + r) * d + k] : 0.0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) vj[c] = (4 * bj + c < N) ? a.X[(size_t)(4 * bj + c) * d + k] : 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) s2[r][c] = dist_fold<KERNEL>(th, vi[r] - vj[c], s2[r][c], pexp);
+        for (int c = 0; c < 4; ++c) s2[c] = dist_fold<KERNEL>(th, vi - xj[min(c, N - 1 - min(4 * sbj, N - 1)) * dP + k], s2[c], pexp);
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int i = 4 * bi + r, j = 4 * bj + c;
-        double v = 0.0;
-        if (!live) {
-          v = 0.0;
-        } else if (border) {
-          if (j < N) v = r == 0 ? a.y[j] : (r == 1 ? 1.0 : 0.0);
-        } else if (i >= N || j >= N) {
-          v = i == j ? 1.0 : 0.0;  // identity padding
-        } else if (i == j) {
-          v = a.diag;
-        } else if (a.div) {
-          v = (a.a * corr_profile<KERNEL>(s2[r][c])) / a.b;
-        } else {
-          v = a.a * corr_profile<KERNEL>(s2[r][c]);
-        }
-        T[r][c] = v;
-      }
+    for (int c = 0; c < 4; ++c) {
+      const int j = 4 * sbj + c;
+      double v;
+      if (i >= N || j >= N) v = i == j ? 1.0 : 0.0;  // identity padding
+      else if (i == j) v = a.diag;
+      else if (a.div) v = (a.a * corr_profile<KERNEL>(s2[c])) / a.b;
+      else v = a.a * corr_profile<KERNEL>(s2[c]);
+      Rst[(4 * r + c) * nbR + t] = v;
+    }
   }
-  double pivprod = 1.0;
-  if (tid == 0) {  // block (0, 0): the first diagonal factor
-    double w[4][4];
-    const int bad = ns_factor4(T, w, pivprod);
-    if (bad) s_info = bad;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) Wb[0][4 * r + c] = w[r][c];
-  }
+  __syncthreads();
 
-  // ---- nb steps of factor / invert / multiply, in place ----------------------------------------------------------
-  for (int k = 0; k < nb; ++k) {
-    __syncthreads();  // W of step k is published; every read of the previous panel is done
-    if (live) {
-      const bool is_col = bj == k && bi > k, is_row = bi == k && bj < k, is_diag = bi == k && bj == k;
-      if (is_col || (GRAD && (is_row || is_diag))) {
-        double w[4][4];
+  // ---- the owner's block of [R; y; 1] ----------------------------------------------------------------------------
+  double T[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double v = 0.0;
+      if (live && !border) v = Rst[(4 * r + c) * nbR + ot];
+      else if (live && 4 * bj + c < N) v = r == 0 ? a.y[4 * bj + c] : (r == 1 ? 1.0 : 0.0);
+      T[r][c] = v;
+    }
+  // Software pipeline, ONE barrier a step: in phase p the owners apply update p (panel P_p) while the panel wave already builds
+  // P_{p+1}.  For that the blocks of column / row p + 1 were copied to `Raw` at the end of phase p - 1, in their state after update
+  // p - 1, and the panel wave applies update p to its copy itself (lane i: M -= P_p[i] P_p[p + 1]^T, P_p[i] being its own output of
+  // the phase before, kept in the T registers it has no other use for).  The owners' registers of those blocks restart from zero
+  // at the END of phase p.  `P` and `Raw` are double-buffered by the parity of the step they belong to.
+#define NS_PUBLISH(q_)                                                                        \
+  {                                                                                           \
+    const int q = (q_);                                                                       \
+    if (live && q < nb && (bj == q || (GRAD && bi == q))) {                                   \
+      double* rawb = Raw[q & 1];                                                              \
+      if (bj == q) {                                                                          \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                         \
+          _Pragma("unroll") for (int c = 0; c < 4; ++c) rawb[(4 * r + c) * NS_PITCH + bi] = T[r][c]; \
+      } else {                                                                                \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                         \
+          _Pragma("unroll") for (int c = 0; c < 4; ++c) rawb[(4 * r + c) * NS_PITCH + bj] = T[c][r]; \
+      }                                                                                       \
+    }                                                                                         \
+  }
+#define NS_RESTART(z_)                                                                        \
+  {                                                                                           \
+    const int z = (z_);                                                                       \
+    if (GRAD && live && z < nb && (bj == z || bi == z)) {                                     \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r)                                           \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) T[r][c] = 0.0;                          \
+    }                                                                                         \
+  }
+  // (the blocks of column q as they are, those of row q (bj < q) transposed; macros, not lambdas: a by-reference capture of T
+  // left the block in scratch memory)
+  NS_PUBLISH(0)
+  NS_RESTART(0)
+  NS_PUBLISH(1)
+  double pivm = 1.0;  // lane 0 of the panel wave: prod(l_cc) = pivm 2^pive
+  int pive = 0;
+#ifdef NS_PROFILE
+  long long tp0 = clock64(), tpA = 0, tpB = 0, tpC = 0, tpre = tp0;
+  if (tid == 0) a.out_scal[20] = (double)(tp0 - tstart);
+#endif
+  __syncthreads();  // raw(0), raw(1) are published
+
+  // ---- nb + 1 phases of factor / invert / multiply, in place ----------------------------------------------------
+  for (int kn = 0; kn <= nb; ++kn) {  // the panel wave: P_kn; the owners: update kn - 1
+    if (tid < npanel) {
+      if (kn < nb) {
+        // panel thread = ONE ROW of a block row's panel block: i = block row, pr = row in the block (T[0][.]: its output of the
+        // phase before).  Every thread factors the diagonal block itself (same instructions in all lanes).
+        const int i = min(tid >> 2, nb), pr = tid & 3;
+        double D[4][4], l[4][4], inv[4], Mr[4];
+        const double* rawb = Raw[kn & 1];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Mr[c] = rawb[(4 * pr + c) * NS_PITCH + i];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) w[r][c] = Wb[k & 1][4 * r + c];
-        // one expression for the three publishers, o = M W^T:  L(bi, k) = T W^T;  X(bj, k) = (W Z)^T = Z^T W^T with Z = this
-        // thread's X(bj, k)^T;  X(k, k) = I W^T
-        double M[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) M[r][c] = is_col ? T[r][c] : (is_row ? T[c][r] : (r == c ? 1.0 : 0.0));
-        double o[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            double s = 0.0;
-#pragma unroll
-            for (int m = 0; m <= c; ++m) s = __builtin_fma(M[r][m], w[c][m], s);
-            o[r][c] = s;
-          }
-        if (is_col && border) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            yt[4 * k + c] = o[0][c];
-            ft[4 * k + c] = o[1][c];
-          }
-        }
-        const int slot = is_col ? bi : bj;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) P[(4 * r + c) * NS_PITCH + slot] = o[r][c];
-        if (GRAD) {
+          for (int c = 0; c <= r; ++c) D[r][c] = rawb[(4 * r + c) * NS_PITCH + kn];
+        if (kn > 0) {
+          // update kn - 1 of the copies: row pr of M -= P[i] P[kn]^T, and the diagonal block D -= P[kn] P[kn]^T from the panel in
+          // LDS (the factorisation below then depends on 4 FMAs, not on another thread's row)
+          const double* q = P[(kn - 1) & 1] + kn;
+          double Q[4][4];
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) T[r][c] = 0.0;
+            for (int m = 0; m < 4; ++m) Q[r][m] = q[(4 * r + m) * NS_PITCH];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+              double sacc = D[r][c];
+#pragma unroll
+              for (int m = 0; m < 4; ++m) sacc = __builtin_fma(-Q[r][m], Q[c][m], sacc);
+              D[r][c] = sacc;
+            }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            double sacc = Mr[c];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sacc = __builtin_fma(-T[0][m], Q[c][m], sacc);
+            Mr[c] = sacc;
+          }
+        }
+        double prod4 = 1.0;
+        const int bad = ns_factor4_sub(D, l, inv, prod4);
+        if (tid == 0) {
+          if (bad && s_info == 0) s_info = 4 * kn + bad;
+          int e2;
+          pivm = frexp(pivm * prod4, &e2);
+          pive += e2;
+        }
+        if (i == kn) {  // X(kn, kn) = I L^-T
+#pragma unroll
+          for (int c = 0; c < 4; ++c) Mr[c] = pr == c ? 1.0 : 0.0;
+        }
+        // row pr of o = M L^-T:  L(i, kn) (i > kn);  X(i, kn) = Z^T L^-T (i < kn; its owner stored Z^T)
+        const bool used = GRAD || i > kn;  // (rows above the diagonal carry nothing without the inverse: keep them finite)
+        double* pdst = P[kn & 1];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          double v = Mr[c];
+#pragma unroll
+          for (int m = 0; m < c; ++m) v = __builtin_fma(-T[0][m], l[c][m], v);
+          v = used ? v * inv[c] : 0.0;
+          T[0][c] = v;
+          if ((tid >> 2) <= nb) pdst[(4 * pr + c) * NS_PITCH + i] = v;
+        }
+        if ((tid >> 2) == nb && pr < 2) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) (pr == 0 ? yt : ft)[4 * kn + c] = T[0][c];
         }
       }
-    }
-    __syncthreads();  // the panel of step k is published
-    if (live && (GRAD || bj > k)) {
-      double pa[4][4], pb[4][4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          pa[r][c] = P[(4 * r + c) * NS_PITCH + bi];
-          pb[r][c] = P[(4 * r + c) * NS_PITCH + bj];
-        }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          double s = T[r][c];
-#pragma unroll
-          for (int m = 0; m < 4; ++m) s = __builtin_fma(-pa[r][m], pb[c][m], s);
-          T[r][c] = s;
-        }
-      if (bi == k + 1 && bj == k + 1 && k + 1 < nb) {  // look-ahead: the next diagonal factor, behind this thread's update
-        double w[4][4];
-        const int bad = ns_factor4(T, w, pivprod);
-        if (bad && s_info == 0) s_info = 4 * (k + 1) + bad;  // (only diagonal threads write, in step order)
+#ifdef NS_PROFILE
+      { const long long t = clock64(); tpB += t - tpre; tpre = t; }
+#endif
+    } else if (kn > 0) {
+      const int p = kn - 1;
+      if (live && (GRAD || bj > p)) {
+        const double* pp = P[p & 1];
+        double pa[4][4], pb[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) Wb[(k + 1) & 1][4 * r + c] = w[r][c];
+          for (int c = 0; c < 4; ++c) {
+            pa[r][c] = pp[(4 * r + c) * NS_PITCH + bi];
+            pb[r][c] = pp[(4 * r + c) * NS_PITCH + bj];
+          }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            double sacc = T[r][c];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sacc = __builtin_fma(-pa[r][m], pb[c][m], sacc);
+            T[r][c] = sacc;
+          }
       }
+      NS_RESTART(kn)
+      NS_PUBLISH(kn + 1)
     }
+    __syncthreads();
+#ifdef NS_PROFILE
+    { const long long t = clock64(); tpA += t - tpre; tpre = t; }
+#endif
   }
-  if (live && bi == bj && bi < nb) logpart[bi] = log(pivprod);
+#ifdef NS_PROFILE
+  if (tid == 0) { a.out_scal[21] = (double)tpA; a.out_scal[22] = (double)tpB; a.out_scal[23] = (double)tpC; }
+  const long long tloop_end = clock64();
+#endif
+  if (tid == 0) s_logdet = log(pivm) + (double)pive * 0.6931471805599453;
   __syncthreads();
 
   // ---- the likelihood's scalars (k_fit_rho's expressions) --------------------------------------------------------
@@ -296,14 +430,12 @@ __global__ __launch_bounds__(NS_THREADS) void k_nll_small(const NllSmallArgs a) 
   }
   double srr = 0.0;
   if (tid < N) {
-    const double r = __builtin_fma(coef, ft[tid], yt[tid]);
-    srr = r * r;
+    const double rr = __builtin_fma(coef, ft[tid], yt[tid]);
+    srr = rr * rr;
   }
   srr = ns_block_sum(srr, red, nwaves);
   if (tid == 0) {
-    double ld = 0.0;
-    for (int b = 0; b < nb; ++b) ld += logpart[b];
-    a.out_scal[0] = ld;
+    a.out_scal[0] = s_logdet;
     a.out_scal[1] = nrm;
     a.out_scal[2] = sfy;
     a.out_scal[3] = srr;
@@ -314,55 +446,61 @@ __global__ __launch_bounds__(NS_THREADS) void k_nll_small(const NllSmallArgs a) 
   }
 
   if (GRAD) {
-    // gamma = R^-1 y - beta R^-1 1 from block row nb
+    // gamma = R^-1 y - beta R^-1 1 from block row nb; R^-1 = -T into the LDS image
     if (live && border) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) gam[4 * bj + c] = -__builtin_fma(coef, T[1][c], T[0][c]);
+    } else if (live) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Rst[(4 * r + c) * nbR + ot] = -T[r][c];
     }
     __syncthreads();
     const double s2t = a.mode == BOGP_MODE_NOISY ? a.s2t_host : (a.mode == BOGP_MODE_NOISELESS ? srr / (N - (a.estimate_trend ? 1 : 0)) : srr / N);
     const double cw = 1.0 / s2t;
-    // the thread's pairs i > j (row 4 bi + r, column 4 bj + c) of the strict lower triangle: A = cw gamma_i gamma_j - Rinv_ij
+    // the pairs i > j of the strict lower triangle, <= 4 strips a thread: A = cw gamma_i gamma_j - Rinv_ij
     double B[4][4];
+    int si[4], sj[4];
     double sd = 0.0, tr = 0.0;
-    const bool pairs = live && !border;
-    {
-      double s2[4][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+    for (int q = 0; q < 4; ++q) {
+      const int s = tid + q * nthr;
+      si[q] = -1;
+      sj[q] = 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s2[r][c] = 0.0;
-      if (pairs) {
-        for (int k = 0; k < d; ++k) {
-          const double th = a.theta[k];
-          double vi[4], vj[4];
+      for (int c = 0; c < 4; ++c) B[q][c] = 0.0;
+      if (s < 4 * nbR) {
+        const int t = s >> 2, r = s & 3;
+        const int sbi = blkmap[t] >> 8, sbj = blkmap[t] & 255;
+        const int i = 4 * sbi + r;
+        if (i < N) {
+          si[q] = i;
+          sj[q] = 4 * sbj;
+          double s2[4] = {0.0, 0.0, 0.0, 0.0};
+          const double* xi = Xs + i * dP;
+          for (int k = 0; k < d; ++k) {
+            const double th = a.theta[k], vi = xi[k];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) vi[r] = (4 * bi + r < N) ? a.X[(size_t)(4 * bi + r) * d + k] : 0.0;
+            for (int c = 0; c < 4; ++c) s2[c] += dist_term<KERNEL>(th, Xs[min(4 * sbj + c, N - 1) * dP + k] - vi);
+          }
+          const double gi = gam[i];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) vj[c] = (4 * bj + c < N) ? a.X[(size_t)(4 * bj + c) * d + k] : 0.0;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) s2[r][c] += dist_term<KERNEL>(th, vj[c] - vi[r]);
+          for (int c = 0; c < 4; ++c) {
+            const int j = 4 * sbj + c;
+            const double rinv = Rst[(4 * r + c) * nbR + t];
+            if (j < i) {
+              double r0, h;
+              ns_corr_pair<KERNEL>(s2[c], r0, h);
+              const double A = (gam[j] * gi) * cw - rinv;
+              B[q][c] = A * h;
+              sd += A * r0;
+            } else if (j == i) {
+              tr += rinv;
+            }
+          }
         }
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int i = 4 * bi + r, j = 4 * bj + c;
-          double bb = 0.0;
-          if (pairs && i > j && i < N) {
-            const double r0 = corr_profile<KERNEL>(s2[r][c]);
-            const double h = corr_dtheta_profile<KERNEL>(s2[r][c], r0);
-            const double rinv = -T[r][c];
-            const double A = __builtin_fma(gam[j] * gam[i], cw, 0.0) - rinv;
-            bb = A * h;
-            sd += A * r0;
-          }
-          if (pairs && i == j && i < N) tr += -T[r][c];
-          B[r][c] = bb;
-        }
     }
     sd = ns_block_sum(sd, red, nwaves);
     tr = ns_block_sum(tr, red, nwaves);
@@ -373,25 +511,23 @@ __global__ __launch_bounds__(NS_THREADS) void k_nll_small(const NllSmallArgs a) 
       __syncthreads();
       for (int kk = 0; kk < kn; ++kk) {
         double acc = 0.0;
-        if (pairs) {
-          double vi[4], vj[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) vi[r] = (4 * bi + r < N) ? a.X[(size_t)(4 * bi + r) * d + k0 + kk] : 0.0;
+        for (int q = 0; q < 4; ++q) {
+          if (si[q] >= 0) {
+            const double vi = Xs[si[q] * dP + k0 + kk];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) vj[c] = (4 * bj + c < N) ? a.X[(size_t)(4 * bj + c) * d + k0 + kk] : 0.0;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc += B[r][c] * (-dtheta_weight<KERNEL>(vj[c] - vi[r]));
+            for (int c = 0; c < 4; ++c)
+              acc += B[q][c] * (-dtheta_weight<KERNEL>(Xs[min(sj[q] + c, N - 1) * dP + k0 + kk] - vi));
+          }
         }
         acc = ns_wave_sum(acc);
         if ((tid & 63) == 0) redk[tid >> 6][kk] = acc;
       }
       __syncthreads();
       if (tid < kn) {
-        double s = 0.0;
-        for (int w = 0; w < nwaves; ++w) s += redk[w][tid];
-        a.out_S[k0 + tid] = s;
+        double ssum = 0.0;
+        for (int w = 0; w < nwaves; ++w) ssum += redk[w][tid];
+        a.out_S[k0 + tid] = ssum;
       }
     }
     if (tid == 0) {
@@ -400,35 +536,438 @@ __global__ __launch_bounds__(NS_THREADS) void k_nll_small(const NllSmallArgs a) 
       a.out_S[d + 2] = gg;
     }
   }
+#ifdef NS_PROFILE
+  if (tid == 0) a.out_scal[24] = (double)(clock64() - tloop_end);
+#endif
   __threadfence_system();
   __syncthreads();
   if (tid == 0) __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// =====================================================================================================================
+// 128 < N <= 252: the same in-place elimination on the matrix cores.  R comes from k_build_R (global memory), R^-1 and gamma
+// go back to global memory for k_grad_contract: the pair work (~150 instructions an entry) belongs on all CUs, the
+// factorisation chain on one.  16 x 16 tiles live in MFMA accumulators, <= 23 a wave, 6 owner waves; a step's update of a
+// tile is ONE v_mfma_f64_16x16x4_f64, D -= P_I P_J^T, the two operands being 64 consecutive doubles of the panel each.
+// D[i][j] sits in lane 16 (i % 4) + j, component i / 4: component v of lane l is element (l / 16, l % 4) of the 4 x 4
+// sub-block (4 I + v, 4 J + (l % 16) / 4) -- the publish / reset events of the 4 x 4 scheme above are per-lane predicates.
+// Wave 0: the panel wave (lane i = block row i, lane nb = the [y; 1] rows); wave 1: block row nb, one 4 x 4 block a lane.
+// =====================================================================================================================
+namespace {
+constexpr int MD_PITCH = 17;    // doubles per panel block in LDS (16 + 1: two-way conflicts at worst for the per-block writers)
+constexpr int MD_SLOTS = 23;    // tiles per owner wave: 16 * 17 / 2 = 136 tiles over 6 waves; 2 waves a SIMD = 256 registers a lane
+constexpr int MD_OWNERS = 6;
+constexpr int MD_WAVES = 8;       // wave w runs on SIMD w % 4: 0 = panel, 4 = block row nb (SIMD 0 to themselves); the other six own tiles
+constexpr int MD_THREADS = 64 * MD_WAVES;
+constexpr int MD_MAXNB = 63;    // N <= 252: block rows 0 .. nb fit the 64 lanes of the panel wave
+
+typedef double md4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void md_mfma(double a, double b, md4& c) {
+  asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+}  // namespace
+
+// The three roles run their own copy of the phase loop (the same number of barriers in each): the 184 accumulator registers of
+// an owner, the ~120 of the panel wave's factor + trsm and the block of wave 1 are then never live together.
+//
+// Software pipeline, ONE barrier a step: in phase p the owners apply update p (panel P_p) while the panel wave already builds
+// P_{p+1}.  For that the blocks of column / row p + 1 were copied to `Raw` at the end of phase p - 1, in their state after update
+// p - 1, and the panel wave applies update p to its copy itself (lane i: M -= P_p[i] P_p[p + 1]^T, P_p[i] being its own output
+// of the phase before).  The owners' registers of those blocks restart from zero at the END of phase p (the update the MFMA
+// just added to them belongs to the old role).  `P2` and `Raw` are double-buffered by the parity of the step they belong to.
+template <bool GRAD>
+__global__ __launch_bounds__(MD_THREADS) void k_spd_mid(const SpdMidArgs a) {
+  __shared__ double P2[2][(MD_MAXNB + 1) * MD_PITCH];
+  __shared__ double Raw[2][(MD_MAXNB + 1) * MD_PITCH];
+  __shared__ double yt[4 * (MD_MAXNB + 1)], ft[4 * (MD_MAXNB + 1)], gy[4 * (MD_MAXNB + 1)], g1[4 * (MD_MAXNB + 1)];
+  __shared__ double red[MD_THREADS / 64];
+  __shared__ int tileTab[MD_OWNERS][MD_SLOTS];   // (I << 8) | J of an owner's slot, -1: none
+  __shared__ int maskTab[MD_OWNERS][MD_SLOTS + 2];  // slots of an owner holding a tile of tile-column or tile-row K
+  __shared__ double s_logdet;
+  __shared__ int s_info;
+
+  const int N = a.N, nb = (N + 3) / 4, NB16 = (N + 15) / 16, ntiles = NB16 * (NB16 + 1) / 2;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = tid & 63;
+  const int nwaves = MD_THREADS / 64;
+  for (int e = tid; e < 2 * (MD_MAXNB + 1) * MD_PITCH; e += MD_THREADS) {
+    (&P2[0][0])[e] = 0.0;
+    (&Raw[0][0])[e] = 0.0;
+  }
+  if (tid == 0) s_info = 0;
+  if (tid < MD_THREADS / 64) red[tid] = 0.0;
+  const bool is_owner = (wave & 3) != 0;
+  const int ow = wave - 1 - (wave > 4 ? 1 : 0);  // 0 .. 5
+  auto tile_of = [&](int t) {  // tile t, row-major over the lower triangle -> (I << 8) | J
+    int I = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+    while ((I + 1) * (I + 2) / 2 <= t) ++I;
+    while (I * (I + 1) / 2 > t) --I;
+    return (I << 8) | (t - I * (I + 1) / 2);
+  };
+  if (is_owner) {
+    if (lane < MD_SLOTS) {
+      const int t = ow + MD_OWNERS * lane;
+      tileTab[ow][lane] = t < ntiles ? tile_of(t) : -1;
+    }
+    if (lane < MD_SLOTS + 2) {  // K = lane
+      int m = 0;
+      for (int sl = 0; sl < MD_SLOTS; ++sl) {
+        const int t = ow + MD_OWNERS * sl;
+        if (t < ntiles) {
+          const int ij = tile_of(t);
+          if ((ij >> 8) == lane || (ij & 255) == lane) m |= 1 << sl;
+        }
+      }
+      maskTab[ow][lane] = m;
+    }
+  }
+  __syncthreads();  // (the zeroed LDS, the tables)
+  // (SIMD 0 is left to the panel wave and the light wave 4: the factor chain sets the pace of a step)
+
+  if (wave == 0) {
+    // ================= the panel wave: lane i = block row i of the panel (lane nb: the [y; 1] rows) =================
+    __builtin_amdgcn_s_setprio(3);
+    double pivm = 1.0;  // prod(l_cc) = pivm 2^pive
+    int pive = 0;
+    const int i = min(lane, nb);
+    double o[4][4];
+#ifdef NS_PROFILE
+    long long tq = clock64(), tpan = 0, twait = 0;
+#endif
+    __syncthreads();  // raw(0), raw(1) are published
+    for (int kn = 0; kn < nb; ++kn) {  // P_kn: before the loop's first barrier for kn = 0, in phase kn - 1 otherwise
+      double D[4][4], w[4][4], M[4][4];
+      const double* rawb = Raw[kn & 1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) M[r][c] = rawb[i * MD_PITCH + 4 * r + c];
+      if (kn > 0) {  // update kn - 1 of the copy: M -= P[i] P[kn]^T
+        const double* q = P2[(kn - 1) & 1] + kn * MD_PITCH;
+        double Q[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) Q[r][c] = q[4 * r + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            double sacc = M[r][c];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sacc = __builtin_fma(-o[r][m], Q[c][m], sacc);
+            M[r][c] = sacc;
+          }
+      }
+      // the diagonal block is lane kn's
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+          const int lo = __builtin_amdgcn_readlane(__double2loint(M[r][c]), kn);
+          const int hi = __builtin_amdgcn_readlane(__double2hiint(M[r][c]), kn);
+          D[r][c] = __hiloint2double(hi, lo);
+        }
+      double prod4 = 1.0;
+      const int bad = ns_factor4(D, w, prod4);
+      if (lane == 0) {
+        if (bad && s_info == 0) s_info = 4 * kn + bad;
+        int e2;
+        pivm = frexp(pivm * prod4, &e2);
+        pive += e2;
+      }
+      if (i == kn) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) M[r][c] = r == c ? 1.0 : 0.0;
+      }
+      const bool used = GRAD || i > kn;  // (rows above the diagonal carry nothing without the inverse: keep them finite)
+      double* pdst = P2[kn & 1] + lane * MD_PITCH;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int m = 0; m <= c; ++m) sacc = __builtin_fma(M[r][m], w[c][m], sacc);
+          sacc = used ? sacc : 0.0;
+          o[r][c] = sacc;
+          if (lane <= nb) pdst[4 * r + c] = sacc;
+          if (lane == nb && r == 0) yt[4 * kn + c] = sacc;
+          if (lane == nb && r == 1) ft[4 * kn + c] = sacc;
+        }
+#ifdef NS_PROFILE
+      { const long long t = clock64(); tpan += t - tq; tq = t; }
+#endif
+      __syncthreads();  // P_kn is published (and the raw blocks of step kn + 1)
+#ifdef NS_PROFILE
+      { const long long t = clock64(); twait += t - tq; tq = t; }
+#endif
+    }
+    __syncthreads();  // (phase nb - 1: the owners' last update)
+#ifdef NS_PROFILE
+    if (lane == 0) { a.scal[21] = (double)twait; a.scal[22] = (double)tpan; }
+#endif
+    if (lane == 0) s_logdet = log(pivm) + (double)pive * 0.6931471805599453;
+  } else if (wave == 4) {
+    // ================= block row nb: block (nb, lane) of [y; 1], 4 x 4 on the vector ALU ==========================
+    double T[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double v = 0.0;
+        if (lane < nb && 4 * lane + c < N) v = r == 0 ? a.y[4 * lane + c] : (r == 1 ? 1.0 : 0.0);
+        T[r][c] = v;
+      }
+    auto events = [&](int z, int q) {  // restart the block of column z; copy out the block of column q
+      if (GRAD && lane == z) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) T[r][c] = 0.0;
+      }
+      if (lane == q && q < nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) Raw[q & 1][nb * MD_PITCH + 4 * r + c] = T[r][c];
+      }
+    };
+    events(-1, 0);
+    events(0, 1);
+    __syncthreads();
+    __syncthreads();
+    for (int p = 0; p < nb; ++p) {
+      if (lane < nb && (GRAD || lane > p)) {
+        const double* pp = P2[p & 1];
+        double pa[4][4], pb[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            pa[r][c] = pp[nb * MD_PITCH + 4 * r + c];
+            pb[r][c] = pp[lane * MD_PITCH + 4 * r + c];
+          }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            double sacc = T[r][c];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sacc = __builtin_fma(-pa[r][m], pb[c][m], sacc);
+            T[r][c] = sacc;
+          }
+      }
+      events(p + 1, p + 2);
+      __syncthreads();
+    }
+    if (GRAD && lane < nb) {  // -(R^-1 y), -(R^-1 1)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        gy[4 * lane + c] = T[0][c];
+        g1[4 * lane + c] = T[1][c];
+      }
+    }
+  } else {
+    // ================= owners: tiles t = ow + 6 s -> (I, J), row-major over the lower triangle ======================
+    const int lr = lane >> 4, lcb = (lane & 15) >> 2, lc = lane & 3;  // the lane's element (lr, lc) of sub-block column lcb
+    int tIJ[MD_SLOTS];  // (I << 8) | J, -1: no tile
+    md4 acc[MD_SLOTS];
+#pragma unroll
+    for (int s = 0; s < MD_SLOTS; ++s) {
+      tIJ[s] = __builtin_amdgcn_readfirstlane(tileTab[ow][s]);
+      acc[s] = (md4){0.0, 0.0, 0.0, 0.0};
+      if (tIJ[s] >= 0) {
+        const int tI = tIJ[s] >> 8, tJ = tIJ[s] & 255;
+        const int col = 16 * tJ + (lane & 15);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * tI + 4 * v + lr;
+          double x;
+          if (row >= N || col >= N) x = row == col ? 1.0 : 0.0;  // identity padding
+          else x = row >= col ? a.R[(size_t)col * a.ldr + row] : a.R[(size_t)row * a.ldr + col];
+          acc[s][v] = -x;  // the accumulators hold the NEGATED state: acc += P_I P_J^T needs no operand negation
+        }
+      }
+    }
+    // Restart (GRAD) the blocks of column z and row z; copy out those of column q (as they are) and row q (transposed).  Only the
+    // few slots of this wave with a tile in tile-column / tile-row z / 4 or q / 4 do anything (maskTab: one bit test a slot).
+    auto events = [&](int z, int q) {
+      const int Kz = max(z, 0) >> 2;
+      const int hit = __builtin_amdgcn_readfirstlane(maskTab[ow][Kz] | maskTab[ow][Kz + 1]);
+      if (hit == 0) return;
+      double* rawb = Raw[q & 1];
+      const int zK = z >> 2, zv = z & 3, qK = q >> 2, qv = q & 3;
+      const bool lane_zc = lcb == zv, lane_qc = lcb == qv;
+#pragma unroll
+      for (int s = 0; s < MD_SLOTS; ++s) {
+        if (!(hit & (1 << s))) continue;
+        const int tI = tIJ[s] >> 8, tJ = tIJ[s] & 255;
+        if (GRAD && z >= 0) {
+          if (tJ == zK) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[s][v] = (lane_zc && 4 * tI + v >= z) ? 0.0 : acc[s][v];
+          }
+          if (tI == zK) {
+            const bool zr = 4 * tJ + lcb < z;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[s][v] = (zr && v == zv) ? 0.0 : acc[s][v];
+          }
+        }
+        if (q < nb) {
+          if (tJ == qK && lane_qc) {  // column q: sub-blocks (4 I + v, q), 4 I + v >= q
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int bi = 4 * tI + v;
+              if (bi >= q && bi < nb) rawb[bi * MD_PITCH + 4 * lr + lc] = -acc[s][v];
+            }
+          }
+          if (GRAD && tI == qK) {  // row q: sub-blocks (q, bj), bj < q, transposed
+            const int bj = 4 * tJ + lcb;
+            if (bj < q) {
+              const double x = qv == 0 ? acc[s][0] : (qv == 1 ? acc[s][1] : (qv == 2 ? acc[s][2] : acc[s][3]));
+              rawb[bj * MD_PITCH + 4 * lc + lr] = -x;
+            }
+          }
+        }
+      }
+    };
+    events(-1, 0);
+    events(0, 1);
+    __syncthreads();
+    __syncthreads();
+    const int offA = ((lane & 15) >> 2) * MD_PITCH + 4 * (lane & 3) + (lane >> 4);
+    static_assert(MD_SLOTS == 23, "the hazard guards below name 23 accumulators");
+#define MD_ALL_ACC "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),       \
+                   "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]), \
+                   "+v"(acc[16]), "+v"(acc[17]), "+v"(acc[18]), "+v"(acc[19]), "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[22])
+    for (int p = 0; p < nb; ++p) {
+      const double* pp = P2[p & 1] + offA;
+      // (VALU writes to the accumulators -- the restarts of events() -- must have retired before an MFMA reads them)
+      asm volatile("s_nop 7\n\ts_nop 7" : MD_ALL_ACC);
+      // operands one slot ahead of the MFMA that consumes them
+      double pa[2], pb[2];
+      pa[0] = pp[4 * max(tIJ[0] >> 8, 0) * MD_PITCH];
+      pb[0] = pp[4 * (max(tIJ[0], 0) & 255) * MD_PITCH];
+#pragma unroll
+      for (int s = 0; s < MD_SLOTS; ++s) {
+        if (s + 1 < MD_SLOTS) {
+          pa[(s + 1) & 1] = pp[4 * max(tIJ[s + 1] >> 8, 0) * MD_PITCH];
+          pb[(s + 1) & 1] = pp[4 * (max(tIJ[s + 1], 0) & 255) * MD_PITCH];
+        }
+        if (tIJ[s] >= 0 && (GRAD || 4 * (tIJ[s] & 255) + 3 > p)) md_mfma(pa[s & 1], pb[s & 1], acc[s]);
+      }
+      // the drain names the accumulators as in/out operands so that no read of them can be scheduled above it
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : MD_ALL_ACC);
+      events(p + 1, p + 2);
+      __syncthreads();
+    }
+#undef MD_ALL_ACC
+    if (GRAD) {  // R^-1 = -S, lower triangle, column-major
+#pragma unroll
+      for (int s = 0; s < MD_SLOTS; ++s) {
+        if (tIJ[s] < 0) continue;
+        const int tI = tIJ[s] >> 8, tJ = tIJ[s] & 255;
+        const int col = 16 * tJ + (lane & 15);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * tI + 4 * v + lr;
+          if (row < N && col <= row) a.Rinv[(size_t)col * a.ldi + row] = acc[s][v];  // (negated state: -S = R^-1)
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- the likelihood's scalars (k_fit_rho's expressions) --------------------------------------------------------
+  double sff = 0.0, sfy = 0.0;
+  if (tid < N) {
+    const double f = ft[tid];
+    sff = f * f;
+    sfy = f * yt[tid];
+  }
+  sff = ns_block_sum(sff, red, nwaves);
+  sfy = ns_block_sum(sfy, red, nwaves);
+  const double nrm = sqrt(sff);
+  double coef;
+  if (a.estimate_trend) {
+    const double G = -nrm, qty = sfy / G;
+    coef = -(qty / G);
+  } else {
+    coef = -a.beta;
+  }
+  double srr = 0.0;
+  if (tid < N) {
+    const double rr = __builtin_fma(coef, ft[tid], yt[tid]);
+    srr = rr * rr;
+  }
+  srr = ns_block_sum(srr, red, nwaves);
+  if (tid == 0) {
+    a.scal[0] = s_logdet;
+    a.scal[1] = nrm;
+    a.scal[2] = sfy;
+    a.scal[3] = srr;
+    double iw = 0.0;
+    int info = s_info;
+    memcpy(&iw, &info, sizeof(info));
+    a.scal[62] = iw;
+    if (GRAD) {  // k_grad_coef's weights for one target
+      const double s2t = a.mode == BOGP_MODE_NOISY ? a.s2t_host : (a.mode == BOGP_MODE_NOISELESS ? srr / (N - (a.estimate_trend ? 1 : 0)) : srr / N);
+      a.coef[0] = 1.0 / s2t;
+      a.coef[8] = 1.0 / s2t;
+    }
+  }
+  if (GRAD && tid < N) a.gamma[tid] = -__builtin_fma(coef, g1[tid], gy[tid]);  // gamma = R^-1 y - beta R^-1 1
+}
+
+int spd_mid_max_n() { return 4 * MD_MAXNB; }
+hipError_t launch_spd_mid(bool grad, const SpdMidArgs& a, hipStream_t st) {
+  if (grad) hipLaunchKernelGGL((k_spd_mid<true>), dim3(1), MD_THREADS, 0, st, a);
+  else hipLaunchKernelGGL((k_spd_mid<false>), dim3(1), MD_THREADS, 0, st, a);
+  return hipGetLastError();
+}
+
 int nll_small_max_n() { return NS_BS * NS_MAXNB; }
+
+size_t nll_small_lds_bytes(int N, int d) {
+  const int nb = (N + NS_BS - 1) / NS_BS;
+  return ((((size_t)N * (d | 1) + 1) & ~(size_t)1) + (size_t)16 * (nb * (nb + 1) / 2)) * sizeof(double);
+}
+
+template <typename K>
+static hipError_t ns_launch(K kern, int block, size_t lds, const NllSmallArgs& a, hipStream_t st) {
+  if (lds > 32768) {  // (above the default limit of dynamic LDS: raise it for this kernel; once would do, the call is cheap)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(1), block, lds, st, a);
+  return hipGetLastError();
+}
 
 hipError_t launch_nll_small(int kernel, bool grad, const NllSmallArgs& a, hipStream_t st) {
   const int nb = (a.N + NS_BS - 1) / NS_BS;
-  const int nthreads = (nb + 1) * (nb + 2) / 2 - 1;
-  const int block = ((nthreads + 63) / 64) * 64;
+  const int nown = (nb + 1) * (nb + 2) / 2 - 1;
+  const int block = ((4 * (nb + 1) + 63) / 64) * 64 + ((nown + 63) / 64) * 64;  // the panel waves + the owners
+  const size_t lds = nll_small_lds_bytes(a.N, a.d);
   if (grad) {
     switch (kernel) {
-      case BOGP_KERNEL_SE: hipLaunchKernelGGL((k_nll_small<BOGP_KERNEL_SE, true>), dim3(1), block, 0, st, a); break;
-      case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL((k_nll_small<BOGP_KERNEL_MATERN12, true>), dim3(1), block, 0, st, a); break;
-      case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL((k_nll_small<BOGP_KERNEL_MATERN32, true>), dim3(1), block, 0, st, a); break;
-      case BOGP_KERNEL_ABSEXP: hipLaunchKernelGGL((k_nll_small<BOGP_KERNEL_ABSEXP, true>), dim3(1), block, 0, st, a); break;
-      case BOGP_KERNEL_MATERN52: hipLaunchKernelGGL((k_nll_small<BOGP_KERNEL_MATERN52, true>), dim3(1), block, 0, st, a); break;
+      case BOGP_KERNEL_SE: return ns_launch(k_nll_small<BOGP_KERNEL_SE, true>, block, lds, a, st);
+      case BOGP_KERNEL_MATERN12: return ns_launch(k_nll_small<BOGP_KERNEL_MATERN12, true>, block, lds, a, st);
+      case BOGP_KERNEL_MATERN32: return ns_launch(k_nll_small<BOGP_KERNEL_MATERN32, true>, block, lds, a, st);
+      case BOGP_KERNEL_ABSEXP: return ns_launch(k_nll_small<BOGP_KERNEL_ABSEXP, true>, block, lds, a, st);
+      case BOGP_KERNEL_MATERN52: return ns_launch(k_nll_small<BOGP_KERNEL_MATERN52, true>, block, lds, a, st);
       default: return hipErrorInvalidValue;  // cubic / generalized_exponential have no theta-derivative
     }
   } else {
     switch (kernel) {
-      case BOGP_KERNEL_SE: hipLaunchKernelGGL((k_nll_small<BOGP_KERNEL_SE, false>), dim3(1), block, 0, st, a); break;
-      case BOGP_KERNEL_MATERN12: hipLaunchKernelGGL((k_nll_small<BOGP_KERNEL_MATERN12, false>), dim3(1), block, 0, st, a); break;
-      case BOGP_KERNEL_MATERN32: hipLaunchKernelGGL((k_nll_small<BOGP_KERNEL_MATERN32, false>), dim3(1), block, 0, st, a); break;
-      case BOGP_KERNEL_ABSEXP: hipLaunchKernelGGL((k_nll_small<BOGP_KERNEL_ABSEXP, false>), dim3(1), block, 0, st, a); break;
-      case BOGP_KERNEL_MATERN52: hipLaunchKernelGGL((k_nll_small<BOGP_KERNEL_MATERN52, false>), dim3(1), block, 0, st, a); break;
-      case BOGP_KERNEL_CUBIC: hipLaunchKernelGGL((k_nll_small<BOGP_KERNEL_CUBIC, false>), dim3(1), block, 0, st, a); break;
-      case BOGP_KERNEL_GENEXP: hipLaunchKernelGGL((k_nll_small<BOGP_KERNEL_GENEXP, false>), dim3(1), block, 0, st, a); break;
+      case BOGP_KERNEL_SE: return ns_launch(k_nll_small<BOGP_KERNEL_SE, false>, block, lds, a, st);
+      case BOGP_KERNEL_MATERN12: return ns_launch(k_nll_small<BOGP_KERNEL_MATERN12, false>, block, lds, a, st);
+      case BOGP_KERNEL_MATERN32: return ns_launch(k_nll_small<BOGP_KERNEL_MATERN32, false>, block, lds, a, st);
+      case BOGP_KERNEL_ABSEXP: return ns_launch(k_nll_small<BOGP_KERNEL_ABSEXP, false>, block, lds, a, st);
+      case BOGP_KERNEL_MATERN52: return ns_launch(k_nll_small<BOGP_KERNEL_MATERN52, false>, block, lds, a, st);
+      case BOGP_KERNEL_CUBIC: return ns_launch(k_nll_small<BOGP_KERNEL_CUBIC, false>, block, lds, a, st);
+      case BOGP_KERNEL_GENEXP: return ns_launch(k_nll_small<BOGP_KERNEL_GENEXP, false>, block, lds, a, st);
       default: return hipErrorInvalidValue;
     }
   }

@@ -1,4 +1,5 @@
-"""The one-launch likelihood of a small training set (csrc/kernels_nllsmall.hip: N <= 128, constant trend, one target) against
+"""The one-launch likelihood of a small training set (csrc/kernels_nllsmall.hip: N <= 128, constant trend, one target) and the
+one-workgroup factor + inverse on the matrix cores for 128 < N <= 252 (k_spd_mid, same file) against
 (i) the general multi-kernel path of the same library (BOGP_NLL_FUSED=0) and (ii) the CPU oracle (oracle/gp_oracle.py, the
 restatement of gpr.py:772-808 / :931-1038) -- every correlation family, all three estimation modes, ARD and isotropic theta,
 estimated and fixed trend coefficient, sizes on every side of the 4 x 4 register blocks, a non-positive-definite matrix.
@@ -30,6 +31,14 @@ def general_path(fn):
         del os.environ["BOGP_NLL_FUSED"]
 
 
+@pytest.fixture(autouse=True)
+def mid_path_on():
+    """k_spd_mid (128 < N <= 252) is opt-in -- it is slower than the general path it would replace -- and tested all the same."""
+    os.environ["BOGP_NLL_MID"] = "1"
+    yield
+    del os.environ["BOGP_NLL_MID"]
+
+
 def make(N, d, seed):
     rng = np.random.default_rng(seed)
     X = rng.uniform(-3, 3, size=(N, d))
@@ -40,7 +49,9 @@ def make(N, d, seed):
 
 
 GRAD_KERNELS = [_lib.KERNEL_SE, _lib.KERNEL_MATERN12, _lib.KERNEL_MATERN32, _lib.KERNEL_MATERN52, _lib.KERNEL_ABSEXP]
-SIZES = [1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128]
+SIZES = [1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128,   # one launch (k_nll_small)
+         129, 131, 144, 145, 177, 200, 240, 249, 252,                             # k_build_R + k_spd_mid + the gradient kernels
+         253]                                                                     # the general path itself
 
 
 def par_of(mode, d, iso, rng):
@@ -145,7 +156,7 @@ def test_not_positive_definite_is_reported(eng):
 def test_against_the_oracle(eng):
     from oracle import gp_oracle
 
-    for N, d, seed in ((12, 2, 0), (50, 5, 1), (128, 10, 2)):
+    for N, d, seed in ((12, 2, 0), (50, 5, 1), (128, 10, 2), (150, 6, 3), (252, 12, 4)):
         X, y = make(N, d, seed)
         eng.set_train(X, y)
         theta = np.random.default_rng(seed).uniform(0.05, 0.4, size=d)
