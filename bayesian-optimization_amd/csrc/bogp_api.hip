@@ -431,10 +431,10 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   hipStream_t st = h->stream;
   HIPCHK(h, hipSetDevice(h->device));
   const bool fused_ok = fz && trend == BOGP_TREND_CONSTANT && h->n_t == 1 && !(getenv("BOGP_NLL_FUSED") && atoi(getenv("BOGP_NLL_FUSED")) == 0);
-  const bool mid = fused_ok && N > nll_small_max_n() && N <= spd_mid_max_n() && (!fz->want_grad || pend) &&
+  const bool mid = fused_ok && !nll_small_fits(N, d) && N > 128 && N <= spd_mid_max_n() && (!fz->want_grad || pend) &&
                    (getenv("BOGP_NLL_MID") && atoi(getenv("BOGP_NLL_MID")) != 0);  // opt-in: measured SLOWER than the general path
                                                                                      // (profiles/r03_nll_small.txt), kept for the record
-  if (fused_ok && N <= nll_small_max_n() && d <= 64) {
+  if (fused_ok && nll_small_fits(N, d)) {
     NllSmallArgs na;
     na.X = h->dX; na.y = h->dy_base; na.N = N; na.d = d;
     for (int k = 0; k < d; ++k) na.theta[k] = th[k];

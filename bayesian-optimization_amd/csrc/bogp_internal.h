@@ -209,6 +209,7 @@ struct NllSmallArgs {
   unsigned long long seq;
 };
 int nll_small_max_n();
+bool nll_small_fits(int N, int d);
 // 128 < N <= 252: factor + inverse + the likelihood's scalars + gamma of a matrix k_build_R left in global memory, one workgroup
 struct SpdMidArgs {
   const double* R;  // column-major, lower triangle (diagonal 64-tiles complete), leading dimension ldr

@@ -28,9 +28,10 @@ namespace bogp {
 namespace {
 
 constexpr int NS_BS = 4;           // block size
-constexpr int NS_MAXNB = 32;       // N <= 128
+constexpr int NS_MAXNB = 39;       // N <= 156 (the 1024-thread instantiation; N <= 128 runs the 768-thread one)
 constexpr int NS_PITCH = NS_MAXNB + 2;
-constexpr int NS_THREADS = 768;    // 4 (nb + 1) = 132 panel threads (3 waves) + (nb + 1)(nb + 2) / 2 - 1 = 560 owners (9 waves) at nb = 32
+constexpr int NS_THREADS = 1024;   // 4 (nb + 1) panel threads (3 waves) + (nb + 1)(nb + 2) / 2 - 1 owners: 132 + 560 at nb = 32, 160 + 819 at nb = 39
+constexpr int NS_THREADS_128 = 768;  // N <= 128: 12 waves = 3 a SIMD = 168 registers a lane; 16 waves leave 128
 constexpr int NS_WAVES = NS_THREADS / 64;
 
 __device__ __forceinline__ double ns_wave_sum(double v) {
@@ -179,8 +180,8 @@ __device__ __forceinline__ void ns_corr_pair(double s2, double& r0, double& h) {
 // The pair work before and after the loop (the correlation matrix; the gradient contractions) is spread over ALL threads in
 // strips of 1 x 4 entries through an LDS image of the blocks, whatever the number of owners (15 at N = 16): it is bound by the
 // exp / sqrt of each pair, ~100 instructions an entry.
-template <int KERNEL, bool GRAD>
-__global__ __launch_bounds__(NS_THREADS) void k_nll_small(const NllSmallArgs a) {
+template <int KERNEL, bool GRAD, int TMAX>
+__global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
   extern __shared__ double dyn[];      // Xs[N][dP] | Rst[16][nbR]: the blocks of R, later of R^-1, element-major
   __shared__ double P[2][16 * NS_PITCH];  // P[step & 1][e * NS_PITCH + i]: element e = 4 r + c of block row i's panel block
   __shared__ double Raw[2][16 * NS_PITCH];
@@ -928,7 +929,15 @@ hipError_t launch_spd_mid(bool grad, const SpdMidArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+size_t nll_small_lds_bytes(int N, int d);
 int nll_small_max_n() { return NS_BS * NS_MAXNB; }
+// one workgroup: <= 1024 threads, <= 160 KB of LDS (~36 KB static + X and the image of the blocks)
+bool nll_small_fits(int N, int d) {
+  if (N > NS_BS * NS_MAXNB || d > 64) return false;
+  const int nb = (N + NS_BS - 1) / NS_BS;
+  const int block = ((4 * (nb + 1) + 63) / 64) * 64 + (((nb + 1) * (nb + 2) / 2 - 1 + 63) / 64) * 64;
+  return block <= NS_THREADS && nll_small_lds_bytes(N, d) + 36 * 1024 <= 160 * 1024;
+}
 
 size_t nll_small_lds_bytes(int N, int d) {
   const int nb = (N + NS_BS - 1) / NS_BS;
@@ -937,7 +946,7 @@ size_t nll_small_lds_bytes(int N, int d) {
 
 template <typename K>
 static hipError_t ns_launch(K kern, int block, size_t lds, const NllSmallArgs& a, hipStream_t st) {
-  if (lds > 32768) {  // (above the default limit of dynamic LDS: raise it for this kernel; once would do, the call is cheap)
+  if (lds > 24576) {  // (static + dynamic above the default 64 KB: raise it for this kernel; once would do, the call is cheap)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
@@ -950,28 +959,31 @@ hipError_t launch_nll_small(int kernel, bool grad, const NllSmallArgs& a, hipStr
   const int nown = (nb + 1) * (nb + 2) / 2 - 1;
   const int block = ((4 * (nb + 1) + 63) / 64) * 64 + ((nown + 63) / 64) * 64;  // the panel waves + the owners
   const size_t lds = nll_small_lds_bytes(a.N, a.d);
+#define NS_GO(K, G) (block <= NS_THREADS_128 ? ns_launch(k_nll_small<K, G, NS_THREADS_128>, block, lds, a, st) : ns_launch(k_nll_small<K, G, NS_THREADS>, block, lds, a, st))
+  if (block > NS_THREADS || lds + 36 * 1024 > 160 * 1024) return hipErrorInvalidValue;  // (nll_small_fits() said otherwise)
   if (grad) {
     switch (kernel) {
-      case BOGP_KERNEL_SE: return ns_launch(k_nll_small<BOGP_KERNEL_SE, true>, block, lds, a, st);
-      case BOGP_KERNEL_MATERN12: return ns_launch(k_nll_small<BOGP_KERNEL_MATERN12, true>, block, lds, a, st);
-      case BOGP_KERNEL_MATERN32: return ns_launch(k_nll_small<BOGP_KERNEL_MATERN32, true>, block, lds, a, st);
-      case BOGP_KERNEL_ABSEXP: return ns_launch(k_nll_small<BOGP_KERNEL_ABSEXP, true>, block, lds, a, st);
-      case BOGP_KERNEL_MATERN52: return ns_launch(k_nll_small<BOGP_KERNEL_MATERN52, true>, block, lds, a, st);
+      case BOGP_KERNEL_SE: return NS_GO(BOGP_KERNEL_SE, true);
+      case BOGP_KERNEL_MATERN12: return NS_GO(BOGP_KERNEL_MATERN12, true);
+      case BOGP_KERNEL_MATERN32: return NS_GO(BOGP_KERNEL_MATERN32, true);
+      case BOGP_KERNEL_ABSEXP: return NS_GO(BOGP_KERNEL_ABSEXP, true);
+      case BOGP_KERNEL_MATERN52: return NS_GO(BOGP_KERNEL_MATERN52, true);
       default: return hipErrorInvalidValue;  // cubic / generalized_exponential have no theta-derivative
     }
   } else {
     switch (kernel) {
-      case BOGP_KERNEL_SE: return ns_launch(k_nll_small<BOGP_KERNEL_SE, false>, block, lds, a, st);
-      case BOGP_KERNEL_MATERN12: return ns_launch(k_nll_small<BOGP_KERNEL_MATERN12, false>, block, lds, a, st);
-      case BOGP_KERNEL_MATERN32: return ns_launch(k_nll_small<BOGP_KERNEL_MATERN32, false>, block, lds, a, st);
-      case BOGP_KERNEL_ABSEXP: return ns_launch(k_nll_small<BOGP_KERNEL_ABSEXP, false>, block, lds, a, st);
-      case BOGP_KERNEL_MATERN52: return ns_launch(k_nll_small<BOGP_KERNEL_MATERN52, false>, block, lds, a, st);
-      case BOGP_KERNEL_CUBIC: return ns_launch(k_nll_small<BOGP_KERNEL_CUBIC, false>, block, lds, a, st);
-      case BOGP_KERNEL_GENEXP: return ns_launch(k_nll_small<BOGP_KERNEL_GENEXP, false>, block, lds, a, st);
+      case BOGP_KERNEL_SE: return NS_GO(BOGP_KERNEL_SE, false);
+      case BOGP_KERNEL_MATERN12: return NS_GO(BOGP_KERNEL_MATERN12, false);
+      case BOGP_KERNEL_MATERN32: return NS_GO(BOGP_KERNEL_MATERN32, false);
+      case BOGP_KERNEL_ABSEXP: return NS_GO(BOGP_KERNEL_ABSEXP, false);
+      case BOGP_KERNEL_MATERN52: return NS_GO(BOGP_KERNEL_MATERN52, false);
+      case BOGP_KERNEL_CUBIC: return NS_GO(BOGP_KERNEL_CUBIC, false);
+      case BOGP_KERNEL_GENEXP: return NS_GO(BOGP_KERNEL_GENEXP, false);
       default: return hipErrorInvalidValue;
     }
   }
   return hipGetLastError();
 }
+#undef NS_GO
 
 }  // namespace bogp

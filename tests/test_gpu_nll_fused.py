@@ -1,5 +1,5 @@
-"""The one-launch likelihood of a small training set (csrc/kernels_nllsmall.hip: N <= 128, constant trend, one target) and the
-one-workgroup factor + inverse on the matrix cores for 128 < N <= 252 (k_spd_mid, same file) against
+"""The one-launch likelihood of a small training set (csrc/kernels_nllsmall.hip: N <= 156, constant trend, one target) and the
+one-workgroup factor + inverse on the matrix cores for N <= 252 (k_spd_mid, same file, opt-in) against
 (i) the general multi-kernel path of the same library (BOGP_NLL_FUSED=0) and (ii) the CPU oracle (oracle/gp_oracle.py, the
 restatement of gpr.py:772-808 / :931-1038) -- every correlation family, all three estimation modes, ARD and isotropic theta,
 estimated and fixed trend coefficient, sizes on every side of the 4 x 4 register blocks, a non-positive-definite matrix.
@@ -49,8 +49,9 @@ def make(N, d, seed):
 
 
 GRAD_KERNELS = [_lib.KERNEL_SE, _lib.KERNEL_MATERN12, _lib.KERNEL_MATERN32, _lib.KERNEL_MATERN52, _lib.KERNEL_ABSEXP]
-SIZES = [1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128,   # one launch (k_nll_small)
-         129, 131, 144, 145, 177, 200, 240, 249, 252,                             # k_build_R + k_spd_mid + the gradient kernels
+SIZES = [1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128,   # one launch (k_nll_small, 768 threads)
+         129, 131, 144, 145, 153, 156,                                            # one launch (k_nll_small, 1024 threads)
+         157, 177, 200, 240, 249, 252,                                            # k_build_R + k_spd_mid + the gradient kernels (opt-in)
          253]                                                                     # the general path itself
 
 
@@ -167,6 +168,16 @@ def test_against_the_oracle(eng):
         assert l == pytest.approx(lo, rel=1e-9)
         go = np.asarray(go).ravel()
         assert np.max(np.abs(g - go)) <= 1e-6 * np.max(np.abs(go))
+
+
+def test_large_d_falls_back_when_the_workgroup_would_not_fit(eng):
+    """N = 150, d = 40: X + the image of the blocks exceed the LDS of one CU -- the evaluation takes the general path, same numbers."""
+    X, y = make(150, 40, 11)
+    eng.set_train(X, y)
+    par = np.r_[np.full(40, 0.02), 0.9]
+    got = eng.nll(_lib.KERNEL_MATERN32, _lib.MODE_NOISY, par, 1e-4, True, 0.0, eval_grad=True)
+    want = general_path(lambda: eng.nll(_lib.KERNEL_MATERN32, _lib.MODE_NOISY, par, 1e-4, True, 0.0, eval_grad=True))
+    check(got, want, 1e3)
 
 
 def test_commit_after_a_fused_evaluation(eng):

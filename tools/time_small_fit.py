@@ -13,7 +13,7 @@ from bogp import _lib  # noqa: E402
 
 def main():
     eng = _lib.Engine(0)
-    for N, d in ((16, 2), (32, 5), (64, 5), (100, 5), (128, 5), (160, 10), (200, 10), (252, 10), (256, 10), (512, 10), (1024, 20)):
+    for N, d in ((16, 2), (32, 5), (64, 5), (100, 5), (128, 5), (144, 10), (156, 10), (160, 10), (200, 10), (252, 10), (256, 10), (512, 10), (1024, 20)):
         rng = np.random.default_rng(0)
         X = rng.uniform(-5, 5, size=(N, d))
         y = np.sum(X**2, axis=1)
