@@ -69,6 +69,11 @@ extern "C" int bogp_create(int device, bogp_handle** out) {
     return BOGP_ERR_HIP;
   }
   memset(h->hfit, 0, 4096 * sizeof(double));
+  if (hipMalloc((void**)&h->dfin_ticket, sizeof(unsigned int)) != hipSuccess || hipMemset(h->dfin_ticket, 0, sizeof(unsigned int)) != hipSuccess) {
+    g_create_error = "device allocation failed";
+    delete h;
+    return BOGP_ERR_HIP;
+  }
   // the factorisation's info word lives in the same block as its scalars (doubles 62-63): ONE read-back fetches both
   h->dinfo = reinterpret_cast<int*>(h->dscal + 62);
   if (const char* e = getenv("BOGP_CHOL_RESERVE_CU")) {
@@ -135,6 +140,7 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream_upd) (void)hipStreamDestroy(h->stream_upd);
   if (h->hfit) (void)hipHostFree(h->hfit);
+  if (h->dfin_ticket) (void)hipFree(h->dfin_ticket);
   delete h;
 }
 
@@ -525,8 +531,9 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   if (ptrend == 1) {
     for (int t = 0; t < n_t; ++t) {  // scal[4 t + 1..3] = |Ft|, Ft.Yt_t, rho_t.rho_t
       HIPCHK(h, launch_gemv2(h->dV, ldr, N, 1, h->dy_base + (size_t)t * N, h->dones, h->dyt_base + (size_t)t * N, h->dft, h->dgemv_scratch, st));
+      // (one target and the gradient queued behind: k_grad_coef's two weights come from this kernel too)
       HIPCHK(h, launch_fit_rho(h->dyt_base + (size_t)t * N, h->dft, N, estimate_trend, beta, h->drho_base + (size_t)t * N, h->dscal + 4 * t, st,
-                               t == 0 ? h->dR : nullptr, ldr));
+                               t == 0 ? h->dR : nullptr, ldr, (pend && n_t == 1) ? h->dscal + 4 * BOGP_MAX_TARGETS : nullptr, mode, s2t));
     }
   } else {
     HIPCHK(h, launch_gemv2(h->dV, ldr, N, 1, h->dy, nullptr, h->dyt, nullptr, h->dgemv_scratch, st));
@@ -535,7 +542,9 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
     HIPCHK(h, launch_sumsq(h->drho, N, h->dscal + 3, st));
   }
   if (want_gamma) {
-    HIPCHK(h, hipMemsetAsync(h->dgamma_base, 0, (size_t)n_t * h->Np * sizeof(double), st));
+    // (the zero padding matters to the sweeps after a commit and to the several-target sum of squares; a likelihood evaluation of
+    // one target reads gamma[0 .. N) only)
+    if (!(fz && n_t == 1)) HIPCHK(h, hipMemsetAsync(h->dgamma_base, 0, (size_t)n_t * h->Np * sizeof(double), st));
     for (int t = 0; t < n_t; ++t)
       HIPCHK(h, launch_gemv2(h->dU, ldr, N, 2, h->drho_base + (size_t)t * N, nullptr, h->dgamma_base + (size_t)t * h->Np, nullptr, h->dgemv_scratch, st));
   }
@@ -703,7 +712,7 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
   if (deferred) {
     // scal[4 n_t ..]: 16 doubles of weights behind the per-target scalars (dscal holds 64 doubles)
     double* dcoef = h->dscal + 4 * BOGP_MAX_TARGETS;
-    if (!fz.mid) HIPCHK(h, launch_grad_coef(h->dscal, n_t, mode, N, estimate_trend ? 1 : 0, fp.s2t, dcoef, st));
+    if (!fz.mid && n_t > 1) HIPCHK(h, launch_grad_coef(h->dscal, n_t, mode, N, estimate_trend ? 1 : 0, fp.s2t, dcoef, st));  // (one target: k_fit_rho did it)
     gv.dcoef = dcoef;
     for (int t = 0; t < BOGP_MAX_TARGETS; ++t) gv.cA[t] = gv.cB[t] = 0.0;
   } else {
@@ -716,8 +725,29 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
   }
   HIPCHK(h, launch_grad_contract(kernel, h->dX, N, d, h->dtheta, gv, nullptr, 0.0, h->dRinv, ldr, nparts, (size_t)ldr * ldr, h->dgrad_partial, nblk, st));
   double* dS = h->dgrad_partial + (size_t)nblk * (d + 1);
-  HIPCHK(h, launch_grad_reduce(h->dgrad_partial, nblk, d + 1, dS, st));
   std::vector<double> S(d + 3);
+  static const bool fit_poll = [] { const char* e_ = getenv("BOGP_FIT_POLL"); return !(e_ && atoi(e_) == 0); }();
+  if (deferred && n_t == 1 && fit_poll && d + 3 <= 512) {
+    // the column sums, trace(R^-1) / gamma.gamma and the read-back in ONE launch (k_grad_finish) + the polled sequence word
+    const unsigned long long seq = ++h->fit_seq;
+    HIPCHK(h, launch_grad_finish(h->dgrad_partial, nblk, d + 1, dS, h->dRinv, ldr, nparts, (size_t)ldr * ldr, N, h->dgamma_base,
+                                 mode == BOGP_MODE_NOISY ? 1 : 0, h->dscal, h->hfit_dev + 2048, h->hfit_dev + 2112,
+                                 reinterpret_cast<unsigned long long*>(h->hfit_dev + 3000), seq, h->dfin_ticket, st));
+    const int ew = fit_wait(h, seq);
+    if (ew) return ew;
+    double blk[64];
+    memcpy(blk, h->hfit + 2048, sizeof(blk));
+    memcpy(S.data(), h->hfit + 2112, (size_t)(d + 3) * sizeof(double));
+    const int info2[2] = {0, 0};
+    int info = 0;
+    memcpy(&info, blk + 62, sizeof(info));
+    rc = factorize_finish(h, fp, (int)info, blk, info2, true, &o);
+    *llf = o.llf;
+    if (rc != BOGP_OK) return rc;
+    nll_gradient_from_sums(mode, iso, d, par, n_par, n_t, S.data(), o.s2t, grad);
+    return BOGP_OK;
+  }
+  HIPCHK(h, launch_grad_reduce(h->dgrad_partial, nblk, d + 1, dS, st));
   if (mode == BOGP_MODE_NOISY) {
     HIPCHK(h, launch_trace_gg(h->dRinv, ldr, nparts, (size_t)ldr * ldr, N, h->dgamma_base, nullptr, dS + d + 1, st));
     if (n_t > 1) HIPCHK(h, launch_sumsq(h->dgamma_base, n_t * h->Np, dS + d + 2, st));  // sum_t gamma_t . gamma_t (zero padding)

@@ -135,6 +135,7 @@ struct bogp_handle {
   double* hfit = nullptr;      // pinned: [0, 2048) theta staging | [2048, 2112) the 64 scalars | [2112, 2112 + 512) gradient sums | [3000] sequence word
   double* hfit_dev = nullptr;  // its device address
   unsigned long long fit_seq = 0;
+  unsigned int* dfin_ticket = nullptr;  // k_grad_finish: which workgroup finished last
   double* hpin = nullptr;  // pinned host buffer the finishing workgroup writes its records into (device-mapped)
   double* hpin_dev = nullptr;
   size_t hpin_cap = 0;

@@ -233,7 +233,11 @@ hipError_t launch_gemv2(const double* M, int ld, int N, int tri, const double* x
                         double* scratch, hipStream_t st);
 // Lfac != null: also scal[0] = sum(log(diag(Lfac))) (what launch_logdet writes, in the same launch)
 hipError_t launch_fit_rho(const double* Yt, const double* Ft, int N, int estimate_trend, double beta, double* rho, double* scal,
-                          hipStream_t st, const double* Lfac = nullptr, int ldL = 0);
+                          hipStream_t st, const double* Lfac = nullptr, int ldL = 0, double* coef = nullptr, int mode = 0,
+                          double s2t_host = 0.0);
+hipError_t launch_grad_finish(const double* partial, int nblk, int nout, double* out, const double* Rinv, int ld, int nparts,
+                              size_t part_stride, int N, const double* gamma, int with_trace, const double* scal, double* out_scal,
+                              double* out_S, unsigned long long* flag, unsigned long long seq, unsigned int* ticket, hipStream_t st);
 hipError_t launch_trace_gg(const double* Rinv, int ld, int nparts, size_t part_stride, int N, const double* gamma,
                            const double* qv, double* out, hipStream_t st);
 hipError_t launch_point_hessian(const double* X, int N, int d, const double* theta, const double* x, const double* r,

@@ -136,7 +136,8 @@ __device__ __forceinline__ double block_sum_1024(double v, double* red /* [16] *
 }
 __global__ __launch_bounds__(1024) void k_fit_rho(const double* __restrict__ Yt, const double* __restrict__ Ft, int N,
                                                   int estimate_trend, double beta, double* __restrict__ rho,
-                                                  double* __restrict__ scal, const double* __restrict__ Lfac, int ldL) {
+                                                  double* __restrict__ scal, const double* __restrict__ Lfac, int ldL,
+                                                  double* __restrict__ gcoef, int mode, double s2t_host) {
   __shared__ double red[16];
   if (Lfac != nullptr) {  // sum(log(diag(L))) into scal[0]: k_logdet's partial sums and tree, by the first 256 threads (one launch less)
     __shared__ double red256[256];
@@ -179,11 +180,16 @@ __global__ __launch_bounds__(1024) void k_fit_rho(const double* __restrict__ Yt,
     scal[1] = nrm;
     scal[2] = sfy;
     scal[3] = srr;
+    if (gcoef != nullptr) {  // one target: k_grad_coef's two weights here (one launch less per likelihood gradient)
+      const double s2t = mode == BOGP_MODE_NOISY ? s2t_host : (mode == BOGP_MODE_NOISELESS ? srr / (N - (estimate_trend ? 1 : 0)) : srr / N);
+      gcoef[8] = 1.0 / s2t;
+      gcoef[0] = 0.0 + 1.0 / s2t;
+    }
   }
 }
 hipError_t launch_fit_rho(const double* Yt, const double* Ft, int N, int estimate_trend, double beta, double* rho, double* scal,
-                          hipStream_t st, const double* Lfac, int ldL) {
-  hipLaunchKernelGGL(k_fit_rho, dim3(1), 1024, 0, st, Yt, Ft, N, estimate_trend, beta, rho, scal, Lfac, ldL);
+                          hipStream_t st, const double* Lfac, int ldL, double* coef, int mode, double s2t_host) {
+  hipLaunchKernelGGL(k_fit_rho, dim3(1), 1024, 0, st, Yt, Ft, N, estimate_trend, beta, rho, scal, Lfac, ldL, coef, mode, s2t_host);
   return hipGetLastError();
 }
 
@@ -353,6 +359,78 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const double* __restrict__ 
 }
 hipError_t launch_grad_reduce(const double* partial, int nblk, int nout, double* out, hipStream_t st) {
   hipLaunchKernelGGL(k_grad_reduce, dim3(nout), 256, 0, st, partial, nblk, nout, out);
+  return hipGetLastError();
+}
+
+// The tail of a likelihood gradient in ONE launch: k_grad_reduce's column sums (workgroup k: out[k], the same order of additions),
+// then the LAST workgroup to finish (a ticket) adds what k_trace_gg computes -- out[nout] = trace(R^-1), out[nout + 1] = gamma.gamma
+// (noisy mode) -- and does k_fit_gather's job: the 64 scalars and the nout + 2 sums into device-mapped pinned memory + the
+// sequence word the host polls.  Three launches less per evaluation on the general path.
+__global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ partial, int nblk, int nout, double* __restrict__ out,
+                                                     const double* __restrict__ Rinv, int ld, int nparts, size_t part_stride, int N,
+                                                     const double* __restrict__ gamma, int with_trace, const double* __restrict__ scal,
+                                                     double* __restrict__ out_scal, double* __restrict__ out_S,
+                                                     unsigned long long* __restrict__ flag, unsigned long long seq,
+                                                     unsigned int* __restrict__ ticket) {
+  __shared__ double red[256];
+  __shared__ int s_last;
+  const int k = blockIdx.x, tid = threadIdx.x;
+  double s = 0.0;
+  for (int b = tid; b < nblk; b += 256) s += partial[(size_t)b * nout + k];
+  red[tid] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    __hip_atomic_store(&out[k], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    s_last = atomicAdd(ticket, 1u) == (unsigned int)(nout - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  double tr = 0.0, gg = 0.0;
+  if (with_trace) {
+    for (int i = tid; i < N; i += 256) {
+      for (int q = 0; q < nparts; ++q) tr += Rinv[q * part_stride + (size_t)i * ld + i];
+      gg = __builtin_fma(gamma[i], gamma[i], gg);
+    }
+    red[tid] = tr;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    tr = red[0];
+    __syncthreads();
+    red[tid] = gg;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    gg = red[0];
+  }
+  if (tid < 64) out_scal[tid] = scal[tid];
+  for (int i = tid; i < nout; i += 256) out_S[i] = __hip_atomic_load(&out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    out_S[nout] = tr;
+    out_S[nout + 1] = gg;
+    out[nout] = tr;
+    out[nout + 1] = gg;
+    *ticket = 0u;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_grad_finish(const double* partial, int nblk, int nout, double* out, const double* Rinv, int ld, int nparts,
+                              size_t part_stride, int N, const double* gamma, int with_trace, const double* scal, double* out_scal,
+                              double* out_S, unsigned long long* flag, unsigned long long seq, unsigned int* ticket, hipStream_t st) {
+  hipLaunchKernelGGL(k_grad_finish, dim3(nout), 256, 0, st, partial, nblk, nout, out, Rinv, ld, nparts, part_stride, N, gamma,
+                     with_trace, scal, out_scal, out_S, flag, seq, ticket);
   return hipGetLastError();
 }
 

@@ -238,14 +238,21 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
         for (int c = 0; c < 4; ++c) s2[c] = dist_fold<KERNEL>(th, vi - xj[min(c, N - 1 - min(4 * sbj, N - 1)) * dP + k], s2[c], pexp);
       }
     }
+    // (the four profiles evaluated unconditionally, side by side: a lone wave waits ~26 cycles for a dependent FP64 result, and a
+    // branch per entry would string the four exp / sqrt chains one behind the other)
+    double pv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pv[c] = a.a * corr_profile<KERNEL>(s2[c]);
+    if (a.div) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pv[c] = pv[c] / a.b;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int j = 4 * sbj + c;
-      double v;
+      double v = pv[c];
       if (i >= N || j >= N) v = i == j ? 1.0 : 0.0;  // identity padding
       else if (i == j) v = a.diag;
-      else if (a.div) v = (a.a * corr_profile<KERNEL>(s2[c])) / a.b;
-      else v = a.a * corr_profile<KERNEL>(s2[c]);
       Rst[(4 * r + c) * nbR + t] = v;
     }
   }
@@ -419,8 +426,21 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
     sff = f * f;
     sfy = f * yt[tid];
   }
-  sff = ns_block_sum(sff, red, nwaves);
-  sfy = ns_block_sum(sfy, red, nwaves);
+  {  // both sums through one pair of barriers
+    sff = ns_wave_sum(sff);
+    sfy = ns_wave_sum(sfy);
+    __syncthreads();
+    if ((tid & 63) == 0) {
+      redk[tid >> 6][0] = sff;
+      redk[tid >> 6][1] = sfy;
+    }
+    __syncthreads();
+    sff = sfy = 0.0;
+    for (int w = 0; w < nwaves; ++w) {
+      sff += redk[w][0];
+      sfy += redk[w][1];
+    }
+  }
   const double nrm = sqrt(sff);
   double coef;
   if (a.estimate_trend) {
@@ -486,43 +506,64 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
             for (int c = 0; c < 4; ++c) s2[c] += dist_term<KERNEL>(th, Xs[min(4 * sbj + c, N - 1) * dP + k] - vi);
           }
           const double gi = gam[i];
+          double r0[4], hh[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ns_corr_pair<KERNEL>(s2[c], r0[c], hh[c]);  // (side by side, see the prologue)
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const int j = 4 * sbj + c;
             const double rinv = Rst[(4 * r + c) * nbR + t];
-            if (j < i) {
-              double r0, h;
-              ns_corr_pair<KERNEL>(s2[c], r0, h);
-              const double A = (gam[j] * gi) * cw - rinv;
-              B[q][c] = A * h;
-              sd += A * r0;
-            } else if (j == i) {
-              tr += rinv;
-            }
+            const double A = (gam[min(j, N - 1)] * gi) * cw - rinv;
+            B[q][c] = j < i ? A * hh[c] : 0.0;
+            sd += j < i ? A * r0[c] : 0.0;
+            tr += j == i ? rinv : 0.0;
           }
         }
       }
     }
-    sd = ns_block_sum(sd, red, nwaves);
-    tr = ns_block_sum(tr, red, nwaves);
     double gg = tid < N ? gam[tid] * gam[tid] : 0.0;
-    gg = ns_block_sum(gg, red, nwaves);
+    {  // the three sums through ONE pair of barriers, their butterflies side by side
+      sd = ns_wave_sum(sd);
+      tr = ns_wave_sum(tr);
+      gg = ns_wave_sum(gg);
+      __syncthreads();
+      if ((tid & 63) == 0) {
+        redk[tid >> 6][0] = sd;
+        redk[tid >> 6][1] = tr;
+        redk[tid >> 6][2] = gg;
+      }
+      __syncthreads();
+      sd = tr = gg = 0.0;
+      for (int w = 0; w < nwaves; ++w) {
+        sd += redk[w][0];
+        tr += redk[w][1];
+        gg += redk[w][2];
+      }
+    }
     for (int k0 = 0; k0 < d; k0 += 64) {
       const int kn = min(64, d - k0);
       __syncthreads();
-      for (int kk = 0; kk < kn; ++kk) {
-        double acc = 0.0;
+      for (int kk = 0; kk < kn; kk += 4) {  // four dimensions at a time: four independent butterflies fill each other's latency
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (si[q] >= 0) {
-            const double vi = Xs[si[q] * dP + k0 + kk];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-              acc += B[q][c] * (-dtheta_weight<KERNEL>(Xs[min(sj[q] + c, N - 1) * dP + k0 + kk] - vi));
+            for (int u = 0; u < 4; ++u) {
+              const int kq = min(k0 + kk + u, d - 1);  // (a dimension past d - 1 is computed and not stored)
+              const double vi = Xs[si[q] * dP + kq];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[u] += B[q][c] * (-dtheta_weight<KERNEL>(Xs[min(sj[q] + c, N - 1) * dP + kq] - vi));
+            }
           }
         }
-        acc = ns_wave_sum(acc);
-        if ((tid & 63) == 0) redk[tid >> 6][kk] = acc;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = ns_wave_sum(acc[u]);
+        if ((tid & 63) == 0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (kk + u < kn) redk[tid >> 6][kk + u] = acc[u];
+        }
       }
       __syncthreads();
       if (tid < kn) {
