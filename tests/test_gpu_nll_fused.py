@@ -180,6 +180,69 @@ def test_large_d_falls_back_when_the_workgroup_would_not_fit(eng):
     check(got, want, 1e3)
 
 
+def test_extremes_of_theta_and_of_the_dimension(eng):
+    """d = 64 (the kernel-argument limit), theta so small that R is nearly rank one and so large that it is nearly the identity."""
+    X, y = make(60, 64, 21)
+    eng.set_train(X, y)
+    for th in (1e-4, 0.3, 50.0):
+        par = np.r_[np.full(64, th / 64), 0.7]
+        args = (_lib.KERNEL_SE, _lib.MODE_NOISY, par, 1e-3, True, 0.0)
+        got = eng.nll(*args, eval_grad=True)
+        want = general_path(lambda: eng.nll(*args, eval_grad=True))
+        check(got, want, cond_of(_lib.KERNEL_SE, _lib.MODE_NOISY, par, X, 1e-3, 64))
+    X, y = make(90, 1, 22)
+    eng.set_train(X, y)
+    for th in (1e-3, 1.0, 1e3):
+        par = np.r_[th, 0.9]
+        args = (_lib.KERNEL_MATERN52, _lib.MODE_NOISE_ESTIM, par, 0.0, False, -0.3)
+        got = eng.nll(*args, eval_grad=True)
+        want = general_path(lambda: eng.nll(*args, eval_grad=True))
+        check(got, want, cond_of(_lib.KERNEL_MATERN52, _lib.MODE_NOISE_ESTIM, par, X, 0.0, 1))
+
+
+def test_duplicate_points_with_a_nugget_and_positive_likelihood_rejection(eng):
+    """Coincident rows are fine with noise on the diagonal; a likelihood > 0 is rejected exactly where the general path rejects it."""
+    X, y = make(40, 3, 23)
+    X[7] = X[8] = X[9]
+    eng.set_train(X, y)
+    par = np.r_[0.2, 0.2, 0.2, 0.8]
+    args = (_lib.KERNEL_MATERN32, _lib.MODE_NOISY, par, 0.05, True, 0.0)
+    check(eng.nll(*args, eval_grad=True), general_path(lambda: eng.nll(*args, eval_grad=True)), 1e3)
+    # tiny targets: sigma2_total small -> llf > 0 (gpr.py:981-982)
+    eng.set_train(X, 1e-4 * y)
+    par = np.r_[0.2, 0.2, 0.2]
+    for fn in (lambda: eng.nll(_lib.KERNEL_SE, _lib.MODE_NOISELESS, np.r_[5.0, 5.0, 5.0], 0.0, True, 0.0, eval_grad=True),):
+        try:
+            want = general_path(fn)
+            got = fn()
+            check(got, want, 1e3)
+        except _lib.BogpError as e:
+            with pytest.raises(type(e)):
+                fn()
+
+
+def test_many_evaluations_on_two_engines_interleaved():
+    """Each engine has its own pinned read-back block and sequence counter: interleaved calls do not see each other's results."""
+    e1, e2 = _lib.Engine(0), _lib.Engine(0)
+    try:
+        X1, y1 = make(33, 4, 31)
+        X2, y2 = make(120, 7, 32)
+        e1.set_train(X1, y1)
+        e2.set_train(X2, y2)
+        p1, p2 = np.r_[np.full(4, 0.2), 0.9], np.r_[np.full(7, 0.1), 0.8]
+        r1 = e1.nll(_lib.KERNEL_MATERN32, _lib.MODE_NOISY, p1, 1e-4, True, 0.0, eval_grad=True)
+        r2 = e2.nll(_lib.KERNEL_SE, _lib.MODE_NOISE_ESTIM, p2, 0.0, True, 0.0, eval_grad=True)
+        for _ in range(300):
+            a = e1.nll(_lib.KERNEL_MATERN32, _lib.MODE_NOISY, p1, 1e-4, True, 0.0, eval_grad=True)
+            b = e2.nll(_lib.KERNEL_SE, _lib.MODE_NOISE_ESTIM, p2, 0.0, True, 0.0, eval_grad=True)
+            assert a[0] == r1[0] and b[0] == r2[0]
+            np.testing.assert_array_equal(a[1], r1[1])
+            np.testing.assert_array_equal(b[1], r2[1])
+    finally:
+        e1.close()
+        e2.close()
+
+
 def test_commit_after_a_fused_evaluation(eng):
     """bogp_commit runs the general path (it must leave the factor buffers): its likelihood equals the fused one."""
     X, y = make(80, 4, 3)
