@@ -437,9 +437,15 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   hipStream_t st = h->stream;
   HIPCHK(h, hipSetDevice(h->device));
   const bool fused_ok = fz && trend == BOGP_TREND_CONSTANT && h->n_t == 1 && !(getenv("BOGP_NLL_FUSED") && atoi(getenv("BOGP_NLL_FUSED")) == 0);
-  const bool mid = fused_ok && !nll_small_fits(N, d) && N > 128 && N <= spd_mid_max_n() && (!fz->want_grad || pend) &&
-                   (getenv("BOGP_NLL_MID") && atoi(getenv("BOGP_NLL_MID")) != 0);  // opt-in: measured SLOWER than the general path
-                                                                                     // (profiles/r03_nll_small.txt), kept for the record
+  const bool spd_mid = fused_ok && !nll_small_fits(N, d) && N > 128 && N <= spd_mid_max_n() && (!fz->want_grad || pend) &&
+                       (getenv("BOGP_NLL_MID") && atoi(getenv("BOGP_NLL_MID")) != 0);  // opt-in: measured SLOWER than the general path
+                                                                                         // (profiles/r03_nll_small.txt), kept for the record
+  // 157 <= N <= 2048 (BOGP_NLL_ELIM_MAX; slower than the kernels it replaces from ~3000 on): factor + inverse + solves as one elimination at 64-block granularity (kernels_chol.hip: k_elim_step), one
+  // launch a block column; BOGP_NLL_ELIM=0 keeps the Cholesky / recursive-doubling / U U^T kernels
+  static const int elim_max = [] { const char* e_ = getenv("BOGP_NLL_ELIM_MAX"); return e_ ? atoi(e_) : 2048; }();
+  const bool elim = fused_ok && !spd_mid && !nll_small_fits(N, d) && N <= elim_max && N <= 6080 && ldr >= 192 && ldr % 64 == 0 && (!fz->want_grad || pend) &&
+                    !(getenv("BOGP_NLL_ELIM") && atoi(getenv("BOGP_NLL_ELIM")) == 0);
+  const bool mid = spd_mid || elim;
   if (fused_ok && nll_small_fits(N, d)) {
     NllSmallArgs na;
     na.X = h->dX; na.y = h->dy_base; na.N = N; na.d = d;
@@ -512,7 +518,24 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   //   rho (:806 / :808), |Ft|, Ft.Yt, rho.rho       k_fit_rho
   //   gamma = U rho (:788 / :996)
   const int n_t = h->n_t;
-  if (mid) {
+  if (elim) {
+    if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * h->cap_ld * h->cap_ld * sizeof(double)));
+    // scratch behind the first of the UUT_PARTS slices of dRinv (the result goes into that slice): two raw panels, block row nb,
+    // Yt, Ft, the log-determinant parts
+    double* sc0 = h->dRinv + (size_t)ldr * ldr;
+    const int lde = ldr + 64;
+    ElimArgs ea;
+    ea.E = h->dR; ea.ld = ldr; ea.nb = ldr / 64; ea.N = N;
+    double* panels = sc0;
+    ea.Eb = panels + (size_t)2 * lde * 64;
+    ea.yt = ea.Eb + (size_t)64 * ldr;
+    ea.ft = ea.yt + ldr;
+    ea.logpart = ea.ft + ldr;
+    ea.info = h->dinfo;
+    HIPCHK(h, launch_elim(ea, h->dy_base, h->ddinv, panels, h->dRinv, ldr, h->dgamma_base, h->dscal, h->dscal + 4 * BOGP_MAX_TARGETS,
+                          estimate_trend, mode, beta, s2t, st));
+    fz->mid = true;
+  } else if (mid) {
     if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * h->cap_ld * h->cap_ld * sizeof(double)));
     SpdMidArgs ma;
     ma.R = h->dR; ma.ldr = ldr; ma.y = h->dy_base; ma.N = N; ma.estimate_trend = estimate_trend; ma.mode = mode;

@@ -224,6 +224,18 @@ struct SpdMidArgs {
   double* coef;   // k_grad_coef's output block
 };
 int spd_mid_max_n();
+// the elimination at 64-block granularity (kernels_chol.hip: k_elim_*): 157 <= N <= 1024, constant basis, one target
+struct ElimArgs {
+  double* E;    // ld x ld, column-major: the state blocks (k_build_R's output to start with)
+  double* Eb;   // 64 x ld (leading dimension 64): block row nb = the right-hand sides [y; 1; 0 ...]
+  int ld, nb, N;
+  double* yt;   // ld: L^-1 y
+  double* ft;   // ld: L^-1 1
+  double* logpart;  // nb: sum(log diag L_kk)
+  int* info;
+};
+hipError_t launch_elim(const ElimArgs& a, const double* y, double* Winv, double* panels, double* Rinv, int ldr, double* gamma, double* scal,
+                       double* coefw, int estimate_trend, int mode, double beta, double s2t_host, hipStream_t st);
 hipError_t launch_spd_mid(bool grad, const SpdMidArgs& a, hipStream_t st);
 hipError_t launch_nll_small(int kernel, bool grad, const NllSmallArgs& a, hipStream_t st);
 hipError_t launch_fit_gather(const double* scal, const double* S, int nS, double* out_scal, double* out_S, unsigned long long* flag,

@@ -1322,4 +1322,274 @@ hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStre
   return hipGetLastError();
 }
 
+// =====================================================================================================================
+// The likelihood's factor + inverse + solves as ONE elimination at 64-block granularity (157 <= N <= 1024, constant basis):
+// the scheme of kernels_nllsmall.hip with 64 x 64 blocks and one workgroup a block.  E holds the block T(bi, bj), bi >= bj,
+// of the bordered matrix [[R, .], [I, 0]] in place: R until block column bj is eliminated, then X(bj, bi)^T (X = L^-T) until step
+// bi, then block (bi, bj) of -R^-1; one extra block row carries [y; 1] and ends as -(R^-1 y)^T, -(R^-1 1)^T.  A step k is ONE
+// launch (k_chol_step's layout): every workgroup forms the two panel blocks it needs itself from the copied-out raw panel,
+// X_i = M_i W_k^T, X_j = M_j W_k^T (M_k = I), and applies T <- (bi == k or bj == k ? 0 : T) - X_i X_j^T; the blocks of column k + 1
+// (as they are) and of row k + 1 (transposed) go into the next raw panel, and the workgroup of block (k + 1, k + 1) factors and
+// inverts it for the next step.  It replaces the Cholesky steps, the recursive-doubling inverse, U U^T and both matrix-vector
+// passes: nb launches of ~27 us instead of ~4 nb + 8 kernels.
+// =====================================================================================================================
+namespace {
+// tile (bi, bj) of the state: block row nb (the right-hand sides) lives in its own 64 x ld array
+__device__ __forceinline__ double* elim_tile(const ElimArgs& a, int bi, int bj, int& ldt) {
+  if (bi < a.nb) {
+    ldt = a.ld;
+    return a.E + (size_t)bj * CB * a.ld + (size_t)bi * CB;
+  }
+  ldt = CB;
+  return a.Eb + (size_t)bj * CB * CB;
+}
+// factor + invert the block staged in cs (pitch CB + 1): W -> Wn (64 x 64 column-major, zeros above the diagonal),
+// sum(log diag L) -> *logpart, LAPACK-style info, and the identity rows of block row kb into the raw panel Pn
+__device__ __forceinline__ void elim_diag(const double* cs, double* sb, double* __restrict__ Wn, double* __restrict__ logpart,
+                                          int* __restrict__ info, int base, int reset, int nlive, double* __restrict__ Pn, int lde,
+                                          int kb, int tid) {
+  double lo[4][4], ww[4][4];
+  const int bad = diag_factor_invert(cs, sb, lo, ww, tid, nlive);
+  const int tr = tid >> 4, tc = tid & 15;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * tr + i, col = 4 * tc + c;
+      Wn[col * CB + r] = tc <= tr ? ww[i][c] : 0.0;
+      Pn[(size_t)col * lde + (size_t)kb * CB + r] = r == col ? 1.0 : 0.0;
+    }
+  __syncthreads();
+  double ls = 0.0;
+  if (tr == tc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ls += log(lo[i][i]);
+  }
+  sb[tid & 15] = 0.0;
+  __syncthreads();
+  if (tr == tc) sb[tr] = ls;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int q = 0; q < 16; ++q) t += sb[q];
+    *logpart = t;
+    if (reset) *info = bad;
+    else if (bad != 0 && *info == 0) *info = base + bad;
+  }
+}
+}  // namespace
+
+// workgroup 0: the first diagonal block; workgroups i >= 1: block (i, 0) into the raw panel as it is
+__global__ __launch_bounds__(256) void k_elim_first(const ElimArgs a, double* __restrict__ W0, double* __restrict__ Pn) {
+  __shared__ __attribute__((aligned(16))) double cs[CB * (CB + 1)];
+  __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
+  const int tid = threadIdx.x, bi = blockIdx.x;
+  const int lde = a.ld + CB;
+  int ldt;
+  const double* T = elim_tile(a, bi, 0, ldt);
+  if (bi == 0) {
+    for (int e = tid; e < CB * CB; e += 256) {
+      const int r = e & 63, c = e >> 6;
+      cs[r * (CB + 1) + c] = T[(size_t)c * ldt + r];
+    }
+    __syncthreads();
+    elim_diag(cs, sb, W0, a.logpart, a.info, 0, 1, max(0, min(CB, a.N)), Pn, lde, 0, tid);
+  } else {
+    for (int e = tid; e < CB * CB; e += 256) {
+      const int r = e & 63, c = e >> 6;
+      Pn[(size_t)c * lde + (size_t)bi * CB + r] = T[(size_t)c * ldt + r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_elim_step(const ElimArgs a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
+                                                   double* __restrict__ Pnext, double* __restrict__ Wn) {
+  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
+  __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
+  int bi, bj;
+  tri_index((int)blockIdx.x, bi, bj);  // bi <= nb (block row nb = the right-hand sides); (nb, nb) is not launched
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lk = lane >> 4;
+  const int lde = a.ld + CB;
+  const int i0 = CB * bi, j0 = CB * bj;
+  const bool restart = bi == k || bj == k;
+
+  stage_aside(lds, Wk, CB, tid);  // tile[kk][c] = W(c, kk)
+  double bv[16], bvi[16];
+  load_bside(bv, Pcur + j0, lde, w, lane);
+  if (bi != bj) load_bside(bvi, Pcur + i0, lde, w, lane);
+  double xj[4][4], xi[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xj[mi][t] = xi[mi][t] = 0.0;
+  int ldt;
+  double* __restrict__ Tb = elim_tile(a, bi, bj, ldt);
+  double acc[4][4];  // negated tile
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[mi][t] = restart ? 0.0 : -Tb[(size_t)(16 * mi + 4 * t + lk) * ldt + 16 * w + (lane & 15)];
+  __syncthreads();
+  mma_64(lds, bv, xj, lane);  // X_j = M_j W^T: rows 16 w .. of block row bj, element (row, col 16 mi + 4 t + lk)
+  if (bi != bj) {
+    mma_64(lds, bvi, xi, lane);
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xi[mi][t] = xj[mi][t];
+  }
+  if (bi == a.nb && bj == k && w == 0 && (lane & 15) < 2) {  // rows 0 / 1 of the solved right-hand sides: Yt, Ft of block k
+    double* dst = (lane & 15) == 0 ? a.yt : a.ft;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) dst[CB * k + 16 * mi + 4 * t + lk] = xi[mi][t];
+  }
+  __syncthreads();  // every wave is done with the W tile
+  // A side of the update: tile[kk][c] = X_j(c, kk)
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) lds[(16 * mi + 4 * t + lk) * CPITCH + 16 * w + (lane & 15)] = xj[mi][t];
+  // B side: X_i(row 16 w + (lane & 15), kk = 4 ks + lk) is exactly xi[ks / 4][ks % 4] of this lane
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bv[4 * mi + t] = xi[mi][t];
+  asm volatile("s_nop 7\n\ts_nop 7"
+               : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7]), "+v"(bv[8]),
+                 "+v"(bv[9]), "+v"(bv[10]), "+v"(bv[11]), "+v"(bv[12]), "+v"(bv[13]), "+v"(bv[14]), "+v"(bv[15]));
+  __syncthreads();
+  mma_64(lds, bv, acc, lane);  // -T_new = -T_old + X_i X_j^T
+
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Tb[(size_t)(16 * mi + 4 * t + lk) * ldt + 16 * w + (lane & 15)] = -acc[mi][t];
+  const int kn = k + 1;
+  if (kn >= a.nb) return;
+  if (bj == kn && bi > kn) {  // column kn, as it is
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Pnext[(size_t)(16 * mi + 4 * t + lk) * lde + i0 + 16 * w + (lane & 15)] = -acc[mi][t];
+  } else if (bi == kn && bj < kn) {  // row kn, transposed: raw row block bj
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Pnext[(size_t)(16 * w + (lane & 15)) * lde + j0 + 16 * mi + 4 * t + lk] = -acc[mi][t];
+  } else if (bi == kn && bj == kn) {  // the next diagonal block: factor + invert it here
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) lds[(16 * w + (lane & 15)) * (CB + 1) + 16 * mi + 4 * t + lk] = -acc[mi][t];
+    __syncthreads();
+    elim_diag(lds, sb, Wn, a.logpart + kn, a.info, CB * kn, 0, max(0, min(CB, a.N - CB * kn)), Pnext, lde, kn, tid);
+  }
+}
+
+// R^-1 = -T into Rinv (lower triangle, column-major, ldr) and, by the last workgroup, the likelihood's scalars (k_fit_rho's
+// expressions), the gradient's two weights and gamma = R^-1 y - beta R^-1 1
+__global__ __launch_bounds__(256) void k_elim_finish(const ElimArgs a, double* __restrict__ Rinv, int ldr, double* __restrict__ gamma,
+                                                     double* __restrict__ scal, double* __restrict__ coefw, int estimate_trend, int mode,
+                                                     double beta, double s2t_host) {
+  const int tid = threadIdx.x;
+  const int ntiles = a.nb * (a.nb + 1) / 2;
+  if ((int)blockIdx.x < ntiles) {
+    int bi, bj;
+    tri_index((int)blockIdx.x, bi, bj);
+    for (int e = tid; e < CB * CB; e += 256) {
+      const int r = e & 63, c = e >> 6;
+      const int row = CB * bi + r, col = CB * bj + c;
+      if (row < a.N && col <= row) Rinv[(size_t)col * ldr + row] = -a.E[(size_t)col * a.ld + row];
+    }
+    return;
+  }
+  __shared__ double red[256];
+  auto block_sum = [&](double v) {
+    red[tid] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+  };
+  const int N = a.N;
+  double sff = 0.0, sfy = 0.0;
+  for (int i = tid; i < N; i += 256) {
+    const double f = a.ft[i];
+    sff = __builtin_fma(f, f, sff);
+    sfy = __builtin_fma(f, a.yt[i], sfy);
+  }
+  sff = block_sum(sff);
+  sfy = block_sum(sfy);
+  const double nrm = sqrt(sff);
+  double coef;
+  if (estimate_trend) {
+    const double G = -nrm, qty = sfy / G;
+    coef = -(qty / G);
+  } else {
+    coef = -beta;
+  }
+  double srr = 0.0;
+  for (int i = tid; i < N; i += 256) {
+    const double r = __builtin_fma(coef, a.ft[i], a.yt[i]);
+    srr = __builtin_fma(r, r, srr);
+  }
+  srr = block_sum(srr);
+  for (int i = tid; i < N; i += 256) {  // block row nb, rows 0 / 1: -(R^-1 y)_i, -(R^-1 1)_i
+    const double gy = a.Eb[(size_t)i * CB + 0], g1 = a.Eb[(size_t)i * CB + 1];
+    gamma[i] = -__builtin_fma(coef, g1, gy);
+  }
+  if (tid == 0) {
+    double ld_ = 0.0;
+    for (int b = 0; b < a.nb; ++b) ld_ += a.logpart[b];
+    scal[0] = ld_;
+    scal[1] = nrm;
+    scal[2] = sfy;
+    scal[3] = srr;
+    double iw = 0.0;
+    int info = *a.info;
+    memcpy(&iw, &info, sizeof(info));
+    scal[62] = iw;
+    const double s2t = mode == BOGP_MODE_NOISY ? s2t_host : (mode == BOGP_MODE_NOISELESS ? srr / (N - (estimate_trend ? 1 : 0)) : srr / N);
+    coefw[0] = 1.0 / s2t;
+    coefw[8] = 1.0 / s2t;
+  }
+}
+
+// [y; 1] into block row nb and identity padding of E outside its leading N x N block (k_build_R wrote the lower 64-tiles)
+__global__ void k_elim_init(const ElimArgs a, const double* __restrict__ y) {
+  const int j = blockIdx.x;  // column
+  const int N = a.N, ld = a.ld;
+  for (int r = threadIdx.x; r < CB; r += blockDim.x) a.Eb[(size_t)j * CB + r] = (j < N && r == 0) ? y[j] : ((j < N && r == 1) ? 1.0 : 0.0);
+  if (j >= N) {
+    for (int i = threadIdx.x; i < ld; i += blockDim.x) a.E[(size_t)j * ld + i] = i == j ? 1.0 : 0.0;
+  } else {
+    for (int i = N + threadIdx.x; i < ld; i += blockDim.x) a.E[(size_t)j * ld + i] = 0.0;
+  }
+}
+
+hipError_t launch_elim(const ElimArgs& a, const double* y, double* Winv, double* panels, double* Rinv, int ldr, double* gamma, double* scal,
+                       double* coefw, int estimate_trend, int mode, double beta, double s2t_host, hipStream_t st) {
+  const int nb = a.nb, lde = a.ld + CB;
+  double* P[2] = {panels, panels + (size_t)lde * CB};
+  hipLaunchKernelGGL(k_elim_init, dim3(a.ld), 64, 0, st, a, y);
+  hipLaunchKernelGGL(k_elim_first, dim3(nb + 1), 256, 0, st, a, Winv, P[0]);
+  const int grid = (nb + 1) * (nb + 2) / 2 - 1;
+  for (int k = 0; k < nb; ++k)
+    hipLaunchKernelGGL(k_elim_step, dim3(grid), 256, 0, st, a, k, Winv + (size_t)k * CB * CB, P[k & 1], P[(k + 1) & 1],
+                       Winv + (size_t)(k + 1) * CB * CB);
+  hipLaunchKernelGGL(k_elim_finish, dim3(nb * (nb + 1) / 2 + 1), 256, 0, st, a, Rinv, ldr, gamma, scal, coefw, estimate_trend, mode, beta,
+                     s2t_host);
+  return hipGetLastError();
+}
+
 }  // namespace bogp

@@ -31,12 +31,16 @@ def general_path(fn):
         del os.environ["BOGP_NLL_FUSED"]
 
 
-@pytest.fixture(autouse=True)
-def mid_path_on():
-    """k_spd_mid (128 < N <= 252) is opt-in -- it is slower than the general path it would replace -- and tested all the same."""
-    os.environ["BOGP_NLL_MID"] = "1"
-    yield
-    del os.environ["BOGP_NLL_MID"]
+@pytest.fixture(autouse=True, params=["elim", "spd_mid"])
+def mid_path(request):
+    """Above N = 156 the default is the elimination at 64-block granularity (k_elim_step, up to N = 1024); k_spd_mid (128 < N <= 252) is
+    opt-in -- it is slower than the general path it would replace -- and tested all the same."""
+    if request.param == "spd_mid":
+        os.environ["BOGP_NLL_MID"] = "1"
+        yield
+        del os.environ["BOGP_NLL_MID"]
+    else:
+        yield
 
 
 def make(N, d, seed):
@@ -51,8 +55,9 @@ def make(N, d, seed):
 GRAD_KERNELS = [_lib.KERNEL_SE, _lib.KERNEL_MATERN12, _lib.KERNEL_MATERN32, _lib.KERNEL_MATERN52, _lib.KERNEL_ABSEXP]
 SIZES = [1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128,   # one launch (k_nll_small, 768 threads)
          129, 131, 144, 145, 153, 156,                                            # one launch (k_nll_small, 1024 threads)
-         157, 177, 200, 240, 249, 252,                                            # k_build_R + k_spd_mid + the gradient kernels (opt-in)
-         253]                                                                     # the general path itself
+         157, 177, 192, 193, 200, 240, 249, 252,                                  # k_build_R + k_elim_* (or k_spd_mid, opt-in) + the gradient kernels
+         253, 256, 257, 320, 511, 512, 700, 1024, 1500, 2048,                     # k_elim_* (k_spd_mid stops at 252)
+         2049]                                                                    # the general path itself
 
 
 def par_of(mode, d, iso, rng):
@@ -93,11 +98,12 @@ def test_fused_equals_the_general_path(eng, N, mode):
     X, y = make(N, d, 100 + N)
     eng.set_train(X, y)
     rng = np.random.default_rng(N * 7 + mode)
-    for kernel in GRAD_KERNELS:
-        for iso in (False, True):
+    big = N > 600  # (one configuration per mode: the condition number below is an SVD of an N x N matrix)
+    for kernel in ([GRAD_KERNELS[N % 5]] if big else GRAD_KERNELS):
+        for iso in ((False,) if big else (False, True)):
             if iso and d == 1:
                 continue
-            for est in (True, False):
+            for est in ((True,) if big else (True, False)):
                 if N == 1 and est and mode == _lib.MODE_NOISELESS:
                     continue  # sigma2 = rho.rho / (N - 1): 0 / 0
                 par = par_of(mode, d, iso, rng)
@@ -157,7 +163,7 @@ def test_not_positive_definite_is_reported(eng):
 def test_against_the_oracle(eng):
     from oracle import gp_oracle
 
-    for N, d, seed in ((12, 2, 0), (50, 5, 1), (128, 10, 2), (150, 6, 3), (252, 12, 4)):
+    for N, d, seed in ((12, 2, 0), (50, 5, 1), (128, 10, 2), (150, 6, 3), (252, 12, 4), (400, 8, 5)):
         X, y = make(N, d, seed)
         eng.set_train(X, y)
         theta = np.random.default_rng(seed).uniform(0.05, 0.4, size=d)
