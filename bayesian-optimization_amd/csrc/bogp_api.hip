@@ -400,7 +400,7 @@ static int factorize_finish(bogp_handle* h, const FitPending& fp, int info, cons
 struct FusedNll {
   bool want_grad = false;
   bool done = false;
-  bool mid = false;  // 128 < N <= 252: k_build_R + ONE workgroup for factor / inverse / scalars / gamma (k_spd_mid); the caller's tail follows
+  bool mid = false;  // 157 <= N <= 2048: k_build_R + k_elim_* left R^-1, gamma, the scalars and the gradient weights; the caller's tail follows
   double S[64 + 3];
 };
 static int factorize(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
@@ -437,15 +437,12 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   hipStream_t st = h->stream;
   HIPCHK(h, hipSetDevice(h->device));
   const bool fused_ok = fz && trend == BOGP_TREND_CONSTANT && h->n_t == 1 && !(getenv("BOGP_NLL_FUSED") && atoi(getenv("BOGP_NLL_FUSED")) == 0);
-  const bool spd_mid = fused_ok && !nll_small_fits(N, d) && N > 128 && N <= spd_mid_max_n() && (!fz->want_grad || pend) &&
-                       (getenv("BOGP_NLL_MID") && atoi(getenv("BOGP_NLL_MID")) != 0);  // opt-in: measured SLOWER than the general path
-                                                                                         // (profiles/r03_nll_small.txt), kept for the record
   // 157 <= N <= 2048 (BOGP_NLL_ELIM_MAX; slower than the kernels it replaces from ~3000 on): factor + inverse + solves as one elimination at 64-block granularity (kernels_chol.hip: k_elim_step), one
   // launch a block column; BOGP_NLL_ELIM=0 keeps the Cholesky / recursive-doubling / U U^T kernels
   static const int elim_max = [] { const char* e_ = getenv("BOGP_NLL_ELIM_MAX"); return e_ ? atoi(e_) : 2048; }();
-  const bool elim = fused_ok && !spd_mid && !nll_small_fits(N, d) && N <= elim_max && N <= 6080 && ldr >= 192 && ldr % 64 == 0 && (!fz->want_grad || pend) &&
+  const bool elim = fused_ok && !nll_small_fits(N, d) && N <= elim_max && N <= 6080 && ldr >= 192 && ldr % 64 == 0 && (!fz->want_grad || pend) &&
                     !(getenv("BOGP_NLL_ELIM") && atoi(getenv("BOGP_NLL_ELIM")) == 0);
-  const bool mid = spd_mid || elim;
+  const bool mid = elim;
   if (fused_ok && nll_small_fits(N, d)) {
     NllSmallArgs na;
     na.X = h->dX; na.y = h->dy_base; na.N = N; na.d = d;
@@ -494,7 +491,7 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   // size -> overflowing inverses -> inf * 0) leaves NaN in the padding rows of the in-place factor, and R is only rebuilt
   // inside its N x N block -- without this, one failed likelihood evaluation made every later one on the handle fail too
   // (found with the near-singular noiseless cubic tables of G25).
-  if (!mid) HIPCHK(h, launch_pad_identity(h->dR, N, ldr, st));  // (k_spd_mid pads in its registers)
+  if (!mid) HIPCHK(h, launch_pad_identity(h->dR, N, ldr, st));  // (k_elim_init pads)
   // correlation matrix with the per-mode normalisation (gpr.py:931-969)
   double s2t = 0, alpha = 0, sigma2_par = 0;
   if (mode == BOGP_MODE_NOISELESS) {
@@ -534,14 +531,6 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
     ea.info = h->dinfo;
     HIPCHK(h, launch_elim(ea, h->dy_base, h->ddinv, panels, h->dRinv, ldr, h->dgamma_base, h->dscal, h->dscal + 4 * BOGP_MAX_TARGETS,
                           estimate_trend, mode, beta, s2t, st));
-    fz->mid = true;
-  } else if (mid) {
-    if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * h->cap_ld * h->cap_ld * sizeof(double)));
-    SpdMidArgs ma;
-    ma.R = h->dR; ma.ldr = ldr; ma.y = h->dy_base; ma.N = N; ma.estimate_trend = estimate_trend; ma.mode = mode;
-    ma.beta = beta; ma.s2t_host = s2t; ma.Rinv = h->dRinv; ma.ldi = ldr; ma.gamma = h->dgamma_base;
-    ma.scal = h->dscal; ma.coef = h->dscal + 4 * BOGP_MAX_TARGETS;
-    HIPCHK(h, launch_spd_mid(fz->want_grad, ma, st));
     fz->mid = true;
   } else {
   if (!h->dchain_flags) HIPCHK(h, hipMalloc((void**)&h->dchain_flags, (size_t)2 * (h->cap_ld / 64 + 1) * sizeof(unsigned int)));
@@ -720,7 +709,7 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
   const int ldr = h->ldr;
   if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * h->cap_ld * h->cap_ld * sizeof(double)));
   int nparts = UUT_PARTS;
-  if (fz.mid) nparts = 1;  // (k_spd_mid left R^-1 itself)
+  if (fz.mid) nparts = 1;  // (k_elim_finish left R^-1 itself)
   else HIPCHK(h, launch_uut(h->dU, h->dRinv, ldr, st, &nparts));  // R^-1 = L^-T L^-1, lower triangle
   const int nblk = grad_contract_blocks(N);
   int e = ensure(h, &h->dgrad_partial, &h->grad_partial_cap, (size_t)nblk * (d + 1) + (d + 4));

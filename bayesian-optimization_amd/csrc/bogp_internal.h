@@ -210,20 +210,6 @@ struct NllSmallArgs {
 };
 int nll_small_max_n();
 bool nll_small_fits(int N, int d);
-// 128 < N <= 252: factor + inverse + the likelihood's scalars + gamma of a matrix k_build_R left in global memory, one workgroup
-struct SpdMidArgs {
-  const double* R;  // column-major, lower triangle (diagonal 64-tiles complete), leading dimension ldr
-  int ldr;
-  const double* y;
-  int N, estimate_trend, mode;
-  double beta, s2t_host;
-  double* Rinv;  // lower triangle, column-major, leading dimension ldi
-  int ldi;
-  double* gamma;  // N
-  double* scal;   // the 64-double scalar block (dscal layout)
-  double* coef;   // k_grad_coef's output block
-};
-int spd_mid_max_n();
 // the elimination at 64-block granularity (kernels_chol.hip: k_elim_*): 157 <= N <= 1024, constant basis, one target
 struct ElimArgs {
   double* E;    // ld x ld, column-major: the state blocks (k_build_R's output to start with)
@@ -236,7 +222,6 @@ struct ElimArgs {
 };
 hipError_t launch_elim(const ElimArgs& a, const double* y, double* Winv, double* panels, double* Rinv, int ldr, double* gamma, double* scal,
                        double* coefw, int estimate_trend, int mode, double beta, double s2t_host, hipStream_t st);
-hipError_t launch_spd_mid(bool grad, const SpdMidArgs& a, hipStream_t st);
 hipError_t launch_nll_small(int kernel, bool grad, const NllSmallArgs& a, hipStream_t st);
 hipError_t launch_fit_gather(const double* scal, const double* S, int nS, double* out_scal, double* out_S, unsigned long long* flag,
                              unsigned long long seq, hipStream_t st);

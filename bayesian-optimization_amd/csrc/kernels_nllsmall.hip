@@ -91,52 +91,6 @@ __device__ __forceinline__ int ns_factor4_sub(const double (&a)[4][4], double (&
   }
   return bad;
 }
-// 4 x 4 Cholesky of the lower triangle of a, then W = L^-1 (lower); returns the 1-based index of the first non-positive
-// pivot (0: none); pivprod *= l_00 l_11 l_22 l_33 (its logarithm is taken once, after the last step)
-__device__ __forceinline__ int ns_factor4(const double (&a)[4][4], double (&w)[4][4], double& pivprod) {
-  double l[4][4];
-  double inv[4];
-  int bad = 0;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    double p = a[c][c];
-#pragma unroll
-    for (int m = 0; m < c; ++m) p = __builtin_fma(-l[c][m], l[c][m], p);
-    if (!(p > 0.0) || !(p < 1e300)) {
-      if (!bad) bad = c + 1;
-      p = 1.0;
-    }
-    double lc;
-    ns_sqrt_rsqrt(p, lc, inv[c]);
-    l[c][c] = lc;
-    pivprod *= lc;
-#pragma unroll
-    for (int r = c + 1; r < 4; ++r) {
-      double v = a[r][c];
-#pragma unroll
-      for (int m = 0; m < c; ++m) v = __builtin_fma(-l[r][m], l[c][m], v);
-      l[r][c] = v * inv[c];
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    w[c][c] = inv[c];
-#pragma unroll
-    for (int r = 0; r < c; ++r) w[r][c] = 0.0;
-  }
-  // column by column of the inverse: w[r][c] = -(sum_{m = c}^{r - 1} l[r][m] w[m][c]) / l[r][r]
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int r = c + 1; r < 4; ++r) {
-      double s = 0.0;
-#pragma unroll
-      for (int m = c; m < r; ++m) s = __builtin_fma(l[r][m], w[m][c], s);
-      w[r][c] = -s * inv[r];
-    }
-  return bad;
-}
-
 // r0 = corr_profile(s2) and h = corr_dtheta_profile(s2, r0) with the square root and the exponential they share evaluated once
 // (the same operations on the same values: bit-identical to the two calls)
 template <int KERNEL>
@@ -584,390 +538,6 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
   __threadfence_system();
   __syncthreads();
   if (tid == 0) __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// =====================================================================================================================
-// 128 < N <= 252: the same in-place elimination on the matrix cores.  R comes from k_build_R (global memory), R^-1 and gamma
-// go back to global memory for k_grad_contract: the pair work (~150 instructions an entry) belongs on all CUs, the
-// factorisation chain on one.  16 x 16 tiles live in MFMA accumulators, <= 23 a wave, 6 owner waves; a step's update of a
-// tile is ONE v_mfma_f64_16x16x4_f64, D -= P_I P_J^T, the two operands being 64 consecutive doubles of the panel each.
-// D[i][j] sits in lane 16 (i % 4) + j, component i / 4: component v of lane l is element (l / 16, l % 4) of the 4 x 4
-// sub-block (4 I + v, 4 J + (l % 16) / 4) -- the publish / reset events of the 4 x 4 scheme above are per-lane predicates.
-// Wave 0: the panel wave (lane i = block row i, lane nb = the [y; 1] rows); wave 1: block row nb, one 4 x 4 block a lane.
-// =====================================================================================================================
-namespace {
-constexpr int MD_PITCH = 17;    // doubles per panel block in LDS (16 + 1: two-way conflicts at worst for the per-block writers)
-constexpr int MD_SLOTS = 23;    // tiles per owner wave: 16 * 17 / 2 = 136 tiles over 6 waves; 2 waves a SIMD = 256 registers a lane
-constexpr int MD_OWNERS = 6;
-constexpr int MD_WAVES = 8;       // wave w runs on SIMD w % 4: 0 = panel, 4 = block row nb (SIMD 0 to themselves); the other six own tiles
-constexpr int MD_THREADS = 64 * MD_WAVES;
-constexpr int MD_MAXNB = 63;    // N <= 252: block rows 0 .. nb fit the 64 lanes of the panel wave
-
-typedef double md4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void md_mfma(double a, double b, md4& c) {
-  asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-}
-}  // namespace
-
-// The three roles run their own copy of the phase loop (the same number of barriers in each): the 184 accumulator registers of
-// an owner, the ~120 of the panel wave's factor + trsm and the block of wave 1 are then never live together.
-//
-// Software pipeline, ONE barrier a step: in phase p the owners apply update p (panel P_p) while the panel wave already builds
-// P_{p+1}.  For that the blocks of column / row p + 1 were copied to `Raw` at the end of phase p - 1, in their state after update
-// p - 1, and the panel wave applies update p to its copy itself (lane i: M -= P_p[i] P_p[p + 1]^T, P_p[i] being its own output
-// of the phase before).  The owners' registers of those blocks restart from zero at the END of phase p (the update the MFMA
-// just added to them belongs to the old role).  `P2` and `Raw` are double-buffered by the parity of the step they belong to.
-template <bool GRAD>
-__global__ __launch_bounds__(MD_THREADS) void k_spd_mid(const SpdMidArgs a) {
-  __shared__ double P2[2][(MD_MAXNB + 1) * MD_PITCH];
-  __shared__ double Raw[2][(MD_MAXNB + 1) * MD_PITCH];
-  __shared__ double yt[4 * (MD_MAXNB + 1)], ft[4 * (MD_MAXNB + 1)], gy[4 * (MD_MAXNB + 1)], g1[4 * (MD_MAXNB + 1)];
-  __shared__ double red[MD_THREADS / 64];
-  __shared__ int tileTab[MD_OWNERS][MD_SLOTS];   // (I << 8) | J of an owner's slot, -1: none
-  __shared__ int maskTab[MD_OWNERS][MD_SLOTS + 2];  // slots of an owner holding a tile of tile-column or tile-row K
-  __shared__ double s_logdet;
-  __shared__ int s_info;
-
-  const int N = a.N, nb = (N + 3) / 4, NB16 = (N + 15) / 16, ntiles = NB16 * (NB16 + 1) / 2;
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = tid & 63;
-  const int nwaves = MD_THREADS / 64;
-  for (int e = tid; e < 2 * (MD_MAXNB + 1) * MD_PITCH; e += MD_THREADS) {
-    (&P2[0][0])[e] = 0.0;
-    (&Raw[0][0])[e] = 0.0;
-  }
-  if (tid == 0) s_info = 0;
-  if (tid < MD_THREADS / 64) red[tid] = 0.0;
-  const bool is_owner = (wave & 3) != 0;
-  const int ow = wave - 1 - (wave > 4 ? 1 : 0);  // 0 .. 5
-  auto tile_of = [&](int t) {  // tile t, row-major over the lower triangle -> (I << 8) | J
-    int I = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
-    while ((I + 1) * (I + 2) / 2 <= t) ++I;
-    while (I * (I + 1) / 2 > t) --I;
-    return (I << 8) | (t - I * (I + 1) / 2);
-  };
-  if (is_owner) {
-    if (lane < MD_SLOTS) {
-      const int t = ow + MD_OWNERS * lane;
-      tileTab[ow][lane] = t < ntiles ? tile_of(t) : -1;
-    }
-    if (lane < MD_SLOTS + 2) {  // K = lane
-      int m = 0;
-      for (int sl = 0; sl < MD_SLOTS; ++sl) {
-        const int t = ow + MD_OWNERS * sl;
-        if (t < ntiles) {
-          const int ij = tile_of(t);
-          if ((ij >> 8) == lane || (ij & 255) == lane) m |= 1 << sl;
-        }
-      }
-      maskTab[ow][lane] = m;
-    }
-  }
-  __syncthreads();  // (the zeroed LDS, the tables)
-  // (SIMD 0 is left to the panel wave and the light wave 4: the factor chain sets the pace of a step)
-
-  if (wave == 0) {
-    // ================= the panel wave: lane i = block row i of the panel (lane nb: the [y; 1] rows) =================
-    __builtin_amdgcn_s_setprio(3);
-    double pivm = 1.0;  // prod(l_cc) = pivm 2^pive
-    int pive = 0;
-    const int i = min(lane, nb);
-    double o[4][4];
-#ifdef NS_PROFILE
-    long long tq = clock64(), tpan = 0, twait = 0;
-#endif
-    __syncthreads();  // raw(0), raw(1) are published
-    for (int kn = 0; kn < nb; ++kn) {  // P_kn: before the loop's first barrier for kn = 0, in phase kn - 1 otherwise
-      double D[4][4], w[4][4], M[4][4];
-      const double* rawb = Raw[kn & 1];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) M[r][c] = rawb[i * MD_PITCH + 4 * r + c];
-      if (kn > 0) {  // update kn - 1 of the copy: M -= P[i] P[kn]^T
-        const double* q = P2[(kn - 1) & 1] + kn * MD_PITCH;
-        double Q[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) Q[r][c] = q[4 * r + c];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            double sacc = M[r][c];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) sacc = __builtin_fma(-o[r][m], Q[c][m], sacc);
-            M[r][c] = sacc;
-          }
-      }
-      // the diagonal block is lane kn's
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c <= r; ++c) {
-          const int lo = __builtin_amdgcn_readlane(__double2loint(M[r][c]), kn);
-          const int hi = __builtin_amdgcn_readlane(__double2hiint(M[r][c]), kn);
-          D[r][c] = __hiloint2double(hi, lo);
-        }
-      double prod4 = 1.0;
-      const int bad = ns_factor4(D, w, prod4);
-      if (lane == 0) {
-        if (bad && s_info == 0) s_info = 4 * kn + bad;
-        int e2;
-        pivm = frexp(pivm * prod4, &e2);
-        pive += e2;
-      }
-      if (i == kn) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) M[r][c] = r == c ? 1.0 : 0.0;
-      }
-      const bool used = GRAD || i > kn;  // (rows above the diagonal carry nothing without the inverse: keep them finite)
-      double* pdst = P2[kn & 1] + lane * MD_PITCH;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          double sacc = 0.0;
-#pragma unroll
-          for (int m = 0; m <= c; ++m) sacc = __builtin_fma(M[r][m], w[c][m], sacc);
-          sacc = used ? sacc : 0.0;
-          o[r][c] = sacc;
-          if (lane <= nb) pdst[4 * r + c] = sacc;
-          if (lane == nb && r == 0) yt[4 * kn + c] = sacc;
-          if (lane == nb && r == 1) ft[4 * kn + c] = sacc;
-        }
-#ifdef NS_PROFILE
-      { const long long t = clock64(); tpan += t - tq; tq = t; }
-#endif
-      __syncthreads();  // P_kn is published (and the raw blocks of step kn + 1)
-#ifdef NS_PROFILE
-      { const long long t = clock64(); twait += t - tq; tq = t; }
-#endif
-    }
-    __syncthreads();  // (phase nb - 1: the owners' last update)
-#ifdef NS_PROFILE
-    if (lane == 0) { a.scal[21] = (double)twait; a.scal[22] = (double)tpan; }
-#endif
-    if (lane == 0) s_logdet = log(pivm) + (double)pive * 0.6931471805599453;
-  } else if (wave == 4) {
-    // ================= block row nb: block (nb, lane) of [y; 1], 4 x 4 on the vector ALU ==========================
-    double T[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        double v = 0.0;
-        if (lane < nb && 4 * lane + c < N) v = r == 0 ? a.y[4 * lane + c] : (r == 1 ? 1.0 : 0.0);
-        T[r][c] = v;
-      }
-    auto events = [&](int z, int q) {  // restart the block of column z; copy out the block of column q
-      if (GRAD && lane == z) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) T[r][c] = 0.0;
-      }
-      if (lane == q && q < nb) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) Raw[q & 1][nb * MD_PITCH + 4 * r + c] = T[r][c];
-      }
-    };
-    events(-1, 0);
-    events(0, 1);
-    __syncthreads();
-    __syncthreads();
-    for (int p = 0; p < nb; ++p) {
-      if (lane < nb && (GRAD || lane > p)) {
-        const double* pp = P2[p & 1];
-        double pa[4][4], pb[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            pa[r][c] = pp[nb * MD_PITCH + 4 * r + c];
-            pb[r][c] = pp[lane * MD_PITCH + 4 * r + c];
-          }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            double sacc = T[r][c];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) sacc = __builtin_fma(-pa[r][m], pb[c][m], sacc);
-            T[r][c] = sacc;
-          }
-      }
-      events(p + 1, p + 2);
-      __syncthreads();
-    }
-    if (GRAD && lane < nb) {  // -(R^-1 y), -(R^-1 1)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        gy[4 * lane + c] = T[0][c];
-        g1[4 * lane + c] = T[1][c];
-      }
-    }
-  } else {
-    // ================= owners: tiles t = ow + 6 s -> (I, J), row-major over the lower triangle ======================
-    const int lr = lane >> 4, lcb = (lane & 15) >> 2, lc = lane & 3;  // the lane's element (lr, lc) of sub-block column lcb
-    int tIJ[MD_SLOTS];  // (I << 8) | J, -1: no tile
-    md4 acc[MD_SLOTS];
-#pragma unroll
-    for (int s = 0; s < MD_SLOTS; ++s) {
-      tIJ[s] = __builtin_amdgcn_readfirstlane(tileTab[ow][s]);
-      acc[s] = (md4){0.0, 0.0, 0.0, 0.0};
-      if (tIJ[s] >= 0) {
-        const int tI = tIJ[s] >> 8, tJ = tIJ[s] & 255;
-        const int col = 16 * tJ + (lane & 15);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int row = 16 * tI + 4 * v + lr;
-          double x;
-          if (row >= N || col >= N) x = row == col ? 1.0 : 0.0;  // identity padding
-          else x = row >= col ? a.R[(size_t)col * a.ldr + row] : a.R[(size_t)row * a.ldr + col];
-          acc[s][v] = -x;  // the accumulators hold the NEGATED state: acc += P_I P_J^T needs no operand negation
-        }
-      }
-    }
-    // Restart (GRAD) the blocks of column z and row z; copy out those of column q (as they are) and row q (transposed).  Only the
-    // few slots of this wave with a tile in tile-column / tile-row z / 4 or q / 4 do anything (maskTab: one bit test a slot).
-    auto events = [&](int z, int q) {
-      const int Kz = max(z, 0) >> 2;
-      const int hit = __builtin_amdgcn_readfirstlane(maskTab[ow][Kz] | maskTab[ow][Kz + 1]);
-      if (hit == 0) return;
-      double* rawb = Raw[q & 1];
-      const int zK = z >> 2, zv = z & 3, qK = q >> 2, qv = q & 3;
-      const bool lane_zc = lcb == zv, lane_qc = lcb == qv;
-#pragma unroll
-      for (int s = 0; s < MD_SLOTS; ++s) {
-        if (!(hit & (1 << s))) continue;
-        const int tI = tIJ[s] >> 8, tJ = tIJ[s] & 255;
-        if (GRAD && z >= 0) {
-          if (tJ == zK) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[s][v] = (lane_zc && 4 * tI + v >= z) ? 0.0 : acc[s][v];
-          }
-          if (tI == zK) {
-            const bool zr = 4 * tJ + lcb < z;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[s][v] = (zr && v == zv) ? 0.0 : acc[s][v];
-          }
-        }
-        if (q < nb) {
-          if (tJ == qK && lane_qc) {  // column q: sub-blocks (4 I + v, q), 4 I + v >= q
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              const int bi = 4 * tI + v;
-              if (bi >= q && bi < nb) rawb[bi * MD_PITCH + 4 * lr + lc] = -acc[s][v];
-            }
-          }
-          if (GRAD && tI == qK) {  // row q: sub-blocks (q, bj), bj < q, transposed
-            const int bj = 4 * tJ + lcb;
-            if (bj < q) {
-              const double x = qv == 0 ? acc[s][0] : (qv == 1 ? acc[s][1] : (qv == 2 ? acc[s][2] : acc[s][3]));
-              rawb[bj * MD_PITCH + 4 * lc + lr] = -x;
-            }
-          }
-        }
-      }
-    };
-    events(-1, 0);
-    events(0, 1);
-    __syncthreads();
-    __syncthreads();
-    const int offA = ((lane & 15) >> 2) * MD_PITCH + 4 * (lane & 3) + (lane >> 4);
-    static_assert(MD_SLOTS == 23, "the hazard guards below name 23 accumulators");
-#define MD_ALL_ACC "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),       \
-                   "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]), \
-                   "+v"(acc[16]), "+v"(acc[17]), "+v"(acc[18]), "+v"(acc[19]), "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[22])
-    for (int p = 0; p < nb; ++p) {
-      const double* pp = P2[p & 1] + offA;
-      // (VALU writes to the accumulators -- the restarts of events() -- must have retired before an MFMA reads them)
-      asm volatile("s_nop 7\n\ts_nop 7" : MD_ALL_ACC);
-      // operands one slot ahead of the MFMA that consumes them
-      double pa[2], pb[2];
-      pa[0] = pp[4 * max(tIJ[0] >> 8, 0) * MD_PITCH];
-      pb[0] = pp[4 * (max(tIJ[0], 0) & 255) * MD_PITCH];
-#pragma unroll
-      for (int s = 0; s < MD_SLOTS; ++s) {
-        if (s + 1 < MD_SLOTS) {
-          pa[(s + 1) & 1] = pp[4 * max(tIJ[s + 1] >> 8, 0) * MD_PITCH];
-          pb[(s + 1) & 1] = pp[4 * (max(tIJ[s + 1], 0) & 255) * MD_PITCH];
-        }
-        if (tIJ[s] >= 0 && (GRAD || 4 * (tIJ[s] & 255) + 3 > p)) md_mfma(pa[s & 1], pb[s & 1], acc[s]);
-      }
-      // the drain names the accumulators as in/out operands so that no read of them can be scheduled above it
-      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : MD_ALL_ACC);
-      events(p + 1, p + 2);
-      __syncthreads();
-    }
-#undef MD_ALL_ACC
-    if (GRAD) {  // R^-1 = -S, lower triangle, column-major
-#pragma unroll
-      for (int s = 0; s < MD_SLOTS; ++s) {
-        if (tIJ[s] < 0) continue;
-        const int tI = tIJ[s] >> 8, tJ = tIJ[s] & 255;
-        const int col = 16 * tJ + (lane & 15);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int row = 16 * tI + 4 * v + lr;
-          if (row < N && col <= row) a.Rinv[(size_t)col * a.ldi + row] = acc[s][v];  // (negated state: -S = R^-1)
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- the likelihood's scalars (k_fit_rho's expressions) --------------------------------------------------------
-  double sff = 0.0, sfy = 0.0;
-  if (tid < N) {
-    const double f = ft[tid];
-    sff = f * f;
-    sfy = f * yt[tid];
-  }
-  sff = ns_block_sum(sff, red, nwaves);
-  sfy = ns_block_sum(sfy, red, nwaves);
-  const double nrm = sqrt(sff);
-  double coef;
-  if (a.estimate_trend) {
-    const double G = -nrm, qty = sfy / G;
-    coef = -(qty / G);
-  } else {
-    coef = -a.beta;
-  }
-  double srr = 0.0;
-  if (tid < N) {
-    const double rr = __builtin_fma(coef, ft[tid], yt[tid]);
-    srr = rr * rr;
-  }
-  srr = ns_block_sum(srr, red, nwaves);
-  if (tid == 0) {
-    a.scal[0] = s_logdet;
-    a.scal[1] = nrm;
-    a.scal[2] = sfy;
-    a.scal[3] = srr;
-    double iw = 0.0;
-    int info = s_info;
-    memcpy(&iw, &info, sizeof(info));
-    a.scal[62] = iw;
-    if (GRAD) {  // k_grad_coef's weights for one target
-      const double s2t = a.mode == BOGP_MODE_NOISY ? a.s2t_host : (a.mode == BOGP_MODE_NOISELESS ? srr / (N - (a.estimate_trend ? 1 : 0)) : srr / N);
-      a.coef[0] = 1.0 / s2t;
-      a.coef[8] = 1.0 / s2t;
-    }
-  }
-  if (GRAD && tid < N) a.gamma[tid] = -__builtin_fma(coef, g1[tid], gy[tid]);  // gamma = R^-1 y - beta R^-1 1
-}
-
-int spd_mid_max_n() { return 4 * MD_MAXNB; }
-hipError_t launch_spd_mid(bool grad, const SpdMidArgs& a, hipStream_t st) {
-  if (grad) hipLaunchKernelGGL((k_spd_mid<true>), dim3(1), MD_THREADS, 0, st, a);
-  else hipLaunchKernelGGL((k_spd_mid<false>), dim3(1), MD_THREADS, 0, st, a);
-  return hipGetLastError();
 }
 
 size_t nll_small_lds_bytes(int N, int d);

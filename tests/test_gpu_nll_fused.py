@@ -1,5 +1,5 @@
 """The one-launch likelihood of a small training set (csrc/kernels_nllsmall.hip: N <= 156, constant trend, one target) and the
-one-workgroup factor + inverse on the matrix cores for N <= 252 (k_spd_mid, same file, opt-in) against
+elimination at 64-block granularity above it, up to N = 2048 (csrc/kernels_chol.hip: k_elim_*), against
 (i) the general multi-kernel path of the same library (BOGP_NLL_FUSED=0) and (ii) the CPU oracle (oracle/gp_oracle.py, the
 restatement of gpr.py:772-808 / :931-1038) -- every correlation family, all three estimation modes, ARD and isotropic theta,
 estimated and fixed trend coefficient, sizes on every side of the 4 x 4 register blocks, a non-positive-definite matrix.
@@ -31,18 +31,6 @@ def general_path(fn):
         del os.environ["BOGP_NLL_FUSED"]
 
 
-@pytest.fixture(autouse=True, params=["elim", "spd_mid"])
-def mid_path(request):
-    """Above N = 156 the default is the elimination at 64-block granularity (k_elim_step, up to N = 1024); k_spd_mid (128 < N <= 252) is
-    opt-in -- it is slower than the general path it would replace -- and tested all the same."""
-    if request.param == "spd_mid":
-        os.environ["BOGP_NLL_MID"] = "1"
-        yield
-        del os.environ["BOGP_NLL_MID"]
-    else:
-        yield
-
-
 def make(N, d, seed):
     rng = np.random.default_rng(seed)
     X = rng.uniform(-3, 3, size=(N, d))
@@ -55,8 +43,8 @@ def make(N, d, seed):
 GRAD_KERNELS = [_lib.KERNEL_SE, _lib.KERNEL_MATERN12, _lib.KERNEL_MATERN32, _lib.KERNEL_MATERN52, _lib.KERNEL_ABSEXP]
 SIZES = [1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128,   # one launch (k_nll_small, 768 threads)
          129, 131, 144, 145, 153, 156,                                            # one launch (k_nll_small, 1024 threads)
-         157, 177, 192, 193, 200, 240, 249, 252,                                  # k_build_R + k_elim_* (or k_spd_mid, opt-in) + the gradient kernels
-         253, 256, 257, 320, 511, 512, 700, 1024, 1500, 2048,                     # k_elim_* (k_spd_mid stops at 252)
+         157, 177, 192, 193, 200, 240, 249, 252,                                  # k_build_R + k_elim_* + the gradient kernels
+         253, 256, 257, 320, 511, 512, 700, 1024, 1500, 2048,
          2049]                                                                    # the general path itself
 
 

@@ -30,19 +30,3 @@ for N, d in ((16, 2), (32, 5), (64, 5), (128, 5), (128, 10)):
         print("N=%3d d=%2d grad=%d: prologue %6.0f clk | per step: wait-W %5.0f  wait-panel %5.0f  update %5.0f | epilogue %6.0f clk | total %7.0f clk"
               % (N, d, grad, pro, tA / nb, tB / nb, tC / nb, epi, pro + tA + tB + tC + epi))
 
-# k_spd_mid (128 < N <= 252): the panel wave's own time per step and its wait for the owners (update + publish)
-lib.bogp_debug_dscal.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
-for N, d in ((160, 10), (200, 10), (252, 10)):
-    rng = np.random.default_rng(0)
-    X = rng.uniform(-5, 5, size=(N, d))
-    y = np.sum(X**2, axis=1)
-    y = ((y - y.mean()) / y.std()).reshape(-1, 1)
-    eng.set_train(X, y)
-    par = np.r_[np.full(d, 0.2 / d), 0.9]
-    for grad in (False, True):
-        for _ in range(3):
-            eng.nll(2, 1, par, 1e-6, True, 0.0, eval_grad=grad)
-        blk = (C.c_double * 64)()
-        lib.bogp_debug_dscal(eng._h, blk)
-        nb = (N + 3) // 4
-        print("N=%3d grad=%d (k_spd_mid): per step: panel %5.0f clk, wait for the owners %5.0f clk" % (N, grad, blk[22] / nb, blk[21] / nb))
