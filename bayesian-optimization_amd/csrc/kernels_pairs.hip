@@ -10,6 +10,8 @@
 // blocks through LDS in chunks of 16 dimensions (k-major, pitch 65: conflict-free stores and reads).  The first
 // versions gave one THREAD one pair and re-read 2 d coordinates from global memory per pair; at N = 8192, d = 50 they
 // took 2.5 ms and 5.2 ms of a 29-ms likelihood + gradient evaluation (profiles/r01_nll_n8192_kernel_stats.csv).
+#include <cstdlib>
+
 #include "bogp_device.h"
 #include "bogp_internal.h"
 
@@ -29,6 +31,19 @@ __device__ __forceinline__ void stage_points(double* dst, const double* __restri
     const int p = idx / KC, kk = idx % KC;
     const int gp = p0 + p, gk = kc + kk;
     dst[kk * PP + p] = (gp < N && gk < d) ? X[(size_t)gp * d + gk] : 0.0;
+  }
+}
+
+// the same for a tile side of 16 Q points (Q = 4: stage_points)
+template <int Q>
+__device__ __forceinline__ void stage_points_q(double* dst, const double* __restrict__ X, int N, int d, int p0, int kc, int tid) {
+  constexpr int PTQ = 16 * Q, PPQ = PTQ + 1;
+#pragma unroll
+  for (int it = 0; it < (PTQ * KC) / 256; ++it) {
+    const int idx = tid + 256 * it;
+    const int p = idx / KC, kk = idx % KC;
+    const int gp = p0 + p, gk = kc + kk;
+    dst[kk * PPQ + p] = (gp < N && gk < d) ? X[(size_t)gp * d + gk] : 0.0;
   }
 }
 
@@ -313,52 +328,53 @@ hipError_t launch_add_vec(double* y, const double* x, int N, hipStream_t st) {
 // Rinv arrives as `nparts` K-slices (lower triangles, part_stride doubles apart) that are added here.
 // Tile (bi <= bj): i in tile bi (thread columns), j in tile bj (thread rows); blk = bj (bj + 1) / 2 + bi.
 // ---------------------------------------------------------------------------------------------------------------
-template <int KERNEL>
+template <int KERNEL, int Q>
 __global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
                                                        const GradVecs gv,
                                                        const double* __restrict__ qv, double c2,
                                                        const double* __restrict__ Rinv, int ld, int nparts, size_t part_stride,
                                                        double* __restrict__ partial) {
-  __shared__ double xi[KC * PP], xj[KC * PP];
+  constexpr int PTQ = 16 * Q, PPQ = PTQ + 1;  // points per tile side (64 or 32), LDS pitch
+  __shared__ double xi[KC * PPQ], xj[KC * PPQ];
   __shared__ double red[4][KC + 1];
   const int bj = blockIdx.y, bi = blockIdx.x;  // j (rows, the larger index) tile, i (columns) tile
   if (bi > bj) return;
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15, lane = tid & 63, wv = tid >> 6;
-  const int i0 = bi * PT, j0 = bj * PT;
+  const int i0 = bi * PTQ, j0 = bj * PTQ;
   double* out = partial + ((size_t)bj * (bj + 1) / 2 + bi) * (d + 1);
 
   // ---- pass 1: weighted distances of the 16 pairs -> r0, h, A ------------------------------------------
-  double s2[4][4];
+  double s2[Q][Q];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < Q; ++r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) s2[r][c] = 0.0;
+    for (int c = 0; c < Q; ++c) s2[r][c] = 0.0;
   for (int kc = 0; kc < d; kc += KC) {
     __syncthreads();
-    stage_points(xi, X, N, d, i0, kc, tid);
-    stage_points(xj, X, N, d, j0, kc, tid);
+    stage_points_q<Q>(xi, X, N, d, i0, kc, tid);
+    stage_points_q<Q>(xj, X, N, d, j0, kc, tid);
     __syncthreads();
     const int kn = min(KC, d - kc);
     for (int kk = 0; kk < kn; ++kk) {
       const double th = theta[kc + kk];
-      double vj[4], vi[4];
+      double vj[Q], vi[Q];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) vj[r] = xj[kk * PP + 4 * ty + r];
+      for (int r = 0; r < Q; ++r) vj[r] = xj[kk * PPQ + Q * ty + r];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) vi[c] = xi[kk * PP + 4 * tx + c];
+      for (int c = 0; c < Q; ++c) vi[c] = xi[kk * PPQ + Q * tx + c];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < Q; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s2[r][c] += dist_term<KERNEL>(th, vi[c] - vj[r]);
+        for (int c = 0; c < Q; ++c) s2[r][c] += dist_term<KERNEL>(th, vi[c] - vj[r]);
     }
   }
-  double B[4][4];  // A_ij * h_ij (zero for pairs outside i < j < N)
+  double B[Q][Q];  // A_ij * h_ij (zero for pairs outside i < j < N)
   double sd = 0.0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < Q; ++r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int i = i0 + 4 * tx + c, j = j0 + 4 * ty + r;
+    for (int c = 0; c < Q; ++c) {
+      const int i = i0 + Q * tx + c, j = j0 + Q * ty + r;
       double bb = 0.0;
       if (i < j && j < N) {
         const double r0 = corr_profile<KERNEL>(s2[r][c]);
@@ -390,21 +406,21 @@ __global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict_
   // ---- pass 2: the d contractions, 16 dimensions at a time ---------------------------------------------
   for (int kc = 0; kc < d; kc += KC) {
     __syncthreads();
-    stage_points(xi, X, N, d, i0, kc, tid);
-    stage_points(xj, X, N, d, j0, kc, tid);
+    stage_points_q<Q>(xi, X, N, d, i0, kc, tid);
+    stage_points_q<Q>(xj, X, N, d, j0, kc, tid);
     __syncthreads();
     const int kn = min(KC, d - kc);
     for (int kk = 0; kk < kn; ++kk) {
-      double vj[4], vi[4];
+      double vj[Q], vi[Q];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) vj[r] = xj[kk * PP + 4 * ty + r];
+      for (int r = 0; r < Q; ++r) vj[r] = xj[kk * PPQ + Q * ty + r];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) vi[c] = xi[kk * PP + 4 * tx + c];
+      for (int c = 0; c < Q; ++c) vi[c] = xi[kk * PPQ + Q * tx + c];
       double acc = 0.0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < Q; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc += B[r][c] * (-dtheta_weight<KERNEL>(vi[c] - vj[r]));
+        for (int c = 0; c < Q; ++c) acc += B[r][c] * (-dtheta_weight<KERNEL>(vi[c] - vj[r]));
       acc = wave_sum(acc);
       if (lane == 0) red[wv][kk] = acc;
     }
@@ -415,18 +431,28 @@ __global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict_
   if (tid == 0) out[d] = ((red[0][KC] + red[1][KC]) + red[2][KC]) + red[3][KC];
 }
 
+// Tile side: 64 x 64 pairs (16 a thread) from N = 1025 on; 32 x 32 (4 a thread) below, 16 x 16 (one a thread) up to N = 256: a likelihood gradient of a few hundred
+// points is ten-odd workgroups either way, and a thread's 16 exp / sqrt chains were 25 us of a 175-us evaluation at N = 200
+static int grad_contract_q(int N) {
+  static const int q1max = [] { const char* e_ = getenv("BOGP_GRADC_Q1_MAX"); return e_ ? atoi(e_) : 256; }();
+  return N <= q1max ? 1 : (N <= 1024 ? 2 : 4);
+}
 int grad_contract_blocks(int N) {
-  const int nt = (N + PT - 1) / PT;
+  const int pt = 16 * grad_contract_q(N);
+  const int nt = (N + pt - 1) / pt;
   return nt * (nt + 1) / 2;
 }
 hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const double* theta, const GradVecs& gv,
                                 const double* qv, double c2, const double* Rinv, int ld, int nparts,
                                 size_t part_stride, double* partial, int nblk, hipStream_t st) {
-  const int nt = (N + PT - 1) / PT;
+  const int q = grad_contract_q(N), pt = 16 * q;
+  const int nt = (N + pt - 1) / pt;
   (void)nblk;
   const dim3 grid(nt, nt);
-#define CALL(K) \
-  hipLaunchKernelGGL((k_grad_contract<K>), grid, 256, 0, st, X, N, d, theta, gv, qv, c2, Rinv, ld, nparts, part_stride, partial)
+#define CALL(K)                                                                                                                     \
+  if (q == 1) hipLaunchKernelGGL((k_grad_contract<K, 1>), grid, 256, 0, st, X, N, d, theta, gv, qv, c2, Rinv, ld, nparts, part_stride, partial); \
+  else if (q == 2) hipLaunchKernelGGL((k_grad_contract<K, 2>), grid, 256, 0, st, X, N, d, theta, gv, qv, c2, Rinv, ld, nparts, part_stride, partial); \
+  else hipLaunchKernelGGL((k_grad_contract<K, 4>), grid, 256, 0, st, X, N, d, theta, gv, qv, c2, Rinv, ld, nparts, part_stride, partial)
   BOGP_FOR_KERNEL(kernel, CALL)
 #undef CALL
   return hipGetLastError();
