@@ -1,5 +1,10 @@
-import os, sys, time
-sys.path.insert(0, "/root/repo")
+"""Likelihood (+ gradient) latency at N = 1024 ... 3072 with and without the 64-block elimination (BOGP_NLL_ELIM=0 / BOGP_NLL_ELIM_MAX=4096):
+where k_elim_* stops paying (profiles/r03_nll_small.txt)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bogp import _lib
 eng = _lib.Engine(0)
