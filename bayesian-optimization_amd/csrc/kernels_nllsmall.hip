@@ -1,8 +1,9 @@
-// kernels_nllsmall.hip -- the WHOLE likelihood evaluation of a small training set (N <= 128, constant trend, one target) in ONE
-// launch of ONE workgroup (gfx950).
+// kernels_nllsmall.hip -- the WHOLE likelihood evaluation of a small training set (N <= 156, constant trend, one target) in ONE
+// launch of ONE workgroup (gfx950).  (Above that, up to N = 2048, the same elimination runs at 64-block granularity with one
+// workgroup a block: kernels_chol.hip, k_elim_*.)
 //
 // Why: at the sizes of an ordinary BO run an evaluation on the general path (bogp_api.hip: factorize + the gradient tail) is a
-// chain of ~15 launches of 3-8 us each, whatever their arithmetic; a BO loop is 98 % such evaluations
+// chain of ~18 launches, whatever their arithmetic; a BO loop is 98 % such evaluations
 // (profiles/r03_bo_loop.txt).  Here the correlation matrix never leaves the register file of one CU.
 //
 // What it computes (gpr.py:772-808 and :931-1038, the same quantities as the general path):
@@ -18,8 +19,9 @@
 // and until step i; from step i on the same registers accumulate block (i, j) of -R^-1.  With P[i] = the block of panel k that
 // block row i publishes (L(i, k) for i > k, X(i, k) for i <= k) EVERY thread does the same update at EVERY step,
 //   T -= P[bi] P[bj]^T        (64 FMAs, operands from a 5-KB LDS panel),
-// so the N^3 / 2 FMAs of factor + inverse + product are spread evenly over all threads and all steps, with two barriers per
-// step.  Block row nb continued the same way ends as -(R^-1 y)^T, -(R^-1 1)^T: gamma, by the reference's cho_solve route.
+// so the N^3 / 2 FMAs of factor + inverse + product are spread evenly over all threads and all steps (one barrier a step: the
+// panel is built by separate threads one step ahead, see k_nll_small).  Block row nb continued the same way ends as
+// -(R^-1 y)^T, -(R^-1 1)^T: gamma, by the reference's cho_solve route.
 #include "bogp_device.h"
 #include "bogp_internal.h"
 
