@@ -22,6 +22,8 @@
 // so the N^3 / 2 FMAs of factor + inverse + product are spread evenly over all threads and all steps (one barrier a step: the
 // panel is built by separate threads one step ahead, see k_nll_small).  Block row nb continued the same way ends as
 // -(R^-1 y)^T, -(R^-1 1)^T: gamma, by the reference's cho_solve route.
+#include <atomic>
+
 #include "bogp_device.h"
 #include "bogp_internal.h"
 
@@ -557,13 +559,20 @@ size_t nll_small_lds_bytes(int N, int d) {
   return ((((size_t)N * (d | 1) + 1) & ~(size_t)1) + (size_t)16 * (nb * (nb + 1) / 2)) * sizeof(double);
 }
 
-template <typename K>
-static hipError_t ns_launch(K kern, int block, size_t lds, const NllSmallArgs& a, hipStream_t st) {
-  if (lds > 24576) {  // (static + dynamic above the default 64 KB: raise it for this kernel; once would do, the call is cheap)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+template <auto KERN>
+static hipError_t ns_launch(int block, size_t lds, const NllSmallArgs& a, hipStream_t st) {
+  // static + dynamic LDS above the default 64 KB: the limit of this instantiation is raised, once per size reached (the largest
+  // request so far is remembered per instantiation and per device)
+  static std::atomic<size_t> raised[16];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<size_t>& r = raised[dev & 15];
+  if (lds > 24576 && lds > r.load(std::memory_order_relaxed)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    r.store(lds, std::memory_order_relaxed);
   }
-  hipLaunchKernelGGL(kern, dim3(1), block, lds, st, a);
+  hipLaunchKernelGGL(KERN, dim3(1), block, lds, st, a);
   return hipGetLastError();
 }
 
@@ -572,7 +581,7 @@ hipError_t launch_nll_small(int kernel, bool grad, const NllSmallArgs& a, hipStr
   const int nown = (nb + 1) * (nb + 2) / 2 - 1;
   const int block = ((4 * (nb + 1) + 63) / 64) * 64 + ((nown + 63) / 64) * 64;  // the panel waves + the owners
   const size_t lds = nll_small_lds_bytes(a.N, a.d);
-#define NS_GO(K, G) (block <= NS_THREADS_128 ? ns_launch(k_nll_small<K, G, NS_THREADS_128>, block, lds, a, st) : ns_launch(k_nll_small<K, G, NS_THREADS>, block, lds, a, st))
+#define NS_GO(K, G) (block <= NS_THREADS_128 ? ns_launch<k_nll_small<K, G, NS_THREADS_128>>(block, lds, a, st) : ns_launch<k_nll_small<K, G, NS_THREADS>>(block, lds, a, st))
   if (block > NS_THREADS || lds + 36 * 1024 > 160 * 1024) return hipErrorInvalidValue;  // (nll_small_fits() said otherwise)
   if (grad) {
     switch (kernel) {
