@@ -18,7 +18,7 @@ KERNEL_SE, KERNEL_MATERN12, KERNEL_MATERN32, KERNEL_MATERN52, KERNEL_ABSEXP, KER
 MODE_NOISELESS, MODE_NOISY, MODE_NOISE_ESTIM = 0, 1, 2
 ACQ_EI, ACQ_EPSILON_PI, ACQ_UCB, ACQ_MGFI = 0, 1, 2, 3
 TREND_CONSTANT, TREND_LINEAR, TREND_QUADRATIC = 0, 1, 2
-ABI_VERSION = 5  # BOGP_ABI_VERSION of include/bogp.h this binding table was written for
+ABI_VERSION = 6  # BOGP_ABI_VERSION of include/bogp.h this binding table was written for
 MAX_Q = 64
 MAX_TARGETS = 8
 COMM_ID_BYTES = 128
@@ -74,6 +74,7 @@ SIGNATURES = {
     "bogp_merge_topk": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _lp, _dp]),
     "bogp_last_timing": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip]),
     "bogp_flops_per_candidate": (C.c_double, [C.c_void_p]),
+    "bogp_nll_path": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "bogp_selftest_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, C.c_int, C.c_double, _dp, C.c_int, C.c_int, C.c_int]),
 }
 

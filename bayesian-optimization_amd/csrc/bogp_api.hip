@@ -395,6 +395,19 @@ static int factorize_finish(bogp_handle* h, const FitPending& fp, int info, cons
 // pend == nullptr: queue the device work, read info + scalars back, finish (ONE host synchronisation).
 // pend != nullptr: queue only -- the caller appends its own device work (the likelihood gradient), reads everything back in ONE
 // synchronisation and calls factorize_finish itself.
+extern "C" int bogp_nll_path(int N, int d, int trend, int n_targets) {
+  if (N <= 0 || d <= 0 || trend != BOGP_TREND_CONSTANT || n_targets != 1) return BOGP_NLL_PATH_GENERAL;
+  if (getenv("BOGP_NLL_FUSED") && atoi(getenv("BOGP_NLL_FUSED")) == 0) return BOGP_NLL_PATH_GENERAL;
+  if (nll_small_fits(N, d)) return BOGP_NLL_PATH_ONE_LAUNCH;
+  // 157 <= N <= 2048 (BOGP_NLL_ELIM_MAX; slower than the kernels it replaces from ~3000 on): factor + inverse + solves as one
+  // elimination at 64-block granularity (kernels_chol.hip: k_elim_step), one launch a block column; BOGP_NLL_ELIM=0 keeps the
+  // Cholesky / recursive-doubling / U U^T kernels
+  static const int elim_max = [] { const char* e_ = getenv("BOGP_NLL_ELIM_MAX"); return e_ ? atoi(e_) : 2048; }();
+  const int ld = ((N + 63) / 64) * 64;
+  if (N <= elim_max && N <= 6080 && ld >= 192 && !(getenv("BOGP_NLL_ELIM") && atoi(getenv("BOGP_NLL_ELIM")) == 0)) return BOGP_NLL_PATH_ELIM;
+  return BOGP_NLL_PATH_GENERAL;
+}
+
 // fz != nullptr: the caller only wants the likelihood (and its gradient sums), not the factor buffers -- a training set of at most
 // 128 points with the constant basis and one target is then evaluated by ONE launch (kernels_nllsmall.hip), `done` says so.
 struct FusedNll {
@@ -436,14 +449,12 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   if (theta_out) theta_out->assign(th, th + d);
   hipStream_t st = h->stream;
   HIPCHK(h, hipSetDevice(h->device));
-  const bool fused_ok = fz && trend == BOGP_TREND_CONSTANT && h->n_t == 1 && !(getenv("BOGP_NLL_FUSED") && atoi(getenv("BOGP_NLL_FUSED")) == 0);
+  const int path = fz ? bogp_nll_path(N, d, trend, h->n_t) : BOGP_NLL_PATH_GENERAL;
   // 157 <= N <= 2048 (BOGP_NLL_ELIM_MAX; slower than the kernels it replaces from ~3000 on): factor + inverse + solves as one elimination at 64-block granularity (kernels_chol.hip: k_elim_step), one
   // launch a block column; BOGP_NLL_ELIM=0 keeps the Cholesky / recursive-doubling / U U^T kernels
-  static const int elim_max = [] { const char* e_ = getenv("BOGP_NLL_ELIM_MAX"); return e_ ? atoi(e_) : 2048; }();
-  const bool elim = fused_ok && !nll_small_fits(N, d) && N <= elim_max && N <= 6080 && ldr >= 192 && ldr % 64 == 0 && (!fz->want_grad || pend) &&
-                    !(getenv("BOGP_NLL_ELIM") && atoi(getenv("BOGP_NLL_ELIM")) == 0);
+  const bool elim = path == BOGP_NLL_PATH_ELIM && (!fz->want_grad || pend);
   const bool mid = elim;
-  if (fused_ok && nll_small_fits(N, d)) {
+  if (path == BOGP_NLL_PATH_ONE_LAUNCH) {
     NllSmallArgs na;
     na.X = h->dX; na.y = h->dy_base; na.N = N; na.d = d;
     for (int k = 0; k < d; ++k) na.theta[k] = th[k];

@@ -28,7 +28,7 @@ extern "C" {
 typedef struct bogp_handle bogp_handle;
 
 /* error codes */
-#define BOGP_ABI_VERSION 5 /* what bogp_abi_version() of a matching library returns */
+#define BOGP_ABI_VERSION 6 /* what bogp_abi_version() of a matching library returns */
 #define BOGP_OK 0
 #define BOGP_ERR_INVALID (-1)      /* bad argument / call order                                           */
 #define BOGP_ERR_HIP (-2)          /* HIP runtime failure (or an in-kernel hand-over that timed out)       */
@@ -309,6 +309,18 @@ double bogp_flops_per_candidate(const bogp_handle* h);
  * What the reference gets from numpy.dot / scipy.linalg (gpr.py:799-808, 850-918); used by tests/test_gpu_gemm.py.        */
 int bogp_selftest_gemm(bogp_handle* h, int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda,
                        const double* B, int ldb, double beta, double* C, int ldc, int tri, int split);
+
+/* Which device path a concentrated-likelihood evaluation (bogp_nll) of N points in d dimensions would take with the constant
+ * basis (trend) and n_targets columns of y -- no handle, no device call (the decision is made from sizes and the environment
+ * switches alone; gpr.py:920-1040 is the function all three evaluate):
+ *   BOGP_NLL_PATH_GENERAL   the multi-kernel path (blocked Cholesky, recursive-doubling inverse, U U^T, ...)
+ *   BOGP_NLL_PATH_ONE_LAUNCH  the whole evaluation in one launch of one workgroup (k_nll_small; N <= 156 if it fits one CU's LDS)
+ *   BOGP_NLL_PATH_ELIM      one launch per 64 columns (k_elim_step; up to N = 2048)
+ * DESIGN.md section 5.12; used by tests/test_abi.py.                                                                         */
+#define BOGP_NLL_PATH_GENERAL 0
+#define BOGP_NLL_PATH_ONE_LAUNCH 1
+#define BOGP_NLL_PATH_ELIM 2
+int bogp_nll_path(int N, int d, int trend, int n_targets);
 
 #ifdef __cplusplus
 }

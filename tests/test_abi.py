@@ -40,7 +40,7 @@ def test_abi_version_and_constants_match_header():
     lib = _lib.load()
     src = open(HEADER).read()
     consts = dict(re.findall(r"#define\s+(BOGP_[A-Z_0-9]+)\s+\(?(-?\d+)\)?", src))
-    assert lib.bogp_abi_version() == int(consts["BOGP_ABI_VERSION"]) == _lib.ABI_VERSION == 5
+    assert lib.bogp_abi_version() == int(consts["BOGP_ABI_VERSION"]) == _lib.ABI_VERSION == 6
     assert int(consts["BOGP_KERNEL_MATERN52"]) == _lib.KERNEL_MATERN52 == 3
     assert int(consts["BOGP_MODE_NOISE_ESTIM"]) == _lib.MODE_NOISE_ESTIM == 2
     assert int(consts["BOGP_ACQ_MGFI"]) == _lib.ACQ_MGFI == 3
@@ -49,6 +49,34 @@ def test_abi_version_and_constants_match_header():
     assert int(consts["BOGP_MAX_Q"]) == _lib.MAX_Q
     assert int(consts["BOGP_TREND_QUADRATIC"]) == _lib.TREND_QUADRATIC == 2
     assert lib.bogp_trend_size(0, 7) == 1 and lib.bogp_trend_size(1, 7) == 8 and lib.bogp_trend_size(2, 7) == 36
+
+
+def test_likelihood_path_by_size():
+    """bogp_nll_path: which device path a likelihood evaluation takes is decided from the sizes alone (no handle, no device call):
+    one launch of one workgroup up to N = 156 while X and the block image fit one CU's LDS, one launch per 64 columns up to
+    N = 2048, the multi-kernel path above, for polynomial bases and for several targets."""
+    lib = _lib.load()
+    consts = dict(re.findall(r"#define\s+(BOGP_[A-Z_0-9]+)\s+\(?(-?\d+)\)?", open(HEADER).read()))
+    general, one, elim = (int(consts["BOGP_NLL_PATH_" + k]) for k in ("GENERAL", "ONE_LAUNCH", "ELIM"))
+    p = lib.bogp_nll_path
+    assert [p(n, 10, 0, 1) for n in (1, 16, 128, 129, 156)] == [one] * 5
+    assert [p(n, 10, 0, 1) for n in (157, 192, 256, 1024, 2048)] == [elim] * 5
+    assert p(2049, 10, 0, 1) == general and p(8192, 50, 0, 1) == general
+    assert p(100, 64, 0, 1) == one and p(100, 65, 0, 1) == general      # theta travels as a kernel argument: d <= 64; ld = 128 < 192
+    assert p(150, 40, 0, 1) == elim                                       # X + the block image exceed 160 KB of LDS: next path
+    assert p(100, 5, 1, 1) == general and p(100, 5, 2, 1) == general      # linear / quadratic basis
+    assert p(100, 5, 0, 2) == general                                     # several targets
+    assert p(0, 5, 0, 1) == general and p(10, 0, 0, 1) == general
+    os.environ["BOGP_NLL_FUSED"] = "0"
+    try:
+        assert p(64, 5, 0, 1) == general and p(300, 5, 0, 1) == general
+    finally:
+        del os.environ["BOGP_NLL_FUSED"]
+    os.environ["BOGP_NLL_ELIM"] = "0"
+    try:
+        assert p(64, 5, 0, 1) == one and p(300, 5, 0, 1) == general
+    finally:
+        del os.environ["BOGP_NLL_ELIM"]
 
 
 def test_oracle_ids_match_library_ids():
