@@ -34,6 +34,7 @@ namespace {
 constexpr int NS_BS = 4;           // block size
 constexpr int NS_MAXNB = 39;       // N <= 156 (the 1024-thread instantiation; N <= 128 runs the 768-thread one)
 constexpr int NS_PITCH = NS_MAXNB + 2;
+__device__ __forceinline__ int ns_pidx(int e, int i) { return (e >> 1) * (2 * NS_PITCH) + 2 * i + (e & 1); }
 constexpr int NS_THREADS = 1024;   // 4 (nb + 1) panel threads (3 waves) + (nb + 1)(nb + 2) / 2 - 1 owners: 132 + 560 at nb = 32, 160 + 819 at nb = 39
 constexpr int NS_THREADS_128 = 768;  // N <= 128: 12 waves = 3 a SIMD = 168 registers a lane; 16 waves leave 128
 constexpr int NS_WAVES = NS_THREADS / 64;
@@ -141,7 +142,9 @@ __device__ __forceinline__ void ns_corr_pair(double s2, double& r0, double& h) {
 template <int KERNEL, bool GRAD, int TMAX>
 __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
   extern __shared__ double dyn[];      // Xs[N][dP] | Rst[16][nbR]: the blocks of R, later of R^-1, element-major
-  __shared__ double P[2][16 * NS_PITCH];  // P[step & 1][e * NS_PITCH + i]: element e = 4 r + c of block row i's panel block
+  // P[step & 1][ns_pidx(e, i)]: element e = 4 r + c of block row i's panel block, elements 2 q and 2 q + 1 next to each other so
+  // that an owner fetches its operands with 16 ds_read_b128 instead of 32 ds_read_b64 (consecutive owners: consecutive 16-byte words)
+  __shared__ __attribute__((aligned(16))) double P[2][16 * NS_PITCH];
   __shared__ double Raw[2][16 * NS_PITCH];
   __shared__ double yt[NS_BS * NS_MAXNB], ft[NS_BS * NS_MAXNB], gam[NS_BS * NS_MAXNB];
   __shared__ double red[NS_WAVES];
@@ -285,12 +288,12 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
         if (kn > 0) {
           // update kn - 1 of the copies: row pr of M -= P[i] P[kn]^T, and the diagonal block D -= P[kn] P[kn]^T from the panel in
           // LDS (the factorisation below then depends on 4 FMAs, not on another thread's row)
-          const double* q = P[(kn - 1) & 1] + kn;
+          const double* q = P[(kn - 1) & 1];
           double Q[4][4];
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) Q[r][m] = q[(4 * r + m) * NS_PITCH];
+            for (int m = 0; m < 4; ++m) Q[r][m] = q[ns_pidx(4 * r + m, kn)];
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
           for (int m = 0; m < c; ++m) v = __builtin_fma(-T[0][m], l[c][m], v);
           v = used ? v * inv[c] : 0.0;
           T[0][c] = v;
-          if ((tid >> 2) <= nb) pdst[(4 * pr + c) * NS_PITCH + i] = v;
+          if ((tid >> 2) <= nb) pdst[ns_pidx(4 * pr + c, i)] = v;
         }
         if ((tid >> 2) == nb && pr < 2) {
 #pragma unroll
@@ -348,9 +351,13 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            pa[r][c] = pp[(4 * r + c) * NS_PITCH + bi];
-            pb[r][c] = pp[(4 * r + c) * NS_PITCH + bj];
+          for (int c = 0; c < 4; c += 2) {
+            const double2 va = *reinterpret_cast<const double2*>(pp + ns_pidx(4 * r + c, bi));
+            const double2 vb = *reinterpret_cast<const double2*>(pp + ns_pidx(4 * r + c, bj));
+            pa[r][c] = va.x;
+            pa[r][c + 1] = va.y;
+            pb[r][c] = vb.x;
+            pb[r][c + 1] = vb.y;
           }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
