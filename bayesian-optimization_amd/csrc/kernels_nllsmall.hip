@@ -293,7 +293,11 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) Q[r][m] = q[ns_pidx(4 * r + m, kn)];
+            for (int m = 0; m < 4; m += 2) {
+              const double2 v = *reinterpret_cast<const double2*>(q + ns_pidx(4 * r + m, kn));
+              Q[r][m] = v.x;
+              Q[r][m + 1] = v.y;
+            }
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
