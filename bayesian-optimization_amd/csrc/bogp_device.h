@@ -165,4 +165,47 @@ __device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int mask) {
   return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 
+// ---- 4 x 4 pivot arithmetic of the in-place elimination (kernels_nllsmall.hip: k_nll_small; kernels_chol.hip: elim_diag) ----
+// sqrt(p) and 1 / sqrt(p) of a pivot 0 < p (no range scaling: pivots of a correlation matrix lie in (1e-300, 4)): the hardware's
+// reciprocal square root estimate + ONE third-order (Halley) step -- five dependent operations where sqrt() followed by a
+// division is ~45; a dependent FP64 operation costs ~26 cycles in a lone wave and this chain is on the critical path of EVERY
+// step (kernels_chol.hip: rsqrt_nr, same arithmetic)
+__device__ __forceinline__ void ns_sqrt_rsqrt(double p, double& root, double& inv) {
+  const double y = __builtin_amdgcn_rsq(p);
+  const double t = p * y;
+  const double e = __builtin_fma(-t, y, 1.0);
+  double q = __builtin_fma(0.375, e, 0.5);
+  q = q * e;
+  inv = __builtin_fma(y, q, y);
+  root = p * inv;
+}
+
+// 4 x 4 Cholesky of the lower triangle of a: l (strict lower part) and inv[c] = 1 / l_cc -- the panel's rows are then solved by
+// substitution, o = M L^-T, column c of o as soon as pivot c is known: off the pivots' dependent chain except for one product
+__device__ __forceinline__ int ns_factor4_sub(const double (&a)[4][4], double (&l)[4][4], double (&inv)[4], double& pivprod) {
+  int bad = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double p = a[c][c];
+#pragma unroll
+    for (int m = 0; m < c; ++m) p = __builtin_fma(-l[c][m], l[c][m], p);
+    if (!(p > 0.0) || !(p < 1e300)) {
+      if (!bad) bad = c + 1;
+      p = 1.0;
+    }
+    double lc;
+    ns_sqrt_rsqrt(p, lc, inv[c]);
+    l[c][c] = lc;
+    pivprod *= lc;
+#pragma unroll
+    for (int r = c + 1; r < 4; ++r) {
+      double v = a[r][c];
+#pragma unroll
+      for (int m = 0; m < c; ++m) v = __builtin_fma(-l[r][m], l[c][m], v);
+      l[r][c] = v * inv[c];
+    }
+  }
+  return bad;
+}
+
 }  // namespace bogp
