@@ -249,18 +249,170 @@ __device__ __forceinline__ int diag_factor_invert(const double* cs, double* sb, 
   return (int)flag[0];
 }
 
-// lower triangle of L into the matrix, W (dense, zeros above the diagonal) into its 64 x 64 column-major buffer
-__device__ __forceinline__ void diag_store(double* __restrict__ Ad /* &A[i0 + i0*ld] */, int ld, double* __restrict__ Wk,
-                                           const double (&a)[4][4], const double (&w)[4][4], int tid) {
-  const int tr = tid >> 4, tc = tid & 15;
+// The 64 x 64 diagonal block by k_nll_small's pipelined scheme (r03; it replaced diag_factor_invert above in every kernel but the
+// opt-in k_chol_chain): the block cut into
+// 4 x 4 blocks, threads 0 .. 63 = the panel (one a ROW of a panel block: block row i = tid / 4), threads 64 .. 199 = one owner a
+// block of the lower triangle, ONE barrier a 4-column step, the panel built one step ahead on copied-out blocks.  L and W = L^-1
+// ARE the panels (L(i, kn) = P_kn[i] for i > kn; X = L^-T appears column by column: W(4 kn + c, 4 i + r) = X(i, kn)[r][c], i <= kn),
+// so an owner's work ends at step bi (no -R^-1 phase) and the panel threads store both straight to global memory: W (dense, zeros
+// above the diagonal) into its 64 x 64 column-major buffer, the lower triangle of L into the matrix at Ad (nullptr: not wanted).
+// ~12.5 us a block against diag_factor_invert's 19.5.  ED_LDS doubles of LDS scratch; returns LAPACK's info (valid in thread 0),
+// *logsum (if given, thread 0) = sum(log diag L).
+constexpr int ED_PITCH = 18;
+constexpr int ED_LDS = 4 * 16 * ED_PITCH;
+__device__ __forceinline__ int ed_pidx(int e, int i) { return (e >> 1) * (2 * ED_PITCH) + 2 * i + (e & 1); }
+__device__ __forceinline__ void ed_tri_index(int q, int& bi, int& bj) {  // q = bi (bi + 1) / 2 + bj, bj <= bi
+  bi = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+  while ((bi + 1) * (bi + 2) / 2 <= q) ++bi;
+  while (bi * (bi + 1) / 2 > q) --bi;
+  bj = q - bi * (bi + 1) / 2;
+}
+__device__ __forceinline__ int diag_pipe(const double* cs, double* scr, double* __restrict__ Wn, double* __restrict__ Ad, int ld, int nlive,
+                                         int tid, double* logsum) {
+  double* P = scr;                        // [2][16 * ED_PITCH], pair layout (ed_pidx)
+  double* Raw = scr + 2 * 16 * ED_PITCH;  // [2][16 * ED_PITCH], element-major
+  const int nb = min(16, (nlive + 3) >> 2);
+  // what no panel thread writes: zeros above the diagonal of W, the identity of the padding (W and the lower triangle of L)
+  for (int e = tid; e < CB * CB; e += 256) {
+    const int r = e & 63, col = e >> 6;
+    const bool pad = r >= 4 * nb || col >= 4 * nb;
+    if (r < col || pad) Wn[col * CB + r] = r == col ? 1.0 : 0.0;
+    if (Ad != nullptr && pad && r >= col) Ad[(size_t)col * ld + r] = r == col ? 1.0 : 0.0;
+  }
+  const int ot = tid - 64;
+  int bi = 0, bj = 0;
+  if (ot >= 0) ed_tri_index(ot, bi, bj);
+  const bool live = ot >= 0 && bi < nb;
+  double T[4][4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = 4 * tr + i, col = 4 * tc + c;
-      if (r >= col) Ad[(size_t)col * ld + r] = a[i][c];
-      Wk[col * CB + r] = tc <= tr ? w[i][c] : 0.0;  // W tiles carry their own zeros above the diagonal
+    for (int c = 0; c < 4; ++c) T[r][c] = live ? cs[(4 * bi + r) * (CB + 1) + 4 * bj + c] : 0.0;
+#define ED_PUBLISH(q_)                                                                                  \
+  {                                                                                                     \
+    const int q = (q_);                                                                                 \
+    if (live && q < nb && (bj == q || bi == q)) {                                                       \
+      double* rawb = Raw + (q & 1) * 16 * ED_PITCH;                                                     \
+      if (bj == q) {                                                                                    \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                   \
+          _Pragma("unroll") for (int c = 0; c < 4; ++c) rawb[(4 * r + c) * ED_PITCH + bi] = T[r][c];    \
+      } else {                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                   \
+          _Pragma("unroll") for (int c = 0; c < 4; ++c) rawb[(4 * r + c) * ED_PITCH + bj] = T[c][r];    \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
+#define ED_RESTART(z_)                                                                                  \
+  {                                                                                                     \
+    const int z = (z_);                                                                                 \
+    if (live && z < nb && bj == z) {                                                                    \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                     \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) T[r][c] = 0.0;                                    \
+    }                                                                                                   \
+  }
+  ED_PUBLISH(0)
+  ED_RESTART(0)
+  ED_PUBLISH(1)
+  double pivm = 1.0;
+  int pive = 0, bad_all = 0;
+  __syncthreads();
+  for (int kn = 0; kn <= nb; ++kn) {  // the panel threads: P_kn; the owners: update kn - 1
+    if (tid < 64) {
+      if (kn < nb) {
+        const int i = min(tid >> 2, nb - 1), pr = tid & 3;
+        double D[4][4], l[4][4], inv[4], Mr[4];
+        const double* rawb = Raw + (kn & 1) * 16 * ED_PITCH;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Mr[c] = rawb[(4 * pr + c) * ED_PITCH + i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c <= r; ++c) D[r][c] = rawb[(4 * r + c) * ED_PITCH + kn];
+        if (kn > 0) {
+          const double* q = P + ((kn - 1) & 1) * 16 * ED_PITCH;
+          double Q[4][4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) Q[r][m] = q[ed_pidx(4 * r + m, kn)];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+              double sacc = D[r][c];
+#pragma unroll
+              for (int m = 0; m < 4; ++m) sacc = __builtin_fma(-Q[r][m], Q[c][m], sacc);
+              D[r][c] = sacc;
+            }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            double sacc = Mr[c];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sacc = __builtin_fma(-T[0][m], Q[c][m], sacc);
+            Mr[c] = sacc;
+          }
+        }
+        double prod4 = 1.0;
+        const int bad = ns_factor4_sub(D, l, inv, prod4);
+        if (tid == 0) {
+          if (bad && bad_all == 0) bad_all = 4 * kn + bad;
+          int e2;
+          pivm = frexp(pivm * prod4, &e2);
+          pive += e2;
+        }
+        if (i == kn) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) Mr[c] = pr == c ? 1.0 : 0.0;
+        }
+        double* pdst = P + (kn & 1) * 16 * ED_PITCH;
+        const bool mine = (tid >> 2) < nb;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          double v = Mr[c];
+#pragma unroll
+          for (int m = 0; m < c; ++m) v = __builtin_fma(-T[0][m], l[c][m], v);
+          v = v * inv[c];
+          T[0][c] = v;
+          if (mine) pdst[ed_pidx(4 * pr + c, i)] = v;
+          if (mine && i <= kn) Wn[(4 * i + pr) * CB + 4 * kn + c] = v;  // W(4 kn + c, 4 i + pr) = X(i, kn)[pr][c]
+          if (Ad != nullptr && mine && i > kn) Ad[(size_t)(4 * kn + c) * ld + 4 * i + pr] = v;  // L(4 i + pr, 4 kn + c)
+          if (Ad != nullptr && mine && i == kn && c <= pr) {  // row pr of the 4 x 4 factor (selected WITHOUT a run-time register index)
+            const double lv = pr == 0 ? l[0][c] : (pr == 1 ? l[1][c < 2 ? c : 1] : (pr == 2 ? l[2][c < 3 ? c : 2] : l[3][c]));
+            Ad[(size_t)(4 * kn + c) * ld + 4 * kn + pr] = lv;
+          }
+        }
+      }
+    } else if (kn > 0) {
+      const int p = kn - 1;
+      if (live && p < bi) {  // R phase (p < bj) or X phase (bj <= p < bi); nothing after step bi
+        const double* pp = P + (p & 1) * 16 * ED_PITCH;
+        double pa[4][4], pb[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            pa[r][c] = pp[ed_pidx(4 * r + c, bi)];
+            pb[r][c] = pp[ed_pidx(4 * r + c, bj)];
+          }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            double sacc = T[r][c];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sacc = __builtin_fma(-pa[r][m], pb[c][m], sacc);
+            T[r][c] = sacc;
+          }
+      }
+      ED_RESTART(kn)
+      ED_PUBLISH(kn + 1)
     }
+    __syncthreads();
+  }
+#undef ED_PUBLISH
+#undef ED_RESTART
+  if (tid == 0 && logsum != nullptr) *logsum = log(pivm) + (double)pive * 0.6931471805599453;
+  return bad_all;
 }
 
 }  // namespace
@@ -280,9 +432,7 @@ __device__ __forceinline__ void diag_from_global(double* __restrict__ A, int ld,
     cs[r * (CB + 1) + c] = A[(size_t)c * ld + r];
   }
   __syncthreads();
-  double a[4][4], w[4][4];
-  const int bad = diag_factor_invert(cs, sb, a, w, tid, nlive);
-  diag_store(A, ld, W0, a, w, tid);
+  const int bad = diag_pipe(cs, sb, W0, A, ld, nlive, tid, nullptr);
   if (tid == 0) {
     if (reset)
       *info = bad;  // also resets the flag of the previous factorisation
@@ -294,7 +444,7 @@ __device__ __forceinline__ void diag_from_global(double* __restrict__ A, int ld,
 __global__ __launch_bounds__(256) void k_chol_first(double* __restrict__ A, int ld, double* __restrict__ W0, int* __restrict__ info,
                                                     int base = 0, int reset = 1, int nlive = CB) {
   __shared__ __attribute__((aligned(16))) double cs[CB * (CB + 1)];
-  __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
+  __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
   diag_from_global(A, ld, W0, info, base, reset, cs, sb, nlive);
 }
 
@@ -345,7 +495,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
                                                      double* __restrict__ Wn, int* __restrict__ info, double* __restrict__ Pnext,
                                                      int tri_grid, int nlive) {
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];  // 40 KB: A-side tile, then the 64 x 65 block staging
-  __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
+  __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
   int bi, bj;
   if (nc == m && tri_grid) {
     tri_index((int)blockIdx.x, bi, bj);
@@ -404,9 +554,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
 #pragma unroll
     for (int t = 0; t < 4; ++t) lds[(16 * w + (lane & 15)) * (CB + 1) + 16 * mi + 4 * t + lk] = -acc[mi][t];
   __syncthreads();
-  double a[4][4], ww[4][4];
-  const int bad = diag_factor_invert(lds, sb, a, ww, tid, nlive);
-  diag_store(Ab, ld, Wn, a, ww, tid);
+  const int bad = diag_pipe(lds, sb, Wn, Ab, ld, nlive, tid, nullptr);
   if (tid == 0 && bad != 0 && *info == 0) *info = i0 + bad;
 }
 
@@ -528,7 +676,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int l
                                                    double* __restrict__ Wn, int* __restrict__ info, int tri_grid, int nlive,
                                                    unsigned int* __restrict__ flagW, unsigned int* __restrict__ flagT) {
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
-  __shared__ __attribute__((aligned(16))) double sb[DIAG_SB];
+  __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
   int bi, bj;
   if (tri_grid) {
     tri_index((int)blockIdx.x, bi, bj);
@@ -622,9 +770,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int l
 #pragma unroll
     for (int t = 0; t < 4; ++t) lds[(16 * w + (lane & 15)) * (CB + 1) + 16 * mi + 4 * t + lk] = -acc[mi][t];
   __syncthreads();
-  double a[4][4], ww[4][4];
-  const int bad = diag_factor_invert(lds, sb, a, ww, tid, nlive);
-  diag_store(Ab, ld, Wn, a, ww, tid);
+  const int bad = diag_pipe(lds, sb, Wn, Ab, ld, nlive, tid, nullptr);
   if (tid == 0 && bad != 0 && *info == 0) *info = i0 + bad;
 }
 
@@ -1343,158 +1489,20 @@ __device__ __forceinline__ double* elim_tile(const ElimArgs& a, int bi, int bj, 
   ldt = CB;
   return a.Eb + (size_t)bj * CB * CB;
 }
-// The 64 x 64 diagonal block of a step by k_nll_small's pipelined scheme instead of diag_factor_invert (r03): the block cut into
-// 4 x 4 blocks, threads 0 .. 63 = the panel (one a ROW of a panel block: block row i = tid / 4), threads 64 .. 199 = one owner a
-// block of the lower triangle, ONE barrier a 4-column step, the panel built one step ahead on copied-out blocks.  Only W = L^-1
-// is wanted here (X = L^-T appears column by column in the panels: W(4 kn + c, 4 i + r) = X(i, kn)[r][c], i <= kn), so an
-// owner's work ends at step bi (no -R^-1 phase), and the panel threads store W straight to global memory.  ~2100 cycles a
-// step against diag_factor_invert's 2900.  ED_LDS doubles of LDS scratch.
-constexpr int ED_PITCH = 18;
-constexpr int ED_LDS = 4 * 16 * ED_PITCH;
-__device__ __forceinline__ int ed_pidx(int e, int i) { return (e >> 1) * (2 * ED_PITCH) + 2 * i + (e & 1); }
+// the diagonal block of an elimination step: diag_pipe + the identity rows of block row kb in the raw panel + sum(log diag L) + info
 __device__ __forceinline__ void elim_diag2(const double* cs, double* scr, double* __restrict__ Wn, double* __restrict__ logpart,
                                            int* __restrict__ info, int base, int reset, int nlive, double* __restrict__ Pn, int lde,
                                            int kb, int tid) {
-  double* P = scr;                        // [2][16 * ED_PITCH], pair layout (ed_pidx)
-  double* Raw = scr + 2 * 16 * ED_PITCH;  // [2][16 * ED_PITCH], element-major
-  const int nb = min(16, (nlive + 3) >> 2);
-  // what no panel thread writes: zeros above the diagonal, the identity of the padding; and the identity rows of the raw panel
   for (int e = tid; e < CB * CB; e += 256) {
     const int r = e & 63, col = e >> 6;
-    if (r < col || r >= 4 * nb || col >= 4 * nb) Wn[col * CB + r] = r == col ? 1.0 : 0.0;
     Pn[(size_t)col * lde + (size_t)kb * CB + r] = r == col ? 1.0 : 0.0;
   }
-  const int ot = tid - 64;
-  int bi = 0, bj = 0;
-  if (ot >= 0) tri_index(ot, bi, bj);
-  const bool live = ot >= 0 && bi < nb;
-  double T[4][4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) T[r][c] = live ? cs[(4 * bi + r) * (CB + 1) + 4 * bj + c] : 0.0;
-#define ED_PUBLISH(q_)                                                                                  \
-  {                                                                                                     \
-    const int q = (q_);                                                                                 \
-    if (live && q < nb && (bj == q || bi == q)) {                                                       \
-      double* rawb = Raw + (q & 1) * 16 * ED_PITCH;                                                     \
-      if (bj == q) {                                                                                    \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                   \
-          _Pragma("unroll") for (int c = 0; c < 4; ++c) rawb[(4 * r + c) * ED_PITCH + bi] = T[r][c];    \
-      } else {                                                                                          \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                   \
-          _Pragma("unroll") for (int c = 0; c < 4; ++c) rawb[(4 * r + c) * ED_PITCH + bj] = T[c][r];    \
-      }                                                                                                 \
-    }                                                                                                   \
-  }
-#define ED_RESTART(z_)                                                                                  \
-  {                                                                                                     \
-    const int z = (z_);                                                                                 \
-    if (live && z < nb && bj == z) {                                                                    \
-      _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                     \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) T[r][c] = 0.0;                                    \
-    }                                                                                                   \
-  }
-  ED_PUBLISH(0)
-  ED_RESTART(0)
-  ED_PUBLISH(1)
-  double pivm = 1.0;
-  int pive = 0, bad_all = 0;
-  __syncthreads();
-  for (int kn = 0; kn <= nb; ++kn) {  // the panel threads: P_kn; the owners: update kn - 1
-    if (tid < 64) {
-      if (kn < nb) {
-        const int i = min(tid >> 2, nb - 1), pr = tid & 3;
-        double D[4][4], l[4][4], inv[4], Mr[4];
-        const double* rawb = Raw + (kn & 1) * 16 * ED_PITCH;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Mr[c] = rawb[(4 * pr + c) * ED_PITCH + i];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c <= r; ++c) D[r][c] = rawb[(4 * r + c) * ED_PITCH + kn];
-        if (kn > 0) {
-          const double* q = P + ((kn - 1) & 1) * 16 * ED_PITCH;
-          double Q[4][4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) Q[r][m] = q[ed_pidx(4 * r + m, kn)];
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c <= r; ++c) {
-              double sacc = D[r][c];
-#pragma unroll
-              for (int m = 0; m < 4; ++m) sacc = __builtin_fma(-Q[r][m], Q[c][m], sacc);
-              D[r][c] = sacc;
-            }
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            double sacc = Mr[c];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) sacc = __builtin_fma(-T[0][m], Q[c][m], sacc);
-            Mr[c] = sacc;
-          }
-        }
-        double prod4 = 1.0;
-        const int bad = ns_factor4_sub(D, l, inv, prod4);
-        if (tid == 0) {
-          if (bad && bad_all == 0) bad_all = 4 * kn + bad;
-          int e2;
-          pivm = frexp(pivm * prod4, &e2);
-          pive += e2;
-        }
-        if (i == kn) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) Mr[c] = pr == c ? 1.0 : 0.0;
-        }
-        double* pdst = P + (kn & 1) * 16 * ED_PITCH;
-        const bool mine = (tid >> 2) < nb;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          double v = Mr[c];
-#pragma unroll
-          for (int m = 0; m < c; ++m) v = __builtin_fma(-T[0][m], l[c][m], v);
-          v = v * inv[c];
-          T[0][c] = v;
-          if (mine) pdst[ed_pidx(4 * pr + c, i)] = v;
-          if (mine && i <= kn) Wn[(4 * i + pr) * CB + 4 * kn + c] = v;  // W(4 kn + c, 4 i + pr) = X(i, kn)[pr][c]
-        }
-      }
-    } else if (kn > 0) {
-      const int p = kn - 1;
-      if (live && p < bi) {  // R phase (p < bj) or X phase (bj <= p < bi); nothing after step bi
-        const double* pp = P + (p & 1) * 16 * ED_PITCH;
-        double pa[4][4], pb[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            pa[r][c] = pp[ed_pidx(4 * r + c, bi)];
-            pb[r][c] = pp[ed_pidx(4 * r + c, bj)];
-          }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            double sacc = T[r][c];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) sacc = __builtin_fma(-pa[r][m], pb[c][m], sacc);
-            T[r][c] = sacc;
-          }
-      }
-      ED_RESTART(kn)
-      ED_PUBLISH(kn + 1)
-    }
-    __syncthreads();
-  }
-#undef ED_PUBLISH
-#undef ED_RESTART
+  double ls = 0.0;
+  const int bad = diag_pipe(cs, scr, Wn, nullptr, 0, nlive, tid, &ls);
   if (tid == 0) {
-    *logpart = log(pivm) + (double)pive * 0.6931471805599453;
-    if (reset) *info = bad_all;
-    else if (bad_all != 0 && *info == 0) *info = base + bad_all;
+    *logpart = ls;
+    if (reset) *info = bad;
+    else if (bad != 0 && *info == 0) *info = base + bad;
   }
 }
 
