@@ -256,7 +256,7 @@ __device__ __forceinline__ int diag_factor_invert(const double* cs, double* sb, 
 // ARE the panels (L(i, kn) = P_kn[i] for i > kn; X = L^-T appears column by column: W(4 kn + c, 4 i + r) = X(i, kn)[r][c], i <= kn),
 // so an owner's work ends at step bi (no -R^-1 phase) and the panel threads store both straight to global memory: W (dense, zeros
 // above the diagonal) into its 64 x 64 column-major buffer, the lower triangle of L into the matrix at Ad (nullptr: not wanted).
-// ~12.5 us a block against diag_factor_invert's 19.5.  ED_LDS doubles of LDS scratch; returns LAPACK's info (valid in thread 0),
+// ~14 us a block (16 steps of ~2100 cycles) against diag_factor_invert's 19.5.  ED_LDS doubles of LDS scratch; returns LAPACK's info (valid in thread 0),
 // *logsum (if given, thread 0) = sum(log diag L).
 constexpr int ED_PITCH = 18;
 constexpr int ED_LDS = 4 * 16 * ED_PITCH;
