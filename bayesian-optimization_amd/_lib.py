@@ -18,7 +18,7 @@ KERNEL_SE, KERNEL_MATERN12, KERNEL_MATERN32, KERNEL_MATERN52, KERNEL_ABSEXP, KER
 MODE_NOISELESS, MODE_NOISY, MODE_NOISE_ESTIM = 0, 1, 2
 ACQ_EI, ACQ_EPSILON_PI, ACQ_UCB, ACQ_MGFI = 0, 1, 2, 3
 TREND_CONSTANT, TREND_LINEAR, TREND_QUADRATIC = 0, 1, 2
-ABI_VERSION = 6  # BOGP_ABI_VERSION of include/bogp.h this binding table was written for
+ABI_VERSION = 7  # BOGP_ABI_VERSION of include/bogp.h this binding table was written for
 MAX_Q = 64
 MAX_TARGETS = 8
 COMM_ID_BYTES = 128
@@ -37,6 +37,7 @@ SIGNATURES = {
     "bogp_set_train": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_int]),
     "bogp_select_target": (C.c_int, [C.c_void_p, C.c_int]),
     "bogp_nll": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp, _dp]),
+    "bogp_nll_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp, _dp, _ip]),
     "bogp_commit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp]),
     "bogp_nll_restricted": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp, _dp]),
     "bogp_get_state": (C.c_int, [C.c_void_p] + [_dp] * 10),
@@ -265,6 +266,25 @@ class Engine:
                                int(bool(estimate_trend)), b, C.byref(llf), _ptr(grad))
         )  # fmt: skip
         return (llf.value, grad) if eval_grad else llf.value
+
+    def nll_batch(self, kernel, mode, pars, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False, trend=TREND_CONSTANT):
+        """P likelihood (+ gradient) evaluations in one device round trip: `pars` is (P, n_par).  Returns (llf (P,), grad (P, n_par)
+        or None, info (P,) int32): llf[s] = -inf where the reference returns -inf (info[s] = ERR_NOT_POSDEF / ERR_LLF_POSITIVE /
+        ERR_INVALID), with a zero gradient row.  Slot s holds the bits of the s-th sequential `nll` call."""
+        pars = _f64(pars)
+        if pars.ndim != 2:
+            raise ValueError("pars must be (P, n_par)")
+        P, n_par = pars.shape
+        llf = np.empty(P)
+        grad = np.zeros((P, n_par)) if eval_grad else None
+        info = np.zeros(P, dtype=np.int32)
+        b = self._trend_beta(trend, estimate_trend, beta)
+        self._check(
+            self._lib.bogp_nll_batch(self._h, kernel, mode, P, _ptr(pars), n_par, float(noise_var), int(trend),
+                                     int(bool(estimate_trend)), b, _ptr(llf), _ptr(grad), info.ctypes.data_as(_ip))
+        )  # fmt: skip
+        llf[info != OK] = -np.inf
+        return llf, grad, info
 
     def nll_restricted(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False, trend=TREND_CONSTANT):
         """Restricted (REML) log-likelihood, gpr.py:813-918.  exp(llf) > 1 gives -inf WITH the gradient of the finite

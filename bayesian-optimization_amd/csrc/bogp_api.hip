@@ -15,6 +15,7 @@
 #include "../../include/bogp.h"
 #include "bogp_handle.h"
 #include "bogp_internal.h"
+#include "bogp_fit.h"
 
 using namespace bogp;
 
@@ -125,6 +126,7 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   comm_release(h);
   point_release(h);
+  batch_release(h);
   free_train(h);
   (void)hipStreamSynchronize(h->stream2);
   if (h->stream_upd) (void)hipStreamSynchronize(h->stream_upd);
@@ -231,13 +233,8 @@ extern "C" int bogp_select_target(bogp_handle* h, int target) {
 // ------------------------------------------------------------------------------------------------------
 // factorise at `par` (shared by bogp_nll and bogp_commit)
 // ------------------------------------------------------------------------------------------------------
-struct FitOut {
-  double llf = 0, sigma2 = 0, noise_var = 0, s2t = 0, G = 0, beta = 0, ftyt = 0, ftft = 0, logdet = 0, rho_ss = 0;
-  // per target (n_t > 1: llf above is the SUM over targets, gpr.py:1040; sigma2 / s2t / rho_ss above are target 0's)
-  double sigma2_t[BOGP_MAX_TARGETS] = {0}, s2t_t[BOGP_MAX_TARGETS] = {0}, nv_t[BOGP_MAX_TARGETS] = {0};
-};
-
-static int trend_size(int trend, int d) {
+// (FitOut / FitPending: bogp_fit.h)
+int bogp::trend_size(int trend, int d) {
   return trend == BOGP_TREND_CONSTANT ? 1 : trend == BOGP_TREND_LINEAR ? d + 1 : (d + 1) * (d + 2) / 2;
 }
 extern "C" int bogp_trend_size(int trend, int d) {
@@ -351,12 +348,8 @@ static int trend_solve(bogp_handle* h, int trend, int estimate_trend) {
 }
 
 // what the host half of a factorisation (factorize_finish) needs once info / the device scalars have been read back
-struct FitPending {
-  int mode = 0, estimate_trend = 0, ptrend = 1, n_t = 1, N = 0;
-  double beta = 0, alpha = 0, sigma2_par = 0, noise_var = 0, s2t = 0;
-};
-static int fit_wait(bogp_handle* h, unsigned long long seq) {
-  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->hfit + 3000);
+int bogp::fit_wait_on(bogp_handle* h, const void* flag_word, unsigned long long seq) {
+  volatile const unsigned long long* flag = reinterpret_cast<volatile const unsigned long long*>(flag_word);
   bool seen = false;
   for (int spin = 0; spin < 400000; ++spin) {
     if (*flag == seq) { seen = true; break; }
@@ -366,6 +359,7 @@ static int fit_wait(bogp_handle* h, unsigned long long seq) {
   if (!seen) HIPCHK(h, hipStreamSynchronize(h->stream));
   return BOGP_OK;
 }
+static int fit_wait(bogp_handle* h, unsigned long long seq) { return fit_wait_on(h, h->hfit + 3000, seq); }
 // The 64 scalars of the evaluation (and nS gradient sums from dS, or none) back on the host: one gather launch into the mapped
 // pinned block + a polled sequence word instead of two copy commands into pageable memory + a stream synchronisation (the
 // host's API calls, not the GPU, bound an evaluation at the sizes of an ordinary BO run: profiles/r03_bo_loop.txt).
@@ -388,9 +382,6 @@ static int fit_readback(bogp_handle* h, const double* dS, int nS, double* blk /*
   if (nS > 0) memcpy(S_out, h->hfit + 2112, (size_t)nS * sizeof(double));
   return BOGP_OK;
 }
-
-static int factorize_finish(bogp_handle* h, const FitPending& fp, int info, const double* sc, const int* info2,
-                            bool reject_positive, FitOut* o);
 
 // pend == nullptr: queue the device work, read info + scalars back, finish (ONE host synchronisation).
 // pend != nullptr: queue only -- the caller appends its own device work (the likelihood gradient), reads everything back in ONE
@@ -595,8 +586,8 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   return factorize_finish(h, fp, (int)info, sc, info2, reject_positive, o);
 }
 
-static int factorize_finish(bogp_handle* h, const FitPending& fp, int info, const double* sc, const int* info2,
-                            bool reject_positive, FitOut* o) {
+int bogp::factorize_finish(bogp_handle* h, const FitPending& fp, int info, const double* sc, const int* info2,
+                           bool reject_positive, FitOut* o) {
   const int mode = fp.mode, estimate_trend = fp.estimate_trend, ptrend = fp.ptrend, n_t = fp.n_t, N = fp.N;
   const double beta = fp.beta, alpha = fp.alpha, sigma2_par = fp.sigma2_par, noise_var = fp.noise_var;
   double s2t = fp.s2t;
@@ -663,8 +654,8 @@ static int factorize_finish(bogp_handle* h, const FitPending& fp, int info, cons
 }
 
 // the likelihood gradient from the d + 1 contractions, trace(R^-1) and gamma.gamma (gpr.py:1001-1038)
-static void nll_gradient_from_sums(int mode, bool iso, int d, const double* par, int n_par, int n_t, const double* S, double s2t,
-                                   double* grad) {
+void bogp::nll_gradient_from_sums(int mode, bool iso, int d, const double* par, int n_par, int n_t, const double* S, double s2t,
+                                  double* grad) {
   const double tr = n_t * S[d + 1], gg = S[d + 2];
   if (iso) {
     grad[0] = mode == BOGP_MODE_NOISE_ESTIM ? par[n_par - 1] * S[0] : S[0];

@@ -14,6 +14,7 @@ struct bogp_handle;
 namespace bogp {
 void comm_release(bogp_handle* h);   // bogp_comm.hip: destroys an owned communicator, frees the exchange buffers
 void point_release(bogp_handle* h);  // bogp_point.hip: frees the point-evaluation buffers
+void batch_release(bogp_handle* h);  // bogp_batch.hip: frees the batched-likelihood staging and workspaces
 // bogp_point.hip: posterior, input-gradients and q criteria of B points through k_point_rhs + k_point_tri.  `Xb` is a HOST
 // array (B x d).  Outputs (host, any may be null): mu, mse (B), dmu, dmse (B x d), acq (B x q), dacq (B x q x d).
 int point_eval_host(bogp_handle* h, const char* who, const double* Xb, int B, int q, const int* acq_id, const double* acq_par,
@@ -140,6 +141,20 @@ struct bogp_handle {
   double* hpin_dev = nullptr;
   size_t hpin_cap = 0;
   unsigned long long pt_seq = 0;  // sequence number of the last one-point call (completion word behind its record)
+  // bogp_nll_batch (bogp_batch.hip): pinned device-mapped staging (parameter rows in, records out; the sequence word sits behind
+  // hbatch_cap doubles), the slot-completion ticket, and the P workspaces of the elimination path with their BatchSlot table
+  double* hbatch = nullptr;
+  double* hbatch_dev = nullptr;
+  size_t hbatch_cap = 0;
+  unsigned int* dbatch_ticket = nullptr;
+  unsigned long long batch_seq = 0;
+  double* dbws = nullptr;
+  size_t bws_cap = 0;
+  bogp::BatchSlot* dbslots = nullptr;
+  size_t bslots_cap = 0;
+  int bws_P = 0, bws_ld = 0, bws_d = 0, bws_N = 0;
+  double* bws_rows = nullptr;  // [bws_P][bws_row] parameter rows on the device
+  size_t bws_row = 0;
 
   // timing of the last sweep/predict
   std::vector<hipEvent_t> ev;

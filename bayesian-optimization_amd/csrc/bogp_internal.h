@@ -207,7 +207,16 @@ struct NllSmallArgs {
   double* out_S;     // d + 3 doubles
   unsigned long long* flag;
   unsigned long long seq;
+  // bogp_nll_batch: P parameter vectors, one workgroup each.  bpar[s][NS_BPAR] = theta (64) | pexp | a | b | diag | s2t_host | div of
+  // slot s (what `theta` .. `s2t_host` above are for one evaluation), bout[s][NS_BOUT] = its 64 scalars | d + 3 sums, bticket = one
+  // zeroed device word (the last workgroup publishes `seq`).  bpar == nullptr: the one-evaluation launch.
+  const double* bpar = nullptr;
+  double* bout = nullptr;
+  unsigned int* bticket = nullptr;
+  int P = 1;
+  int bout_stride = 0;  // doubles per slot of bout: 64 scalars + the d + 3 sums
 };
+constexpr int NS_BPAR = 72;   // doubles per slot of NllSmallArgs::bpar
 int nll_small_max_n();
 bool nll_small_fits(int N, int d);
 // the elimination at 64-block granularity (kernels_chol.hip: k_elim_*): 157 <= N <= 1024, constant basis, one target
@@ -220,6 +229,28 @@ struct ElimArgs {
   double* logpart;  // nb: sum(log diag L_kk)
   int* info;
 };
+// one parameter vector of bogp_nll_batch on the elimination path: its workspace (fixed while the batch buffers live) and where this
+// evaluation's parameters are (rewritten by every call) -- an array of these in device memory is what the *_b kernels index by slot
+struct BatchSlot {
+  const double* theta;  // d + 1 doubles: theta, then the exponent of generalized_exponential
+  const double* par;    // [0] a, [1] b, [2] diag (k_build_R's arguments), [3] sigma2 + noise_var (noisy mode)
+  ElimArgs ea;          // state blocks, block row nb, Yt, Ft, log-determinant parts; ea.info = (int*)(scal + 62)
+  double* Winv;         // (nb + 1) x 64 x 64: inverses of the diagonal blocks
+  double* panels;       // 2 x (ld + 64) x 64: the two raw panels
+  double* Rinv;         // ld x ld
+  double* gamma;        // Np
+  double* scal;         // 64: [0..3] the likelihood's scalars, [32..48) the gradient's weights, [62] info
+  double* partial;      // grad_contract_blocks(N) x (d + 1) tile sums
+  double* S;            // d + 3 gradient sums
+  unsigned int* ticket; // zeroed word of k_grad_finish_b
+};
+hipError_t launch_build_R_batch(int kernel, bool div, const double* X, int N, int d, const BatchSlot* slots, int P, int ld, hipStream_t st);
+hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double* y, int estimate_trend, int mode, double beta, hipStream_t st);
+hipError_t launch_grad_contract_batch(int kernel, const double* X, int N, int d, const BatchSlot* slots, int P, int Np, int ld, hipStream_t st);
+hipError_t launch_grad_finish_batch(const BatchSlot* slots, int P, int nblk, int nout, int ld, int N, int with_trace, double* bout,
+                                    int bout_stride, unsigned long long* flag, unsigned long long seq, unsigned int* gticket, hipStream_t st);
+hipError_t launch_fit_gather_batch(const BatchSlot* slots, int P, double* bout, int bout_stride, unsigned long long* flag,
+                                   unsigned long long seq, unsigned int* gticket, hipStream_t st);
 hipError_t launch_elim(const ElimArgs& a, const double* y, double* Winv, double* panels, double* Rinv, int ldr, double* gamma, double* scal,
                        double* coefw, int estimate_trend, int mode, double beta, double s2t_host, hipStream_t st);
 hipError_t launch_nll_small(int kernel, bool grad, const NllSmallArgs& a, hipStream_t st);

@@ -1509,7 +1509,7 @@ __device__ __forceinline__ void elim_diag2(const double* cs, double* scr, double
 }  // namespace
 
 // workgroup 0: the first diagonal block; workgroups i >= 1: block (i, 0) into the raw panel as it is
-__global__ __launch_bounds__(256) void k_elim_first(const ElimArgs a, double* __restrict__ W0, double* __restrict__ Pn) {
+__device__ __forceinline__ void elim_first_block(const ElimArgs& a, double* __restrict__ W0, double* __restrict__ Pn) {
   __shared__ __attribute__((aligned(16))) double cs[CB * (CB + 1)];
   __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
   const int tid = threadIdx.x, bi = blockIdx.x;
@@ -1530,9 +1530,18 @@ __global__ __launch_bounds__(256) void k_elim_first(const ElimArgs a, double* __
     }
   }
 }
+__global__ __launch_bounds__(256) void k_elim_first(const ElimArgs a, double* __restrict__ W0, double* __restrict__ Pn) {
+  elim_first_block(a, W0, Pn);
+}
+// bogp_nll_batch flavours of the three elimination kernels: blockIdx.y = the parameter vector, whose state / panels / factors come
+// from its BatchSlot; the block routines are the one-evaluation kernels' own
+__global__ __launch_bounds__(256) void k_elim_first_b(const BatchSlot* __restrict__ slots) {
+  const BatchSlot& sl = slots[blockIdx.y];
+  elim_first_block(sl.ea, sl.Winv, sl.panels);
+}
 
-__global__ __launch_bounds__(256) void k_elim_step(const ElimArgs a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
-                                                   double* __restrict__ Pnext, double* __restrict__ Wn) {
+__device__ __forceinline__ void elim_step_block(const ElimArgs& a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
+                                                double* __restrict__ Pnext, double* __restrict__ Wn) {
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
   __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
   int bi, bj;
@@ -1620,12 +1629,23 @@ __global__ __launch_bounds__(256) void k_elim_step(const ElimArgs a, int k, cons
     elim_diag2(lds, sb, Wn, a.logpart + kn, a.info, CB * kn, 0, max(0, min(CB, a.N - CB * kn)), Pnext, lde, kn, tid);
   }
 }
+__global__ __launch_bounds__(256) void k_elim_step(const ElimArgs a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
+                                                   double* __restrict__ Pnext, double* __restrict__ Wn) {
+  elim_step_block(a, k, Wk, Pcur, Pnext, Wn);
+}
+__global__ __launch_bounds__(256) void k_elim_step_b(const BatchSlot* __restrict__ slots, int k) {
+  const BatchSlot& sl = slots[blockIdx.y];
+  const size_t lde = (size_t)sl.ea.ld + CB;
+  double* P0 = sl.panels;
+  double* P1 = sl.panels + lde * CB;
+  elim_step_block(sl.ea, k, sl.Winv + (size_t)k * CB * CB, (k & 1) ? P1 : P0, (k & 1) ? P0 : P1, sl.Winv + (size_t)(k + 1) * CB * CB);
+}
 
 // R^-1 = -T into Rinv (lower triangle, column-major, ldr) and, by the last workgroup, the likelihood's scalars (k_fit_rho's
 // expressions), the gradient's two weights and gamma = R^-1 y - beta R^-1 1
-__global__ __launch_bounds__(256) void k_elim_finish(const ElimArgs a, double* __restrict__ Rinv, int ldr, double* __restrict__ gamma,
-                                                     double* __restrict__ scal, double* __restrict__ coefw, int estimate_trend, int mode,
-                                                     double beta, double s2t_host) {
+__device__ __forceinline__ void elim_finish_block(const ElimArgs& a, double* __restrict__ Rinv, int ldr, double* __restrict__ gamma,
+                                                  double* __restrict__ scal, double* __restrict__ coefw, int estimate_trend, int mode,
+                                                  double beta, double s2t_host) {
   const int tid = threadIdx.x;
   const int ntiles = a.nb * (a.nb + 1) / 2;
   if ((int)blockIdx.x < ntiles) {
@@ -1693,9 +1713,18 @@ __global__ __launch_bounds__(256) void k_elim_finish(const ElimArgs a, double* _
     coefw[8] = 1.0 / s2t;
   }
 }
+__global__ __launch_bounds__(256) void k_elim_finish(const ElimArgs a, double* __restrict__ Rinv, int ldr, double* __restrict__ gamma,
+                                                     double* __restrict__ scal, double* __restrict__ coefw, int estimate_trend, int mode,
+                                                     double beta, double s2t_host) {
+  elim_finish_block(a, Rinv, ldr, gamma, scal, coefw, estimate_trend, mode, beta, s2t_host);
+}
+__global__ __launch_bounds__(256) void k_elim_finish_b(const BatchSlot* __restrict__ slots, int estimate_trend, int mode, double beta) {
+  const BatchSlot& sl = slots[blockIdx.y];
+  elim_finish_block(sl.ea, sl.Rinv, sl.ea.ld, sl.gamma, sl.scal, sl.scal + 4 * BOGP_MAX_TARGETS, estimate_trend, mode, beta, sl.par[3]);
+}
 
 // [y; 1] into block row nb and identity padding of E outside its leading N x N block (k_build_R wrote the lower 64-tiles)
-__global__ void k_elim_init(const ElimArgs a, const double* __restrict__ y) {
+__device__ __forceinline__ void elim_init_column(const ElimArgs& a, const double* __restrict__ y) {
   const int j = blockIdx.x;  // column
   const int N = a.N, ld = a.ld;
   for (int r = threadIdx.x; r < CB; r += blockDim.x) a.Eb[(size_t)j * CB + r] = (j < N && r == 0) ? y[j] : ((j < N && r == 1) ? 1.0 : 0.0);
@@ -1704,6 +1733,19 @@ __global__ void k_elim_init(const ElimArgs a, const double* __restrict__ y) {
   } else {
     for (int i = N + threadIdx.x; i < ld; i += blockDim.x) a.E[(size_t)j * ld + i] = 0.0;
   }
+}
+__global__ void k_elim_init(const ElimArgs a, const double* __restrict__ y) { elim_init_column(a, y); }
+__global__ void k_elim_init_b(const BatchSlot* __restrict__ slots, const double* __restrict__ y) { elim_init_column(slots[blockIdx.y].ea, y); }
+
+// the elimination of P matrices at once (bogp_nll_batch): the launches of launch_elim with a second grid dimension over the slots
+hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double* y, int estimate_trend, int mode, double beta, hipStream_t st) {
+  const int nb = ld / CB;
+  hipLaunchKernelGGL(k_elim_init_b, dim3(ld, P), 64, 0, st, slots, y);
+  hipLaunchKernelGGL(k_elim_first_b, dim3(nb + 1, P), 256, 0, st, slots);
+  const int grid = (nb + 1) * (nb + 2) / 2 - 1;
+  for (int k = 0; k < nb; ++k) hipLaunchKernelGGL(k_elim_step_b, dim3(grid, P), 256, 0, st, slots, k);
+  hipLaunchKernelGGL(k_elim_finish_b, dim3(nb * (nb + 1) / 2 + 1, P), 256, 0, st, slots, estimate_trend, mode, beta);
+  return hipGetLastError();
 }
 
 hipError_t launch_elim(const ElimArgs& a, const double* y, double* Winv, double* panels, double* Rinv, int ldr, double* gamma, double* scal,

@@ -366,12 +366,12 @@ hipError_t launch_grad_reduce(const double* partial, int nblk, int nout, double*
 // then the LAST workgroup to finish (a ticket) adds what k_trace_gg computes -- out[nout] = trace(R^-1), out[nout + 1] = gamma.gamma
 // (noisy mode) -- and does k_fit_gather's job: the 64 scalars and the nout + 2 sums into device-mapped pinned memory + the
 // sequence word the host polls.  Three launches less per evaluation on the general path.
-__global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ partial, int nblk, int nout, double* __restrict__ out,
-                                                     const double* __restrict__ Rinv, int ld, int nparts, size_t part_stride, int N,
-                                                     const double* __restrict__ gamma, int with_trace, const double* __restrict__ scal,
-                                                     double* __restrict__ out_scal, double* __restrict__ out_S,
-                                                     unsigned long long* __restrict__ flag, unsigned long long seq,
-                                                     unsigned int* __restrict__ ticket) {
+// (returns true, in every thread of the finishing workgroup only, once its record is fenced to the system)
+__device__ __forceinline__ bool grad_finish_block(const double* __restrict__ partial, int nblk, int nout, double* __restrict__ out,
+                                                  const double* __restrict__ Rinv, int ld, int nparts, size_t part_stride, int N,
+                                                  const double* __restrict__ gamma, int with_trace, const double* __restrict__ scal,
+                                                  double* __restrict__ out_scal, double* __restrict__ out_S,
+                                                  unsigned int* __restrict__ ticket) {
   __shared__ double red[256];
   __shared__ int s_last;
   const int k = blockIdx.x, tid = threadIdx.x;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ 
     s_last = atomicAdd(ticket, 1u) == (unsigned int)(nout - 1);
   }
   __syncthreads();
-  if (!s_last) return;
+  if (!s_last) return false;
   __threadfence();
   double tr = 0.0, gg = 0.0;
   if (with_trace) {
@@ -424,7 +424,58 @@ __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ 
   }
   __threadfence_system();
   __syncthreads();
-  if (tid == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  return true;
+}
+__global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ partial, int nblk, int nout, double* __restrict__ out,
+                                                     const double* __restrict__ Rinv, int ld, int nparts, size_t part_stride, int N,
+                                                     const double* __restrict__ gamma, int with_trace, const double* __restrict__ scal,
+                                                     double* __restrict__ out_scal, double* __restrict__ out_S,
+                                                     unsigned long long* __restrict__ flag, unsigned long long seq,
+                                                     unsigned int* __restrict__ ticket) {
+  if (grad_finish_block(partial, nblk, nout, out, Rinv, ld, nparts, part_stride, N, gamma, with_trace, scal, out_scal, out_S, ticket) &&
+      threadIdx.x == 0)
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// bogp_nll_batch: blockIdx.y = the parameter vector; slot s leaves its record in bout + s * bout_stride (64 scalars, then the
+// nout + 2 sums) and the last SLOT to finish (a second ticket) publishes the sequence word
+__global__ __launch_bounds__(256) void k_grad_finish_b(const BatchSlot* __restrict__ slots, int nblk, int nout, int ld, int N, int with_trace,
+                                                       double* __restrict__ bout, int bout_stride, unsigned long long* __restrict__ flag,
+                                                       unsigned long long seq, unsigned int* __restrict__ gticket) {
+  const BatchSlot& sl = slots[blockIdx.y];
+  double* rec = bout + (size_t)blockIdx.y * bout_stride;
+  if (grad_finish_block(sl.partial, nblk, nout, sl.S, sl.Rinv, ld, 1, (size_t)ld * ld, N, sl.gamma, with_trace, sl.scal, rec, rec + 64, sl.ticket) &&
+      threadIdx.x == 0) {
+    if (atomicAdd(gticket, 1u) == gridDim.y - 1) {
+      *gticket = 0u;
+      __threadfence_system();
+      __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+// value-only batches: slot s's 64 scalars into its record, the last slot publishes (k_fit_gather's job for P evaluations)
+__global__ __launch_bounds__(64) void k_fit_gather_b(const BatchSlot* __restrict__ slots, double* __restrict__ bout, int bout_stride,
+                                                     unsigned long long* __restrict__ flag, unsigned long long seq,
+                                                     unsigned int* __restrict__ gticket) {
+  const BatchSlot& sl = slots[blockIdx.x];
+  double* rec = bout + (size_t)blockIdx.x * bout_stride;
+  rec[threadIdx.x] = sl.scal[threadIdx.x];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(gticket, 1u) == gridDim.x - 1) {
+    *gticket = 0u;
+    __threadfence_system();
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+hipError_t launch_grad_finish_batch(const BatchSlot* slots, int P, int nblk, int nout, int ld, int N, int with_trace, double* bout,
+                                    int bout_stride, unsigned long long* flag, unsigned long long seq, unsigned int* gticket, hipStream_t st) {
+  hipLaunchKernelGGL(k_grad_finish_b, dim3(nout, P), 256, 0, st, slots, nblk, nout, ld, N, with_trace, bout, bout_stride, flag, seq, gticket);
+  return hipGetLastError();
+}
+hipError_t launch_fit_gather_batch(const BatchSlot* slots, int P, double* bout, int bout_stride, unsigned long long* flag,
+                                   unsigned long long seq, unsigned int* gticket, hipStream_t st) {
+  hipLaunchKernelGGL(k_fit_gather_b, dim3(P), 64, 0, st, slots, bout, bout_stride, flag, seq, gticket);
+  return hipGetLastError();
 }
 hipError_t launch_grad_finish(const double* partial, int nblk, int nout, double* out, const double* Rinv, int ld, int nparts,
                               size_t part_stride, int N, const double* gamma, int with_trace, const double* scal, double* out_scal,

@@ -98,7 +98,13 @@ __device__ __forceinline__ void ns_corr_pair(double s2, double& r0, double& h) {
 // The pair work before and after the loop (the correlation matrix; the gradient contractions) is spread over ALL threads in
 // strips of 1 x 4 entries through an LDS image of the blocks, whatever the number of owners (15 at N = 16): it is bound by the
 // exp / sqrt of each pair, ~100 instructions an entry.
-template <int KERNEL, bool GRAD, int TMAX>
+//
+// BATCH (bogp_nll_batch): grid = P workgroups, one parameter vector each.  Slot s = blockIdx.x takes what differs between the
+// evaluations -- theta, the exponent, k_build_R's (a, b, diag, div) and the noisy mode's total variance -- from the block
+// a.bpar + s * NS_BPAR (device-mapped pinned memory the host filled), leaves its 64 scalars and d + 3 sums in a.bout + s * a.bout_stride,
+// and the LAST workgroup to finish (a ticket) publishes the sequence word.  The arithmetic is the one-evaluation kernel's own
+// (same expressions on the same values): slot s returns the bits of the s-th sequential call.
+template <int KERNEL, bool GRAD, int TMAX, bool BATCH>
 __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
   extern __shared__ double dyn[];      // Xs[N][dP] | Rst[16][nbR]: the blocks of R, later of R^-1, element-major
   // P[step & 1][ns_pidx(e, i)]: element e = 4 r + c of block row i's panel block, elements 2 q and 2 q + 1 next to each other so
@@ -111,12 +117,18 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
   __shared__ unsigned short blkmap[NS_MAXNB * (NS_MAXNB + 1) / 2];
   __shared__ double s_logdet;
   __shared__ int s_info;
+  __shared__ double s_par[BATCH ? NS_BPAR : 1];
 
 #ifdef NS_PROFILE
   const long long tstart = clock64();
 #endif
   const int N = a.N, d = a.d, nb = (N + NS_BS - 1) / NS_BS;
   const int tid = threadIdx.x, nthr = blockDim.x;
+  const int slot = BATCH ? (int)blockIdx.x : 0;
+  if (BATCH && tid < NS_BPAR) s_par[tid] = a.bpar[(size_t)slot * NS_BPAR + tid];
+  double* const out_scal = BATCH ? a.bout + (size_t)slot * a.bout_stride : a.out_scal;
+  double* const out_S = BATCH ? out_scal + 64 : a.out_S;
+#define NS_TH(k_) (BATCH ? s_par[k_] : a.theta[k_])
   const int nbR = nb * (nb + 1) / 2;              // blocks of R
   const int nown = (nb + 1) * (nb + 2) / 2 - 1;   // + block row nb; block (nb, nb) does not exist
   const int nwaves = nthr >> 6;
@@ -139,6 +151,9 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
   if (tid == 0) s_info = 0;
   for (int e = tid; e < N * d; e += nthr) Xs[(e / d) * dP + (e % d)] = a.X[e];
   __syncthreads();
+  const double par_pexp = BATCH ? s_par[64] : a.pexp, par_a = BATCH ? s_par[65] : a.a, par_b = BATCH ? s_par[66] : a.b;
+  const double par_diag = BATCH ? s_par[67] : a.diag, par_s2t = BATCH ? s_par[68] : a.s2t_host;
+  const int par_div = BATCH ? (s_par[69] != 0.0 ? 1 : 0) : a.div;
 
   // ---- R, strip by strip, into the LDS image ---------------------------------------------------------------------
   for (int s = tid; s < 4 * nbR; s += nthr) {
@@ -149,11 +164,11 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) s2[c] = dist_init<KERNEL>();
     if (i < N) {
-      const double pexp = a.pexp;
+      const double pexp = par_pexp;
       const double* xi = Xs + i * dP;
       const double* xj = Xs + min(4 * sbj, N - 1) * dP;  // (columns j <= i < N; the clamp only keeps padding reads in range)
       for (int k = 0; k < d; ++k) {
-        const double th = a.theta[k], vi = xi[k];
+        const double th = NS_TH(k), vi = xi[k];
 #pragma unroll
         for (int c = 0; c < 4; ++c) s2[c] = dist_fold<KERNEL>(th, vi - xj[min(c, N - 1 - min(4 * sbj, N - 1)) * dP + k], s2[c], pexp);
       }
@@ -162,17 +177,17 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
     // branch per entry would string the four exp / sqrt chains one behind the other)
     double pv[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) pv[c] = a.a * corr_profile<KERNEL>(s2[c]);
-    if (a.div) {
+    for (int c = 0; c < 4; ++c) pv[c] = par_a * corr_profile<KERNEL>(s2[c]);
+    if (par_div) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) pv[c] = pv[c] / a.b;
+      for (int c = 0; c < 4; ++c) pv[c] = pv[c] / par_b;
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int j = 4 * sbj + c;
       double v = pv[c];
       if (i >= N || j >= N) v = i == j ? 1.0 : 0.0;  // identity padding
-      else if (i == j) v = a.diag;
+      else if (i == j) v = par_diag;
       Rst[(4 * r + c) * nbR + t] = v;
     }
   }
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
   int pive = 0;
 #ifdef NS_PROFILE
   long long tp0 = clock64(), tpA = 0, tpB = 0, tpC = 0, tpre = tp0;
-  if (tid == 0) a.out_scal[20] = (double)(tp0 - tstart);
+  if (tid == 0) out_scal[20] = (double)(tp0 - tstart);
 #endif
   __syncthreads();  // raw(0), raw(1) are published
 
@@ -341,7 +356,7 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
 #endif
   }
 #ifdef NS_PROFILE
-  if (tid == 0) { a.out_scal[21] = (double)tpA; a.out_scal[22] = (double)tpB; a.out_scal[23] = (double)tpC; }
+  if (tid == 0) { out_scal[21] = (double)tpA; out_scal[22] = (double)tpB; out_scal[23] = (double)tpC; }
   const long long tloop_end = clock64();
 #endif
   if (tid == 0) s_logdet = log(pivm) + (double)pive * 0.6931471805599453;
@@ -384,14 +399,14 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
   }
   srr = ns_block_sum(srr, red, nwaves);
   if (tid == 0) {
-    a.out_scal[0] = s_logdet;
-    a.out_scal[1] = nrm;
-    a.out_scal[2] = sfy;
-    a.out_scal[3] = srr;
+    out_scal[0] = s_logdet;
+    out_scal[1] = nrm;
+    out_scal[2] = sfy;
+    out_scal[3] = srr;
     double iw = 0.0;
     int info = s_info;
     memcpy(&iw, &info, sizeof(info));
-    a.out_scal[62] = iw;
+    out_scal[62] = iw;
   }
 
   if (GRAD) {
@@ -406,7 +421,7 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
         for (int c = 0; c < 4; ++c) Rst[(4 * r + c) * nbR + ot] = -T[r][c];
     }
     __syncthreads();
-    const double s2t = a.mode == BOGP_MODE_NOISY ? a.s2t_host : (a.mode == BOGP_MODE_NOISELESS ? srr / (N - (a.estimate_trend ? 1 : 0)) : srr / N);
+    const double s2t = a.mode == BOGP_MODE_NOISY ? par_s2t : (a.mode == BOGP_MODE_NOISELESS ? srr / (N - (a.estimate_trend ? 1 : 0)) : srr / N);
     const double cw = 1.0 / s2t;
     // the pairs i > j of the strict lower triangle, <= 4 strips a thread: A = cw gamma_i gamma_j - Rinv_ij
     double B[4][4];
@@ -429,7 +444,7 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
           double s2[4] = {0.0, 0.0, 0.0, 0.0};
           const double* xi = Xs + i * dP;
           for (int k = 0; k < d; ++k) {
-            const double th = a.theta[k], vi = xi[k];
+            const double th = NS_TH(k), vi = xi[k];
 #pragma unroll
             for (int c = 0; c < 4; ++c) s2[c] += dist_term<KERNEL>(th, Xs[min(4 * sbj + c, N - 1) * dP + k] - vi);
           }
@@ -497,21 +512,32 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
       if (tid < kn) {
         double ssum = 0.0;
         for (int w = 0; w < nwaves; ++w) ssum += redk[w][tid];
-        a.out_S[k0 + tid] = ssum;
+        out_S[k0 + tid] = ssum;
       }
     }
     if (tid == 0) {
-      a.out_S[d] = sd;
-      a.out_S[d + 1] = tr;
-      a.out_S[d + 2] = gg;
+      out_S[d] = sd;
+      out_S[d + 1] = tr;
+      out_S[d + 2] = gg;
     }
   }
 #ifdef NS_PROFILE
-  if (tid == 0) a.out_scal[24] = (double)(clock64() - tloop_end);
+  if (tid == 0) out_scal[24] = (double)(clock64() - tloop_end);
 #endif
+#undef NS_TH
   __threadfence_system();
   __syncthreads();
-  if (tid == 0) __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tid == 0) {
+    bool publish = true;
+    if (BATCH) {  // (every slot's record was fenced to the system before its ticket: the last one may publish for all)
+      publish = atomicAdd(a.bticket, 1u) == (unsigned int)(a.P - 1);
+      if (publish) {
+        *a.bticket = 0u;
+        __threadfence_system();
+      }
+    }
+    if (publish) __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 size_t nll_small_lds_bytes(int N, int d);
@@ -542,7 +568,7 @@ static hipError_t ns_launch(int block, size_t lds, const NllSmallArgs& a, hipStr
     if (e != hipSuccess) return e;
     r.store(lds, std::memory_order_relaxed);
   }
-  hipLaunchKernelGGL(KERN, dim3(1), block, lds, st, a);
+  hipLaunchKernelGGL(KERN, dim3(a.bpar ? a.P : 1), block, lds, st, a);
   return hipGetLastError();
 }
 
@@ -551,7 +577,11 @@ hipError_t launch_nll_small(int kernel, bool grad, const NllSmallArgs& a, hipStr
   const int nown = (nb + 1) * (nb + 2) / 2 - 1;
   const int block = ((4 * (nb + 1) + 63) / 64) * 64 + ((nown + 63) / 64) * 64;  // the panel waves + the owners
   const size_t lds = nll_small_lds_bytes(a.N, a.d);
-#define NS_GO(K, G) (block <= NS_THREADS_128 ? ns_launch<k_nll_small<K, G, NS_THREADS_128>>(block, lds, a, st) : ns_launch<k_nll_small<K, G, NS_THREADS>>(block, lds, a, st))
+#define NS_GO(K, G)                                                                                                               \
+  (a.bpar ? (block <= NS_THREADS_128 ? ns_launch<k_nll_small<K, G, NS_THREADS_128, true>>(block, lds, a, st)                        \
+                                     : ns_launch<k_nll_small<K, G, NS_THREADS, true>>(block, lds, a, st))                           \
+          : (block <= NS_THREADS_128 ? ns_launch<k_nll_small<K, G, NS_THREADS_128, false>>(block, lds, a, st)                       \
+                                     : ns_launch<k_nll_small<K, G, NS_THREADS, false>>(block, lds, a, st)))
   if (block > NS_THREADS || lds + 36 * 1024 > 160 * 1024) return hipErrorInvalidValue;  // (nll_small_fits() said otherwise)
   if (grad) {
     switch (kernel) {

@@ -61,8 +61,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 //   DIV = true:   off-diagonal = (a * corr) / b    (NOISY: C = sigma2 R0 + tau2 I; R = C / sigma2_total, :966-967)
 // ---------------------------------------------------------------------------------------------------------------
 template <int KERNEL, bool DIV>
-__global__ __launch_bounds__(256) void k_build_R(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
-                                                 double a, double b, double diag, double* __restrict__ R, int ld) {
+__device__ __forceinline__ void build_R_tile(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
+                                             double a, double b, double diag, double* __restrict__ R, int ld) {
   __shared__ double xi[KC * PP], xj[KC * PP];
   const int bi = blockIdx.y, bj = blockIdx.x;  // row tile, column tile
   if (bj > bi) return;
@@ -108,6 +108,17 @@ __global__ __launch_bounds__(256) void k_build_R(const double* __restrict__ X, i
         v = a * corr_profile<KERNEL>(s2[r][c]);
       R[(size_t)j * ld + i] = v;
     }
+}
+template <int KERNEL, bool DIV>
+__global__ __launch_bounds__(256) void k_build_R(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
+                                                 double a, double b, double diag, double* __restrict__ R, int ld) {
+  build_R_tile<KERNEL, DIV>(X, N, d, theta, a, b, diag, R, ld);
+}
+// bogp_nll_batch: blockIdx.z = the parameter vector; the same tile routine on that slot's theta / normalisation / matrix
+template <int KERNEL, bool DIV>
+__global__ __launch_bounds__(256) void k_build_R_b(const double* __restrict__ X, int N, int d, const BatchSlot* __restrict__ slots, int ld) {
+  const BatchSlot& sl = slots[blockIdx.z];
+  build_R_tile<KERNEL, DIV>(X, N, d, sl.theta, sl.par[0], sl.par[1], sl.par[2], sl.ea.E, ld);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -206,6 +217,17 @@ hipError_t launch_build_R(int kernel, const double* X, int N, int d, const doubl
   const int nt = (N + PT - 1) / PT;
   const dim3 grid(nt, nt);
 #define CALL(K) hipLaunchKernelGGL((k_build_R<K, false>), grid, 256, 0, st, X, N, d, theta, off_scale, 1.0, diag, R, ld)
+  BOGP_FOR_KERNEL_R(kernel, CALL)
+#undef CALL
+  return hipGetLastError();
+}
+
+hipError_t launch_build_R_batch(int kernel, bool div, const double* X, int N, int d, const BatchSlot* slots, int P, int ld, hipStream_t st) {
+  const int nt = (N + PT - 1) / PT;
+  const dim3 grid(nt, nt, P);
+#define CALL(K)                                                                                  \
+  if (div) hipLaunchKernelGGL((k_build_R_b<K, true>), grid, 256, 0, st, X, N, d, slots, ld);    \
+  else hipLaunchKernelGGL((k_build_R_b<K, false>), grid, 256, 0, st, X, N, d, slots, ld)
   BOGP_FOR_KERNEL_R(kernel, CALL)
 #undef CALL
   return hipGetLastError();
@@ -329,11 +351,11 @@ hipError_t launch_add_vec(double* y, const double* x, int N, hipStream_t st) {
 // Tile (bi <= bj): i in tile bi (thread columns), j in tile bj (thread rows); blk = bj (bj + 1) / 2 + bi.
 // ---------------------------------------------------------------------------------------------------------------
 template <int KERNEL, int Q>
-__global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
-                                                       const GradVecs gv,
-                                                       const double* __restrict__ qv, double c2,
-                                                       const double* __restrict__ Rinv, int ld, int nparts, size_t part_stride,
-                                                       double* __restrict__ partial) {
+__device__ __forceinline__ void grad_contract_tile(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
+                                                   const GradVecs& gv,
+                                                   const double* __restrict__ qv, double c2,
+                                                   const double* __restrict__ Rinv, int ld, int nparts, size_t part_stride,
+                                                   double* __restrict__ partial) {
   constexpr int PTQ = 16 * Q, PPQ = PTQ + 1;  // points per tile side (64 or 32), LDS pitch
   __shared__ double xi[KC * PPQ], xj[KC * PPQ];
   __shared__ double red[4][KC + 1];
@@ -430,6 +452,25 @@ __global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict_
   __syncthreads();
   if (tid == 0) out[d] = ((red[0][KC] + red[1][KC]) + red[2][KC]) + red[3][KC];
 }
+template <int KERNEL, int Q>
+__global__ __launch_bounds__(256) void k_grad_contract(const double* __restrict__ X, int N, int d, const double* __restrict__ theta,
+                                                       const GradVecs gv,
+                                                       const double* __restrict__ qv, double c2,
+                                                       const double* __restrict__ Rinv, int ld, int nparts, size_t part_stride,
+                                                       double* __restrict__ partial) {
+  grad_contract_tile<KERNEL, Q>(X, N, d, theta, gv, qv, c2, Rinv, ld, nparts, part_stride, partial);
+}
+// bogp_nll_batch: blockIdx.z = the parameter vector (one target, weights from that slot's k_elim_finish)
+template <int KERNEL, int Q>
+__global__ __launch_bounds__(256) void k_grad_contract_b(const double* __restrict__ X, int N, int d, const BatchSlot* __restrict__ slots,
+                                                         int Np, int ld) {
+  const BatchSlot& sl = slots[blockIdx.z];
+  GradVecs gv;
+  gv.v = sl.gamma; gv.stride = (size_t)Np; gv.n = 1; gv.c0 = 1.0;
+  for (int t = 0; t < BOGP_MAX_TARGETS; ++t) gv.cA[t] = gv.cB[t] = 0.0;
+  gv.dcoef = sl.scal + 4 * BOGP_MAX_TARGETS;
+  grad_contract_tile<KERNEL, Q>(X, N, d, sl.theta, gv, nullptr, 0.0, sl.Rinv, ld, 1, (size_t)ld * ld, sl.partial);
+}
 
 // Tile side: 64 x 64 pairs (16 a thread) from N = 1025 on; 32 x 32 (4 a thread) below, 16 x 16 (one a thread) up to N = 256: a likelihood gradient of a few hundred
 // points is ten-odd workgroups either way, and a thread's 16 exp / sqrt chains were 25 us of a 175-us evaluation at N = 200
@@ -441,6 +482,18 @@ int grad_contract_blocks(int N) {
   const int pt = 16 * grad_contract_q(N);
   const int nt = (N + pt - 1) / pt;
   return nt * (nt + 1) / 2;
+}
+hipError_t launch_grad_contract_batch(int kernel, const double* X, int N, int d, const BatchSlot* slots, int P, int Np, int ld, hipStream_t st) {
+  const int q = grad_contract_q(N), pt = 16 * q;
+  const int nt = (N + pt - 1) / pt;
+  const dim3 grid(nt, nt, P);
+#define CALL(K)                                                                                           \
+  if (q == 1) hipLaunchKernelGGL((k_grad_contract_b<K, 1>), grid, 256, 0, st, X, N, d, slots, Np, ld);     \
+  else if (q == 2) hipLaunchKernelGGL((k_grad_contract_b<K, 2>), grid, 256, 0, st, X, N, d, slots, Np, ld); \
+  else hipLaunchKernelGGL((k_grad_contract_b<K, 4>), grid, 256, 0, st, X, N, d, slots, Np, ld)
+  BOGP_FOR_KERNEL(kernel, CALL)
+#undef CALL
+  return hipGetLastError();
 }
 hipError_t launch_grad_contract(int kernel, const double* X, int N, int d, const double* theta, const GradVecs& gv,
                                 const double* qv, double c2, const double* Rinv, int ld, int nparts,

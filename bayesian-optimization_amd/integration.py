@@ -136,6 +136,15 @@ class _Dispatch(type):
     `hasattr(cls, "plugin")`, bayes_opt.py:21-23, answers as both originals do)."""
 
     def __call__(cls, *args, **kwargs):
+        if "_pick" not in cls.__dict__:
+            # a user's `class My(bayes_optim.GaussianProcess)` inherits this metaclass: its overrides were written against the
+            # reference's class, so it is built on the HOST class with the subclass's own namespace on top (never silently
+            # replaced by a plain device object)
+            host = next((b._host for b in cls.__mro__ if isinstance(b, _Dispatch) and "_host" in b.__dict__ and b._host is not None), None)
+            if host is None:
+                raise TypeError("%s derives from a dispatching bogp class that has no host class to fall back to" % cls.__name__)
+            ns = {k: v for k, v in cls.__dict__.items() if k not in ("__dict__", "__weakref__")}
+            return type(cls.__name__, (host,), ns)(*args, **kwargs)
         return cls._pick(args, kwargs)(*args, **kwargs)
 
     def __instancecheck__(cls, obj):
@@ -190,7 +199,8 @@ class _AcquisitionNamespace:
 def _dispatching_surrogate(host_cls):
     def _pick(args, kwargs):
         try:  # validate on a throw-away instance: the constructor touches no device
-            _DeviceGP(*args, **kwargs)
+            probe = _DeviceGP(*args, **kwargs)
+            probe._trend_args()  # a trend basis the device does not evaluate is found NOW, not at fit() (it raises NotImplementedError)
             return _DeviceGP
         except NotImplementedError as e:
             warnings.warn("bogp: this GaussianProcess configuration stays on the reference's CPU class (%s)" % e, stacklevel=3)

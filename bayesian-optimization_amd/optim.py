@@ -249,9 +249,9 @@ def batch_argmax(criteria: Sequence, search_space, eval_budget: int, history: Op
     outcome (`feasible_rows`) enter the sweep; with none, `((), ())` -- the reference's "no feasible restart" answer."""
     if rank is None or world is None:
         rank, world = engine_rank_world(criteria[0].model.engine, group)
-    if int(eval_budget) < world:
-        raise ValueError("%d candidates cannot be sharded over %d ranks (every rank must own at least one)" % (eval_budget, world))
     if design is not None:  # "uniform" | "LHS" | "sobol": the candidates are drawn on the GPU(s) and never touch the host
+        if int(eval_budget) < world:  # (only ONE design is sharded; on the host-sampled path every rank draws its own eval_budget rows)
+            raise ValueError("%d candidates cannot be sharded over %d ranks (every rank must own at least one)" % (eval_budget, world))
         if masks is not None or h is not None or g is not None:
             raise NotImplementedError("device-generated designs take neither fixed variables nor constraints")
         seed = int(np.random.randint(0, 2**62)) if seed is None else int(seed)

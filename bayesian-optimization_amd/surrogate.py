@@ -503,9 +503,7 @@ class GaussianProcess:
 
             best_p, best_l, first, wait, left = None, np.inf, True, 0, budget
             for it in range(w, self.random_start, streams):
-                with warnings.catch_warnings():
-                    warnings.simplefilter("ignore")
-                    p_, l_, info = fmin_l_bfgs_b(obj, starts[it], bounds=log10bounds, maxfun=left)
+                p_, l_, info = fmin_l_bfgs_b(obj, starts[it], bounds=log10bounds, maxfun=left)
                 if first:
                     best_p, best_l, first = p_, l_, False
                 elif l_ <= best_l:
@@ -517,8 +515,12 @@ class GaussianProcess:
                     break
             return best_p, float(best_l), calls[0]
 
-        with ThreadPoolExecutor(max_workers=streams) as pool:
-            results = list(pool.map(worker, range(streams)))
+        # (ONE warnings context, entered by the calling thread around the pool: catch_warnings saves / restores the process-global
+        # filter list and is not thread-safe, so the workers must not enter their own)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with ThreadPoolExecutor(max_workers=streams) as pool:
+                results = list(pool.map(worker, range(streams)))
         self.eval_count = sum(r[2] for r in results)
         best = min(range(streams), key=lambda w: (results[w][1], w))
         if self.verbose:

@@ -28,7 +28,7 @@ extern "C" {
 typedef struct bogp_handle bogp_handle;
 
 /* error codes */
-#define BOGP_ABI_VERSION 6 /* what bogp_abi_version() of a matching library returns */
+#define BOGP_ABI_VERSION 7 /* what bogp_abi_version() of a matching library returns */
 #define BOGP_OK 0
 #define BOGP_ERR_INVALID (-1)      /* bad argument / call order                                           */
 #define BOGP_ERR_HIP (-2)          /* HIP runtime failure (or an in-kernel hand-over that timed out)       */
@@ -109,6 +109,21 @@ int bogp_select_target(bogp_handle* h, int target);
  * Returns BOGP_ERR_NOT_POSDEF / BOGP_ERR_LLF_POSITIVE where the reference returns -inf.                 */
 int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
              int estimate_trend, double beta, double* llf, double* grad);
+
+/* P likelihood (+ gradient) evaluations in ONE device round trip: the restarts of GaussianProcess._optimize_hyperparameter
+ * (gpr.py:1127-1162) are independent L-BFGS-B runs whose objective calls (gpr.py:1113-1123 -> log_likelihood_concentrated) can be
+ * evaluated together -- at the sizes of a BO run one evaluation occupies one workgroup of the 256 CUs.
+ *   par   P x n_par row-major (row s: the parameter vector of slot s, layout as bogp_nll);  llf (P);  grad (P x n_par) or NULL
+ *   info  P per-slot outcomes: BOGP_OK, BOGP_ERR_NOT_POSDEF, BOGP_ERR_LLF_POSITIVE (llf[s] then holds the finite value), or
+ *         BOGP_ERR_INVALID (a non-finite / non-positive parameter: that slot is skipped, the others are evaluated); llf[s] is NaN
+ *         and grad row s zero for a failed slot
+ * Slot s returns exactly the bits the s-th of P sequential bogp_nll calls returns.  The return value is BOGP_OK when the batch ran
+ * (whatever the slots' outcomes) and an error code for what stops a bogp_nll call before the device (bad ids, no training set, HIP).
+ * N <= 156: one launch, one workgroup a slot; N <= 2048: the elimination kernels over P workspaces (2 ld^2 doubles a slot, groups
+ * bounded by BOGP_BATCH_MAX_MB, default 8192); above, and for polynomial trends / several targets: the P calls one after the
+ * other.  The two batched paths leave the handle's factor buffers -- a committed model -- untouched.                          */
+int bogp_nll_batch(bogp_handle* h, int kernel, int mode, int P, const double* par, int n_par, double noise_var, int trend,
+                   int estimate_trend, double beta, double* llf, double* grad, int* info);
 
 /* ---- commit a fitted state ------------------------------------------------------------------------
  * Replaces the tail of GaussianProcess.fit (gpr.py:402-415) + compute_beta_gamma (:784-788): factorise at
