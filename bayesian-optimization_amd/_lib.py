@@ -18,7 +18,7 @@ KERNEL_SE, KERNEL_MATERN12, KERNEL_MATERN32, KERNEL_MATERN52, KERNEL_ABSEXP, KER
 MODE_NOISELESS, MODE_NOISY, MODE_NOISE_ESTIM = 0, 1, 2
 ACQ_EI, ACQ_EPSILON_PI, ACQ_UCB, ACQ_MGFI = 0, 1, 2, 3
 TREND_CONSTANT, TREND_LINEAR, TREND_QUADRATIC = 0, 1, 2
-ABI_VERSION = 7  # BOGP_ABI_VERSION of include/bogp.h this binding table was written for
+ABI_VERSION = 8  # BOGP_ABI_VERSION of include/bogp.h this binding table was written for
 MAX_Q = 64
 MAX_TARGETS = 8
 COMM_ID_BYTES = 128
@@ -38,6 +38,10 @@ SIGNATURES = {
     "bogp_select_target": (C.c_int, [C.c_void_p, C.c_int]),
     "bogp_nll": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp, _dp]),
     "bogp_nll_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp, _dp, _ip]),
+    "bogp_mle_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_double,
+                                 C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp, _ip, _ip, _ip]),
+    "bogp_lbfgsb_minimize": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       _dp, _ip, _ip, _ip]),
     "bogp_commit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp]),
     "bogp_nll_restricted": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp, _dp]),
     "bogp_get_state": (C.c_int, [C.c_void_p] + [_dp] * 10),
@@ -131,6 +135,36 @@ def _f64(a, shape=None) -> np.ndarray:
 
 def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(_dp)
+
+
+OBJECTIVE_FN = C.CFUNCTYPE(None, _dp, C.c_int, _dp, _dp, C.c_void_p)
+
+
+def lbfgsb_minimize(fun, x0, bounds, m=10, factr=1e7, pgtol=1e-5, maxfun=15000, maxiter=15000):
+    """libbogp's L-BFGS-B (csrc/bogp_lbfgsb.h, the optimiser of the lock-step MLE) on a Python objective `fun(x) -> (f, g)`:
+    the counterpart of scipy.optimize.fmin_l_bfgs_b(fun, x0, bounds=bounds) for tests.  No device is touched.
+    Returns (x, f, {"funcalls", "nit", "status"})."""
+    lib = load()
+    x = np.array(x0, dtype=np.float64).ravel()
+    n = len(x)
+    b = np.asarray(bounds, dtype=np.float64).reshape(n, 2)
+    lo, hi = np.ascontiguousarray(b[:, 0]), np.ascontiguousarray(b[:, 1])
+
+    def cb(xp, nn, fp, gp, _user):
+        xv = np.ctypeslib.as_array(xp, shape=(nn,)).copy()
+        f, g = fun(xv)
+        fp[0] = float(f)
+        gv = np.asarray(g, dtype=np.float64).ravel()
+        for i in range(nn):
+            gp[i] = gv[i]
+
+    cfn = OBJECTIVE_FN(cb)
+    f, nfev, nit, status = C.c_double(), C.c_int(), C.c_int(), C.c_int()
+    rc = lib.bogp_lbfgsb_minimize(n, int(m), _ptr(x), _ptr(lo), _ptr(hi), float(factr), float(pgtol), int(maxfun), int(maxiter),
+                                  C.cast(cfn, C.c_void_p), None, C.byref(f), C.byref(nfev), C.byref(nit), C.byref(status))
+    if rc != OK:
+        raise BogpError(rc, "bogp_lbfgsb_minimize: invalid arguments")
+    return x, f.value, {"funcalls": nfev.value, "nit": nit.value, "status": status.value}
 
 
 def comm_unique_id() -> bytes:
@@ -285,6 +319,29 @@ class Engine:
         )  # fmt: skip
         llf[info != OK] = -np.inf
         return llf, grad, info
+
+    def mle_batch(self, kernel, mode, x0, lo, hi, noise_var=0.0, estimate_trend=False, beta=0.0, trend=TREND_CONSTANT, restricted=False,
+                  eval_budget=0, m=10, factr=1e7, pgtol=1e-5, chain_rule=False):
+        """The R restarts of the MLE in lock step (bogp_mle_batch): x0 (R, n_par) log10 starts, lo / hi (n_par,) log10 bounds.
+        `chain_rule=True` hands the optimiser the gradient w.r.t. log10(par) instead of the reference's un-scaled one (an extension).
+        Returns (xopt (R, n_par) log10, fopt (R,) = -llf, n_evals (R,), status (R,), rounds)."""
+        x0 = _f64(x0)
+        if x0.ndim != 2:
+            raise ValueError("x0 must be (R, n_par)")
+        R, n_par = x0.shape
+        lo, hi = _f64(lo).ravel(), _f64(hi).ravel()
+        if len(lo) != n_par or len(hi) != n_par:
+            raise ValueError("bounds must have n_par entries")
+        xopt, fopt = np.empty((R, n_par)), np.empty(R)
+        nev, status = np.zeros(R, dtype=np.int32), np.zeros(R, dtype=np.int32)
+        rounds = C.c_int()
+        b = self._trend_beta(trend, estimate_trend, beta)
+        self._check(
+            self._lib.bogp_mle_batch(self._h, kernel, mode, int(bool(restricted)), R, _ptr(x0), n_par, _ptr(lo), _ptr(hi), float(noise_var),
+                                     int(trend), int(bool(estimate_trend)), b, int(eval_budget), int(m), float(factr), float(pgtol),
+                                     1 if chain_rule else 0, _ptr(xopt), _ptr(fopt), nev.ctypes.data_as(_ip), status.ctypes.data_as(_ip), C.byref(rounds))
+        )  # fmt: skip
+        return xopt, fopt, nev, status, rounds.value
 
     def nll_restricted(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False, trend=TREND_CONSTANT):
         """Restricted (REML) log-likelihood, gpr.py:813-918.  exp(llf) > 1 gives -inf WITH the gradient of the finite

@@ -96,6 +96,8 @@ class GaussianProcess:
         device=0,
         distribute_restarts=False,
         restart_streams=None,
+        restart_batch=None,
+        mle_chain_rule=False,
     ):
         self.mean = mean
         self.corr = corr
@@ -108,6 +110,12 @@ class GaussianProcess:
         self.distribute_restarts = bool(distribute_restarts)
         # MLE restarts on `restart_streams` engines (= HIP streams) of the SAME GPU at once (opt-in; None: BOGP_RESTART_STREAMS or 1)
         self.restart_streams = int(restart_streams if restart_streams is not None else os.environ.get("BOGP_RESTART_STREAMS", "1"))
+        # MLE restarts advanced TOGETHER on the device, `restart_batch` at a time (opt-in; None: BOGP_RESTART_BATCH or 0 = the
+        # reference's sequential scipy loop): bogp_mle_batch, one batched likelihood call per round of all active restarts
+        self.restart_batch = int(restart_batch if restart_batch is not None else os.environ.get("BOGP_RESTART_BATCH", "0"))
+        # extension, with restart_batch only: hand the optimiser the gradient of the function it minimises (d / d log10 par) instead of
+        # the reference's d / d par (which stays the default)
+        self.mle_chain_rule = bool(mle_chain_rule)
         self._worker_engines = []
 
         self.theta0 = np.array(theta0, dtype=float).flatten() if theta0 is not None else None
@@ -419,6 +427,17 @@ class GaussianProcess:
         if dist is not None:
             rank, world = dist.get_rank(), dist.get_world_size()
             eval_budget = max(1, -(-eval_budget // world))
+        batch = int(getattr(self, "restart_batch", 0) or 0)
+        if batch > 0 and dist is None:
+            param_opt, llf_opt = self._restarts_in_lock_step(batch, log10param, log10bounds, eval_budget, restricted)
+            optimal_param = 10.0**param_opt
+            env = {}
+            optimal_llf_value = llf_fun(optimal_param, env, _adopt=True)
+            param, i = {}, 0
+            for name, len_ in zip(par_list, par_len):
+                param[name] = optimal_param[i : i + len_]
+                i += len_
+            return param, optimal_llf_value, env, optimal_param
         streams = min(int(getattr(self, "restart_streams", 1) or 1), self.random_start)
         if streams > 1 and dist is None and not restricted:
             param_opt, llf_opt = self._restarts_on_streams(streams, log10param, log10bounds, eval_budget)
@@ -464,6 +483,56 @@ class GaussianProcess:
             param[name] = optimal_param[i : i + len_]
             i += len_
         return param, optimal_llf_value, env, optimal_param
+
+    def _restarts_in_lock_step(self, batch, log10param0, log10bounds, eval_budget, restricted):
+        """The MLE restarts of gpr.py:1127-1162 advanced together, `batch` at a time (bogp_mle_batch): every round of the
+        lock-step loop evaluates the current trial point of each active restart with ONE batched likelihood call (one workgroup a
+        restart for N <= 156, the elimination kernels over `batch` workspaces up to N = 2048), and the optimiser is libbogp's own
+        L-BFGS-B -- the published algorithm scipy's fmin_l_bfgs_b implements, with its defaults, as a re-entrant state machine
+        (tests/test_lbfgsb.py follows scipy's iterates) -- so no Python runs between evaluations.
+
+        The reference's bookkeeping is kept at WAVE granularity: wave w starts restarts w * batch ... (start points drawn from the
+        global np.random in the sequential loop's order, the first being the warm start), its runs share the remaining evaluation
+        budget, and after the wave the best value / stagnation counter / budget are updated restart by restart exactly as
+        gpr.py:1142-1162 does (`<=`: a later restart wins a tie).  batch = 1 is therefore the reference's loop with libbogp's optimiser;
+        batch >= random_start starts every restart, where the sequential loop may stop after `wait_iter` of them bring nothing."""
+        tid, est, beta = self._trend_args()
+        mode, nv, kid = self._MODE[self.estimation_mode], self._nv(), self.kernel_id
+        if restricted:  # the REML objective takes the fixed nugget of the noisy mode as an argument (gpr.py:826-834)
+            nv = self._nv() if self.estimation_mode == "noisy" else 0.0
+        lo, hi = np.ascontiguousarray(log10bounds[:, 0]), np.ascontiguousarray(log10bounds[:, 1])
+        param_opt, llf_opt, first, wait_count = np.array(log10param0, dtype=float), np.inf, True, 0
+        self.eval_count, self.mle_rounds = 0, 0
+        it = 0
+        while it < self.random_start:
+            n_w = min(batch, self.random_start - it)
+            starts = []
+            for r in range(n_w):
+                starts.append(np.array(log10param0, dtype=float) if it + r == 0 else np.random.uniform(lo, hi))
+            xopt, fopt, nev, status, rounds = self.engine.mle_batch(kid, mode, np.array(starts), lo, hi, nv, est, beta, trend=tid,
+                                                                    restricted=restricted, eval_budget=int(eval_budget),
+                                                                    chain_rule=bool(getattr(self, "mle_chain_rule", False)))  # fmt: skip
+            self.mle_rounds += rounds
+            stop = False
+            for r in range(n_w):
+                if first:
+                    param_opt, llf_opt, first = xopt[r], fopt[r], False
+                elif fopt[r] <= llf_opt:
+                    param_opt, llf_opt = xopt[r], fopt[r]
+                    wait_count = 0
+                else:
+                    wait_count += 1
+                if self.verbose:
+                    print("MLE restart %d (lock step): %d likelihood evaluations, status %d, best llf so far %.10g" % (it + r + 1, nev[r], status[r], -llf_opt))
+                self.eval_count += int(nev[r])
+                eval_budget -= int(nev[r])
+                if eval_budget <= 0 or wait_count >= self.wait_iter:
+                    stop = True  # (the whole wave has already run: its later restarts still count, as above)
+            it += n_w
+            if stop:
+                break
+        self._committed_par = None  # (the batched paths leave the factor buffers alone, the fallback paths do not)
+        return np.asarray(param_opt, dtype=float), float(llf_opt)
 
     def _restarts_on_streams(self, streams, log10param0, log10bounds, eval_budget):
         """The MLE restarts of gpr.py:1127-1162 on `streams` engines of ONE GPU at once (the single-device flavour of

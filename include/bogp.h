@@ -28,7 +28,7 @@ extern "C" {
 typedef struct bogp_handle bogp_handle;
 
 /* error codes */
-#define BOGP_ABI_VERSION 7 /* what bogp_abi_version() of a matching library returns */
+#define BOGP_ABI_VERSION 8 /* what bogp_abi_version() of a matching library returns */
 #define BOGP_OK 0
 #define BOGP_ERR_INVALID (-1)      /* bad argument / call order                                           */
 #define BOGP_ERR_HIP (-2)          /* HIP runtime failure (or an in-kernel hand-over that timed out)       */
@@ -124,6 +124,29 @@ int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par, int n_par,
  * other.  The two batched paths leave the handle's factor buffers -- a committed model -- untouched.                          */
 int bogp_nll_batch(bogp_handle* h, int kernel, int mode, int P, const double* par, int n_par, double noise_var, int trend,
                    int estimate_trend, double beta, double* llf, double* grad, int* info);
+
+/* ---- the restarts of the MLE in lock step --------------------------------------------------------------
+ * Replaces the restart loop of GaussianProcess._optimize_hyperparameter (gpr.py:1127-1162: `random_start` runs of
+ * scipy.optimize.fmin_l_bfgs_b over log10(parameters), one after the other) by R bound-constrained L-BFGS runs that advance
+ * TOGETHER: every round evaluates the current trial point of each active run with one bogp_nll_batch call.  Kept from the reference:
+ * the log10 search space and bounds (:1088-1090), the objective -llf(10^x) with the UN-scaled gradient -d llf / d par (:1113-1123),
+ * +inf / zero gradient where the likelihood is rejected, fmin_l_bfgs_b's defaults (m = 10, factr = 1e7, pgtol = 1e-5) and its rule
+ * that budgets are tested when an iterate is accepted, never inside a line search.  Relaxed (hence opt-in on the Python side): the
+ * evaluation budget is shared by runs that all start, so `wait_iter` has nothing to count.
+ *   restricted  0: concentrated likelihood (bogp_nll_batch);  1: REML (bogp_nll_restricted per slot; par layout gpr.py:826-834)
+ *   x0          R x n_par starting points in log10 space (clipped into the bounds);  lo, hi: n_par log10 bounds
+ *   eval_budget evaluations allowed in total over all runs (<= 0: 15000 per run)
+ *   m, factr, pgtol  <= 0: the defaults above
+ *   flags       0: the reference's gradient.  BOGP_MLE_CHAIN_RULE: hand the optimiser d(-llf) / d log10(par) = ln(10) par d / d par,
+ *               the gradient of the function it actually minimises -- NOT what the reference does (an extension: ~4 x fewer
+ *               evaluations per run from a start inside a basin, an immediate stop on the flat plateau of huge theta)
+ *   xopt (R x n_par, log10), fopt (R: -llf at xopt, +inf if a run never saw a finite value), n_evals (R), status (R: 0 projected
+ *   gradient <= pgtol, 1 relative reduction <= factr eps, 2 budget, 3 iterations, 4 line search failed, 5 start not finite),
+ *   n_rounds: batched device calls made; the last three may be NULL.                                                        */
+#define BOGP_MLE_CHAIN_RULE 1 /* flags bit 0 */
+int bogp_mle_batch(bogp_handle* h, int kernel, int mode, int restricted, int R, const double* x0, int n_par, const double* lo,
+                   const double* hi, double noise_var, int trend, int estimate_trend, double beta, int eval_budget, int m, double factr,
+                   double pgtol, int flags, double* xopt, double* fopt, int* n_evals, int* status, int* n_rounds);
 
 /* ---- commit a fitted state ------------------------------------------------------------------------
  * Replaces the tail of GaussianProcess.fit (gpr.py:402-415) + compute_beta_gamma (:784-788): factorise at
@@ -324,6 +347,14 @@ double bogp_flops_per_candidate(const bogp_handle* h);
  * What the reference gets from numpy.dot / scipy.linalg (gpr.py:799-808, 850-918); used by tests/test_gpu_gemm.py.        */
 int bogp_selftest_gemm(bogp_handle* h, int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda,
                        const double* B, int ldb, double beta, double* C, int ldc, int tri, int split);
+
+/* The optimiser behind bogp_mle_batch (csrc/bogp_lbfgsb.h: L-BFGS-B after Byrd, Lu, Nocedal & Zhu 1995 with the More'-Thuente
+ * line search) on a HOST objective: what the reference gets from scipy.optimize.fmin_l_bfgs_b (gpr.py:1136).  No device, no handle;
+ * used by tests/test_lbfgsb.py to compare it with scipy on the CPU.  x: in the start, out the minimiser (n); fn fills *f and g (n).
+ * m / maxfun / maxiter <= 0: 10 / 15000 / 15000.  status as in bogp_mle_batch.                                                  */
+typedef void (*bogp_objective_fn)(const double* x, int n, double* f, double* g, void* user);
+int bogp_lbfgsb_minimize(int n, int m, double* x, const double* lo, const double* hi, double factr, double pgtol, int maxfun,
+                         int maxiter, bogp_objective_fn fn, void* user, double* f, int* nfev, int* nit, int* status);
 
 /* Which device path a concentrated-likelihood evaluation (bogp_nll) of N points in d dimensions would take with the constant
  * basis (trend) and n_targets columns of y -- no handle, no device call (the decision is made from sizes and the environment

@@ -2,7 +2,7 @@
 Rastrigin function; per iteration  tell = standardise + GaussianProcess.fit (multi-restart L-BFGS-B MLE, every likelihood on the GPU),
 ask = EI swept over 1e5 device-generated candidates + lock-step polish of the top 32 ("sweep-device-BFGS").  The model is what
 `bayes_optim.fmin` builds (`__init__.py:147-160`).  Prints the split at a few training-set sizes and the totals.
-usage: python tools/time_bo_loop.py [restart_streams ...]   (e.g. `1 4 8`: the MLE restarts on that many engines of the GPU at once)"""
+usage: python tools/time_bo_loop.py [restart_streams | bR ...]   (e.g. `1 4 8`: the MLE restarts on that many engines of the GPU at once; `b10`: restart_batch = 10, the restarts in lock step)"""
 import os
 import sys
 import time
@@ -14,7 +14,7 @@ import bogp
 from bogp import optim
 
 
-def main(dim=10, max_FEs=200, n_doe=20, seed=1, streams=1):
+def main(dim=10, max_FEs=200, n_doe=20, seed=1, streams=1, batch=0):
     f = lambda x: float(10 * len(x) + np.sum(np.asarray(x) ** 2 - 10 * np.cos(2 * np.pi * np.asarray(x))))  # noqa: E731
     lo, hi = -5.12, 5.12
     box = optim.Box([(lo, hi)] * dim)
@@ -25,7 +25,7 @@ def main(dim=10, max_FEs=200, n_doe=20, seed=1, streams=1):
     rng_len = np.full(dim, hi - lo)
     model = bogp.GaussianProcess(mean=bogp.trend.constant_trend(dim), corr="matern", thetaL=1e-3 * rng_len, thetaU=1e3 * rng_len,
                                  nugget=1e-6, optimizer="BFGS", wait_iter=3, random_start=max(10, dim), eval_budget=100 * dim,
-                                 restart_streams=streams)  # fmt: skip
+                                 restart_streams=streams, restart_batch=batch)  # fmt: skip
     t_tell, t_ask, sizes = [], [], []
     t_all = time.perf_counter()
     while len(y) < max_FEs:
@@ -46,7 +46,7 @@ def main(dim=10, max_FEs=200, n_doe=20, seed=1, streams=1):
         sizes.append(len(y) - 1)
     total = time.perf_counter() - t_all
     t_tell, t_ask, sizes = np.array(t_tell), np.array(t_ask), np.array(sizes)
-    print("== restart_streams = %d" % streams)
+    print("== restart_streams = %d, restart_batch = %d" % (streams, batch))
     print("d = %d, %d evaluations (%d-point DoE), Rastrigin: best %.4f; loop wall time %.2f s = tell %.2f s + ask %.2f s (+ %.2f s of host glue)"
           % (dim, max_FEs, n_doe, y.min(), total, t_tell.sum(), t_ask.sum(), total - t_tell.sum() - t_ask.sum()))
     for n in (25, 50, 100, 150, 199):
@@ -56,5 +56,8 @@ def main(dim=10, max_FEs=200, n_doe=20, seed=1, streams=1):
 
 
 if __name__ == "__main__":
-    for st in [int(a) for a in sys.argv[1:]] or [1]:
-        main(streams=st)
+    for a in sys.argv[1:] or ["1"]:
+        if a.startswith("b"):  # b10: restart_batch = 10 (the restarts in lock step, bogp_mle_batch)
+            main(batch=int(a[1:]))
+        else:
+            main(streams=int(a))
