@@ -97,7 +97,7 @@ int ensure_pinned(bogp_handle* h, size_t doubles) {
 
 // doubles of one slot's workspace on the elimination path, and the offsets of its parts
 struct SlotLayout {
-  size_t E, Eb, yt, ft, logpart, Winv, panels, Rinv, gamma, scal, partial, S, total;
+  size_t E, Eb, yt, ft, logpart, Winv, panels, xpanel, Rinv, gamma, scal, partial, S, total;
 };
 SlotLayout slot_layout(int ld, int d, int N) {
   const size_t nb = (size_t)ld / 64, lde = (size_t)ld + 64;
@@ -111,6 +111,7 @@ SlotLayout slot_layout(int ld, int d, int N) {
   L.logpart = o; o += up8(nb + 1);
   L.Winv = o; o += (nb + 1) * 64 * 64;
   L.panels = o; o += 2 * lde * 64;
+  L.xpanel = o; o += (nb + 1) * 64 * 64;
   L.Rinv = o; o += (size_t)ld * ld;
   L.gamma = o; o += Np;
   L.scal = o; o += 64;
@@ -161,7 +162,7 @@ int ensure_slots(bogp_handle* h, int P, int ld, int d, int N) {
     b.par = b.theta + up8((size_t)d + 1);
     b.ea.E = w + L.E; b.ea.Eb = w + L.Eb; b.ea.ld = ld; b.ea.nb = ld / 64; b.ea.N = N;
     b.ea.yt = w + L.yt; b.ea.ft = w + L.ft; b.ea.logpart = w + L.logpart;
-    b.Winv = w + L.Winv; b.panels = w + L.panels; b.Rinv = w + L.Rinv; b.gamma = w + L.gamma; b.scal = w + L.scal;
+    b.Winv = w + L.Winv; b.panels = w + L.panels; b.xpanel = w + L.xpanel; b.Rinv = w + L.Rinv; b.gamma = w + L.gamma; b.scal = w + L.scal;
     b.ea.info = reinterpret_cast<int*>(b.scal + 62);
     b.partial = w + L.partial; b.S = w + L.S;
     b.ticket = reinterpret_cast<unsigned int*>(tickets + (size_t)s * 8);

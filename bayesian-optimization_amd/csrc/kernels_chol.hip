@@ -1540,6 +1540,43 @@ __global__ __launch_bounds__(256) void k_elim_first_b(const BatchSlot* __restric
   elim_first_block(sl.ea, sl.Winv, sl.panels);
 }
 
+// the updated block back into the state; the blocks of column / row k + 1 into the next raw panel; block (k + 1, k + 1) factored and
+// inverted for the next step.  Shared by the fused step (k_elim_step) and the split one (k_elim_update_b).
+__device__ __forceinline__ void elim_store_block(const ElimArgs& a, int k, int bi, int bj, double (&acc)[4][4], double* __restrict__ Tb, int ldt,
+                                                 double* lds, double* sb, double* __restrict__ Pnext, double* __restrict__ Wn) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lk = lane >> 4;
+  const int lde = a.ld + CB;
+  const int i0 = CB * bi, j0 = CB * bj;
+
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Tb[(size_t)(16 * mi + 4 * t + lk) * ldt + 16 * w + (lane & 15)] = -acc[mi][t];
+  const int kn = k + 1;
+  if (kn >= a.nb) return;
+  if (bj == kn && bi > kn) {  // column kn, as it is
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Pnext[(size_t)(16 * mi + 4 * t + lk) * lde + i0 + 16 * w + (lane & 15)] = -acc[mi][t];
+  } else if (bi == kn && bj < kn) {  // row kn, transposed: raw row block bj
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Pnext[(size_t)(16 * w + (lane & 15)) * lde + j0 + 16 * mi + 4 * t + lk] = -acc[mi][t];
+  } else if (bi == kn && bj == kn) {  // the next diagonal block: factor + invert it here
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) lds[(16 * w + (lane & 15)) * (CB + 1) + 16 * mi + 4 * t + lk] = -acc[mi][t];
+    __syncthreads();
+    elim_diag2(lds, sb, Wn, a.logpart + kn, a.info, CB * kn, 0, max(0, min(CB, a.N - CB * kn)), Pnext, lde, kn, tid);
+  }
+}
+
 __device__ __forceinline__ void elim_step_block(const ElimArgs& a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
                                                 double* __restrict__ Pnext, double* __restrict__ Wn) {
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
@@ -1602,32 +1639,7 @@ __device__ __forceinline__ void elim_step_block(const ElimArgs& a, int k, const 
                  "+v"(bv[9]), "+v"(bv[10]), "+v"(bv[11]), "+v"(bv[12]), "+v"(bv[13]), "+v"(bv[14]), "+v"(bv[15]));
   __syncthreads();
   mma_64(lds, bv, acc, lane);  // -T_new = -T_old + X_i X_j^T
-
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) Tb[(size_t)(16 * mi + 4 * t + lk) * ldt + 16 * w + (lane & 15)] = -acc[mi][t];
-  const int kn = k + 1;
-  if (kn >= a.nb) return;
-  if (bj == kn && bi > kn) {  // column kn, as it is
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) Pnext[(size_t)(16 * mi + 4 * t + lk) * lde + i0 + 16 * w + (lane & 15)] = -acc[mi][t];
-  } else if (bi == kn && bj < kn) {  // row kn, transposed: raw row block bj
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) Pnext[(size_t)(16 * w + (lane & 15)) * lde + j0 + 16 * mi + 4 * t + lk] = -acc[mi][t];
-  } else if (bi == kn && bj == kn) {  // the next diagonal block: factor + invert it here
-    __syncthreads();
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) lds[(16 * w + (lane & 15)) * (CB + 1) + 16 * mi + 4 * t + lk] = -acc[mi][t];
-    __syncthreads();
-    elim_diag2(lds, sb, Wn, a.logpart + kn, a.info, CB * kn, 0, max(0, min(CB, a.N - CB * kn)), Pnext, lde, kn, tid);
-  }
+  elim_store_block(a, k, bi, bj, acc, Tb, ldt, lds, sb, Pnext, Wn);
 }
 __global__ __launch_bounds__(256) void k_elim_step(const ElimArgs a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
                                                    double* __restrict__ Pnext, double* __restrict__ Wn) {
@@ -1639,6 +1651,72 @@ __global__ __launch_bounds__(256) void k_elim_step_b(const BatchSlot* __restrict
   double* P0 = sl.panels;
   double* P1 = sl.panels + lde * CB;
   elim_step_block(sl.ea, k, sl.Winv + (size_t)k * CB * CB, (k & 1) ? P1 : P0, (k & 1) ? P0 : P1, sl.Winv + (size_t)(k + 1) * CB * CB);
+}
+
+// ---- the step split in two launches (batches whose blocks outnumber the workgroup slots) --------------------------------------------
+// k_elim_step lets every workgroup form the two solved panel blocks it needs itself (three 64^3 products a block and step: free while
+// the machine has idle slots, 3 x the flops once P matrices fill it).  Here the nb + 1 solved blocks X_i = M_i W_k^T of a step are
+// formed ONCE (k_elim_panel_b: the same mma_64 on the same operands, stored as plain 64 x 64 tiles) and the update reads them back
+// in the layouts the fused kernel built in registers / LDS (k_elim_update_b: stage_aside / load_bside on the stored tiles): one
+// product a block and step, bit-identical results.
+__global__ __launch_bounds__(256) void k_elim_panel_b(const BatchSlot* __restrict__ slots, int k) {
+  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
+  const BatchSlot& sl = slots[blockIdx.y];
+  const ElimArgs& a = sl.ea;
+  const int bi = blockIdx.x;  // block row 0 .. nb
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lk = lane >> 4;
+  const size_t lde = (size_t)a.ld + CB;
+  const double* __restrict__ Pcur = sl.panels + ((k & 1) ? lde * CB : 0);
+  stage_aside(lds, sl.Winv + (size_t)k * CB * CB, CB, tid);  // tile[kk][c] = W(c, kk)
+  double bv[16];
+  load_bside(bv, Pcur + (size_t)CB * bi, (int)lde, w, lane);
+  double x[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[mi][t] = 0.0;
+  __syncthreads();
+  mma_64(lds, bv, x, lane);  // X_i = M_i W^T: rows 16 w .. of block row bi, element (row, col 16 mi + 4 t + lk)
+  if (bi == a.nb && w == 0 && (lane & 15) < 2) {  // rows 0 / 1 of the solved right-hand sides: Yt, Ft of block k
+    double* dst = (lane & 15) == 0 ? a.yt : a.ft;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) dst[CB * k + 16 * mi + 4 * t + lk] = x[mi][t];
+  }
+  double* __restrict__ Xs = sl.xpanel + (size_t)bi * CB * CB;  // element (row, col) at Xs[row + 64 col]
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Xs[(size_t)(16 * mi + 4 * t + lk) * CB + 16 * w + (lane & 15)] = x[mi][t];
+}
+__global__ __launch_bounds__(256) void k_elim_update_b(const BatchSlot* __restrict__ slots, int k) {
+  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
+  __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
+  const BatchSlot& sl = slots[blockIdx.y];
+  const ElimArgs& a = sl.ea;
+  int bi, bj;
+  tri_index((int)blockIdx.x, bi, bj);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lk = lane >> 4;
+  const size_t lde = (size_t)a.ld + CB;
+  const bool restart = bi == k || bj == k;
+  stage_aside(lds, sl.xpanel + (size_t)bj * CB * CB, CB, tid);  // A side: tile[kk][c] = X_j(c, kk)
+  double bv[16];
+  load_bside(bv, sl.xpanel + (size_t)bi * CB * CB, CB, w, lane);  // B side: X_i(row 16 w + (lane & 15), kk = 4 ks + lk)
+  int ldt;
+  double* __restrict__ Tb = elim_tile(a, bi, bj, ldt);
+  double acc[4][4];  // negated tile
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[mi][t] = restart ? 0.0 : -Tb[(size_t)(16 * mi + 4 * t + lk) * ldt + 16 * w + (lane & 15)];
+  __syncthreads();
+  mma_64(lds, bv, acc, lane);  // -T_new = -T_old + X_i X_j^T
+  elim_store_block(a, k, bi, bj, acc, Tb, ldt, lds, sb, sl.panels + ((k & 1) ? 0 : lde * CB), sl.Winv + (size_t)(k + 1) * CB * CB);
 }
 
 // R^-1 = -T into Rinv (lower triangle, column-major, ldr) and, by the last workgroup, the likelihood's scalars (k_fit_rho's
@@ -1743,7 +1821,18 @@ hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double
   hipLaunchKernelGGL(k_elim_init_b, dim3(ld, P), 64, 0, st, slots, y);
   hipLaunchKernelGGL(k_elim_first_b, dim3(nb + 1, P), 256, 0, st, slots);
   const int grid = (nb + 1) * (nb + 2) / 2 - 1;
-  for (int k = 0; k < nb; ++k) hipLaunchKernelGGL(k_elim_step_b, dim3(grid, P), 256, 0, st, slots, k);
+  // fused steps while the batch leaves workgroup slots idle, split steps (a third of the matrix-core work, one more launch a step)
+  // once it does not: same bits either way.  BOGP_ELIM_SPLIT_BLOCKS: blocks per step from which the split is taken
+  static const long split_from = [] { const char* e = getenv("BOGP_ELIM_SPLIT_BLOCKS"); return e ? atol(e) : 600L; }();
+  const bool split = (long)grid * P >= split_from;
+  for (int k = 0; k < nb; ++k) {
+    if (split) {
+      hipLaunchKernelGGL(k_elim_panel_b, dim3(nb + 1, P), 256, 0, st, slots, k);
+      hipLaunchKernelGGL(k_elim_update_b, dim3(grid, P), 256, 0, st, slots, k);
+    } else {
+      hipLaunchKernelGGL(k_elim_step_b, dim3(grid, P), 256, 0, st, slots, k);
+    }
+  }
   hipLaunchKernelGGL(k_elim_finish_b, dim3(nb * (nb + 1) / 2 + 1, P), 256, 0, st, slots, estimate_trend, mode, beta);
   return hipGetLastError();
 }

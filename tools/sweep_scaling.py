@@ -12,8 +12,11 @@ from bogp import _lib  # noqa: E402
 
 def main():
     eng = _lib.Engine(0)
-    print("%6s %4s %9s %10s %14s %8s" % ("N", "d", "M", "ms/sweep", "candidates/s", "TFLOP/s"))
-    for N, d in ((128, 5), (256, 10), (384, 10), (512, 10), (2048, 20), (8192, 50)):
+    print("%6s %4s %9s %10s %14s %8s %8s   %s" % ("N", "d", "M", "ms/sweep", "candidates/s", "TFLOP/s", "of peak", "kernels of the last sweep (ms): producer / contraction / acquisition+argmax"))
+    sizes = ((128, 5), (256, 10), (384, 10), (512, 10), (768, 10), (1024, 10), (1536, 20), (2048, 20), (8192, 50))
+    if len(sys.argv) > 1:
+        sizes = tuple((int(a), 10 if int(a) < 1536 else 20) for a in sys.argv[1:])
+    for N, d in sizes:
         rng = np.random.default_rng(0)
         X = rng.uniform(-5, 5, size=(N, d))
         y = np.sum(X**2, axis=1)
@@ -30,7 +33,9 @@ def main():
             for _ in range(reps):
                 eng.sweep([(0, 0.0)], float(y.min()), True)
             ms = (time.perf_counter() - t0) / reps * 1e3
-            print("%6d %4d %9d %10.3f %14.3e %8.2f" % (N, d, M, ms, M / ms * 1e3, (float(N) * N + 3.0 * N) * M / ms * 1e3 / 1e12))
+            lt = eng.last_timing()
+            tf = (float(N) * N + 3.0 * N) * M / ms * 1e3 / 1e12
+            print("%6d %4d %9d %10.3f %14.3e %8.2f %8.3f   %.3f / %.3f / %.3f" % (N, d, M, ms, M / ms * 1e3, tf, tf / 78.6, lt["corr_ms"], lt["contract_ms"], lt["acquisition_ms"]))
 
 
 if __name__ == "__main__":
