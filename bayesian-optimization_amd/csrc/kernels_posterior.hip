@@ -117,173 +117,9 @@ constexpr int NWJ = 4;               // waves per workgroup (along j)
 constexpr int KB = 32;               // training points per staged block
 constexpr int PITCH = 64 + 16;       // LDS row pitch in doubles: 640 B == 128 (mod 256) -> conflict-free A reads
 
-// In-place accumulate (vDst == SrcC) through inline asm.  With the builtin, hipcc gives the MFMA a destination
-// different from its SrcC and then restores the accumulator layout with ~128 v_accvgpr_mov per 512-MFMA block at
-// the loop back-edge (and more around every guarded branch); tying the operand removes all of them.
-// Hazards (cdna_hip_programming.md 5.7): A/B operands come straight from LDS / global loads (the compiler's own
-// s_waitcnt covers them, no VALU write precedes the MFMA); D is only ever consumed by the next MFMA on the same
-// accumulator as its whole SrcC (0 wait states) until the epilogue, which is fenced by BOGP_MFMA_DRAIN().
-__device__ __forceinline__ void mfma4_acc(double a, double b, double& c) {
-  asm("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
-#define BOGP_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
-
-// One 32-row block of n: 4 k-pairs x 2 k-steps x (MR x NR x 4) MFMAs.  GUARDED = this block touches the diagonal
-// (16x16 tiles above it are skipped, wave-uniform predicates).  All global loads are unconditional (addresses
-// clamped) so that the compiler can keep counted vmcnt waits and the B prefetch stays one k-pair ahead.
-template <int NR>
-__device__ __forceinline__ void contract_block(const bool GUARDED, const double* __restrict__ tile, const double2* __restrict__ vp,
-                                               const size_t (&boff)[NR], const int (&jt)[NR], const int (&aoff)[4],
-                                               int kb, int kp_last, double2 (&bq)[2][NR], double (&acc)[MR][NR][4]) {
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int kp = kb * 4 + s;
-    const int kb16 = kp >> 1;
-    {  // prefetch the next k-pair of B fragments (clamped at the end of this group's range)
-      const int kpn = min(kp + 1, kp_last);
-#pragma unroll
-      for (int ni = 0; ni < NR; ++ni) bq[(s + 1) & 1][ni] = vp[boff[ni] + (size_t)kpn * 64];
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const double* trow = tile + (4 * (2 * s + h)) * PITCH;
-      double af[MR][4];
-#pragma unroll
-      for (int mi = 0; mi < MR; ++mi)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) af[mi][t] = trow[aoff[t] + 16 * mi];
-#pragma unroll
-      for (int ni = 0; ni < NR; ++ni) {
-        if (!GUARDED || kb16 <= jt[ni]) {
-          const double bv = h == 0 ? bq[s & 1][ni].x : bq[s & 1][ni].y;
-#pragma unroll
-          for (int mi = 0; mi < MR; ++mi)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) mfma4_acc(af[mi][t], bv, acc[mi][ni][t]);
-        }
-      }
-    }
-  }
-}
-
-template <int NR>
-__global__ __launch_bounds__(256, 2) void k_contract(ContractArgs a) {
-  constexpr int JT16 = NWJ * NR;  // sixteen-wide column tiles per workgroup
-  __shared__ __attribute__((aligned(16))) double lds[2 * KB * PITCH];  // 40 KB: two r tiles [32][80]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // heavy (long-K) column groups first
-  const int nMt = a.nMt;
-  const int jg = a.nJ - 1 - (int)(blockIdx.x / nMt);
-  const int mt = blockIdx.x % nMt;
-  const int64_t mc0 = (int64_t)mt * 64;
-  const int NJ16 = a.NJ16, NKP = a.NKP;
-  const int kmax16 = min((jg + 1) * JT16, NJ16);  // sixteen-blocks of n this group needs (even: Np % 32 == 0)
-  const int nkb = kmax16 >> 1;
-  const int nkb_full = jg * (JT16 / 2);  // blocks entirely below this group's diagonal: every tile is active
-  const int kp_last = 2 * kmax16 - 1;
-
-  // column tiles of this wave, interleaved across the 4 waves; tiles past the matrix edge are computed on
-  // clamped (valid) addresses and dropped in the epilogue
-  int jt[NR];
-  size_t boff[NR];
-  bool valid[NR];
-#pragma unroll
-  for (int ni = 0; ni < NR; ++ni) {
-    const int j = jg * JT16 + w + NWJ * ni;
-    valid[ni] = j < NJ16;
-    jt[ni] = valid[ni] ? j : -1;  // -1: never active in the guarded phase
-    boff[ni] = (size_t)min(j, NJ16 - 1) * NKP * 64;
-  }
-
-  double acc[MR][NR][4];
-#pragma unroll
-  for (int mi = 0; mi < MR; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NR; ++ni)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[mi][ni][t] = 0.0;
-
-  // ---- staging of the r tile: 32 rows x 512 B, 4 x 16 B per thread --------------------------------
-  const int srow = tid >> 5;        // 0..7 (+8c)
-  const int scol = (tid & 31) * 2;  // double index inside the 64-wide row
-  const double* __restrict__ rbase = a.rT + mc0 + scol;
-  const size_t Mc = (size_t)a.Mc;
-  double2 st0, st1, st2, st3;  // named registers: an indexed array here ends up in scratch
-#define BOGP_STAGE_LOAD(kb_)                                                                         \
-  do {                                                                                               \
-    const double* p_ = rbase + (size_t)((kb_)*KB + srow) * Mc;                                       \
-    st0 = *reinterpret_cast<const double2*>(p_);                                                     \
-    st1 = *reinterpret_cast<const double2*>(p_ + 8 * Mc);                                            \
-    st2 = *reinterpret_cast<const double2*>(p_ + 16 * Mc);                                           \
-    st3 = *reinterpret_cast<const double2*>(p_ + 24 * Mc);                                           \
-  } while (0)
-#define BOGP_STAGE_STORE(buf_)                                                                       \
-  do {                                                                                               \
-    double* q_ = &lds[(buf_)*KB * PITCH + srow * PITCH + scol];                                      \
-    *reinterpret_cast<double2*>(q_) = st0;                                                           \
-    *reinterpret_cast<double2*>(q_ + 8 * PITCH) = st1;                                               \
-    *reinterpret_cast<double2*>(q_ + 16 * PITCH) = st2;                                              \
-    *reinterpret_cast<double2*>(q_ + 24 * PITCH) = st3;                                              \
-  } while (0)
-
-  // ---- B fragments: Vp[jt][kp][lane] = (V[j][8kp + k], V[j][8kp + 4 + k]),  j = 16 jt + (lane&15), k = lane>>4
-  const double2* __restrict__ vp = a.Vp + lane;
-  double2 bq[2][NR];
-#pragma unroll
-  for (int ni = 0; ni < NR; ++ni) bq[0][ni] = vp[boff[ni]];
-
-  // A-fragment read offsets (doubles) for this lane: A lane = 16k + 4b + i reads row k, column 4*((b+t)&3) + i
-  const int lk = lane >> 4, lb = (lane >> 2) & 3, li = lane & 3;
-  int aoff[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) aoff[t] = lk * PITCH + 4 * ((lb + t) & 3) + li;
-
-  BOGP_STAGE_LOAD(0);
-  BOGP_STAGE_STORE(0);
-
-  for (int kb = 0; kb < nkb; ++kb) {
-    __syncthreads();                       // tile kb is in lds[kb & 1]; every wave is done with the other buffer
-    BOGP_STAGE_LOAD(min(kb + 1, nkb - 1));  // next tile -> registers, in flight during the MFMAs
-    const double* tile = &lds[(kb & 1) * KB * PITCH];
-    contract_block<NR>(kb >= nkb_full, tile, vp, boff, jt, aoff, kb, kp_last, bq, acc);
-    BOGP_STAGE_STORE((kb + 1) & 1);
-  }
-#undef BOGP_STAGE_LOAD
-#undef BOGP_STAGE_STORE
-
-  // ---- epilogue: sum of squares over this group's columns, per candidate row -----------------------
-  BOGP_MFMA_DRAIN();
-#pragma unroll
-  for (int mi = 0; mi < MR; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NR; ++ni)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) asm volatile("" : "+a"(acc[mi][ni][t]));  // reads of the accumulators stay behind the drain
-  __syncthreads();
-  double* red = lds;  // [NWJ][64 rows][16 slots]
-#pragma unroll
-  for (int mi = 0; mi < MR; ++mi)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      double s = 0.0;
-#pragma unroll
-      for (int ni = 0; ni < NR; ++ni)
-        if (valid[ni]) s = __builtin_fma(acc[mi][ni][t], acc[mi][ni][t], s);
-      const int row = 16 * mi + 4 * ((lb + t) & 3) + lk;  // D lane = 16 i + 4 b + j  ->  i = lane>>4
-      red[(w * 64 + row) * 16 + 4 * lb + li] = s;  // slot = column inside the 16-tile: row-position independent order
-    }
-  __syncthreads();
-  if (tid < 64) {
-    double s = 0.0;
-    for (int ww = 0; ww < NWJ; ++ww)
-#pragma unroll
-      for (int sl = 0; sl < 16; ++sl) s += red[(ww * 64 + tid) * 16 + sl];
-    a.ss_part[(size_t)jg * a.Mc + mc0 + tid] = s;
-  }
-}
+// (r04: the first contraction kernel, k_contract on v_mfma_f64_4x4x4_4b_f64 with AGPR accumulators -- opt-in since r01 through
+// BOGP_CONTRACT_MFMA=4x4, 20 % slower than k_contract16 -- was removed: tests/test_isa_lint.py found AGPR spills inside its main loop and an
+// accumulator read ahead of its drain in the ROCm 7.2 build.  Its description stays in DESIGN.md section 5.2; the code is in git 26333e7.)
 
 // ---------------------------------------------------------------------------------------------------
 // Kernel B': the same contraction on v_mfma_f64_16x16x4_f64.
@@ -445,13 +281,19 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
 #undef BOGP_STAGE_STORE
 
   // ---- epilogue: D[i][j] sits in lane 16 (i % 4) + j, register i / 4 ---------------------------------
+  // (BOGP_LINT_NO_DRAIN / BOGP_LINT_NO_FENCE: negative controls of tests/test_isa_lint.py -- builds WITHOUT the drain / the fences must
+  // be flagged by the ISA lint; never defined in the product build)
+#ifndef BOGP_LINT_NO_DRAIN
   BOGP_MFMA16_DRAIN();
+#endif
   // (the drain has no register operands: an empty volatile asm per accumulator behind it keeps the epilogue's reads from being
   // scheduled above it -- the MFMAs are inline asm whose results look ready at once to the compiler; kernels_small.hip)
+#ifndef BOGP_LINT_NO_FENCE
 #pragma unroll
   for (int mi = 0; mi < MR; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NR; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
+#endif
   __syncthreads();
   // red[slot][wave][row] with a row pitch of 65 doubles: the writes (lanes = 4 rows x 16 slots) fall on (4 slot + row)
   // mod 32 = every bank pair twice, the reads (lanes = 64 consecutive rows) are conflict free.  (The first layout,
@@ -551,27 +393,9 @@ static int contract_nr() {
   return nr;
 }
 
-static bool contract_use_16x16() {
-  static bool v = [] {
-    const char* e = getenv("BOGP_CONTRACT_MFMA");  // "4x4": kernel B (v_mfma_f64_4x4x4_4b_f64), kept for A/B measurements
-    return !(e && e[0] == '4');
-  }();
-  return v;
-}
-
 hipError_t launch_contract(const ContractArgs& a, hipStream_t st) {
-  if (contract_use_16x16() && contract_nr() == 4) {
-    hipLaunchKernelGGL(k_contract16<4>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
-    return hipGetLastError();
-  }
-  if (contract_use_16x16() && contract_nr() == 2) {
-    hipLaunchKernelGGL(k_contract16<2>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
-    return hipGetLastError();
-  }
-  if (contract_nr() == 4)
-    hipLaunchKernelGGL(k_contract<4>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
-  else
-    hipLaunchKernelGGL(k_contract<2>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
+  if (contract_nr() == 4) hipLaunchKernelGGL(k_contract16<4>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
+  else hipLaunchKernelGGL(k_contract16<2>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
   return hipGetLastError();
 }
 

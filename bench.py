@@ -327,10 +327,8 @@ def main():
         if tim["corr_ms"] == 0.0 and tim["acquisition_ms"] == 0.0:  # the fused small-N sweep: ONE kernel, its whole time
             kernel_label = ("k_sweep_small (N <= 512: correlation producer + v_mfma_f64_16x16x4_f64 contraction + acquisition + "
                             "argmax in ONE kernel; `achieved` counts the contraction's flops over the whole kernel's time)")
-        elif os.environ.get("BOGP_CONTRACT_MFMA", "16")[0] != "4":
-            kernel_label = "k_contract16 (v_mfma_f64_16x16x4_f64, VGPR accumulators)"
         else:
-            kernel_label = "k_contract (v_mfma_f64_4x4x4_4b_f64)"
+            kernel_label = "k_contract16 (v_mfma_f64_16x16x4_f64, VGPR accumulators)"
         res = {
             "metric": "candidates/sec (GP posterior+EI) at N=2048,d=20 and ask() wall-time, 1/2/4/8 GPU",
             "value": value,
