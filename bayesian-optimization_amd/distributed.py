@@ -46,12 +46,22 @@ def init_engine_comm(engine, group=None):
     if getattr(engine, "comm_world", 0):
         return engine.comm_rank, engine.comm_world
     dist = _dist()
+    make_id = getattr(engine, "comm_unique_id", _lib.comm_unique_id)  # (an engine may bring its own transport's id: CPU stand-ins in tests)
     if dist is None:
-        engine.comm_init(_lib.comm_unique_id(), 0, 1)
+        engine.comm_init(make_id(), 0, 1)
         return 0, 1
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    box = [_lib.comm_unique_id() if rank == 0 else None]
+    # (rank 0 may fail to create the id -- librccl missing, say: the failure travels in the broadcast, so that every rank raises
+    # instead of waiting for an id that never comes)
+    box = [None]
+    if rank == 0:
+        try:
+            box = [make_id()]
+        except Exception as e:  # noqa: BLE001
+            box = [RuntimeError("rank 0 could not create the communicator id: %s" % e)]
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if isinstance(box[0], Exception):
+        raise box[0]
     engine.comm_init(box[0], rank, world)
     return rank, world
 

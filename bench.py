@@ -122,7 +122,14 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: M candidates per GPU (default); strong: the workload's total (C3 1e6, C4 8e6, C5 4e6) split over the ranks")
     ap.add_argument("--plumbing-check", action="store_true", help=argparse.SUPPRESS)
+    # CPU dry run of the WHOLE step on N gloo ranks (tests/test_dist_gloo.py): the engine is a stand-in class named here
+    # (tests/support/oracle_engine.py:OracleEngine -- test infrastructure, loaded only under this flag), sizes are cut down to "N,d,M";
+    # --dry-fail-comm-rank R makes rank R fail to build its communicator, which must send EVERY rank down the fallback exchange
+    ap.add_argument("--dry-run-engine", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--dry-size", default="96,4,4001", help=argparse.SUPPRESS)
+    ap.add_argument("--dry-fail-comm-rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    dry = args.dry_run_engine is not None
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         import subprocess
@@ -142,20 +149,29 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs a %d-rank torch.distributed.run launch (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
-    torch.cuda.set_device(local)
+    dev = torch.device("cpu") if dry else torch.device("cuda", local)
+    if not dry:
+        torch.cuda.set_device(local)
     use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run (also with 1 rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    total_strong = {"C2": 100_000, "C3": 1_000_000, "C4": 8_000_000, "C5": 4_000_000}[args.workload]
+    if dry:  # the same criteria and kernel, a problem the CPU stand-in sweeps in a second
+        w["N"], w["d"], w["M"] = (int(v) for v in args.dry_size.split(","))
+        w["theta"] = 0.3 / w["d"]
+        total_strong = w["M"] * world + 3  # ragged for every world size > 1
     N, d, M = w["N"], w["d"], w["M"]
     offset = rank * M
     if args.scaling == "strong":  # fixed total, contiguous ragged shards (optim.shard_bounds)
         from bogp.optim import shard_bounds
 
-        total_strong = {"C2": 100_000, "C3": 1_000_000, "C4": 8_000_000, "C5": 4_000_000}[args.workload]
         a_, b_ = shard_bounds(total_strong, rank, world)
         M, offset = b_ - a_, a_
     rng = np.random.default_rng(0)  # the model is replicated: every rank builds and factorises the same one
@@ -165,7 +181,14 @@ def main():
     par = np.r_[np.full(d, w["theta"]), 0.9]
     plugin = float(y.min())
 
-    eng = _lib.Engine(local)
+    if dry:
+        import importlib
+
+        mod, cls = args.dry_run_engine.split(":")
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        eng = getattr(importlib.import_module(mod), cls)()
+    else:
+        eng = _lib.Engine(local)
     eng.set_train(X, y)
     t0 = time.perf_counter()
     llf = eng.commit(w["kernel"], _lib.MODE_NOISY, par, 1e-6, False, 0.0)
@@ -173,7 +196,7 @@ def main():
     # fit is reported separately: one likelihood (+ gradient) evaluation at the pinned parameters = what the
     # MLE loop of GaussianProcess.fit pays per L-BFGS-B evaluation; the model is re-committed afterwards
     fit_ms = {}
-    if True:
+    if not dry:
         for name, eg in (("llf_ms", False), ("llf_grad_ms", True)):
             eng.nll(w["kernel"], _lib.MODE_NOISY, par, 1e-6, False, 0.0, eval_grad=eg)
             t0 = time.perf_counter()
@@ -193,11 +216,17 @@ def main():
         fit_ms["commit_ms"] = (time.perf_counter() - t0) * 1e3
 
     # this rank's candidate shard, generated on the device and adopted without a copy
-    g = torch.Generator(device="cuda")
-    g.manual_seed(1234 + rank)
-    Xs = (torch.rand((M, d), dtype=torch.float64, device="cuda", generator=g) * 10.0 - 5.0).contiguous()
-    torch.cuda.synchronize()
-    eng.bind_candidates(Xs.data_ptr(), M, owner=Xs)
+    if dry:
+        # rows [offset, offset + M) of ONE global table that every rank (and the checking test) can rebuild: row i is drawn from its own
+        # seed, so a shard does not depend on how the table is cut
+        Xs = torch.from_numpy(dry_candidates(offset, M, d))
+        eng.upload_candidates(Xs.numpy())
+    else:
+        g = torch.Generator(device="cuda")
+        g.manual_seed(1234 + rank)
+        Xs = (torch.rand((M, d), dtype=torch.float64, device="cuda", generator=g) * 10.0 - 5.0).contiguous()
+        torch.cuda.synchronize()
+        eng.bind_candidates(Xs.data_ptr(), M, owner=Xs)
     # the library's own RCCL communicator over the ranks (a one-rank communicator at N = 1: the collective still runs)
     # (RCCL announces itself on C stdout: send that to stderr so that stdout carries the JSON line and nothing else)
     sys.stdout.flush()
@@ -205,6 +234,12 @@ def main():
     os.dup2(2, 1)
     comm_error = None
     try:
+        if rank == args.dry_fail_comm_rank:  # (fails where ncclCommInitRank would: after the id has been broadcast)
+
+            def _fail(*_a):
+                raise RuntimeError("communicator creation failed on rank %d (forced by --dry-fail-comm-rank)" % rank)
+
+            eng.comm_init = _fail
         distributed.init_engine_comm(eng)
     except Exception as e:  # noqa: BLE001 -- reported in the JSON line, never silent
         comm_error = "%s: %s" % (type(e).__name__, e)
@@ -213,7 +248,7 @@ def main():
         os.dup2(saved, 1)
         os.close(saved)
     if use_dist:  # every rank takes the same path: the library exchange only if EVERY rank has its communicator
-        ok = torch.tensor([0.0 if comm_error else 1.0], dtype=torch.float64, device="cuda")
+        ok = torch.tensor([0.0 if comm_error else 1.0], dtype=torch.float64, device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if float(ok.item()) == 0.0 and comm_error is None:
             comm_error = "another rank could not create the library communicator"
@@ -233,7 +268,8 @@ def main():
     def fence():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -252,14 +288,14 @@ def main():
     elapsed = time.perf_counter() - t0
     per_rank_ms = [elapsed / args.steps * 1e3]
     if use_dist:
-        each = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
-        dist.all_gather(each, torch.tensor([elapsed], dtype=torch.float64, device="cuda"))
+        each = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(each, torch.tensor([elapsed], dtype=torch.float64, device=dev))
         per_rank_ms = [float(e.item()) / args.steps * 1e3 for e in each]
         elapsed = max(float(e.item()) for e in each)  # MAX over ranks
 
     # PCIe-inclusive ask(): H2D of the shard + one step (noted, never `value`)
     h2d_ms = gen_ms = full_ms = None
-    if rank == 0 and args.scaling == "weak":
+    if rank == 0 and args.scaling == "weak" and not dry:
         Xh = Xs.cpu().numpy()
         t1 = time.perf_counter()
         eng.upload_candidates(Xh)
@@ -286,7 +322,7 @@ def main():
     # for seeds 1 and 2 -- another training set, another candidate shard, the model re-committed outside the timed steps -- and the
     # median / min / max step of each seed is reported beside it.  The committed model and candidates are seed 0's again afterwards.
     seed_stats = None
-    if rank == 0 and world == 1 and args.scaling == "weak" and not args.no_seeds:
+    if rank == 0 and world == 1 and args.scaling == "weak" and not args.no_seeds and not dry:
         seed_stats = {"0": {"median_ms": float(np.median(step_ms)), "min_ms": float(np.min(step_ms)), "max_ms": float(np.max(step_ms)), "steps": len(step_ms)}}
         for sd in (1, 2):
             r2 = np.random.default_rng(sd)
@@ -313,11 +349,28 @@ def main():
         eng.bind_candidates(Xs.data_ptr(), M, owner=Xs)
 
     if use_dist:  # ragged shards under --scaling strong: the job's candidate count is the sum over ranks
-        tm = torch.tensor([float(M)], dtype=torch.float64, device="cuda")
+        tm = torch.tensor([float(M)], dtype=torch.float64, device=dev)
         dist.all_reduce(tm, op=dist.ReduceOp.SUM)
         M_total = float(tm.item())
     else:
         M_total = float(M)
+    if dry:
+        # every rank must hold the same (values, GLOBAL indices, points): gathered and compared here, reported by rank 0
+        mine = [np.asarray(out[0]).tolist(), [int(i) for i in out[1]], np.asarray(out[2]).tolist()]
+        everyone = [None] * world
+        if use_dist:
+            dist.all_gather_object(everyone, mine)
+        else:
+            everyone = [mine]
+        if rank == 0:
+            ctypes.CDLL(None).fflush(None)
+            print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "scaling": args.scaling, "M_total": M_total, "shard": [offset, M],
+                              "values": mine[0], "argmax": mine[1], "points": mine[2], "ranks_identical": all(e == mine for e in everyone),
+                              "exchange": "engine" if comm_error is None else "fallback (%s)" % comm_error,
+                              "ms_per_step": elapsed / args.steps * 1e3}), flush=True)  # fmt: skip
+        if use_dist:
+            dist.destroy_process_group()
+        return
     if rank == 0:
         total = M_total * args.steps
         value = total / elapsed
@@ -379,6 +432,11 @@ def main():
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def dry_candidates(first_row, n_rows, d):
+    """Rows [first_row, first_row + n_rows) of the dry run's global candidate table: row i = default_rng(10_000 + i).uniform(-5, 5, d)."""
+    return np.array([np.random.default_rng(10_000 + i).uniform(-5.0, 5.0, size=d) for i in range(first_row, first_row + n_rows)]).reshape(n_rows, d)
 
 
 def cpu_baseline(w, X, y, par, plugin, Xh, n_sample, eng):

@@ -72,11 +72,42 @@ class OracleEngine:
         mu, mse = self.predict()
         return [O.acquisition(a, p, mu, mse, plugin, self.st.sigma2[0], minimize) for a, p in acq]
 
-    def sweep(self, acq, plugin, minimize=True, return_values=False):
+    def sweep(self, acq, plugin, minimize=True, return_values=False, local_result=True):
         vals = self._vals(acq, plugin, minimize)
         idx = np.array([int(np.argmax(v)) for v in vals], dtype=np.int64)
         best = np.array([v[i] for v, i in zip(vals, idx)])
+        self._last = (best, idx)
+        if not local_result:  # bogp_sweep with NULL outputs: the winners stay "on the device" for exchange_argmax
+            return None
         return (best, idx, np.array(vals)) if return_values else (best, idx)
+
+    def read_candidates(self, rows):
+        return self.Xs[np.asarray(rows, dtype=np.int64)].copy()
+
+    def last_timing(self):
+        return dict(corr_ms=0.0, contract_ms=0.0, acquisition_ms=0.0, n_chunks=0)
+
+    # -- the cross-rank exchange of bogp_comm.hip, on torch.distributed (gloo) instead of RCCL: same records, same reduce ------------
+    comm_rank, comm_world = 0, 0
+
+    @staticmethod
+    def comm_unique_id():
+        return b"oracle-engine-stand-in".ljust(_lib.COMM_ID_BYTES, b"\0")
+
+    def comm_init(self, uid, rank, world):
+        assert len(uid) == _lib.COMM_ID_BYTES
+        self.comm_rank, self.comm_world = int(rank), int(world)
+
+    def comm_destroy(self):
+        self.comm_rank, self.comm_world = 0, 0
+
+    def exchange_argmax(self, q, index_offset, with_x=True):
+        from bogp import distributed
+
+        assert self.comm_world > 0, "exchange without a communicator"
+        best, idx = self._last
+        assert len(best) == q
+        return distributed.exchange_argmax(best, idx + int(index_offset), self.Xs[idx] if with_x else None)
 
     def sweep_topk(self, acq, plugin, minimize=True, k=1):
         vals = self._vals(acq, plugin, minimize)
