@@ -49,6 +49,7 @@ SIGNATURES = {
     "bogp_set_trend_beta": (C.c_int, [C.c_void_p, _dp, C.c_int]),
     "bogp_get_trend_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
     "bogp_candidates_upload": (C.c_int, [C.c_void_p, _dp, C.c_int64]),
+    "bogp_candidates_upload_lazy": (C.c_int, [C.c_void_p, _dp, C.c_int64]),
     "bogp_candidates_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "bogp_candidates_generate": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_uint64, C.c_int64]),
     "bogp_candidates_generate_lhs": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_uint64, C.c_int64, C.c_int64]),
@@ -409,14 +410,18 @@ class Engine:
         return out
 
     # -- candidates ---------------------------------------------------------------------------------
-    def upload_candidates(self, Xs):
+    def upload_candidates(self, Xs, lazy=False):
+        """Host candidates (M, d).  `lazy=True`: only the head is copied now, the rest travels chunk by chunk beside the kernels of the
+        NEXT predict / sweep / sweep_topk call (bogp_candidates_upload_lazy) -- the array is kept alive by the engine until then, and
+        the caller must not modify it before that call returns."""
         Xs = _f64(Xs)
         if Xs.ndim != 2 or Xs.shape[1] != self.d:
             raise ValueError("candidates must have shape (M, %d)" % self.d)
-        self._check(self._lib.bogp_candidates_upload(self._h, _ptr(Xs), Xs.shape[0]))
+        fn = self._lib.bogp_candidates_upload_lazy if lazy else self._lib.bogp_candidates_upload
+        self._check(fn(self._h, _ptr(Xs), Xs.shape[0]))
         self.M = Xs.shape[0]
         self._last_q, self._last_topk = -1, (-1, -1)  # winners of an earlier sweep refer to other rows
-        self._keep = None
+        self._keep = Xs if lazy else None
 
     def bind_candidates(self, device_ptr: int, M: int, owner=None):
         """Adopt caller-owned device memory (M x d float64 row-major), e.g. a torch tensor's data_ptr()."""

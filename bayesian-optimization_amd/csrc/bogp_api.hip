@@ -141,6 +141,8 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream_upd) (void)hipStreamDestroy(h->stream_upd);
+  if (h->stream_copy) (void)hipStreamDestroy(h->stream_copy);
+  if (h->ev_copy) (void)hipEventDestroy(h->ev_copy);
   if (h->hfit) (void)hipHostFree(h->hfit);
   if (h->dfin_ticket) (void)hipFree(h->dfin_ticket);
   delete h;
@@ -1073,14 +1075,74 @@ extern "C" int bogp_get_trend_state(bogp_handle* h, double* Ft, double* Q, doubl
 // bogp_exchange_* (stale or out-of-range rows would be packed otherwise).
 static void invalidate_sweep_results(bogp_handle* h) { h->last_q = h->last_topk_q = h->last_topk_k = 0; }
 
+// ---- lazy upload: the copy of chunk c + 1 runs beside the kernels of chunk c --------------------------------------------------------
+// rows [lazy_done, upto) onto the copy stream (a copy from pageable memory blocks the HOST while the runtime stages it, not the
+// device: the kernels queued before it keep running), the event re-recorded behind it
+static int lazy_copy_to(bogp_handle* h, int64_t upto) {
+  if (!h->hXs_lazy) return BOGP_OK;
+  upto = std::min<int64_t>(upto, h->M);
+  if (upto <= h->lazy_done) return BOGP_OK;
+  const size_t d = (size_t)h->d;
+  HIPCHK(h, hipMemcpyAsync(h->dXs_owned + (size_t)h->lazy_done * d, h->hXs_lazy + (size_t)h->lazy_done * d,
+                           (size_t)(upto - h->lazy_done) * d * sizeof(double), hipMemcpyHostToDevice, h->stream_copy));
+  HIPCHK(h, hipEventRecord(h->ev_copy, h->stream_copy));
+  h->lazy_done = upto;
+  return BOGP_OK;
+}
+// `st` waits for every copy enqueued so far
+static int lazy_wait(bogp_handle* h, hipStream_t st) {
+  if (!h->hXs_lazy || h->lazy_done == 0) return BOGP_OK;
+  HIPCHK(h, hipStreamWaitEvent(st, h->ev_copy, 0));
+  return BOGP_OK;
+}
+// everything copied and visible to the main stream; the host rows are not needed any more
+static int lazy_finish(bogp_handle* h) {
+  if (!h->hXs_lazy) return BOGP_OK;
+  int e = lazy_copy_to(h, h->M);
+  if (e) return e;
+  HIPCHK(h, hipStreamSynchronize(h->stream_copy));
+  h->hXs_lazy = nullptr;
+  return BOGP_OK;
+}
+static int lazy_drop(bogp_handle* h) {  // new candidates arrive: pending copies of the old ones must not land later
+  if (h->hXs_lazy) {
+    HIPCHK(h, hipStreamSynchronize(h->stream_copy));
+    h->hXs_lazy = nullptr;
+  }
+  return BOGP_OK;
+}
+
+extern "C" int bogp_candidates_upload_lazy(bogp_handle* h, const double* Xs, int64_t M) {
+  if (!h) return BOGP_ERR_INVALID;
+  invalidate_sweep_results(h);
+  if (!Xs || M <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_upload_lazy: Xs must be non-null and M > 0");
+  if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_upload_lazy: call bogp_set_train first (d is unknown)");
+  HIPCHK(h, hipSetDevice(h->device));
+  int e = lazy_drop(h);
+  if (e) return e;
+  if (!h->stream_copy) HIPCHK(h, hipStreamCreateWithFlags(&h->stream_copy, hipStreamNonBlocking));
+  if (!h->ev_copy) HIPCHK(h, hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming));
+  if ((e = ensure(h, &h->dXs_owned, &h->xs_cap, (size_t)M * h->d))) return e;
+  // (the buffer may have been re-allocated, and the last sweep may still read the old candidates: the copies start behind it)
+  HIPCHK(h, hipEventRecord(h->ev_copy, h->stream));
+  HIPCHK(h, hipStreamWaitEvent(h->stream_copy, h->ev_copy, 0));
+  h->dXs = h->dXs_owned;
+  h->M = M;
+  h->hXs_lazy = Xs;
+  h->lazy_done = 0;
+  // the first 8 MB go now: they are what the first chunk of the next sweep waits for
+  return lazy_copy_to(h, std::max<int64_t>(1, ((int64_t)8 << 20) / (int64_t)(h->d * sizeof(double))));
+}
+
 extern "C" int bogp_candidates_upload(bogp_handle* h, const double* Xs, int64_t M) {
   if (!h) return BOGP_ERR_INVALID;
   invalidate_sweep_results(h);
   if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_upload: call bogp_set_train first (d is unknown)");
   if (!Xs || M <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_upload: Xs must be non-null and M > 0");
   HIPCHK(h, hipSetDevice(h->device));
-  int e = ensure(h, &h->dXs_owned, &h->xs_cap, (size_t)M * h->d);
+  int e = lazy_drop(h);
   if (e) return e;
+  if ((e = ensure(h, &h->dXs_owned, &h->xs_cap, (size_t)M * h->d))) return e;
   HIPCHK(h, hipMemcpyAsync(h->dXs_owned, Xs, (size_t)M * h->d * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->dXs = h->dXs_owned;
@@ -1097,8 +1159,9 @@ static int generate_prepare(bogp_handle* h, const char* who, const double* lo, c
   for (int k = 0; k < d; ++k)
     if (!(std::isfinite(lo[k]) && std::isfinite(hi[k]) && lo[k] <= hi[k])) FAIL(h, BOGP_ERR_INVALID, "%s: bad bounds in dimension %d", who, k);
   HIPCHK(h, hipSetDevice(h->device));
-  int e = ensure(h, &h->dXs_owned, &h->xs_cap, (size_t)M * d);
+  int e = lazy_drop(h);
   if (e) return e;
+  if ((e = ensure(h, &h->dXs_owned, &h->xs_cap, (size_t)M * d))) return e;
   if ((e = ensure(h, &h->dbounds, &h->bounds_cap, (size_t)2 * d))) return e;
   HIPCHK(h, hipMemcpyAsync(h->dbounds, lo, d * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->dbounds + d, hi, d * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1175,6 +1238,10 @@ extern "C" int bogp_candidates_min_pdist2(bogp_handle* h, double* min_sq) {
   if (!min_sq) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_min_pdist2: null output");
   if (h->M > BOGP_MAXIMIN_MAX_POINTS) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_candidates_min_pdist2: %lld points exceed the %lld-point limit of the O(M^2 d) pair sweep", (long long)h->M, (long long)BOGP_MAXIMIN_MAX_POINTS);
   HIPCHK(h, hipSetDevice(h->device));
+  {
+    const int e = lazy_finish(h);
+    if (e) return e;
+  }
   unsigned long long* dout = (unsigned long long*)h->dscal;
   HIPCHK(h, launch_min_pdist2(h->dXs, (int)h->M, h->d, dout, h->stream));
   unsigned long long bits = 0;
@@ -1246,6 +1313,10 @@ extern "C" int bogp_candidates_read(bogp_handle* h, const int64_t* rows, int n, 
   if (!h->dXs || h->M <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_read: no candidates");
   if (!rows || !out || n < 0) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_read: null pointer");
   HIPCHK(h, hipSetDevice(h->device));
+  {
+    const int e = lazy_finish(h);
+    if (e) return e;
+  }
   const int d = h->d;
   for (int i = 0; i < n; ++i)
     if (rows[i] < 0 || rows[i] >= h->M) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_read: row %lld outside [0, %lld)", (long long)rows[i], (long long)h->M);
@@ -1263,6 +1334,10 @@ extern "C" int bogp_candidates_bind(bogp_handle* h, const void* d_Xs, int64_t M)
   if (!h) return BOGP_ERR_INVALID;
   if (!d_Xs || M <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_candidates_bind: pointer must be non-null and M > 0");
   invalidate_sweep_results(h);
+  {
+    const int e = lazy_drop(h);
+    if (e) return e;
+  }
   h->dXs = (const double*)d_Xs;
   h->M = M;
   return BOGP_OK;
@@ -1337,6 +1412,12 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
   // r -> rt = V r (k_gemm64 with M right-hand sides) -> column reductions, feeding the same acquisition kernel.
   int small_m = 32;
   if (const char* env = getenv("BOGP_SMALL_M")) small_m = atoi(env);
+  const bool one_launch = h->p == 1 && sweep_small_supported(Np, d, h->kernel);
+  if (h->hXs_lazy && ((M <= small_m && h->p == 1) || one_launch || nchunk == 1)) {
+    // nothing to overlap with: the whole upload first (one launch reads every candidate)
+    const int el = lazy_finish(h);
+    if (el) return el;
+  }
   if (M <= small_m && h->p == 1) {
     const int B = (int)M, N = h->N;
     int e2;
@@ -1380,7 +1461,7 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
 
   // Small training sets (Np <= 512, d <= 60, constant trend): the whole sweep is ONE launch of k_sweep_small -- producer,
   // triangular contraction, posterior, criteria and argmax fused, r never leaves LDS (kernels_small.hip).
-  if (h->p == 1 && sweep_small_supported(Np, d, h->kernel)) {
+  if (one_launch) {
     const int64_t nblk = std::max<int64_t>(sweep_small_blocks(M, h->n_cu), (M + 15) / 16);
     int e2;
     if (q > 0) {
@@ -1499,6 +1580,12 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     ka.NJ16 = NJ16; ka.NKP = Np / 8;
     // producer: may reuse buffer b only after chunk c-2 (its previous user) is completely done
     if (overlap && c >= 2) HIPCHK(h, hipStreamWaitEvent(stP, h->ev[(size_t)((c - 2) * EPC + 4)], 0));
+    if (h->hXs_lazy) {  // lazily uploaded candidates: this chunk's rows must have arrived (chunk 0: copied here; later ones: below)
+      int el = lazy_copy_to(h, m0 + mcount);
+      if (el) return el;
+      if ((el = lazy_wait(h, stP))) return el;
+      if (stP != st && (el = lazy_wait(h, st))) return el;
+    }
     HIPCHK(h, hipEventRecord(ev[0], stP));
     HIPCHK(h, launch_corr_chunk(h->kernel, ca, (int)(Mc_eff / 64), S, stP));
     HIPCHK(h, hipEventRecord(ev[1], stP));
@@ -1550,6 +1637,14 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     HIPCHK(h, launch_acquisition(aa, st));
     HIPCHK(h, hipEventRecord(ev[4], st));
     blk_offset += (mcount + 255) / 256;
+    if (h->hXs_lazy) {  // the next chunk's rows travel while this chunk's kernels (queued above) run
+      const int el = lazy_copy_to(h, m0 + mcount + Mc);
+      if (el) return el;
+    }
+  }
+  if (h->hXs_lazy) {  // every row is on its way; once the copy stream is idle the caller's buffer is no longer needed
+    const int el = lazy_finish(h);
+    if (el) return el;
   }
   if (q > 0) HIPCHK(h, launch_argmax_final(h->dblk_val, h->dblk_idx, blk_offset, nblk_total, q, h->dbest_val, h->dbest_idx, st));
   h->n_chunks = (int)nchunk;

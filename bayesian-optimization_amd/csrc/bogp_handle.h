@@ -82,6 +82,12 @@ struct bogp_handle {
   double* dsobol = nullptr;  // d x bits direction numbers (uint64 bit patterns)
   size_t sobol_cap = 0;
   int64_t M = 0;
+  // bogp_candidates_upload_lazy: host rows that are copied chunk by chunk on `stream_copy` WHILE the sweep contracts the chunk before
+  // (run_sweep); lazy_done = rows whose copy has been enqueued, ev_copy = recorded behind the last enqueued copy
+  const double* hXs_lazy = nullptr;
+  int64_t lazy_done = 0;
+  hipStream_t stream_copy = nullptr;
+  hipEvent_t ev_copy = nullptr;
 
   // sweep scratch
   double *drT[2] = {nullptr, nullptr}, *dmu_part[2] = {nullptr, nullptr}, *dw_part[2] = {nullptr, nullptr};

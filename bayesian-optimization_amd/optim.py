@@ -161,7 +161,7 @@ def sweep_argmax(criteria: Sequence, Xs: np.ndarray, index_offset: int = 0, grou
         if c.model is not model or c.minimize != c0.minimize or c.effective_plugin() != c0.effective_plugin():
             raise ValueError("criteria sharing one sweep must share model, minimize and plugin")
     Xs = model._check_X(Xs)
-    eng.upload_candidates(Xs)
+    eng.upload_candidates(Xs, lazy=True)  # (the sweep right below overlaps the copy with its first chunks)
     acq = [(c.acq_id, c.acq_par()) for c in criteria]
     best, idx = eng.sweep(acq, c0.effective_plugin(), c0.minimize)
     if getattr(eng, "comm_world", 0):  # the library's own exchange: device records, ONE ncclAllGather, no host bounce
@@ -202,7 +202,7 @@ def sweep_topk(criteria: Sequence, Xs: np.ndarray, k: int, index_offset: int = 0
         raise Exception("The model is not fitted yet!")
     Xs = model._check_X(Xs)
     eng = model.engine
-    eng.upload_candidates(Xs)
+    eng.upload_candidates(Xs, lazy=True)  # (the sweep right below overlaps the copy with its first chunks)
     best, idx = eng.sweep_topk([(c.acq_id, c.acq_par()) for c in criteria], c0.effective_plugin(), c0.minimize, k)
     if getattr(eng, "comm_world", 0):
         return eng.exchange_topk(len(criteria), k, int(index_offset), True)

@@ -297,10 +297,14 @@ def main():
     h2d_ms = gen_ms = full_ms = None
     if rank == 0 and args.scaling == "weak" and not dry:
         Xh = Xs.cpu().numpy()
-        t1 = time.perf_counter()
-        eng.upload_candidates(Xh)
-        eng.sweep(w["acq"], plugin, True)
-        h2d_ms = (time.perf_counter() - t1) * 1e3
+        h2d = []
+        for i in range(4):  # (the first pass allocates the library's candidate buffer and creates the copy stream: not timed)
+            t1 = time.perf_counter()
+            eng.upload_candidates(Xh, lazy=True)  # (what optim.sweep_argmax does: the copy of chunk c + 1 rides beside the kernels of chunk c)
+            eng.sweep(w["acq"], plugin, True)
+            if i:
+                h2d.append((time.perf_counter() - t1) * 1e3)
+        h2d_ms = float(np.median(h2d))
         # fully on-device ask(): candidates drawn by the library's Philox kernel (no host sampling, no H2D) + sweep
         eng.generate_candidates([-5.0] * d, [5.0] * d, M, seed=99)
         t1 = time.perf_counter()

@@ -189,6 +189,12 @@ int bogp_get_trend_state(bogp_handle* h, double* Ft, double* Q, double* G, doubl
  * M x d row-major float64.  `upload` copies from host (PCIe); `bind` adopts caller-owned DEVICE memory
  * (e.g. a torch tensor's data_ptr()) without copying -- it must stay alive until the next upload/bind.   */
 int bogp_candidates_upload(bogp_handle* h, const double* Xs, int64_t M);
+/* The same upload, overlapped with the sweep that follows: only the first 8 MB are copied here; the next bogp_predict / bogp_sweep /
+ * bogp_sweep_topk copies the rows of candidate chunk c + 1 on a copy stream WHILE chunk c is contracted (a host-sampled ask() of
+ * optimizer="sweep", acquisition/optim/__init__.py:55-153, no longer pays the H2D copy of its M x d candidates in front of the
+ * sweep).  `Xs` must stay valid and unchanged until that next call returns -- it returns with every row resident, later calls
+ * need the buffer no more.  One-launch sweeps (N <= 512) and single-chunk sweeps finish the upload first.                       */
+int bogp_candidates_upload_lazy(bogp_handle* h, const double* Xs, int64_t M);
 int bogp_candidates_bind(bogp_handle* h, const void* d_Xs, int64_t M);
 /* `generate` draws M uniform points in the box [lo, hi] ON the device (replaces RealSpace._sample,
  * search_space/search_space.py:742-754, and the H2D copy): counter-based Philox4x32-10, element (row, k) is a pure

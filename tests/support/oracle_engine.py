@@ -60,7 +60,7 @@ class OracleEngine:
                     G=0.0 if st.G is None else float(st.G[0, 0]), beta=float(st.beta[0, 0]), sigma2=float(st.sigma2[0]),
                     noise_var=st.noise_var)  # fmt: skip
 
-    def upload_candidates(self, Xs):
+    def upload_candidates(self, Xs, lazy=False):
         self.Xs = np.asarray(Xs, float)
         self.M = len(self.Xs)
 

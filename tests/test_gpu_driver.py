@@ -733,3 +733,51 @@ def test_replay_of_the_real_driver_trace(fixture):
         assert seen.get("gradient", 0) >= 20 and seen.get("sweep", 0) >= 20 and seen.get("commit", 0) == 3
     else:
         assert seen.get("nll", 0) >= 500 and seen.get("gradient", 0) >= 40 and seen.get("commit", 0) == 4
+
+
+@pytest.mark.parametrize("N,d,M", [(2048, 20, 200_000), (700, 7, 300_001), (300, 5, 50_000), (1100, 12, 20)])
+def test_lazy_upload_gives_the_sweep_of_the_plain_upload(N, d, M):
+    """bogp_candidates_upload_lazy: the rows of chunk c + 1 are copied on a copy stream while chunk c is contracted.  Same winners,
+    same posterior, bit for bit, as after the plain upload -- over several chunks (C3-size model), a ragged last chunk, the one-launch
+    sweep (N <= 512: the upload is finished first) and the small-batch path; the host array may be dropped once the sweep returned."""
+    from bogp import _lib
+
+    rng = np.random.default_rng(N + M)
+    X = rng.uniform(-5, 5, size=(N, d))
+    y = np.sum(X**2, axis=1)
+    y = ((y - y.mean()) / y.std()).reshape(-1, 1)
+    eng = _lib.Engine(0)
+    try:
+        eng.set_train(X, y)
+        eng.commit(_lib.KERNEL_MATERN52, _lib.MODE_NOISY, np.r_[np.full(d, 0.2 / d), 0.9], 1e-6, True, 0.0)
+        Xs = rng.uniform(-5, 5, size=(M, d))
+        acq = [(_lib.ACQ_MGFI, 2.0), (_lib.ACQ_EI, 0.0)]
+        pl = float(y.min())
+        eng.upload_candidates(Xs)
+        want = eng.sweep(acq, pl, True)
+        want_k = eng.sweep_topk(acq, pl, True, 8)
+        want_mu, want_mse = eng.predict()
+        for _ in range(2):
+            tmp = Xs.copy()
+            eng.upload_candidates(tmp, lazy=True)
+            got = eng.sweep(acq, pl, True)
+            tmp[:] = np.nan  # the sweep has returned: every row is resident, the host rows are free
+            del tmp
+            np.testing.assert_array_equal(got[0], want[0])
+            np.testing.assert_array_equal(got[1], want[1])
+            np.testing.assert_array_equal(eng.read_candidates(got[1]), Xs[got[1]])
+            gk = eng.sweep_topk(acq, pl, True, 8)  # a second consumer of the same (now resident) candidates
+            np.testing.assert_array_equal(gk[0], want_k[0])
+            np.testing.assert_array_equal(gk[1], want_k[1])
+        eng.upload_candidates(Xs.copy(), lazy=True)
+        mu, mse = eng.predict()
+        np.testing.assert_array_equal(mu, want_mu)
+        np.testing.assert_array_equal(mse, want_mse)
+        # lazy upload straight into read / a new upload before any sweep: nothing dangles
+        eng.upload_candidates(Xs.copy(), lazy=True)
+        np.testing.assert_array_equal(eng.read_candidates(np.array([0, M - 1])), Xs[[0, M - 1]])
+        eng.upload_candidates(Xs[: max(1, M // 2)].copy(), lazy=True)
+        eng.upload_candidates(Xs[:7].copy())
+        assert eng.sweep(acq, pl, True)[1].max() < 7
+    finally:
+        eng.close()

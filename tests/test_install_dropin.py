@@ -34,7 +34,7 @@ def installed(monkeypatch):
     class Recording(OracleEngine):
         """remembers the size of every candidate upload (a sweep shows up as one upload of its budget)"""
 
-        def upload_candidates(self, Xs):
+        def upload_candidates(self, Xs, lazy=False):
             self.__dict__.setdefault("uploads", []).append(len(Xs))
             return super().upload_candidates(Xs)
 
