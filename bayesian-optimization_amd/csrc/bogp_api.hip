@@ -134,7 +134,7 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   for (int b = 0; b < 2; ++b) { dfree(h->drT[b]); dfree(h->dmu_part[b]); dfree(h->dw_part[b]); }
   dfree(h->dblk_val); dfree(h->dblk_idx); dfree(h->dmu_out); dfree(h->dmse_out); dfree(h->dacq_out);
   dfree(h->dbest_val); dfree(h->dbest_idx); dfree(h->dtopk_val); dfree(h->dtopk_idx); dfree(h->dcounter); h->dinfo = nullptr; dfree(h->dscal); dfree(h->dgrad_partial); dfree(h->dbatch);
-  dfree(h->dTt); dfree(h->dCS); dfree(h->duu); dfree(h->dmtrend);
+  dfree(h->dTt); dfree(h->dCS); dfree(h->duu); dfree(h->dmtrend); dfree(h->dtpart[0]); dfree(h->dtpart[1]);
   for (auto e : h->ev) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; ++i)
     if (h->ev_chol[i]) (void)hipEventDestroy(h->ev_chol[i]);
@@ -1538,6 +1538,12 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     if ((e = ensure(h, &h->duu, &h->uu_cap, (size_t)Mc))) return e;
     if ((e = ensure(h, &h->dmtrend, &h->mtrend_cap, (size_t)Mc))) return e;
   }
+  // a polynomial basis of at most 32 columns under universal kriging: T = W^T r is accumulated by the producer itself
+  // (k_corr_chunk<K, PV>) and finished by ONE per-candidate launch (k_trend_small); BOGP_TREND_FUSED=0 keeps the tile products
+  const int pv = (h->p > 1 && h->estimate_trend && !(getenv("BOGP_TREND_FUSED") && atoi(getenv("BOGP_TREND_FUSED")) == 0)) ? corr_trend_columns(h->p) : 0;
+  if (pv > 0)
+    for (int b = 0; b < nbuf; ++b)
+      if ((e = ensure(h, &h->dtpart[b], &h->tpart_cap[b], (size_t)S * pv * Mc))) return e;
   if (q > 0) {
     if ((e = ensure(h, &h->dblk_val, &h->blk_val_cap, (size_t)q * nblk_total))) return e;
     if ((e = ensure(h, &h->dblk_idx, &h->blk_idx_cap, (size_t)q * nblk_total))) return e;
@@ -1575,6 +1581,9 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     ca.Xs = h->dXs; ca.M = M; ca.m0 = m0; ca.Mc = Mc; ca.d = d; ca.Np = Np; ca.nblk_per_split = nblk_per_split;
     ca.sqrt_theta = h->dsqrt_theta; ca.XthT = h->dXthT; ca.gamma = h->dgamma; ca.wvec = h->dw;
     ca.rT = h->drT[b]; ca.mu_part = h->dmu_part[b]; ca.w_part = h->dw_part[b];
+    if (pv > 0) {
+      ca.pv = pv; ca.Wrow = h->dWpT; ca.wld = (h->p + 127) / 128 * 128; ca.t_part = h->dtpart[b];
+    }
     ContractArgs ka;
     ka.rT = h->drT[b]; ka.Vp = h->dVp; ka.ss_part = h->dss_part; ka.Mc = Mc; ka.nMt = (int)(Mc_eff / 64); ka.nJ = nJ;
     ka.NJ16 = NJ16; ka.NKP = Np / 8;
@@ -1615,6 +1624,10 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
       const int TI = (int)((Mc_eff + 127) / 128);
       const double one = 1.0, zero = 0.0;
       double* Tt = nullptr;
+      if (pv > 0) {
+        HIPCHK(h, launch_trend_small(h->trend, h->dXs, m0, mcount, d, Mc, h->dbetav, h->dtpart[b], S, pv, pt, h->dSinv, h->dmtrend, h->duu, st));
+        aa.uu = h->duu;
+      } else {
       if (h->estimate_trend) {
         if (tiles128)
           HIPCHK(h, launch_mm128_gen(h->drT[b], (int)Mc, h->dWpT, pp, h->dTt, (int)Mc, TI, pp / 128, Np, st));
@@ -1631,6 +1644,7 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
         HIPCHK(h, launch_rowdot(h->dTt, h->dCS, Mc, mcount, pt, h->duu, st));
         aa.uu = h->duu;
       }
+      }  // pv == 0
       aa.mtrend = h->dmtrend;
       aa.estimate_trend = 0;  // the scalar w_part path is for the constant basis
     }

@@ -119,6 +119,8 @@ struct bogp_handle {
   int* dinfo2 = nullptr;
   double *dTt = nullptr, *dCS = nullptr, *duu = nullptr, *dmtrend = nullptr;  // per sweep chunk: Mc x p, Mc x p, Mc, Mc
   size_t Tt_cap = 0, CS_cap = 0, uu_cap = 0, mtrend_cap = 0;
+  double* dtpart[2] = {nullptr, nullptr};  // [S][pv][Mc] slice sums of W^T r from the fused producer (p <= 32)
+  size_t tpart_cap[2] = {0, 0};
 
   // cross-rank exchange (bogp_comm.hip): RCCL communicator (owned or borrowed), send / receive records on the device, and
   // what the last sweep left in dbest_* / dtopk_* for bogp_exchange_* to pack

@@ -23,7 +23,13 @@ struct CorrArgs {
   double* rT;                // [Np][Mc] correlation chunk, n-major
   double* mu_part;           // [S][Mc]
   double* w_part;            // [S][Mc]
+  // polynomial trend with few columns, fused into the producer (k_corr_chunk<K, PV>): pv = 0 (off) / 16 / 24 / 32 >= p
+  int pv = 0;
+  const double* Wrow = nullptr;  // [Np][wld] row-major W = L^-T Ft, zero padded columns
+  int wld = 0;
+  double* t_part = nullptr;      // [S][pv][Mc] slice sums of W^T r
 };
+int corr_trend_columns(int p);  // the PV instantiation serving p trend columns, 0 if none does
 
 struct ContractArgs {
   const double* rT;   // [Np][Mc]
@@ -191,6 +197,9 @@ size_t gemv2_scratch_doubles(int N);
 hipError_t launch_trend_train(int trend, const double* X, int N, int d, double* F, hipStream_t st);
 hipError_t launch_trend_terms(int trend, const double* Xs, int64_t m0, int64_t mcount, int d, int64_t Mc, const double* beta,
                               double* T, double* mtrend, hipStream_t st);
+// small polynomial bases after the fused producer: T = sum of the slice sums, c = T - f(x*), mtrend = f(x*) . beta, uu = c^T Sinv c in ONE launch
+hipError_t launch_trend_small(int trend, const double* Xs, int64_t m0, int64_t mcount, int d, int64_t Mc, const double* beta, const double* t_part,
+                              int S, int pv, int p, const double* Sinv, double* mtrend, double* uu, hipStream_t st);
 hipError_t launch_rowdot(const double* Cm, const double* CS, int64_t Mc, int64_t mcount, int p, double* uu, hipStream_t st);
 hipError_t launch_sumsq(const double* v, int N, double* out, hipStream_t st);
 // the one-launch likelihood of a small training set (kernels_nllsmall.hip)

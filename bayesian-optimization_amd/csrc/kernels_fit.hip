@@ -317,6 +317,43 @@ hipError_t launch_trend_terms(int trend, const double* Xs, int64_t m0, int64_t m
   return hipGetLastError();
 }
 
+// Universal kriging with a SMALL polynomial basis (p <= 32: a linear trend up to d = 31), everything after the fused producer in one
+// launch, one thread a candidate: T = the slice sums of W^T r added in slice order, c = T - f(x*) (gpr.py:496-498 before the G
+// solve), mtrend = f(x*) . beta (trend.py:34-37), uu = c^T (Ft^T Ft)^-1 c = u^T u.  c lives in LDS ([col][thread]: conflict-free).
+__global__ __launch_bounds__(256) void k_trend_small(int trend, const double* __restrict__ Xs, int64_t m0, int64_t mcount, int d, int64_t Mc,
+                                                     const double* __restrict__ beta, const double* __restrict__ t_part, int S, int pv, int p,
+                                                     const double* __restrict__ Sinv, double* __restrict__ mtrend, double* __restrict__ uu) {
+  __shared__ double cs[32 * 256];
+  const int tid = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + tid;
+  if (i >= mcount) return;
+  for (int col = 0; col < p; ++col) {
+    double t = 0.0;
+    for (int s = 0; s < S; ++s) t += t_part[((size_t)s * pv + col) * Mc + i];
+    cs[col * 256 + tid] = t;
+  }
+  double acc = 0.0;
+  trend_basis(trend, Xs + (size_t)(m0 + i) * d, d, [&](int col, double v) {
+    acc = __builtin_fma(v, beta[col], acc);
+    cs[col * 256 + tid] -= v;
+  });
+  mtrend[i] = acc;
+  double q = 0.0;
+  for (int a = 0; a < p; ++a) {
+    double row = 0.0;
+    for (int b = 0; b < p; ++b) row = __builtin_fma(Sinv[(size_t)b * p + a], cs[b * 256 + tid], row);  // column-major p x p (symmetric)
+    q = __builtin_fma(cs[a * 256 + tid], row, q);
+  }
+  uu[i] = q;
+}
+hipError_t launch_trend_small(int trend, const double* Xs, int64_t m0, int64_t mcount, int d, int64_t Mc, const double* beta, const double* t_part,
+                              int S, int pv, int p, const double* Sinv, double* mtrend, double* uu, hipStream_t st) {
+  if (p > 32) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_trend_small, dim3((unsigned)((mcount + 255) / 256)), 256, 0, st, trend, Xs, m0, mcount, d, Mc, beta, t_part, S, pv, p,
+                     Sinv, mtrend, uu);
+  return hipGetLastError();
+}
+
 // uu[m] = sum_col C(m, col) * CS(m, col)   (= u^T u with u = G^-T c, because CS = C (G^T G)^-1)
 __global__ void k_rowdot(const double* __restrict__ Cm, const double* __restrict__ CS, int64_t Mc, int64_t mcount, int p,
                          double* __restrict__ uu) {

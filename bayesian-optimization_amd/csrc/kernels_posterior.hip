@@ -41,15 +41,23 @@ namespace bogp {
 struct CorrDims {
   int64_t M, m0, Mc;
   int d, Np, nblk_per_split;
+  int wld;  // PV > 0: row pitch of Wrow
 };
 // pointers are separate __restrict__ kernel arguments (not struct members) so that the wave-uniform reads of
 // XthT / gamma / wvec are provably read-only and become scalar (SMEM) loads
-template <int KERNEL>
+// PV > 0 (polynomial trend with p <= PV columns under universal kriging, r04): the producer also forms the slice sums of
+// T = W^T r, W = L^-T Ft (gpr.py:496-498: Ft^T L^-1 r).  Every 32-row block of r is parked in LDS on its way out and contracted there
+// against the rows Wrow[n][0 .. PV) on the matrix cores -- wave g: candidates 16 g .. 16 g + 15 x PV / 16 column tiles,
+// v_mfma_f64_16x16x4_f64 (the columns p .. PV of Wrow are zero padding) -- 16 MFMAs a block and wave beside ~450 FP64 VALU
+// instructions.  The separate tile product it replaces re-read the whole 1-GiB correlation chunk for 21 live columns of a 128-column
+// tile (+13 % per sweep for a linear trend at C3).  A first version with PV scalar-loaded FMAs a pair doubled the producer's time
+// (SGPR-starved: 8 x 24 wave-uniform doubles a block): profiles/r04_trend_timing.txt.
+template <int KERNEL, int PV>
 __global__ __launch_bounds__(256) void k_corr_chunk(const double* __restrict__ Xs, const double* __restrict__ sqrt_theta,
                                                     const double* __restrict__ XthT, const double* __restrict__ gamma,
                                                     const double* __restrict__ wvec, double* __restrict__ rT,
                                                     double* __restrict__ mu_part, double* __restrict__ w_part,
-                                                    CorrDims a) {
+                                                    const double* __restrict__ Wrow, double* __restrict__ t_part, CorrDims a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* xs = smem;  // [d][64] theta-scaled candidate tile, k-major
   const int tid = threadIdx.x;
@@ -71,6 +79,13 @@ __global__ __launch_bounds__(256) void k_corr_chunk(const double* __restrict__ X
   const int nb0 = blockIdx.y * a.nblk_per_split * 32;
   const int nb1 = min(a.Np, nb0 + a.nblk_per_split * 32);
   double mu = 0.0, wd = 0.0;
+  constexpr int NTT = PV > 0 ? PV / 16 : 1;
+  typedef double d4t __attribute__((ext_vector_type(4)));
+  d4t tacc[NTT];
+#pragma unroll
+  for (int c = 0; c < NTT; ++c) tacc[c] = (d4t){0.0, 0.0, 0.0, 0.0};
+  double* rtile = smem + max(64 * d, 512);  // PV > 0: [32][64] the block of r being contracted (behind the candidate tile / the reduction arrays)
+  const int lk = m >> 4, li = m & 15;
   for (int nb = nb0; nb < nb1; nb += 32) {
     const int n0 = nb + g * 8;
     double acc[8];
@@ -91,6 +106,22 @@ __global__ __launch_bounds__(256) void k_corr_chunk(const double* __restrict__ X
       rT[(size_t)(n0 + i) * a.Mc + mc0 + m] = r;
       mu = __builtin_fma(r, gamma[n0 + i], mu);
       wd = __builtin_fma(r, wvec[n0 + i], wd);
+      if (PV > 0) rtile[(g * 8 + i) * 64 + m] = r;
+    }
+    if (PV > 0) {
+      __syncthreads();
+      // A: lane (k, i) = r[candidate 16 g + i][n = nb + 4 ks + k];  B: lane (k, j) = W[n][16 t + j]
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const double av = rtile[(4 * ks + lk) * 64 + 16 * g + li];
+        const double* __restrict__ wr = Wrow + (size_t)(nb + 4 * ks + lk) * a.wld + li;
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) {
+          const double bv = wr[16 * t];
+          asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(tacc[t]) : "v"(av), "v"(bv));
+        }
+      }
+      __syncthreads();  // the block is overwritten by the next trip
     }
   }
   // reduce the 4 n-groups (fixed order) -> partial sums of this training-set slice
@@ -104,6 +135,17 @@ __global__ __launch_bounds__(256) void k_corr_chunk(const double* __restrict__ X
     const double s1 = ((red[256 + tid] + red[320 + tid]) + red[384 + tid]) + red[448 + tid];
     mu_part[(size_t)blockIdx.y * a.Mc + mc0 + tid] = s0;
     w_part[(size_t)blockIdx.y * a.Mc + mc0 + tid] = s1;
+  }
+  if (PV > 0) {
+    // the trend tiles: D[i][j] sits in lane 16 (i % 4) + j, component i / 4 (i = candidate in the fragment, j = column in the tile)
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < NTT; ++t) asm volatile("" : "+v"(tacc[t]));
+#pragma unroll
+    for (int t = 0; t < NTT; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        t_part[((size_t)blockIdx.y * PV + 16 * t + li) * a.Mc + mc0 + 16 * g + 4 * c + lk] = tacc[t][c];
   }
 }
 
@@ -357,20 +399,27 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
 // ---------------------------------------------------------------------------------------------------
 hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipStream_t st) {
   dim3 grid((unsigned)nMt, (unsigned)S);
-  size_t shm = (size_t)max(64 * a.d, 512) * sizeof(double);
-  CorrDims dm{a.M, a.m0, a.Mc, a.d, a.Np, a.nblk_per_split};
+  size_t shm = (size_t)(max(64 * a.d, 512) + (a.pv > 0 ? 32 * 64 : 0)) * sizeof(double);
+  CorrDims dm{a.M, a.m0, a.Mc, a.d, a.Np, a.nblk_per_split, a.wld};
   // the candidate tile is 64 x d doubles of dynamic LDS: above the 64 KB default (d > 128) the kernel has to be allowed
   // more, up to the CU's 160 KB (d <= 320; occupancy then drops to one workgroup per CU, which only matters for the
   // ~10 % of the sweep this producer accounts for)
-#define BOGP_LAUNCH_CORR(K)                                                                                              \
+#define BOGP_LAUNCH_CORR_PV(K, PV)                                                                                       \
   do {                                                                                                                   \
     if (shm > 64 * 1024) {                                                                                               \
-      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_corr_chunk<K>),                               \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_corr_chunk<K, PV>),                           \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                         \
       if (e_ != hipSuccess) return e_;                                                                                   \
     }                                                                                                                    \
-    hipLaunchKernelGGL(k_corr_chunk<K>, grid, 256, shm, st, a.Xs, a.sqrt_theta, a.XthT, a.gamma, a.wvec, a.rT, a.mu_part, \
-                       a.w_part, dm);                                                                                    \
+    hipLaunchKernelGGL((k_corr_chunk<K, PV>), grid, 256, shm, st, a.Xs, a.sqrt_theta, a.XthT, a.gamma, a.wvec, a.rT, a.mu_part, \
+                       a.w_part, a.Wrow, a.t_part, dm);                                                                  \
+  } while (0)
+#define BOGP_LAUNCH_CORR(K)                                    \
+  do {                                                         \
+    if (a.pv == 0) BOGP_LAUNCH_CORR_PV(K, 0);                  \
+    else if (a.pv == 16) BOGP_LAUNCH_CORR_PV(K, 16);           \
+    else if (a.pv == 32) BOGP_LAUNCH_CORR_PV(K, 32);           \
+    else return hipErrorInvalidValue;                          \
   } while (0)
   switch (kernel) {
     case BOGP_KERNEL_SE: BOGP_LAUNCH_CORR(BOGP_KERNEL_SE); break;
@@ -381,9 +430,15 @@ hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipS
     case BOGP_KERNEL_GENEXP: BOGP_LAUNCH_CORR(BOGP_KERNEL_GENEXP); break;
     default: BOGP_LAUNCH_CORR(BOGP_KERNEL_MATERN52); break;
   }
+#undef BOGP_LAUNCH_CORR_PV
 #undef BOGP_LAUNCH_CORR
   return hipGetLastError();
 }
+
+// (wider bases stay on the tile products: with 16 column tiles a wave -- PV = 256, quadratic trend at d = 20 -- the producer went from
+// 6.8 to 88 ms per 1e6 candidates: 128 accumulator registers beside the distance loop and 16 un-staged B loads a k-step;
+// profiles/r04_trend_timing.txt)
+int corr_trend_columns(int p) { return p <= 1 ? 0 : (p <= 16 ? 16 : (p <= 32 ? 32 : 0)); }
 
 static int contract_nr() {
   static int nr = [] {
