@@ -39,7 +39,7 @@ SIGNATURES = {
     "bogp_nll": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp, _dp]),
     "bogp_nll_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp, _dp, _ip]),
     "bogp_mle_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_double,
-                                 C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp, _ip, _ip, _ip]),
+                                 C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, _dp, _dp, _ip, _ip, _ip]),
     "bogp_lbfgsb_minimize": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        _dp, _ip, _ip, _ip]),
     "bogp_commit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp]),
@@ -322,8 +322,9 @@ class Engine:
         return llf, grad, info
 
     def mle_batch(self, kernel, mode, x0, lo, hi, noise_var=0.0, estimate_trend=False, beta=0.0, trend=TREND_CONSTANT, restricted=False,
-                  eval_budget=0, m=10, factr=1e7, pgtol=1e-5, chain_rule=False):
+                  eval_budget=0, m=10, factr=1e7, pgtol=1e-5, chain_rule=False, prune_reserve=0):
         """The R restarts of the MLE in lock step (bogp_mle_batch): x0 (R, n_par) log10 starts, lo / hi (n_par,) log10 bounds.
+        `prune_reserve` > 0 stops the worst run whenever fewer than that many evaluations per active run remain of a shared budget.
         `chain_rule=True` hands the optimiser the gradient w.r.t. log10(par) instead of the reference's un-scaled one (an extension).
         Returns (xopt (R, n_par) log10, fopt (R,) = -llf, n_evals (R,), status (R,), rounds)."""
         x0 = _f64(x0)
@@ -340,7 +341,7 @@ class Engine:
         self._check(
             self._lib.bogp_mle_batch(self._h, kernel, mode, int(bool(restricted)), R, _ptr(x0), n_par, _ptr(lo), _ptr(hi), float(noise_var),
                                      int(trend), int(bool(estimate_trend)), b, int(eval_budget), int(m), float(factr), float(pgtol),
-                                     1 if chain_rule else 0, _ptr(xopt), _ptr(fopt), nev.ctypes.data_as(_ip), status.ctypes.data_as(_ip), C.byref(rounds))
+                                     1 if chain_rule else 0, int(prune_reserve), _ptr(xopt), _ptr(fopt), nev.ctypes.data_as(_ip), status.ctypes.data_as(_ip), C.byref(rounds))
         )  # fmt: skip
         return xopt, fopt, nev, status, rounds.value
 

@@ -52,7 +52,8 @@ extern "C" int bogp_lbfgsb_minimize(int n, int m, double* x, const double* lo, c
 
 extern "C" int bogp_mle_batch(bogp_handle* h, int kernel, int mode, int restricted, int R, const double* x0, int n_par, const double* lo,
                               const double* hi, double noise_var, int trend, int estimate_trend, double beta, int eval_budget, int m,
-                              double factr, double pgtol, int flags, double* xopt, double* fopt, int* n_evals, int* status, int* n_rounds) {
+                              double factr, double pgtol, int flags, int prune_reserve, double* xopt, double* fopt, int* n_evals, int* status,
+                              int* n_rounds) {
   if (!h) return BOGP_ERR_INVALID;
   if (!x0 || !lo || !hi || !xopt || !fopt || R <= 0 || n_par <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_mle_batch: x0 / lo / hi / xopt / fopt must be non-null, R and n_par > 0");
   for (int i = 0; i < n_par; ++i)
@@ -76,6 +77,20 @@ extern "C" int bogp_mle_batch(bogp_handle* h, int kernel, int mode, int restrict
     act.clear();
     for (int r = 0; r < R; ++r)
       if (runs[(size_t)r].running()) act.push_back(r);
+    // A shared budget spread over R runs starves all of them alike.  With prune_reserve > 0 the budget is concentrated as it runs out:
+    // while fewer than prune_reserve evaluations per active run are left, the run with the worst value so far is stopped (it keeps
+    // its last iterate), so that the leading runs can still converge -- what the sequential loop gives its first restarts.
+    if (prune_reserve > 0 && opt.shared_budget > 0) {
+      while (act.size() > 1 && opt.shared_budget - evals < (long)prune_reserve * (long)act.size()) {
+        size_t worst = 0;
+        for (size_t i = 1; i < act.size(); ++i) {
+          const double fi = runs[(size_t)act[i]].best_f(), fw = runs[(size_t)act[worst]].best_f();
+          if (fi > fw || (fi == fw && act[i] > act[worst]) || (std::isnan(fi) && !std::isnan(fw))) worst = i;
+        }
+        runs[(size_t)act[worst]].stop(Lbfgsb::STOP_MAXFUN);
+        act.erase(act.begin() + (long)worst);
+      }
+    }
     if (act.empty()) break;
     const int P = (int)act.size();
     par.resize((size_t)P * n_par);

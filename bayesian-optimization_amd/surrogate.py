@@ -98,6 +98,7 @@ class GaussianProcess:
         restart_streams=None,
         restart_batch=None,
         mle_chain_rule=False,
+        mle_prune_reserve=0,
     ):
         self.mean = mean
         self.corr = corr
@@ -116,6 +117,9 @@ class GaussianProcess:
         # extension, with restart_batch only: hand the optimiser the gradient of the function it minimises (d / d log10 par) instead of
         # the reference's d / d par (which stays the default)
         self.mle_chain_rule = bool(mle_chain_rule)
+        # restart_batch only: as the shared evaluation budget runs out (fewer than this many evaluations per active restart left) the worst
+        # restart is stopped, so that the budget ends on the leading ones (0: equal shares to the end)
+        self.mle_prune_reserve = int(mle_prune_reserve)
         self._worker_engines = []
 
         self.theta0 = np.array(theta0, dtype=float).flatten() if theta0 is not None else None
@@ -511,7 +515,8 @@ class GaussianProcess:
                 starts.append(np.array(log10param0, dtype=float) if it + r == 0 else np.random.uniform(lo, hi))
             xopt, fopt, nev, status, rounds = self.engine.mle_batch(kid, mode, np.array(starts), lo, hi, nv, est, beta, trend=tid,
                                                                     restricted=restricted, eval_budget=int(eval_budget),
-                                                                    chain_rule=bool(getattr(self, "mle_chain_rule", False)))  # fmt: skip
+                                                                    chain_rule=bool(getattr(self, "mle_chain_rule", False)),
+                                                                    prune_reserve=int(getattr(self, "mle_prune_reserve", 0)))  # fmt: skip
             self.mle_rounds += rounds
             stop = False
             for r in range(n_w):

@@ -137,6 +137,9 @@ int bogp_nll_batch(bogp_handle* h, int kernel, int mode, int P, const double* pa
  *   x0          R x n_par starting points in log10 space (clipped into the bounds);  lo, hi: n_par log10 bounds
  *   eval_budget evaluations allowed in total over all runs (<= 0: 15000 per run)
  *   m, factr, pgtol  <= 0: the defaults above
+ *   prune_reserve  0: every run keeps going until the shared budget is spent.  > 0: while fewer than this many evaluations per active
+ *               run are left, the run with the worst value so far is stopped (status 2, its last iterate returned): the budget
+ *               is concentrated on the leading runs as it runs out, where equal shares would leave all R runs unconverged
  *   flags       0: the reference's gradient.  BOGP_MLE_CHAIN_RULE: hand the optimiser d(-llf) / d log10(par) = ln(10) par d / d par,
  *               the gradient of the function it actually minimises -- NOT what the reference does (an extension: ~4 x fewer
  *               evaluations per run from a start inside a basin, an immediate stop on the flat plateau of huge theta)
@@ -146,7 +149,7 @@ int bogp_nll_batch(bogp_handle* h, int kernel, int mode, int P, const double* pa
 #define BOGP_MLE_CHAIN_RULE 1 /* flags bit 0 */
 int bogp_mle_batch(bogp_handle* h, int kernel, int mode, int restricted, int R, const double* x0, int n_par, const double* lo,
                    const double* hi, double noise_var, int trend, int estimate_trend, double beta, int eval_budget, int m, double factr,
-                   double pgtol, int flags, double* xopt, double* fopt, int* n_evals, int* status, int* n_rounds);
+                   double pgtol, int flags, int prune_reserve, double* xopt, double* fopt, int* n_evals, int* status, int* n_rounds);
 
 /* ---- commit a fitted state ------------------------------------------------------------------------
  * Replaces the tail of GaussianProcess.fit (gpr.py:402-415) + compute_beta_gamma (:784-788): factorise at

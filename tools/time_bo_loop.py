@@ -14,7 +14,7 @@ import bogp
 from bogp import optim
 
 
-def main(dim=10, max_FEs=200, n_doe=20, seed=1, streams=1, batch=0):
+def main(dim=10, max_FEs=200, n_doe=20, seed=1, streams=1, batch=0, chain=False):
     f = lambda x: float(10 * len(x) + np.sum(np.asarray(x) ** 2 - 10 * np.cos(2 * np.pi * np.asarray(x))))  # noqa: E731
     lo, hi = -5.12, 5.12
     box = optim.Box([(lo, hi)] * dim)
@@ -25,7 +25,7 @@ def main(dim=10, max_FEs=200, n_doe=20, seed=1, streams=1, batch=0):
     rng_len = np.full(dim, hi - lo)
     model = bogp.GaussianProcess(mean=bogp.trend.constant_trend(dim), corr="matern", thetaL=1e-3 * rng_len, thetaU=1e3 * rng_len,
                                  nugget=1e-6, optimizer="BFGS", wait_iter=3, random_start=max(10, dim), eval_budget=100 * dim,
-                                 restart_streams=streams, restart_batch=batch)  # fmt: skip
+                                 restart_streams=streams, restart_batch=batch, mle_chain_rule=chain)  # fmt: skip
     t_tell, t_ask, sizes = [], [], []
     t_all = time.perf_counter()
     while len(y) < max_FEs:
@@ -46,7 +46,7 @@ def main(dim=10, max_FEs=200, n_doe=20, seed=1, streams=1, batch=0):
         sizes.append(len(y) - 1)
     total = time.perf_counter() - t_all
     t_tell, t_ask, sizes = np.array(t_tell), np.array(t_ask), np.array(sizes)
-    print("== restart_streams = %d, restart_batch = %d" % (streams, batch))
+    print("== restart_streams = %d, restart_batch = %d%s" % (streams, batch, ", mle_chain_rule (extension: gradient w.r.t. log10 par)" if chain else ""))
     print("d = %d, %d evaluations (%d-point DoE), Rastrigin: best %.4f; loop wall time %.2f s = tell %.2f s + ask %.2f s (+ %.2f s of host glue)"
           % (dim, max_FEs, n_doe, y.min(), total, t_tell.sum(), t_ask.sum(), total - t_tell.sum() - t_ask.sum()))
     for n in (25, 50, 100, 150, 199):
@@ -57,7 +57,9 @@ def main(dim=10, max_FEs=200, n_doe=20, seed=1, streams=1, batch=0):
 
 if __name__ == "__main__":
     for a in sys.argv[1:] or ["1"]:
-        if a.startswith("b"):  # b10: restart_batch = 10 (the restarts in lock step, bogp_mle_batch)
+        if a.startswith("c"):  # c10: restart_batch = 10 with the chain-rule gradient (an extension, not the reference's objective)
+            main(batch=int(a[1:]), chain=True)
+        elif a.startswith("b"):  # b10: restart_batch = 10 (the restarts in lock step, bogp_mle_batch)
             main(batch=int(a[1:]))
         else:
             main(streams=int(a))
