@@ -37,7 +37,7 @@ out = {
     "algorithmic_bytes_per_launch": per_launch * N * 8 + 4 * N * N + per_launch * 8,
     "TCC_HIT_sum": vals.get("TCC_HIT_sum"),
     "TCC_MISS_sum": vals.get("TCC_MISS_sum"),
-    "note": "traffic/algorithmic = the (nJ+1)/2 = 4.5 re-reads of the 1 GiB correlation chunk by the 8 column groups; the kernel is FP64-MFMA bound (DESIGN.md 5.2, 9)",
+    "note": "traffic/algorithmic = the (nJ+1)/2 = 4.5 re-reads of the 1 GiB correlation chunk by the 8 column groups; the kernel is FP64-MFMA bound (DESIGN.md 5.2; EXPERIMENTS.md r01)",
     "SQ_VALU_MFMA_BUSY_CYCLES": vals["SQ_VALU_MFMA_BUSY_CYCLES"],
     "GRBM_GUI_ACTIVE": vals["GRBM_GUI_ACTIVE"],
     "mfma_pipe_busy_frac": round(vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (vals["GRBM_GUI_ACTIVE"] * 128.0), 4),
