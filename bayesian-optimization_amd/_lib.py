@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libbogp.so")
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_NOT_POSDEF, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_LLF_POSITIVE = -1, -2, -3, -4, -5, -6
-KERNEL_SE, KERNEL_MATERN12, KERNEL_MATERN32, KERNEL_MATERN52, KERNEL_ABSEXP, KERNEL_CUBIC, KERNEL_GENEXP = 0, 1, 2, 3, 4, 5, 6
+KERNEL_SE, KERNEL_MATERN12, KERNEL_MATERN32, KERNEL_MATERN52, KERNEL_ABSEXP, KERNEL_CUBIC, KERNEL_GENEXP, KERNEL_MATERN_NU = 0, 1, 2, 3, 4, 5, 6, 7
 MODE_NOISELESS, MODE_NOISY, MODE_NOISE_ESTIM = 0, 1, 2
 ACQ_EI, ACQ_EPSILON_PI, ACQ_UCB, ACQ_MGFI = 0, 1, 2, 3
 TREND_CONSTANT, TREND_LINEAR, TREND_QUADRATIC = 0, 1, 2

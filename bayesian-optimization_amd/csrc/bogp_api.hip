@@ -413,13 +413,19 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
                      int estimate_trend, double beta, bool want_gamma, FitOut* o, std::vector<double>* theta_out,
                      bool reject_positive = true, FitPending* pend = nullptr, FusedNll* fz = nullptr) {
   if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "no training set: call bogp_set_train first");
-  if (kernel < 0 || kernel > BOGP_KERNEL_GENEXP) FAIL(h, BOGP_ERR_INVALID, "unknown kernel id %d", kernel);
+  if (kernel < 0 || kernel > BOGP_KERNEL_MATERN_NU) FAIL(h, BOGP_ERR_INVALID, "unknown kernel id %d", kernel);
   if (mode < 0 || mode > 2) FAIL(h, BOGP_ERR_INVALID, "unknown estimation mode %d", mode);
   if (trend < BOGP_TREND_CONSTANT || trend > BOGP_TREND_QUADRATIC) FAIL(h, BOGP_ERR_INVALID, "unknown trend id %d", trend);
   const int ptrend = trend_size(trend, h->d);
   const int N = h->N, d = h->d, ldr = h->ldr;
   int n_theta = n_par - (mode == BOGP_MODE_NOISELESS ? 0 : 1);
   double pexp = 0.0;
+  if (kernel == BOGP_KERNEL_MATERN_NU) {  // theta = [theta_1 .. theta_d, nu], or [theta, nu]: the order travels where generalized_exponential's exponent does
+    if (n_theta != d + 1 && n_theta != 2) FAIL(h, BOGP_ERR_INVALID, "general-nu matern: len(theta) = %d must be 2 or d + 1 = %d (the last entry is nu)", n_theta, d + 1);
+    pexp = par[n_theta - 1];
+    if (!(pexp > 0) || !std::isfinite(pexp) || pexp > 60.0) FAIL(h, BOGP_ERR_INVALID, "general-nu matern: nu = %g must be in (0, 60]", pexp);
+    n_theta -= 1;
+  }
   if (kernel == BOGP_KERNEL_GENEXP) {  // theta = [theta_1 .. theta_d, p], or [theta, p] (kernel.py:369-373)
     if (n_theta != d + 1 && n_theta != 2) FAIL(h, BOGP_ERR_INVALID, "generalized_exponential: len(theta) = %d must be 2 or d + 1 = %d", n_theta, d + 1);
     pexp = par[n_theta - 1];
@@ -679,7 +685,7 @@ extern "C" int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par,
                         int estimate_trend, double beta, double* llf, double* grad) {
   if (!h) return BOGP_ERR_INVALID;
   if (!par || !llf || n_par <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_nll: par/llf must be non-null");
-  if (grad && (kernel == BOGP_KERNEL_CUBIC || kernel == BOGP_KERNEL_GENEXP))
+  if (grad && (kernel == BOGP_KERNEL_CUBIC || kernel == BOGP_KERNEL_GENEXP || kernel == BOGP_KERNEL_MATERN_NU))
     FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll: the cubic / generalized_exponential correlation has no theta-derivative (the reference's corr_grad_theta leaves it undefined, gpr.py:763-766: its own likelihood gradient raises UnboundLocalError)");
   h->committed = false;  // the factor buffers are about to be overwritten
   FitOut o;
@@ -797,7 +803,7 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
                                    int trend, int estimate_trend, double beta, double* llf, double* grad) {
   if (!h) return BOGP_ERR_INVALID;
   if (!par || !llf || n_par <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_nll_restricted: par/llf must be non-null");
-  if (grad && (kernel == BOGP_KERNEL_CUBIC || kernel == BOGP_KERNEL_GENEXP)) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_restricted: the cubic / generalized_exponential correlation has no theta-derivative");
+  if (grad && (kernel == BOGP_KERNEL_CUBIC || kernel == BOGP_KERNEL_GENEXP || kernel == BOGP_KERNEL_MATERN_NU)) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_restricted: the cubic / generalized_exponential correlation has no theta-derivative");
   if (mode < 0 || mode > 2) FAIL(h, BOGP_ERR_INVALID, "unknown estimation mode %d", mode);
   if (trend < BOGP_TREND_CONSTANT || trend > BOGP_TREND_QUADRATIC) FAIL(h, BOGP_ERR_INVALID, "unknown trend id %d", trend);
   if (h->n_t != 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_restricted: single-target y only (have %d targets)", h->n_t);
@@ -1762,7 +1768,7 @@ extern "C" double bogp_flops_per_candidate(const bogp_handle* h) {
 extern "C" int bogp_gradient(bogp_handle* h, const double* x, double* dmu, double* dmse) {
   if (!h) return BOGP_ERR_INVALID;
   if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "bogp_gradient: no committed model");
-  if (h->kernel == BOGP_KERNEL_CUBIC || h->kernel == BOGP_KERNEL_GENEXP) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_gradient: the cubic correlation has no input-derivative (corr_dx leaves it undefined in the reference, gpr.py:655-658)");
+  if (h->kernel == BOGP_KERNEL_CUBIC || h->kernel == BOGP_KERNEL_GENEXP || h->kernel == BOGP_KERNEL_MATERN_NU) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_gradient: the cubic correlation has no input-derivative (corr_dx leaves it undefined in the reference, gpr.py:655-658)");
   if (!x || !dmu || !dmse) FAIL(h, BOGP_ERR_INVALID, "bogp_gradient: null pointer");
   const int N = h->N, d = h->d;
   hipStream_t st = h->stream;

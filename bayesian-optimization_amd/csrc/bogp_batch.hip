@@ -46,9 +46,9 @@ bool prep_slot(int kernel, int mode, int d, const double* par, int n_par, double
   double pexp = 0.0;
   for (int k = 0; k < n_par; ++k)
     if (!std::isfinite(par[k])) return false;
-  if (kernel == BOGP_KERNEL_GENEXP) {
+  if (kernel == BOGP_KERNEL_GENEXP || kernel == BOGP_KERNEL_MATERN_NU) {
     pexp = par[n_theta - 1];
-    if (!(pexp > 0)) return false;
+    if (!(pexp > 0) || (kernel == BOGP_KERNEL_MATERN_NU && pexp > 60.0)) return false;
     n_theta -= 1;
   }
   for (int k = 0; k < d; ++k) {
@@ -197,7 +197,7 @@ static int run_group(bogp_handle* h, int path, int kernel, int mode, const std::
   const int N = h->N, d = h->d, Pg = (int)slot_of.size();
   const bool want_grad = grad != nullptr;
   hipStream_t st = h->stream;
-  const int n_theta = n_par - (mode == BOGP_MODE_NOISELESS ? 0 : 1) - (kernel == BOGP_KERNEL_GENEXP ? 1 : 0);
+  const int n_theta = n_par - (mode == BOGP_MODE_NOISELESS ? 0 : 1) - ((kernel == BOGP_KERNEL_GENEXP || kernel == BOGP_KERNEL_MATERN_NU) ? 1 : 0);
   const bool iso = n_theta != d;
   const size_t out_stride = 64 + up8((size_t)d + 3);
   const size_t in_stride = path == BOGP_NLL_PATH_ONE_LAUNCH ? (size_t)NS_BPAR : up8((size_t)d + 1) + 8;
@@ -288,15 +288,15 @@ extern "C" int bogp_nll_batch(bogp_handle* h, int kernel, int mode, int P, const
   if (!h) return BOGP_ERR_INVALID;
   if (!par || !llf || !info || n_par <= 0 || P <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_nll_batch: par / llf / info must be non-null, P and n_par > 0");
   if (!h->dX) FAIL(h, BOGP_ERR_INVALID, "no training set: call bogp_set_train first");
-  if (kernel < 0 || kernel > BOGP_KERNEL_GENEXP) FAIL(h, BOGP_ERR_INVALID, "unknown kernel id %d", kernel);
+  if (kernel < 0 || kernel > BOGP_KERNEL_MATERN_NU) FAIL(h, BOGP_ERR_INVALID, "unknown kernel id %d", kernel);
   if (mode < 0 || mode > 2) FAIL(h, BOGP_ERR_INVALID, "unknown estimation mode %d", mode);
   if (trend < BOGP_TREND_CONSTANT || trend > BOGP_TREND_QUADRATIC) FAIL(h, BOGP_ERR_INVALID, "unknown trend id %d", trend);
-  if (grad && (kernel == BOGP_KERNEL_CUBIC || kernel == BOGP_KERNEL_GENEXP))
+  if (grad && (kernel == BOGP_KERNEL_CUBIC || kernel == BOGP_KERNEL_GENEXP || kernel == BOGP_KERNEL_MATERN_NU))
     FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_batch: the cubic / generalized_exponential correlation has no theta-derivative (gpr.py:763-766)");
   const int N = h->N, d = h->d;
   {
     int n_theta = n_par - (mode == BOGP_MODE_NOISELESS ? 0 : 1);
-    if (kernel == BOGP_KERNEL_GENEXP) {
+    if (kernel == BOGP_KERNEL_GENEXP || kernel == BOGP_KERNEL_MATERN_NU) {
       if (n_theta != d + 1 && n_theta != 2) FAIL(h, BOGP_ERR_INVALID, "generalized_exponential: len(theta) = %d must be 2 or d + 1 = %d", n_theta, d + 1);
       n_theta -= 1;
     }

@@ -30,7 +30,7 @@ PointPlan plan_of(const bogp_handle* h, int B, int q, bool want_dacq) {
 
 int check_common(bogp_handle* h, const char* who, int q, const int* acq_id, const double* acq_par) {
   if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "%s: no committed model", who);
-  if (h->kernel == BOGP_KERNEL_CUBIC || h->kernel == BOGP_KERNEL_GENEXP)
+  if (h->kernel == BOGP_KERNEL_CUBIC || h->kernel == BOGP_KERNEL_GENEXP || h->kernel == BOGP_KERNEL_MATERN_NU)
     FAIL(h, BOGP_ERR_UNSUPPORTED, "%s: the cubic correlation has no input-derivative (corr_dx leaves it undefined in the reference, gpr.py:655-658)", who);
   if (h->p > 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "%s: constant trend basis only (polynomial trends: bogp_predict + bogp_gradient)", who);
   if (h->d > BOGP_POINT_MAX_D) FAIL(h, BOGP_ERR_UNSUPPORTED, "%s: at most %d input dimensions", who, BOGP_POINT_MAX_D);

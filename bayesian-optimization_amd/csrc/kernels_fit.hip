@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void k_batch_corr(const double* __restrict__ X
   double s2 = dist_init<KERNEL>();
   const double pexp = kernel_exponent<KERNEL>(theta, d);
   for (int k = 0; k < d; ++k) s2 = dist_fold<KERNEL>(theta[k], Xb[(size_t)b * d + k] - X[(size_t)n * d + k], s2, pexp);
-  r[(size_t)b * N + n] = corr_profile<KERNEL>(s2);
+  r[(size_t)b * N + n] = corr_profile<KERNEL>(s2, pexp);
   s2out[(size_t)b * N + n] = s2;
 }
 
@@ -730,6 +730,10 @@ hipError_t launch_batch_corr(int kernel, const double* X, int N, int d, const do
                              double* r, double* s2, hipStream_t st) {
   dim3 grid((N + 255) / 256, B);
 #define CALL(K) hipLaunchKernelGGL(k_batch_corr<K>, grid, 256, 0, st, X, N, d, theta, Xb, r, s2)
+  if (kernel == BOGP_KERNEL_MATERN_NU) {
+    CALL(BOGP_KERNEL_MATERN_NU);
+    return hipGetLastError();
+  }
   if (kernel == BOGP_KERNEL_CUBIC || kernel == BOGP_KERNEL_GENEXP) {  // values only (small-batch posterior, prior correlation): no derivative kernels
     if (kernel == BOGP_KERNEL_CUBIC) {
       CALL(BOGP_KERNEL_CUBIC);

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
     // branch per entry would string the four exp / sqrt chains one behind the other)
     double pv[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) pv[c] = par_a * corr_profile<KERNEL>(s2[c]);
+    for (int c = 0; c < 4; ++c) pv[c] = par_a * corr_profile<KERNEL>(s2[c], par_pexp);
     if (par_div) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) pv[c] = pv[c] / par_b;
@@ -601,6 +601,7 @@ hipError_t launch_nll_small(int kernel, bool grad, const NllSmallArgs& a, hipStr
       case BOGP_KERNEL_MATERN52: return NS_GO(BOGP_KERNEL_MATERN52, false);
       case BOGP_KERNEL_CUBIC: return NS_GO(BOGP_KERNEL_CUBIC, false);
       case BOGP_KERNEL_GENEXP: return NS_GO(BOGP_KERNEL_GENEXP, false);
+      case BOGP_KERNEL_MATERN_NU: return NS_GO(BOGP_KERNEL_MATERN_NU, false);
       default: return hipErrorInvalidValue;
     }
   }

@@ -103,9 +103,9 @@ __device__ __forceinline__ void build_R_tile(const double* __restrict__ X, int N
       if (i == j)
         v = diag;
       else if (DIV)
-        v = (a * corr_profile<KERNEL>(s2[r][c])) / b;
+        v = (a * corr_profile<KERNEL>(s2[r][c], pexp)) / b;
       else
-        v = a * corr_profile<KERNEL>(s2[r][c]);
+        v = a * corr_profile<KERNEL>(s2[r][c], pexp);
       R[(size_t)j * ld + i] = v;
     }
 }
@@ -209,6 +209,7 @@ hipError_t launch_min_pdist2(const double* X, int M, int d, unsigned long long* 
   switch (kernel) {                                        \
     case BOGP_KERNEL_CUBIC: { CALL(BOGP_KERNEL_CUBIC); } break; \
     case BOGP_KERNEL_GENEXP: { CALL(BOGP_KERNEL_GENEXP); } break; \
+    case BOGP_KERNEL_MATERN_NU: { CALL(BOGP_KERNEL_MATERN_NU); } break; \
     default: BOGP_FOR_KERNEL(kernel, CALL)                 \
   }
 
@@ -298,9 +299,9 @@ __global__ __launch_bounds__(256) void k_resid_gamma(const double* __restrict__ 
         if (i == j)
           v = diag;
         else if (DIV)
-          v = (a * corr_profile<KERNEL>(s2[r][c])) / b;
+          v = (a * corr_profile<KERNEL>(s2[r][c], pexp)) / b;
         else
-          v = a * corr_profile<KERNEL>(s2[r][c]);
+          v = a * corr_profile<KERNEL>(s2[r][c], pexp);
         rowacc[r] = __builtin_fma(v, gj, rowacc[r]);
       }
     }

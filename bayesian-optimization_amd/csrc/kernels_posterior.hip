@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_corr_chunk(const double* __restrict__ X
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const double r = corr_profile<KERNEL>(acc[i]);
+      const double r = corr_profile<KERNEL>(acc[i], pexp);
       rT[(size_t)(n0 + i) * a.Mc + mc0 + m] = r;
       mu = __builtin_fma(r, gamma[n0 + i], mu);
       wd = __builtin_fma(r, wvec[n0 + i], wd);
@@ -428,6 +428,7 @@ hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipS
     case BOGP_KERNEL_ABSEXP: BOGP_LAUNCH_CORR(BOGP_KERNEL_ABSEXP); break;
     case BOGP_KERNEL_CUBIC: BOGP_LAUNCH_CORR(BOGP_KERNEL_CUBIC); break;
     case BOGP_KERNEL_GENEXP: BOGP_LAUNCH_CORR(BOGP_KERNEL_GENEXP); break;
+    case BOGP_KERNEL_MATERN_NU: BOGP_LAUNCH_CORR(BOGP_KERNEL_MATERN_NU); break;
     default: BOGP_LAUNCH_CORR(BOGP_KERNEL_MATERN52); break;
   }
 #undef BOGP_LAUNCH_CORR_PV

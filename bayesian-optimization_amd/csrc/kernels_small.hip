@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep_small(const double* __rest
 bool sweep_small_supported(int Np, int d, int kernel) {
   // generalized_exponential calls pow() per pair and dimension: inlined 16 times per producer trip it spills > 1000 VGPRs
   // next to the resident accumulators -- that kernel (values only, never fitted) keeps the chunked schedule
-  if (kernel == BOGP_KERNEL_GENEXP) return false;
+  if (kernel == BOGP_KERNEL_GENEXP || kernel == BOGP_KERNEL_MATERN_NU) return false;
   const char* e = getenv("BOGP_NO_FUSED_SMALL");  // read per call: the tests run both schedules in one process
   const bool off = e && atoi(e) != 0;
   return !off && Np <= 2 * SM_PANEL && d <= 60;  // LDS: 128 KB panel + 64 x roundup(d, 2) doubles <= 160 KB

@@ -66,7 +66,9 @@ def kernel_id_of(corr) -> int:
         nu = (getattr(corr, "keywords", None) or {}).get("nu", 1.5)
         if nu in _NU_IDS:
             return _NU_IDS[nu]
-        raise NotImplementedError("general-nu Matern (Bessel kv) is not built on the device")
+        if not (isinstance(nu, (int, float)) and 0.0 < float(nu) <= 60.0):
+            raise NotImplementedError("general-nu Matern: nu = %r outside (0, 60]" % (nu,))
+        return _lib.KERNEL_MATERN_NU  # kernel.py:201-207 (scipy.special.kv there, a device K_nu here); values only, like the reference
     raise NotImplementedError("callable correlation %r is not built on the device" % (corr,))
 
 
@@ -106,6 +108,9 @@ class GaussianProcess:
         self.verbose = bool(verbose)
         self.corr_type = corr
         self.kernel_id = kernel_id_of(corr)
+        # general-nu Matern: the order is a keyword of the correlation function in the reference (functools.partial(matern, nu=...)),
+        # an extra trailing entry of theta at the C ABI (like generalized_exponential's exponent): `_epar` puts it there
+        self._nu = float((getattr(corr, "keywords", None) or {}).get("nu", 1.5)) if self.kernel_id == _lib.KERNEL_MATERN_NU else None
         self.is_fitted = False
         self.device = int(device)
         self.distribute_restarts = bool(distribute_restarts)
@@ -195,6 +200,14 @@ class GaussianProcess:
         if np.ndim(st["G"]) == 0:  # constant basis: the C ABI hands back vectors and a scalar
             return st["Ft"].reshape(-1, 1), np.array([[st["G"]]]), st["Q"].reshape(-1, 1), np.array([[st["beta"]]])
         return st["Ft"], st["G"], st["Q"], np.asarray(st["beta"], dtype=float).reshape(-1, 1)
+
+    def _epar(self, par):
+        """The parameter vector as the engine takes it: nu inserted behind the theta entries for the general-nu Matern kernel."""
+        if self.kernel_id != _lib.KERNEL_MATERN_NU:
+            return par
+        par = np.asarray(par, dtype=np.float64).ravel()
+        n_theta = len(self.thetaL)
+        return np.r_[par[:n_theta], self._nu, par[n_theta:]]
 
     def _nv(self) -> float:
         return float(np.atleast_1d(self.noise_var)[0]) if self.estimation_mode == "noisy" else 0.0
@@ -292,7 +305,7 @@ class GaussianProcess:
                     if not _adopt:
                         self._restore(prev)
                     return llf
-            out = self.engine.nll(self.kernel_id, mode, par, self._nv(), est, beta, eval_grad=eval_grad, trend=tid)
+            out = self.engine.nll(self.kernel_id, mode, self._epar(par), self._nv(), est, beta, eval_grad=eval_grad, trend=tid)
             # nll overwrote the factor buffers: re-establish the state that is to survive this call
             self._restore(after)
             return out
@@ -329,7 +342,7 @@ class GaussianProcess:
                            Yt=st["Yt"].reshape(-1, 1), C=st["C"], Ft=Ft, G=G, Q=Q, gamma=st["gamma"].reshape(-1, 1))  # fmt: skip
                 if _adopt:
                     after = (np.array(par, dtype=float), True)
-            out = self.engine.nll_restricted(self.kernel_id, self._MODE[self.estimation_mode], par, self._nv(), est, beta, eval_grad=eval_grad, trend=tid)
+            out = self.engine.nll_restricted(self.kernel_id, self._MODE[self.estimation_mode], self._epar(par), self._nv(), est, beta, eval_grad=eval_grad, trend=tid)
             self._restore(after)
             return out
         except _lib.NotPositiveDefinite:
@@ -342,12 +355,12 @@ class GaussianProcess:
         self._committed_restricted = restricted  # how `_committed_par` is to be read when the state is rebuilt
         if restricted:  # R = (sigma2 R0 + nv I) / (sigma2 + nv): the NOISY-mode state (gpr.py:836-839)
             theta, s2, nv = self._split_restricted(par)
-            llf = self.engine.commit(self.kernel_id, _lib.MODE_NOISY, np.r_[theta, s2], nv, est, beta, trend=tid)
+            llf = self.engine.commit(self.kernel_id, _lib.MODE_NOISY, self._epar(np.r_[theta, s2]), nv, est, beta, trend=tid)
             self._committed_par = np.array(par, dtype=float)
             if refresh_attributes:
                 self._pull_state(par)
             return llf
-        llf = self.engine.commit(self.kernel_id, self._MODE[self.estimation_mode], par, self._nv(), est, beta, trend=tid)
+        llf = self.engine.commit(self.kernel_id, self._MODE[self.estimation_mode], self._epar(par), self._nv(), est, beta, trend=tid)
         self._committed_par = np.array(par, dtype=float)
         if refresh_attributes:
             self._pull_state(par)
@@ -603,7 +616,7 @@ class GaussianProcess:
 
     def fit(self, X, y):
         """gpr.py:355-417.  Returns self; sets `is_fitted`."""
-        if self.kernel_id in (_lib.KERNEL_CUBIC, _lib.KERNEL_GENEXP):
+        if self.kernel_id in (_lib.KERNEL_CUBIC, _lib.KERNEL_GENEXP, _lib.KERNEL_MATERN_NU):
             # the MLE needs d llf / d theta; for these two the reference's own fit raises UnboundLocalError at gpr.py:1001
             # (corr_grad_theta :763-766 defines nothing).  Pinned hyper-parameters work: set_state / predict / sweep.
             raise NotImplementedError("corr=%r has no theta-derivative (neither here nor in the reference): use set_state(par, X, y)" % (self.corr,))

@@ -49,6 +49,8 @@ typedef struct bogp_handle bogp_handle;
 #define BOGP_KERNEL_ABSEXP 4 /* absolute_exponential :247-286   exp(-sum_k theta_k |d_k|) */
 #define BOGP_KERNEL_GENEXP 6 /* exp(-sum_k theta_k |d_k|^p), kernel.py:332-379; theta = [theta_1 .. theta_d, p] (d + 1 entries, or [theta, p]):
                                 values only, like BOGP_KERNEL_CUBIC */
+#define BOGP_KERNEL_MATERN_NU 7 /* matern with any nu > 0, kernel.py:201-207: (2^(1-nu) / Gamma(nu)) t^nu K_nu(t), t = sqrt(2 nu) s (scipy.special.kv there, a device
+                                   K_nu here); theta = [theta_1 .. theta_d, nu] (or [theta, nu]); values only -- corr_grad_theta / corr_dx define nothing for it */
 #define BOGP_KERNEL_CUBIC 5 /* prod_k max(0, 1 - 3 (theta_k d_k)^2 + 2 (theta_k d_k)^3), kernel.py:419-466: likelihood VALUE, commit,
                                predict, sweep -- no derivatives, like the reference (corr_grad_theta / corr_dx leave it undefined) */
 

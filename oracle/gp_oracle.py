@@ -33,6 +33,7 @@ KERNEL_MATERN52 = 3
 KERNEL_ABSEXP = 4
 KERNEL_CUBIC = 5
 KERNEL_GENEXP = 6  # theta = [theta_1 .. theta_d, p]
+KERNEL_MATERN_NU = 7  # theta = [theta_1 .. theta_d, nu]: matern(theta, d, nu=nu) with nu outside {1/2, 3/2, 5/2} (kernel.py:201-207)
 KERNEL_NAMES = {"squared_exponential": KERNEL_SE, "matern": KERNEL_MATERN32, "absolute_exponential": KERNEL_ABSEXP,
                 "cubic": KERNEL_CUBIC, "generalized_exponential": KERNEL_GENEXP}
 
@@ -108,6 +109,9 @@ def corr(kernel: int, theta: np.ndarray, d: np.ndarray) -> np.ndarray:
         if theta.size != n_features:
             raise ValueError("Length of theta must be 1 or %s" % n_features)
         return np.exp(-np.sum(theta.reshape(1, n_features) * d, axis=1))
+    nu = None
+    if kernel == KERNEL_MATERN_NU:  # the order travels as the last entry of theta (bogp.h); the reference takes it as a keyword
+        nu, theta = float(theta[-1]), theta[:-1]
     if theta.size == 1:
         s = theta[0] * np.sum(d**2, axis=1)
     else:
@@ -125,6 +129,16 @@ def corr(kernel: int, theta: np.ndarray, d: np.ndarray) -> np.ndarray:
     if kernel == KERNEL_MATERN52:
         K = dists * _SQRT5
         return (1.0 + K + K**2 / 3.0) * np.exp(-K)
+    if kernel == KERNEL_MATERN_NU:  # kernel.py:201-207, operation for operation
+        from scipy.special import gamma, kv
+
+        K = dists
+        K[K == 0.0] += np.finfo(float).eps  # strict zeros result in nan
+        tmp = math.sqrt(2 * nu) * K
+        K.fill((2 ** (1.0 - nu)) / gamma(nu))
+        K *= tmp**nu
+        K *= kv(nu, tmp)
+        return K
     raise ValueError("unknown kernel id %r" % kernel)
 
 

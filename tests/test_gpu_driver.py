@@ -467,9 +467,10 @@ def _compare_fit_outputs(b, s):
     np.testing.assert_allclose(b[5], s[5], rtol=1e-6, atol=1e-11)
 
 
-@pytest.mark.parametrize("name", ["G25_cubic_ok_noisy", "G26_genexp_sk_noisy"])
+@pytest.mark.parametrize("name", ["G25_cubic_ok_noisy", "G26_genexp_sk_noisy", "G31_matern_nu08_ok_noisy", "G32_matern_nu37_sk_noisy"])
 def test_value_only_kernels_on_the_device(name):
-    """cubic / generalized_exponential against the reference's outputs (G25 / G26): committed state, posterior, the six
+    """cubic / generalized_exponential / the general-nu Matern arm (kernel.py:201-207; a K_nu of real order on the device where the reference
+    calls scipy.special.kv) against the reference's outputs (G25 / G26 / G31 / G32): committed state, posterior, the six
     criteria with argmax, likelihood values incl. the -inf convention; derivatives are refused (the reference has none)."""
     from conftest import load_golden, state_from_golden
 
@@ -532,11 +533,26 @@ def test_value_only_kernels_on_the_device(name):
         assert ei.value.code == _lib.ERR_UNSUPPORTED
     # the drop-in class: pinned state, predictions and a sweep through the front end
     d = g["X"].shape[1]
-    corr = {5: "cubic", 6: "generalized_exponential"}[kid]
-    n = len(g["par"]) - 1
+    user_par = g["par"]
+    if kid == 7:  # the order is a keyword of the correlation function for the user, a trailing theta entry for the engine
+        import functools
+
+        def matern(theta, X, nu=1.5):  # (only its name and keyword are looked at: surrogate.kernel_id_of)
+            raise AssertionError("the device path never calls the correlation function")
+
+        corr = functools.partial(matern, nu=float(g["nu"]))
+        user_par = np.r_[g["par"][:d], g["par"][d + 1:]]
+        n = d
+    else:
+        corr = {5: "cubic", 6: "generalized_exponential"}[kid]
+        n = len(g["par"]) - 1
     gp = bogp.GaussianProcess(mean=bogp.trend.constant_trend(d, beta=None if est else 0.0), corr=corr, thetaL=[1e-5] * n, thetaU=[1e2] * n,
                               nugget=1e-6)  # fmt: skip
-    gp.set_state(g["par"], g["X"], g["y"])
+    gp.set_state(user_par, g["X"], g["y"])
+    if kid == 7:
+        with pytest.raises(NotImplementedError):
+            gp.fit(g["X"], g["y"])
+        gp.set_state(user_par, g["X"], g["y"])
     m2, s2 = gp.predict(g["Xs"], eval_MSE=True)
     np.testing.assert_allclose(m2, g["mu"], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(np.ravel(bogp.UCB(model=gp)(g["Xs"])), g["UCB_0.5"], rtol=1e-6)
