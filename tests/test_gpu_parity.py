@@ -103,8 +103,11 @@ def test_acquisitions_and_argmax_match_reference(eng, name):
             ref = g[prefix + key]
             ok = ~noise_rows if a in (O.ACQ_EPSILON_PI, O.ACQ_MGFI) else np.ones(len(ref), bool)
             np.testing.assert_allclose(v[ok], ref[ok], rtol=1e-6, atol=1e-300, equal_nan=True, err_msg=prefix + key)
-            if ok.all():
-                assert i == int(g[prefix + "argmax_" + key][0]), (prefix + key, i)
+            ra = int(g[prefix + "argmax_" + key][0])
+            # (rows whose reference MSE is <= 1e-12 sigma2 are 0 / 0 territory for EpsilonPI / MGFI: their values are not compared -- and
+            # the argmax is, whenever neither the reference's winner nor the device's is such a row)
+            if ok.all() or (ok[ra] and ok[i]):
+                assert i == ra, (prefix + key, i, ra)
             assert i == int(np.argmax(v))  # the device argmax is np.argmax of the device values, always
             np.testing.assert_array_equal(b, v[i])
 

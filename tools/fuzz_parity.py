@@ -20,8 +20,8 @@ from bogp import _lib  # noqa: E402
 from oracle import gp_oracle as O  # noqa: E402
 from support.oracle_engine import OracleEngine  # noqa: E402
 
-KERNELS = [O.KERNEL_SE, O.KERNEL_MATERN12, O.KERNEL_MATERN32, O.KERNEL_MATERN52, O.KERNEL_ABSEXP, O.KERNEL_CUBIC, O.KERNEL_GENEXP]
-NO_GRAD = (O.KERNEL_CUBIC, O.KERNEL_GENEXP)
+KERNELS = [O.KERNEL_SE, O.KERNEL_MATERN12, O.KERNEL_MATERN32, O.KERNEL_MATERN52, O.KERNEL_ABSEXP, O.KERNEL_CUBIC, O.KERNEL_GENEXP, O.KERNEL_MATERN_NU]
+NO_GRAD = (O.KERNEL_CUBIC, O.KERNEL_GENEXP, O.KERNEL_MATERN_NU)
 EDGE_N = [2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 640, 1023, 1025]
 
 
@@ -59,6 +59,8 @@ def one(seed, eng, orc):
     theta = np.exp(rng.uniform(np.log(0.02), np.log(0.5), d)) / d
     if kernel == O.KERNEL_GENEXP:
         theta = np.r_[theta, rng.uniform(1.0, 2.0)]
+    if kernel == O.KERNEL_MATERN_NU:  # the order as the last theta entry (general-nu arm, kernel.py:201-207)
+        theta = np.r_[theta, rng.choice([0.3, 0.8, 1.0, 2.0, 3.7, 4.5]) if rng.random() < 0.5 else rng.uniform(0.2, 5.0)]
     nv = 0.0
     if mode == O.MODE_NOISELESS:
         par = theta
@@ -127,6 +129,30 @@ def one(seed, eng, orc):
             fails.append("grad max diff %g (|grad| %.3g, cond %.1e)" % (np.abs(np.ravel(got[1]) - np.ravel(ref[1])).max(), np.abs(ref[1]).max(), cond))
     elif not close(got, ref, tol, tol):
         fails.append("llf %r vs %r" % (got, ref))
+    # r04: the batched likelihood must return the sequential call's BITS, slot by slot (bogp_nll_batch), whatever the conditioning
+    if True:
+        P = int(rng.integers(2, 7))
+        pars = np.tile(par, (P, 1)) * 10.0 ** rng.uniform(-0.15, 0.15, size=(P, len(par)))
+        if mode == 2:
+            pars[:, -1] = np.clip(pars[:, -1], 1e-6, 1 - 1e-9)
+        pars[0] = par
+        try:
+            bl, bg, bi = eng.nll_batch(kernel, mode, pars, nv, est, beta, eval_grad=grad, trend=trend)
+        except _lib.BogpError as e:
+            fails.append("nll_batch raised %s" % e)
+            bl = None
+        if bl is not None:
+            for s_ in range(P):
+                try:
+                    one = eng.nll(kernel, mode, pars[s_], nv, est, beta, eval_grad=grad, trend=trend)
+                    l1, g1 = (one[0], np.ravel(one[1])) if grad else (one, None)
+                except _lib.NotPositiveDefinite:
+                    l1, g1 = -np.inf, (np.zeros(len(par)) if grad else None)
+                except _lib.BogpError:
+                    continue
+                if not (bl[s_] == l1 or (np.isnan(bl[s_]) and np.isnan(l1))) or (grad and not np.array_equal(bg[s_], g1)):
+                    fails.append("nll_batch slot %d of %d differs from the sequential call: %r vs %r" % (s_, P, bl[s_], l1))
+                    break
     try:
         orc.commit(kernel, mode, par, nv, est, beta, trend=trend)
         eng.commit(kernel, mode, par, nv, est, beta, trend=trend)
