@@ -90,6 +90,7 @@ def fused_batch_arg_max_acquisition(self, n_point: int, return_dx: bool, fixed=N
 
 _ORIGINAL: dict = {}
 _REROUTE: dict = {}
+_SURROGATE_DEFAULTS: dict = {}  # keyword defaults install() gives the device GaussianProcess (e.g. restart_batch)
 
 
 def _effective(optimizer, eval_budget):
@@ -198,11 +199,17 @@ class _AcquisitionNamespace:
 
 def _dispatching_surrogate(host_cls):
     def _pick(args, kwargs):
+        # install(restart_batch=...): defaults of the device models the drivers build themselves (taken back if the host class is picked)
+        added = [k for k in _SURROGATE_DEFAULTS if k not in kwargs]
+        for k in added:
+            kwargs[k] = _SURROGATE_DEFAULTS[k]
         try:  # validate on a throw-away instance: the constructor touches no device
             probe = _DeviceGP(*args, **kwargs)
             probe._trend_args()  # a trend basis the device does not evaluate is found NOW, not at fit() (it raises NotImplementedError)
             return _DeviceGP
         except NotImplementedError as e:
+            for k in added:
+                kwargs.pop(k, None)
             warnings.warn("bogp: this GaussianProcess configuration stays on the reference's CPU class (%s)" % e, stacklevel=3)
             return host_cls
 
@@ -211,7 +218,8 @@ def _dispatching_surrogate(host_cls):
                                                         "else bayes_optim's CPU class"})  # fmt: skip
 
 
-def install(bayes_optim=None, fuse_batch: bool = True, reroute_bfgs: str = None, sweep_budget: int = 1_000_000, surrogate: bool = True):
+def install(bayes_optim=None, fuse_batch: bool = True, reroute_bfgs: str = None, sweep_budget: int = 1_000_000, surrogate: bool = True,
+            restart_batch: int = None):
     """Re-point the reference's extension points at this package (see the module docstring).  `bayes_optim` is the
     imported reference package (default: `import bayes_optim`).  Returns `uninstall()`.  Idempotent.
 
@@ -222,7 +230,14 @@ def install(bayes_optim=None, fuse_batch: bool = True, reroute_bfgs: str = None,
     `reroute_bfgs` = "sweep" | "sweep-device" | "sweep-device-lhs" | "sweep-device-sobol" | "sweep-BFGS" | "sweep-device-BFGS": drivers constructed
     WITHOUT `acquisition_optimization` fall to the reference's default "BFGS" (one device round trip per point); with a
     reroute their inner maximisation becomes one sweep of `sweep_budget` candidates instead -- no change to the driver's
-    constructor call.  Constrained problems, foreign models and non-real spaces are never rerouted."""
+    constructor call.  Constrained problems, foreign models and non-real spaces are never rerouted.
+
+    `restart_batch` = R: device models built through the re-pointed name get `restart_batch=R` unless the call names its own."""
+    if restart_batch is not None:
+        # the models `fmin` / the drivers build through the re-pointed GaussianProcess name fit with their MLE restarts in lock step
+        # (surrogate.GaussianProcess(restart_batch=R), DESIGN.md 5.13): `tell()` is most of a BO loop's wall time.  Opt-in: the
+        # sequential loop with scipy's optimiser stays the default, as in the reference.
+        _SURROGATE_DEFAULTS["restart_batch"] = int(restart_batch)
     if reroute_bfgs is not None:
         if reroute_bfgs not in _OURS:
             raise ValueError("reroute_bfgs must be one of %s" % (_OURS,))
@@ -270,3 +285,4 @@ def uninstall():
         pkg.GaussianProcess, rsur.GaussianProcess = _ORIGINAL["gp"]
     _ORIGINAL.clear()
     _REROUTE.clear()
+    _SURROGATE_DEFAULTS.clear()

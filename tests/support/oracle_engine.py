@@ -34,6 +34,51 @@ class OracleEngine:
             raise _lib.NotPositiveDefinite(_lib.ERR_NOT_POSDEF, "oracle: -inf")
         return (out[0], np.asarray(out[1], float).ravel()) if eval_grad else out
 
+    def nll_batch(self, kernel, mode, pars, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False, trend=0):
+        pars = np.atleast_2d(np.asarray(pars, float))
+        llf, grad, info = np.empty(len(pars)), (np.zeros(pars.shape) if eval_grad else None), np.zeros(len(pars), dtype=np.int32)
+        for s, p in enumerate(pars):
+            if not (np.all(np.isfinite(p)) and np.all(p > 0)):
+                llf[s], info[s] = -np.inf, _lib.ERR_INVALID
+                continue
+            try:
+                out = self.nll(kernel, mode, p, noise_var, estimate_trend, beta, eval_grad=eval_grad, trend=trend)
+                llf[s] = out[0] if eval_grad else out
+                if eval_grad:
+                    grad[s] = out[1]
+            except _lib.NotPositiveDefinite as e:
+                llf[s], info[s] = -np.inf, e.code
+        return llf, grad, info
+
+    def mle_batch(self, kernel, mode, x0, lo, hi, noise_var=0.0, estimate_trend=False, beta=0.0, trend=0, restricted=False, eval_budget=0,
+                  m=10, factr=1e7, pgtol=1e-5, chain_rule=False, prune_reserve=0):
+        """bogp_mle_batch's contract on the CPU: the library's OWN optimiser (bogp_lbfgsb_minimize, no device needed) on the oracle's
+        likelihood, one start after the other (the lock step only changes how evaluations are grouped, not what a run does as long as the
+        shared budget does not bind)."""
+        x0 = np.atleast_2d(np.asarray(x0, float))
+        fun = self.nll_restricted if restricted else self.nll
+
+        def obj(x):
+            par = 10.0 ** np.asarray(x)
+            try:
+                llf, g = fun(kernel, mode, par, noise_var, estimate_trend, beta, eval_grad=True, trend=trend)
+            except _lib.NotPositiveDefinite:
+                return np.inf, np.zeros(len(par))
+            if not np.isfinite(llf):
+                return np.inf, -np.asarray(g, float).ravel()
+            g = -np.asarray(g, float).ravel()
+            return -llf, (g * np.log(10.0) * par if chain_rule else g)
+
+        R = len(x0)
+        xopt, fopt = np.empty_like(x0), np.empty(R)
+        nev, status = np.zeros(R, dtype=np.int32), np.zeros(R, dtype=np.int32)
+        left = int(eval_budget) if eval_budget > 0 else 15000 * R
+        for r in range(R):
+            xopt[r], fopt[r], info = _lib.lbfgsb_minimize(obj, x0[r], np.c_[lo, hi], m=m, factr=factr, pgtol=pgtol, maxfun=max(1, left // (R - r)))
+            nev[r], status[r] = info["funcalls"], info["status"]
+            left -= info["funcalls"]
+        return xopt, fopt, nev, status, int(nev.max())
+
     def nll_restricted(self, kernel, mode, par, noise_var=0.0, estimate_trend=False, beta=0.0, eval_grad=False, trend=0):
         out = O.log_likelihood_restricted(par, self.X, self.y, kernel, mode, noise_var, trend, estimate_trend, beta, eval_grad=eval_grad)
         return (out[0], np.asarray(out[1], float).ravel()) if eval_grad else out

@@ -317,3 +317,70 @@ def test_reference_suite_passes_under_install(tmp_path):
                                      "--no-header", "-W", "ignore", nodeid], cwd=str(tmp_path), env=env, capture_output=True,
                                     text=True, timeout=600) for _ in range(2)]
             assert any(r.returncode == 0 for r in again), "%s fails repeatedly under install():\n%s" % (nodeid, again[-1].stdout[-3000:])
+
+
+@pytest.mark.timeout(900)
+def test_install_restart_batch_reaches_the_models_fmin_builds(monkeypatch):
+    """install(restart_batch=R): the GaussianProcess `fmin` constructs itself (`__init__.py:147-160`) fits with its MLE restarts through
+    bogp_mle_batch (the engine stand-in runs the library's own L-BFGS-B on the oracle's likelihood); a configuration that stays on the
+    reference's CPU class does not receive the keyword it would not know."""
+    for p in (REF, os.path.join(ROOT, "oracle", "shims")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    warnings.filterwarnings("ignore")
+    import bayes_optim
+
+    import bogp
+    from bayes_optim.surrogate.gaussian_process import GaussianProcess as CpuGP
+    from support.oracle_engine import OracleEngine
+
+    calls = []
+
+    class Recording(OracleEngine):
+        def mle_batch(self, *a, **k):
+            calls.append(len(np.atleast_2d(a[2])))
+            return super().mle_batch(*a, **k)
+
+    monkeypatch.setattr(bogp._lib, "Engine", lambda device=0: Recording(device))
+    undo = bogp.install(bayes_optim, restart_batch=3)
+    try:
+        gp = bayes_optim.GaussianProcess(corr="matern", thetaL=[1e-2] * 2, thetaU=[1e2] * 2, random_start=5)
+        assert type(gp) is bogp.GaussianProcess and gp.restart_batch == 3
+        assert bayes_optim.GaussianProcess(corr="matern", thetaL=[1e-2] * 2, thetaU=[1e2] * 2, restart_batch=0).restart_batch == 0
+        with pytest.warns(UserWarning, match="stays on the reference's CPU class"):
+            cpu = bayes_optim.GaussianProcess(corr="matern", thetaL=[1e-2] * 2, thetaU=[1e2] * 2, optimizer="CMA")
+        assert type(cpu) is CpuGP
+        minimum = bayes_optim.fmin(_sphere, [-5] * 2, [5] * 2, seed=42, max_FEs=16, verbose=False)
+        assert minimum[3] == 16 and calls and max(calls) <= 3
+        assert minimum[1] < 5.0
+    finally:
+        undo()
+    assert bayes_optim.GaussianProcess is not None and not bogp.integration._SURROGATE_DEFAULTS
+
+
+def test_subclasses_and_foreign_trends_of_the_dispatching_class_stay_on_the_host(installed):
+    """(1) `class My(bayes_optim.GaussianProcess)` inherits the dispatching metaclass -- its overrides were written against the
+    reference's class, so it is built on the host class with the overrides in place, not replaced by a plain device object; (2) a trend
+    basis the device does not evaluate is found at CONSTRUCTION (fallback + warning), not at fit()."""
+    bayes_optim, bogp, created = installed
+    from bayes_optim.surrogate.gaussian_process import GaussianProcess as CpuGP
+    from bayes_optim.surrogate.gaussian_process.trend import BasisExpansionTrend
+
+    class My(bayes_optim.GaussianProcess):
+        def predict(self, X, eval_MSE=False, batch_size=None):
+            return "overridden"
+
+    m = My(corr="matern", thetaL=[1e-2] * 2, thetaU=[1e2] * 2)
+    assert isinstance(m, CpuGP) and not isinstance(m, bogp.GaussianProcess) and m.predict(None) == "overridden"
+
+    class CubicTrend(BasisExpansionTrend):
+        def __init__(self, n_feature, beta=None):
+            super().__init__(n_feature, n_feature + 1, beta)
+
+        def F(self, X):
+            X = self.check_input(X)
+            return np.c_[np.ones(len(X)), X**3]
+
+    with pytest.warns(UserWarning, match="stays on the reference's CPU class"):
+        gp = bayes_optim.GaussianProcess(mean=CubicTrend(2), corr="matern", thetaL=[1e-2] * 2, thetaU=[1e2] * 2)
+    assert type(gp) is CpuGP
