@@ -445,8 +445,12 @@ class GaussianProcess:
             rank, world = dist.get_rank(), dist.get_world_size()
             eval_budget = max(1, -(-eval_budget // world))
         batch = int(getattr(self, "restart_batch", 0) or 0)
-        if batch > 0 and dist is None:
-            param_opt, llf_opt = self._restarts_in_lock_step(batch, log10param, log10bounds, eval_budget, restricted)
+        if batch > 0:
+            # (with `distribute_restarts` every rank runs ITS restarts -- i % world == rank, all start points drawn on every rank from the
+            # identically seeded global stream -- in lock-step waves on its own GPU with budget / world, then ONE all-gather picks the winner)
+            param_opt, llf_opt = self._restarts_in_lock_step(batch, log10param, log10bounds, eval_budget, restricted, rank, world)
+            if world > 1:
+                param_opt, llf_opt = distributed.exchange_best_parameters(np.asarray(param_opt, float), float(llf_opt))
             optimal_param = 10.0**param_opt
             env = {}
             optimal_llf_value = llf_fun(optimal_param, env, _adopt=True)
@@ -501,7 +505,7 @@ class GaussianProcess:
             i += len_
         return param, optimal_llf_value, env, optimal_param
 
-    def _restarts_in_lock_step(self, batch, log10param0, log10bounds, eval_budget, restricted):
+    def _restarts_in_lock_step(self, batch, log10param0, log10bounds, eval_budget, restricted, rank=0, world=1):
         """The MLE restarts of gpr.py:1127-1162 advanced together, `batch` at a time (bogp_mle_batch): every round of the
         lock-step loop evaluates the current trial point of each active restart with ONE batched likelihood call (one workgroup a
         restart for N <= 156, the elimination kernels over `batch` workspaces up to N = 2048), and the optimiser is libbogp's own
@@ -522,10 +526,18 @@ class GaussianProcess:
         self.eval_count, self.mle_rounds = 0, 0
         it = 0
         while it < self.random_start:
-            n_w = min(batch, self.random_start - it)
-            starts = []
-            for r in range(n_w):
-                starts.append(np.array(log10param0, dtype=float) if it + r == 0 else np.random.uniform(lo, hi))
+            # the next wave: up to `batch` restarts of THIS rank; the start points of the other ranks' restarts are drawn and dropped so
+            # that every rank consumes the global stream alike
+            starts, idx = [], []
+            while it < self.random_start and len(starts) < batch:
+                x = np.array(log10param0, dtype=float) if it == 0 else np.random.uniform(lo, hi)
+                if it % world == rank:
+                    starts.append(x)
+                    idx.append(it)
+                it += 1
+            n_w = len(starts)
+            if n_w == 0:
+                break
             xopt, fopt, nev, status, rounds = self.engine.mle_batch(kid, mode, np.array(starts), lo, hi, nv, est, beta, trend=tid,
                                                                     restricted=restricted, eval_budget=int(eval_budget),
                                                                     chain_rule=bool(getattr(self, "mle_chain_rule", False)),
@@ -541,12 +553,11 @@ class GaussianProcess:
                 else:
                     wait_count += 1
                 if self.verbose:
-                    print("MLE restart %d (lock step): %d likelihood evaluations, status %d, best llf so far %.10g" % (it + r + 1, nev[r], status[r], -llf_opt))
+                    print("MLE restart %d (lock step): %d likelihood evaluations, status %d, best llf so far %.10g" % (idx[r] + 1, nev[r], status[r], -llf_opt))
                 self.eval_count += int(nev[r])
                 eval_budget -= int(nev[r])
                 if eval_budget <= 0 or wait_count >= self.wait_iter:
                     stop = True  # (the whole wave has already run: its later restarts still count, as above)
-            it += n_w
             if stop:
                 break
         self._committed_par = None  # (the batched paths leave the factor buffers alone, the fallback paths do not)

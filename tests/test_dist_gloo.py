@@ -150,7 +150,7 @@ def test_sweep_optimiser_returns_the_same_point_on_every_rank():
     assert xs0[0] != xs0[1]  # two identical criteria: the second takes its fall-back, not the same point
 
 
-def _fit_worker(rank, world, port, q_out):
+def _fit_worker(rank, world, port, q_out, restart_batch=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -166,7 +166,7 @@ def _fit_worker(rank, world, port, q_out):
         y = np.sum(X**2, axis=1)
         y = (y - y.mean()) / y.std() + 0.05 * rng.standard_normal(40)
         gp = bogp.GaussianProcess(thetaL=[1e-3] * 3, thetaU=[1e2] * 3, nugget=1e-6, random_start=6, wait_iter=6,
-                                  eval_budget=240, distribute_restarts=True)  # fmt: skip
+                                  eval_budget=240, distribute_restarts=True, restart_batch=restart_batch)  # fmt: skip
         gp._engine = OracleEngine()  # host-logic test: see tests/support/oracle_engine.py
         np.random.seed(11)  # identical stream on every rank
         gp.fit(X, y)
@@ -192,6 +192,27 @@ def test_mle_restarts_spread_over_two_ranks():
     (r0, llf0, th0, n0), (r1, llf1, th1, n1) = res
     assert llf0 == llf1 and np.array_equal(th0, th1)  # every rank commits the same winner
     assert np.isfinite(llf0) and n0 <= 135 and n1 <= 135  # ~half the budget each (L-BFGS-B overshoots maxfun by a line search)
+
+
+@pytest.mark.timeout(300)
+def test_lock_step_restarts_spread_over_two_ranks():
+    """restart_batch with distribute_restarts: rank r advances ITS restarts (i % world == r) in lock-step waves on its own engine -- here
+    the stand-in, i.e. the library's own L-BFGS-B on the oracle's likelihood -- with half the budget; one all-gather picks the winner."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, q_out, 2)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q_out.get(timeout=250) for _ in procs])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (r0, llf0, th0, n0), (r1, llf1, th1, n1) = res
+    assert llf0 == llf1 and np.array_equal(th0, th1)
+    assert np.isfinite(llf0) and 0 < n0 <= 190 and 0 < n1 <= 190
 
 
 @pytest.mark.timeout(300)
