@@ -78,7 +78,7 @@ extern "C" int bogp_create(int device, bogp_handle** out) {
   // the factorisation's info word lives in the same block as its scalars (doubles 62-63): ONE read-back fetches both
   h->dinfo = reinterpret_cast<int*>(h->dscal + 62);
   if (const char* e = getenv("BOGP_CHOL_RESERVE_CU")) {
-    // experiment (tools/ab_big_chol_cumask.sh): the look-ahead update of the two-level factorisation on a stream that may
+    // experiment (tools/ab/ab_big_chol_cumask.sh): the look-ahead update of the two-level factorisation on a stream that may
     // not use the last n CUs (mask bit i -> XCD i % 8, so n / 8 CUs per XCD stay free for the panel chain on the main stream)
     const int n = atoi(e);
     if (n > 0 && n < h->n_cu) {

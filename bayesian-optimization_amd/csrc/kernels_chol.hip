@@ -15,7 +15,7 @@
 //                                   exchanged through 4 KB of LDS, two barriers per 4 columns); the serial chain of
 //                                   the factorisation runs BESIDE the trailing update
 //                     others:       A_ij -= X_i X_j^T (64x64 tiles, K = 64), same MFMA micro-kernel
-// Measured alternatives for the diagonal block (tools/ubench_potf2.hip, profiles/r01_ubench_potf2.txt): one wave with
+// Measured alternatives for the diagonal block (tools/probes/ubench_potf2.hip, profiles/r01_ubench_potf2.txt): one wave with
 // a row per lane and v_readlane / ds_bpermute / LDS broadcasts needs 50-300 us per block (SGPR pressure and spills).
 #include "bogp_device.h"
 #include "bogp_internal.h"
@@ -28,7 +28,7 @@ constexpr int CB = 64;           // block size
 constexpr int CPITCH = 64 + 16;  // LDS pitch (doubles) of a k-major tile: conflict-free rotated A-fragment reads
 
 // v_mfma_f64_16x16x4_f64 accumulating in place in ARCHITECTURAL VGPRs: 64-cycle issue = the FP64 matrix peak (with AGPR
-// accumulators the same instruction takes 130 cycles, tools/ubench_mfma16.hip); one A and one B register per 2048 flop.
+// accumulators the same instruction takes 130 cycles, tools/probes/ubench_mfma16.hip); one A and one B register per 2048 flop.
 // Lanes: A = 16 k + i, B = 16 k + j, D[i][j] in lane 16 (i % 4) + j, component i / 4.
 typedef double d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void mfma16(double a, double b, d4& c) {
@@ -39,7 +39,7 @@ __device__ __forceinline__ void mfma16(double a, double b, d4& c) {
 
 // 1/sqrt(x): hardware estimate + ONE third-order (Halley) step, e = 1 - x y^2, y' = y (1 + e/2 + 3 e^2/8): five dependent
 // operations after v_rsq_f64 instead of the eight of two Newton steps.  A dependent FP64 operation costs ~26 cycles on
-// the 64-pivot chain of the diagonal block (tools/ubench_diag.hip: 21.7 -> 19.5 us per 64 x 64 block together with the
+// the 64-pivot chain of the diagonal block (tools/probes/ubench_diag.hip: 21.7 -> 19.5 us per 64 x 64 block together with the
 // merged phases below); relative error ~ e0^3 (e0 ~ 2^-26) + one rounding, the same 2.2e-16 against LAPACK's factor.
 __device__ __forceinline__ double rsqrt_nr(double x) {
   const double y = __builtin_amdgcn_rsq(x);
@@ -1399,7 +1399,7 @@ hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStre
   // Measured 13.0 -> 13.0 / 13.2 / 13.4 ms per likelihood at N = 8192 for G = 2 / 3 / 4: the 64 x 64 tile kernel is bound
   // by its un-pipelined operand loads, not by that read-modify-write.  (Also measured, and removed again: the group's
   // trailing update as ONE k_mm128 SYRK with the diagonal duty in its tile (0, 0): 38-43 TF/s at K = 128 against 28-33,
-  // but a longer chain per block column -- 13.5-13.8 ms for every threshold tried; tools/ab_chol_group.sh.)
+  // but a longer chain per block column -- 13.5-13.8 ms for every threshold tried; tools/ab/ab_chol_group.sh.)
   static const int G = [] {
     const char* e = getenv("BOGP_CHOL_GROUP");
     const int v = e ? atoi(e) : 1;
@@ -1418,13 +1418,13 @@ hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStre
                                     (size_t)(ld - CB) * sizeof(double), CB, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return e;
   }
-  static const int tri = [] {  // 0: the r02 m x m grids whose upper half exits at once (A/B: tools/ab_chol_tri.sh)
+  static const int tri = [] {  // 0: the r02 m x m grids whose upper half exits at once (A/B: tools/ab/ab_chol_tri.sh)
     const char* e = getenv("BOGP_CHOL_TRI_GRID");
     return e ? atoi(e) : 1;
   }();
   // BOGP_CHOL_CHAIN=1 (off by default; read per call so that the tests can run both): the fused block columns with their diagonal
   // chain in ONE resident workgroup (k_chol_chain) on the second stream instead of workgroup (0, 0) of every k_chol_step.
-  // Measured (tools/ab_chol_chain.sh, profiles/r03_chol_chain_ab.txt): with agent-scope release fences at the hand-overs every
+  // Measured (tools/ab/ab_chol_chain.sh, profiles/r03_chol_chain_ab.txt): with agent-scope release fences at the hand-overs every
   // block column got 1.3-2.4 us SLOWER (a fence is a write-back of the XCD's L2: what a kernel boundary costs anyway); with
   // write-through stores + relaxed flags the per-column time equals k_chol_step's (31 us: flag poll + acquire + two tile
   // loads + two 64^3 products + staging + stores are the same ~11 us around the 19.5-us diagonal routine whoever runs them)

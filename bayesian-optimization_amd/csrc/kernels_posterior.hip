@@ -7,7 +7,7 @@
 //     rt = solve_triangular(L, r.T)      N^2 flops per candidate     -> k_contract     (FP64 MFMA)
 //     1 - sum(rt^2) [+ sum(u^2)]                                     -> k_contract epilogue (+ acquisition kernel)
 //
-// Design constants come from measurements on the target (tools/ubench_f64*.hip, tools/ubench_mfma16.hip; profiles/r01_ubench_f64.txt,
+// Design constants come from measurements on the target (tools/probes/ubench_f64*.hip, tools/probes/ubench_mfma16.hip; profiles/r01_ubench_f64.txt,
 // r01_ubench_mfma16.txt, r01_ubench_mfma_stream.txt):
 //   * v_mfma_f64_4x4x4_4b_f64 issues every 16 cycles (512 flop) = 32 flop/clk/SIMD = the 78.6 TF/s FP64 peak (kernel B below);
 //     v_mfma_f64_16x16x4_f64 issues every 64 cycles (2048 flop) = the same rate -- but only with its accumulator in
@@ -16,7 +16,7 @@
 //   * FP64 VALU work does not hide beside FP64 MFMA (same DP pipe: times add), so the kernel-matrix
 //     producer must run ONCE per (candidate, training point) -- it is split into its own kernel and r is
 //     staged through HBM/L2 in candidate chunks instead of being recomputed per column tile.
-//   * lane layout of v_mfma_f64_4x4x4_4b_f64 (tools/probe_mfma_layout.hip): A lane = 16k+4b+i,
+//   * lane layout of v_mfma_f64_4x4x4_4b_f64 (tools/probes/probe_mfma_layout.hip): A lane = 16k+4b+i,
 //     B lane = 16k+4b+j, D lane = 16i+4b+j  (b = block 0..3).
 //
 // Triangular contraction.  With V = L^-1 (lower triangular, packed once per fit into B-fragment order),
@@ -168,10 +168,10 @@ constexpr int PITCH = 64 + 16;       // LDS row pitch in doubles: 640 B == 128 (
 //
 // The first probe of this instruction (builtin, accumulators where the compiler put them: AGPRs) measured 130-150
 // cycles = half the FP64 rate, which is why kernel B was built on the 4x4x4 form.  With the accumulator tied in place in
-// ARCHITECTURAL VGPRs it issues every 64.0 cycles = 77.5 TF/s, at 1-4 waves per SIMD (tools/ubench_mfma16.hip,
+// ARCHITECTURAL VGPRs it issues every 64.0 cycles = 77.5 TF/s, at 1-4 waves per SIMD (tools/probes/ubench_mfma16.hip,
 // profiles/r01_ubench_mfma16.txt; AGPR accumulators: 130 cycles) -- and it needs ONE A register and ONE B register per
 // 2048 flop where the 4x4x4 form needs four rotated A registers: a quarter of the LDS reads, no rotation, a quarter
-// of the MFMA issue slots.  Lane layout (tools/probe_mfma_layout.hip): A lane = 16 k + i, B lane = 16 k + j (the SAME
+// of the MFMA issue slots.  Lane layout (tools/probes/probe_mfma_layout.hip): A lane = 16 k + i, B lane = 16 k + j (the SAME
 // order k_pack_V already produces), D[i][j] in lane 16 (i % 4) + j, register i / 4.
 // Tiling, staging, guards and the epilogue's summation order are those of kernel B.
 // ---------------------------------------------------------------------------------------------------
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
   const int nMt = a.nMt;
   // Column-group-major order, heaviest group first: concurrent workgroups then walk the SAME 256-column panel of V, which
   // stays hot in every XCD's L2 (the B fragments feed the MFMAs straight from global loads).  Measured alternative (r02,
-  // tools/ab_contract_order.sh): the nJ groups of one candidate tile back to back on one XCD -- r tiles shared in L2, but the
+  // tools/ab/ab_contract_order.sh): the nJ groups of one candidate tile back to back on one XCD -- r tiles shared in L2, but the
   // B reads then span all of V (16 MB against 4 MB of L2): 61.5 -> 85.4 ms per step.  r is re-read (nJ + 1) / 2 times instead.
   const int jg = a.nJ - 1 - (int)(blockIdx.x / nMt);
   const int mt = blockIdx.x % nMt;

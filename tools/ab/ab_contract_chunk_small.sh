@@ -1,7 +1,7 @@
 # r04 A/B asked for by the r03 review: correlation-chunk sizes that fit the 256-MiB Infinity Cache (BOGP_CHUNK_MB = 64 / 128 / 192)
 # against the default 1 GiB, C3.  Per setting: ms/step + kernel times from bench.py (no profiler), then three PMC passes of ONE
 # sweep (tools/pmc_sweep.py; separate runs, kernel-trace only): FETCH_SIZE, WRITE_SIZE, GRBM_GUI_ACTIVE (+ MFMA busy).
-# usage (GPU box): bash tools/ab_contract_chunk_small.sh > gpurun_out/r04_contract_chunk_small_ab.txt
+# usage (GPU box): bash tools/ab/ab_contract_chunk_small.sh > gpurun_out/r04_contract_chunk_small_ab.txt
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/chunk_ab
 mkdir -p $OUT

@@ -1,6 +1,6 @@
 // rocBLAS FP64 rates at the shapes the large-N fit path would hand to the library (MI355X): syrk with K = 256 / 512 on a
 // growing trailing matrix, trmm against a triangular block, and plain gemm for comparison.
-//   hipcc --offload-arch=gfx950 -O2 tools/ubench_blas.hip -lrocblas -o tools/ubench_blas
+//   hipcc --offload-arch=gfx950 -O2 tools/probes/ubench_blas.hip -lrocblas -o tools/probes/ubench_blas
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
 #include <cstdio>

@@ -8,7 +8,7 @@
 // Reading: a dependent FP64 operation costs ~26 cycles on the pivot chain (three fewer per pivot = -2 us per block); the
 // rank-k update phase is issue bound (rank-8 costs exactly two rank-4), and the wider diagonal block puts ~2x the
 // instructions into the ONE wave that carries the chain -- fewer barriers do not pay for that.
-// build: hipcc -O3 --offload-arch=gfx950 tools/ubench_diag.hip -o tools/ubench_diag
+// build: hipcc -O3 --offload-arch=gfx950 tools/probes/ubench_diag.hip -o tools/probes/ubench_diag
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>

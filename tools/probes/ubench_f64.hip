@@ -3,7 +3,7 @@
 //   (2) v_fma_f64 VALU rate
 //   (3) whether f64 VALU work issued between MFMAs hides in the MFMA shadow (same wave) or beside it (2 waves/SIMD)
 //   (4) software exp() / sqrt() f64 cost
-// Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_f64.hip -o tools/ubench_f64
+// Build: hipcc --offload-arch=gfx950 -O3 tools/probes/ubench_f64.hip -o tools/probes/ubench_f64
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,8 +1,8 @@
 // ubench_mfma16.hip -- issue rate of v_mfma_f64_16x16x4_f64 on gfx950 when it accumulates IN PLACE (inline asm, vDst ==
-// SrcC, accumulators in AGPRs) -- the first probe (tools/ubench_f64.hip, builtin, 137-150 cycles) may have measured the
+// SrcC, accumulators in AGPRs) -- the first probe (tools/probes/ubench_f64.hip, builtin, 137-150 cycles) may have measured the
 // compiler's accumulator copies rather than the instruction.  Variants: N independent accumulators (N = 4, 8, 16), same
 // or distinct A/B registers, 1 or 2 waves per SIMD.
-// build: hipcc -O3 --offload-arch=gfx950 tools/ubench_mfma16.hip -o tools/ubench_mfma16
+// build: hipcc -O3 --offload-arch=gfx950 tools/probes/ubench_mfma16.hip -o tools/probes/ubench_mfma16
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double d4 __attribute__((ext_vector_type(4)));

@@ -4,7 +4,7 @@
 //   V1  v_rsq_f64 + 2 Newton steps, v_readlane broadcast
 //   V2  V1 pivots, broadcast through LDS (one ds_write_b64, uniform-address ds_read_b128)
 //   V3  V1 + the inverse of the factor formed in the same sweep (rows of L^-1 beside rows of L)
-// build: hipcc -O3 --offload-arch=gfx950 tools/ubench_potf2.hip -o tools/ubench_potf2
+// build: hipcc -O3 --offload-arch=gfx950 tools/probes/ubench_potf2.hip -o tools/probes/ubench_potf2
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>

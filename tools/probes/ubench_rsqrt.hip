@@ -1,6 +1,6 @@
 // accuracy of the two 1/sqrt(x) refinements used on the Cholesky pivot chain (kernels_chol.hip), in ulps of the result,
 // against the correctly rounded value computed on the host in long double.
-// build: hipcc -O3 --offload-arch=gfx950 tools/ubench_rsqrt.hip -o tools/ubench_rsqrt
+// build: hipcc -O3 --offload-arch=gfx950 tools/probes/ubench_rsqrt.hip -o tools/probes/ubench_rsqrt
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
