@@ -49,12 +49,16 @@ PMC_FILE = os.path.join("profiles", "c3_pmc.json")
 
 
 def kernel_source_hash():
-    """sha256 of the translation unit that holds the dominant kernel: a committed PMC figure is only quoted for the
-    source it was measured on."""
+    """sha256 of the CODE of the translation unit that holds the dominant kernel (comments and blank lines stripped: a reworded comment does not
+    invalidate a measurement): a committed PMC figure is only quoted for the source it was measured on."""
     import hashlib
+    import re
 
-    with open(os.path.join(ROOT, "bayesian-optimization_amd", "csrc", "kernels_posterior.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    with open(os.path.join(ROOT, "bayesian-optimization_amd", "csrc", "kernels_posterior.hip")) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    code = [re.sub(r"\s+", " ", re.sub(r"//.*$", "", ln)).strip() for ln in src.split("\n")]
+    return hashlib.sha256("\n".join(c for c in code if c).encode()).hexdigest()[:16]
 
 
 def measured_traffic(workload, n_per_launch):
