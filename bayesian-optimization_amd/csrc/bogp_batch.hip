@@ -140,8 +140,11 @@ int ensure_slots(bogp_handle* h, int P, int ld, int d, int N) {
     dfree(h->dbws);
     h->bws_cap = 0;
     h->bws_P = 0;
-    HIPCHK(h, hipMalloc((void**)&h->dbws, need * sizeof(double)));
-    h->bws_cap = need;
+    // (a BO loop grows N by one point per tell(): a quarter of head room keeps the slab for ~60 iterations instead of re-allocating
+    // every time a tile count ticks up)
+    const size_t cap = need + need / 4;
+    HIPCHK(h, hipMalloc((void**)&h->dbws, cap * sizeof(double)));
+    h->bws_cap = cap;
   }
   if (h->bslots_cap < (size_t)P) {
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -52,6 +52,24 @@ def main():
             if d <= 64 and it % 3 == 0:
                 Xp, fp, ne = eng.polish(Xb[: min(B, 16)], [-5.0] * d, [5.0] * d, (2, 0.5), float(y.min()), True, max_evals=12)
                 assert np.all(np.isfinite(fp)) and np.all(Xp >= -5) and np.all(Xp <= 5)
+        if trend == 0 and n_t == 1:  # r04: batched likelihoods of changing batch size, a lock-step MLE, a lazily uploaded sweep
+            P = int(rng.integers(1, 24))
+            pars = np.tile(par, (P, 1)) * 10.0 ** rng.uniform(-0.3, 0.3, size=(P, d + 1))
+            if it % 5 == 0:
+                pars[P // 2, 0] = np.nan  # an invalid slot now and then
+            kb = int(rng.integers(0, 5))
+            l, g, info = eng.nll_batch(kb, 1, pars, 1e-3, est, 0.0, eval_grad=bool(it % 2))
+            assert np.all(np.isfinite(l[info == 0])) and (it % 5 != 0 or info[P // 2] == _lib.ERR_INVALID)
+            if it % 4 == 0:
+                lo_, hi_ = np.r_[np.full(d, -3.0), -5.0], np.r_[np.full(d, 1.0), 0.0]
+                xo, fo, ne, st_, rounds = eng.mle_batch(kb, 1, rng.uniform(lo_, hi_, size=(int(rng.integers(1, 9)), d + 1)), lo_, hi_, 1e-3, est, 0.0,
+                                                        eval_budget=int(rng.integers(20, 200)), prune_reserve=int(rng.integers(0, 2)) * 10)  # fmt: skip
+                assert np.all(xo >= lo_) and np.all(xo <= hi_) and rounds <= ne.sum()
+            eng.commit(3, 1, par, 1e-3, est, beta, trend=trend)
+            Xh = rng.uniform(-5, 5, (int(rng.integers(1, 60000)), d))
+            eng.upload_candidates(Xh, lazy=True)
+            b2, i2 = eng.sweep([(0, 0.0)], float(y[:, 0].min()), True)
+            assert np.isfinite(b2[0]) and 0 <= i2[0] < len(Xh)
         if it == 20:
             base = used_mb()
     mid = used_mb()
