@@ -111,7 +111,7 @@ SlotLayout slot_layout(int ld, int d, int N) {
   L.logpart = o; o += up8(nb + 1);
   L.Winv = o; o += (nb + 1) * 64 * 64;
   L.panels = o; o += 2 * lde * 64;
-  L.xpanel = o; o += (nb + 1) * 64 * 64;
+  L.xpanel = o; o += 2 * (nb + 1) * 64 * 64;  // two solved panels (pair steps)
   L.Rinv = o; o += (size_t)ld * ld;
   L.gamma = o; o += Np;
   L.scal = o; o += 64;

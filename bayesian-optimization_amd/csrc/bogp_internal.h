@@ -246,7 +246,7 @@ struct BatchSlot {
   ElimArgs ea;          // state blocks, block row nb, Yt, Ft, log-determinant parts; ea.info = (int*)(scal + 62)
   double* Winv;         // (nb + 1) x 64 x 64: inverses of the diagonal blocks
   double* panels;       // 2 x (ld + 64) x 64: the two raw panels
-  double* xpanel;       // (nb + 1) x 64 x 64: the solved panel of a split step (k_elim_panel_b -> k_elim_update_b)
+  double* xpanel;       // 2 x (nb + 1) x 64 x 64: the solved panels of split steps, by the parity of k (k_elim_panel_b -> k_elim_update_b / update2_b)
   double* Rinv;         // ld x ld
   double* gamma;        // Np
   double* scal;         // 64: [0..3] the likelihood's scalars, [32..48) the gradient's weights, [62] info

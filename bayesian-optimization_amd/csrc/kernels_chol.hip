@@ -1686,27 +1686,48 @@ __global__ __launch_bounds__(256) void k_elim_panel_b(const BatchSlot* __restric
 #pragma unroll
       for (int t = 0; t < 4; ++t) dst[CB * k + 16 * mi + 4 * t + lk] = x[mi][t];
   }
-  double* __restrict__ Xs = sl.xpanel + (size_t)bi * CB * CB;  // element (row, col) at Xs[row + 64 col]
+  // (two solved panels are kept, by the parity of k: a pair step needs X of steps k and k + 1 at once)
+  double* __restrict__ Xs = sl.xpanel + (size_t)(k & 1) * ((size_t)a.nb + 1) * CB * CB + (size_t)bi * CB * CB;  // element (row, col) at Xs[row + 64 col]
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
     for (int t = 0; t < 4; ++t) Xs[(size_t)(16 * mi + 4 * t + lk) * CB + 16 * w + (lane & 15)] = x[mi][t];
 }
-__global__ __launch_bounds__(256) void k_elim_update_b(const BatchSlot* __restrict__ slots, int k) {
+// xcd != 0: a 1-D grid of G * P workgroups whose linear id L is dealt XCD-locally -- the hardware hands workgroup L to XCD L % 8, so XCD x
+// is given the x-th eighth of the slot-major work list (unit u = slot * G + block): a slot's solved panel (1 MB at N = 2048) is then read by
+// the workgroups of one or two XCDs only and stays in their L2 instead of being fetched by all eight.
+// xcd < 0 (first half of a PAIR step, below): only the nb + 1 blocks of column k + 1 and of row k + 1 -- blockIdx.x = t: block (k + 1, t) for
+// t <= k, the diagonal block for t = k + 1, block (t, k + 1) above -- i.e. exactly the blocks whose state after step k the next raw panel and
+// the next diagonal factor are made of.
+__global__ __launch_bounds__(256) void k_elim_update_b(const BatchSlot* __restrict__ slots, int k, int xcd, int G, int P) {
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
   __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
-  const BatchSlot& sl = slots[blockIdx.y];
+  int slot = (int)blockIdx.y, blk = (int)blockIdx.x;
+  if (xcd < 0) {
+    const int t = (int)blockIdx.x;
+    const int sbi = t <= k + 1 ? k + 1 : t, sbj = t <= k + 1 ? t : k + 1;
+    blk = sbi * (sbi + 1) / 2 + sbj;
+  } else if (xcd) {
+    const long U = (long)G * P, L = (long)blockIdx.x;
+    const long per = (U + 7) / 8;           // units per XCD (the last ones may run short)
+    const long u = (L % 8) * per + L / 8;   // L / 8 < per by the grid size 8 * per
+    if (u >= U) return;
+    slot = (int)(u / G);
+    blk = (int)(u % G);
+  }
+  const BatchSlot& sl = slots[slot];
   const ElimArgs& a = sl.ea;
   int bi, bj;
-  tri_index((int)blockIdx.x, bi, bj);
+  tri_index(blk, bi, bj);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lk = lane >> 4;
   const size_t lde = (size_t)a.ld + CB;
   const bool restart = bi == k || bj == k;
-  stage_aside(lds, sl.xpanel + (size_t)bj * CB * CB, CB, tid);  // A side: tile[kk][c] = X_j(c, kk)
+  const double* __restrict__ xp = sl.xpanel + (size_t)(k & 1) * ((size_t)a.nb + 1) * CB * CB;
+  stage_aside(lds, xp + (size_t)bj * CB * CB, CB, tid);  // A side: tile[kk][c] = X_j(c, kk)
   double bv[16];
-  load_bside(bv, sl.xpanel + (size_t)bi * CB * CB, CB, w, lane);  // B side: X_i(row 16 w + (lane & 15), kk = 4 ks + lk)
+  load_bside(bv, xp + (size_t)bi * CB * CB, CB, w, lane);  // B side: X_i(row 16 w + (lane & 15), kk = 4 ks + lk)
   int ldt;
   double* __restrict__ Tb = elim_tile(a, bi, bj, ldt);
   double acc[4][4];  // negated tile
@@ -1717,6 +1738,70 @@ __global__ __launch_bounds__(256) void k_elim_update_b(const BatchSlot* __restri
   __syncthreads();
   mma_64(lds, bv, acc, lane);  // -T_new = -T_old + X_i X_j^T
   elim_store_block(a, k, bi, bj, acc, Tb, ldt, lds, sb, sl.panels + ((k & 1) ? 0 : lde * CB), sl.Winv + (size_t)(k + 1) * CB * CB);
+}
+
+// ---- PAIR steps: two block columns per pass over the state (r04) -------------------------------------------------------------------
+// A batch that fills the GPU is bound by the read-modify-write of the N x N state, once per 64-column step (~1.1 GB of traffic per
+// evaluation at N = 2048).  Steps k and k + 1 are therefore applied in ONE pass:
+//   k_elim_panel_b(k)                X^k  (as for a split step)
+//   k_elim_update_b(k, sub mode)     step k on the nb + 1 blocks of column / row k + 1 only: they make the raw panel of step k + 1 and its
+//                                    diagonal factor W_{k+1} -- the ordinary block routine, nothing new
+//   k_elim_panel_b(k + 1)            X^{k+1}
+//   k_elim_update2_b(k)              every block once: T <- step k (unless done above) then step k + 1, the intermediate state kept in the
+//                                    accumulators instead of a store + reload -- the same mma_64 calls on the same values in the same order,
+//                                    (-(-x) = x exactly), so the bits of the two separate steps; then what step k + 1 publishes (raw panel and
+//                                    diagonal factor of k + 2).
+__global__ __launch_bounds__(256) void k_elim_update2_b(const BatchSlot* __restrict__ slots, int k, int xcd, int G, int P) {
+  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
+  __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
+  int slot = (int)blockIdx.y, blk = (int)blockIdx.x;
+  if (xcd) {
+    const long U = (long)G * P, L = (long)blockIdx.x;
+    const long per = (U + 7) / 8;
+    const long u = (L % 8) * per + L / 8;
+    if (u >= U) return;
+    slot = (int)(u / G);
+    blk = (int)(u % G);
+  }
+  const BatchSlot& sl = slots[slot];
+  const ElimArgs& a = sl.ea;
+  int bi, bj;
+  tri_index(blk, bi, bj);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lk = lane >> 4;
+  const size_t lde = (size_t)a.ld + CB;
+  const size_t xsz = ((size_t)a.nb + 1) * CB * CB;
+  const double* __restrict__ x0 = sl.xpanel + (size_t)(k & 1) * xsz;        // X of step k
+  const double* __restrict__ x1 = sl.xpanel + (size_t)((k + 1) & 1) * xsz;  // X of step k + 1
+  const int k1 = k + 1;
+  const bool done_k = bi == k1 || bj == k1;  // step k was applied (and stored) by the sub-mode launch; step k + 1 restarts these blocks
+  const bool restart = bi == k || bj == k;
+  int ldt;
+  double* __restrict__ Tb = elim_tile(a, bi, bj, ldt);
+  double bv[16];
+  double acc[4][4];  // negated tile
+  if (!done_k) {
+    stage_aside(lds, x0 + (size_t)bj * CB * CB, CB, tid);
+    load_bside(bv, x0 + (size_t)bi * CB * CB, CB, w, lane);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[mi][t] = restart ? 0.0 : -Tb[(size_t)(16 * mi + 4 * t + lk) * ldt + 16 * w + (lane & 15)];
+    __syncthreads();
+    mma_64(lds, bv, acc, lane);  // step k:  -T' = -T + X^k_i X^k_j^T
+    __syncthreads();             // every wave is done with the X^k_j tile
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[mi][t] = 0.0;
+  }
+  stage_aside(lds, x1 + (size_t)bj * CB * CB, CB, tid);
+  load_bside(bv, x1 + (size_t)bi * CB * CB, CB, w, lane);
+  __syncthreads();
+  mma_64(lds, bv, acc, lane);  // step k + 1:  -T'' = -T' + X^{k+1}_i X^{k+1}_j^T
+  elim_store_block(a, k1, bi, bj, acc, Tb, ldt, lds, sb, sl.panels + ((k1 & 1) ? 0 : lde * CB), sl.Winv + (size_t)(k1 + 1) * CB * CB);
 }
 
 // R^-1 = -T into Rinv (lower triangle, column-major, ldr) and, by the last workgroup, the likelihood's scalars (k_fit_rho's
@@ -1825,10 +1910,22 @@ hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double
   // once it does not: same bits either way.  BOGP_ELIM_SPLIT_BLOCKS: blocks per step from which the split is taken
   static const long split_from = [] { const char* e = getenv("BOGP_ELIM_SPLIT_BLOCKS"); return e ? atol(e) : 600L; }();
   const bool split = (long)grid * P >= split_from;
+  static const bool xcd_local = [] { const char* e = getenv("BOGP_ELIM_XCD"); return !(e && atoi(e) == 0); }();
+  static const bool pairs = [] { const char* e = getenv("BOGP_ELIM_PAIRS"); return !(e && atoi(e) == 0); }();
   for (int k = 0; k < nb; ++k) {
+    if (split && pairs && k + 1 < nb) {  // two block columns per pass over the state
+      const unsigned g1 = xcd_local ? (unsigned)(8 * (((long)grid * P + 7) / 8)) : (unsigned)grid;
+      hipLaunchKernelGGL(k_elim_panel_b, dim3(nb + 1, P), 256, 0, st, slots, k);
+      hipLaunchKernelGGL(k_elim_update_b, dim3(nb + 1, P), 256, 0, st, slots, k, -1, grid, P);
+      hipLaunchKernelGGL(k_elim_panel_b, dim3(nb + 1, P), 256, 0, st, slots, k + 1);
+      hipLaunchKernelGGL(k_elim_update2_b, dim3(g1, xcd_local ? 1 : P), 256, 0, st, slots, k, xcd_local ? 1 : 0, grid, P);
+      ++k;
+      continue;
+    }
     if (split) {
       hipLaunchKernelGGL(k_elim_panel_b, dim3(nb + 1, P), 256, 0, st, slots, k);
-      hipLaunchKernelGGL(k_elim_update_b, dim3(grid, P), 256, 0, st, slots, k);
+      if (xcd_local) hipLaunchKernelGGL(k_elim_update_b, dim3((unsigned)(8 * (((long)grid * P + 7) / 8))), 256, 0, st, slots, k, 1, grid, P);
+      else hipLaunchKernelGGL(k_elim_update_b, dim3(grid, P), 256, 0, st, slots, k, 0, grid, P);
     } else {
       hipLaunchKernelGGL(k_elim_step_b, dim3(grid, P), 256, 0, st, slots, k);
     }
