@@ -44,6 +44,16 @@ _UNBUILT_KERNELS = ("linear",)
 _NU_IDS = {0.5: _lib.KERNEL_MATERN12, 1.5: _lib.KERNEL_MATERN32, 2.5: _lib.KERNEL_MATERN52}
 
 
+_ENV_WARNED = set()
+
+
+def _warn_env_once(name, what):
+    """An environment variable switched a non-default fit schedule on from OUTSIDE the code: say so once per process."""
+    if name not in _ENV_WARNED:
+        _ENV_WARNED.add(name)
+        warnings.warn("bogp: %s is set -- %s" % (name, what), stacklevel=3)
+
+
 def kernel_id_of(corr) -> int:
     """Map the reference's `corr` argument (a name, or a callable such as functools.partial(matern, nu=2.5))."""
     if isinstance(corr, str):
@@ -116,9 +126,15 @@ class GaussianProcess:
         self.distribute_restarts = bool(distribute_restarts)
         # MLE restarts on `restart_streams` engines (= HIP streams) of the SAME GPU at once (opt-in; None: BOGP_RESTART_STREAMS or 1)
         self.restart_streams = int(restart_streams if restart_streams is not None else os.environ.get("BOGP_RESTART_STREAMS", "1"))
+        if restart_streams is None and self.restart_streams > 1:
+            _warn_env_once("BOGP_RESTART_STREAMS", "the MLE restarts run on %d streams: ALL start points are drawn up front from the global np.random "
+                           "stream (the sequential loop draws lazily and stops early), so later draws differ from the reference's trajectory" % self.restart_streams)
         # MLE restarts advanced TOGETHER on the device, `restart_batch` at a time (opt-in; None: BOGP_RESTART_BATCH or 0 = the
         # reference's sequential scipy loop): bogp_mle_batch, one batched likelihood call per round of all active restarts
         self.restart_batch = int(restart_batch if restart_batch is not None else os.environ.get("BOGP_RESTART_BATCH", "0"))
+        if restart_batch is None and self.restart_batch > 0:
+            _warn_env_once("BOGP_RESTART_BATCH", "the MLE restarts run in lock step, %d at a time, on libbogp's own L-BFGS-B (not scipy's): every restart of a wave "
+                           "starts and its start point is drawn, so the fit and the np.random stream differ from the reference's sequential loop" % self.restart_batch)
         # extension, with restart_batch only: hand the optimiser the gradient of the function it minimises (d / d log10 par) instead of
         # the reference's d / d par (which stays the default)
         self.mle_chain_rule = bool(mle_chain_rule)
