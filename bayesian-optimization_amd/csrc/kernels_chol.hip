@@ -92,6 +92,37 @@ __device__ __forceinline__ void mma_64(const double* lds, const double (&bv)[16]
     for (int t = 0; t < 4; ++t) acc[mi][t] = c[mi][t];
 }
 
+// mma_64 for two block rows against ONE staged tile, the accumulators held as MFMA operands throughout (k_elim_updateS_b keeps four tiles
+// live and has no registers to spare for repacking): every A fragment read from LDS feeds both rows' MFMAs (half the LDS reads), the fragments of
+// step ks + 1 are fetched while the eight MFMAs of step ks issue, and the scheduling fences keep the compiler from hoisting all 64
+// fragment reads (128 VGPRs) above the chain.  Per output element the same sixteen accumulations in the same order as mma_64.
+__device__ __forceinline__ void mma_64v2(const double* lds, const double (&bv0)[16], const double (&bv1)[16], d4 (&c0)[4], d4 (&c1)[4], int lane) {
+  const int aoff = (lane >> 4) * CPITCH + (lane & 15);
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]));
+  double an[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) an[mi] = lds[aoff + 16 * mi];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    double ac[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) ac[mi] = an[mi];
+    if (ks + 1 < 16) {
+      const double* trow = &lds[4 * (ks + 1) * CPITCH];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) an[mi] = trow[aoff + 16 * mi];
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      mfma16(ac[mi], bv0[ks], c0[mi]);
+      mfma16(ac[mi], bv1[ks], c1[mi]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+               : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]));
+}
+
 // ---- diagonal block: Cholesky factor and its inverse, blocked by 4 columns -----------------------------------------
 // Thread (tr, tc) = (tid >> 4, tid & 15) owns ONE 4x4 register tile z of the symmetric block (rows 4 tr.., columns
 // 4 tc..; both triangles are kept).  With M = (4x4 diagonal factor)^-1 of block step jb, the block row
@@ -1542,8 +1573,8 @@ __global__ __launch_bounds__(256) void k_elim_first_b(const BatchSlot* __restric
 
 // the updated block back into the state; the blocks of column / row k + 1 into the next raw panel; block (k + 1, k + 1) factored and
 // inverted for the next step.  Shared by the fused step (k_elim_step) and the split one (k_elim_update_b).
-__device__ __forceinline__ void elim_store_block(const ElimArgs& a, int k, int bi, int bj, double (&acc)[4][4], double* __restrict__ Tb, int ldt,
-                                                 double* lds, double* sb, double* __restrict__ Pnext, double* __restrict__ Wn) {
+__device__ __forceinline__ bool elim_store_plain(const ElimArgs& a, int k, int bi, int bj, const double (&acc)[4][4], double* __restrict__ Tb,
+                                                 int ldt, double* __restrict__ Pnext) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lk = lane >> 4;
@@ -1555,7 +1586,7 @@ __device__ __forceinline__ void elim_store_block(const ElimArgs& a, int k, int b
 #pragma unroll
     for (int t = 0; t < 4; ++t) Tb[(size_t)(16 * mi + 4 * t + lk) * ldt + 16 * w + (lane & 15)] = -acc[mi][t];
   const int kn = k + 1;
-  if (kn >= a.nb) return;
+  if (kn >= a.nb) return false;
   if (bj == kn && bi > kn) {  // column kn, as it is
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -1566,15 +1597,27 @@ __device__ __forceinline__ void elim_store_block(const ElimArgs& a, int k, int b
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int t = 0; t < 4; ++t) Pnext[(size_t)(16 * w + (lane & 15)) * lde + j0 + 16 * mi + 4 * t + lk] = -acc[mi][t];
-  } else if (bi == kn && bj == kn) {  // the next diagonal block: factor + invert it here
-    __syncthreads();
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) lds[(16 * w + (lane & 15)) * (CB + 1) + 16 * mi + 4 * t + lk] = -acc[mi][t];
-    __syncthreads();
-    elim_diag2(lds, sb, Wn, a.logpart + kn, a.info, CB * kn, 0, max(0, min(CB, a.N - CB * kn)), Pnext, lde, kn, tid);
   }
+  return bi == kn && bj == kn;  // the next diagonal block: the caller stages and factors it (elim_stage_diag, elim_diag2)
+}
+// the next diagonal block out of the accumulators into the 64 x 65 staging elim_diag2 reads
+__device__ __forceinline__ void elim_stage_diag(const double (&acc)[4][4], double* lds) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lk = lane >> 4;
+  __syncthreads();  // every wave is done with what the tile held
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) lds[(16 * w + (lane & 15)) * (CB + 1) + 16 * mi + 4 * t + lk] = -acc[mi][t];
+  __syncthreads();
+}
+__device__ __forceinline__ void elim_store_block(const ElimArgs& a, int k, int bi, int bj, double (&acc)[4][4], double* __restrict__ Tb, int ldt,
+                                                 double* lds, double* sb, double* __restrict__ Pnext, double* __restrict__ Wn) {
+  if (!elim_store_plain(a, k, bi, bj, acc, Tb, ldt, Pnext)) return;
+  const int kn = k + 1;
+  elim_stage_diag(acc, lds);
+  elim_diag2(lds, sb, Wn, a.logpart + kn, a.info, CB * kn, 0, max(0, min(CB, a.N - CB * kn)), Pnext, a.ld + CB, kn, threadIdx.x);
 }
 
 __device__ __forceinline__ void elim_step_block(const ElimArgs& a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
@@ -1686,8 +1729,9 @@ __global__ __launch_bounds__(256) void k_elim_panel_b(const BatchSlot* __restric
 #pragma unroll
       for (int t = 0; t < 4; ++t) dst[CB * k + 16 * mi + 4 * t + lk] = x[mi][t];
   }
-  // (two solved panels are kept, by the parity of k: a pair step needs X of steps k and k + 1 at once)
-  double* __restrict__ Xs = sl.xpanel + (size_t)(k & 1) * ((size_t)a.nb + 1) * CB * CB + (size_t)bi * CB * CB;  // element (row, col) at Xs[row + 64 col]
+  // (eight solved panels are kept, by k mod 8: a grouped step needs X of up to four consecutive steps at once, and with look-ahead the next
+  // group's are written while this group's are still being read)
+  double* __restrict__ Xs = sl.xpanel + (size_t)(k & 7) * ((size_t)a.nb + 1) * CB * CB + (size_t)bi * CB * CB;  // element (row, col) at Xs[row + 64 col]
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -1696,16 +1740,19 @@ __global__ __launch_bounds__(256) void k_elim_panel_b(const BatchSlot* __restric
 // xcd != 0: a 1-D grid of G * P workgroups whose linear id L is dealt XCD-locally -- the hardware hands workgroup L to XCD L % 8, so XCD x
 // is given the x-th eighth of the slot-major work list (unit u = slot * G + block): a slot's solved panel (1 MB at N = 2048) is then read by
 // the workgroups of one or two XCDs only and stays in their L2 instead of being fetched by all eight.
-// xcd < 0 (first half of a PAIR step, below): only the nb + 1 blocks of column k + 1 and of row k + 1 -- blockIdx.x = t: block (k + 1, t) for
-// t <= k, the diagonal block for t = k + 1, block (t, k + 1) above -- i.e. exactly the blocks whose state after step k the next raw panel and
-// the next diagonal factor are made of.
+// xcd < 0 (inside a GROUPED step, below): only the blocks of the -xcd columns / rows c = G, G + 1, ... -- for column / row c the nb + 1 blocks
+// (c, t) for t <= c and (t, c) above -- i.e. the blocks whose state after step k the raw panels and diagonal factors of the group's later steps
+// are made of.
 __global__ __launch_bounds__(256) void k_elim_update_b(const BatchSlot* __restrict__ slots, int k, int xcd, int G, int P) {
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
   __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
   int slot = (int)blockIdx.y, blk = (int)blockIdx.x;
-  if (xcd < 0) {
-    const int t = (int)blockIdx.x;
-    const int sbi = t <= k + 1 ? k + 1 : t, sbj = t <= k + 1 ? t : k + 1;
+  if (xcd < 0) {  // sub mode: -xcd columns / rows starting at c0 = G, blockIdx.x = ci (nb + 1) + t
+    const int nb1 = slots[slot].ea.nb + 1;
+    const int ci = (int)blockIdx.x / nb1, t = (int)blockIdx.x % nb1;
+    const int c0 = G, c = c0 + ci;
+    if (t >= c0 && t < c) return;  // block (c, t) already belongs to the earlier column / row t of this launch
+    const int sbi = t <= c ? c : t, sbj = t <= c ? t : c;
     blk = sbi * (sbi + 1) / 2 + sbj;
   } else if (xcd) {
     const long U = (long)G * P, L = (long)blockIdx.x;
@@ -1724,7 +1771,7 @@ __global__ __launch_bounds__(256) void k_elim_update_b(const BatchSlot* __restri
   const int lk = lane >> 4;
   const size_t lde = (size_t)a.ld + CB;
   const bool restart = bi == k || bj == k;
-  const double* __restrict__ xp = sl.xpanel + (size_t)(k & 1) * ((size_t)a.nb + 1) * CB * CB;
+  const double* __restrict__ xp = sl.xpanel + (size_t)(k & 7) * ((size_t)a.nb + 1) * CB * CB;
   stage_aside(lds, xp + (size_t)bj * CB * CB, CB, tid);  // A side: tile[kk][c] = X_j(c, kk)
   double bv[16];
   load_bside(bv, xp + (size_t)bi * CB * CB, CB, w, lane);  // B side: X_i(row 16 w + (lane & 15), kk = 4 ks + lk)
@@ -1740,18 +1787,54 @@ __global__ __launch_bounds__(256) void k_elim_update_b(const BatchSlot* __restri
   elim_store_block(a, k, bi, bj, acc, Tb, ldt, lds, sb, sl.panels + ((k & 1) ? 0 : lde * CB), sl.Winv + (size_t)(k + 1) * CB * CB);
 }
 
-// ---- PAIR steps: two block columns per pass over the state (r04) -------------------------------------------------------------------
+// ---- GROUPED steps: two or four block columns per pass over the state (r04) ----------------------------------------------------------
 // A batch that fills the GPU is bound by the read-modify-write of the N x N state, once per 64-column step (~1.1 GB of traffic per
 // evaluation at N = 2048).  Steps k and k + 1 are therefore applied in ONE pass:
 //   k_elim_panel_b(k)                X^k  (as for a split step)
 //   k_elim_update_b(k, sub mode)     step k on the nb + 1 blocks of column / row k + 1 only: they make the raw panel of step k + 1 and its
 //                                    diagonal factor W_{k+1} -- the ordinary block routine, nothing new
 //   k_elim_panel_b(k + 1)            X^{k+1}
-//   k_elim_update2_b(k)              every block once: T <- step k (unless done above) then step k + 1, the intermediate state kept in the
+//   k_elim_updateG_b(k, 2)           every block once: T <- step k (unless done above) then step k + 1, the intermediate state kept in the
 //                                    accumulators instead of a store + reload -- the same mma_64 calls on the same values in the same order,
 //                                    (-(-x) = x exactly), so the bits of the two separate steps; then what step k + 1 publishes (raw panel and
 //                                    diagonal factor of k + 2).
-__global__ __launch_bounds__(256) void k_elim_update2_b(const BatchSlot* __restrict__ slots, int k, int xcd, int G, int P) {
+// With ng = 4 the same, one level deeper: after panel(k + g) the sub-mode launch applies step k + g to the blocks of the columns / rows
+// k + g + 1 .. k + 3 (each block once: a block lying in two of them is taken by the earlier one), and k_elim_updateG_b(k, 4) applies to every
+// block the steps from its last restart inside the group (or from k) to k + 3.
+__device__ __forceinline__ void elim_group_block(const BatchSlot& sl, int k, int ng, int bi, int bj, double* lds, double* sb) {
+  const ElimArgs& a = sl.ea;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lk = lane >> 4;
+  const size_t lde = (size_t)a.ld + CB;
+  const size_t xsz = ((size_t)a.nb + 1) * CB * CB;
+  const int klast = k + ng - 1;
+  // the LAST step of the group that restarts this block (its row or column index); the sub-mode launches have carried the blocks of
+  // columns / rows k + 1 .. klast up to their restart, which zeroes them anyway: what such a block still needs are the steps from there on
+  int first = -1;
+  if (bi >= k && bi <= klast) first = bi;
+  if (bj >= k && bj <= klast) first = max(first, bj);
+  const bool restart = first >= 0;
+  if (!restart) first = k;
+  int ldt;
+  double* __restrict__ Tb = elim_tile(a, bi, bj, ldt);
+  double bv[16];
+  double acc[4][4];  // negated tile
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[mi][t] = restart ? 0.0 : -Tb[(size_t)(16 * mi + 4 * t + lk) * ldt + 16 * w + (lane & 15)];
+  for (int sidx = first; sidx <= klast; ++sidx) {
+    const double* __restrict__ xs = sl.xpanel + (size_t)(sidx & 7) * xsz;
+    if (sidx > first) __syncthreads();  // every wave is done with the previous step's X_j tile
+    stage_aside(lds, xs + (size_t)bj * CB * CB, CB, tid);
+    load_bside(bv, xs + (size_t)bi * CB * CB, CB, w, lane);
+    __syncthreads();
+    mma_64(lds, bv, acc, lane);  // step sidx:  -T <- -T + X_i X_j^T, the intermediate state never leaves the accumulators
+  }
+  elim_store_block(a, klast, bi, bj, acc, Tb, ldt, lds, sb, sl.panels + ((klast & 1) ? 0 : lde * CB), sl.Winv + (size_t)(klast + 1) * CB * CB);
+}
+__global__ __launch_bounds__(256) void k_elim_updateG_b(const BatchSlot* __restrict__ slots, int k, int ng, int xcd, int G, int P) {
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
   __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
   int slot = (int)blockIdx.y, blk = (int)blockIdx.x;
@@ -1763,45 +1846,199 @@ __global__ __launch_bounds__(256) void k_elim_update2_b(const BatchSlot* __restr
     slot = (int)(u / G);
     blk = (int)(u % G);
   }
-  const BatchSlot& sl = slots[slot];
-  const ElimArgs& a = sl.ea;
   int bi, bj;
   tri_index(blk, bi, bj);
+  elim_group_block(slots[slot], k, ng, bi, bj, lds, sb);
+}
+
+// LOOK-AHEAD: the blocks of the NEXT group's columns / rows c0 .. c0 + ncol - 1 (sub-mode indexing of k_elim_update_b) taken through this
+// group's steps first -- with the next raw panel and diagonal factor they publish, the next group's panel chain can start on a second stream
+// while k_elim_updateS_b (which then skips these blocks) takes the rest of the state through the same steps.
+__global__ __launch_bounds__(256) void k_elim_updateGsub_b(const BatchSlot* __restrict__ slots, int k, int ng, int c0) {
+  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
+  __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
+  const BatchSlot& sl = slots[blockIdx.y];
+  const int nb1 = sl.ea.nb + 1;
+  const int ci = (int)blockIdx.x / nb1, t = (int)blockIdx.x % nb1;
+  const int c = c0 + ci;
+  if (t >= c0 && t < c) return;  // block (c, t) already belongs to the earlier column / row t of this launch
+  elim_group_block(sl, k, ng, t <= c ? c : t, t <= c ? t : c, lds, sb);
+}
+
+// ---- the grouped update on 128 x 128 SUPER-TILES (r04) --------------------------------------------------------------------------------
+// k_elim_updateG_b fetches two 32-KB solved tiles per 64^3 product: with P matrices in flight the solved panels of a slot (4 MB at
+// N = 2048) do not stay in an XCD's 4-MB L2 next to the streaming state, and the kernel sits at ~47 % of the matrix peak on those
+// fetches (profiles/r04_nll_batch_group.txt).  Here a workgroup owns the 2 x 2 blocks (2 BI + a, 2 BJ + b): per step it stages the TWO
+// A-side tiles X_{2BJ}, X_{2BJ+1} and loads the TWO B-side fragments X_{2BI}, X_{2BI+1} for FOUR products -- half the fetches per
+// flop.  Every block still sees exactly the mma_64 calls of k_elim_updateG_b on the same operands in the same order (its own
+// first step .. klast), then elim_store_block: the same bits.  Blocks above the diagonal or outside the nb + 1 block rows / nb block
+// columns are skipped (workgroup-uniform).
+// (buffer accesses: a uniform descriptor, ONE 32-bit lane offset and a scalar offset per access.  The slot's pointers come out of memory,
+// i.e. generic, and a generic / global access costs a 64-bit address pair per load that the compiler keeps live across the step loop --
+// ~100 VGPRs in this kernel, which has none to spare)
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const double* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ double buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff_doubles, unsigned soff_doubles) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, 8 * voff_doubles, 8 * soff_doubles, 0));
+}
+__device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t r, unsigned voff_doubles, unsigned soff_doubles) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, 8 * voff_doubles, 8 * soff_doubles, 0);
+}
+__device__ __forceinline__ void stage_aside_b(double* lds, __amdgpu_buffer_rsrc_t r, int tid) {  // stage_aside for a 64 x 64 tile, lda = 64
+  const unsigned srow = tid >> 5, scol = (tid & 31) * 2;
+  const unsigned voff = 8 * (srow * CB + scol);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 8 * (p * 8 * CB), 0);
+    *reinterpret_cast<v4u*>(&lds[(srow + 8 * p) * CPITCH + scol]) = v;
+  }
+}
+__device__ __forceinline__ void load_bside_b(double (&bv)[16], __amdgpu_buffer_rsrc_t r, int w, int lane) {  // load_bside, ldb = 64
+  const unsigned voff = (unsigned)(lane >> 4) * CB + 16 * w + (lane & 15);
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) bv[ks] = buf_load(r, voff, ks * 4 * CB);
+}
+__global__ __launch_bounds__(256, 2) void k_elim_updateS_b(const BatchSlot* __restrict__ slots, int k, int ng, int xcd, int G, int P, int x0, int nx) {
+  __shared__ __attribute__((aligned(16))) double lds[2][CB * CPITCH];
+  int slot = (int)blockIdx.y, blk = (int)blockIdx.x;
+  if (xcd) {
+    const long U = (long)G * P, L = (long)blockIdx.x;
+    const long per = (U + 7) / 8;
+    const long u = (L % 8) * per + L / 8;
+    if (u >= U) return;
+    slot = (int)(u / G);
+    blk = (int)(u % G);
+  }
+  slot = __builtin_amdgcn_readfirstlane(slot);
+  const BatchSlot& sl = slots[slot];
+  const ElimArgs& a = sl.ea;
+  int BI, BJ;
+  tri_index(blk, BI, BJ);
+  BI = __builtin_amdgcn_readfirstlane(BI);  // (tri_index goes through the vector ALU: tell the compiler the result is uniform, or every
+  BJ = __builtin_amdgcn_readfirstlane(BJ);  //  buffer descriptor below gets a waterfall loop)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lk = lane >> 4;
-  const size_t lde = (size_t)a.ld + CB;
+  const unsigned lde = (unsigned)a.ld + CB;
   const size_t xsz = ((size_t)a.nb + 1) * CB * CB;
-  const double* __restrict__ x0 = sl.xpanel + (size_t)(k & 1) * xsz;        // X of step k
-  const double* __restrict__ x1 = sl.xpanel + (size_t)((k + 1) & 1) * xsz;  // X of step k + 1
-  const int k1 = k + 1;
-  const bool done_k = bi == k1 || bj == k1;  // step k was applied (and stored) by the sub-mode launch; step k + 1 restarts these blocks
-  const bool restart = bi == k || bj == k;
-  int ldt;
-  double* __restrict__ Tb = elim_tile(a, bi, bj, ldt);
-  double bv[16];
-  double acc[4][4];  // negated tile
-  if (!done_k) {
-    stage_aside(lds, x0 + (size_t)bj * CB * CB, CB, tid);
-    load_bside(bv, x0 + (size_t)bi * CB * CB, CB, w, lane);
+  const int klast = k + ng - 1;
+  // per block: is it there, and the first step of the group it still needs (k_elim_updateG_b's rule).  The step loop itself has NO per-block
+  // control flow -- all four products every step: a block that restarts at step f > k is simply zeroed when the loop gets there (what it
+  // gathered before is discarded, as are the blocks above the diagonal / past the edge), so that the four accumulator tiles live in fixed
+  // registers.  (With a branch per block the compiler keeps copies of the tiles across the variants and spills.)
+  bool valid[2][2];
+  int first[2][2];
+  bool any = false;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+  for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[mi][t] = restart ? 0.0 : -Tb[(size_t)(16 * mi + 4 * t + lk) * ldt + 16 * w + (lane & 15)];
+    for (int ib = 0; ib < 2; ++ib) {
+      const int bi = 2 * BI + ia, bj = 2 * BJ + ib;
+      valid[ia][ib] = bi <= a.nb && bj < a.nb && bj <= bi && !(bi >= x0 && bi < x0 + nx) && !(bj >= x0 && bj < x0 + nx);  // [x0, x0 + nx): look-ahead's
+      int f = -1;
+      if (bi >= k && bi <= klast) f = bi;
+      if (bj >= k && bj <= klast) f = max(f, bj);
+      first[ia][ib] = f;  // -1: no restart inside the group, the block comes from the state
+      any = any || valid[ia][ib];
+    }
+  if (!any) return;  // nothing of this super-tile is there
+  d4 acc[2][2][4];  // negated tiles, as MFMA accumulators: [mi] component t
+#pragma unroll
+  for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      if (valid[ia][ib] && first[ia][ib] < 0) {
+        int ldt;
+        const __amdgpu_buffer_rsrc_t Tb = tile_rsrc(elim_tile(a, 2 * BI + ia, 2 * BJ + ib, ldt));
+        const unsigned voff = (unsigned)lk * ldt + 16 * w + (lane & 15);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[ia][ib][mi][t] = -buf_load(Tb, voff, (unsigned)(16 * mi + 4 * t) * ldt);
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ia][ib][mi] = (d4){0.0, 0.0, 0.0, 0.0};
+      }
+    }
+  const int tj1 = 2 * BJ + (2 * BJ + 1 <= a.nb ? 1 : 0), ti1 = 2 * BI + (2 * BI + 1 <= a.nb ? 1 : 0);  // (past the edge: the tile before, discarded)
+  for (int sidx = k; sidx <= klast; ++sidx) {
+    const double* xs = sl.xpanel + (size_t)(sidx & 7) * xsz;
+    double bv0[16], bv1[16];
+    if (sidx > k) __syncthreads();  // every wave is done with the previous step's tiles
+    stage_aside_b(lds[0], tile_rsrc(xs + (size_t)(2 * BJ) * CB * CB), tid);
+    stage_aside_b(lds[1], tile_rsrc(xs + (size_t)tj1 * CB * CB), tid);
+    __builtin_amdgcn_sched_barrier(0);  // the staging registers are dead before the B-side fragments go live: 2 workgroups a CU (<= 256 VGPRs)
+    load_bside_b(bv0, tile_rsrc(xs + (size_t)(2 * BI) * CB * CB), w, lane);
+    load_bside_b(bv1, tile_rsrc(xs + (size_t)ti1 * CB * CB), w, lane);
+#pragma unroll
+    for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+        if (sidx == first[ia][ib]) {  // the restart: T <- 0 - X_i X_j^T from this step on
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) acc[ia][ib][mi] = (d4){0.0, 0.0, 0.0, 0.0};
+        }
     __syncthreads();
-    mma_64(lds, bv, acc, lane);  // step k:  -T' = -T + X^k_i X^k_j^T
-    __syncthreads();             // every wave is done with the X^k_j tile
-  } else {
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[mi][t] = 0.0;
+    // step sidx:  -T <- -T + X_i X_j^T
+    mma_64v2(lds[0], bv0, bv1, acc[0][0], acc[1][0], lane);
+    mma_64v2(lds[1], bv0, bv1, acc[0][1], acc[1][1], lane);
   }
-  stage_aside(lds, x1 + (size_t)bj * CB * CB, CB, tid);
-  load_bside(bv, x1 + (size_t)bi * CB * CB, CB, w, lane);
+  // elim_store_block's stores: the block back into the state; column kn as it is / row kn transposed into the next raw panel (the next
+  // diagonal block is factored by k_elim_diag_b)
+  const __amdgpu_buffer_rsrc_t Pnext = tile_rsrc(sl.panels + ((klast & 1) ? 0 : (size_t)lde * CB));
+  const int kn = klast + 1;
+#pragma unroll
+  for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      if (!valid[ia][ib]) continue;
+      const int bi = 2 * BI + ia, bj = 2 * BJ + ib;
+      int ldt;
+      const __amdgpu_buffer_rsrc_t Tb = tile_rsrc(elim_tile(a, bi, bj, ldt));
+      const unsigned voff = (unsigned)lk * ldt + 16 * w + (lane & 15);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) buf_store(-acc[ia][ib][mi][t], Tb, voff, (unsigned)(16 * mi + 4 * t) * ldt);
+      if (kn >= a.nb) continue;
+      if (bj == kn && bi > kn) {
+        const unsigned vo = (unsigned)lk * lde + 16 * w + (lane & 15);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) buf_store(-acc[ia][ib][mi][t], Pnext, vo, (unsigned)(16 * mi + 4 * t) * lde + (unsigned)(CB * bi));
+      } else if (bi == kn && bj < kn) {
+        const unsigned vo = (unsigned)(16 * w + (lane & 15)) * lde + lk;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) buf_store(-acc[ia][ib][mi][t], Pnext, vo, (unsigned)(CB * bj + 16 * mi + 4 * t));
+      }
+    }
+}
+
+// the next diagonal block after a super-tile update: factored and inverted from the state by a workgroup of its own launch (inlined
+// into k_elim_updateS_b, the factorisation takes that kernel's allocation past 256 VGPRs: one workgroup a CU instead of two).  The tile
+// read back is the value elim_store_block stages from the accumulators, so W, log-determinant part and info are the same bits.
+__global__ __launch_bounds__(256) void k_elim_diag_b(const BatchSlot* __restrict__ slots, int kn) {
+  __shared__ __attribute__((aligned(16))) double cs[CB * (CB + 1)];
+  __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
+  const BatchSlot& sl = slots[blockIdx.x];
+  const ElimArgs& a = sl.ea;
+  const int tid = threadIdx.x;
+  const size_t lde = (size_t)a.ld + CB;
+  int ldt;
+  const double* __restrict__ T = elim_tile(a, kn, kn, ldt);
+  for (int e = tid; e < CB * CB; e += 256) {
+    const int r = e & 63, c = e >> 6;
+    cs[r * (CB + 1) + c] = T[(size_t)c * ldt + r];
+  }
   __syncthreads();
-  mma_64(lds, bv, acc, lane);  // step k + 1:  -T'' = -T' + X^{k+1}_i X^{k+1}_j^T
-  elim_store_block(a, k1, bi, bj, acc, Tb, ldt, lds, sb, sl.panels + ((k1 & 1) ? 0 : lde * CB), sl.Winv + (size_t)(k1 + 1) * CB * CB);
+  elim_diag2(cs, sb, sl.Winv + (size_t)kn * CB * CB, a.logpart + kn, a.info, CB * kn, 0, max(0, min(CB, a.N - CB * kn)),
+             sl.panels + ((kn & 1) ? lde * CB : 0), (int)lde, kn, tid);
 }
 
 // R^-1 = -T into Rinv (lower triangle, column-major, ldr) and, by the last workgroup, the likelihood's scalars (k_fit_rho's
@@ -1901,7 +2138,8 @@ __global__ void k_elim_init(const ElimArgs a, const double* __restrict__ y) { el
 __global__ void k_elim_init_b(const BatchSlot* __restrict__ slots, const double* __restrict__ y) { elim_init_column(slots[blockIdx.y].ea, y); }
 
 // the elimination of P matrices at once (bogp_nll_batch): the launches of launch_elim with a second grid dimension over the slots
-hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double* y, int estimate_trend, int mode, double beta, hipStream_t st) {
+hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double* y, int estimate_trend, int mode, double beta, hipStream_t st,
+                             hipStream_t st_la, hipEvent_t* ev_la) {
   const int nb = ld / CB;
   hipLaunchKernelGGL(k_elim_init_b, dim3(ld, P), 64, 0, st, slots, y);
   hipLaunchKernelGGL(k_elim_first_b, dim3(nb + 1, P), 256, 0, st, slots);
@@ -1911,15 +2149,66 @@ hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double
   static const long split_from = [] { const char* e = getenv("BOGP_ELIM_SPLIT_BLOCKS"); return e ? atol(e) : 600L; }();
   const bool split = (long)grid * P >= split_from;
   static const bool xcd_local = [] { const char* e = getenv("BOGP_ELIM_XCD"); return !(e && atoi(e) == 0); }();
-  static const bool pairs = [] { const char* e = getenv("BOGP_ELIM_PAIRS"); return !(e && atoi(e) == 0); }();
+  static const int group = [] {  // block columns per pass over the state: 4 (default), 2 (pair steps), 1; BOGP_ELIM_PAIRS=0 is the old name of 1
+    const char* e = getenv("BOGP_ELIM_GROUP");
+    const char* p2 = getenv("BOGP_ELIM_PAIRS");
+    if (p2 && atoi(p2) == 0) return 1;
+    const int g = e ? atoi(e) : 4;
+    return g >= 4 ? 4 : (g >= 2 ? 2 : 1);
+  }();
+  // the whole-state update of a grouped step on 128 x 128 super-tiles (k_elim_updateS_b)
+  // -- from BOGP_ELIM_SUPER super-tile workgroups a launch (default 1500: N = 2048 from P = 10; below that the 64 x 64 kernel's finer grain
+  // fills the GPU better; 0 = never); the next group's panel chain on the look-ahead stream beside the update only with BOGP_ELIM_LOOKAHEAD=1
+  // (measured slower: EXPERIMENTS.md)
+  static const long super_from = [] { const char* e = getenv("BOGP_ELIM_SUPER"); return e ? atol(e) : 1500L; }();
+  static const bool lookahead = [] { const char* e = getenv("BOGP_ELIM_LOOKAHEAD"); return e && atoi(e) != 0; }();
+  const int SR = (nb + 2) / 2, sgrid = SR * (SR + 1) / 2;
+  const bool super_tiles = super_from > 0 && (long)sgrid * P >= super_from;
+  const unsigned gs = xcd_local ? (unsigned)(8 * (((long)sgrid * P + 7) / 8)) : (unsigned)sgrid;
+  // the panel chain of the group k .. k + ng - 1: X^(k+g), then step k + g on the blocks of the columns / rows k + g + 1 .. k + ng - 1
+  auto chain = [&](int k, int ng, hipStream_t s) {
+    for (int g = 0; g < ng; ++g) {
+      hipLaunchKernelGGL(k_elim_panel_b, dim3(nb + 1, P), 256, 0, s, slots, k + g);
+      if (g + 1 < ng) hipLaunchKernelGGL(k_elim_update_b, dim3((unsigned)((ng - 1 - g) * (nb + 1)), P), 256, 0, s, slots, k + g, -(ng - 1 - g), k + g + 1, P);
+    }
+  };
+  if (split && super_tiles && lookahead && group > 1 && st_la && ev_la) {
+    // look-ahead (bit-identical: the same block routines on the same values, only on two streams):
+    //   st_la:  chain(g)                                   chain(g + 1)                       ...
+    //   st:              Gsub(g) [next group's blocks]  S(g) [the rest of the state]   Gsub(g + 1)  S(g + 1)
+    // Gsub(g) waits for chain(g); chain(g + 1) waits for Gsub(g); S(g) reads the solved panels k .. k + 3 (buffers k mod 8) while chain(g + 1)
+    // writes k + 4 .. k + 7, and touches no block of the next group's columns / rows, which the chain's sub-mode launches update.
+    hipError_t e;
+    if ((e = hipEventRecord(ev_la[1], st)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(st_la, ev_la[1], 0)) != hipSuccess) return e;
+    for (int k = 0; k < nb;) {
+      const int ng = min(group, nb - k), k2 = k + ng, ng2 = min(group, nb - k2);
+      chain(k, ng, st_la);
+      if ((e = hipEventRecord(ev_la[0], st_la)) != hipSuccess) return e;
+      if ((e = hipStreamWaitEvent(st, ev_la[0], 0)) != hipSuccess) return e;
+      if (ng2 > 0) {
+        hipLaunchKernelGGL(k_elim_updateGsub_b, dim3((unsigned)(ng2 * (nb + 1)), P), 256, 0, st, slots, k, ng, k2);
+        if ((e = hipEventRecord(ev_la[1], st)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(st_la, ev_la[1], 0)) != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL(k_elim_updateS_b, dim3(gs, xcd_local ? 1 : P), 256, 0, st, slots, k, ng, xcd_local ? 1 : 0, sgrid, P, k2, max(ng2, 0));
+      k = k2;
+    }
+    hipLaunchKernelGGL(k_elim_finish_b, dim3(nb * (nb + 1) / 2 + 1, P), 256, 0, st, slots, estimate_trend, mode, beta);
+    return hipGetLastError();
+  }
   for (int k = 0; k < nb; ++k) {
-    if (split && pairs && k + 1 < nb) {  // two block columns per pass over the state
+    const int ng = !split ? 1 : (group >= 4 && k + 3 < nb ? 4 : (group >= 2 && k + 1 < nb ? 2 : 1));
+    if (ng > 1) {
       const unsigned g1 = xcd_local ? (unsigned)(8 * (((long)grid * P + 7) / 8)) : (unsigned)grid;
-      hipLaunchKernelGGL(k_elim_panel_b, dim3(nb + 1, P), 256, 0, st, slots, k);
-      hipLaunchKernelGGL(k_elim_update_b, dim3(nb + 1, P), 256, 0, st, slots, k, -1, grid, P);
-      hipLaunchKernelGGL(k_elim_panel_b, dim3(nb + 1, P), 256, 0, st, slots, k + 1);
-      hipLaunchKernelGGL(k_elim_update2_b, dim3(g1, xcd_local ? 1 : P), 256, 0, st, slots, k, xcd_local ? 1 : 0, grid, P);
-      ++k;
+      chain(k, ng, st);
+      if (super_tiles) {
+        hipLaunchKernelGGL(k_elim_updateS_b, dim3(gs, xcd_local ? 1 : P), 256, 0, st, slots, k, ng, xcd_local ? 1 : 0, sgrid, P, 0, 0);
+        if (k + ng < nb) hipLaunchKernelGGL(k_elim_diag_b, dim3(P), 256, 0, st, slots, k + ng);
+      } else {
+        hipLaunchKernelGGL(k_elim_updateG_b, dim3(g1, xcd_local ? 1 : P), 256, 0, st, slots, k, ng, xcd_local ? 1 : 0, grid, P);
+      }
+      k += ng - 1;
       continue;
     }
     if (split) {

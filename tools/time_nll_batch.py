@@ -30,7 +30,8 @@ def main(sizes):
         t_seq = (time.perf_counter() - t0) / reps
         line = "N = %4d, d = %d (path %d): sequential %7.1f us / evaluation (%6.0f /s)" % (N, d, _lib.load().bogp_nll_path(N, d, 0, 1), 1e6 * t_seq, 1 / t_seq)
         print(line)
-        for P in (1, 2, 4, 8, 10, 16, 32, 64):
+        only = [int(v) for v in os.environ.get("BOGP_TIME_P", "").split(",") if v]  # e.g. BOGP_TIME_P=16 under rocprofv3
+        for P in only or (1, 2, 4, 8, 10, 16, 32, 64):
             if N > 1024 and P > 16:
                 continue
             pars = np.tile(base, (P, 1)) * 10.0 ** rng.uniform(-0.3, 0.3, size=(P, d + 1))
