@@ -1702,11 +1702,9 @@ __global__ __launch_bounds__(256) void k_elim_step_b(const BatchSlot* __restrict
 // formed ONCE (k_elim_panel_b: the same mma_64 on the same operands, stored as plain 64 x 64 tiles) and the update reads them back
 // in the layouts the fused kernel built in registers / LDS (k_elim_update_b: stage_aside / load_bside on the stored tiles): one
 // product a block and step, bit-identical results.
-__global__ __launch_bounds__(256) void k_elim_panel_b(const BatchSlot* __restrict__ slots, int k) {
-  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
-  const BatchSlot& sl = slots[blockIdx.y];
+// the solved panel block of block row bi at step k: X = M W_k^T from the raw panel, into the slot's solved panel k mod 8
+__device__ __forceinline__ void elim_panel_row(const BatchSlot& sl, int k, int bi, double* lds) {
   const ElimArgs& a = sl.ea;
-  const int bi = blockIdx.x;  // block row 0 .. nb
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lk = lane >> 4;
@@ -1737,6 +1735,33 @@ __global__ __launch_bounds__(256) void k_elim_panel_b(const BatchSlot* __restric
 #pragma unroll
     for (int t = 0; t < 4; ++t) Xs[(size_t)(16 * mi + 4 * t + lk) * CB + 16 * w + (lane & 15)] = x[mi][t];
 }
+__global__ __launch_bounds__(256) void k_elim_panel_b(const BatchSlot* __restrict__ slots, int k) {
+  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
+  elim_panel_row(slots[blockIdx.y], k, (int)blockIdx.x, lds);
+}
+// step k on ONE block from the stored solved panel: T <- (restart ? 0 : T) - X_i X_j^T, then elim_store_block
+__device__ __forceinline__ void elim_update_one(const BatchSlot& sl, int k, int bi, int bj, double* lds, double* sb) {
+  const ElimArgs& a = sl.ea;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lk = lane >> 4;
+  const size_t lde = (size_t)a.ld + CB;
+  const bool restart = bi == k || bj == k;
+  const double* __restrict__ xp = sl.xpanel + (size_t)(k & 7) * ((size_t)a.nb + 1) * CB * CB;
+  stage_aside(lds, xp + (size_t)bj * CB * CB, CB, tid);  // A side: tile[kk][c] = X_j(c, kk)
+  double bv[16];
+  load_bside(bv, xp + (size_t)bi * CB * CB, CB, w, lane);  // B side: X_i(row 16 w + (lane & 15), kk = 4 ks + lk)
+  int ldt;
+  double* __restrict__ Tb = elim_tile(a, bi, bj, ldt);
+  double acc[4][4];  // negated tile
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[mi][t] = restart ? 0.0 : -Tb[(size_t)(16 * mi + 4 * t + lk) * ldt + 16 * w + (lane & 15)];
+  __syncthreads();
+  mma_64(lds, bv, acc, lane);  // -T_new = -T_old + X_i X_j^T
+  elim_store_block(a, k, bi, bj, acc, Tb, ldt, lds, sb, sl.panels + ((k & 1) ? 0 : lde * CB), sl.Winv + (size_t)(k + 1) * CB * CB);
+}
 // xcd != 0: a 1-D grid of G * P workgroups whose linear id L is dealt XCD-locally -- the hardware hands workgroup L to XCD L % 8, so XCD x
 // is given the x-th eighth of the slot-major work list (unit u = slot * G + block): a slot's solved panel (1 MB at N = 2048) is then read by
 // the workgroups of one or two XCDs only and stays in their L2 instead of being fetched by all eight.
@@ -1762,29 +1787,52 @@ __global__ __launch_bounds__(256) void k_elim_update_b(const BatchSlot* __restri
     slot = (int)(u / G);
     blk = (int)(u % G);
   }
-  const BatchSlot& sl = slots[slot];
-  const ElimArgs& a = sl.ea;
   int bi, bj;
   tri_index(blk, bi, bj);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lk = lane >> 4;
-  const size_t lde = (size_t)a.ld + CB;
-  const bool restart = bi == k || bj == k;
-  const double* __restrict__ xp = sl.xpanel + (size_t)(k & 7) * ((size_t)a.nb + 1) * CB * CB;
-  stage_aside(lds, xp + (size_t)bj * CB * CB, CB, tid);  // A side: tile[kk][c] = X_j(c, kk)
-  double bv[16];
-  load_bside(bv, xp + (size_t)bi * CB * CB, CB, w, lane);  // B side: X_i(row 16 w + (lane & 15), kk = 4 ks + lk)
-  int ldt;
-  double* __restrict__ Tb = elim_tile(a, bi, bj, ldt);
-  double acc[4][4];  // negated tile
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[mi][t] = restart ? 0.0 : -Tb[(size_t)(16 * mi + 4 * t + lk) * ldt + 16 * w + (lane & 15)];
-  __syncthreads();
-  mma_64(lds, bv, acc, lane);  // -T_new = -T_old + X_i X_j^T
-  elim_store_block(a, k, bi, bj, acc, Tb, ldt, lds, sb, sl.panels + ((k & 1) ? 0 : lde * CB), sl.Winv + (size_t)(k + 1) * CB * CB);
+  elim_update_one(slots[slot], k, bi, bj, lds, sb);
+}
+
+// ---- the panel chain of a group in TWO launches (r04) -------------------------------------------------------------------------------
+// k_elim_panel_b / k_elim_update_b(sub mode) alternate 2 ng - 1 times per group, each launch waiting for the one before: ~50 us a step of which
+// the arithmetic is a few.  The same block routines, regrouped by who depends on whom:
+//   k_elim_gdiag_b  ONE workgroup a slot walks the group's DIAGONAL triangle (blocks (c, c'), k < c' <= c <= klast) through the steps
+//                   k .. klast - 1: the solved blocks X^s_c (s < c), the updates of the triangle, the diagonal factors W_{k+1} .. W_klast --
+//                   the serial chain, with no launch boundary inside;
+//   k_elim_grow_b   one workgroup a block row t: for s = k .. klast its solved block X^s_t and step s on its blocks (c, t) / (t, c), c > s --
+//                   everything it needs from others (W_s, X^s_c) is the first kernel's output; rows t inside the group take part from step t on.
+// Each block sees the same steps in the same order with the same operands as in the alternating launches: the same bits.
+__global__ __launch_bounds__(256) void k_elim_gdiag_b(const BatchSlot* __restrict__ slots, int k, int ng) {
+  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
+  __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
+  const BatchSlot& sl = slots[blockIdx.x];
+  const int klast = k + ng - 1;
+  for (int s = k; s < klast; ++s) {
+    for (int c = s + 1; c <= klast; ++c) {
+      __syncthreads();  // the tile in LDS is free; what this workgroup stored before (raw panel rows, W_s) is visible to all its waves
+      elim_panel_row(sl, s, c, lds);
+    }
+    for (int c2 = s + 1; c2 <= klast; ++c2)
+      for (int c = c2; c <= klast; ++c) {
+        __syncthreads();
+        elim_update_one(sl, s, c, c2, lds, sb);  // (c2 == c == s + 1: the next diagonal block, factored and inverted in elim_store_block)
+      }
+  }
+}
+__global__ __launch_bounds__(256) void k_elim_grow_b(const BatchSlot* __restrict__ slots, int k, int ng) {
+  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
+  __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
+  const BatchSlot& sl = slots[blockIdx.y];
+  const int t = (int)blockIdx.x;  // block row 0 .. nb
+  const int klast = k + ng - 1;
+  for (int s = k; s <= klast; ++s) {
+    if (t > s && t <= klast) continue;  // a row inside the group: the diagonal kernel's until the elimination has passed its column
+    __syncthreads();
+    elim_panel_row(sl, s, t, lds);
+    for (int c = s + 1; c <= klast; ++c) {
+      __syncthreads();
+      elim_update_one(sl, s, t <= c ? c : t, t <= c ? t : c, lds, sb);
+    }
+  }
 }
 
 // ---- GROUPED steps: two or four block columns per pass over the state (r04) ----------------------------------------------------------
@@ -2166,7 +2214,13 @@ hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double
   const bool super_tiles = super_from > 0 && (long)sgrid * P >= super_from;
   const unsigned gs = xcd_local ? (unsigned)(8 * (((long)sgrid * P + 7) / 8)) : (unsigned)sgrid;
   // the panel chain of the group k .. k + ng - 1: X^(k+g), then step k + g on the blocks of the columns / rows k + g + 1 .. k + ng - 1
+  static const bool two_launch_chain = [] { const char* e = getenv("BOGP_ELIM_CHAIN2"); return !(e && atoi(e) == 0); }();
   auto chain = [&](int k, int ng, hipStream_t s) {
+    if (two_launch_chain) {
+      if (ng > 1) hipLaunchKernelGGL(k_elim_gdiag_b, dim3(P), 256, 0, s, slots, k, ng);
+      hipLaunchKernelGGL(k_elim_grow_b, dim3(nb + 1, P), 256, 0, s, slots, k, ng);
+      return;
+    }
     for (int g = 0; g < ng; ++g) {
       hipLaunchKernelGGL(k_elim_panel_b, dim3(nb + 1, P), 256, 0, s, slots, k + g);
       if (g + 1 < ng) hipLaunchKernelGGL(k_elim_update_b, dim3((unsigned)((ng - 1 - g) * (nb + 1)), P), 256, 0, s, slots, k + g, -(ng - 1 - g), k + g + 1, P);
