@@ -143,9 +143,6 @@ extern "C" void bogp_destroy(bogp_handle* h) {
   if (h->stream_upd) (void)hipStreamDestroy(h->stream_upd);
   if (h->stream_copy) (void)hipStreamDestroy(h->stream_copy);
   if (h->ev_copy) (void)hipEventDestroy(h->ev_copy);
-  if (h->stream_la) { (void)hipStreamSynchronize(h->stream_la); (void)hipStreamDestroy(h->stream_la); }
-  for (int i = 0; i < 2; ++i)
-    if (h->ev_la[i]) (void)hipEventDestroy(h->ev_la[i]);
   if (h->hfit) (void)hipHostFree(h->hfit);
   if (h->dfin_ticket) (void)hipFree(h->dfin_ticket);
   delete h;

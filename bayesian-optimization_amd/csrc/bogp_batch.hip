@@ -111,7 +111,7 @@ SlotLayout slot_layout(int ld, int d, int N) {
   L.logpart = o; o += up8(nb + 1);
   L.Winv = o; o += (nb + 1) * 64 * 64;
   L.panels = o; o += 2 * lde * 64;
-  L.xpanel = o; o += 8 * (nb + 1) * 64 * 64;  // eight solved panels (grouped steps with look-ahead)
+  L.xpanel = o; o += 4 * (nb + 1) * 64 * 64;  // four solved panels (grouped steps)
   L.Rinv = o; o += (size_t)ld * ld;
   L.gamma = o; o += Np;
   L.scal = o; o += 64;
@@ -253,13 +253,7 @@ static int run_group(bogp_handle* h, int path, int kernel, int mode, const std::
     }
     HIPCHK(h, hipMemcpyAsync(h->bws_rows, hin, (size_t)Pg * row * sizeof(double), hipMemcpyHostToDevice, st));
     HIPCHK(h, launch_build_R_batch(kernel, mode == BOGP_MODE_NOISY, h->dX, N, d, h->dbslots, Pg, ld, st));
-    if (!h->stream_la) {  // the look-ahead stream: above `stream` in priority, its small kernels take the slots the big update frees
-      int lo = 0, hi = 0;
-      HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-      HIPCHK(h, hipStreamCreateWithPriority(&h->stream_la, hipStreamNonBlocking, hi));
-      for (int i = 0; i < 2; ++i) HIPCHK(h, hipEventCreateWithFlags(&h->ev_la[i], hipEventDisableTiming));
-    }
-    HIPCHK(h, launch_elim_batch(h->dbslots, Pg, ld, h->dy_base, estimate_trend, mode, beta, st, h->stream_la, h->ev_la));
+    HIPCHK(h, launch_elim_batch(h->dbslots, Pg, ld, h->dy_base, estimate_trend, mode, beta, st));
     if (want_grad) {
       HIPCHK(h, launch_grad_contract_batch(kernel, h->dX, N, d, h->dbslots, Pg, h->Np, ld, st));
       HIPCHK(h, launch_grad_finish_batch(h->dbslots, Pg, grad_contract_blocks(N), d + 1, ld, N, mode == BOGP_MODE_NOISY ? 1 : 0, dout,

@@ -88,10 +88,6 @@ struct bogp_handle {
   int64_t lazy_done = 0;
   hipStream_t stream_copy = nullptr;
   hipEvent_t ev_copy = nullptr;
-  // bogp_nll_batch's elimination with look-ahead: the panel chain of block-column group g + 1 runs on `stream_la` (high priority) beside the
-  // whole-state update of group g on `stream` (launch_elim_batch); ev_la = {chain done, next group's columns updated}
-  hipStream_t stream_la = nullptr;
-  hipEvent_t ev_la[2] = {nullptr, nullptr};
 
   // sweep scratch
   double *drT[2] = {nullptr, nullptr}, *dmu_part[2] = {nullptr, nullptr}, *dw_part[2] = {nullptr, nullptr};

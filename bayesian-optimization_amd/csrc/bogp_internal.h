@@ -246,8 +246,7 @@ struct BatchSlot {
   ElimArgs ea;          // state blocks, block row nb, Yt, Ft, log-determinant parts; ea.info = (int*)(scal + 62)
   double* Winv;         // (nb + 1) x 64 x 64: inverses of the diagonal blocks
   double* panels;       // 2 x (ld + 64) x 64: the two raw panels
-  double* xpanel;       // 8 x (nb + 1) x 64 x 64: the solved panels of split steps, by k mod 8 (two groups of four: the look-ahead chain writes
-                        // the next group's while the whole-state update reads this group's)
+  double* xpanel;       // 4 x (nb + 1) x 64 x 64: the solved panels of split steps, by k mod 4 (k_elim_panel_b -> k_elim_update_b / updateG_b / updateS_b)
   double* Rinv;         // ld x ld
   double* gamma;        // Np
   double* scal;         // 64: [0..3] the likelihood's scalars, [32..48) the gradient's weights, [62] info
@@ -256,9 +255,7 @@ struct BatchSlot {
   unsigned int* ticket; // zeroed word of k_grad_finish_b
 };
 hipError_t launch_build_R_batch(int kernel, bool div, const double* X, int N, int d, const BatchSlot* slots, int P, int ld, hipStream_t st);
-// st_la / ev_la (two events): the look-ahead stream, or null for everything in order on st
-hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double* y, int estimate_trend, int mode, double beta, hipStream_t st,
-                             hipStream_t st_la, hipEvent_t* ev_la);
+hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double* y, int estimate_trend, int mode, double beta, hipStream_t st);
 hipError_t launch_grad_contract_batch(int kernel, const double* X, int N, int d, const BatchSlot* slots, int P, int Np, int ld, hipStream_t st);
 hipError_t launch_grad_finish_batch(const BatchSlot* slots, int P, int nblk, int nout, int ld, int N, int with_trace, double* bout,
                                     int bout_stride, unsigned long long* flag, unsigned long long seq, unsigned int* gticket, hipStream_t st);

@@ -1727,9 +1727,8 @@ __device__ __forceinline__ void elim_panel_row(const BatchSlot& sl, int k, int b
 #pragma unroll
       for (int t = 0; t < 4; ++t) dst[CB * k + 16 * mi + 4 * t + lk] = x[mi][t];
   }
-  // (eight solved panels are kept, by k mod 8: a grouped step needs X of up to four consecutive steps at once, and with look-ahead the next
-  // group's are written while this group's are still being read)
-  double* __restrict__ Xs = sl.xpanel + (size_t)(k & 7) * ((size_t)a.nb + 1) * CB * CB + (size_t)bi * CB * CB;  // element (row, col) at Xs[row + 64 col]
+  // (four solved panels are kept, by k mod 4: a grouped step needs X of up to four consecutive steps at once)
+  double* __restrict__ Xs = sl.xpanel + (size_t)(k & 3) * ((size_t)a.nb + 1) * CB * CB + (size_t)bi * CB * CB;  // element (row, col) at Xs[row + 64 col]
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -1747,7 +1746,7 @@ __device__ __forceinline__ void elim_update_one(const BatchSlot& sl, int k, int 
   const int lk = lane >> 4;
   const size_t lde = (size_t)a.ld + CB;
   const bool restart = bi == k || bj == k;
-  const double* __restrict__ xp = sl.xpanel + (size_t)(k & 7) * ((size_t)a.nb + 1) * CB * CB;
+  const double* __restrict__ xp = sl.xpanel + (size_t)(k & 3) * ((size_t)a.nb + 1) * CB * CB;
   stage_aside(lds, xp + (size_t)bj * CB * CB, CB, tid);  // A side: tile[kk][c] = X_j(c, kk)
   double bv[16];
   load_bside(bv, xp + (size_t)bi * CB * CB, CB, w, lane);  // B side: X_i(row 16 w + (lane & 15), kk = 4 ks + lk)
@@ -1792,49 +1791,6 @@ __global__ __launch_bounds__(256) void k_elim_update_b(const BatchSlot* __restri
   elim_update_one(slots[slot], k, bi, bj, lds, sb);
 }
 
-// ---- the panel chain of a group in TWO launches (r04) -------------------------------------------------------------------------------
-// k_elim_panel_b / k_elim_update_b(sub mode) alternate 2 ng - 1 times per group, each launch waiting for the one before: ~50 us a step of which
-// the arithmetic is a few.  The same block routines, regrouped by who depends on whom:
-//   k_elim_gdiag_b  ONE workgroup a slot walks the group's DIAGONAL triangle (blocks (c, c'), k < c' <= c <= klast) through the steps
-//                   k .. klast - 1: the solved blocks X^s_c (s < c), the updates of the triangle, the diagonal factors W_{k+1} .. W_klast --
-//                   the serial chain, with no launch boundary inside;
-//   k_elim_grow_b   one workgroup a block row t: for s = k .. klast its solved block X^s_t and step s on its blocks (c, t) / (t, c), c > s --
-//                   everything it needs from others (W_s, X^s_c) is the first kernel's output; rows t inside the group take part from step t on.
-// Each block sees the same steps in the same order with the same operands as in the alternating launches: the same bits.
-__global__ __launch_bounds__(256) void k_elim_gdiag_b(const BatchSlot* __restrict__ slots, int k, int ng) {
-  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
-  __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
-  const BatchSlot& sl = slots[blockIdx.x];
-  const int klast = k + ng - 1;
-  for (int s = k; s < klast; ++s) {
-    for (int c = s + 1; c <= klast; ++c) {
-      __syncthreads();  // the tile in LDS is free; what this workgroup stored before (raw panel rows, W_s) is visible to all its waves
-      elim_panel_row(sl, s, c, lds);
-    }
-    for (int c2 = s + 1; c2 <= klast; ++c2)
-      for (int c = c2; c <= klast; ++c) {
-        __syncthreads();
-        elim_update_one(sl, s, c, c2, lds, sb);  // (c2 == c == s + 1: the next diagonal block, factored and inverted in elim_store_block)
-      }
-  }
-}
-__global__ __launch_bounds__(256) void k_elim_grow_b(const BatchSlot* __restrict__ slots, int k, int ng) {
-  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
-  __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
-  const BatchSlot& sl = slots[blockIdx.y];
-  const int t = (int)blockIdx.x;  // block row 0 .. nb
-  const int klast = k + ng - 1;
-  for (int s = k; s <= klast; ++s) {
-    if (t > s && t <= klast) continue;  // a row inside the group: the diagonal kernel's until the elimination has passed its column
-    __syncthreads();
-    elim_panel_row(sl, s, t, lds);
-    for (int c = s + 1; c <= klast; ++c) {
-      __syncthreads();
-      elim_update_one(sl, s, t <= c ? c : t, t <= c ? t : c, lds, sb);
-    }
-  }
-}
-
 // ---- GROUPED steps: two or four block columns per pass over the state (r04) ----------------------------------------------------------
 // A batch that fills the GPU is bound by the read-modify-write of the N x N state, once per 64-column step (~1.1 GB of traffic per
 // evaluation at N = 2048).  Steps k and k + 1 are therefore applied in ONE pass:
@@ -1873,7 +1829,7 @@ __device__ __forceinline__ void elim_group_block(const BatchSlot& sl, int k, int
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[mi][t] = restart ? 0.0 : -Tb[(size_t)(16 * mi + 4 * t + lk) * ldt + 16 * w + (lane & 15)];
   for (int sidx = first; sidx <= klast; ++sidx) {
-    const double* __restrict__ xs = sl.xpanel + (size_t)(sidx & 7) * xsz;
+    const double* __restrict__ xs = sl.xpanel + (size_t)(sidx & 3) * xsz;
     if (sidx > first) __syncthreads();  // every wave is done with the previous step's X_j tile
     stage_aside(lds, xs + (size_t)bj * CB * CB, CB, tid);
     load_bside(bv, xs + (size_t)bi * CB * CB, CB, w, lane);
@@ -1897,20 +1853,6 @@ __global__ __launch_bounds__(256) void k_elim_updateG_b(const BatchSlot* __restr
   int bi, bj;
   tri_index(blk, bi, bj);
   elim_group_block(slots[slot], k, ng, bi, bj, lds, sb);
-}
-
-// LOOK-AHEAD: the blocks of the NEXT group's columns / rows c0 .. c0 + ncol - 1 (sub-mode indexing of k_elim_update_b) taken through this
-// group's steps first -- with the next raw panel and diagonal factor they publish, the next group's panel chain can start on a second stream
-// while k_elim_updateS_b (which then skips these blocks) takes the rest of the state through the same steps.
-__global__ __launch_bounds__(256) void k_elim_updateGsub_b(const BatchSlot* __restrict__ slots, int k, int ng, int c0) {
-  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
-  __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
-  const BatchSlot& sl = slots[blockIdx.y];
-  const int nb1 = sl.ea.nb + 1;
-  const int ci = (int)blockIdx.x / nb1, t = (int)blockIdx.x % nb1;
-  const int c = c0 + ci;
-  if (t >= c0 && t < c) return;  // block (c, t) already belongs to the earlier column / row t of this launch
-  elim_group_block(sl, k, ng, t <= c ? c : t, t <= c ? t : c, lds, sb);
 }
 
 // ---- the grouped update on 128 x 128 SUPER-TILES (r04) --------------------------------------------------------------------------------
@@ -1949,7 +1891,7 @@ __device__ __forceinline__ void load_bside_b(double (&bv)[16], __amdgpu_buffer_r
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) bv[ks] = buf_load(r, voff, ks * 4 * CB);
 }
-__global__ __launch_bounds__(256, 2) void k_elim_updateS_b(const BatchSlot* __restrict__ slots, int k, int ng, int xcd, int G, int P, int x0, int nx) {
+__global__ __launch_bounds__(256, 2) void k_elim_updateS_b(const BatchSlot* __restrict__ slots, int k, int ng, int xcd, int G, int P) {
   __shared__ __attribute__((aligned(16))) double lds[2][CB * CPITCH];
   int slot = (int)blockIdx.y, blk = (int)blockIdx.x;
   if (xcd) {
@@ -1985,7 +1927,7 @@ __global__ __launch_bounds__(256, 2) void k_elim_updateS_b(const BatchSlot* __re
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib) {
       const int bi = 2 * BI + ia, bj = 2 * BJ + ib;
-      valid[ia][ib] = bi <= a.nb && bj < a.nb && bj <= bi && !(bi >= x0 && bi < x0 + nx) && !(bj >= x0 && bj < x0 + nx);  // [x0, x0 + nx): look-ahead's
+      valid[ia][ib] = bi <= a.nb && bj < a.nb && bj <= bi;
       int f = -1;
       if (bi >= k && bi <= klast) f = bi;
       if (bj >= k && bj <= klast) f = max(f, bj);
@@ -2013,7 +1955,7 @@ __global__ __launch_bounds__(256, 2) void k_elim_updateS_b(const BatchSlot* __re
     }
   const int tj1 = 2 * BJ + (2 * BJ + 1 <= a.nb ? 1 : 0), ti1 = 2 * BI + (2 * BI + 1 <= a.nb ? 1 : 0);  // (past the edge: the tile before, discarded)
   for (int sidx = k; sidx <= klast; ++sidx) {
-    const double* xs = sl.xpanel + (size_t)(sidx & 7) * xsz;
+    const double* xs = sl.xpanel + (size_t)(sidx & 3) * xsz;
     double bv0[16], bv1[16];
     if (sidx > k) __syncthreads();  // every wave is done with the previous step's tiles
     stage_aside_b(lds[0], tile_rsrc(xs + (size_t)(2 * BJ) * CB * CB), tid);
@@ -2186,8 +2128,7 @@ __global__ void k_elim_init(const ElimArgs a, const double* __restrict__ y) { el
 __global__ void k_elim_init_b(const BatchSlot* __restrict__ slots, const double* __restrict__ y) { elim_init_column(slots[blockIdx.y].ea, y); }
 
 // the elimination of P matrices at once (bogp_nll_batch): the launches of launch_elim with a second grid dimension over the slots
-hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double* y, int estimate_trend, int mode, double beta, hipStream_t st,
-                             hipStream_t st_la, hipEvent_t* ev_la) {
+hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double* y, int estimate_trend, int mode, double beta, hipStream_t st) {
   const int nb = ld / CB;
   hipLaunchKernelGGL(k_elim_init_b, dim3(ld, P), 64, 0, st, slots, y);
   hipLaunchKernelGGL(k_elim_first_b, dim3(nb + 1, P), 256, 0, st, slots);
@@ -2206,58 +2147,25 @@ hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double
   }();
   // the whole-state update of a grouped step on 128 x 128 super-tiles (k_elim_updateS_b)
   // -- from BOGP_ELIM_SUPER super-tile workgroups a launch (default 1500: N = 2048 from P = 10; below that the 64 x 64 kernel's finer grain
-  // fills the GPU better; 0 = never); the next group's panel chain on the look-ahead stream beside the update only with BOGP_ELIM_LOOKAHEAD=1
-  // (measured slower: EXPERIMENTS.md)
+  // fills the GPU better; 0 = never)
   static const long super_from = [] { const char* e = getenv("BOGP_ELIM_SUPER"); return e ? atol(e) : 1500L; }();
-  static const bool lookahead = [] { const char* e = getenv("BOGP_ELIM_LOOKAHEAD"); return e && atoi(e) != 0; }();
   const int SR = (nb + 2) / 2, sgrid = SR * (SR + 1) / 2;
   const bool super_tiles = super_from > 0 && (long)sgrid * P >= super_from;
   const unsigned gs = xcd_local ? (unsigned)(8 * (((long)sgrid * P + 7) / 8)) : (unsigned)sgrid;
   // the panel chain of the group k .. k + ng - 1: X^(k+g), then step k + g on the blocks of the columns / rows k + g + 1 .. k + ng - 1
-  static const bool two_launch_chain = [] { const char* e = getenv("BOGP_ELIM_CHAIN2"); return !(e && atoi(e) == 0); }();
   auto chain = [&](int k, int ng, hipStream_t s) {
-    if (two_launch_chain) {
-      if (ng > 1) hipLaunchKernelGGL(k_elim_gdiag_b, dim3(P), 256, 0, s, slots, k, ng);
-      hipLaunchKernelGGL(k_elim_grow_b, dim3(nb + 1, P), 256, 0, s, slots, k, ng);
-      return;
-    }
     for (int g = 0; g < ng; ++g) {
       hipLaunchKernelGGL(k_elim_panel_b, dim3(nb + 1, P), 256, 0, s, slots, k + g);
       if (g + 1 < ng) hipLaunchKernelGGL(k_elim_update_b, dim3((unsigned)((ng - 1 - g) * (nb + 1)), P), 256, 0, s, slots, k + g, -(ng - 1 - g), k + g + 1, P);
     }
   };
-  if (split && super_tiles && lookahead && group > 1 && st_la && ev_la) {
-    // look-ahead (bit-identical: the same block routines on the same values, only on two streams):
-    //   st_la:  chain(g)                                   chain(g + 1)                       ...
-    //   st:              Gsub(g) [next group's blocks]  S(g) [the rest of the state]   Gsub(g + 1)  S(g + 1)
-    // Gsub(g) waits for chain(g); chain(g + 1) waits for Gsub(g); S(g) reads the solved panels k .. k + 3 (buffers k mod 8) while chain(g + 1)
-    // writes k + 4 .. k + 7, and touches no block of the next group's columns / rows, which the chain's sub-mode launches update.
-    hipError_t e;
-    if ((e = hipEventRecord(ev_la[1], st)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(st_la, ev_la[1], 0)) != hipSuccess) return e;
-    for (int k = 0; k < nb;) {
-      const int ng = min(group, nb - k), k2 = k + ng, ng2 = min(group, nb - k2);
-      chain(k, ng, st_la);
-      if ((e = hipEventRecord(ev_la[0], st_la)) != hipSuccess) return e;
-      if ((e = hipStreamWaitEvent(st, ev_la[0], 0)) != hipSuccess) return e;
-      if (ng2 > 0) {
-        hipLaunchKernelGGL(k_elim_updateGsub_b, dim3((unsigned)(ng2 * (nb + 1)), P), 256, 0, st, slots, k, ng, k2);
-        if ((e = hipEventRecord(ev_la[1], st)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(st_la, ev_la[1], 0)) != hipSuccess) return e;
-      }
-      hipLaunchKernelGGL(k_elim_updateS_b, dim3(gs, xcd_local ? 1 : P), 256, 0, st, slots, k, ng, xcd_local ? 1 : 0, sgrid, P, k2, max(ng2, 0));
-      k = k2;
-    }
-    hipLaunchKernelGGL(k_elim_finish_b, dim3(nb * (nb + 1) / 2 + 1, P), 256, 0, st, slots, estimate_trend, mode, beta);
-    return hipGetLastError();
-  }
   for (int k = 0; k < nb; ++k) {
     const int ng = !split ? 1 : (group >= 4 && k + 3 < nb ? 4 : (group >= 2 && k + 1 < nb ? 2 : 1));
     if (ng > 1) {
       const unsigned g1 = xcd_local ? (unsigned)(8 * (((long)grid * P + 7) / 8)) : (unsigned)grid;
       chain(k, ng, st);
       if (super_tiles) {
-        hipLaunchKernelGGL(k_elim_updateS_b, dim3(gs, xcd_local ? 1 : P), 256, 0, st, slots, k, ng, xcd_local ? 1 : 0, sgrid, P, 0, 0);
+        hipLaunchKernelGGL(k_elim_updateS_b, dim3(gs, xcd_local ? 1 : P), 256, 0, st, slots, k, ng, xcd_local ? 1 : 0, sgrid, P);
         if (k + ng < nb) hipLaunchKernelGGL(k_elim_diag_b, dim3(P), 256, 0, st, slots, k + ng);
       } else {
         hipLaunchKernelGGL(k_elim_updateG_b, dim3(g1, xcd_local ? 1 : P), 256, 0, st, slots, k, ng, xcd_local ? 1 : 0, grid, P);

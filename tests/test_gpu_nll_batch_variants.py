@@ -1,5 +1,5 @@
 """The batched elimination picks its launch plan by size (fused / split steps, steps grouped by 2 or 4 block columns, 64 x 64 or
-128 x 128 update tiles, XCD-local work lists, two-launch or alternating panel chain, look-ahead stream: csrc/kernels_chol.hip launch_elim_batch).  Every plan must give the
+128 x 128 update tiles, XCD-local work lists: csrc/kernels_chol.hip launch_elim_batch).  Every plan must give the
 bits of sequential bogp_nll; the plans are chosen once per process from the environment, so each variant re-runs
 tests/test_gpu_nll_batch.py in a process of its own with the thresholds forced down to the test sizes.
 Needs a real MI355X: `pytest -m gpu`."""
@@ -21,10 +21,6 @@ VARIANTS = {
     "super": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "1"},
     "super-pairs": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "1", "BOGP_ELIM_GROUP": "2"},
     "super-no-xcd": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "1", "BOGP_ELIM_XCD": "0"},
-    "super-lookahead": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "1", "BOGP_ELIM_LOOKAHEAD": "1"},
-    "split-alternating-chain": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "0", "BOGP_ELIM_CHAIN2": "0"},
-    "super-alternating-chain": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "1", "BOGP_ELIM_CHAIN2": "0"},
-    "super-lookahead-pairs": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "1", "BOGP_ELIM_LOOKAHEAD": "1", "BOGP_ELIM_GROUP": "2"},
 }
 
 
