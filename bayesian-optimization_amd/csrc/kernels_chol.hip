@@ -69,6 +69,26 @@ __device__ __forceinline__ void load_bside(double (&bv)[16], const double* __res
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) bv[ks] = Bs[(size_t)(4 * ks + lk) * ldb + 16 * w + (lane & 15)];
 }
+// the same two for pointers KNOWN to be global (address space 1): a pointer that comes out of memory (a BatchSlot's) is generic to the compiler,
+// and generic loads are flat_load -- they also wait on the LDS counter and take no scalar base
+typedef __attribute__((address_space(1))) double gdouble;
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) d2v gd2v;
+__device__ __forceinline__ const gdouble* as_global(const double* p) { return (const gdouble*)p; }
+__device__ __forceinline__ void stage_aside(double* lds, const gdouble* As, int lda, int tid) {
+  const int srow = tid >> 5, scol = (tid & 31) * 2;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int kk = srow + 8 * p;
+    const d2v v = *(const gd2v*)(As + (size_t)kk * lda + scol);
+    *reinterpret_cast<d2v*>(&lds[kk * CPITCH + scol]) = v;
+  }
+}
+__device__ __forceinline__ void load_bside(double (&bv)[16], const gdouble* Bs, int ldb, int w, int lane) {
+  const int lk = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) bv[ks] = Bs[(size_t)(4 * ks + lk) * ldb + 16 * w + (lane & 15)];
+}
 __device__ __forceinline__ void mma_64(const double* lds, const double (&bv)[16], double (&acc)[4][4], int lane) {
   const int aoff = (lane >> 4) * CPITCH + (lane & 15);  // MFMA-A = the LDS-staged side: lane (k, i) reads tile[k][16 mi + i]
   d4 c[4];
@@ -1633,10 +1653,10 @@ __device__ __forceinline__ void elim_step_block(const ElimArgs& a, int k, const 
   const int i0 = CB * bi, j0 = CB * bj;
   const bool restart = bi == k || bj == k;
 
-  stage_aside(lds, Wk, CB, tid);  // tile[kk][c] = W(c, kk)
+  stage_aside(lds, as_global(Wk), CB, tid);  // tile[kk][c] = W(c, kk)
   double bv[16], bvi[16];
-  load_bside(bv, Pcur + j0, lde, w, lane);
-  if (bi != bj) load_bside(bvi, Pcur + i0, lde, w, lane);
+  load_bside(bv, as_global(Pcur + j0), lde, w, lane);
+  if (bi != bj) load_bside(bvi, as_global(Pcur + i0), lde, w, lane);
   double xj[4][4], xi[4][4];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
@@ -1710,9 +1730,9 @@ __device__ __forceinline__ void elim_panel_row(const BatchSlot& sl, int k, int b
   const int lk = lane >> 4;
   const size_t lde = (size_t)a.ld + CB;
   const double* __restrict__ Pcur = sl.panels + ((k & 1) ? lde * CB : 0);
-  stage_aside(lds, sl.Winv + (size_t)k * CB * CB, CB, tid);  // tile[kk][c] = W(c, kk)
+  stage_aside(lds, as_global(sl.Winv + (size_t)k * CB * CB), CB, tid);  // tile[kk][c] = W(c, kk)
   double bv[16];
-  load_bside(bv, Pcur + (size_t)CB * bi, (int)lde, w, lane);
+  load_bside(bv, as_global(Pcur + (size_t)CB * bi), (int)lde, w, lane);
   double x[4][4];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
@@ -1747,9 +1767,9 @@ __device__ __forceinline__ void elim_update_one(const BatchSlot& sl, int k, int 
   const size_t lde = (size_t)a.ld + CB;
   const bool restart = bi == k || bj == k;
   const double* __restrict__ xp = sl.xpanel + (size_t)(k & 3) * ((size_t)a.nb + 1) * CB * CB;
-  stage_aside(lds, xp + (size_t)bj * CB * CB, CB, tid);  // A side: tile[kk][c] = X_j(c, kk)
+  stage_aside(lds, as_global(xp + (size_t)bj * CB * CB), CB, tid);  // A side: tile[kk][c] = X_j(c, kk)
   double bv[16];
-  load_bside(bv, xp + (size_t)bi * CB * CB, CB, w, lane);  // B side: X_i(row 16 w + (lane & 15), kk = 4 ks + lk)
+  load_bside(bv, as_global(xp + (size_t)bi * CB * CB), CB, w, lane);  // B side: X_i(row 16 w + (lane & 15), kk = 4 ks + lk)
   int ldt;
   double* __restrict__ Tb = elim_tile(a, bi, bj, ldt);
   double acc[4][4];  // negated tile
@@ -1831,8 +1851,8 @@ __device__ __forceinline__ void elim_group_block(const BatchSlot& sl, int k, int
   for (int sidx = first; sidx <= klast; ++sidx) {
     const double* __restrict__ xs = sl.xpanel + (size_t)(sidx & 3) * xsz;
     if (sidx > first) __syncthreads();  // every wave is done with the previous step's X_j tile
-    stage_aside(lds, xs + (size_t)bj * CB * CB, CB, tid);
-    load_bside(bv, xs + (size_t)bi * CB * CB, CB, w, lane);
+    stage_aside(lds, as_global(xs + (size_t)bj * CB * CB), CB, tid);
+    load_bside(bv, as_global(xs + (size_t)bi * CB * CB), CB, w, lane);
     __syncthreads();
     mma_64(lds, bv, acc, lane);  // step sidx:  -T <- -T + X_i X_j^T, the intermediate state never leaves the accumulators
   }
