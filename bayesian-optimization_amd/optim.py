@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import functools
 import inspect
+import warnings
 from typing import Callable, List, Optional, Sequence
 
 import numpy as np
@@ -131,6 +132,9 @@ def feasible_rows(X: np.ndarray, h: Optional[Callable], g: Optional[Callable]) -
     |h(x)| within 1e-1 of zero for every equality constraint and g(x) <= 0 for every inequality constraint.  `h` / `g`
     take one point as a list, like the wrappers `BaseBO` binds (base.py:224-229, 236-237)."""
     keep = np.ones(len(X), dtype=bool)
+    if len(X) > 100_000 and (h is not None or g is not None):  # (ADVICE r03) one Python call per candidate and constraint
+        warnings.warn("a constrained sweep calls the constraint functions once per candidate (%d Python calls): lower eval_budget "
+                      "or keep the problem on the reference's optimiser" % len(X), RuntimeWarning, stacklevel=3)
     for i in range(len(X)):
         x = X[i].tolist()
         if h is not None:
