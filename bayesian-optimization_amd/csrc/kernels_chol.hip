@@ -1722,7 +1722,7 @@ __global__ __launch_bounds__(256) void k_elim_step_b(const BatchSlot* __restrict
 // formed ONCE (k_elim_panel_b: the same mma_64 on the same operands, stored as plain 64 x 64 tiles) and the update reads them back
 // in the layouts the fused kernel built in registers / LDS (k_elim_update_b: stage_aside / load_bside on the stored tiles): one
 // product a block and step, bit-identical results.
-// the solved panel block of block row bi at step k: X = M W_k^T from the raw panel, into the slot's solved panel k mod 8
+// the solved panel block of block row bi at step k: X = M W_k^T from the raw panel, into the slot's solved panel k mod 4
 __device__ __forceinline__ void elim_panel_row(const BatchSlot& sl, int k, int bi, double* lds) {
   const ElimArgs& a = sl.ea;
   const int tid = threadIdx.x, lane = tid & 63;
