@@ -806,7 +806,11 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
   if (grad && (kernel == BOGP_KERNEL_CUBIC || kernel == BOGP_KERNEL_GENEXP || kernel == BOGP_KERNEL_MATERN_NU)) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_restricted: the cubic / generalized_exponential correlation has no theta-derivative");
   if (mode < 0 || mode > 2) FAIL(h, BOGP_ERR_INVALID, "unknown estimation mode %d", mode);
   if (trend < BOGP_TREND_CONSTANT || trend > BOGP_TREND_QUADRATIC) FAIL(h, BOGP_ERR_INVALID, "unknown trend id %d", trend);
-  if (h->n_t != 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_restricted: single-target y only (have %d targets)", h->n_t);
+  // several targets: the VALUE as the reference's arithmetic gives it (the scalar terms broadcast over the n_t x n_t matrix rho^T rho and everything
+  // summed, gpr.py:861-866); its gradient raises there (a (1, N n_t) by (N, N) product, :875, :896)
+  if (h->n_t != 1 && grad) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_restricted: no gradient with %d targets (the reference raises ValueError at gpr.py:896)", h->n_t);
+  if (h->n_t != 1 && (estimate_trend || trend != BOGP_TREND_CONSTANT))
+    FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_nll_restricted: %d targets need a FIXED constant trend (gpr.py:787)", h->n_t);
   h->committed = false;
   const int n_tail = mode == BOGP_MODE_NOISE_ESTIM ? 2 : 1;
   const int n_theta = n_par - n_tail;
@@ -862,7 +866,21 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
     v = -0.5 * ((N - ptrend) * std::log(TWO_PI * tv) - h->reml_logdet_ftf + 2.0 * o.logdet + 2.0 * lg + o.rho_ss / tv);
   } else if (estimate_trend)  // p = 1: det(F^T F) = N, prod(diag G)^2 = |Ft|^2  (:850-860)
     v = -0.5 * ((N - 1) * std::log(TWO_PI * tv) - std::log((double)N) + 2.0 * o.logdet + std::log(o.ftft) + o.rho_ss / tv);
-  else  // the reference SUBTRACTS the log-determinant here (:861-866)
+  else if (h->n_t > 1) {
+    // (scalar + rho^T rho / tv).sum() over the n_t x n_t matrix: n_t^2 times the scalar terms + sum_ab rho_a . rho_b = |sum_a rho_a|^2
+    const int T = h->n_t;
+    std::vector<double> rho((size_t)T * N);
+    HIPCHK(h, hipMemcpyAsync(rho.data(), h->drho_base, rho.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double cross = 0.0;  // row by row of rho^T rho, like the matrix the reference sums
+    for (int a = 0; a < T; ++a)
+      for (int b = 0; b < T; ++b) {
+        double s_ = 0.0;
+        for (int i = 0; i < N; ++i) s_ += rho[(size_t)a * N + i] * rho[(size_t)b * N + i];
+        cross += s_;
+      }
+    v = -0.5 * ((double)T * T * (N * std::log(TWO_PI * tv) - 2.0 * o.logdet) + cross / tv);
+  } else  // the reference SUBTRACTS the log-determinant here (:861-866)
     v = -0.5 * (N * std::log(TWO_PI * tv) - 2.0 * o.logdet + o.rho_ss / tv);
   if (!std::isfinite(v)) FAIL(h, BOGP_ERR_NOT_POSDEF, "restricted log-likelihood is not finite (%g)", v);
   const bool positive = v > 0;  // exp(llf) > 1

@@ -345,6 +345,15 @@ class GaussianProcess:
         model as it was)."""
         par = np.asarray(par, dtype=np.float64).ravel()
         tid, est, beta = self._trend_args()
+        if self.y.shape[1] > 1:
+            # several targets: the reference's arithmetic yields a VALUE (the scalar terms broadcast over the n_t x n_t matrix rho^T rho,
+            # everything summed, gpr.py:861-866) and raises in the gradient (a (1, N n_t) by (N, N) product, :875, :896); `env` would
+            # receive one column per target there -- not built, nothing in the reference reads it
+            if eval_grad:
+                raise ValueError("shapes (1,%d) and (%d,%d) not aligned: the restricted likelihood has no gradient with several targets "
+                                 "(gpr.py:875, 896)" % (self.y.size, len(self.y), len(self.y)))
+            if env is not None:
+                raise NotImplementedError("env of the restricted likelihood with several targets")
         if not (np.all(np.isfinite(par)) and np.all(par > 0)):
             return (-np.inf, np.zeros((len(par), 1))) if eval_grad else -np.inf
         prev = (self._committed_par, getattr(self, "_committed_restricted", False))

@@ -170,7 +170,9 @@ int bogp_get_state(bogp_handle* h, double* C, double* gamma, double* rho, double
 /* ---- restricted (REML) likelihood ---------------------------------------------------------------------
  * Replaces GaussianProcess.log_likelihood_restricted(par, eval_grad) (gpr.py:813-918).  Parameter layout (:826-834):
  * NOISELESS [theta, sigma2]; NOISY [theta, sigma2] with the fixed `noise_var`; NOISE_ESTIM [theta, sigma2, noise_var].
- * All three trend bases (constant, linear, quadratic; estimated or fixed coefficients); single target.  Quirks kept: the simple-kriging value subtracts the log-determinant term (:861-866);
+ * All three trend bases (constant, linear, quadratic; estimated or fixed coefficients) with one target; with several targets (fixed
+ * constant trend only, as everywhere) the VALUE the reference's arithmetic yields -- the scalar terms broadcast over the n_t x n_t matrix
+ * rho^T rho and everything summed (:861-866) -- and BOGP_ERR_UNSUPPORTED for its gradient (ValueError there, :875, :896).  Quirks kept: the simple-kriging value subtracts the log-determinant term (:861-866);
  * exp(llf) > 1 is rejected (:868-871): BOGP_ERR_LLF_POSITIVE, with *llf = the finite value and grad (if requested)
  * filled as the reference returns it.  The state for prediction at REML parameters is the NOISY-mode one:
  * bogp_commit(mode = BOGP_MODE_NOISY, par = [theta, sigma2], noise_var).                                       */

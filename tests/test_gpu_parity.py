@@ -885,6 +885,44 @@ def test_reml_tables(eng):
     assert n == 48
 
 
+def test_reml_with_several_targets_gives_the_reference_value(eng):
+    """G33 (imported reference): the restricted likelihood of a model whose y has 2 / 3 columns is a VALUE -- scalar terms broadcast over
+    the n_t x n_t matrix rho^T rho, everything summed (gpr.py:861-866) -- and its gradient raises (ValueError there, :875, :896)."""
+    g = load_golden("G33_reml_multitarget")
+    beta = float(g["beta"])
+    n = 0
+    for T in (2, 3):
+        eng.set_train(g["X"], g["Y"][:, :T])
+        for kid in (0, 2):
+            for mid in (0, 1, 2):
+                key = "T%d_k%d_m%d" % (T, kid, mid)
+                for p, v in zip(g[key + "_par"], g[key + "_llf"]):
+                    nv = 1e-4 if mid == 1 else 0.0
+                    if np.isneginf(v):
+                        assert np.isneginf(eng.nll_restricted(kid, mid, p, nv, False, beta))
+                    else:
+                        np.testing.assert_allclose(eng.nll_restricted(kid, mid, p, nv, False, beta), v, rtol=1e-9)
+                    n += 1
+        with pytest.raises(_lib.BogpError):
+            eng.nll_restricted(0, 1, g["T%d_k0_m1_par" % T][0], 1e-4, False, beta, eval_grad=True)
+        with pytest.raises(_lib.BogpError):  # estimated coefficients with several targets: the reference raises at gpr.py:787
+            eng.nll_restricted(0, 1, g["T%d_k0_m1_par" % T][0], 1e-4, True, 0.0)
+    assert n == 36
+    # the host class: a model fitted with the concentrated likelihood answers the restricted one by value, raises in its gradient
+    X, Y = g["X"], g["Y"]
+    d = X.shape[1]
+    gp = bogp.GaussianProcess(mean=bogp.trend.constant_trend(d, beta=beta), corr="matern", thetaL=[1e-4] * d, thetaU=[1e2] * d, nugget=1e-4,
+                              random_start=2, eval_budget=60)  # fmt: skip
+    np.random.seed(3)
+    gp.fit(X, Y)
+    p = g["T3_k2_m1_par"][1]
+    np.testing.assert_allclose(gp.log_likelihood_restricted(p), g["T3_k2_m1_llf"][1], rtol=1e-9)
+    with pytest.raises(ValueError):
+        gp.log_likelihood_restricted(p, eval_grad=True)
+    mu = gp.predict(X[:5])
+    assert mu.shape == (5, 3) and np.all(np.isfinite(mu))  # the fitted state survived both calls
+
+
 @pytest.mark.parametrize("kw", [dict(nugget=1e-6), dict(nugget=0), dict(nugget=1e-6, noise_estim=True)])
 def test_fit_with_the_restricted_likelihood(kw):
     """`fit(likelihood="restricted")` completes here (the reference raises TypeError at gpr.py:405 after optimising); the
@@ -1286,7 +1324,7 @@ def test_batch_proposal_over_device_generated_designs():
 
 def test_unsupported_combinations_are_refused_loudly(eng):
     """Entry points that serve a subset of the models say so with BOGP_ERR_UNSUPPORTED instead of computing something
-    else: the fused one-point call and the Hessian with a polynomial basis / a non-SE kernel, REML with several targets."""
+    else: the fused one-point call and the Hessian with a polynomial basis / a non-SE kernel, the REML gradient with several targets."""
     g = load_golden("G13_linear_uk_se")
     commit_trend_golden(eng, g)
     x = g["Xs"][0]
@@ -1301,8 +1339,8 @@ def test_unsupported_combinations_are_refused_loudly(eng):
     assert ei.value.code == _lib.ERR_UNSUPPORTED
     g17 = load_golden("G17_multitarget")
     eng.set_train(g17["X"], g17["y"])
-    with pytest.raises(_lib.BogpError) as ei:
-        eng.nll_restricted(0, 1, np.r_[g17["k0_m1_par"][0]], 1e-3, False, 0.0)
+    with pytest.raises(_lib.BogpError) as ei:  # (the value exists since r04: test_reml_with_several_targets_gives_the_reference_value)
+        eng.nll_restricted(0, 1, np.r_[g17["k0_m1_par"][0]], 1e-3, False, 0.0, eval_grad=True)
     assert ei.value.code == _lib.ERR_UNSUPPORTED
 
 

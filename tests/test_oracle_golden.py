@@ -336,6 +336,26 @@ def test_reml_tables():
     assert n == 48
 
 
+def test_reml_multitarget_tables():
+    """The restricted likelihood on y with 2 / 3 columns (G33, generated by importing the reference): the value the reference's
+    arithmetic yields -- scalar terms broadcast over the n_t x n_t matrix rho^T rho, everything summed (gpr.py:861-866)."""
+    g = load_golden("G33_reml_multitarget")
+    n = 0
+    for T in (2, 3):
+        for kid in (0, 2):
+            for mid in (0, 1, 2):
+                key = "T%d_k%d_m%d" % (T, kid, mid)
+                for p, v in zip(g[key + "_par"], g[key + "_llf"]):
+                    out = O.log_likelihood_restricted(p, g["X"], g["Y"][:, :T], kid, mid, noise_var=1e-4 if mid == 1 else 0.0,
+                                                      estimate_trend=False, beta=float(g["beta"]))  # fmt: skip
+                    if np.isneginf(v):
+                        assert np.isneginf(out)
+                    else:
+                        close(out, v, rtol=1e-11)
+                    n += 1
+    assert n == 36
+
+
 MT_NV = {0: 0.0, 1: 1e-3, 2: 0.0}  # nugget of G17's noisy-mode model
 
 
