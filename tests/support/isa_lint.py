@@ -11,8 +11,14 @@ convention:
   (b) every access to a register an MFMA has written -- by anything but an MFMA that takes the whole range as its accumulator
       operand (the accumulate chain) -- has at least `REQUIRED_WAIT_STATES` wait states of `s_nop` (`s_nop N` = N + 1) between that MFMA
       and itself.  Only the nops count: they are the drain the source wrote; any other instruction in between is there by the
-      scheduler's choice and may be gone with the next compiler.  18 is LLVM's own figure for a 16-pass FP64 MFMA result read by a VALU / memory instruction (GCNHazardRecognizer: DMFMA
-      16x16 write -> VALU / VMEM / LDS read), the largest of the family, applied to every MFMA here.
+      scheduler's choice and may be gone with the next compiler.  19 is what hipcc (ROCm 7.2) itself places behind the BUILTIN form of
+      v_mfma_f64_16x16x4_f64 on gfx950 before a VALU reads the result (`s_nop 15; s_nop 2`: the 16-pass DGEMM write -> VALU / VMEM / LDS
+      read rule of LLVM's GCNHazardRecognizer), the largest of the family, applied to every MFMA here;
+  (c) a register written by a VALU instruction is not read by an MFMA (as A, B or C) with fewer than `VALU_TO_MFMA_WAIT_STATES` = 2
+      wait states in between -- what hipcc places between a `v_mov` / `v_mul_f64` and the builtin MFMA that reads its result (`s_nop 1`).
+      Any instruction counts as one state here, `s_nop N` as N + 1.  The sources keep this distance by hand where they build MFMA operands
+      with VALU code (`s_nop 7; s_nop 7` in front of the chains of mma_64 / elim_step_block): to the compiler an inline-asm MFMA is just
+      another instruction, it pads nothing.
 
 The scan is linear in address order and every taken branch edge is followed from its target while a result is still pending (an MFMA at
 the bottom of a loop against a read at its top; an epilogue placed before the loop in the address space).  A pass is a guarantee of
@@ -26,7 +32,8 @@ import subprocess
 import tempfile
 
 LLVM_BIN = "/opt/rocm/lib/llvm/bin"
-REQUIRED_WAIT_STATES = 18
+REQUIRED_WAIT_STATES = 19
+VALU_TO_MFMA_WAIT_STATES = 2
 _REG = re.compile(r"\b([va])(?:\[(\d+):(\d+)\]|(\d+)\b)")
 _FUNC = re.compile(r"^[0-9a-f]+ <([^>]+)>:")
 _INSN = re.compile(r"^\s+([a-z_0-9]+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):")
@@ -97,7 +104,7 @@ def parse_functions(asm_text):
 
 
 def lint_function(insns, required=REQUIRED_WAIT_STATES, nops_only=True):
-    """Violations of rules (a) and (b) in one kernel: a list of strings (empty = clean).  `insns` as parse_functions gives them."""
+    """Violations of rules (a), (b) and (c) in one kernel: a list of strings (empty = clean).  `insns` as parse_functions gives them."""
     mfma_idx = [i for i, (_, mn, _) in enumerate(insns) if mn.startswith("v_mfma")]
     if not mfma_idx:
         return []
@@ -172,6 +179,44 @@ def lint_function(insns, required=REQUIRED_WAIT_STATES, nops_only=True):
                 if changed:
                     work.append(j)
     bad.extend(sorted(set(flagged.values())))
+
+    # (c): walk back from every MFMA over at most VALU_TO_MFMA_WAIT_STATES - 1 wait states of predecessors
+    pred = [[] for _ in range(n)]
+    for i in range(n):
+        for j in succ[i]:
+            pred[j].append(i)
+
+    def states(j):
+        _, mn, ops = insns[j]
+        if mn == "s_nop":
+            try:
+                return int(ops.split()[0], 0) + 1
+            except (ValueError, IndexError):
+                return 1
+        return 1
+
+    close = set()
+    for i in mfma_idx:
+        addr, mn, ops = insns[i]
+        o = _split_operands(ops)
+        src = _regs(o[1]) | _regs(o[2]) | (_regs(o[3]) if len(o) > 3 else set())
+        stack = [(j, 0) for j in pred[i]]  # (instruction, wait states between it and the MFMA)
+        seen = set()
+        while stack:
+            j, gap = stack.pop()
+            if (j, gap) in seen or gap >= VALU_TO_MFMA_WAIT_STATES:
+                continue
+            seen.add((j, gap))
+            _, pmn, pops = insns[j]
+            if pmn.startswith("v_") and not pmn.startswith("v_mfma") and pmn != "v_nop":
+                po = _split_operands(pops)
+                hit = (_regs(po[0]) if po else set()) & src
+                if hit:
+                    r = sorted(hit)[0]
+                    close.add("(c) %s at 0x%x reads %s%d %d wait state(s) after %s wrote it (< %d)" % (mn, addr, r[0], r[1], gap, pmn, VALU_TO_MFMA_WAIT_STATES))
+            for q in pred[j]:
+                stack.append((q, gap + states(j)))
+    bad.extend(sorted(close))
     return bad
 
 

@@ -1,6 +1,7 @@
 """ISA lint of the inline-asm MFMA kernels (tests/support/isa_lint.py): the gfx950 code objects of the library as built are disassembled
 and every kernel that issues a matrix instruction is checked for (a) scratch traffic between its first and last MFMA and (b) the
-hand-written `s_nop` drain sitting between an MFMA and the first access of its accumulator by anything but the next MFMA of the chain.
+hand-written `s_nop` drain sitting between an MFMA and the first access of its accumulator by anything but the next MFMA of the chain,
+and (c) two wait states between a VALU write and an MFMA that reads the register (r04 late: the distance hipcc keeps for its builtin).
 Two negative controls prove the lint can see what it is for: kernels_posterior.hip rebuilt WITHOUT the drain, and rebuilt without the
 empty volatile asms that pin the accumulators behind it (the r03 incident: hipcc then schedules epilogue reads above the drain) --
 both must be flagged.  CPU only: hipcc cross-compiles, llvm-objdump disassembles."""
@@ -61,13 +62,20 @@ def test_a_build_without_the_accumulator_fences_is_flagged(tmp_path):
 def test_the_lint_rules_on_hand_made_sequences():
     mk = lambda rows: [(4 * i, mn, ops) for i, (mn, ops) in enumerate(rows)]  # noqa: E731
     mf = ("v_mfma_f64_16x16x4_f64", "v[0:7], v[20:21], v[22:23], v[0:7]")
-    assert isa_lint.lint_function(mk([mf, mf, ("s_nop", "15"), ("s_nop", "1"), ("v_add_f64", "v[30:31], v[0:1], v[2:3]"), ("s_endpgm", "")])) == []
+    assert isa_lint.lint_function(mk([mf, mf, ("s_nop", "15"), ("s_nop", "2"), ("v_add_f64", "v[30:31], v[0:1], v[2:3]"), ("s_endpgm", "")])) == []
     bad = isa_lint.lint_function(mk([mf, ("s_nop", "15"), ("v_add_f64", "v[30:31], v[0:1], v[2:3]"), ("s_endpgm", "")]))
-    assert len(bad) == 4 and all("16 wait states" in b for b in bad)  # v0..v3, 16 < 18
+    assert len(bad) == 4 and all("16 wait states" in b for b in bad)  # v0..v3, 16 < 19
     # another MFMA reading the result as an A operand is an access too; the accumulate chain is not
     assert isa_lint.lint_function(mk([mf, ("v_mfma_f64_16x16x4_f64", "v[8:15], v[0:1], v[22:23], v[8:15]"), ("s_endpgm", "")]))
     # a loop: the read at the top is reached from the MFMA at the bottom through the back edge
     loop = mk([("v_mov_b32_e32", "v40, v3"), mf, ("s_cbranch_scc1", str(65536 - 3)), ("s_endpgm", "")])
     assert any("v_mov_b32" in b for b in isa_lint.lint_function(loop))
+    # (c) a VALU result read by an MFMA at once / one state later is flagged, two states later (s_nop 1, or two other instructions) is not
+    mv = ("v_mov_b32_e32", "v20, v3")
+    assert any(b.startswith("(c)") for b in isa_lint.lint_function(mk([mv, mf, ("s_endpgm", "")])))
+    assert any(b.startswith("(c)") for b in isa_lint.lint_function(mk([mv, ("s_nop", "0"), mf, ("s_endpgm", "")])))
+    assert isa_lint.lint_function(mk([mv, ("s_nop", "1"), mf, ("s_nop", "15"), ("s_nop", "2"), ("s_endpgm", "")])) == []
+    assert isa_lint.lint_function(mk([("v_mul_f64", "v[0:1], v[30:31], v[32:33]"), ("s_waitcnt", "vmcnt(0)"), ("s_nop", "0"), mf, ("s_endpgm", "")])) == []  # hipcc's own spacing
+    assert any(b.startswith("(c)") for b in isa_lint.lint_function(mk([("v_mul_f64", "v[6:7], v[30:31], v[32:33]"), ("s_nop", "0"), mf, ("s_endpgm", "")])))  # as SrcC
     # scratch between the first and the last MFMA
     assert any(b.startswith("(a)") for b in isa_lint.lint_function(mk([mf, ("scratch_store_dwordx2", "off, v[50:51], off"), mf, ("s_endpgm", "")])))
