@@ -1891,11 +1891,17 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const double* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, 0x7fffffff, 0x00020000);
 }
+#ifndef BOGP_STATE_AUX
+#define BOGP_STATE_AUX 2
+#endif
+// AUX = 2: non-temporal (the state tiles: touched once per pass, they should not push the solved panels out of the L2)
+template <int AUX = 0>
 __device__ __forceinline__ double buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff_doubles, unsigned soff_doubles) {
-  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, 8 * voff_doubles, 8 * soff_doubles, 0));
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, 8 * voff_doubles, 8 * soff_doubles, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t r, unsigned voff_doubles, unsigned soff_doubles) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, 8 * voff_doubles, 8 * soff_doubles, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, 8 * voff_doubles, 8 * soff_doubles, AUX);
 }
 __device__ __forceinline__ void stage_aside_b(double* lds, __amdgpu_buffer_rsrc_t r, int tid) {  // stage_aside for a 64 x 64 tile, lda = 64
   const unsigned srow = tid >> 5, scol = (tid & 31) * 2;
@@ -1967,7 +1973,7 @@ __global__ __launch_bounds__(256, 2) void k_elim_updateS_b(const BatchSlot* __re
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[ia][ib][mi][t] = -buf_load(Tb, voff, (unsigned)(16 * mi + 4 * t) * ldt);
+          for (int t = 0; t < 4; ++t) acc[ia][ib][mi][t] = -buf_load<BOGP_STATE_AUX>(Tb, voff, (unsigned)(16 * mi + 4 * t) * ldt);
       } else {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) acc[ia][ib][mi] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -2012,7 +2018,7 @@ __global__ __launch_bounds__(256, 2) void k_elim_updateS_b(const BatchSlot* __re
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) buf_store(-acc[ia][ib][mi][t], Tb, voff, (unsigned)(16 * mi + 4 * t) * ldt);
+        for (int t = 0; t < 4; ++t) buf_store<BOGP_STATE_AUX>(-acc[ia][ib][mi][t], Tb, voff, (unsigned)(16 * mi + 4 * t) * ldt);
       if (kn >= a.nb) continue;
       if (bj == kn && bi > kn) {
         const unsigned vo = (unsigned)lk * lde + 16 * w + (lane & 15);
