@@ -466,10 +466,17 @@ template <int KERNEL, int Q>
 __global__ __launch_bounds__(256) void k_grad_contract_b(const double* __restrict__ X, int N, int d, const BatchSlot* __restrict__ slots,
                                                          int Np, int ld) {
   const BatchSlot& sl = slots[blockIdx.z];
-  GradVecs gv;
-  gv.v = sl.gamma; gv.stride = (size_t)Np; gv.n = 1; gv.c0 = 1.0;
-  for (int t = 0; t < BOGP_MAX_TARGETS; ++t) gv.cA[t] = gv.cB[t] = 0.0;
-  gv.dcoef = sl.scal + 4 * BOGP_MAX_TARGETS;
+  // the weights' descriptor in LDS, one per workgroup: built in registers it went to SCRATCH (the tile routine indexes its arrays at run time) --
+  // 176 B a lane, 470 MB of writes a launch at N = 2048, P = 16 (WRITE_SIZE of profiles/r04_elim_batch_pmc.txt; the one-evaluation kernel
+  // takes it as a kernel argument)
+  __shared__ __attribute__((aligned(16))) unsigned char gv_raw[sizeof(GradVecs)];  // (raw: the struct has default member initialisers)
+  GradVecs& gv = *reinterpret_cast<GradVecs*>(gv_raw);
+  if (threadIdx.x == 0) {
+    gv.v = sl.gamma; gv.stride = (size_t)Np; gv.n = 1; gv.c0 = 1.0;
+    for (int t = 0; t < BOGP_MAX_TARGETS; ++t) gv.cA[t] = gv.cB[t] = 0.0;
+    gv.dcoef = sl.scal + 4 * BOGP_MAX_TARGETS;
+  }
+  __syncthreads();
   grad_contract_tile<KERNEL, Q>(X, N, d, sl.theta, gv, nullptr, 0.0, sl.Rinv, ld, 1, (size_t)ld * ld, sl.partial);
 }
 
