@@ -166,13 +166,30 @@ template <int KERNEL>
 __device__ __forceinline__ double dtheta_weight(double diff) {
   return KERNEL == BOGP_KERNEL_ABSEXP ? fabs(diff) : diff * diff;
 }
+// r0 = corr_profile(s2) and h (the comment above) with the square root and the exponential they share evaluated once: the likelihood gradient's
+// pair work (k_grad_contract, k_nll_small)
 template <int KERNEL>
-__device__ __forceinline__ double corr_dtheta_profile(double s2, double r) {
-  if (KERNEL == BOGP_KERNEL_SE || KERNEL == BOGP_KERNEL_ABSEXP) return r;
+__device__ __forceinline__ void corr_pair(double s2, double& r0, double& h) {
+  if (KERNEL == BOGP_KERNEL_SE || KERNEL == BOGP_KERNEL_ABSEXP) {
+    r0 = exp(-s2);
+    h = r0;
+    return;
+  }
   const double D = sqrt(s2);
-  if (KERNEL == BOGP_KERNEL_MATERN32) return 1.5 * exp(-1.7320508075688772 * D);
-  if (KERNEL == BOGP_KERNEL_MATERN52) return (5.0 / 6.0) * (1.0 + 2.23606797749979 * D) * exp(-2.23606797749979 * D);
-  return D > 0.0 ? 0.5 * r / D : 0.0;
+  if (KERNEL == BOGP_KERNEL_MATERN12) {
+    r0 = exp(-D);
+    h = D > 0.0 ? 0.5 * r0 / D : 0.0;
+  } else if (KERNEL == BOGP_KERNEL_MATERN32) {
+    const double K = D * 1.7320508075688772;
+    const double E = exp(-K);
+    r0 = (1.0 + K) * E;
+    h = 1.5 * E;
+  } else {
+    const double K = D * 2.23606797749979;
+    const double E = exp(-K);
+    r0 = (1.0 + K + (K * K) * 0.3333333333333333) * E;
+    h = (5.0 / 6.0) * (1.0 + K) * E;
+  }
 }
 
 // scipy.special.ndtr (cephes ndtr.c) branch structure on top of the device erf/erfc:

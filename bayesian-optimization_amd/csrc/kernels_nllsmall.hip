@@ -55,32 +55,6 @@ __device__ __forceinline__ double ns_block_sum(double v, double* red /* [NS_WAVE
   return s;
 }
 
-// r0 = corr_profile(s2) and h = corr_dtheta_profile(s2, r0) with the square root and the exponential they share evaluated once
-// (the same operations on the same values: bit-identical to the two calls)
-template <int KERNEL>
-__device__ __forceinline__ void ns_corr_pair(double s2, double& r0, double& h) {
-  if (KERNEL == BOGP_KERNEL_SE || KERNEL == BOGP_KERNEL_ABSEXP) {
-    r0 = exp(-s2);
-    h = r0;
-    return;
-  }
-  const double D = sqrt(s2);
-  if (KERNEL == BOGP_KERNEL_MATERN12) {
-    r0 = exp(-D);
-    h = D > 0.0 ? 0.5 * r0 / D : 0.0;
-  } else if (KERNEL == BOGP_KERNEL_MATERN32) {
-    const double K = D * 1.7320508075688772;
-    const double E = exp(-K);
-    r0 = (1.0 + K) * E;
-    h = 1.5 * E;
-  } else {
-    const double K = D * 2.23606797749979;
-    const double E = exp(-K);
-    r0 = (1.0 + K + (K * K) * 0.3333333333333333) * E;
-    h = (5.0 / 6.0) * (1.0 + K) * E;
-  }
-}
-
 }  // namespace
 
 // out_scal: [0] sum(log diag L), [1] |Ft|, [2] Ft.Yt, [3] rho.rho, [62] the info word (int); out_S: the d + 1 contractions,
@@ -451,7 +425,7 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
           const double gi = gam[i];
           double r0[4], hh[4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) ns_corr_pair<KERNEL>(s2[c], r0[c], hh[c]);  // (side by side, see the prologue)
+          for (int c = 0; c < 4; ++c) corr_pair<KERNEL>(s2[c], r0[c], hh[c]);  // (side by side, see the prologue)
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const int j = 4 * sbj + c;

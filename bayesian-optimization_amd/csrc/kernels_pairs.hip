@@ -35,7 +35,10 @@ __device__ __forceinline__ void stage_points(double* dst, const double* __restri
 }
 
 // the same for a tile side of 16 Q points (Q = 4: stage_points)
-template <int Q>
+// PERM: point p of the tile goes to slot (p % Q) 16 + p / Q, so that the 16 lanes tx of a row of threads, which own the points Q tx + c, read
+// consecutive words for a given c (in point order their reads are Q doubles apart: 4-way bank conflicts at Q = 4, ~7 % of k_grad_contract's time,
+// profiles/r04_elim_batch_pmc.txt)
+template <int Q, bool PERM = false>
 __device__ __forceinline__ void stage_points_q(double* dst, const double* __restrict__ X, int N, int d, int p0, int kc, int tid) {
   constexpr int PTQ = 16 * Q, PPQ = PTQ + 1;
 #pragma unroll
@@ -43,7 +46,7 @@ __device__ __forceinline__ void stage_points_q(double* dst, const double* __rest
     const int idx = tid + 256 * it;
     const int p = idx / KC, kk = idx % KC;
     const int gp = p0 + p, gk = kc + kk;
-    dst[kk * PPQ + p] = (gp < N && gk < d) ? X[(size_t)gp * d + gk] : 0.0;
+    dst[kk * PPQ + (PERM ? (p % Q) * 16 + p / Q : p)] = (gp < N && gk < d) ? X[(size_t)gp * d + gk] : 0.0;
   }
 }
 
@@ -374,7 +377,7 @@ __device__ __forceinline__ void grad_contract_tile(const double* __restrict__ X,
     for (int c = 0; c < Q; ++c) s2[r][c] = 0.0;
   for (int kc = 0; kc < d; kc += KC) {
     __syncthreads();
-    stage_points_q<Q>(xi, X, N, d, i0, kc, tid);
+    stage_points_q<Q, true>(xi, X, N, d, i0, kc, tid);
     stage_points_q<Q>(xj, X, N, d, j0, kc, tid);
     __syncthreads();
     const int kn = min(KC, d - kc);
@@ -384,7 +387,7 @@ __device__ __forceinline__ void grad_contract_tile(const double* __restrict__ X,
 #pragma unroll
       for (int r = 0; r < Q; ++r) vj[r] = xj[kk * PPQ + Q * ty + r];
 #pragma unroll
-      for (int c = 0; c < Q; ++c) vi[c] = xi[kk * PPQ + Q * tx + c];
+      for (int c = 0; c < Q; ++c) vi[c] = xi[kk * PPQ + 16 * c + tx];
 #pragma unroll
       for (int r = 0; r < Q; ++r)
 #pragma unroll
@@ -400,8 +403,8 @@ __device__ __forceinline__ void grad_contract_tile(const double* __restrict__ X,
       const int i = i0 + Q * tx + c, j = j0 + Q * ty + r;
       double bb = 0.0;
       if (i < j && j < N) {
-        const double r0 = corr_profile<KERNEL>(s2[r][c]);
-        const double h = corr_dtheta_profile<KERNEL>(s2[r][c], r0);
+        double r0, h;  // corr_profile and corr_dtheta_profile with the square root and the exponential they share evaluated once
+        corr_pair<KERNEL>(s2[r][c], r0, h);
         double rinv = 0.0;  // element (j, i) of the lower triangle, column-major
         for (int q = 0; q < nparts; ++q) rinv += Rinv[q * part_stride + (size_t)i * ld + j];
         // A = sum_t c_t gamma_t gamma_t^T - c0 R^-1: one vector per target (gpr.py:996-1037 with n_targets columns);
@@ -429,7 +432,7 @@ __device__ __forceinline__ void grad_contract_tile(const double* __restrict__ X,
   // ---- pass 2: the d contractions, 16 dimensions at a time ---------------------------------------------
   for (int kc = 0; kc < d; kc += KC) {
     __syncthreads();
-    stage_points_q<Q>(xi, X, N, d, i0, kc, tid);
+    stage_points_q<Q, true>(xi, X, N, d, i0, kc, tid);
     stage_points_q<Q>(xj, X, N, d, j0, kc, tid);
     __syncthreads();
     const int kn = min(KC, d - kc);
@@ -438,7 +441,7 @@ __device__ __forceinline__ void grad_contract_tile(const double* __restrict__ X,
 #pragma unroll
       for (int r = 0; r < Q; ++r) vj[r] = xj[kk * PPQ + Q * ty + r];
 #pragma unroll
-      for (int c = 0; c < Q; ++c) vi[c] = xi[kk * PPQ + Q * tx + c];
+      for (int c = 0; c < Q; ++c) vi[c] = xi[kk * PPQ + 16 * c + tx];
       double acc = 0.0;
 #pragma unroll
       for (int r = 0; r < Q; ++r)
