@@ -1880,9 +1880,11 @@ __global__ __launch_bounds__(256) void k_elim_updateG_b(const BatchSlot* __restr
 // N = 2048) do not stay in an XCD's 4-MB L2 next to the streaming state, and the kernel sits at ~47 % of the matrix peak on those
 // fetches (profiles/r04_nll_batch_group.txt).  Here a workgroup owns the 2 x 2 blocks (2 BI + a, 2 BJ + b): per step it stages the TWO
 // A-side tiles X_{2BJ}, X_{2BJ+1} and loads the TWO B-side fragments X_{2BI}, X_{2BI+1} for FOUR products -- half the fetches per
-// flop.  Every block still sees exactly the mma_64 calls of k_elim_updateG_b on the same operands in the same order (its own
-// first step .. klast), then elim_store_block: the same bits.  Blocks above the diagonal or outside the nb + 1 block rows / nb block
-// columns are skipped (workgroup-uniform).
+// flop.  Every block still sees the accumulations of k_elim_updateG_b on the same operands in the same order (its own first step ..
+// klast; mma_64v2 issues mma_64's instructions for two block rows at once), then elim_store_block's stores: the same bits.  Blocks above
+// the diagonal or outside the nb + 1 block rows / nb block columns are computed and discarded, a block that restarts inside the group is
+// zeroed when the loop reaches its step (no per-block control flow around the MFMA chains: see the kernel).  The next diagonal block is
+// factored by k_elim_diag_b.
 // (buffer accesses: a uniform descriptor, ONE 32-bit lane offset and a scalar offset per access.  The slot's pointers come out of memory,
 // i.e. generic, and a generic / global access costs a 64-bit address pair per load that the compiler keeps live across the step loop --
 // ~100 VGPRs in this kernel, which has none to spare)
