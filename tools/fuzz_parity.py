@@ -94,6 +94,10 @@ def one(seed, eng, orc):
     compare = cond <= 1e12
     tol = max(1e-8, 100.0 * cond * 2.2e-16)  # likelihood tolerance: both sides carry cond(R) eps
     ptol = max(1e-6, 100.0 * cond * 2.2e-16)  # posterior / criterion tolerance
+    if kernel == O.KERNEL_MATERN_NU:
+        # the entries of R themselves differ here: the device's K_nu is held to scipy's at 6e-14 relative (tests/test_oracle_golden.py), ~270 eps,
+        # and cond(R) amplifies that like any other perturbation of the matrix (seed 960921: cond 8e9, mu 1.5e-4 apart)
+        tol, ptol = max(tol, 3.0 * cond * 6e-14), max(ptol, 3.0 * cond * 6e-14)
     eng.set_train(X, y)
     orc.set_train(X, y)
     fails = []
