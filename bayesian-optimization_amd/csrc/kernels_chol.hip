@@ -1640,12 +1640,13 @@ __device__ __forceinline__ void elim_store_block(const ElimArgs& a, int k, int b
   elim_diag2(lds, sb, Wn, a.logpart + kn, a.info, CB * kn, 0, max(0, min(CB, a.N - CB * kn)), Pnext, a.ld + CB, kn, threadIdx.x);
 }
 
-__device__ __forceinline__ void elim_step_block(const ElimArgs& a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
-                                                double* __restrict__ Pnext, double* __restrict__ Wn) {
+// XROW >= 0 (the group chain of a batch, k_elim_substep_b): this workgroup also leaves the solved block of block row XROW (= bi or bj) in
+// `Xout` (the layout of k_elim_panel_b) and, for the right-hand sides' row, Yt / Ft of block k -- what the separate panel launch would have
+// written for that row
+__device__ __forceinline__ void elim_step_core(const ElimArgs& a, int k, int bi, int bj, const double* __restrict__ Wk, const double* __restrict__ Pcur,
+                                               double* __restrict__ Pnext, double* __restrict__ Wn, int xrow, double* __restrict__ Xout) {
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
   __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
-  int bi, bj;
-  tri_index((int)blockIdx.x, bi, bj);  // bi <= nb (block row nb = the right-hand sides); (nb, nb) is not launched
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lk = lane >> 4;
@@ -1679,12 +1680,19 @@ __device__ __forceinline__ void elim_step_block(const ElimArgs& a, int k, const 
 #pragma unroll
       for (int t = 0; t < 4; ++t) xi[mi][t] = xj[mi][t];
   }
-  if (bi == a.nb && bj == k && w == 0 && (lane & 15) < 2) {  // rows 0 / 1 of the solved right-hand sides: Yt, Ft of block k
+  if (bi == a.nb && (bj == k || xrow == a.nb) && w == 0 && (lane & 15) < 2) {  // rows 0 / 1 of the solved right-hand sides: Yt, Ft of block k
     double* dst = (lane & 15) == 0 ? a.yt : a.ft;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int t = 0; t < 4; ++t) dst[CB * k + 16 * mi + 4 * t + lk] = xi[mi][t];
+  }
+  if (xrow >= 0) {  // element (row, col) of X_xrow at Xout[row + 64 col]
+    const bool from_i = xrow == bi;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Xout[(size_t)(16 * mi + 4 * t + lk) * CB + 16 * w + (lane & 15)] = from_i ? xi[mi][t] : xj[mi][t];
   }
   __syncthreads();  // every wave is done with the W tile
   // A side of the update: tile[kk][c] = X_j(c, kk)
@@ -1703,6 +1711,12 @@ __device__ __forceinline__ void elim_step_block(const ElimArgs& a, int k, const 
   __syncthreads();
   mma_64(lds, bv, acc, lane);  // -T_new = -T_old + X_i X_j^T
   elim_store_block(a, k, bi, bj, acc, Tb, ldt, lds, sb, Pnext, Wn);
+}
+__device__ __forceinline__ void elim_step_block(const ElimArgs& a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
+                                                double* __restrict__ Pnext, double* __restrict__ Wn) {
+  int bi, bj;
+  tri_index((int)blockIdx.x, bi, bj);  // bi <= nb (block row nb = the right-hand sides); (nb, nb) is not launched
+  elim_step_core(a, k, bi, bj, Wk, Pcur, Pnext, Wn, -1, nullptr);
 }
 __global__ __launch_bounds__(256) void k_elim_step(const ElimArgs a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
                                                    double* __restrict__ Pnext, double* __restrict__ Wn) {
@@ -1809,6 +1823,25 @@ __global__ __launch_bounds__(256) void k_elim_update_b(const BatchSlot* __restri
   int bi, bj;
   tri_index(blk, bi, bj);
   elim_update_one(slots[slot], k, bi, bj, lds, sb);
+}
+
+// The group chain's step in ONE launch: the sub-mode update with the solved panel formed by the workgroups themselves (elim_step_core: X_i, X_j
+// from the raw panel and W_k, the fused kernel's three products a block -- free here, the launch is a handful of blocks per slot waiting for its
+// diagonal block's factorisation).  The workgroups of the first column (ci = 0: one per block row t) leave X^k_t in the solved panel for the
+// whole-state update that follows the group.  Saves the k_elim_panel_b launch of every step but the group's last (13 us each).
+__global__ __launch_bounds__(256) void k_elim_substep_b(const BatchSlot* __restrict__ slots, int k, int ncol) {
+  const BatchSlot& sl = slots[blockIdx.y];
+  const ElimArgs& a = sl.ea;
+  const int nb1 = a.nb + 1;
+  const int ci = (int)blockIdx.x / nb1, t = (int)blockIdx.x % nb1;
+  const int c0 = k + 1, c = c0 + ci;
+  if (t >= c0 && t < c) return;  // block (c, t) already belongs to the earlier column / row t of this launch
+  const size_t lde = (size_t)a.ld + CB;
+  double* P0 = sl.panels;
+  double* P1 = sl.panels + lde * CB;
+  double* Xout = sl.xpanel + (size_t)(k & 3) * ((size_t)a.nb + 1) * CB * CB + (size_t)t * CB * CB;
+  elim_step_core(a, k, t <= c ? c : t, t <= c ? t : c, sl.Winv + (size_t)k * CB * CB, (k & 1) ? P1 : P0, (k & 1) ? P0 : P1,
+                 sl.Winv + (size_t)(k + 1) * CB * CB, ci == 0 ? t : -1, Xout);
 }
 
 // ---- GROUPED steps: two or four block columns per pass over the state (r04) ----------------------------------------------------------
@@ -2181,7 +2214,17 @@ hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double
   const bool super_tiles = super_from > 0 && (long)sgrid * P >= super_from;
   const unsigned gs = xcd_local ? (unsigned)(8 * (((long)sgrid * P + 7) / 8)) : (unsigned)sgrid;
   // the panel chain of the group k .. k + ng - 1: X^(k+g), then step k + g on the blocks of the columns / rows k + g + 1 .. k + ng - 1
+  // the chain's steps as ONE launch each (k_elim_substep_b: the panel formed by the update's own workgroups) while the first of them is at most
+  // BOGP_ELIM_SUBSTEP blocks (default 600; 0 = never): -4 % a batch at P = 2 .. 4, +2 % at P = 16 (N = 2048), where the tripled products cost
+  // more than the saved launch
+  static const long substep_upto = [] { const char* e = getenv("BOGP_ELIM_SUBSTEP"); return e ? atol(e) : 600L; }();
   auto chain = [&](int k, int ng, hipStream_t s) {
+    if ((long)(ng - 1) * (nb + 1) * P <= substep_upto && ng > 1) {
+      for (int g = 0; g + 1 < ng; ++g)
+        hipLaunchKernelGGL(k_elim_substep_b, dim3((unsigned)((ng - 1 - g) * (nb + 1)), P), 256, 0, s, slots, k + g, ng - 1 - g);
+      hipLaunchKernelGGL(k_elim_panel_b, dim3(nb + 1, P), 256, 0, s, slots, k + ng - 1);
+      return;
+    }
     for (int g = 0; g < ng; ++g) {
       hipLaunchKernelGGL(k_elim_panel_b, dim3(nb + 1, P), 256, 0, s, slots, k + g);
       if (g + 1 < ng) hipLaunchKernelGGL(k_elim_update_b, dim3((unsigned)((ng - 1 - g) * (nb + 1)), P), 256, 0, s, slots, k + g, -(ng - 1 - g), k + g + 1, P);

@@ -18,6 +18,9 @@ VARIANTS = {
     "split-ungrouped": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "0", "BOGP_ELIM_GROUP": "1"},
     "split-pairs": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "0", "BOGP_ELIM_GROUP": "2"},
     "split-no-xcd": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "0", "BOGP_ELIM_XCD": "0"},
+    "split-fused-substeps": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "0", "BOGP_ELIM_SUBSTEP": "1000000"},
+    "super-fused-substeps": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "1", "BOGP_ELIM_SUBSTEP": "1000000"},
+    "split-separate-panels": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "0", "BOGP_ELIM_SUBSTEP": "0"},
     "super": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "1"},
     "super-pairs": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "1", "BOGP_ELIM_GROUP": "2"},
     "super-no-xcd": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "1", "BOGP_ELIM_XCD": "0"},
