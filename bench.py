@@ -215,6 +215,14 @@ def main():
         for _ in range(3):
             eng.nll_batch(w["kernel"], _lib.MODE_NOISY, pars10, 1e-6, False, 0.0, eval_grad=True)
         fit_ms["llf_grad_ms_per_evaluation_in_a_batch_of_10"] = (time.perf_counter() - t0) / 3 / 10 * 1e3
+        # a whole MLE the lock-step way (bogp_mle_batch = GaussianProcess(restart_batch=10)): 10 restarts around the pinned parameters,
+        # a shared budget of 400 likelihood + gradient evaluations, log10 search box of 2.5 decades per parameter
+        x0 = np.log10(pars10)
+        t0 = time.perf_counter()
+        _, _, nev, _, rounds = eng.mle_batch(w["kernel"], _lib.MODE_NOISY, x0, np.log10(par) - 1.5, np.log10(par) + 1.0, 1e-6, False, 0.0,
+                                             eval_budget=400)
+        fit_ms["mle_10_restarts_in_lock_step_ms"] = (time.perf_counter() - t0) * 1e3
+        fit_ms["mle_evaluations"], fit_ms["mle_device_rounds"] = int(np.sum(nev)), int(rounds)
         t0 = time.perf_counter()
         eng.commit(w["kernel"], _lib.MODE_NOISY, par, 1e-6, False, 0.0)
         fit_ms["commit_ms"] = (time.perf_counter() - t0) * 1e3
