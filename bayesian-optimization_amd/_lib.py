@@ -18,7 +18,8 @@ KERNEL_SE, KERNEL_MATERN12, KERNEL_MATERN32, KERNEL_MATERN52, KERNEL_ABSEXP, KER
 MODE_NOISELESS, MODE_NOISY, MODE_NOISE_ESTIM = 0, 1, 2
 ACQ_EI, ACQ_EPSILON_PI, ACQ_UCB, ACQ_MGFI = 0, 1, 2, 3
 TREND_CONSTANT, TREND_LINEAR, TREND_QUADRATIC = 0, 1, 2
-ABI_VERSION = 8  # BOGP_ABI_VERSION of include/bogp.h this binding table was written for
+SELFTEST_PROFILE, SELFTEST_BESSEL_K, SELFTEST_RGAMMA, SELFTEST_BESSEL_K_PAIRS, SELFTEST_MATERN_NU_PAIRS = range(5)
+ABI_VERSION = 9  # BOGP_ABI_VERSION of include/bogp.h this binding table was written for
 MAX_Q = 64
 MAX_TARGETS = 8
 COMM_ID_BYTES = 128
@@ -81,6 +82,7 @@ SIGNATURES = {
     "bogp_last_timing": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip]),
     "bogp_flops_per_candidate": (C.c_double, [C.c_void_p]),
     "bogp_nll_path": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "bogp_selftest_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, _dp, C.c_int64, _dp]),
     "bogp_selftest_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, C.c_int, C.c_double, _dp, C.c_int, C.c_int, C.c_int]),
 }
 
@@ -711,3 +713,14 @@ class Engine:
 
     def flops_per_candidate(self) -> float:
         return float(self._lib.bogp_flops_per_candidate(self._h))
+
+    def selftest_profile(self, what, arg, kernel=0, pexp=0.0):
+        """`what` (SELFTEST_*) of every entry of `arg` on the device: the radial profile of `kernel`, K_pexp or 1 / Gamma exactly as the
+        producers evaluate them per pair (csrc/bogp_device.h).  The *_PAIRS selectors take an (n, 2) array of (order, argument) rows."""
+        arg = np.ascontiguousarray(arg, dtype=np.float64)
+        n = arg.shape[0] if what >= SELFTEST_BESSEL_K_PAIRS else arg.size
+        if what >= SELFTEST_BESSEL_K_PAIRS and (arg.ndim != 2 or arg.shape[1] != 2):
+            raise ValueError("the *_PAIRS selectors take an (n, 2) array")
+        out = np.empty(n)
+        self._check(self._lib.bogp_selftest_profile(self._h, int(what), int(kernel), float(pexp), _ptr(arg), n, _ptr(out)))
+        return out

@@ -114,7 +114,7 @@ static void free_train(bogp_handle* h) {
   dfree(h->dyt_base); dfree(h->dft); dfree(h->drho_base); dfree(h->dtmp); dfree(h->dgamma_base); dfree(h->dw);
   h->dyt = h->drho = h->dgamma = nullptr;
   h->n_t = 1; h->target = 0;
-  dfree(h->dtheta); h->dsqrt_theta = nullptr; dfree(h->dXthT); dfree(h->dVp);
+  dfree(h->dtheta); h->dsqrt_theta = nullptr; dfree(h->dXthT); dfree(h->dXnorm); dfree(h->dVp);
   free_trend(h);
   h->committed = false;
   h->cap_ld = h->cap_d = h->cap_nt = 0;
@@ -1003,7 +1003,8 @@ extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* p
   }
   // [d][Np] + two zero rows: k_sweep_small walks the dimensions three at a time
   if (!h->dXthT) HIPCHK(h, hipMalloc((void**)&h->dXthT, (size_t)(h->cap_d + 2) * h->cap_ld * sizeof(double)));
-  HIPCHK(h, launch_scale_transpose(h->dX, N, d, Np, h->dsqrt_theta, h->dXthT, st));
+  if (!h->dXnorm) HIPCHK(h, hipMalloc((void**)&h->dXnorm, (size_t)h->cap_ld * sizeof(double)));
+  HIPCHK(h, launch_scale_transpose(h->dX, N, d, Np, h->dsqrt_theta, h->dXthT, h->dXnorm, st));
   HIPCHK(h, hipMemsetAsync(h->dXthT + (size_t)d * Np, 0, (size_t)2 * Np * sizeof(double), st));
   HIPCHK(h, hipStreamSynchronize(st));
   h->kernel = kernel; h->mode = mode; h->estimate_trend = estimate_trend;
@@ -1603,7 +1604,7 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     const int64_t Mc_eff = ((mcount + 63) / 64) * 64;  // rows actually launched; array stride stays Mc
     CorrArgs ca;
     ca.Xs = h->dXs; ca.M = M; ca.m0 = m0; ca.Mc = Mc; ca.d = d; ca.Np = Np; ca.nblk_per_split = nblk_per_split;
-    ca.sqrt_theta = h->dsqrt_theta; ca.XthT = h->dXthT; ca.gamma = h->dgamma; ca.wvec = h->dw;
+    ca.sqrt_theta = h->dsqrt_theta; ca.XthT = h->dXthT; ca.xnorm = h->dXnorm; ca.gamma = h->dgamma; ca.wvec = h->dw;
     ca.rT = h->drT[b]; ca.mu_part = h->dmu_part[b]; ca.w_part = h->dw_part[b];
     if (pv > 0) {
       ca.pv = pv; ca.Wrow = h->dWpT; ca.wld = (h->p + 127) / 128 * 128; ca.t_part = h->dtpart[b];

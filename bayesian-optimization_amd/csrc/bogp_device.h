@@ -52,38 +52,105 @@ __device__ __forceinline__ double dist_accumulate(double diff_scaled, double acc
 }
 
 // ---- modified Bessel function of the second kind K_nu(x), real order nu >= 0, x > 0 -----------------------------------------------
-// What the reference gets from scipy.special.kv in the general-nu arm of its Matern kernel (kernel.py:201-207).  Method: with
-// nu = mu + n, |mu| <= 1/2, K_mu and K_mu+1 come from Temme's series (N. M. Temme, J. Comput. Phys. 19 (1975)) for x <= 2 and from
-// the continued fraction CF2 evaluated by Steed's algorithm (I. J. Thompson, A. R. Barnett, J. Comput. Phys. 64 (1986)) for x > 2;
-// the order is then raised by the (upward-stable) recurrence K_{m+1} = K_{m-1} + (2 m / x) K_m.  Relative accuracy ~1e-14 (measured
-// against scipy on the CPU restatement of the same steps, tests/test_oracle_golden.py), far inside the path's 1e-6.
-// 1 / Gamma(1 +- mu) come from the device's tgamma; their scaled difference gam1 = (1/Gamma(1-mu) - 1/Gamma(1+mu)) / (2 mu)
-// switches to its Taylor form -(g + a3 mu^2) below |mu| = 1e-4 (g = Euler's constant, a3 = the cubic coefficient of 1 / Gamma(1 + z),
-// Abramowitz & Stegun 6.1.34), where the difference would cancel.
-__device__ __forceinline__ double bessel_k_nu(double nu, double x) {
-  const double EPS = 1.0e-16, PI = 3.141592653589793;
+// What the reference gets from scipy.special.kv in the general-nu arm of its Matern kernel (kernel.py:201-207).  scipy's kv (AMOS zbesk) is
+// itself up to ~500 eps from the true value on nu in (0, 10], x in [1e-8, 700] (profiles/r05_kv_accuracy.txt, against mpmath at 40 digits), so
+// the target here is the TRUE value: <= 5 eps over that domain (same file; tests/test_gpu_special.py holds the device to a committed mpmath table).
+// Method, with nu = mu + n, |mu| <= 1/2:
+//   * x <= 1: Temme's series (N. M. Temme, J. Comput. Phys. 19 (1975) 324) for K_mu, K_mu+1.  1/Gamma(1 -+ mu) and their scaled difference
+//     gam1 = (1/Gamma(1-mu) - 1/Gamma(1+mu)) / (2 mu), gam2 = their mean, come from Chebyshev expansions in 8 mu^2 - 1 (coefficients by mpmath,
+//     tools/kv_coefficients.py) -- no cancellation at any mu; (x/2)^(-+mu) from pow(), whose exponent reduction is exact, not from exp(mu log(x/2)),
+//     which loses |mu log(x/2)| eps at small x;
+//   * x > 1: the trapezoidal rule on K_mu(x) = e^-x int_0^inf exp(-2 x sinh^2(t/2)) cosh(mu t) dt with step min(0.2, 0.55 / sqrt(x)): the
+//     integrand is analytic in |Im t| < pi/2, so the rule converges geometrically (~20 points for 1e-17), every term is positive (no cancellation)
+//     and e^-x is factored out so that the exponent's rounding error is relative to 2 x sinh^2, not to x.  (Steed's CF2, used until r04,
+//     accumulates ~10 eps of recurrence rounding over its 30-170 iterations at x in [1, 3].)
+//   * the order is raised by the upward-stable recurrence K_{m+1} = K_{m-1} + (2 m / x) K_m in double-double arithmetic, so that the n <= 10
+//     steps add nothing to the error of the two starting values.
+// `rgamma_nu` (out): 1 / Gamma(nu) from the same expansion, Gamma(nu) = Gamma(1 + mu) prod_{i=1}^{n-1} (mu + i)  (Gamma(1 + mu) / mu for n = 0).
+struct DD {
+  double h, l;
+};
+__device__ __forceinline__ DD dd_fast_sum(double a, double b) {  // |a| >= |b|
+  const double s = a + b;
+  return {s, b - (s - a)};
+}
+__device__ __forceinline__ DD dd_sum(double a, double b) {
+  const double s = a + b, bb = s - a;
+  return {s, (a - (s - bb)) + (b - bb)};
+}
+__device__ __forceinline__ DD dd_mul(DD a, DD b) {
+  const double p = a.h * b.h;
+  double e = __builtin_fma(a.h, b.h, -p);
+  e = __builtin_fma(a.h, b.l, __builtin_fma(a.l, b.h, e));
+  return dd_fast_sum(p, e);
+}
+__device__ __forceinline__ DD dd_add(DD a, DD b) {
+  DD s = dd_sum(a.h, b.h);
+  s.l += a.l + b.l;
+  return dd_fast_sum(s.h, s.l);
+}
+__device__ __forceinline__ DD dd_div_d(DD a, double x) {
+  const double q1 = a.h / x;
+  const double r = __builtin_fma(-q1, x, a.h) + a.l;
+  return dd_fast_sum(q1, r / x);
+}
+__device__ __forceinline__ double cheb_even(const double* c, int n, double t) {  // Clenshaw: sum_j c_j T_j(t)
+  double b1 = 0.0, b2 = 0.0;
+  const double t2 = 2.0 * t;
+  for (int j = n - 1; j >= 1; --j) {
+    const double b0 = __builtin_fma(t2, b1, c[j] - b2);
+    b2 = b1;
+    b1 = b0;
+  }
+  return __builtin_fma(t, b1, c[0] - b2);
+}
+__device__ __forceinline__ double bessel_k_nu(double nu, double x, double* rgamma_nu = nullptr) {
+  const double PI = 3.141592653589793;
+  // gam1, gam2 on |mu| <= 1/2 as Chebyshev series in t = 8 mu^2 - 1 (truncation < 1e-18)
+  const double G1[9] = {-0.5710113401855839203,    0.0065165112670736880645,  0.00030870901730853682431,
+                        -3.470626964904317836e-6,  6.9437664486674495957e-9,  3.6779539885744101652e-11,
+                        -1.3563951023664248708e-13, -3.6802984806357979599e-17, 5.4582162333769858553e-19};
+  const double G2[10] = {0.92187029365045265648,     -0.07685284084478667369,    0.0012719271366545622927, -4.9717367041957398581e-6,
+                         -3.3126119768180852711e-8,  2.4230957900482704055e-10,  -1.7023776642512729175e-13, -1.4943667065169001769e-15,
+                         2.3826220476859635824e-18,  2.9017595056104745456e-21};
   const int nl = (int)(nu + 0.5);
   const double mu = nu - (double)nl, mu2 = mu * mu;
+  const double tc = __builtin_fma(8.0, mu2, -1.0);
+  const double gam1 = cheb_even(G1, 9, tc), gam2 = cheb_even(G2, 10, tc);
+  const double gampl = __builtin_fma(-mu, gam1, gam2), gammi = __builtin_fma(mu, gam1, gam2);  // 1 / Gamma(1 + mu), 1 / Gamma(1 - mu)
+  if (rgamma_nu) {
+    DD g = dd_div_d(DD{1.0, 0.0}, gampl);  // Gamma(1 + mu)
+    if (nl == 0) {
+      g = dd_div_d(g, mu);
+    } else {
+      for (int i = 1; i < nl; ++i) g = dd_mul(g, dd_sum((double)i, mu));
+    }
+    *rgamma_nu = 1.0 / (g.h + g.l);
+  }
   double kmu, kmu1;
-  if (x <= 2.0) {
-    const double gampl = 1.0 / tgamma(1.0 + mu), gammi = 1.0 / tgamma(1.0 - mu);
-    const double gam1 = fabs(mu) < 1.0e-4 ? -(0.5772156649015329 + (-0.0420026350340952) * mu2) : (gammi - gampl) / (2.0 * mu);
-    const double gam2 = 0.5 * (gammi + gampl);
+  if (x <= 1.0) {
     const double b = 0.5 * x;
     double dd = -log(b);
-    double e = mu * dd;
-    const double fact2 = fabs(e) < EPS ? 1.0 : sinh(e) / e;
+    const double e = mu * dd;
+    const double pw = pow(b, -mu), pwi = 1.0 / pw;  // exp(+-e)
+    double fact2, ch;
+    if (fabs(e) < 0.5) {
+      fact2 = fabs(e) < 1e-8 ? 1.0 : sinh(e) / e;
+      ch = cosh(e);
+    } else {
+      fact2 = 0.5 * (pw - pwi) / e;
+      ch = 0.5 * (pw + pwi);
+    }
     const double pimu = PI * mu;
-    const double fact = fabs(pimu) < EPS ? 1.0 : pimu / sin(pimu);
-    double ff = fact * (gam1 * cosh(e) + gam2 * fact2 * dd);
+    const double fact = fabs(pimu) < 1e-8 ? 1.0 : pimu / sin(pimu);
+    double ff = fact * (gam1 * ch + gam2 * fact2 * dd);
     double sum = ff;
-    e = exp(e);
-    double p = 0.5 * e / gampl;
-    double q = 0.5 / (e * gammi);
+    double p = 0.5 * pw / gampl;
+    double q = 0.5 * pwi / gammi;
     double c = 1.0;
     dd = b * b;
     double sum1 = p;
-    for (int i = 1; i <= 500; ++i) {
+    for (int i = 1; i <= 60; ++i) {
       const double di = (double)i;
       ff = (di * ff + p + q) / (di * di - mu2);
       c *= dd / di;
@@ -92,44 +159,36 @@ __device__ __forceinline__ double bessel_k_nu(double nu, double x) {
       const double del = c * ff;
       sum += del;
       sum1 += c * (p - di * ff);
-      if (fabs(del) < fabs(sum) * EPS) break;
+      if (fabs(del) < fabs(sum) * 1.0e-17) break;
     }
     kmu = sum;
     kmu1 = sum1 * (2.0 / x);
   } else {
-    double b = 2.0 * (1.0 + x);
-    double dd = 1.0 / b;
-    double h = dd, delh = dd;
-    double q1 = 0.0, q2 = 1.0;
-    const double a1 = 0.25 - mu2;
-    double q = a1, c = a1;
-    double a = -a1;
-    double s = 1.0 + q * delh;
-    for (int i = 2; i <= 500; ++i) {
-      a -= 2.0 * (double)(i - 1);
-      c = -a * c / (double)i;
-      const double qnew = (q1 - b * q2) / a;
-      q1 = q2;
-      q2 = qnew;
-      q += c * qnew;
-      b += 2.0;
-      dd = 1.0 / (b + a * dd);
-      delh = (b * dd - 1.0) * delh;
-      h += delh;
-      const double dels = q * delh;
-      s += dels;
-      if (fabs(dels / s) < EPS) break;
+    const double h = fmin(0.2, 0.55 / sqrt(x));
+    double s0 = 0.5, s1 = 0.5;
+    for (int k = 1; k <= 200; ++k) {
+      const double t = (double)k * h;
+      const double sh = sinh(0.5 * t);
+      const double w = exp(-2.0 * x * sh * sh);
+      const double wb = w * cosh((mu + 1.0) * t);
+      s0 = __builtin_fma(w, cosh(mu * t), s0);
+      s1 += wb;
+      if (wb < 1.0e-18 * s1) break;
     }
-    h = a1 * h;
-    kmu = sqrt(PI / (2.0 * x)) * exp(-x) / s;
-    kmu1 = kmu * (mu + x + 0.5 - h) / x;
+    const double ex = exp(-x) * h;
+    kmu = ex * s0;
+    kmu1 = ex * s1;
   }
+  DD k0{kmu, 0.0}, k1{kmu1, 0.0};
   for (int i = 1; i <= nl; ++i) {
-    const double knew = (mu + (double)i) * (2.0 / x) * kmu1 + kmu;
-    kmu = kmu1;
-    kmu1 = knew;
+    DD c = dd_sum((double)i, mu);
+    c.h *= 2.0;
+    c.l *= 2.0;
+    const DD kn = dd_add(dd_mul(dd_div_d(c, x), k1), k0);
+    k0 = k1;
+    k1 = kn;
   }
-  return kmu;
+  return k0.h + k0.l;
 }
 
 // `pexp`: the exponent p of generalized_exponential (used in dist_fold, not here) / the order nu of the general Matern kernel
@@ -141,9 +200,11 @@ __device__ __forceinline__ double corr_profile(double s2, double pexp = 0.0) {
     double K = sqrt(s2);
     if (K == 0.0) K += 2.220446049250313e-16;
     const double tmp = sqrt(2.0 * pexp) * K;
-    double r = pow(2.0, 1.0 - pexp) / tgamma(pexp);
+    double rg;
+    const double kv = bessel_k_nu(pexp, tmp, &rg);
+    double r = pow(2.0, 1.0 - pexp) * rg;
     r *= pow(tmp, pexp);
-    r *= bessel_k_nu(pexp, tmp);
+    r *= kv;
     return r;
   }
   if (KERNEL == BOGP_KERNEL_SE || KERNEL == BOGP_KERNEL_ABSEXP || KERNEL == BOGP_KERNEL_GENEXP) return exp(-s2);

@@ -69,6 +69,7 @@ struct bogp_handle {
   int kernel = 0, mode = 0, estimate_trend = 0;
   double beta = 0, G = 0, sigma2 = 0, noise_var = 0, llf = 0, ftft = 0;
   double* dXthT = nullptr;  // [d][Np]
+  double* dXnorm = nullptr;  // [Np] squared norms of the columns of XthT (k_corr_mfma)
   double2* dVp = nullptr;   // [Np/16][Np/8][64]
 
   // candidates

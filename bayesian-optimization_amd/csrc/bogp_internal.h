@@ -18,6 +18,7 @@ struct CorrArgs {
   int nblk_per_split;        // 32-blocks of n per workgroup (grid.y slices the training set)
   const double* sqrt_theta;  // d
   const double* XthT;        // [d][Np] theta-scaled training points, transposed
+  const double* xnorm = nullptr;  // [Np] squared norms of the columns of XthT (k_corr_mfma); null: kernel A
   const double* gamma;       // Np (zero padded)
   const double* wvec;        // Np (zero padded): L^-T Ft, or zeros for simple kriging
   double* rT;                // [Np][Mc] correlation chunk, n-major
@@ -134,7 +135,7 @@ hipError_t launch_resid_gamma(int kernel, bool div, const double* X, int N, int 
                               double diag, const double* bvec, const double* gamma, double* res, hipStream_t st);
 hipError_t launch_sub_const(const double* y, double c, double* out, int N, hipStream_t st);
 hipError_t launch_add_vec(double* y, const double* x, int N, hipStream_t st);
-hipError_t launch_scale_transpose(const double* X, int N, int d, int Np, const double* sqrt_theta, double* XthT,
+hipError_t launch_scale_transpose(const double* X, int N, int d, int Np, const double* sqrt_theta, double* XthT, double* xnorm,
                                   hipStream_t st);
 hipError_t launch_pack_V(const double* Vcm, int N, int ld, int Np, double2* Vp, hipStream_t st);
 hipError_t launch_logdet(const double* L, int N, int ld, double* out, hipStream_t st);

@@ -13,14 +13,20 @@
 namespace bogp {
 
 __global__ void k_scale_transpose(const double* __restrict__ X, int N, int d, int Np, const double* __restrict__ sth,
-                                  double* __restrict__ XthT) {
+                                  double* __restrict__ XthT, double* __restrict__ xnorm) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= Np) return;
-  for (int k = 0; k < d; ++k) XthT[(size_t)k * Np + n] = n < N ? X[(size_t)n * d + k] * sth[k] : 0.0;
+  double s = 0.0;  // |sqrt(theta) x_n|^2, summed in dimension order: the training side of k_corr_mfma's cross-term distance
+  for (int k = 0; k < d; ++k) {
+    const double v = n < N ? X[(size_t)n * d + k] * sth[k] : 0.0;
+    XthT[(size_t)k * Np + n] = v;
+    s = __builtin_fma(v, v, s);
+  }
+  if (xnorm) xnorm[n] = s;
 }
-hipError_t launch_scale_transpose(const double* X, int N, int d, int Np, const double* sqrt_theta, double* XthT,
+hipError_t launch_scale_transpose(const double* X, int N, int d, int Np, const double* sqrt_theta, double* XthT, double* xnorm,
                                   hipStream_t st) {
-  hipLaunchKernelGGL(k_scale_transpose, dim3((Np + 255) / 256), 256, 0, st, X, N, d, Np, sqrt_theta, XthT);
+  hipLaunchKernelGGL(k_scale_transpose, dim3((Np + 255) / 256), 256, 0, st, X, N, d, Np, sqrt_theta, XthT, xnorm);
   return hipGetLastError();
 }
 

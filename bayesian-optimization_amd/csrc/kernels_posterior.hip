@@ -150,6 +150,164 @@ __global__ __launch_bounds__(256) void k_corr_chunk(const double* __restrict__ X
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Kernel A' (r05, the DEFAULT for the squared-distance kernels without a fused polynomial trend): the same chunk with the
+// weighted squared distance formed on the matrix cores.
+//   s2(m, n) = |a_m|^2 + |b_n|^2 - 2 a_m . b_n          a = sqrt(theta) x*_m,  b = sqrt(theta) x_n
+// The (sub, fma) pair per dimension of kernel A is 2 d FP64 VALU instructions per pair -- half of the producer at C3 -- and an FP64 MFMA
+// moves exactly as many flops per clock as the FP64 VALU, so the cross term a . b as a 16 x 16 x 4 matrix product costs d
+// FMA-equivalents per pair instead of 2 d, plus three for the assembly of s2.  The price is cancellation: the cross-term form carries an
+// ABSOLUTE error of ~sqrt(d) eps (|a|^2 + |b|^2) / 2 where the difference form carries a RELATIVE error of ~d eps.  Hence the guard:
+//   a pair with s2 * 64 < |a|^2 + |b|^2 (a candidate within an eighth of the typical distance of a training point; never, for
+//   space-filling candidates in d >= 3; routinely, once a BO run concentrates around the incumbent) is recomputed in the difference form,
+//   with kernel A's very operations in kernel A's order -- so a candidate ON a training point still gives s2 = 0, r = 1 and a clipped
+//   MSE of exactly 0 (the guards of EI / MGFI, acquisition_fun.py:162-164, 274-275, see tests G7), and every pair has s2 to <= ~64 sqrt(d) eps
+//   relative.  The branch is wave-uniform (ballot); a wave pays the slow path only for its flagged lanes' values.
+// Layout: workgroup = 64 candidates x one slice of the training set (as kernel A); wave g owns training rows 16 g .. 16 g + 15 of every
+// 64-row block and all 64 candidates: four 16 x 16 output tiles D[i = row][j = candidate] sharing one A fragment (training rows, a
+// 128-byte run of XthT per dimension: L1 / L2 resident) against four B fragments (candidate tile, LDS, k-major: conflict-free).
+// v_mfma_f64_16x16x4_f64: A lane 16 k + i, B lane 16 k + j, D[i][j] in lane 16 (i % 4) + j, component i / 4 (probe_mfma_layout).
+// ---------------------------------------------------------------------------------------------------
+template <int KERNEL>
+__global__ __launch_bounds__(256) void k_corr_mfma(const double* __restrict__ Xs, const double* __restrict__ sqrt_theta,
+                                                   const double* __restrict__ XthT, const double* __restrict__ xnorm,
+                                                   const double* __restrict__ gamma, const double* __restrict__ wvec,
+                                                   double* __restrict__ rT, double* __restrict__ mu_part, double* __restrict__ w_part,
+                                                   CorrDims a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int d = a.d;
+  const int KS = (d + 3) >> 2;       // k-steps of 4 dimensions; rows d .. 4 KS - 1 of the tile are zero
+  double* xs = smem;                 // [4 KS][64] theta-scaled candidate tile, k-major
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t mc0 = (int64_t)blockIdx.x * 64;
+  const int64_t mg0 = a.m0 + mc0;
+  for (int idx = tid; idx < 64 * d; idx += 256) {
+    const int row = idx / d, k = idx - row * d;
+    const int64_t gm = mg0 + row;
+    const double v = gm < a.M ? Xs[gm * d + k] : 0.0;
+    xs[k * 64 + row] = v * sqrt_theta[k];
+  }
+  for (int idx = tid + 64 * d; idx < 64 * 4 * KS; idx += 256) xs[idx] = 0.0;
+  __syncthreads();
+  const double pexp = kernel_exponent<KERNEL>(sqrt_theta, d);
+  const int li = lane & 15, lk = lane >> 4;
+  double na[4];  // |a_m|^2 of this lane's four candidates m = 16 t + li, summed in dimension order (as k_scale_transpose sums |b_n|^2)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) na[t] = 0.0;
+  for (int k = 0; k < d; ++k) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double v = xs[k * 64 + 16 * t + li];
+      na[t] = __builtin_fma(v, v, na[t]);
+    }
+  }
+  const int nb0 = blockIdx.y * a.nblk_per_split * 32;
+  const int nb1 = min(a.Np, nb0 + a.nblk_per_split * 32);
+  typedef double d4t __attribute__((ext_vector_type(4)));
+  double mu[4] = {0.0, 0.0, 0.0, 0.0}, wd[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int n0 = nb0 + 16 * g; n0 < nb1; n0 += 64) {
+    d4t acc[4];
+    // a_m . b_n over the dimensions, four at a time
+    {
+      const double* __restrict__ ap = XthT + (size_t)lk * a.Np + n0 + li;
+      const double* bp = xs + lk * 64 + li;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = (d4t){0.0, 0.0, 0.0, 0.0};
+      constexpr int KB = 8;  // A fragments (128-byte runs of XthT: L2 round trips) requested together: 5.5 -> 5.1 ms at C3, 17.5 -> 14.3 ms at C5
+      for (int ks0 = 0; ks0 < KS; ks0 += KB) {
+        double av[KB];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) av[u] = (4 * (ks0 + u) + lk) < d ? ap[(size_t)4 * (ks0 + u) * a.Np] : 0.0;
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+          if (ks0 + u < KS) {
+            const int ks = ks0 + u;
+            const double b0 = bp[ks * 256], b1 = bp[ks * 256 + 16], b2 = bp[ks * 256 + 32], b3 = bp[ks * 256 + 48];
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[0]) : "v"(av[u]), "v"(b0));
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[1]) : "v"(av[u]), "v"(b1));
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[2]) : "v"(av[u]), "v"(b2));
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[3]) : "v"(av[u]), "v"(b3));
+          }
+        }
+      }
+    }
+    // this lane's four training rows n0 + 4 c + lk: norm, gamma, w (the loads fly while the matrix pipe drains)
+    double nbv[4], gv[4], wv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int n = n0 + 4 * c + lk;
+      nbv[c] = xnorm[n];
+      gv[c] = gamma[n];
+      wv[c] = wvec[n];
+    }
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(acc[t]));
+    double s2[4][4];
+    bool near = false;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double nab = na[t] + nbv[c];
+        const double v = __builtin_fma(-2.0, acc[t][c], nab);
+        s2[t][c] = v;
+        near |= v * 64.0 < nab;
+      }
+    if (__builtin_expect(__ballot(near) != 0ull, 0)) {
+      // difference form for the flagged values: kernel A's operations in kernel A's order
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double nab = na[t] + nbv[c];
+          if (s2[t][c] * 64.0 < nab) {
+            const double* __restrict__ xr = XthT + n0 + 4 * c + lk;
+            const double* xc = xs + 16 * t + li;
+            double e = 0.0;
+            for (int k = 0; k < d; ++k) {
+              const double df = xc[k * 64] - xr[(size_t)k * a.Np];
+              e = __builtin_fma(df, df, e);
+            }
+            s2[t][c] = e;
+          }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double* __restrict__ rrow = rT + (size_t)(n0 + 4 * c + lk) * a.Mc + mc0 + li;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double r = corr_profile<KERNEL>(s2[t][c], pexp);
+        rrow[16 * t] = r;
+        mu[t] = __builtin_fma(r, gv[c], mu[t]);
+        wd[t] = __builtin_fma(r, wv[c], wd[t]);
+      }
+    }
+  }
+  // reduce over the 4 waves x 4 row groups of a lane (fixed order) -> partial sums of this slice
+  __syncthreads();
+  double* red = smem;  // [2][16][64]
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    red[(4 * g + lk) * 64 + 16 * t + li] = mu[t];
+    red[1024 + (4 * g + lk) * 64 + 16 * t + li] = wd[t];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      s0 += red[j * 64 + tid];
+      s1 += red[1024 + j * 64 + tid];
+    }
+    mu_part[(size_t)blockIdx.y * a.Mc + mc0 + tid] = s0;
+    w_part[(size_t)blockIdx.y * a.Mc + mc0 + tid] = s1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Kernel B: triangular contraction  ss_part[jg][m] = sum_{j in group jg} (sum_{n<=j} V[j][n] r[m][n])^2
 // ---------------------------------------------------------------------------------------------------
 constexpr int MR = 4;                // 16-row fragments per wave  (64 candidates)
@@ -397,8 +555,43 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
 // ---------------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------------
+// BOGP_CORR_MFMA=0: every kernel through kernel A (the r04 producer); the A/B switch of profiles/r05_corr_mfma_ab.txt
+static bool corr_mfma_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("BOGP_CORR_MFMA");
+    return !(e && atoi(e) == 0);
+  }();
+  return on;
+}
+
 hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipStream_t st) {
   dim3 grid((unsigned)nMt, (unsigned)S);
+  const bool sqdist = kernel == BOGP_KERNEL_SE || kernel == BOGP_KERNEL_MATERN12 || kernel == BOGP_KERNEL_MATERN32 ||
+                      kernel == BOGP_KERNEL_MATERN52 || kernel == BOGP_KERNEL_MATERN_NU;
+  if (sqdist && a.pv == 0 && a.xnorm && corr_mfma_enabled()) {
+    const int KS = (a.d + 3) / 4;
+    const size_t shm = (size_t)max(4 * KS * 64, 2048) * sizeof(double);  // <= 160 KB up to d = 320, like kernel A
+    CorrDims dm{a.M, a.m0, a.Mc, a.d, a.Np, a.nblk_per_split, a.wld};
+#define BOGP_LAUNCH_CORR_MFMA(K)                                                                                                      \
+  do {                                                                                                                                \
+    if (shm > 64 * 1024) {                                                                                                            \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_corr_mfma<K>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)shm);                                                                                  \
+      if (e_ != hipSuccess) return e_;                                                                                                \
+    }                                                                                                                                 \
+    hipLaunchKernelGGL((k_corr_mfma<K>), grid, 256, shm, st, a.Xs, a.sqrt_theta, a.XthT, a.xnorm, a.gamma, a.wvec, a.rT, a.mu_part,   \
+                       a.w_part, dm);                                                                                                 \
+  } while (0)
+    switch (kernel) {
+      case BOGP_KERNEL_SE: BOGP_LAUNCH_CORR_MFMA(BOGP_KERNEL_SE); break;
+      case BOGP_KERNEL_MATERN12: BOGP_LAUNCH_CORR_MFMA(BOGP_KERNEL_MATERN12); break;
+      case BOGP_KERNEL_MATERN32: BOGP_LAUNCH_CORR_MFMA(BOGP_KERNEL_MATERN32); break;
+      case BOGP_KERNEL_MATERN_NU: BOGP_LAUNCH_CORR_MFMA(BOGP_KERNEL_MATERN_NU); break;
+      default: BOGP_LAUNCH_CORR_MFMA(BOGP_KERNEL_MATERN52); break;
+    }
+#undef BOGP_LAUNCH_CORR_MFMA
+    return hipGetLastError();
+  }
   size_t shm = (size_t)(max(64 * a.d, 512) + (a.pv > 0 ? 32 * 64 : 0)) * sizeof(double);
   CorrDims dm{a.M, a.m0, a.Mc, a.d, a.Np, a.nblk_per_split, a.wld};
   // the candidate tile is 64 x d doubles of dynamic LDS: above the 64 KB default (d > 128) the kernel has to be allowed

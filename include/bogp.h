@@ -28,7 +28,7 @@ extern "C" {
 typedef struct bogp_handle bogp_handle;
 
 /* error codes */
-#define BOGP_ABI_VERSION 8 /* what bogp_abi_version() of a matching library returns */
+#define BOGP_ABI_VERSION 9 /* what bogp_abi_version() of a matching library returns */
 #define BOGP_OK 0
 #define BOGP_ERR_INVALID (-1)      /* bad argument / call order                                           */
 #define BOGP_ERR_HIP (-2)          /* HIP runtime failure (or an in-kernel hand-over that timed out)       */
@@ -360,6 +360,19 @@ double bogp_flops_per_candidate(const bogp_handle* h);
  * What the reference gets from numpy.dot / scipy.linalg (gpr.py:799-808, 850-918); used by tests/test_gpu_gemm.py.        */
 int bogp_selftest_gemm(bogp_handle* h, int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda,
                        const double* B, int ldb, double beta, double* C, int ldc, int tri, int split);
+
+/* The radial profile r(s2) of correlation function `kernel` (BOGP_SELFTEST_PROFILE; s2 = the weighted squared distance the producers
+ * accumulate, pexp = the exponent p / the order nu where the kernel has one) or one of the special functions behind it, evaluated on the
+ * device for n arguments: what the reference gets per pair from kernel.py:186-207, 289-329 (numpy sqrt / exp, scipy.special.kv and
+ * scipy.special.gamma).  BESSEL_K: K_pexp(arg); RGAMMA: 1 / Gamma(arg); BESSEL_K_PAIRS: arg holds n pairs (nu, x) -> K_nu(x);
+ * MATERN_NU_PAIRS: n pairs (nu, s2) -> the general-nu Matern profile at squared distance s2.
+ * Used by tests/test_gpu_special.py to hold them to committed tables argument by argument.                                            */
+#define BOGP_SELFTEST_PROFILE 0
+#define BOGP_SELFTEST_BESSEL_K 1
+#define BOGP_SELFTEST_RGAMMA 2
+#define BOGP_SELFTEST_BESSEL_K_PAIRS 3
+#define BOGP_SELFTEST_MATERN_NU_PAIRS 4
+int bogp_selftest_profile(bogp_handle* h, int what, int kernel, double pexp, const double* arg, int64_t n, double* out);
 
 /* The optimiser behind bogp_mle_batch (csrc/bogp_lbfgsb.h: L-BFGS-B after Byrd, Lu, Nocedal & Zhu 1995 with the More'-Thuente
  * line search) on a HOST objective: what the reference gets from scipy.optimize.fmin_l_bfgs_b (gpr.py:1136).  No device, no handle;

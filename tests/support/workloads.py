@@ -28,3 +28,16 @@ def full_size_problem(cfg):
     par = np.r_[np.full(w["d"], w["theta"]), 0.9]
     Xs = rng.uniform(-5.0, 5.0, size=(w["M"], w["d"]))
     return X, y.reshape(-1, 1), par, Xs
+
+
+# configs[3] / configs[4] WHOLE: 8 contiguous shards of the candidate grid, rank r owning rows [r * M, (r + 1) * M).
+# Shard 0 is the single-rank workload above (so G22 / G23 stay its fixtures); shards 1..7 come from their own seeded streams.
+SHARDED = {"C4": dict(R=8, M_total=8_000_000), "C5": dict(R=8, M_total=4_000_000)}
+
+
+def shard_candidates(cfg, r):
+    """Rank r's (M x d) block of the 8-shard candidate grid of `cfg`; its global row offset is r * M."""
+    w = FULL_SIZE[cfg]
+    if r == 0:
+        return full_size_problem(cfg)[3]
+    return np.random.default_rng(10_000 + 100 * int(cfg[1:]) + r).uniform(-5.0, 5.0, size=(w["M"], w["d"]))

@@ -40,7 +40,7 @@ def test_abi_version_and_constants_match_header():
     lib = _lib.load()
     src = open(HEADER).read()
     consts = dict(re.findall(r"#define\s+(BOGP_[A-Z_0-9]+)\s+\(?(-?\d+)\)?", src))
-    assert lib.bogp_abi_version() == int(consts["BOGP_ABI_VERSION"]) == _lib.ABI_VERSION == 8
+    assert lib.bogp_abi_version() == int(consts["BOGP_ABI_VERSION"]) == _lib.ABI_VERSION == 9
     assert int(consts["BOGP_KERNEL_MATERN52"]) == _lib.KERNEL_MATERN52 == 3
     assert int(consts["BOGP_MODE_NOISE_ESTIM"]) == _lib.MODE_NOISE_ESTIM == 2
     assert int(consts["BOGP_ACQ_MGFI"]) == _lib.ACQ_MGFI == 3

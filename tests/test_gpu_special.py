@@ -1,0 +1,103 @@
+"""The special functions behind the general-nu Matern kernel (kernel.py:201-207: scipy.special.kv, scipy.special.gamma) on the device,
+argument by argument.
+
+The committed table tests/golden/G36_kv_table.npz (oracle/make_kv_table.py) holds, for 1e5 (nu, x) pairs on nu in (0, 10],
+x in [1e-8, 700], the TRUE K_nu(x) (mpmath at 40 digits, stored as double + relative residual) beside scipy's value.  scipy's kv (AMOS)
+is itself up to ~700 eps from the truth on this domain, median 2 eps (the generator prints it; profiles/r05_kv_accuracy.txt) -- so an
+accurate device K_nu cannot agree with scipy to a few eps.  What is asserted per pair:
+    |device - truth| <= 6 eps                              (measured: <= 3.6 eps)
+    |device - scipy| <= |scipy - truth| + 6 eps            (the device is never further from the reference than the reference is from the truth, + 6 eps)
+and for the profile r = 2^(1-nu) / Gamma(nu) t^nu K_nu(t) the same against mpmath on a sub-sample (the device forms t itself)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle.make_kv_table import pairs
+
+pytestmark = pytest.mark.gpu
+
+from bogp import _lib  # noqa: E402
+
+EPS = 2.0**-52
+TOL = 6.0
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = _lib.Engine(0)
+    yield e
+    e.close()
+
+
+def test_bessel_k_against_the_truth_table(eng):
+    g = load_golden("G36_kv_table")
+    nu, x = pairs()
+    assert len(nu) == int(g["n"]) == 100_000 and float(np.sum(nu) + np.sum(x)) == float(g["nu_x_checksum"])
+    dev = eng.selftest_profile(_lib.SELFTEST_BESSEL_K_PAIRS, np.column_stack([nu, x]))
+    true, rlo, sc = g["kv_true"], g["kv_true_rlo"].astype(np.float64), g["kv_scipy"]
+    ok = np.isfinite(true) & (true > 1e-290) & (true < 1e290)  # normal range on both sides
+    assert ok.sum() > 99_000
+    # (v - truth) / truth with truth = true (1 + rlo)
+    err_dev = np.abs((dev - true) / true - rlo)[ok] / EPS
+    err_sc = np.abs((sc - true) / true - rlo)[ok] / EPS
+    assert err_dev.max() <= TOL, (err_dev.max(), nu[ok][err_dev.argmax()], x[ok][err_dev.argmax()])
+    assert np.median(err_dev) <= 1.0
+    assert err_sc.max() > 100.0  # the premise: the reference's own kv is hundreds of eps off somewhere on this domain
+    gap = np.abs(dev - sc)[ok] / np.abs(true[ok]) / EPS
+    assert np.all(gap <= err_sc + TOL), float(np.max(gap - err_sc))
+    # the single-order entry point is the same function
+    k = eng.selftest_profile(_lib.SELFTEST_BESSEL_K, x[:2000], pexp=float(nu[7]))
+    np.testing.assert_array_equal(k, eng.selftest_profile(_lib.SELFTEST_BESSEL_K_PAIRS, np.column_stack([np.full(2000, nu[7]), x[:2000]])))
+
+
+def test_reciprocal_gamma_and_the_matern_nu_profile(eng):
+    mp = pytest.importorskip("mpmath")
+    from scipy.special import gamma, kv
+
+    mp.mp.dps = 40
+    rng = np.random.default_rng(5)
+    z = np.r_[rng.uniform(1e-6, 12.0, 20_000), np.arange(1, 25) / 2.0]
+    rg = eng.selftest_profile(_lib.SELFTEST_RGAMMA, z)
+    # scipy.special.gamma is within 2.3 eps of the truth on (0, 12] (tools/kv_check.py); the device within 2.6
+    assert np.max(np.abs(rg * gamma(z) - 1.0)) / EPS <= 6.0
+    n = 3000
+    nu = np.r_[rng.uniform(1e-3, 10.0, n - 300), rng.choice([0.5, 1.0, 1.5, 2.5, 0.25, 3.7, 0.8, 10.0, 0.49999, 1.00001], 300)]
+    t_want = 10.0 ** rng.uniform(-8, np.log10(600.0), n)
+    s2 = (t_want / np.sqrt(2.0 * nu)) ** 2
+    dev = eng.selftest_profile(_lib.SELFTEST_MATERN_NU_PAIRS, np.column_stack([nu, s2]))
+    tmp = np.sqrt(2.0 * nu) * np.sqrt(s2)  # kernel.py:204 as the device forms it
+    ref = 2.0 ** (1.0 - nu) / gamma(nu)
+    ref = ref * tmp**nu
+    ref = ref * kv(nu, tmp)
+    worst, worst_ref = 0.0, 0.0
+    for i in range(n):
+        a, b = mp.mpf(float(nu[i])), mp.mpf(float(tmp[i]))
+        tr = mp.mpf(2) ** (1 - a) / mp.gamma(a) * b**a * mp.besselk(a, b)
+        if tr < 1e-290:
+            continue
+        e_dev = float(abs(mp.mpf(float(dev[i])) - tr) / tr) / EPS
+        e_ref = float(abs(mp.mpf(float(ref[i])) - tr) / tr) / EPS
+        assert abs(dev[i] - ref[i]) / float(tr) / EPS <= e_ref + 8.0, (nu[i], tmp[i])
+        worst, worst_ref = max(worst, e_dev), max(worst_ref, e_ref)
+    assert worst <= 8.0, worst  # measured 4.5
+    assert worst_ref > 3.0 * worst  # the reference's own expression is the looser of the two
+    # the profile at zero distance: kernel.py:202-203 adds eps to zero distances; r -> 1
+    one = eng.selftest_profile(_lib.SELFTEST_MATERN_NU_PAIRS, np.array([[0.8, 0.0], [2.5, 0.0], [3.7, 0.0]]))
+    np.testing.assert_allclose(one, 1.0, rtol=1e-13)
+
+
+def test_selftest_profile_is_the_reference_expression_for_the_closed_form_kernels(eng):
+    """SE / Matern-1/2, 3/2, 5/2 through the same entry point: numpy's expression (kernel.py:186-200, 289-329) to <= 4 ulp
+    (one sqrt, one exp and the polynomial; the library's exp differs from glibc's by <= 1 ulp)."""
+    rng = np.random.default_rng(9)
+    s2 = np.r_[rng.uniform(0, 40.0, 200_000), 10.0 ** rng.uniform(-20, 2.5, 200_000), 0.0]
+    D = np.sqrt(s2)
+    want = {_lib.KERNEL_SE: np.exp(-s2), _lib.KERNEL_MATERN12: np.exp(-D), _lib.KERNEL_MATERN32: (1.0 + D * np.sqrt(3.0)) * np.exp(-D * np.sqrt(3.0)),
+            _lib.KERNEL_MATERN52: (1.0 + D * np.sqrt(5.0) + (D * np.sqrt(5.0)) ** 2 / 3.0) * np.exp(-D * np.sqrt(5.0))}  # fmt: skip
+    for kid, w in want.items():
+        got = eng.selftest_profile(_lib.SELFTEST_PROFILE, s2, kernel=kid)
+        ok = w > 1e-300
+        assert np.max(np.abs(got - w)[ok] / np.spacing(w)[ok]) <= 4.0, kid
+        assert got[-1] == 1.0
+    with pytest.raises(_lib.BogpError):
+        eng.selftest_profile(9, np.zeros((4, 2)))  # unknown selector

@@ -34,6 +34,7 @@ WIDE = False  # --wide: d up to 60 (the fused sweep's limit), N up to 2200, + th
 
 
 def one(seed, eng, orc):
+    O.KV_OVERRIDE = None  # (a previous ill-conditioned general-nu problem may have set it, see below)
     rng = np.random.default_rng(seed)
     d = int(rng.integers(1, 13))
     N = int(rng.choice(EDGE_N)) if rng.random() < 0.6 else int(rng.integers(2, 700))
@@ -94,10 +95,15 @@ def one(seed, eng, orc):
     compare = cond <= 1e12
     tol = max(1e-8, 100.0 * cond * 2.2e-16)  # likelihood tolerance: both sides carry cond(R) eps
     ptol = max(1e-6, 100.0 * cond * 2.2e-16)  # posterior / criterion tolerance
-    if kernel == O.KERNEL_MATERN_NU:
-        # the entries of R themselves differ here: the device's K_nu is held to scipy's at 6e-14 relative (tests/test_oracle_golden.py), ~270 eps,
-        # and cond(R) amplifies that like any other perturbation of the matrix (seed 960921: cond 8e9, mu 1.5e-4 apart)
-        tol, ptol = max(tol, 3.0 * cond * 6e-14), max(ptol, 3.0 * cond * 6e-14)
+    if kernel == O.KERNEL_MATERN_NU and compare and cond > 1e4:
+        # r05: the device's K_nu is within 4 eps of the TRUE value (tests/test_gpu_special.py), but scipy.special.kv -- the oracle's, the reference's --
+        # is up to hundreds of eps off (tests/golden/G36_kv_table.npz): the reference's R is a perturbed matrix and cond(R) amplifies the
+        # perturbation (seed 960921: cond 8e9, the two means 1e-4 apart).  On ill-conditioned problems of this kernel the oracle therefore gets an
+        # ACCURATE kv (tests/support/bessel.py: the device's algorithm restated in Python, held to the mpmath table at 6 eps) and the comparison is
+        # made at the generic tolerance; everything but the Bessel function -- distances, factorisation, solves, criteria -- is still the oracle's.
+        from support.bessel import kv_accurate
+
+        O.KV_OVERRIDE = kv_accurate
     eng.set_train(X, y)
     orc.set_train(X, y)
     fails = []
