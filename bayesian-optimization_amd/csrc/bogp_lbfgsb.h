@@ -53,11 +53,11 @@ class MoreThuente {
       // first stage: the auxiliary function psi(stp) = f(stp) - f(0) - ftol stp f'(0) decides the interval update
       double fm = f - stp * gtest_, fxm = fx_ - stx_ * gtest_, fym = fy_ - sty_ * gtest_;
       double gm = g - gtest_, gxm = gx_ - gtest_, gym = gy_ - gtest_;
-      trial(stx_, fxm, gxm, sty_, fym, gym, stp_, fm, gm);
+      trial(stx_, fxm, gxm, sty_, fym, gym, stp_, fm, gm, stmin_, stmax_);
       fx_ = fxm + stx_ * gtest_; fy_ = fym + sty_ * gtest_;
       gx_ = gxm + gtest_; gy_ = gym + gtest_;
     } else {
-      trial(stx_, fx_, gx_, sty_, fy_, gy_, stp_, f, g);
+      trial(stx_, fx_, gx_, sty_, fy_, gy_, stp_, f, g, stmin_, stmax_);
     }
     if (brackt_) {  // force a sufficient decrease of the interval
       if (std::fabs(sty_ - stx_) >= 0.66 * width1_) stp_ = stx_ + 0.5 * (sty_ - stx_);
@@ -85,8 +85,12 @@ class MoreThuente {
   double best_value() const { return fx_; }
 
  private:
-  // the safeguarded step of More' & Thuente, section 4: cases by the relative position of the new point and the best point
-  void trial(double& stx, double& fx, double& dx, double& sty, double& fy, double& dy, double& stp, double fp, double dp) {
+  // the safeguarded step of More' & Thuente, section 4 (MINPACK-2 dcstep): cases by the relative position of the new point and the best
+  // point.  [lo, hi] is the MOVING interval dcsrch hands to dcstep -- [stmin, stmax] as left by the previous call: the bracket once there
+  // is one, else [stp + 1.1 (stp - stx), stp + 4 (stp - stx)] -- so an un-bracketed extrapolation (cases 3 and 4) goes at most four
+  // step-lengths beyond the best point, not straight to the global stpmax (that was the box edge in the MLE, 1e10 with open bounds).
+  void trial(double& stx, double& fx, double& dx, double& sty, double& fy, double& dy, double& stp, double fp, double dp, double lo,
+             double hi) {
     const double sgnd = dp * (dx / std::fabs(dx));
     double stpf, stpc, stpq;
     if (fp > fx) {  // higher value: the minimum is bracketed
@@ -116,14 +120,14 @@ class MoreThuente {
       if (stp > stx) gamma = -gamma;
       const double p = (gamma - dp) + theta, q = (gamma + (dx - dp)) + gamma, r = p / q;
       if (r < 0.0 && gamma != 0.0) stpc = stp + r * (stx - stp);
-      else stpc = stp > stx ? stpmax_ : stpmin_;
+      else stpc = stp > stx ? hi : lo;
       stpq = stp + (dp / (dp - dx)) * (stx - stp);
       if (brackt_) {
         stpf = std::fabs(stpc - stp) < std::fabs(stpq - stp) ? stpc : stpq;
         stpf = stp > stx ? std::min(stp + 0.66 * (sty - stp), stpf) : std::max(stp + 0.66 * (sty - stp), stpf);
       } else {
         stpf = std::fabs(stpc - stp) > std::fabs(stpq - stp) ? stpc : stpq;
-        stpf = std::min(std::max(stpf, stpmin_), stpmax_);
+        stpf = std::max(lo, std::min(hi, stpf));
       }
     } else {  // lower value, same sign, the derivative does not decrease
       if (brackt_) {
@@ -134,7 +138,7 @@ class MoreThuente {
         const double p = (gamma - dp) + theta, q = ((gamma - dp) + gamma) + dy, r = p / q;
         stpf = stp + r * (sty - stp);
       } else {
-        stpf = stp > stx ? stpmax_ : stpmin_;
+        stpf = stp > stx ? hi : lo;
       }
     }
     if (fp > fx) {
@@ -177,6 +181,13 @@ class Lbfgsb {
     lo_.assign(lo, lo + n); hi_.assign(hi, hi + n);
     x_.assign(x0, x0 + n);
     for (int i = 0; i < n; ++i) x_[i] = std::min(std::max(x_[i], lo_[i]), hi_[i]);
+    // a bound of +-1e300 or beyond (or infinite) is "none": scipy's bounds=None / nbd = 0
+    cnstnd_ = false; boxed_ = true;
+    for (int i = 0; i < n; ++i) {
+      const bool has_lo = lo_[i] > -1e300, has_hi = hi_[i] < 1e300;
+      cnstnd_ = cnstnd_ || has_lo || has_hi;
+      boxed_ = boxed_ && has_lo && has_hi;
+    }
     xt_ = x_;
     g_.assign(n, 0.0); gold_.assign(n, 0.0); xold_.assign(n, 0.0); d_.assign(n, 0.0); xcp_.assign(n, 0.0);
     S_.assign((size_t)n * m_, 0.0); Y_.assign((size_t)n * m_, 0.0);
@@ -551,9 +562,11 @@ class Lbfgsb {
         dnorm2 += d_[i] * d_[i];
       }
       if (gd < 0.0 && dnorm2 > 0.0) {
-        // largest step that keeps x + stp d inside the box (1 on the first iteration: the model has no curvature yet)
+        // largest step that keeps x + stp d inside the box (L-BFGS-B's lnsrlb: 1 on the first iteration of a CONSTRAINED problem -- the
+        // model has no curvature yet --, 1e10 when no variable has a bound)
         double stpmax = 1e10;
-        if (nit_ == 0) {
+        if (!cnstnd_) {
+        } else if (nit_ == 0) {
           stpmax = 1.0;
         } else {
           for (int i = 0; i < n_; ++i) {
@@ -573,7 +586,9 @@ class Lbfgsb {
           xold_ = x_;
           gold_ = g_;
           fold_ = f_;
-          ls_.start(f_, gd, std::min(1.0, stpmax), 0.0, stpmax, 1e-3, 0.9, 0.1);
+          // first trial (lnsrlb): 1 / |d| on the first iteration unless every variable is boxed, else the quasi-Newton step 1
+          const double stp0 = (nit_ == 0 && !boxed_) ? std::min(1.0 / std::sqrt(dnorm2), stpmax) : std::min(1.0, stpmax);
+          ls_.start(f_, gd, stp0, 0.0, stpmax, 1e-3, 0.9, 0.1);
           ls_evals_ = 0;
           phase_ = SEARCH;
           set_trial(ls_.step());
@@ -604,6 +619,7 @@ class Lbfgsb {
   }
 
   int n_ = 0, m_ = 10, col_ = 0, nfev_ = 0, nit_ = 0, nskip_ = 0, ls_evals_ = 0;
+  bool cnstnd_ = true, boxed_ = true;  // any variable bounded / every variable bounded on both sides (lnsrlb's first-step rules)
   Options opt_;
   Status status_ = RUNNING;
   Phase phase_ = FIRST;

@@ -101,3 +101,29 @@ def test_selftest_profile_is_the_reference_expression_for_the_closed_form_kernel
         assert got[-1] == 1.0
     with pytest.raises(_lib.BogpError):
         eng.selftest_profile(9, np.zeros((4, 2)))  # unknown selector
+
+
+def test_ill_conditioned_general_nu_model_against_the_exact_posterior(eng):
+    """G37 (oracle/make_golden_r05.py): nu = 3.7, noiseless, ordinary kriging, cond(R) = 7.9e9.  The fixture holds the reference's
+    posterior AND the exact posterior of the same model (R from mpmath's K_nu, 50-digit solves).  Both implementations factorise a
+    double-precision R whose condition number amplifies every rounding, so each is held to the exact answer at the tolerance of an
+    ill-conditioned problem, 100 cond eps relative to the scale of the data -- the device (accurate K_nu) and the reference (scipy's kv)
+    alike -- and to each other at the sum."""
+    g = load_golden("G37_matern_nu_illcond")
+    cond = float(g["cond"])
+    assert cond >= 1e9
+    eng.set_train(g["X"], g["y"])
+    llf = eng.commit(int(g["kernel"]), int(g["mode"]), g["par"], 0.0, True, 0.0)
+    np.testing.assert_allclose(llf, float(g["llf"]), rtol=1e-6)  # log det of an ill-conditioned matrix: cond eps / N per pivot
+    eng.upload_candidates(g["Xs"])
+    mu, mse = eng.predict()
+    tol = 100.0 * cond * EPS
+    s2 = float(g["true_sigma2"])
+    scale = float(np.abs(g["y"]).max())
+    dev_mu, dev_mse = np.abs(mu - g["true_mu"]).max() / scale, np.abs(mse - g["true_mse"]).max() / s2
+    ref_mu, ref_mse = float(g["ref_err_mu"]) / scale, float(g["ref_err_mse"])
+    print("G37: cond %.2e; device vs exact: mu %.2e mse %.2e; reference vs exact: mu %.2e mse %.2e; tolerance %.2e" % (cond, dev_mu, dev_mse, ref_mu, ref_mse, tol))
+    assert dev_mu <= tol and dev_mse <= tol
+    assert ref_mu <= tol and ref_mse <= tol
+    np.testing.assert_allclose(mu, g["mu"], rtol=0, atol=2 * tol * scale)
+    np.testing.assert_allclose(mse, g["mse"], rtol=0, atol=2 * tol * s2)

@@ -102,3 +102,38 @@ def test_budget_is_tested_at_iterates_like_scipy():
 def test_invalid_arguments_are_refused():
     with pytest.raises(_lib.BogpError):
         _lib.lbfgsb_minimize(rosen, np.zeros(3), [(1.0, -1.0)] * 3)
+
+
+@pytest.mark.parametrize("bounds", ["boxed", "open", "lower only"])
+@pytest.mark.parametrize("shape", ["quadratic", "quartic"])
+def test_evaluation_points_follow_scipy_point_by_point(bounds, shape):
+    """MINPACK-2's dcsrch hands dcstep the MOVING interval [stmin, stmax]: an un-bracketed extrapolation is capped at
+    stp + 4 (stp - stx), not at the global stpmax; and lnsrlb's first-step rules depend on the bounds (unconstrained: first trial 1 / |d|,
+    stpmax 1e10; constrained: stpmax = 1 on the first iteration; every variable boxed: first trial 1).  A shallow bowl far from its
+    minimiser makes the searches extrapolate: the SEQUENCE of evaluation points must be scipy's, point by point, in all three regimes."""
+    n = 4
+    c = np.array([30.0, -45.0, 60.0, 20.0])
+    fn = {"quadratic": lambda x: (float(0.001 * np.sum((x - c) ** 2)), 0.002 * (x - c)),
+          "quartic": lambda x: (float(1e-6 * np.sum((x - c) ** 4)), 4e-6 * (x - c) ** 3)}[shape]  # fmt: skip
+
+    def make():
+        seen = []
+
+        def fun(x):
+            seen.append(np.array(x, dtype=float))
+            return fn(x)
+
+        return fun, seen
+
+    b = {"boxed": [(-500.0, 500.0)] * n, "open": [(None, None)] * n, "lower only": [(-500.0, None)] * n}[bounds]
+    f1, s1 = make()
+    xs, fs, ds = fmin_l_bfgs_b(f1, np.zeros(n), bounds=b)
+    f2, s2 = make()
+    xo, fo, do = _lib.lbfgsb_minimize(f2, np.zeros(n), [(-1e300 if lo is None else lo, 1e300 if hi is None else hi) for lo, hi in b])
+    assert len(s2) == len(s1) == ds["funcalls"] == do["funcalls"]
+    for i in range(len(s1)):
+        np.testing.assert_allclose(s2[i], s1[i], rtol=1e-7, atol=1e-9, err_msg="evaluation %d" % i)
+    if bounds == "open":  # the first search extrapolates by the capped factor: |x_2| = 5 |x_1| (stmax = stp + 4 stp), not to stpmax = 1e10
+        r = [np.linalg.norm(v) for v in s2[1:3]]
+        np.testing.assert_allclose([r[1] / r[0]], [5.0], rtol=1e-12)
+    np.testing.assert_allclose(xo, xs, rtol=1e-7, atol=1e-7)
