@@ -45,17 +45,34 @@ WORKLOADS = {
 }
 
 
-PMC_FILE = os.path.join("profiles", "c3_pmc.json")
+def dominant_kernel(workload):
+    """(name pattern, source file, first line marker, last line marker) of the kernel `roofline` is about: the one-launch sweep at N <= 512,
+    the triangular contraction otherwise."""
+    if WORKLOADS[workload]["N"] <= 512:
+        return "k_sweep_small", "kernels_small.hip", None, None
+    return "k_contract16", "kernels_posterior.hip", "// Kernel B: triangular contraction", "// host-side launchers"
 
 
-def kernel_source_hash():
-    """sha256 of the CODE of the translation unit that holds the dominant kernel (comments and blank lines stripped: a reworded comment does not
-    invalidate a measurement): a committed PMC figure is only quoted for the source it was measured on."""
+def candidates_per_launch(workload):
+    """Candidates one launch of the dominant kernel processes: the whole sweep for k_sweep_small, one 1-GiB chunk of r otherwise."""
+    w = WORKLOADS[workload]
+    if w["N"] <= 512:
+        return w["M"]
+    return ((1 << 30) // (((w["N"] + 31) // 32 * 32) * 8)) // 64 * 64
+
+
+def kernel_source_hash(workload="C3"):
+    """sha256 of the CODE of the dominant kernel (its region of the translation unit; comments and blank lines stripped: neither a reworded
+    comment nor an edit to ANOTHER kernel of the file invalidates a measurement): a committed PMC figure is only quoted for the source it
+    was measured on."""
     import hashlib
     import re
 
-    with open(os.path.join(ROOT, "bayesian-optimization_amd", "csrc", "kernels_posterior.hip")) as f:
+    _, fname, first, last = dominant_kernel(workload)
+    with open(os.path.join(ROOT, "bayesian-optimization_amd", "csrc", fname)) as f:
         src = f.read()
+    if first is not None:
+        src = src[src.index(first) : src.index(last)]
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     code = [re.sub(r"\s+", " ", re.sub(r"//.*$", "", ln)).strip() for ln in src.split("\n")]
     return hashlib.sha256("\n".join(c for c in code if c).encode()).hexdigest()[:16]
@@ -63,21 +80,22 @@ def kernel_source_hash():
 
 def measured_traffic(workload, n_per_launch):
     """HBM bytes per launch of the dominant kernel.  rocprofv3 counters cannot be collected from inside this process, so
-    this is a COMMITTED figure: the last PMC passes (tools/pmc_sweep.py -> profiles/c3_pmc.json: FETCH_SIZE x2 gfx950
-    correction + WRITE_SIZE, separate --pmc runs), quoted only when workload, chunk size AND the kernel source hash
-    recorded with it match the running code; otherwise (None, reason) -- never a stale number."""
+    this is a COMMITTED figure: the last PMC passes (tools/pmc_passes.sh -> profiles/<workload>_pmc.json: FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, separate --pmc runs), quoted only when chunk size AND the kernel source hash recorded with it match the
+    running code; otherwise (None, reason) -- never a stale number."""
+    pmc_file = os.path.join("profiles", "%s_pmc.json" % workload.lower())
     try:
-        with open(os.path.join(ROOT, PMC_FILE)) as f:
+        with open(os.path.join(ROOT, pmc_file)) as f:
             p = json.load(f)
     except Exception:
-        return None, "no committed PMC file (%s)" % PMC_FILE
-    if workload != p.get("workload", "C3") or os.environ.get("BOGP_CHUNK_MB"):
-        return None, "committed PMC passes are for %s at the default chunk size" % p.get("workload", "C3")
+        return None, "no committed PMC file (%s)" % pmc_file
+    if os.environ.get("BOGP_CHUNK_MB"):
+        return None, "committed PMC passes are for the default chunk size"
     if int(p["candidates_per_launch"]) != int(n_per_launch):
         return None, "committed PMC passes used %s candidates per launch" % p["candidates_per_launch"]
-    if p.get("kernel_source_sha256") != kernel_source_hash():
-        return None, "kernel source changed since the committed PMC passes (%s, commit %s)" % (PMC_FILE, p.get("commit", "?"))
-    return float(p["traffic_bytes_per_launch"]), "committed PMC passes of commit %s (%s); not collected in this run" % (p.get("commit", "?"), PMC_FILE)
+    if p.get("kernel_source_sha256") != kernel_source_hash(workload):
+        return None, "kernel source changed since the committed PMC passes (%s, commit %s)" % (pmc_file, p.get("commit", "?"))
+    return float(p["traffic_bytes_per_launch"]), "committed PMC passes of commit %s (%s); not collected in this run" % (p.get("commit", "?"), pmc_file)
 
 
 def launch_command(n_gpus, argv, port=None):
@@ -120,7 +138,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-sample", type=int, default=49152, help="candidates timed through the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-sample", type=int, default=40960, help="candidates timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-seeds", action="store_true", help="skip the seed-1 / seed-2 repeats of the workload (SURVEY.md 8d)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -390,7 +408,7 @@ def main():
     if rank == 0:
         total = M_total * args.steps
         value = total / elapsed
-        traffic, traffic_source = measured_traffic(args.workload, ((1 << 30) // (((N + 31) // 32 * 32) * 8)) // 64 * 64)
+        traffic, traffic_source = measured_traffic(args.workload, min(candidates_per_launch(args.workload), M) if N <= 512 else candidates_per_launch(args.workload))
         flops_contract = (float(N) * N + 3.0 * N) * M * args.steps  # k_contract: forward substitution + sum of squares
         achieved = flops_contract / (tim["contract_ms"] * 1e-3) / 1e12
         if tim["corr_ms"] == 0.0 and tim["acquisition_ms"] == 0.0:  # the fused small-N sweep: ONE kernel, its whole time
@@ -456,32 +474,67 @@ def dry_candidates(first_row, n_rows, d):
 
 
 def cpu_baseline(w, X, y, par, plugin, Xh, n_sample, eng):
-    """The oracle ('port' of gpr.py:486-510 + the vectorised acquisition closed forms) on a bounded sample of the
-    same candidates, 1024-row chunks, BLAS threads = all host cores.  Doubles as a parity check of the GPU run."""
+    """The oracle ('port' of gpr.py:486-510 + the vectorised acquisition closed forms) on a bounded sample of the same candidates, 1024-row
+    chunks, BLAS threads = all host cores: 2 warm-up passes, then the MEDIAN of 5 timed passes over disjoint fifths of the sample
+    (BASELINE.md section 3.3).  Doubles as a parity check of the GPU run.  Second figure, `as_is`: how the unmodified
+    reference consumes the path -- one acquisition call per point (acquisition_fun.py:153-176 through gpr.py:486-510 on a (1, d) array) --
+    beside the device's one-point call (bogp_point_eval)."""
     from oracle import gp_oracle as O
 
+    pools = []
     try:
         from threadpoolctl import threadpool_info
 
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        pools = [{k: p.get(k) for k in ("user_api", "internal_api", "num_threads", "version")} for p in threadpool_info()]
+        threads = max([p.get("num_threads") or 1 for p in pools] or [1])
     except Exception:
         threads = os.cpu_count() or 1
     n = min(n_sample, len(Xh))
+    n_pass = 5
+    per = (n // n_pass) // 1024 * 1024 or n // n_pass
     st = O.make_state(par, X, y, w["kernel"], O.MODE_NOISY, 1e-6)
-    O.sweep(st, Xh[:1024], w["acq"], plugin, True)  # warm-up
-    t0 = time.perf_counter()
-    obest, oidx, ovals, omu, omse = O.sweep(st, Xh[:n], w["acq"], plugin, True, return_values=True)
-    dt = time.perf_counter() - t0
-    # parity of the very run that was timed: same rows through the GPU path
-    eng.upload_candidates(Xh[:n])
+    for _ in range(2):
+        O.sweep(st, Xh[:1024], w["acq"], plugin, True)  # warm-up
+    secs, omu, omse, ovals = [], [], [], []
+    for i in range(n_pass):
+        t0 = time.perf_counter()
+        _, _, v, m, s = O.sweep(st, Xh[i * per : (i + 1) * per], w["acq"], plugin, True, return_values=True)
+        secs.append(time.perf_counter() - t0)
+        omu.append(m.ravel()), omse.append(s.ravel()), ovals.append(v)
+    nt = n_pass * per
+    omu, omse, ovals = np.concatenate(omu), np.concatenate(omse), np.concatenate(ovals, axis=1)
+    oidx = np.array([O.nan_first_argmax(v) for v in ovals])
+    # parity of the very rows that were timed: the same rows through the GPU path
+    eng.upload_candidates(Xh[:nt])
     mu, mse = eng.predict()
     best, idx = eng.sweep(w["acq"], plugin, True)
-    np.testing.assert_allclose(mu, omu.ravel(), rtol=1e-6, atol=1e-9)
-    np.testing.assert_allclose(mse, omse.ravel(), rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(mu, omu, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(mse, omse, rtol=1e-6, atol=1e-12)
     np.testing.assert_array_equal(idx, oidx)
-    return {"value": n / dt, "unit": "candidates/s", "cores": threads, "kind": "port",
-            "sample": "%d of the timed run's candidates, 1024-row chunks, NumPy/SciPy oracle; parity vs GPU checked (1e-6, argmax exact)" % n,
-            "seconds": dt}  # fmt: skip
+    med = float(np.median(secs))
+    # as-is: single-row calls
+    n_one = 200 if w["N"] <= 2048 else 40
+    t0 = time.perf_counter()
+    for i in range(n_one):
+        m1, s1 = O.predict(st, Xh[i : i + 1])
+        O.acquisition(w["acq"][0][0], w["acq"][0][1], m1.ravel(), s1.ravel(), plugin, float(st.sigma2[0]), True)
+    one_cpu = (time.perf_counter() - t0) / n_one
+    dev_us = None
+    try:
+        eng.point_eval(Xh[0], w["acq"][:1], plugin, True)
+        t0 = time.perf_counter()
+        for i in range(n_one):
+            eng.point_eval(Xh[i], w["acq"][:1], plugin, True)
+        dev_us = (time.perf_counter() - t0) / n_one * 1e6
+    except Exception:  # a model the one-point path does not serve
+        pass
+    return {"value": per / med, "unit": "candidates/s", "cores": threads, "kind": "port",
+            "sample": "2 warm-ups, then the median of %d timed passes of %d rows each (disjoint slices of the timed run's candidates, %d rows in all), 1024-row chunks, "
+                      "NumPy/SciPy oracle; parity vs GPU checked on those rows (1e-6, argmax exact)" % (n_pass, per, nt),
+            "seconds_per_pass": [round(t, 4) for t in secs], "threadpool_info": pools, "os_cpu_count": os.cpu_count(),
+            "as_is": {"value": 1.0 / one_cpu, "unit": "single-row acquisition evaluations/s (value only)", "calls": n_one,
+                      "what": "one predict(eval_MSE=True) + one criterion per (1, d) row through the oracle: how the unmodified reference consumes the path (BASELINE.md 3.5)",
+                      "device_point_eval_us": dev_us, "device_evaluations_per_s": (1e6 / dev_us) if dev_us else None}}  # fmt: skip
 
 
 if __name__ == "__main__":

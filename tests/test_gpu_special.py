@@ -123,7 +123,9 @@ def test_ill_conditioned_general_nu_model_against_the_exact_posterior(eng):
     dev_mu, dev_mse = np.abs(mu - g["true_mu"]).max() / scale, np.abs(mse - g["true_mse"]).max() / s2
     ref_mu, ref_mse = float(g["ref_err_mu"]) / scale, float(g["ref_err_mse"])
     print("G37: cond %.2e; device vs exact: mu %.2e mse %.2e; reference vs exact: mu %.2e mse %.2e; tolerance %.2e" % (cond, dev_mu, dev_mse, ref_mu, ref_mse, tol))
-    assert dev_mu <= tol and dev_mse <= tol
     assert ref_mu <= tol and ref_mse <= tol
-    np.testing.assert_allclose(mu, g["mu"], rtol=0, atol=2 * tol * scale)
-    np.testing.assert_allclose(mse, g["mse"], rtol=0, atol=2 * tol * s2)
+    # measured (MI355X, r05): device 4.6e-8 / 2.1e-11, reference 1.4e-7 / 2.5e-10 -- both far inside the tolerance an ill-conditioned problem
+    # is entitled to, and the device inside the path's own 1e-6 even here; the two agree with each other at 1e-6 as well
+    assert dev_mu <= 1e-6 and dev_mse <= 1e-6
+    np.testing.assert_allclose(mu, g["mu"], rtol=0, atol=1e-6 * scale)
+    np.testing.assert_allclose(mse, g["mse"], rtol=0, atol=1e-6 * s2)
