@@ -165,6 +165,18 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
   if (d > BOGP_MAX_DIM) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_set_train: d = %d > %d: the sweep producer keeps a 64 x d candidate tile in the CU's 160 KB of LDS", d, BOGP_MAX_DIM);
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->dX && d != h->d && (h->dXs || h->hXs_lazy)) {
+    // candidates were uploaded / bound / generated as M x (old d): rows of another width are not candidates of this model.  A lazy upload
+    // in flight would otherwise be finished later with the NEW d -- (M - lazy_done) * d_new doubles read from a host buffer of M * d_old
+    //  -- so it is dropped and the candidate set forgotten: the next sweep says "no candidates" until new ones arrive.
+    if (h->hXs_lazy) {
+      HIPCHK(h, hipStreamSynchronize(h->stream_copy));
+      h->hXs_lazy = nullptr;
+    }
+    h->dXs = nullptr;
+    h->M = 0;
+    h->last_q = h->last_topk_q = h->last_topk_k = 0;
+  }
   // leading dimension: N rounded up to 64; to 128 from 6144 on, where the inverse and R^-1 work on 128 x 128 tiles
   const int ld_need = N > 6080 ? ((N + 127) / 128) * 128 : ((N + 63) / 64) * 64;
   const bool fits = h->dX && h->dtheta && ld_need <= h->cap_ld && d <= h->cap_d && n_targets <= h->cap_nt;

@@ -44,8 +44,10 @@ bool prep_slot(int kernel, int mode, int d, const double* par, int n_par, double
                double* th, SlotPrep* sp) {
   int n_theta = n_par - (mode == BOGP_MODE_NOISELESS ? 0 : 1);
   double pexp = 0.0;
+  // ONE predicate for the three paths of bogp_nll_batch (include/bogp.h: a non-finite or non-positive parameter -> BOGP_ERR_INVALID for that slot):
+  // the sequential path below applies the same test before it calls bogp_nll
   for (int k = 0; k < n_par; ++k)
-    if (!std::isfinite(par[k])) return false;
+    if (!std::isfinite(par[k]) || !(par[k] > 0)) return false;
   if (kernel == BOGP_KERNEL_GENEXP || kernel == BOGP_KERNEL_MATERN_NU) {
     pexp = par[n_theta - 1];
     if (!(pexp > 0) || (kernel == BOGP_KERNEL_MATERN_NU && pexp > 60.0)) return false;

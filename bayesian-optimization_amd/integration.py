@@ -33,6 +33,7 @@ other inner optimiser ("BFGS", ...) the reference's method runs unchanged.
 """
 from __future__ import annotations
 
+import types
 import warnings
 from copy import copy
 
@@ -139,19 +140,19 @@ class _Dispatch(type):
     def __call__(cls, *args, **kwargs):
         if "_pick" not in cls.__dict__:
             # a user's `class My(bayes_optim.GaussianProcess)` inherits this metaclass: its overrides were written against the
-            # reference's class, so it is built on the HOST class with the subclass's own namespace on top (never silently
-            # replaced by a plain device object)
-            host = next((b._host for b in cls.__mro__ if isinstance(b, _Dispatch) and "_host" in b.__dict__ and b._host is not None), None)
-            if host is None:
-                raise TypeError("%s derives from a dispatching bogp class that has no host class to fall back to" % cls.__name__)
-            ns = {k: v for k, v in cls.__dict__.items() if k not in ("__dict__", "__weakref__")}
-            return type(cls.__name__, (host,), ns)(*args, **kwargs)
+            # reference's class, so it is realised on the HOST class with the subclass's own namespace on top (never silently
+            # replaced by a plain device object); see _realise
+            return _realise(cls)(*args, **kwargs)
         return cls._pick(args, kwargs)(*args, **kwargs)
 
     def __instancecheck__(cls, obj):
+        if "_pick" not in cls.__dict__:  # a user's subclass: its instances are instances of its realisation (and of the realisations of ITS subclasses)
+            return isinstance(obj, _realise(cls))
         return isinstance(obj, tuple(t for t in (cls._device, cls._host) if t is not None))
 
     def __subclasscheck__(cls, sub):
+        if "_pick" not in cls.__dict__:
+            return sub is cls or (isinstance(sub, _Dispatch) and cls in sub.__mro__) or issubclass(sub, _realise(cls))
         return sub is cls or issubclass(sub, tuple(t for t in (cls._device, cls._host) if t is not None))
 
     def __getattr__(cls, name):
@@ -161,6 +162,70 @@ class _Dispatch(type):
             if t is not None and hasattr(t, name):
                 return getattr(t, name)
         raise AttributeError("%s has no attribute %r" % (cls.__name__, name))
+
+
+_REALISED = {}
+
+
+def _rebind_class_cell(v, cell):
+    """`v` with the `__class__` cell of zero-argument super() re-pointed at `cell` (functions, and the functions inside static / class
+    methods and properties); anything else unchanged."""
+    if isinstance(v, types.FunctionType):
+        if "__class__" not in v.__code__.co_freevars:
+            return v
+        closure = tuple(cell if n == "__class__" else c for n, c in zip(v.__code__.co_freevars, v.__closure__))
+        f = types.FunctionType(v.__code__, v.__globals__, v.__name__, v.__defaults__, closure)
+        f.__kwdefaults__, f.__qualname__, f.__doc__, f.__module__ = v.__kwdefaults__, v.__qualname__, v.__doc__, v.__module__
+        f.__dict__.update(v.__dict__)
+        f.__annotations__ = dict(getattr(v, "__annotations__", {}) or {})
+        return f
+    if isinstance(v, staticmethod):
+        return staticmethod(_rebind_class_cell(v.__func__, cell))
+    if isinstance(v, classmethod):
+        return classmethod(_rebind_class_cell(v.__func__, cell))
+    if isinstance(v, property):
+        return property(*(None if f is None else _rebind_class_cell(f, cell) for f in (v.fget, v.fset, v.fdel)), v.__doc__)
+    return v
+
+
+def _bare_instance(cls):
+    r = _realise(cls)
+    return r.__new__(r)
+
+
+def _realise(cls):
+    """The ordinary class behind a user's subclass of a dispatching name: built ONCE per subclass -- so type(a) is type(b) and
+    isinstance works --, on the host class (or on the realisations of the user's own intermediate subclasses), with the subclass's
+    namespace on top and the `__class__` cell of its methods re-pointed at the realisation, so that zero-argument `super()` resolves
+    (`super().__init__(...)`, an overriding `fit` that calls `super().fit`).  Instances pickle through the dispatching name the user's
+    module holds (`__reduce_ex__`), which is the only name pickle / dill can look up."""
+    r = _REALISED.get(cls)
+    if r is not None:
+        return r
+    bases = []
+    for b in cls.__bases__:
+        if isinstance(b, _Dispatch):
+            if "_pick" in b.__dict__:
+                host = b.__dict__.get("_host")
+                if host is None:
+                    raise TypeError("%s derives from a dispatching bogp class that has no host class to fall back to" % cls.__name__)
+                bases.append(host)
+            else:
+                bases.append(_realise(b))
+        else:
+            bases.append(b)
+    cell = types.CellType()
+    ns = {k: _rebind_class_cell(v, cell) for k, v in cls.__dict__.items() if k not in ("__dict__", "__weakref__")}
+
+    def __reduce_ex__(self, protocol, _cls=cls):
+        state = self.__getstate__() if hasattr(self, "__getstate__") and type(self).__getstate__ is not getattr(object, "__getstate__", None) else self.__dict__
+        return (_bare_instance, (_cls,), state)
+
+    ns.setdefault("__reduce_ex__", __reduce_ex__)
+    r = type(cls.__name__, tuple(bases), ns)
+    cell.cell_contents = r
+    _REALISED[cls] = r
+    return r
 
 
 def _dispatching_criterion(name, device_cls, host_cls):

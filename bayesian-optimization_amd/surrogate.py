@@ -519,6 +519,8 @@ class GaussianProcess:
             if eval_budget <= 0 or wait_count >= self.wait_iter:
                 break
         if world > 1:
+            for _ in range(iteration + 1, self.random_start):  # (as in _restarts_in_lock_step: every rank consumes random_start - 1 draws)
+                np.random.uniform(log10bounds[:, 0], log10bounds[:, 1])
             param_opt, llf_opt = distributed.exchange_best_parameters(np.asarray(param_opt, float), float(llf_opt))
 
         optimal_param = 10.0**param_opt
@@ -585,6 +587,13 @@ class GaussianProcess:
                     stop = True  # (the whole wave has already run: its later restarts still count, as above)
             if stop:
                 break
+        if world > 1:
+            # ranks leave the loop on their OWN budget / stagnation counters: the start points of the restarts nobody ran are still drawn,
+            # so that every rank has consumed exactly random_start - 1 draws and the identically seeded global streams stay identical for
+            # whatever samples next
+            while it < self.random_start:
+                np.random.uniform(lo, hi)
+                it += 1
         self._committed_par = None  # (the batched paths leave the factor buffers alone, the fallback paths do not)
         return np.asarray(param_opt, dtype=float), float(llf_opt)
 

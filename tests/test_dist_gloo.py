@@ -170,7 +170,7 @@ def _fit_worker(rank, world, port, q_out, restart_batch=0):
         gp._engine = OracleEngine()  # host-logic test: see tests/support/oracle_engine.py
         np.random.seed(11)  # identical stream on every rank
         gp.fit(X, y)
-        q_out.put((rank, gp.log_likelihood_, gp.theta_.copy(), gp.eval_count))
+        q_out.put((rank, gp.log_likelihood_, gp.theta_.copy(), gp.eval_count, float(np.random.uniform())))  # last: the NEXT draw of the global stream
     finally:
         dist.destroy_process_group()
 
@@ -189,8 +189,9 @@ def test_mle_restarts_spread_over_two_ranks():
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
-    (r0, llf0, th0, n0), (r1, llf1, th1, n1) = res
+    (r0, llf0, th0, n0, u0), (r1, llf1, th1, n1, u1) = res
     assert llf0 == llf1 and np.array_equal(th0, th1)  # every rank commits the same winner
+    assert u0 == u1  # ... and has consumed the global np.random stream alike: host-sampled ask() calls stay in step
     assert np.isfinite(llf0) and n0 <= 135 and n1 <= 135  # ~half the budget each (L-BFGS-B overshoots maxfun by a line search)
 
 
@@ -210,8 +211,9 @@ def test_lock_step_restarts_spread_over_two_ranks():
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
-    (r0, llf0, th0, n0), (r1, llf1, th1, n1) = res
+    (r0, llf0, th0, n0, u0), (r1, llf1, th1, n1, u1) = res
     assert llf0 == llf1 and np.array_equal(th0, th1)
+    assert u0 == u1  # the ranks left the wave loop on their own counters, yet drew the same number of start points
     assert np.isfinite(llf0) and 0 < n0 <= 190 and 0 < n1 <= 190
 
 

@@ -373,6 +373,49 @@ def test_subclasses_and_foreign_trends_of_the_dispatching_class_stay_on_the_host
     m = My(corr="matern", thetaL=[1e-2] * 2, thetaU=[1e2] * 2)
     assert isinstance(m, CpuGP) and not isinstance(m, bogp.GaussianProcess) and m.predict(None) == "overridden"
 
+    # the usual pattern -- zero-argument super() in __init__ and in an overriding fit -- must resolve; the realised class is
+    # built once (type identity, isinstance against the user's name), further subclassing works, and instances pickle
+    global _Sup, _Sub  # (module level names: pickle looks classes up by module attribute)
+
+    class _Sup(bayes_optim.GaussianProcess):
+        def __init__(self, *a, tag="t", **kw):
+            super().__init__(*a, **kw)
+            self.tag = tag
+
+        def fit(self, X, y):
+            self.fits = getattr(self, "fits", 0) + 1
+            return super().fit(X, y)
+
+        @property
+        def label(self):
+            return "sup:" + super().__class__.__name__
+
+    class _Sub(_Sup):
+        def fit(self, X, y):
+            self.sub_fits = getattr(self, "sub_fits", 0) + 1
+            return super().fit(X, y)
+
+    a = _Sup(corr="matern", thetaL=[1e-2] * 2, thetaU=[1e2] * 2, nugget=1e-6, random_start=2, tag="a")
+    b = _Sup(corr="matern", thetaL=[1e-2] * 2, thetaU=[1e2] * 2, nugget=1e-6, random_start=2)
+    assert type(a) is type(b) and isinstance(a, _Sup) and isinstance(a, CpuGP) and issubclass(_Sub, _Sup) and not isinstance(m, _Sup)
+    assert a.tag == "a" and b.tag == "t" and a.label.startswith("sup:")
+    rng = np.random.default_rng(0)
+    X = rng.uniform(-1, 1, (12, 2))
+    y = np.sum(X**2, axis=1).reshape(-1, 1)
+    np.random.seed(1)
+    assert a.fit(X, y) is a and a.fits == 1 and a.is_fitted
+    c = _Sub(corr="matern", thetaL=[1e-2] * 2, thetaU=[1e2] * 2, nugget=1e-6, random_start=2)
+    assert isinstance(c, _Sub) and isinstance(c, _Sup) and not isinstance(a, _Sub)
+    np.random.seed(1)
+    c.fit(X, y)
+    assert c.sub_fits == 1 and c.fits == 1
+    np.testing.assert_allclose(c.predict(X[:3]), a.predict(X[:3]))
+    import pickle
+
+    a2 = pickle.loads(pickle.dumps(a))
+    assert type(a2) is type(a) and a2.tag == "a" and a2.fits == 1
+    np.testing.assert_array_equal(a2.predict(X[:3]), a.predict(X[:3]))
+
     class CubicTrend(BasisExpansionTrend):
         def __init__(self, n_feature, beta=None):
             super().__init__(n_feature, n_feature + 1, beta)
