@@ -101,11 +101,21 @@ extern "C" int bogp_create(int device, bogp_handle** out) {
   return BOGP_OK;
 }
 
+// BOGP_TREND_ROWS=0: polynomial bases with p > 32 columns stay on the r02-r04 tile products (the A/B switch of profiles/r05_trend_timing.txt)
+static bool trend_rows_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("BOGP_TREND_ROWS");
+    return !(e && atoi(e) == 0);
+  }();
+  return on;
+}
+
 static void free_trend(bogp_handle* h) {
   dfree(h->dF); dfree(h->dFt); dfree(h->dQ1); dfree(h->dQ); dfree(h->dWp); dfree(h->dWpT); dfree(h->dSinvP);
   dfree(h->gsplit.scratch); dfree(h->gsplit.tickets); h->gsplit.cap = 0; h->gsplit.max_tiles = 0;
   for (int b = 0; b < 2; ++b) { dfree(h->dA[b]); dfree(h->dAV[b]); dfree(h->dAU[b]); }
   dfree(h->dAw); dfree(h->dAT); dfree(h->dGinv); dfree(h->dSinv); dfree(h->dbetav); dfree(h->dqty); dfree(h->dinfo2);
+  dfree(h->dVpx); h->vpx_cap = 0; dfree(h->dAtx); h->atx_cap = 0; h->vx_Ne = h->vx_Nt = 0;
   h->tr_built = -1; h->tr_p = 0; h->ldp = 0; h->trend = BOGP_TREND_CONSTANT; h->p = 1; h->reml_ftf_basis = -1;
 }
 
@@ -898,7 +908,6 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
   const bool positive = v > 0;  // exp(llf) > 1
   *llf = v;
   if (grad) {
-    if (n_theta != d) FAIL(h, BOGP_ERR_UNSUPPORTED, "gradient with isotropic theta (len %d, d = %d) is not built", n_theta, d);
     hipStream_t st = h->stream;
     if (!h->dRinv) HIPCHK(h, hipMalloc((void**)&h->dRinv, (size_t)UUT_PARTS * h->cap_ld * h->cap_ld * sizeof(double)));
     int nparts = UUT_PARTS;
@@ -934,9 +943,22 @@ extern "C" int bogp_nll_restricted(bogp_handle* h, int kernel, int mode, const d
     HIPCHK(h, hipStreamSynchronize(st));
     const double tr = S[d + 1], gg = S[d + 2], qq = (estimate_trend && ptrend == 1) ? S[d + 3] / o.ftft : 0.0;
     const double diag = -0.5 * (tr / tv - gg / (tv * tv) - qq);  // sum over the diagonal of (Cinv - gamma_ gamma_^T - term)
-    for (int k = 0; k < d; ++k) grad[k] = S[k];
-    grad[d] = S[d] / tv + diag;                              // d / d sigma2: C_grad = R0 (:883)
-    if (mode == BOGP_MODE_NOISE_ESTIM) grad[d + 1] = diag;   // d / d noise_var: C_grad = I (:885-887)
+    if (n_theta == d) {
+      for (int k = 0; k < d; ++k) grad[k] = S[k];
+      grad[d] = S[d] / tv + diag;                              // d / d sigma2: C_grad = R0 (:883)
+      if (mode == BOGP_MODE_NOISE_ESTIM) grad[d + 1] = diag;   // d / d noise_var: C_grad = I (:885-887)
+    } else {
+      // isotropic theta (one entry for d dimensions): the reference still builds the (N, N, d) tensor of PER-DIMENSION derivatives
+      // (corr_grad_theta, :736-770: `diff` has d slices whatever len(theta) is), appends R0 [and I], and reads slice i for parameter i
+      // (:889-900) -- so entry 0 is the derivative w.r.t. the FIRST dimension's weight alone, and for d >= 2 the sigma2 entry is the
+      // second dimension's slice, not R0's.  Reproduced as it is (as for the concentrated likelihood, G18): slices 0 .. n_par - 1 of
+      // [dims 0 .. d - 1 | R0 | I].
+      std::vector<double> full((size_t)d + 2);
+      for (int k = 0; k < d; ++k) full[k] = S[k];
+      full[d] = S[d] / tv + diag;
+      full[d + 1] = diag;
+      for (int i = 0; i < n_par; ++i) grad[i] = full[i];
+    }
   }
   if (positive) FAIL(h, BOGP_ERR_LLF_POSITIVE, "restricted log-likelihood %g > 0 is rejected by the reference (gpr.py:868-871)", v);
   return BOGP_OK;
@@ -1011,6 +1033,23 @@ extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* p
       HIPCHK(h, hipMemsetAsync(h->dSinvP, 0, (size_t)pp * pp * sizeof(double), st));
       HIPCHK(h, launch_transpose_pad(h->dSinv, ptrend, ptrend, ptrend, h->dSinvP, pp, st));
       HIPCHK(h, hipMemcpyAsync(h->h_Sinv.data(), h->dSinv, (size_t)ptrend * ptrend * sizeof(double), hipMemcpyDeviceToHost, st));
+      // more than 32 columns (a quadratic basis; a linear one from d = 32): the u term as p extra rows of the packed factor (k_pack_Vx)
+      h->vx_Ne = h->vx_Nt = 0;
+      if (trend_rows_enabled() && ptrend > 32) {
+        const int cols = contract_cols_per_group();
+        const int Ne = (Np + cols - 1) / cols * cols, Nt = Ne + (ptrend + 31) / 32 * 32;
+        int e2;
+        if ((e2 = ensure(h, &h->dAtx, &h->atx_cap, (size_t)N * ptrend))) return e2;
+        if (h->vpx_cap < (size_t)Nt * Nt / 2 || !h->dVpx) {
+          dfree(h->dVpx);
+          h->vpx_cap = 0;
+          HIPCHK(h, hipMalloc((void**)&h->dVpx, (size_t)Nt * Nt / 2 * sizeof(double2)));
+          h->vpx_cap = (size_t)Nt * Nt / 2;
+        }
+        HIPCHK(h, launch_gemm(0, 0, N, ptrend, ptrend, one, h->dWp, Np, h->dGinv, ptrend, zero, h->dAtx, N, st, 0, &h->gsplit));  // W G^-1
+        HIPCHK(h, launch_pack_Vx(h->dV, N, ldr, h->dAtx, N, h->dGinv, ptrend, Ne, Nt, h->dVpx, st));
+        h->vx_Ne = Ne; h->vx_Nt = Nt;
+      }
     }
   }
   // [d][Np] + two zero rows: k_sweep_small walks the dimensions three at a time
@@ -1431,16 +1470,21 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
   const int64_t Mpad = ((M + 63) / 64) * 64;
   size_t chunk_bytes = (size_t)1 << 30;
   if (const char* env = getenv("BOGP_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, atoi(env)) << 20;
-  int64_t Mc = (int64_t)(chunk_bytes / ((size_t)Np * sizeof(double)) / 64) * 64;
+  // trend-rows path (k_pack_Vx): the chunk carries Nt - Np extra rows (the hole up to a whole column group, then -f(x*)), the contraction
+  // runs over the extended factor
+  const bool vx = h->vx_Nt > 0 && h->p > 32 && h->estimate_trend && need_var;
+  const int Nrows = vx ? h->vx_Nt : Np;
+  int64_t Mc = (int64_t)(chunk_bytes / ((size_t)Nrows * sizeof(double)) / 64) * 64;
   Mc = std::max<int64_t>(64, std::min<int64_t>(Mc, Mpad));
   const int nblk32 = Np / 32;
   // the training set is sliced into groups of 8 x 32 rows per producer workgroup: a function of N only, so that the
   // grouping of the partial sums of mu (hence every output bit) does not depend on the chunk size
   const int nblk_per_split = 8;
   const int S = (nblk32 + nblk_per_split - 1) / nblk_per_split;
-  const int NJ16 = Np / 16;
   const int cols = contract_cols_per_group();
-  const int nJ = (Np + cols - 1) / cols;
+  const int NJ16 = Nrows / 16;
+  const int nJ_main = (Np + cols - 1) / cols;            // column groups of V: |L^-1 r|^2
+  const int nJ = vx ? (Nrows + cols - 1) / cols : nJ_main;  // ... + the groups of the trend rows: |u|^2
   const int64_t nchunk = (M + Mc - 1) / Mc;
   const int64_t nblk_total = (M + 255) / 256 + nchunk;  // per-chunk block counts are rounded up
 
@@ -1563,21 +1607,23 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
   const int nbuf = overlap ? 2 : 1;
   int e;
   for (int b = 0; b < nbuf; ++b) {
-    if ((e = ensure(h, &h->drT[b], &h->rT_cap[b], (size_t)Np * Mc))) return e;
+    if ((e = ensure(h, &h->drT[b], &h->rT_cap[b], (size_t)Nrows * Mc))) return e;
     if ((e = ensure(h, &h->dmu_part[b], &h->mu_part_cap[b], (size_t)S * Mc))) return e;
     if ((e = ensure(h, &h->dw_part[b], &h->w_part_cap[b], (size_t)S * Mc))) return e;
   }
   if ((e = ensure(h, &h->dss_part, &h->ss_part_cap, (size_t)nJ * Mc))) return e;
   if (h->p > 1) {
     if (Mc > 0x7fffffff / 2) FAIL(h, BOGP_ERR_UNSUPPORTED, "chunk of %lld candidates is too large for the trend GEMM (lower BOGP_CHUNK_MB)", (long long)Mc);
-    if ((e = ensure(h, &h->dTt, &h->Tt_cap, (size_t)Mc * ((h->p + 127) / 128 * 128)))) return e;  // whole 128-column tiles (k_mm128)
-    if ((e = ensure(h, &h->dCS, &h->CS_cap, (size_t)Mc * ((h->p + 127) / 128 * 128)))) return e;
+    if (!vx) {
+      if ((e = ensure(h, &h->dTt, &h->Tt_cap, (size_t)Mc * ((h->p + 127) / 128 * 128)))) return e;  // whole 128-column tiles (k_mm128)
+      if ((e = ensure(h, &h->dCS, &h->CS_cap, (size_t)Mc * ((h->p + 127) / 128 * 128)))) return e;
+    }
     if ((e = ensure(h, &h->duu, &h->uu_cap, (size_t)Mc))) return e;
     if ((e = ensure(h, &h->dmtrend, &h->mtrend_cap, (size_t)Mc))) return e;
   }
   // a polynomial basis of at most 32 columns under universal kriging: T = W^T r is accumulated by the producer itself
   // (k_corr_chunk<K, PV>) and finished by ONE per-candidate launch (k_trend_small); BOGP_TREND_FUSED=0 keeps the tile products
-  const int pv = (h->p > 1 && h->estimate_trend && !(getenv("BOGP_TREND_FUSED") && atoi(getenv("BOGP_TREND_FUSED")) == 0)) ? corr_trend_columns(h->p) : 0;
+  const int pv = (!vx && h->p > 1 && h->estimate_trend && !(getenv("BOGP_TREND_FUSED") && atoi(getenv("BOGP_TREND_FUSED")) == 0)) ? corr_trend_columns(h->p) : 0;
   if (pv > 0)
     for (int b = 0; b < nbuf; ++b)
       if ((e = ensure(h, &h->dtpart[b], &h->tpart_cap[b], (size_t)S * pv * Mc))) return e;
@@ -1622,8 +1668,8 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
       ca.pv = pv; ca.Wrow = h->dWpT; ca.wld = (h->p + 127) / 128 * 128; ca.t_part = h->dtpart[b];
     }
     ContractArgs ka;
-    ka.rT = h->drT[b]; ka.Vp = h->dVp; ka.ss_part = h->dss_part; ka.Mc = Mc; ka.nMt = (int)(Mc_eff / 64); ka.nJ = nJ;
-    ka.NJ16 = NJ16; ka.NKP = Np / 8;
+    ka.rT = h->drT[b]; ka.Vp = vx ? h->dVpx : h->dVp; ka.ss_part = h->dss_part; ka.Mc = Mc; ka.nMt = (int)(Mc_eff / 64); ka.nJ = nJ;
+    ka.NJ16 = NJ16; ka.NKP = Nrows / 8;
     // producer: may reuse buffer b only after chunk c-2 (its previous user) is completely done
     if (overlap && c >= 2) HIPCHK(h, hipStreamWaitEvent(stP, h->ev[(size_t)((c - 2) * EPC + 4)], 0));
     if (h->hXs_lazy) {  // lazily uploaded candidates: this chunk's rows must have arrived (chunk 0: copied here; later ones: below)
@@ -1634,6 +1680,11 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     }
     HIPCHK(h, hipEventRecord(ev[0], stP));
     HIPCHK(h, launch_corr_chunk(h->kernel, ca, (int)(Mc_eff / 64), S, stP));
+    if (vx) {  // rows Np .. Ne - 1 = 0 (their columns of the factor are zero: any FINITE value would do), rows Ne .. = -f(x*), then zeros
+      if (h->vx_Ne > Np) HIPCHK(h, hipMemsetAsync(h->drT[b] + (size_t)Np * Mc, 0, (size_t)(h->vx_Ne - Np) * Mc * sizeof(double), stP));
+      HIPCHK(h, launch_trend_rows(h->trend, h->dXs, m0, mcount, Mc_eff, d, Mc, h->dbetav, h->drT[b] + (size_t)h->vx_Ne * Mc, h->p,
+                                  h->vx_Nt - h->vx_Ne, h->dmtrend, stP));
+    }
     HIPCHK(h, hipEventRecord(ev[1], stP));
     if (overlap) HIPCHK(h, hipStreamWaitEvent(st, ev[1], 0));
     HIPCHK(h, hipEventRecord(ev[2], st));
@@ -1643,7 +1694,8 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     HIPCHK(h, hipEventRecord(ev[3], st));
     AcqArgs aa;
     memset(&aa, 0, sizeof(aa));
-    aa.mu_part = h->dmu_part[b]; aa.w_part = h->dw_part[b]; aa.ss_part = h->dss_part; aa.S = S; aa.nJ = need_var ? nJ : 0; aa.Mc = Mc;
+    aa.mu_part = h->dmu_part[b]; aa.w_part = h->dw_part[b]; aa.ss_part = h->dss_part; aa.S = S; aa.nJ = need_var ? nJ_main : 0; aa.Mc = Mc;
+    aa.nJ_plus = vx ? nJ - nJ_main : 0;
     aa.mcount = mcount; aa.m0 = m0; aa.beta = h->beta; aa.G = h->G; aa.estimate_trend = h->estimate_trend;
     aa.sigma2 = h->sigma2; aa.mu_out = want_out ? h->dmu_out : nullptr; aa.mse_out = want_out ? h->dmse_out : nullptr;
     aa.q = q;
@@ -1661,7 +1713,9 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
       const int TI = (int)((Mc_eff + 127) / 128);
       const double one = 1.0, zero = 0.0;
       double* Tt = nullptr;
-      if (pv > 0) {
+      if (vx) {
+        // (mtrend was written by k_trend_rows beside the chunk's extra rows; |u|^2 comes out of the contraction)
+      } else if (pv > 0) {
         HIPCHK(h, launch_trend_small(h->trend, h->dXs, m0, mcount, d, Mc, h->dbetav, h->dtpart[b], S, pv, pt, h->dSinv, h->dmtrend, h->duu, st));
         aa.uu = h->duu;
       } else {

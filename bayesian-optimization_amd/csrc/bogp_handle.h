@@ -70,6 +70,12 @@ struct bogp_handle {
   double beta = 0, G = 0, sigma2 = 0, noise_var = 0, llf = 0, ftft = 0;
   double* dXthT = nullptr;  // [d][Np]
   double* dXnorm = nullptr;  // [Np] squared norms of the columns of XthT (k_corr_mfma)
+  // trend-rows path (p > 32 columns under universal kriging, kernels_fit.hip: k_pack_Vx): the packed extended factor, its row offsets
+  double2* dVpx = nullptr;
+  size_t vpx_cap = 0;
+  double* dAtx = nullptr;  // W G^-1 (N x p)
+  size_t atx_cap = 0;
+  int vx_Ne = 0, vx_Nt = 0;  // 0: the committed model does not use the path
   double2* dVp = nullptr;   // [Np/16][Np/8][64]
 
   // candidates

@@ -49,6 +49,7 @@ struct AcqArgs {
   const double* w_part;   // [S][Mc]
   const double* ss_part;  // [nJ][Mc]
   int S, nJ;
+  int nJ_plus = 0;        // trend-rows path (k_pack_Vx): column groups nJ .. nJ + nJ_plus - 1 of ss_part hold |u|^2 and are ADDED
   int64_t Mc;      // chunk stride of the partial arrays
   int64_t mcount;  // valid candidates in this chunk
   int64_t m0;      // global index of the chunk's first candidate
@@ -196,6 +197,10 @@ int grad_contract_blocks(int N);
 size_t gemv2_scratch_doubles(int N);
 // polynomial trends (p > 1)
 hipError_t launch_trend_train(int trend, const double* X, int N, int d, double* F, hipStream_t st);
+hipError_t launch_pack_Vx(const double* Vcm, int N, int ld, const double* At, int ldA, const double* Ginv, int p, int Ne, int Nt,
+                          double2* Vp, hipStream_t st);
+hipError_t launch_trend_rows(int trend, const double* Xs, int64_t m0, int64_t mcount, int64_t mrows, int d, int64_t Mc, const double* beta,
+                             double* Rext, int p, int prows, double* mtrend, hipStream_t st);
 hipError_t launch_trend_terms(int trend, const double* Xs, int64_t m0, int64_t mcount, int d, int64_t Mc, const double* beta,
                               double* T, double* mtrend, hipStream_t st);
 // small polynomial bases after the fused producer: T = sum of the slice sums, c = T - f(x*), mtrend = f(x*) . beta, uu = c^T Sinv c in ONE launch

@@ -30,7 +30,9 @@ __global__ __launch_bounds__(256) void k_acquisition(AcqArgs a) {
     for (int j = 0; j < a.nJ; ++j) ss += a.ss_part[(size_t)j * a.Mc + i];
     mu = (a.mtrend ? a.mtrend[i] : a.beta) + mu;
     double u2 = 0.0;
-    if (a.uu) {
+    if (a.nJ_plus > 0) {
+      for (int j = a.nJ; j < a.nJ + a.nJ_plus; ++j) u2 += a.ss_part[(size_t)j * a.Mc + i];
+    } else if (a.uu) {
       u2 = a.uu[i];
     } else if (a.estimate_trend) {
       const double u = (wd - 1.0) / a.G;

@@ -46,6 +46,43 @@ hipError_t launch_pack_V(const double* Vcm, int N, int ld, int Np, double2* Vp, 
   return hipGetLastError();
 }
 
+// r05, polynomial trends under universal kriging with p > 32 columns: the u term of the variance (gpr.py:496-498,
+//   u = G^-T (Ft^T L^-1 r - f(x*)),  MSE = (1 - |L^-1 r|^2 + |u|^2) sigma2)
+// becomes p EXTRA ROWS of the triangular factor.  With W = L^-T Ft (N x p) and B = G^-T (p x p, LOWER triangular because the G of the QR is
+// upper triangular):  u = (B W^T) r + B (-f).  So the matrix
+//        [ V        0   0 ]   rows 0 .. Np - 1           (V = L^-1, zero padded)
+//   Vx = [ 0        0   0 ]   rows Np .. Ne - 1          (Ne = Np rounded up to a whole column group of k_contract16)
+//        [ B W^T    0   B ]   rows Ne .. Ne + p - 1
+// is lower triangular, and against the extended chunk column  rx = [r ; 0 ; -f(x*)]  the contraction kernel -- unchanged -- returns
+// |V r|^2 in its first Ne / 256 column groups and |u|^2 in the groups behind them; k_acquisition subtracts the former and adds the latter.
+// The two per-chunk tile products of the r02-r04 path (T = W^T r: 2 N p flop a candidate at k_mm128's 60 %, then T S^-1) and their
+// second pass over the 1-GiB chunk are gone: the same 2 N p flop run inside k_contract16 at its 0.87, on the chunk it reads anyway.
+// Same packing as k_pack_V: Vp[(jt*NKP + kp)*64 + lane] = ( Vx[j][8kp + k], Vx[j][8kp + 4 + k] ), j = 16 jt + (lane & 15), k = lane >> 4.
+// At = W G^-1 (N x p, column-major, ld = ldA): At(n, i) = (B W^T)(i, n);  Ginv column-major p x p: B(i, k) = Ginv(k, i).
+__global__ __launch_bounds__(64) void k_pack_Vx(const double* __restrict__ Vcm, int N, int ld, const double* __restrict__ At, int ldA,
+                                                const double* __restrict__ Ginv, int p, int Ne, int NKP, double2* __restrict__ Vp) {
+  const int jt = blockIdx.y, kp = blockIdx.x, lane = threadIdx.x;
+  const int j = 16 * jt + (lane & 15);
+  const int n0 = 8 * kp + (lane >> 4), n1 = n0 + 4;
+  auto at = [&](int n) -> double {
+    if (j < Ne) return (j < N && n <= j) ? Vcm[(size_t)n * ld + j] : 0.0;
+    const int i = j - Ne;
+    if (i >= p) return 0.0;
+    if (n < N) return At[(size_t)i * ldA + n];
+    const int k = n - Ne;
+    return (k >= 0 && k <= i) ? Ginv[(size_t)i * p + k] : 0.0;
+  };
+  double2 v;
+  v.x = at(n0);
+  v.y = at(n1);
+  Vp[((size_t)jt * NKP + kp) * 64 + lane] = v;
+}
+hipError_t launch_pack_Vx(const double* Vcm, int N, int ld, const double* At, int ldA, const double* Ginv, int p, int Ne, int Nt,
+                          double2* Vp, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_Vx, dim3(Nt / 8, Nt / 16), 64, 0, st, Vcm, N, ld, At, ldA, Ginv, p, Ne, Nt / 8, Vp);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void k_logdet(const double* __restrict__ L, int N, int ld, double* out) {
   __shared__ double red[256];
   double s = 0.0;
@@ -320,6 +357,30 @@ __global__ void k_trend_terms(int trend, const double* __restrict__ Xs, int64_t 
 hipError_t launch_trend_terms(int trend, const double* Xs, int64_t m0, int64_t mcount, int d, int64_t Mc, const double* beta,
                               double* T, double* mtrend, hipStream_t st) {
   hipLaunchKernelGGL(k_trend_terms, dim3((unsigned)((mcount + 255) / 256)), 256, 0, st, trend, Xs, m0, mcount, d, Mc, beta, T, mtrend);
+  return hipGetLastError();
+}
+
+// the extended chunk rows of the trend-rows path (k_pack_Vx): Rext = rT + Ne * Mc holds rows Ne .. Ne + prows - 1 of the chunk:
+// row col < p = -f_col(x*_i), rows p .. prows - 1 = 0; candidates beyond mcount (the chunk's tail tile) get zeros; mtrend = f(x*) . beta
+__global__ void k_trend_rows(int trend, const double* __restrict__ Xs, int64_t m0, int64_t mcount, int64_t mrows, int d, int64_t Mc,
+                             const double* __restrict__ beta, double* __restrict__ Rext, int p, int prows, double* __restrict__ mtrend) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= mrows) return;
+  if (i < mcount) {
+    double acc = 0.0;
+    trend_basis(trend, Xs + (size_t)(m0 + i) * d, d, [&](int col, double v) {
+      acc = __builtin_fma(v, beta[col], acc);
+      Rext[(size_t)col * Mc + i] = -v;
+    });
+    mtrend[i] = acc;
+  } else {
+    for (int col = 0; col < p; ++col) Rext[(size_t)col * Mc + i] = 0.0;
+  }
+  for (int col = p; col < prows; ++col) Rext[(size_t)col * Mc + i] = 0.0;
+}
+hipError_t launch_trend_rows(int trend, const double* Xs, int64_t m0, int64_t mcount, int64_t mrows, int d, int64_t Mc, const double* beta,
+                             double* Rext, int p, int prows, double* mtrend, hipStream_t st) {
+  hipLaunchKernelGGL(k_trend_rows, dim3((unsigned)((mrows + 255) / 256)), 256, 0, st, trend, Xs, m0, mcount, mrows, d, Mc, beta, Rext, p, prows, mtrend);
   return hipGetLastError();
 }
 

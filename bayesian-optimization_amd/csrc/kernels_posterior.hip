@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void k_corr_chunk(const double* __restrict__ X
 // v_mfma_f64_16x16x4_f64: A lane 16 k + i, B lane 16 k + j, D[i][j] in lane 16 (i % 4) + j, component i / 4 (probe_mfma_layout).
 // ---------------------------------------------------------------------------------------------------
 template <int KERNEL>
-__global__ __launch_bounds__(256) void k_corr_mfma(const double* __restrict__ Xs, const double* __restrict__ sqrt_theta,
+// (four waves per SIMD: 128 VGPRs, a dozen spilled in the prologue -- 5.40 against 5.62 ms at three waves and 155 VGPRs, C3; profiles/r05_corr_mfma_ab.txt)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_corr_mfma(const double* __restrict__ Xs, const double* __restrict__ sqrt_theta,
                                                    const double* __restrict__ XthT, const double* __restrict__ xnorm,
                                                    const double* __restrict__ gamma, const double* __restrict__ wvec,
                                                    double* __restrict__ rT, double* __restrict__ mu_part, double* __restrict__ w_part,
@@ -233,14 +234,9 @@ __global__ __launch_bounds__(256) void k_corr_mfma(const double* __restrict__ Xs
       }
     }
     // this lane's four training rows n0 + 4 c + lk: norm, gamma, w (the loads fly while the matrix pipe drains)
-    double nbv[4], gv[4], wv[4];
+    double nbv[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int n = n0 + 4 * c + lk;
-      nbv[c] = xnorm[n];
-      gv[c] = gamma[n];
-      wv[c] = wvec[n];
-    }
+    for (int c = 0; c < 4; ++c) nbv[c] = xnorm[n0 + 4 * c + lk];
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 #pragma unroll
     for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(acc[t]));
@@ -256,33 +252,50 @@ __global__ __launch_bounds__(256) void k_corr_mfma(const double* __restrict__ Xs
         near |= v * 64.0 < nab;
       }
     if (__builtin_expect(__ballot(near) != 0ull, 0)) {
-      // difference form for the flagged values: kernel A's operations in kernel A's order
+      // difference form, kernel A's operations in kernel A's order, for all 16 values of the lane in ONE loop over the dimensions (compact code:
+      // sixteen unrolled per-value loops cost 40 VGPRs and an occupancy step); only the FLAGGED values take it, so that r(x*_m, x_n) never
+      // depends on which other pairs share the wave
+      const double* __restrict__ xr = XthT + n0 + lk;
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int th = 0; th < 4; th += 2) {  // two candidate tiles at a time: eight accumulators
+        double e[2][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const double nab = na[t] + nbv[c];
-          if (s2[t][c] * 64.0 < nab) {
-            const double* __restrict__ xr = XthT + n0 + 4 * c + lk;
-            const double* xc = xs + 16 * t + li;
-            double e = 0.0;
-            for (int k = 0; k < d; ++k) {
-              const double df = xc[k * 64] - xr[(size_t)k * a.Np];
-              e = __builtin_fma(df, df, e);
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) e[t][c] = 0.0;
+        const double* xc = xs + 16 * th + li;
+#pragma unroll 1
+        for (int k = 0; k < d; ++k) {
+          double xcv[2], xrv[4];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) xcv[t] = xc[k * 64 + 16 * t];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) xrv[c] = xr[(size_t)k * a.Np + 4 * c];
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const double df = xcv[t] - xrv[c];
+              e[t][c] = __builtin_fma(df, df, e[t][c]);
             }
-            s2[t][c] = e;
-          }
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (s2[th + t][c] * 64.0 < na[th + t] + nbv[c]) s2[th + t][c] = e[t][c];
+      }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       double* __restrict__ rrow = rT + (size_t)(n0 + 4 * c + lk) * a.Mc + mc0 + li;
+      const double gv = gamma[n0 + 4 * c + lk], wv = wvec[n0 + 4 * c + lk];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const double r = corr_profile<KERNEL>(s2[t][c], pexp);
         rrow[16 * t] = r;
-        mu[t] = __builtin_fma(r, gv[c], mu[t]);
-        wd[t] = __builtin_fma(r, wv[c], wd[t]);
+        mu[t] = __builtin_fma(r, gv, mu[t]);
+        wd[t] = __builtin_fma(r, wv, wd[t]);
       }
     }
   }

@@ -101,3 +101,38 @@ if __name__ == "__main__":
     save("G37_matern_nu_illcond", par=par_engine, nu=np.array(nu), Xs=Xs, mu=mu, mse=mse, kernel=np.array(7), mode=np.array(0),
          true_mu=tmu, true_mse=tmse, true_beta=np.array(tbeta), true_sigma2=np.array(ts2), cond=np.array(cond),
          ref_err_mu=np.array(ref_err_mu), ref_err_mse=np.array(ref_err_mse), **state_dict(gp, llf))
+
+
+def golden_reml_isotropic():
+    """G38: the restricted likelihood's GRADIENT with an isotropic theta (thetaL of length 1 on d = 1 / 2 / 3 / 4 inputs), three modes x
+    {simple, ordinary kriging} x {SE, Matern-3/2}.  The reference builds the (N, N, d) tensor of per-dimension derivatives whatever
+    len(theta) is (gpr.py:736-770), appends R0 [and I] and reads slice i for parameter i (:889-900): for d >= 2 the entries of the returned
+    vector are the first n_par per-dimension slices, not (d/dtheta, d/dsigma2[, d/dnoise]).  That is what the golden holds and what the
+    device returns (VERDICT r04 "missing" item 4: it refused the call)."""
+    rng = np.random.default_rng(538)
+    out, n = {}, 0
+    for d in (1, 2, 3, 4):
+        X, y = make_data(38 + d, 36, d)
+        y = y + 0.2 * rng.standard_normal(y.shape)
+        out["X%d" % d], out["y%d" % d] = X, y
+        for kid, corr in ((0, "squared_exponential"), (2, "matern")):
+            for mid, kw in ((0, dict(nugget=0)), (1, dict(nugget=1e-6)), (2, dict(nugget=1e-6, noise_estim=True))):
+                for tname in ("sk", "ok"):  # (mean=None would size the default trend by len(thetaL) = 1: gpr.py:269-270)
+                    mean = trend.constant_trend(d) if tname == "ok" else trend.constant_trend(d, beta=0)
+                    gp = GaussianProcess(mean=mean, corr=corr, thetaL=[1e-4], thetaU=[1e2], likelihood="restricted", **kw)
+                    gp._check_data(X, y)
+                    pars, vals, grads = [], [], []
+                    while len(pars) < 3:
+                        p = np.r_[10 ** rng.uniform(-1.2, -0.3) * {1: 200.0, 2: 4.0, 3: 1.5, 4: 1.0}[d], rng.uniform(0.3, 1.2)]  # (36 points: well conditioned in every d)
+                        if mid == 2:
+                            p = np.r_[p, 10 ** rng.uniform(-4, -1)]
+                        v, g = gp.log_likelihood_restricted(p, eval_grad=True)
+                        if not np.isfinite(v):  # a positive value is rejected (-inf, :868-871): draw again
+                            continue
+                        assert len(np.ravel(g)) == len(p), (d, kid, mid, tname, np.shape(g))
+                        pars.append(p), vals.append(float(v)), grads.append(np.asarray(g, float).ravel())
+                        n += 1
+                    key = "d%d_k%d_m%d_%s" % (d, kid, mid, tname)
+                    out[key + "_par"], out[key + "_llf"], out[key + "_grad"] = np.array(pars), np.array(vals), np.array(grads)
+    assert n == 4 * 2 * 3 * 2 * 3
+    save("G38_reml_isotropic", **out)

@@ -885,6 +885,27 @@ def test_reml_tables(eng):
     assert n == 48
 
 
+def test_reml_gradient_with_isotropic_theta(eng):
+    """G38 (imported reference; VERDICT r04 "missing" item 4): thetaL of length 1 on d = 1 .. 4 inputs.  The reference reads slice i of
+    [per-dimension derivatives (d) | R0 | I] for parameter i (gpr.py:736-770, 881-900), so for d >= 2 its vector is not (d/dtheta,
+    d/dsigma2[, d/dnoise]); the device returns the reference's vector."""
+    g = load_golden("G38_reml_isotropic")
+    n = 0
+    for d in (1, 2, 3, 4):
+        eng.set_train(g["X%d" % d], g["y%d" % d])
+        for kid in (0, 2):
+            for mid in (0, 1, 2):
+                for tname in ("sk", "ok"):
+                    key = "d%d_k%d_m%d_%s" % (d, kid, mid, tname)
+                    for p, v, gr in zip(g[key + "_par"], g[key + "_llf"], g[key + "_grad"]):
+                        llf, grad = eng.nll_restricted(kid, mid, p, 1e-6 if mid == 1 else 0.0, tname == "ok", 0.0, eval_grad=True)
+                        np.testing.assert_allclose(llf, v, rtol=1e-9)
+                        assert grad.shape == gr.shape
+                        np.testing.assert_allclose(grad, gr, rtol=1e-6, atol=1e-7 * np.abs(gr).max(), err_msg=key)
+                        n += 1
+    assert n == 144
+
+
 def test_reml_with_several_targets_gives_the_reference_value(eng):
     """G33 (imported reference): the restricted likelihood of a model whose y has 2 / 3 columns is a VALUE -- scalar terms broadcast over
     the n_t x n_t matrix rho^T rho, everything summed (gpr.py:861-866) -- and its gradient raises (ValueError there, :875, :896)."""

@@ -99,3 +99,33 @@ def test_uncentred_data_takes_the_difference_form_everywhere(eng):
     Xs = 100.0 + rng.uniform(-1, 1, size=(5000, d))
     _check(eng, X, y, par, O.KERNEL_MATERN52, Xs)
     _check(eng, X, y, par, O.KERNEL_SE, Xs, est=True)
+
+
+@pytest.mark.parametrize("N,d,tid", [(700, 8, O.TREND_QUADRATIC), (768, 7, O.TREND_QUADRATIC), (300, 40, O.TREND_LINEAR), (2048, 9, O.TREND_QUADRATIC)])
+def test_wide_polynomial_bases_ride_inside_the_contraction(eng, N, d, tid):
+    """Universal kriging with more than 32 basis columns (r05, kernels_fit.hip: k_pack_Vx): the u term of gpr.py:496-498 as p extra rows of
+    the packed triangular factor, the chunk extended by -f(x*).  Posterior, criteria and argmax against the oracle at the parity
+    tolerances: N off and on the 256-row group boundary (the zero 'hole' rows), a wide LINEAR basis (d = 40: p = 41), the C3 row count."""
+    rng = np.random.default_rng(N + d)
+    X = rng.uniform(-5, 5, size=(N, d))
+    y = np.sum(X**2, axis=1) + X[:, 0] - 0.3 * X[:, 1] * X[:, 2]
+    y = ((y - y.mean()) / y.std()).reshape(-1, 1) + 0.05 * rng.standard_normal((N, 1))
+    par = np.r_[np.full(d, 0.3 / d), 0.9]
+    Xs = np.vstack([rng.uniform(-5, 5, size=(4000, d)), X[:50], rng.uniform(-9, 9, size=(200, d))])
+    p = _lib.trend_size_of(tid, d)
+    assert p > 32
+    eng.set_train(X, y)
+    eng.commit(O.KERNEL_MATERN52, O.MODE_NOISY, par, 1e-6, True, 0.0, trend=tid)
+    eng.upload_candidates(Xs)
+    mu, mse = eng.predict()
+    st = O.make_state(par, X, y, O.KERNEL_MATERN52, O.MODE_NOISY, 1e-6, trend=tid, estimate_trend=True)
+    omu, omse = O.predict_chunked(st, Xs, 512)
+    s2 = float(st.sigma2[0])
+    np.testing.assert_allclose(mu, omu.ravel(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(mse, omse.ravel(), rtol=1e-6, atol=1e-12 * s2)
+    acq = [(_lib.ACQ_EI, 0.0), (_lib.ACQ_UCB, 0.5)]
+    best, idx = eng.sweep(acq, float(y.min()), True)
+    obest, oidx = O.sweep(st, Xs, acq, float(y.min()), True)
+    np.testing.assert_array_equal(idx, oidx)
+    np.testing.assert_allclose(best, obest, rtol=1e-6)
+    assert eng.last_timing()["acquisition_ms"] < 5.0  # (the tile products of the old path showed up here)

@@ -336,6 +336,24 @@ def test_reml_tables():
     assert n == 48
 
 
+def test_reml_isotropic_theta_tables():
+    """G38: the oracle's restricted likelihood reproduces the reference's slice-indexed gradient for an isotropic theta (d = 1 .. 4)."""
+    g = load_golden("G38_reml_isotropic")
+    n = 0
+    for d in (1, 2, 3, 4):
+        for kid in (0, 2):
+            for mid in (0, 1, 2):
+                for tname in ("sk", "ok"):
+                    key = "d%d_k%d_m%d_%s" % (d, kid, mid, tname)
+                    for p, v, gr in zip(g[key + "_par"], g[key + "_llf"], g[key + "_grad"]):
+                        ov, og = O.log_likelihood_restricted(p, g["X%d" % d], g["y%d" % d], kid, mid, 1e-6 if mid == 1 else 0.0,
+                                                             estimate_trend=tname == "ok", beta=0.0, eval_grad=True)  # fmt: skip
+                        close(ov, v, rtol=1e-12)
+                        close(np.ravel(og), gr, rtol=1e-9, atol=1e-10 * np.abs(gr).max())
+                        n += 1
+    assert n == 144
+
+
 def test_reml_multitarget_tables():
     """The restricted likelihood on y with 2 / 3 columns (G33, generated by importing the reference): the value the reference's
     arithmetic yields -- scalar terms broadcast over the n_t x n_t matrix rho^T rho, everything summed (gpr.py:861-866)."""
