@@ -109,6 +109,14 @@ static bool trend_rows_enabled() {
   }();
   return on;
 }
+// smallest basis that takes the path (BOGP_TREND_ROWS_MIN, default 33: p <= 32 stays fused into kernel A, profiles/r05_trend_timing.txt)
+static int trend_rows_min() {
+  static const int v = [] {
+    const char* e = getenv("BOGP_TREND_ROWS_MIN");
+    return e ? std::max(2, atoi(e)) : 33;
+  }();
+  return v;
+}
 
 static void free_trend(bogp_handle* h) {
   dfree(h->dF); dfree(h->dFt); dfree(h->dQ1); dfree(h->dQ); dfree(h->dWp); dfree(h->dWpT); dfree(h->dSinvP);
@@ -1035,7 +1043,7 @@ extern "C" int bogp_commit(bogp_handle* h, int kernel, int mode, const double* p
       HIPCHK(h, hipMemcpyAsync(h->h_Sinv.data(), h->dSinv, (size_t)ptrend * ptrend * sizeof(double), hipMemcpyDeviceToHost, st));
       // more than 32 columns (a quadratic basis; a linear one from d = 32): the u term as p extra rows of the packed factor (k_pack_Vx)
       h->vx_Ne = h->vx_Nt = 0;
-      if (trend_rows_enabled() && ptrend > 32) {
+      if (trend_rows_enabled() && ptrend >= trend_rows_min()) {
         const int cols = contract_cols_per_group();
         const int Ne = (Np + cols - 1) / cols * cols, Nt = Ne + (ptrend + 31) / 32 * 32;
         int e2;
@@ -1472,7 +1480,7 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
   if (const char* env = getenv("BOGP_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, atoi(env)) << 20;
   // trend-rows path (k_pack_Vx): the chunk carries Nt - Np extra rows (the hole up to a whole column group, then -f(x*)), the contraction
   // runs over the extended factor
-  const bool vx = h->vx_Nt > 0 && h->p > 32 && h->estimate_trend && need_var;
+  const bool vx = h->vx_Nt > 0 && h->p >= trend_rows_min() && h->estimate_trend && need_var;
   const int Nrows = vx ? h->vx_Nt : Np;
   int64_t Mc = (int64_t)(chunk_bytes / ((size_t)Nrows * sizeof(double)) / 64) * 64;
   Mc = std::max<int64_t>(64, std::min<int64_t>(Mc, Mpad));
