@@ -140,6 +140,10 @@ static void free_train(bogp_handle* h) {
 
 extern "C" void bogp_destroy(bogp_handle* h) {
   if (!h) return;
+  if (h->aux) {
+    bogp_destroy(h->aux);
+    h->aux = nullptr;
+  }
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   comm_release(h);
@@ -251,6 +255,9 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
     for (int t = 0; t < n_targets; ++t) ycols[(size_t)t * N + i] = y[(size_t)i * n_targets + t];
   HIPCHK(h, hipMemcpyAsync(h->dy_base, ycols.data(), nt * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->h_X.assign(X, X + (size_t)N * d);  // (3 MB at C5: what a helper handle of bogp_nll_batch is fed from)
+  h->h_y.assign(y, y + (size_t)N * n_targets);
+  ++h->train_gen;
   return BOGP_OK;
 }
 

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "../../include/bogp.h"
@@ -312,20 +313,53 @@ extern "C" int bogp_nll_batch(bogp_handle* h, int kernel, int mode, int P, const
   // (the elimination path of ONE evaluation is taken with the gradient queued behind it -- BOGP_NLL_TWO_SYNCS=1 switches that off)
   const bool two_syncs = getenv("BOGP_NLL_TWO_SYNCS") && atoi(getenv("BOGP_NLL_TWO_SYNCS")) != 0;
   if (path == BOGP_NLL_PATH_GENERAL || (path == BOGP_NLL_PATH_ELIM && grad && two_syncs)) {
-    // evaluations that fill the GPU on their own (N > 2048) or are rare (polynomial trends, several targets): one after the other
-    for (int s = 0; s < P; ++s) {
+    // evaluations that fill most of the GPU on their own (N > 2048) or are rare (polynomial trends, several targets): the sequential call,
+    // slot by slot -- on TWO handles at once when there are at least two slots and the evaluation is a large one (r05): each evaluation is
+    // a chain of small launches (the diagonal blocks) between rank-128 updates, and two independent chains interleave on the device
+    // (C5: 15.4 -> 13.5 ms per evaluation, N = 4096: 4.4 -> 3.2, N = 3000: 2.7 -> 1.8; profiles/r05_nll_two_handles.txt).  Every slot is
+    // the sequential call's bits either way: same kernels, same launch geometry, no cross-stream reduction.  BOGP_NLL_WORKERS=1: off.
+    auto run_slot = [&](bogp_handle* hh, int s) -> int {
       double* g = grad ? grad + (size_t)s * n_par : nullptr;
       const double* p = par + (size_t)s * n_par;
       bool ok = true;
       for (int k = 0; k < n_par; ++k) ok = ok && std::isfinite(p[k]) && p[k] > 0;
       int rc = BOGP_ERR_INVALID;
       llf[s] = std::numeric_limits<double>::quiet_NaN();
-      if (ok) rc = bogp_nll(h, kernel, mode, p, n_par, noise_var, trend, estimate_trend, beta, &llf[s], g);
+      if (ok) rc = bogp_nll(hh, kernel, mode, p, n_par, noise_var, trend, estimate_trend, beta, &llf[s], g);
       info[s] = rc;
       if (rc != BOGP_OK && rc != BOGP_ERR_LLF_POSITIVE) llf[s] = std::numeric_limits<double>::quiet_NaN();
       if (rc != BOGP_OK && g) for (int k = 0; k < n_par; ++k) g[k] = 0.0;
-      if (rc == BOGP_ERR_HIP || rc == BOGP_ERR_UNSUPPORTED || rc == BOGP_ERR_NO_DEVICE) return rc;
+      return rc;
+    };
+    auto fatal = [](int rc) { return rc == BOGP_ERR_HIP || rc == BOGP_ERR_UNSUPPORTED || rc == BOGP_ERR_NO_DEVICE; };
+    static const int workers = [] { const char* e = getenv("BOGP_NLL_WORKERS"); return e ? std::max(1, std::min(2, atoi(e))) : 2; }();
+    bogp_handle* aux = nullptr;
+    if (workers > 1 && P >= 2 && N > 2048 && !h->h_X.empty()) {
+      if (!h->aux && bogp_create(h->device, &h->aux) != BOGP_OK) h->aux = nullptr;  // (no helper: one handle does it all)
+      if (h->aux && h->aux_gen != h->train_gen) {
+        if (bogp_set_train(h->aux, h->h_X.data(), h->h_y.data(), N, d, h->n_t) == BOGP_OK) h->aux_gen = h->train_gen;
+        else { bogp_destroy(h->aux); h->aux = nullptr; }
+      }
+      if (h->aux) {
+        h->aux->h_beta_fixed = h->h_beta_fixed;  // fixed coefficients of a polynomial basis, if any
+        aux = h->aux;
+      }
     }
+    if (!aux) {
+      for (int s = 0; s < P; ++s) {
+        const int rc = run_slot(h, s);
+        if (fatal(rc)) return rc;
+      }
+      return BOGP_OK;
+    }
+    int rc_aux = BOGP_OK, rc_main = BOGP_OK;
+    std::thread t([&] {
+      for (int s = 1; s < P && !fatal(rc_aux); s += 2) rc_aux = run_slot(aux, s);
+    });
+    for (int s = 0; s < P && !fatal(rc_main); s += 2) rc_main = run_slot(h, s);
+    t.join();
+    if (fatal(rc_main)) return rc_main;
+    if (fatal(rc_aux)) FAIL(h, rc_aux, "bogp_nll_batch (second handle): %s", bogp_last_error(aux));
     return BOGP_OK;
   }
   std::vector<SlotPrep> prep((size_t)P);

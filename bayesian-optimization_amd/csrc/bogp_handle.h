@@ -114,6 +114,12 @@ struct bogp_handle {
   int reml_ftf_basis = -1;
   int tr_built = -1, tr_p = 0, ldp = 0;    // basis currently held in dF / sizes of the buffers below
   std::vector<double> h_beta_fixed;        // bogp_set_trend_beta: simple-kriging coefficients
+  // bogp_nll_batch above N = 2048 (r05): a second handle -- own stream, own factor buffers -- evaluates every other slot on a second host
+  // thread, so that one evaluation's chain of small launches runs beside the other's rank-128 updates.  The host copy of the training set
+  // (as bogp_set_train received it) is what the second handle is fed from; `train_gen` tells it when to take it again.
+  std::vector<double> h_X, h_y;
+  unsigned long train_gen = 0, aux_gen = 0;
+  bogp_handle* aux = nullptr;
   std::vector<double> h_betav, h_Sinv;     // committed beta (p) and (Ft^T Ft)^-1 (p x p, column-major) for bogp_gradient
   double *dF = nullptr, *dFt = nullptr, *dQ1 = nullptr, *dQ = nullptr;  // N x p, column-major, ld = N
   double* dWp = nullptr;                                                // Np x p: L^-T Ft, zero-padded rows
