@@ -140,10 +140,9 @@ static void free_train(bogp_handle* h) {
 
 extern "C" void bogp_destroy(bogp_handle* h) {
   if (!h) return;
-  if (h->aux) {
-    bogp_destroy(h->aux);
-    h->aux = nullptr;
-  }
+  for (bogp_handle* a : h->aux) bogp_destroy(a);
+  h->aux.clear();
+  h->aux_gen.clear();
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   comm_release(h);

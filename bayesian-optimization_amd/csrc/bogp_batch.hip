@@ -313,11 +313,11 @@ extern "C" int bogp_nll_batch(bogp_handle* h, int kernel, int mode, int P, const
   // (the elimination path of ONE evaluation is taken with the gradient queued behind it -- BOGP_NLL_TWO_SYNCS=1 switches that off)
   const bool two_syncs = getenv("BOGP_NLL_TWO_SYNCS") && atoi(getenv("BOGP_NLL_TWO_SYNCS")) != 0;
   if (path == BOGP_NLL_PATH_GENERAL || (path == BOGP_NLL_PATH_ELIM && grad && two_syncs)) {
-    // evaluations that fill most of the GPU on their own (N > 2048) or are rare (polynomial trends, several targets): the sequential call,
-    // slot by slot -- on TWO handles at once when there are at least two slots and the evaluation is a large one (r05): each evaluation is
-    // a chain of small launches (the diagonal blocks) between rank-128 updates, and two independent chains interleave on the device
-    // (C5: 15.4 -> 13.5 ms per evaluation, N = 4096: 4.4 -> 3.2, N = 3000: 2.7 -> 1.8; profiles/r05_nll_two_handles.txt).  Every slot is
-    // the sequential call's bits either way: same kernels, same launch geometry, no cross-stream reduction.  BOGP_NLL_WORKERS=1: off.
+    // evaluations above N = 2048, with a polynomial trend or with several targets: the sequential call, slot by slot -- on SEVERAL handles at
+    // once when there are at least two slots (r05): an evaluation is a chain of small launches between larger ones, and independent chains
+    // interleave on the device (C5: 15.4 -> 13.5 ms per evaluation, N = 4096: 4.4 -> 3.2, N = 3000: 2.7 -> 1.8; linear trend at N = 2048:
+    // 1.88 -> 1.22; profiles/r05_nll_two_handles.txt).  Every slot is the sequential call's bits either way: same kernels, same launch
+    // geometry, no cross-stream reduction.
     auto run_slot = [&](bogp_handle* hh, int s) -> int {
       double* g = grad ? grad + (size_t)s * n_par : nullptr;
       const double* p = par + (size_t)s * n_par;
@@ -332,34 +332,47 @@ extern "C" int bogp_nll_batch(bogp_handle* h, int kernel, int mode, int P, const
       return rc;
     };
     auto fatal = [](int rc) { return rc == BOGP_ERR_HIP || rc == BOGP_ERR_UNSUPPORTED || rc == BOGP_ERR_NO_DEVICE; };
-    static const int workers = [] { const char* e = getenv("BOGP_NLL_WORKERS"); return e ? std::max(1, std::min(2, atoi(e))) : 2; }();
-    bogp_handle* aux = nullptr;
-    if (workers > 1 && P >= 2 && N > 2048 && !h->h_X.empty()) {
-      if (!h->aux && bogp_create(h->device, &h->aux) != BOGP_OK) h->aux = nullptr;  // (no helper: one handle does it all)
-      if (h->aux && h->aux_gen != h->train_gen) {
-        if (bogp_set_train(h->aux, h->h_X.data(), h->h_y.data(), N, d, h->n_t) == BOGP_OK) h->aux_gen = h->train_gen;
-        else { bogp_destroy(h->aux); h->aux = nullptr; }
-      }
-      if (h->aux) {
-        h->aux->h_beta_fixed = h->h_beta_fixed;  // fixed coefficients of a polynomial basis, if any
-        aux = h->aux;
+    // workers: 3 handles up to N = 4096 (a linear-trend evaluation at N = 1024: 0.97 -> 0.47 ms), 2 above (C5: three gain nothing over two and
+    // cost another set of N^2 buffers); none below N = 192, where an evaluation is a handful of launches.  BOGP_NLL_WORKERS = 1: off.
+    static const int workers_env = [] { const char* e = getenv("BOGP_NLL_WORKERS"); return e ? std::max(1, std::min(3, atoi(e))) : 3; }();
+    const int workers = std::min(std::min(workers_env, N > 4096 ? 2 : 3), P);
+    std::vector<bogp_handle*> team{h};
+    if (workers > 1 && N >= 192 && !h->h_X.empty()) {
+      for (int w = 1; w < workers; ++w) {
+        if ((int)h->aux.size() < w) {
+          bogp_handle* a = nullptr;
+          if (bogp_create(h->device, &a) != BOGP_OK) break;  // (no helper: fewer handles do it all)
+          h->aux.push_back(a);
+          h->aux_gen.push_back(0);
+        }
+        bogp_handle* a = h->aux[(size_t)w - 1];
+        if (h->aux_gen[(size_t)w - 1] != h->train_gen) {
+          if (bogp_set_train(a, h->h_X.data(), h->h_y.data(), N, d, h->n_t) != BOGP_OK) break;
+          h->aux_gen[(size_t)w - 1] = h->train_gen;
+        }
+        a->h_beta_fixed = h->h_beta_fixed;  // fixed coefficients of a polynomial basis, if any
+        team.push_back(a);
       }
     }
-    if (!aux) {
+    const int W = (int)team.size();
+    if (W == 1) {
       for (int s = 0; s < P; ++s) {
         const int rc = run_slot(h, s);
         if (fatal(rc)) return rc;
       }
       return BOGP_OK;
     }
-    int rc_aux = BOGP_OK, rc_main = BOGP_OK;
-    std::thread t([&] {
-      for (int s = 1; s < P && !fatal(rc_aux); s += 2) rc_aux = run_slot(aux, s);
-    });
-    for (int s = 0; s < P && !fatal(rc_main); s += 2) rc_main = run_slot(h, s);
-    t.join();
-    if (fatal(rc_main)) return rc_main;
-    if (fatal(rc_aux)) FAIL(h, rc_aux, "bogp_nll_batch (second handle): %s", bogp_last_error(aux));
+    std::vector<int> rcs((size_t)W, BOGP_OK);
+    std::vector<std::thread> threads;
+    for (int w = 1; w < W; ++w)
+      threads.emplace_back([&, w] {
+        for (int s = w; s < P && !fatal(rcs[(size_t)w]); s += W) rcs[(size_t)w] = run_slot(team[(size_t)w], s);
+      });
+    for (int s = 0; s < P && !fatal(rcs[0]); s += W) rcs[0] = run_slot(h, s);
+    for (auto& t : threads) t.join();
+    if (fatal(rcs[0])) return rcs[0];
+    for (int w = 1; w < W; ++w)
+      if (fatal(rcs[(size_t)w])) FAIL(h, rcs[(size_t)w], "bogp_nll_batch (helper handle %d): %s", w, bogp_last_error(team[(size_t)w]));
     return BOGP_OK;
   }
   std::vector<SlotPrep> prep((size_t)P);

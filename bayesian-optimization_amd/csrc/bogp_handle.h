@@ -118,8 +118,9 @@ struct bogp_handle {
   // thread, so that one evaluation's chain of small launches runs beside the other's rank-128 updates.  The host copy of the training set
   // (as bogp_set_train received it) is what the second handle is fed from; `train_gen` tells it when to take it again.
   std::vector<double> h_X, h_y;
-  unsigned long train_gen = 0, aux_gen = 0;
-  bogp_handle* aux = nullptr;
+  unsigned long train_gen = 0;
+  std::vector<bogp_handle*> aux;       // helper handles (up to 2)
+  std::vector<unsigned long> aux_gen;  // the train_gen each was last fed at
   std::vector<double> h_betav, h_Sinv;     // committed beta (p) and (Ft^T Ft)^-1 (p x p, column-major) for bogp_gradient
   double *dF = nullptr, *dFt = nullptr, *dQ1 = nullptr, *dQ = nullptr;  // N x p, column-major, ld = N
   double* dWp = nullptr;                                                // Np x p: L^-T Ft, zero-padded rows

@@ -11,19 +11,20 @@ X = rng.uniform(-5, 5, size=(N, d)); y = np.sum(X**2, axis=1); y = ((y - y.mean(
 th = 0.004 if N > 4096 else 0.01
 pars = [np.r_[np.full(d, th * f), 0.9] for f in (1.0, 1.1, 0.9, 1.2, 0.8, 1.05, 0.95, 1.15)]
 K = len(pars)
+TREND = int(os.environ.get("TREND", "0"))
 engs = [_lib.Engine(0) for _ in range(int(os.environ.get("WORKERS", "2")))]
 for e in engs:
     e.set_train(X, y)
-    e.nll(0, _lib.MODE_NOISY, pars[0], 1e-6, False, 0.0, eval_grad=True)  # warm-up / allocation
-ref = [engs[0].nll(0, _lib.MODE_NOISY, p, 1e-6, False, 0.0, eval_grad=True) for p in pars]
+    e.nll(0, _lib.MODE_NOISY, pars[0], 1e-6, True, 0.0, eval_grad=True, trend=TREND)  # warm-up / allocation
+ref = [engs[0].nll(0, _lib.MODE_NOISY, p, 1e-6, True, 0.0, eval_grad=True, trend=TREND) for p in pars]
 t0 = time.perf_counter()
 for p in pars:
-    engs[0].nll(0, _lib.MODE_NOISY, p, 1e-6, False, 0.0, eval_grad=True)
+    engs[0].nll(0, _lib.MODE_NOISY, p, 1e-6, True, 0.0, eval_grad=True, trend=TREND)
 t_seq = (time.perf_counter() - t0) / K
 out = [None] * K
 def work(w):
     for i in range(w, K, len(engs)):
-        out[i] = engs[w].nll(0, _lib.MODE_NOISY, pars[i], 1e-6, False, 0.0, eval_grad=True)
+        out[i] = engs[w].nll(0, _lib.MODE_NOISY, pars[i], 1e-6, True, 0.0, eval_grad=True, trend=TREND)
 for rep in range(2):
     ths = [threading.Thread(target=work, args=(w,)) for w in range(len(engs))]
     t0 = time.perf_counter()
@@ -31,5 +32,5 @@ for rep in range(2):
     for t in ths: t.join()
     t_par = (time.perf_counter() - t0) / K
 same = all(o[0] == r[0] and np.array_equal(o[1], r[1]) for o, r in zip(out, ref))
-print("N = %d, d = %d: sequential %.3f ms per llf + gradient; %d engines on %d threads %.3f ms per evaluation (x%.2f); results bit-identical: %s" % (
-    N, d, t_seq * 1e3, len(engs), len(engs), t_par * 1e3, t_seq / t_par, same))
+print("N = %d, d = %d, trend %d: sequential %.3f ms per llf + gradient; %d engines on %d threads %.3f ms per evaluation (x%.2f); results bit-identical: %s" % (
+    N, d, TREND, t_seq * 1e3, len(engs), len(engs), t_par * 1e3, t_seq / t_par, same))
