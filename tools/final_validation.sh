@@ -1,6 +1,6 @@
 # Round-end validation on the GPU box: bash tools/final_validation.sh rNN  (gpurun -- 'bash tools/final_validation.sh r04')
 # the whole -m gpu suite, smoke(), the default bench line (C3) and C2 / C4 / C5, then the rocprofv3 kernel statistics of the same bench commands.
-R=${1:-r04}
+R=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
 python -m pytest tests -x -q -m gpu > gpurun_out/${R}_gpu_tests.log 2>&1; grep -E "passed|failed|error" gpurun_out/${R}_gpu_tests.log | tail -2
