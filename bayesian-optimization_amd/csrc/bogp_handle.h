@@ -151,6 +151,8 @@ struct bogp_handle {
   unsigned int* dpt_counter = nullptr;  // [cap] arrival tickets (zero between launches) + 1 word: finished starts of the polish
   size_t pt_counter_cap = 0;
   double* dpt_split = nullptr;  // partial tiles of split row blocks (one-point latency mode of k_point_tri)
+  double *dpt_tw = nullptr, *dpt_trec = nullptr;  // linear trend in the one-point path: W^T [r | dr/dx] per point, the trend records
+  size_t pt_tw_cap = 0, pt_trec_cap = 0;
   unsigned int* dpt_splitc = nullptr;
   size_t pt_split_cap = 0, pt_splitc_cap = 0;
   // the likelihood's host traffic (r03): theta travels through a pinned staging block, the scalars / gradient sums come back through

@@ -326,6 +326,7 @@ struct PointTriArgs {
   int acq_id[64];
   double acq_par[64];
   double plugin, beta, G, ftft, sigma2;
+  const double* trend_rec;  // [B][2 + 2 d] = mu_t, uu, dmu_t, duu of a linear trend basis (k_point_trend_fin), or null: constant basis
   unsigned long long* done_flag;  // device-mapped pinned word k_point_finish stores `done_seq` into last (one-point calls), or null
   unsigned long long done_seq;
 };
@@ -343,6 +344,8 @@ int point_passes(int d);
 void point_tri_geometry(int N, int d, int B, int* rb, int* nsplit);
 hipError_t launch_point_rhs(int kernel, const PointRhsArgs& a, int B, hipStream_t st);
 hipError_t launch_point_tri(const PointTriArgs& a, int B, hipStream_t st);
+hipError_t launch_point_trend(const PointRhsArgs& ra, const double* W, int ldW, int p, const double* betav, const double* Sinv,
+                              int estimate_trend, double* Tw, double* trec, int B, hipStream_t st);
 // MFMA flavour of the B-point path (kernels_point.hip): ncp = point_mfma_columns(d) right-hand-side columns per point (0: d too large)
 int point_mfma_columns(int d);
 hipError_t launch_point_rhs_T(int kernel, const PointRhsArgs& a, int ncp, double* rT, long long Mc, int Np, int B, hipStream_t st);

@@ -32,7 +32,9 @@ int check_common(bogp_handle* h, const char* who, int q, const int* acq_id, cons
   if (!h->committed) FAIL(h, BOGP_ERR_INVALID, "%s: no committed model", who);
   if (h->kernel == BOGP_KERNEL_CUBIC || h->kernel == BOGP_KERNEL_GENEXP || h->kernel == BOGP_KERNEL_MATERN_NU)
     FAIL(h, BOGP_ERR_UNSUPPORTED, "%s: the cubic correlation has no input-derivative (corr_dx leaves it undefined in the reference, gpr.py:655-658)", who);
-  if (h->p > 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "%s: constant trend basis only (polynomial trends: bogp_predict + bogp_gradient)", who);
+  if (h->p > 1 && h->trend != BOGP_TREND_LINEAR)
+    FAIL(h, BOGP_ERR_UNSUPPORTED, "%s: the quadratic trend has no Jacobian in the reference either (trend.py:138-139)", who);
+  if (h->n_t > 1) FAIL(h, BOGP_ERR_UNSUPPORTED, "%s: one target (several: bogp_predict + bogp_gradient per target)", who);
   if (h->d > BOGP_POINT_MAX_D) FAIL(h, BOGP_ERR_UNSUPPORTED, "%s: at most %d input dimensions", who, BOGP_POINT_MAX_D);
   if (q < 0 || q > BOGP_MAX_Q || (q > 0 && !acq_id)) FAIL(h, BOGP_ERR_INVALID, "%s: 0 <= q <= %d with non-null acq_id", who, BOGP_MAX_Q);
   for (int i = 0; i < q; ++i) {
@@ -81,7 +83,7 @@ int queue_point_eval(bogp_handle* h, const PointPlan& pl, const double* dXb, con
   const int ncp = point_mfma_columns(h->d);
   const char* e_min = getenv("BOGP_POINT_MFMA_MIN");  // read per call: the tests run both flavours in one process
   const long long mfma_min = e_min ? atoll(e_min) : 768LL;
-  if (dXb && ncp > 0 && h->dVp && mfma_min > 0 && (((long long)B * ncp + 63) / 64) * ((h->Np + 255) / 256) >= mfma_min) {
+  if (dXb && ncp > 0 && h->dVp && h->p == 1 && mfma_min > 0 && (((long long)B * ncp + 63) / 64) * ((h->Np + 255) / 256) >= mfma_min) {
     const int Np = h->Np, nJ = (Np + 255) / 256;
     const long long Mc = ((long long)B * ncp + 63) / 64 * 64;
     if ((e = ensure(h, &h->drT[0], &h->rT_cap[0], (size_t)Np * Mc))) return e;
@@ -128,6 +130,13 @@ int queue_point_eval(bogp_handle* h, const PointPlan& pl, const double* dXb, con
   ra.N = h->N; ra.d = h->d; ra.Npp = pl.Npp; ra.npass = pl.npass;
   if (!dXb) memcpy(ra.x, x_host, (size_t)h->d * sizeof(double));
   HIPCHK(h, launch_point_rhs(h->kernel, ra, B, st));
+  const double* trend_rec = nullptr;
+  if (h->p > 1) {  // linear basis: (Ft^T L^-1) [r | dr/dx] and the trend's share of mu, MSE and their gradients (kernels_point.hip)
+    if ((e = ensure(h, &h->dpt_tw, &h->pt_tw_cap, (size_t)B * pl.npass * h->p * pl.NC))) return e;
+    if ((e = ensure(h, &h->dpt_trec, &h->pt_trec_cap, (size_t)B * (2 + 2 * h->d)))) return e;
+    HIPCHK(h, launch_point_trend(ra, h->dWp, h->Np, h->p, h->dbetav, h->dSinv, h->estimate_trend, h->dpt_tw, h->dpt_trec, B, st));
+    trend_rec = h->dpt_trec;
+  }
   PointTriArgs ta;
   memset(&ta, 0, sizeof(ta));
   ta.V = h->dV; ta.gamma = h->dgamma; ta.wvec = h->dw; ta.rhs = h->dpt_rhs; ta.part = h->dpt_part;
@@ -138,7 +147,7 @@ int queue_point_eval(bogp_handle* h, const PointPlan& pl, const double* dXb, con
   ta.minimize = minimize;
   for (int i = 0; i < q; ++i) { ta.acq_id[i] = acq_id[i]; ta.acq_par[i] = acq_par ? acq_par[i] : 0.0; }
   ta.plugin = plugin; ta.beta = h->beta; ta.G = h->G; ta.ftft = h->ftft; ta.sigma2 = h->sigma2;
-  ta.done_flag = done_flag; ta.done_seq = done_seq;
+  ta.done_flag = done_flag; ta.done_seq = done_seq; ta.trend_rec = trend_rec;
   HIPCHK(h, launch_point_tri(ta, B, st));
   return BOGP_OK;
 }
@@ -149,7 +158,8 @@ namespace bogp {
 
 void point_release(bogp_handle* h) {
   dfree(h->dpt_rhs); dfree(h->dpt_part); dfree(h->dpt_out); dfree(h->dpt_Xb); dfree(h->dpt_state); dfree(h->dpt_box);
-  dfree(h->dpt_counter); dfree(h->dpt_split); dfree(h->dpt_splitc);
+  dfree(h->dpt_counter); dfree(h->dpt_split); dfree(h->dpt_splitc); dfree(h->dpt_tw); dfree(h->dpt_trec);
+  h->pt_tw_cap = h->pt_trec_cap = 0;
   h->pt_split_cap = h->pt_splitc_cap = 0;
   h->pt_rhs_cap = h->pt_part_cap = h->pt_out_cap = h->pt_Xb_cap = h->pt_state_cap = h->pt_box_cap = h->pt_counter_cap = 0;
   if (h->hpin) (void)hipHostFree(h->hpin);

@@ -172,6 +172,77 @@ __global__ __launch_bounds__(256) void k_point_gw(const double* __restrict__ rT,
   rec[NCP + c] = (w[0] + w[1]) + (w[2] + w[3]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Linear trend basis f(x) = [1, x] (trend.py:94-116) in the one-point path (r05; the reference's `gradient` serves it, gpr.py:556-575;
+// the quadratic basis has no Jacobian there either, trend.py:138-139).  Two small launches between k_point_tri and k_point_finish:
+//   k_point_wt<NC>     Tw[b][g][j][c] = sum_n W[n][j] rhs[b][g][n][c],  W = L^-T Ft (N x p): (Ft^T L^-1) [r | dr/dx] (gpr.py:570-571);
+//                      a workgroup = 8 basis columns j x 32 lanes over the pass's NC right-hand-side columns, every thread walks n
+//   k_point_trend_fin  per point: mu_t = f . beta, dmu_t = beta_{1+k}; under universal kriging c = Tw[:, 0] - f, Sc = (Ft^T Ft)^-1 c,
+//                      uu = c . Sc, duu_k = 2 Sc . (Tw[:, 1+k] - e_{1+k})  ->  trec[b] = [mu_t, uu, dmu_t (d), duu (d)]
+// k_point_finish then adds them: mu = mu_t + gamma . r, MSE = (1 - |V r|^2 + uu) sigma2, dMSE_k = 2 sigma2 (-z . dr_k + duu_k / 2).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256) void k_point_wt(const double* __restrict__ rhs, const double* __restrict__ W, int ldW, int N, int Npp, int npass,
+                                                  int p, double* __restrict__ Tw) {
+  const int b = blockIdx.z, g = blockIdx.y;
+  const int j = blockIdx.x * 8 + (threadIdx.x >> 5), c = threadIdx.x & 31;
+  if (j >= p || c >= NC) return;
+  const double* __restrict__ col = rhs + (((size_t)b * npass + g) * Npp) * NC + c;
+  const double* __restrict__ w = W + (size_t)j * ldW;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  int n = 0;
+  for (; n + 4 <= N; n += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = __builtin_fma(w[n + u], col[(size_t)(n + u) * NC], s[u]);
+  }
+  for (; n < N; ++n) s[0] = __builtin_fma(w[n], col[(size_t)n * NC], s[0]);
+  Tw[(((size_t)b * npass + g) * p + j) * NC + c] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void k_point_trend_fin(PointRhsArgs pa, const double* __restrict__ Tw, int p, const double* __restrict__ betav,
+                                                         const double* __restrict__ Sinv, int estimate_trend, double* __restrict__ trec) {
+  extern __shared__ double sm[];
+  double* f = sm;          // [p]
+  double* cv = sm + p;     // [p]
+  double* Sc = sm + 2 * p; // [p]
+  const int b = blockIdx.x, tid = threadIdx.x, d = pa.d, npass = pa.npass;
+  for (int j = tid; j < p; j += 256) f[j] = j == 0 ? 1.0 : (pa.Xb ? pa.Xb[(size_t)b * d + (j - 1)] : pa.x[j - 1]);
+  __syncthreads();
+  const double* T0 = Tw + ((size_t)b * npass) * p * NC;  // pass 0: column 0 is r
+  double* out = trec + (size_t)b * (2 + 2 * d);
+  if (estimate_trend) {
+    for (int j = tid; j < p; j += 256) cv[j] = T0[(size_t)j * NC] - f[j];
+    __syncthreads();
+    for (int j = tid; j < p; j += 256) {
+      double a = 0.0;
+      for (int i = 0; i < p; ++i) a = __builtin_fma(Sinv[(size_t)i * p + j], cv[i], a);
+      Sc[j] = a;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double m = 0.0, uu = 0.0;
+    for (int j = 0; j < p; ++j) m = __builtin_fma(f[j], betav[j], m);  // the order of k_trend_terms: the sweep's f . beta bit for bit
+    if (estimate_trend)
+      for (int j = 0; j < p; ++j) uu = __builtin_fma(cv[j], Sc[j], uu);
+    out[0] = m;
+    out[1] = uu;
+  }
+  for (int k = tid; k < d; k += 256) {
+    out[2 + k] = betav[1 + k];  // beta^T f_dx: the Jacobian of [1, x] is [0; I] (trend.py:109-112)
+    double du = 0.0;
+    if (estimate_trend) {
+      const int g = k / (NC - 1), cc = 1 + (k - g * (NC - 1));
+      const double* Tk = Tw + (((size_t)b * npass + g) * p) * NC + cc;
+      double a = 0.0;
+      for (int j = 0; j < p; ++j) a = __builtin_fma(Sc[j], Tk[(size_t)j * NC], a);
+      du = 2.0 * (a - Sc[1 + k]);
+    }
+    out[2 + d + k] = du;
+  }
+}
+
 // d acq / d x_k = a_dy * dy_k + a_dsd * dsd_k   (acquisition_fun.py:139-146, 181-188, 220-227, 292-309); the guards of
 // the reference return a zero gradient, its FloatingPointError path (np.errstate(all="raise")) likewise
 __device__ __forceinline__ void acq_grad_coef(int id, double par, double y, double sd, double plugin, double sigma2, double& a_dy,
@@ -370,9 +441,16 @@ __global__ __launch_bounds__(256) void k_point_finish(PointTriArgs a) {
     }
     __syncthreads();
   }
-  // posterior of the point and its input-gradients (constant trend basis)
+  // posterior of the point and its input-gradients (constant trend basis; a linear one through the record of k_point_trend_fin)
+  const double* tr = a.trend_rec ? a.trend_rec + (size_t)b * (2 + 2 * d) : nullptr;
   double mu, mse;
-  posterior_of_sums(sc[1], sc[2], sc[0], a.beta, a.G, a.estimate_trend, a.sigma2, mu, mse);
+  if (tr) {
+    mu = tr[0] + sc[1];
+    mse = (1.0 - sc[0] + (a.estimate_trend ? tr[1] : 0.0)) * a.sigma2;
+    if (mse < 0.0) mse = 0.0;
+  } else {
+    posterior_of_sums(sc[1], sc[2], sc[0], a.beta, a.G, a.estimate_trend, a.sigma2, mu, mse);
+  }
   const double sign = a.minimize ? 1.0 : -1.0;
   const double y = sign * mu, sd = sqrt(mse);
   double* out = a.out + (size_t)b * a.rec_stride;  // [mu, mse, acq (q), dmu (d), dmse (d), dacq (q x d)]
@@ -383,9 +461,13 @@ __global__ __launch_bounds__(256) void k_point_finish(PointTriArgs a) {
   }
   if (tid < q) out[2 + tid] = acq_value(a.acq_id[tid], a.acq_par[tid], y, sd, a.plugin, a.sigma2);
   for (int k = tid; k < d; k += 256) {
-    const double dmu = gdr[k];  // beta^T f_dx = 0 for the constant basis (gpr.py:561)
+    const double dmu = gdr[k] + (tr ? tr[2 + k] : 0.0);  // beta^T f_dx = 0 for the constant basis (gpr.py:561)
     double m = -1.0 * zdr[k];
-    if (a.estimate_trend) m += (sc[2] - 1.0) * (1.0 / a.ftft) * wdr[k];
+    if (tr) {
+      if (a.estimate_trend) m += 0.5 * tr[2 + d + k];
+    } else if (a.estimate_trend) {
+      m += (sc[2] - 1.0) * (1.0 / a.ftft) * wdr[k];
+    }
     const double dmse = 2.0 * a.sigma2 * m;  // gpr.py:573-576
     out[2 + q + k] = dmu;
     out[2 + q + d + k] = dmse;
@@ -620,6 +702,19 @@ hipError_t launch_point_tri(const PointTriArgs& a, int B, hipStream_t st) {
     if (a.rb == 128) hipLaunchKernelGGL((k_point_tri<22, 2>), grid, 256, 0, st, a.V, a.gamma, a.wvec, a.rhs, a);
     else hipLaunchKernelGGL((k_point_tri<22, 1>), grid, 256, 0, st, a.V, a.gamma, a.wvec, a.rhs, a);
     hipLaunchKernelGGL(k_point_finish<22>, dim3(B), 256, 0, st, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_point_trend(const PointRhsArgs& ra, const double* W, int ldW, int p, const double* betav, const double* Sinv,
+                              int estimate_trend, double* Tw, double* trec, int B, hipStream_t st) {
+  const size_t shm = (size_t)3 * p * sizeof(double);
+  if (point_columns_per_pass(ra.d) == 12) {
+    if (estimate_trend) hipLaunchKernelGGL(k_point_wt<12>, dim3((p + 7) / 8, ra.npass, B), 256, 0, st, ra.rhs, W, ldW, ra.N, ra.Npp, ra.npass, p, Tw);
+    hipLaunchKernelGGL(k_point_trend_fin<12>, dim3(B), 256, shm, st, ra, Tw, p, betav, Sinv, estimate_trend, trec);
+  } else {
+    if (estimate_trend) hipLaunchKernelGGL(k_point_wt<22>, dim3((p + 7) / 8, ra.npass, B), 256, 0, st, ra.rhs, W, ldW, ra.N, ra.Npp, ra.npass, p, Tw);
+    hipLaunchKernelGGL(k_point_trend_fin<22>, dim3(B), 256, shm, st, ra, Tw, p, betav, Sinv, estimate_trend, trec);
   }
   return hipGetLastError();
 }

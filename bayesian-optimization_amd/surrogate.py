@@ -799,8 +799,9 @@ class GaussianProcess:
         return np.sqrt((C_prior**2.0).sum(axis=0) / n_t)
 
     def _fused_point_ok(self) -> bool:
-        """bogp_point_eval serves the constant trend basis with a single target."""
-        return self._trend_args()[0] == _lib.TREND_CONSTANT and self.y.shape[1] == 1
+        """bogp_point_eval serves the constant and (r05) the linear trend basis -- the two the reference's `gradient` can differentiate
+        (gpr.py:556-575; quadratic_trend.Jacobian raises, trend.py:138-139) -- with a single target."""
+        return self._trend_args()[0] in (_lib.TREND_CONSTANT, _lib.TREND_LINEAR) and self.y.shape[1] == 1
 
     def gradient_batch(self, X):
         """`gradient` at B rows in one device call: (d mu / dx (B, d), d MSE / dx (B, d)).  Not in the reference
@@ -808,7 +809,7 @@ class GaussianProcess:
         if self._committed_par is None:
             raise Exception("The model is not fitted yet!")
         X = self._check_X(X)
-        if self._trend_args()[0] != _lib.TREND_CONSTANT:  # polynomial bases: the batched kernel serves p = 1 only
+        if not self._fused_point_ok():  # the quadratic basis / several targets: row by row (and the reference's errors)
             rows = [self.gradient(x.reshape(1, -1)) for x in X]
             return np.array([r[0].ravel() for r in rows]), np.array([r[1].ravel() for r in rows])
         return self.engine.gradient_batch(X)

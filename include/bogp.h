@@ -280,7 +280,7 @@ int bogp_sweep_topk(bogp_handle* h, int q, const int* acq_id, const double* acq_
 /* ---- input-gradient of the posterior at ONE point ---------------------------------------------------
  * Replaces GaussianProcess.gradient(x) (gpr.py:537-576, corr_dx :600-661): dmu (d), dmse (d).            */
 int bogp_gradient(bogp_handle* h, const double* x, double* dmu, double* dmse);
-/* The same for B points at once (Xb: B x d; dmu, dmse: B x d row-major); constant trend basis.  r03: k_point_rhs +
+/* The same for B points at once (Xb: B x d; dmu, dmse: B x d row-major); constant or (r05) linear trend basis, one target.  r03: k_point_rhs +
  * k_point_tri (csrc/kernels_point.hip) -- ONE pass over L^-1 per point serves all d + 1 right-hand sides.     */
 int bogp_gradient_batch(bogp_handle* h, const double* Xb, int B, double* dmu, double* dmse);
 /* Hessian of the posterior mean at x (GaussianProcess.Hessian, gpr.py:578-598), d x d row-major.  Squared exponential
@@ -292,7 +292,9 @@ int bogp_prior_corr(bogp_handle* h, const double* X1, int n1, double* R);
 /* One point, everything at once: what `criterion(x, return_dx=True)` needs (acquisition_fun.py:139-146, 181-188,
  * 220-227, 292-309 call predict, gradient and the closed form) -- mu, mse, dmu (d), dmse (d) and the q criterion values --
  * with a single host synchronisation.  This is the call the reference's DEFAULT inner optimiser (multi-restart
- * L-BFGS-B, base.py:201-243) makes thousands of times per ask().  Constant trend basis; q may be 0.            */
+ * L-BFGS-B, base.py:201-243) makes thousands of times per ask().  Constant or (r05) linear trend basis -- the two the
+ * reference's `gradient` differentiates (gpr.py:556-575; the quadratic basis has no Jacobian, trend.py:138-139) --, one target;
+ * q may be 0.                                                                                                        */
 int bogp_point_eval(bogp_handle* h, const double* x, int q, const int* acq_id, const double* acq_par, double plugin,
                     int minimize, double* mu, double* mse, double* dmu, double* dmse, double* acq);
 /* The same for B points (Xb: B x d, host) in ONE device round trip, plus the criteria's own input-gradients -- the
@@ -311,7 +313,7 @@ int bogp_point_eval_batch(bogp_handle* h, const double* Xb, int B, int q, const 
  * point per call.  Stop rules per start as the reference configures scipy's L-BFGS-B (:94-101): projected gradient
  * below pgtol (1e-8), relative improvement below factr (1e6) x machine epsilon, or max_evals evaluations.
  * X0: B x d starting points (clipped into the box); Xout: B x d; fout: B (criterion value at Xout, >= the value at
- * X0); n_evals: B evaluations used, may be NULL.  d <= 64; constant trend basis.                              */
+ * X0); n_evals: B evaluations used, may be NULL.  d <= 64; constant or linear trend basis.                              */
 int bogp_polish(bogp_handle* h, const double* X0, int B, const double* lo, const double* hi, int acq_id, double acq_par,
                 double plugin, int minimize, int max_evals, double pgtol, double factr, double* Xout, double* fout,
                 int* n_evals);
