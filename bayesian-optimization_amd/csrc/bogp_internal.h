@@ -352,7 +352,7 @@ hipError_t launch_point_rhs_T(int kernel, const PointRhsArgs& a, int ncp, double
 hipError_t launch_point_gw(int ncp, const double* rT, long long Mc, const double* gamma, const double* wvec, int Nr32, int B, int nJ,
                            double* part, hipStream_t st);
 hipError_t launch_point_finish_mfma(const PointTriArgs& a, int ncp, int B, hipStream_t st);
-size_t polish_state_doubles();
+size_t polish_state_doubles(int d);
 hipError_t launch_polish_step(const PolishArgs& a, int B, hipStream_t st);
 
 }  // namespace bogp

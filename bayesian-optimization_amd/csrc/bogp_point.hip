@@ -267,7 +267,6 @@ extern "C" int bogp_polish(bogp_handle* h, const double* X0, int B, const double
   if (e) return e;
   if (!X0 || !lo || !hi || !Xout || !fout || B <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_polish: null pointer or B <= 0");
   const int d = h->d;
-  if (d > 64) FAIL(h, BOGP_ERR_UNSUPPORTED, "bogp_polish: at most 64 input dimensions (one coordinate per lane)");
   if (max_evals <= 0) FAIL(h, BOGP_ERR_INVALID, "bogp_polish: max_evals must be positive");
   double wmin = INFINITY;
   for (int k = 0; k < d; ++k) {
@@ -278,7 +277,7 @@ extern "C" int bogp_polish(bogp_handle* h, const double* X0, int B, const double
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = h->stream;
   const PointPlan pl = plan_of(h, B, 1, true);
-  const size_t ss = polish_state_doubles();
+  const size_t ss = polish_state_doubles(d);
   if ((e = ensure(h, &h->dpt_Xb, &h->pt_Xb_cap, (size_t)B * d))) return e;
   if ((e = ensure(h, &h->dpt_out, &h->pt_out_cap, (size_t)B * pl.rec_stride))) return e;
   if ((e = ensure(h, &h->dpt_state, &h->pt_state_cap, (size_t)B * ss))) return e;

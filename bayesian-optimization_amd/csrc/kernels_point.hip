@@ -515,54 +515,84 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// CPL = coordinates per lane: lane l owns coordinates l, l + 64, ... (d <= 64 CPL; r05: CPL up to 5 = BOGP_MAX_DIM, where r03-r04 refused
+// d > 64).  CPL = 1 is the r03 kernel operation for operation.  The state's vectors have a pitch of DP = 64 CPL doubles.
+template <int CPL>
 __global__ __launch_bounds__(64) void k_polish_step(PolishArgs a) {
+  constexpr int DP = 64 * CPL;
   const int b = blockIdx.x, lane = threadIdx.x;
-  const int d = a.d;  // d <= 64: one coordinate per lane
-  const bool on = lane < d;
+  const int d = a.d;
+  bool on[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) on[c] = lane + 64 * c < d;
   double* st = a.state + (size_t)b * a.state_stride;
-  // state layout: [f, alpha, nhist, head, nfail, done, nevals, first] (8) | x (64) | g (64) | S (M x 64) | Y (M x 64) | rho (M)
+  // state layout: [f, alpha, nhist, head, nfail, done, nevals, first] (8) | x (DP) | g (DP) | S (M x DP) | Y (M x DP) | rho (M)
   double* sx = st + 8;
-  double* sg = sx + 64;
-  double* sS = sg + 64;
-  double* sY = sS + POLISH_M * 64;
-  double* srho = sY + POLISH_M * 64;
+  double* sg = sx + DP;
+  double* sS = sg + DP;
+  double* sY = sS + POLISH_M * DP;
+  double* srho = sY + POLISH_M * DP;
   const double* rec = a.rec + (size_t)b * a.rec_stride;
-  const double ft = rec[2];                                           // criterion 0 at the trial point
-  const double gt = on ? rec[2 + a.q + 2 * d + lane] : 0.0;           // its gradient
-  const double xt = on ? a.Xt[(size_t)b * d + lane] : 0.0;
-  const double lo = on ? a.lo[lane] : 0.0, hi = on ? a.hi[lane] : 0.0;
+  const double ft = rec[2];  // criterion 0 at the trial point
+  double gt[CPL], xt[CPL], lo[CPL], hi[CPL], x[CPL], gcur[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int k = lane + 64 * c;
+    gt[c] = on[c] ? rec[2 + a.q + 2 * d + k] : 0.0;  // its gradient
+    xt[c] = on[c] ? a.Xt[(size_t)b * d + k] : 0.0;
+    lo[c] = on[c] ? a.lo[k] : 0.0;
+    hi[c] = on[c] ? a.hi[k] : 0.0;
+    x[c] = on[c] ? sx[k] : 0.0;
+    gcur[c] = on[c] ? sg[k] : 0.0;
+  }
+  // sum over the lane's coordinates, then over the wave (CPL = 1: exactly the r03 order)
+  auto dot = [&](auto f) {
+    double v = f(0);
+#pragma unroll
+    for (int c = 1; c < CPL; ++c) v += f(c);
+    return wave_sum(v);
+  };
+  auto amax = [&](auto f) {
+    double v = f(0);
+#pragma unroll
+    for (int c = 1; c < CPL; ++c) v = fmax(v, f(c));
+    return wave_max(v);
+  };
   double f = st[0], alpha = st[1];
   int nhist = (int)st[2], head = (int)st[3], nfail = (int)st[4], done = (int)st[5], nevals = (int)st[6];
   const int first = (int)st[7];
-  double x = on ? sx[lane] : 0.0, gcur = on ? sg[lane] : 0.0;
   if (done) return;  // the trial buffer already holds x
   nevals += 1;
   bool accepted = false;
   if (first) {
-    x = xt;
-    gcur = gt;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { x[c] = xt[c]; gcur[c] = gt[c]; }
     f = ft;
     accepted = true;
     if (!(ft == ft) || !isfinite(ft)) done = 1;  // nothing to climb from
   } else {
-    const double slope = wave_sum(gcur * (xt - x));
-    const bool finite = (ft == ft) && isfinite(ft) && isfinite(wave_sum(fabs(gt)));
+    const double slope = dot([&](int c) { return gcur[c] * (xt[c] - x[c]); });
+    const bool finite = (ft == ft) && isfinite(ft) && isfinite(dot([&](int c) { return fabs(gt[c]); }));
     if (finite && ft >= f + 1e-4 * slope && ft > f) {
-      const double s = xt - x, yv = gcur - gt;  // pair of the equivalent minimisation of -f
-      const double sy = wave_sum(s * yv), yy = wave_sum(yv * yv);
+      double sv[CPL], yv[CPL];  // pair of the equivalent minimisation of -f
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { sv[c] = xt[c] - x[c]; yv[c] = gcur[c] - gt[c]; }
+      const double sy = dot([&](int c) { return sv[c] * yv[c]; }), yy = dot([&](int c) { return yv[c] * yv[c]; });
       if (sy > 2.2e-16 * yy) {
-        if (on) {
-          sS[head * 64 + lane] = s;
-          sY[head * 64 + lane] = yv;
-        }
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+          if (on[c]) {
+            sS[head * DP + lane + 64 * c] = sv[c];
+            sY[head * DP + lane + 64 * c] = yv[c];
+          }
         if (lane == 0) srho[head] = 1.0 / sy;
         head = (head + 1) % POLISH_M;
         nhist = nhist < POLISH_M ? nhist + 1 : POLISH_M;
       }
       const double gain = ft - f;
       const double scale_f = fmax(fmax(fabs(f), fabs(ft)), 1.0);
-      x = xt;
-      gcur = gt;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { x[c] = xt[c]; gcur[c] = gt[c]; }
       f = ft;
       alpha = 1.0;
       nfail = 0;
@@ -575,59 +605,79 @@ __global__ __launch_bounds__(64) void k_polish_step(PolishArgs a) {
     }
   }
   if (accepted && !done) {
-    const double pg = on ? fmin(fmax(x + gcur, lo), hi) - x : 0.0;  // projected gradient of the ascent
-    if (wave_max(fabs(pg)) < a.pgtol) done = 1;
+    // projected gradient of the ascent
+    if (amax([&](int c) { return on[c] ? fabs(fmin(fmax(x[c] + gcur[c], lo[c]), hi[c]) - x[c]) : 0.0; }) < a.pgtol) done = 1;
   }
   if (nevals >= a.max_evals) done = 1;
   // next trial point
-  double xn = x;
+  double xn[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) xn[c] = x[c];
   if (!done) {
     __syncthreads();  // history written above is read below (one wave: a compiler barrier is all this is)
-    const bool blocked = on && ((x <= lo && gcur < 0.0) || (x >= hi && gcur > 0.0));
-    const double gf = (on && !blocked) ? gcur : 0.0;
-    double p = gf;
-    const double gnorm = sqrt(wave_sum(gf * gf));
+    bool blocked[CPL];
+    double gf[CPL], p[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      blocked[c] = on[c] && ((x[c] <= lo[c] && gcur[c] < 0.0) || (x[c] >= hi[c] && gcur[c] > 0.0));
+      gf[c] = (on[c] && !blocked[c]) ? gcur[c] : 0.0;
+      p[c] = gf[c];
+    }
+    const double gnorm = sqrt(dot([&](int c) { return gf[c] * gf[c]; }));
     if (nhist > 0) {
-      double qv = gf;
+      double qv[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) qv[c] = gf[c];
       double al[POLISH_M];
 #pragma unroll
       for (int i = 0; i < POLISH_M; ++i) {
         al[i] = 0.0;
         if (i < nhist) {
           const int h = (head - 1 - i + 2 * POLISH_M) % POLISH_M;
-          al[i] = srho[h] * wave_sum((on ? sS[h * 64 + lane] : 0.0) * qv);
-          qv -= al[i] * (on ? sY[h * 64 + lane] : 0.0);
+          al[i] = srho[h] * dot([&](int c) { return (on[c] ? sS[h * DP + lane + 64 * c] : 0.0) * qv[c]; });
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) qv[c] -= al[i] * (on[c] ? sY[h * DP + lane + 64 * c] : 0.0);
         }
       }
       const int hl = (head - 1 + POLISH_M) % POLISH_M;
-      const double yl = on ? sY[hl * 64 + lane] : 0.0;
-      const double gam = 1.0 / (srho[hl] * wave_sum(yl * yl));
-      qv *= gam;
+      const double gam = 1.0 / (srho[hl] * dot([&](int c) { const double yl = on[c] ? sY[hl * DP + lane + 64 * c] : 0.0; return yl * yl; }));
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) qv[c] *= gam;
 #pragma unroll
       for (int i = POLISH_M - 1; i >= 0; --i) {
         if (i < nhist) {
           const int h = (head - 1 - i + 2 * POLISH_M) % POLISH_M;
-          const double be = srho[h] * wave_sum((on ? sY[h * 64 + lane] : 0.0) * qv);
-          qv += (al[i] - be) * (on ? sS[h * 64 + lane] : 0.0);
+          const double be = srho[h] * dot([&](int c) { return (on[c] ? sY[h * DP + lane + 64 * c] : 0.0) * qv[c]; });
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) qv[c] += (al[i] - be) * (on[c] ? sS[h * DP + lane + 64 * c] : 0.0);
         }
       }
-      p = blocked ? 0.0 : qv;
-      const double asc = wave_sum(p * gf);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) p[c] = blocked[c] ? 0.0 : qv[c];
+      const double asc = dot([&](int c) { return p[c] * gf[c]; });
       if (!(asc > 0.0) || !isfinite(asc)) {  // not an ascent direction: steepest ascent, history dropped
-        p = gf;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) p[c] = gf[c];
         nhist = 0;
         head = 0;
       }
     }
-    if (nhist == 0 && gnorm > 0.0) p = gf * (a.first_step / gnorm);  // first move: a fixed length along the gradient
-    xn = on ? fmin(fmax(x + alpha * p, lo), hi) : 0.0;
-    if (wave_max(fabs(xn - x)) == 0.0) done = 1;  // the step no longer moves any coordinate
+    if (nhist == 0 && gnorm > 0.0) {  // first move: a fixed length along the gradient
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) p[c] = gf[c] * (a.first_step / gnorm);
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) xn[c] = on[c] ? fmin(fmax(x[c] + alpha * p[c], lo[c]), hi[c]) : 0.0;
+    if (amax([&](int c) { return fabs(xn[c] - x[c]); }) == 0.0) done = 1;  // the step no longer moves any coordinate
   }
-  if (done) xn = x;
-  if (on) {
-    sx[lane] = x;
-    sg[lane] = gcur;
-    a.Xt[(size_t)b * d + lane] = xn;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    if (done) xn[c] = x[c];
+    if (on[c]) {
+      sx[lane + 64 * c] = x[c];
+      sg[lane + 64 * c] = gcur[c];
+      a.Xt[(size_t)b * d + lane + 64 * c] = xn[c];
+    }
   }
   if (lane == 0) {
     st[0] = f;
@@ -757,10 +807,20 @@ hipError_t launch_point_finish_mfma(const PointTriArgs& a, int ncp, int B, hipSt
   return hipGetLastError();
 }
 
-size_t polish_state_doubles() { return 8 + 64 + 64 + 2 * (size_t)POLISH_M * 64 + POLISH_M; }
+size_t polish_state_doubles(int d) {
+  const size_t DP = (size_t)((d + 63) / 64) * 64;
+  return 8 + 2 * DP + 2 * (size_t)POLISH_M * DP + POLISH_M;
+}
 
 hipError_t launch_polish_step(const PolishArgs& a, int B, hipStream_t st) {
-  hipLaunchKernelGGL(k_polish_step, dim3(B), 64, 0, st, a);
+  switch ((a.d + 63) / 64) {
+    case 1: hipLaunchKernelGGL(k_polish_step<1>, dim3(B), 64, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(k_polish_step<2>, dim3(B), 64, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(k_polish_step<3>, dim3(B), 64, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(k_polish_step<4>, dim3(B), 64, 0, st, a); break;
+    case 5: hipLaunchKernelGGL(k_polish_step<5>, dim3(B), 64, 0, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

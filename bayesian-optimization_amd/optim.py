@@ -479,7 +479,7 @@ def polish_topk(crit, starts: np.ndarray, bounds: np.ndarray, max_iter: int = 50
     model = crit.model
     eng = getattr(model, "engine", None)
     fused = getattr(model, "_fused_point_ok", None)
-    if eng is not None and hasattr(eng, "polish") and fused is not None and fused() and starts.shape[1] <= 64:
+    if eng is not None and hasattr(eng, "polish") and fused is not None and fused():  # (r05: any d up to BOGP_MAX_DIM; r03-r04 stopped at 64)
         if getattr(model, "_committed_par", None) is None:
             raise Exception("The model is not fitted yet!")
         xs, fs, _ = eng.polish(model._check_X(starts), bounds[:, 0], bounds[:, 1], (crit.acq_id, crit.acq_par()), crit.effective_plugin(),

@@ -313,7 +313,7 @@ int bogp_point_eval_batch(bogp_handle* h, const double* Xb, int B, int q, const 
  * point per call.  Stop rules per start as the reference configures scipy's L-BFGS-B (:94-101): projected gradient
  * below pgtol (1e-8), relative improvement below factr (1e6) x machine epsilon, or max_evals evaluations.
  * X0: B x d starting points (clipped into the box); Xout: B x d; fout: B (criterion value at Xout, >= the value at
- * X0); n_evals: B evaluations used, may be NULL.  d <= 64; constant or linear trend basis.                              */
+ * X0); n_evals: B evaluations used, may be NULL.  any d up to BOGP_MAX_DIM (r05; r03-r04: d <= 64); constant or linear trend basis.                              */
 int bogp_polish(bogp_handle* h, const double* X0, int B, const double* lo, const double* hi, int acq_id, double acq_par,
                 double plugin, int minimize, int max_evals, double pgtol, double factr, double* Xout, double* fout,
                 int* n_evals);

@@ -337,3 +337,28 @@ def test_linear_trend_return_dx_matches_the_reference(eng, name):
     for c, (key, _, _) in enumerate(DX_ACQ):
         np.testing.assert_allclose(vals[:, c], g["dx_val_" + key], rtol=1e-6, atol=1e-300, err_msg=key)
         np.testing.assert_allclose(dvals[:, c, :], g["dx_" + key], rtol=1e-6, atol=1e-12, err_msg=key)
+
+
+@pytest.mark.parametrize("N,d,tid", [(400, 100, O.TREND_CONSTANT), (300, 70, O.TREND_LINEAR), (500, 200, O.TREND_CONSTANT)])
+def test_polish_beyond_64_dimensions_and_with_a_linear_trend(eng, N, d, tid):
+    """r05: the lock-step polish for d up to BOGP_MAX_DIM (several coordinates per lane; r03-r04 refused d > 64) and on a
+    linear-trend model.  Properties: stays in the box, never ends below its start, the reported value IS the criterion at the reported
+    point, and it improves on the starts."""
+    rng = np.random.default_rng(d)
+    X = rng.uniform(-5, 5, size=(N, d))
+    y = np.sum((X - 1.0) ** 2, axis=1) + rng.standard_normal(N)
+    y = ((y - y.mean()) / y.std()).reshape(-1, 1)
+    par = np.r_[np.full(d, 0.3 / d), 0.8]
+    eng.set_train(X, y)
+    eng.commit(O.KERNEL_MATERN52, O.MODE_NOISY, par, 1e-4, True, 0.0, trend=tid)
+    pl = float(y.min())
+    acq = (O.ACQ_UCB, 0.5)
+    starts = rng.uniform(-5, 5, size=(16, d))
+    lo, hi = np.full(d, -5.0), np.full(d, 5.0)
+    _, _, _, _, v0, _ = eng.point_eval_batch(starts, [acq], pl, True)
+    Xp, fp, ne = eng.polish(starts, lo, hi, acq, pl, True, max_evals=40)
+    assert Xp.shape == (16, d) and np.all(Xp >= lo) and np.all(Xp <= hi) and np.all(ne >= 1) and np.all(ne <= 40)
+    assert np.all(fp >= v0[:, 0] - 1e-12 * np.abs(v0[:, 0]))
+    assert np.mean(fp > v0[:, 0]) > 0.8  # it climbs
+    _, _, _, _, vcheck, _ = eng.point_eval_batch(Xp, [acq], pl, True)
+    np.testing.assert_allclose(vcheck[:, 0], fp, rtol=1e-12)
