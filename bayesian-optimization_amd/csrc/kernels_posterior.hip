@@ -579,8 +579,9 @@ static bool corr_mfma_enabled() {
 
 hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipStream_t st) {
   dim3 grid((unsigned)nMt, (unsigned)S);
-  const bool sqdist = kernel == BOGP_KERNEL_SE || kernel == BOGP_KERNEL_MATERN12 || kernel == BOGP_KERNEL_MATERN32 ||
-                      kernel == BOGP_KERNEL_MATERN52 || kernel == BOGP_KERNEL_MATERN_NU;
+  // (the general-nu Matern kernel is a squared-distance kernel too, but its profile -- K_nu: hundreds of operations a pair -- dwarfs the distance and
+  // needs 270 VGPRs: it stays on kernel A, which holds it without spills)
+  const bool sqdist = kernel == BOGP_KERNEL_SE || kernel == BOGP_KERNEL_MATERN12 || kernel == BOGP_KERNEL_MATERN32 || kernel == BOGP_KERNEL_MATERN52;
   if (sqdist && a.pv == 0 && a.xnorm && corr_mfma_enabled()) {
     const int KS = (a.d + 3) / 4;
     const size_t shm = (size_t)max(4 * KS * 64, 2048) * sizeof(double);  // <= 160 KB up to d = 320, like kernel A
@@ -599,7 +600,6 @@ hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipS
       case BOGP_KERNEL_SE: BOGP_LAUNCH_CORR_MFMA(BOGP_KERNEL_SE); break;
       case BOGP_KERNEL_MATERN12: BOGP_LAUNCH_CORR_MFMA(BOGP_KERNEL_MATERN12); break;
       case BOGP_KERNEL_MATERN32: BOGP_LAUNCH_CORR_MFMA(BOGP_KERNEL_MATERN32); break;
-      case BOGP_KERNEL_MATERN_NU: BOGP_LAUNCH_CORR_MFMA(BOGP_KERNEL_MATERN_NU); break;
       default: BOGP_LAUNCH_CORR_MFMA(BOGP_KERNEL_MATERN52); break;
     }
 #undef BOGP_LAUNCH_CORR_MFMA
