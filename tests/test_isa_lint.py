@@ -79,3 +79,25 @@ def test_the_lint_rules_on_hand_made_sequences():
     assert any(b.startswith("(c)") for b in isa_lint.lint_function(mk([("v_mul_f64", "v[6:7], v[30:31], v[32:33]"), ("s_nop", "0"), mf, ("s_endpgm", "")])))  # as SrcC
     # scratch between the first and the last MFMA
     assert any(b.startswith("(a)") for b in isa_lint.lint_function(mk([mf, ("scratch_store_dwordx2", "off, v[50:51], off"), mf, ("s_endpgm", "")])))
+
+
+def test_instruction_mix_of_the_producers_is_reported_from_the_disassembly():
+    """tools/isa_valu_mix.py: the per-pair FP64 VALU count of both correlation producers read off the shipped library --
+    kernel A' must keep the distance off the VALU (no more than 45 DP instructions a pair for Matern-5/2, kernel A: 39 + 40 at d = 20)."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(_lib.LIB_PATH)))
+    spec = importlib.util.spec_from_file_location("isa_valu_mix", os.path.join(root, "tools", "isa_valu_mix.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    seen = {}
+    for text in isa_lint.disassemble_library(_lib.LIB_PATH):
+        for name, insns in mod.kernels(text).items():
+            for tag in ("k_corr_mfmaILi3E", "k_corr_chunkILi3ELi0E"):
+                if tag in name:
+                    blocks = [mod.classify(b) for b in mod.basic_blocks(insns)]
+                    prof = max(blocks, key=lambda c: (c["stores"], c["dp_valu"]))
+                    seen[tag] = (prof["dp_valu"] / prof["stores"], prof["stores"], max(c["mfma"] for c in blocks))
+    assert set(seen) == {"k_corr_mfmaILi3E", "k_corr_chunkILi3ELi0E"}
+    assert seen["k_corr_mfmaILi3E"][1] == 16 and seen["k_corr_mfmaILi3E"][0] <= 45.0 and seen["k_corr_mfmaILi3E"][2] >= 4
+    assert seen["k_corr_chunkILi3ELi0E"][1] == 8 and seen["k_corr_chunkILi3ELi0E"][2] == 0
