@@ -289,6 +289,40 @@ static int run_group(bogp_handle* h, int path, int kernel, int mode, const std::
   return BOGP_OK;
 }
 
+namespace bogp {
+
+// The handles a batch of P independent one-evaluation calls (bogp_nll, bogp_nll_restricted) is dealt over: the caller's + helpers of the library's
+// own (own stream, own factor buffers, fed from the host copy of the training set), one host thread each.  An evaluation is a chain of small
+// launches between larger ones; independent chains interleave on the device (profiles/r05_nll_two_handles.txt).
+std::vector<bogp_handle*> nll_team(bogp_handle* h, int P) {
+  const int N = h->N, d = h->d;
+  // workers: 3 handles up to N = 4096 (a linear-trend evaluation at N = 1024: 0.97 -> 0.47 ms), 2 above (C5: three gain nothing over two and
+  // cost another set of N^2 buffers); none below N = 192, where an evaluation is a handful of launches.  BOGP_NLL_WORKERS = 1: off.
+  static const int workers_env = [] { const char* e = getenv("BOGP_NLL_WORKERS"); return e ? std::max(1, std::min(3, atoi(e))) : 3; }();
+  const int workers = std::min(std::min(workers_env, N > 4096 ? 2 : 3), P);
+  std::vector<bogp_handle*> team{h};
+  if (workers > 1 && N >= 192 && !h->h_X.empty()) {
+    for (int w = 1; w < workers; ++w) {
+      if ((int)h->aux.size() < w) {
+        bogp_handle* a = nullptr;
+        if (bogp_create(h->device, &a) != BOGP_OK) break;  // (no helper: fewer handles do it all)
+        h->aux.push_back(a);
+        h->aux_gen.push_back(0);
+      }
+      bogp_handle* a = h->aux[(size_t)w - 1];
+      if (h->aux_gen[(size_t)w - 1] != h->train_gen) {
+        if (bogp_set_train(a, h->h_X.data(), h->h_y.data(), N, d, h->n_t) != BOGP_OK) break;
+        h->aux_gen[(size_t)w - 1] = h->train_gen;
+      }
+      a->h_beta_fixed = h->h_beta_fixed;  // fixed coefficients of a polynomial basis, if any
+      team.push_back(a);
+    }
+  }
+  return team;
+}
+
+}  // namespace bogp
+
 extern "C" int bogp_nll_batch(bogp_handle* h, int kernel, int mode, int P, const double* par, int n_par, double noise_var, int trend,
                               int estimate_trend, double beta, double* llf, double* grad, int* info) {
   if (!h) return BOGP_ERR_INVALID;
@@ -332,28 +366,7 @@ extern "C" int bogp_nll_batch(bogp_handle* h, int kernel, int mode, int P, const
       return rc;
     };
     auto fatal = [](int rc) { return rc == BOGP_ERR_HIP || rc == BOGP_ERR_UNSUPPORTED || rc == BOGP_ERR_NO_DEVICE; };
-    // workers: 3 handles up to N = 4096 (a linear-trend evaluation at N = 1024: 0.97 -> 0.47 ms), 2 above (C5: three gain nothing over two and
-    // cost another set of N^2 buffers); none below N = 192, where an evaluation is a handful of launches.  BOGP_NLL_WORKERS = 1: off.
-    static const int workers_env = [] { const char* e = getenv("BOGP_NLL_WORKERS"); return e ? std::max(1, std::min(3, atoi(e))) : 3; }();
-    const int workers = std::min(std::min(workers_env, N > 4096 ? 2 : 3), P);
-    std::vector<bogp_handle*> team{h};
-    if (workers > 1 && N >= 192 && !h->h_X.empty()) {
-      for (int w = 1; w < workers; ++w) {
-        if ((int)h->aux.size() < w) {
-          bogp_handle* a = nullptr;
-          if (bogp_create(h->device, &a) != BOGP_OK) break;  // (no helper: fewer handles do it all)
-          h->aux.push_back(a);
-          h->aux_gen.push_back(0);
-        }
-        bogp_handle* a = h->aux[(size_t)w - 1];
-        if (h->aux_gen[(size_t)w - 1] != h->train_gen) {
-          if (bogp_set_train(a, h->h_X.data(), h->h_y.data(), N, d, h->n_t) != BOGP_OK) break;
-          h->aux_gen[(size_t)w - 1] = h->train_gen;
-        }
-        a->h_beta_fixed = h->h_beta_fixed;  // fixed coefficients of a polynomial basis, if any
-        team.push_back(a);
-      }
-    }
+    std::vector<bogp_handle*> team = nll_team(h, P);
     const int W = (int)team.size();
     if (W == 1) {
       for (int s = 0; s < P; ++s) {

@@ -15,6 +15,7 @@ namespace bogp {
 void comm_release(bogp_handle* h);   // bogp_comm.hip: destroys an owned communicator, frees the exchange buffers
 void point_release(bogp_handle* h);  // bogp_point.hip: frees the point-evaluation buffers
 void batch_release(bogp_handle* h);  // bogp_batch.hip: frees the batched-likelihood staging and workspaces
+std::vector<bogp_handle*> nll_team(bogp_handle* h, int P);  // bogp_batch.hip: the handles a batch of one-evaluation calls is dealt over
 // bogp_point.hip: posterior, input-gradients and q criteria of B points through k_point_rhs + k_point_tri.  `Xb` is a HOST
 // array (B x d).  Outputs (host, any may be null): mu, mse (B), dmu, dmse (B x d), acq (B x q), dacq (B x q x d).
 int point_eval_host(bogp_handle* h, const char* who, const double* Xb, int B, int q, const int* acq_id, const double* acq_par,

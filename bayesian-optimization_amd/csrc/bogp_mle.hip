@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "../../include/bogp.h"
@@ -107,17 +108,31 @@ extern "C" int bogp_mle_batch(bogp_handle* h, int kernel, int mode, int restrict
     } else {
       // REML (gpr.py:813-918): its device path is the one-evaluation one; the restarts still share this loop (no host optimiser
       // overhead between evaluations).  exp(llf) > 1 is -inf WITH the gradient of the finite value, as the reference returns it
-      for (int i = 0; i < P; ++i) {
+      // r05: dealt over the caller's handle and the library's helper handles (bogp_batch.hip: nll_team), one host thread each
+      auto run_slot = [&](bogp_handle* hh, int i) -> int {
         const double* p = par.data() + (size_t)i * n_par;
         bool ok = true;
         for (int k = 0; k < n_par; ++k) ok = ok && std::isfinite(p[k]) && p[k] > 0;
         int rc = BOGP_ERR_INVALID;
-        if (ok) rc = bogp_nll_restricted(h, kernel, mode, p, n_par, noise_var, trend, estimate_trend, beta, &llf[(size_t)i], grad.data() + (size_t)i * n_par);
-        if (rc == BOGP_ERR_HIP || rc == BOGP_ERR_UNSUPPORTED || rc == BOGP_ERR_NO_DEVICE) return rc;
+        if (ok) rc = bogp_nll_restricted(hh, kernel, mode, p, n_par, noise_var, trend, estimate_trend, beta, &llf[(size_t)i], grad.data() + (size_t)i * n_par);
         if (rc != BOGP_OK && rc != BOGP_ERR_LLF_POSITIVE)
           for (int k = 0; k < n_par; ++k) grad[(size_t)i * n_par + k] = 0.0;
         info[(size_t)i] = rc;
-      }
+        return rc;
+      };
+      auto fatal = [](int rc) { return rc == BOGP_ERR_HIP || rc == BOGP_ERR_UNSUPPORTED || rc == BOGP_ERR_NO_DEVICE; };
+      std::vector<bogp_handle*> team = nll_team(h, P);
+      const int W = (int)team.size();
+      std::vector<int> rcs((size_t)W, BOGP_OK);
+      std::vector<std::thread> threads;
+      for (int w = 1; w < W; ++w)
+        threads.emplace_back([&, w] {
+          for (int i = w; i < P && !fatal(rcs[(size_t)w]); i += W) rcs[(size_t)w] = run_slot(team[(size_t)w], i);
+        });
+      for (int i = 0; i < P && !fatal(rcs[0]); i += W) rcs[0] = run_slot(h, i);
+      for (auto& t : threads) t.join();
+      for (int w = 0; w < W; ++w)
+        if (fatal(rcs[(size_t)w])) return rcs[(size_t)w];
     }
     ++rounds;
     evals += P;
