@@ -109,6 +109,7 @@ class GaussianProcess:
         distribute_restarts=False,
         restart_streams=None,
         restart_batch=None,
+        restart_lookahead=None,
         mle_chain_rule=False,
         mle_prune_reserve=0,
     ):
@@ -141,6 +142,11 @@ class GaussianProcess:
         # restart_batch only: as the shared evaluation budget runs out (fewer than this many evaluations per active restart left) the worst
         # restart is stopped, so that the budget ends on the leading ones (0: equal shares to the end)
         self.mle_prune_reserve = int(mle_prune_reserve)
+        # r05: the reference's SEQUENTIAL restart loop with look-ahead -- restart i + 1 (.. i + L) is run speculatively on a second (..) engine
+        # while restart i runs; results, evaluation count and the np.random stream are the sequential loop's, bit for bit
+        # (`_restarts_with_lookahead`).  None: BOGP_RESTART_LOOKAHEAD, or by size (two restarts ahead from N = 1500, where the device time of an
+        # evaluation dwarfs the interpreter's share, one below); 0: off.
+        self.restart_lookahead = int(restart_lookahead if restart_lookahead is not None else os.environ.get("BOGP_RESTART_LOOKAHEAD", "-1"))  # -1: by size
         self._worker_engines = []
 
         self.theta0 = np.array(theta0, dtype=float).flatten() if theta0 is not None else None
@@ -495,6 +501,20 @@ class GaussianProcess:
                 param[name] = optimal_param[i : i + len_]
                 i += len_
             return param, optimal_llf_value, env, optimal_param
+        ahead = int(getattr(self, "restart_lookahead", 0) or 0)
+        if ahead < 0:
+            ahead = 2 if len(self.X) >= 1500 else 1
+        ahead = min(ahead, self.random_start - 1, 3)
+        if ahead > 0 and dist is None and not restricted:
+            param_opt, llf_opt = self._restarts_with_lookahead(ahead, log10param, log10bounds, eval_budget)
+            optimal_param = 10.0**param_opt
+            env = {}
+            optimal_llf_value = llf_fun(optimal_param, env, _adopt=True)
+            param, i = {}, 0
+            for name, len_ in zip(par_list, par_len):
+                param[name] = optimal_param[i : i + len_]
+                i += len_
+            return param, optimal_llf_value, env, optimal_param
         wait_count = 0
         param_opt, llf_opt = np.array(log10param, dtype=float), np.inf
         first = True
@@ -595,6 +615,119 @@ class GaussianProcess:
                 np.random.uniform(lo, hi)
                 it += 1
         self._committed_par = None  # (the batched paths leave the factor buffers alone, the fallback paths do not)
+        return np.asarray(param_opt, dtype=float), float(llf_opt)
+
+    def _restarts_with_lookahead(self, ahead, log10param0, log10bounds, eval_budget):
+        """The reference's sequential restart loop (gpr.py:1127-1162) -- same restarts, same order, same shared budget, same stagnation stop,
+        same draws from the global np.random, same evaluation count, same result BIT FOR BIT -- with the next `ahead` restarts run
+        SPECULATIVELY on further engines of the same GPU (own HIP stream, own factor buffers, one host thread each; ctypes releases the GIL)
+        while the current one runs.  A likelihood evaluation up to N ~ 4000 is a chain of small launches that leaves most of the GPU idle,
+        and two independent chains interleave (profiles/r05_nll_two_handles.txt); a default BO loop is 95 % such evaluations.
+
+        Why this is exact.  A restart is a deterministic function of (start point, maxfun): the engines run the same kernels with the same
+        launch geometry, and nothing in an evaluation touches np.random.  What restart i + 1 inherits from restart i is only (a) whether it
+        runs at all (budget left, stagnation counter), (b) its maxfun = the budget left.  So it is launched with the budget known at launch
+        time -- an upper bound of (b) -- and its start point is drawn early, with the generator's state saved before the draw:
+          * if the loop stops before it, it is cancelled and the generator is put back (the draw never happened);
+          * if it used no more evaluations than the budget it really had, scipy's `evaluations > maxfun` test (made at every new iterate)
+            could not have fired either way: the result IS the sequential one;
+          * otherwise (it ran into the end of the budget) it is re-run with the true maxfun -- which is what the sequential loop does.
+        `restart_lookahead=0` (or BOGP_RESTART_LOOKAHEAD=0) runs the plain loop."""
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+
+        lo, hi = log10bounds[:, 0], log10bounds[:, 1]
+        W = ahead + 1
+        make = type(self.engine)  # (the oracle-backed stand-in of the CPU tests speculates on stand-ins)
+        while len(self._worker_engines) < ahead:
+            self._worker_engines.append(make(self.device))
+        engines = [self.engine] + self._worker_engines[:ahead]
+        for eng in engines[1:]:
+            eng.set_train(self.X, self.y)
+        tid, est, beta = self._trend_args()
+        mode, nv, kid = self._MODE[self.estimation_mode], self._nv(), self.kernel_id
+
+        class _Cancelled(Exception):
+            pass
+
+        def run(eng, start, maxfun, cancel):
+            calls = [0]
+
+            def obj(log10param):  # what obj_func of the sequential loop returns, value for value
+                if cancel is not None and cancel.is_set():
+                    raise _Cancelled()
+                calls[0] += 1
+                par = 10.0 ** np.array(log10param)
+                if not (np.all(np.isfinite(par)) and np.all(par > 0)):
+                    return -1.0 * -np.inf, -1.0 * np.zeros(len(par))
+                try:
+                    llf, grad = eng.nll(kid, mode, self._epar(par), nv, est, beta, eval_grad=True, trend=tid)
+                except _lib.NotPositiveDefinite:
+                    return -1.0 * -np.inf, -1.0 * np.zeros(len(par))
+                return -1.0 * llf, -1.0 * np.asarray(grad, dtype=float).ravel()
+
+            try:
+                p_, l_, info = fmin_l_bfgs_b(obj, start, bounds=log10bounds, maxfun=maxfun)
+            except _Cancelled:
+                return None
+            return p_, l_, info, calls[0]
+
+        free = list(range(W))
+        inflight = {}
+        stats = dict(restarts=0, speculated=0, rerun=0, cancelled=0)  # (kept in self.lookahead_stats: tests, `verbose`)
+        next_it, budget, wait_count, first, most = 0, int(eval_budget), 0, True, 0
+        param_opt, llf_opt = np.array(log10param0, dtype=float), np.inf
+        self.eval_count = 0
+        with warnings.catch_warnings():  # (ONE context around the pool: catch_warnings is not thread-safe)
+            warnings.simplefilter("ignore")
+            with ThreadPoolExecutor(max_workers=W) as pool:
+                it = 0
+                while it < self.random_start:
+                    while next_it < self.random_start and next_it <= it + ahead and free:
+                        # speculate only while the budget is roomy: a restart that runs into the end of the budget it was GUESSED to have must be
+                        # re-run with the real one, and near the end of the budget that is the common case (twice the largest restart so far)
+                        if next_it > it and budget < 2 * max(most, 1) * (next_it - it + 1):
+                            break
+                        state = np.random.get_state() if next_it != 0 else None
+                        start = np.array(log10param0, dtype=float) if next_it == 0 else np.random.uniform(lo, hi)
+                        e = free.pop(0)
+                        cancel = threading.Event()
+                        inflight[next_it] = (pool.submit(run, engines[e], start, budget, cancel), e, budget, state, cancel, start)
+                        stats["speculated"] += int(next_it > it)
+                        next_it += 1
+                    fut, e, spec_budget, _, _, start = inflight.pop(it)
+                    p_, l_, info, calls = fut.result()
+                    if spec_budget != budget and info["funcalls"] > budget:
+                        p_, l_, info, calls = run(engines[e], start, budget, None)  # it ran into a budget it did not have: the sequential call
+                        stats["rerun"] += 1
+                    free.append(e)
+                    stats["restarts"] += 1
+                    if first:
+                        param_opt, llf_opt, first = p_, l_, False
+                    elif l_ <= llf_opt:
+                        param_opt, llf_opt = p_, l_
+                        wait_count = 0
+                    else:
+                        wait_count += 1
+                    if self.verbose:
+                        print("MLE restart %d: %d likelihood evaluations, best llf so far %.10g" % (it + 1, info["funcalls"], -llf_opt))
+                    self.eval_count += calls
+                    budget -= info["funcalls"]
+                    most = max(most, int(info["funcalls"]))
+                    it += 1
+                    if budget <= 0 or wait_count >= self.wait_iter:
+                        break
+                # restarts launched beyond the loop's end never happened: stop them, and un-draw their start points
+                rest = sorted(inflight)
+                for j in rest:
+                    inflight[j][4].set()
+                for j in rest:
+                    inflight[j][0].result()
+                if rest:
+                    np.random.set_state(inflight[rest[0]][3])
+                stats["cancelled"] = len(rest)
+        self.lookahead_stats = stats
+        self._committed_par = None
         return np.asarray(param_opt, dtype=float), float(llf_opt)
 
     def _restarts_on_streams(self, streams, log10param0, log10bounds, eval_budget):

@@ -1345,13 +1345,16 @@ def test_batch_proposal_over_device_generated_designs():
 
 def test_unsupported_combinations_are_refused_loudly(eng):
     """Entry points that serve a subset of the models say so with BOGP_ERR_UNSUPPORTED instead of computing something
-    else: the fused one-point call and the Hessian with a polynomial basis / a non-SE kernel, the REML gradient with several targets."""
+    else: the fused one-point call with the quadratic basis, the Hessian with a non-SE kernel, the REML gradient with several targets."""
+    gq = load_golden("G14_quadratic_uk_m32")
+    commit_trend_golden(eng, gq)
+    with pytest.raises(_lib.BogpError) as ei:  # the quadratic basis has no Jacobian in the reference (trend.py:138-139): no input-gradients here either
+        eng.point_eval(gq["Xs"][0], [(O.ACQ_EI, 0.0)], 0.0, True)
+    assert ei.value.code == _lib.ERR_UNSUPPORTED
     g = load_golden("G13_linear_uk_se")
     commit_trend_golden(eng, g)
     x = g["Xs"][0]
-    with pytest.raises(_lib.BogpError) as ei:
-        eng.point_eval(x, [(O.ACQ_EI, 0.0)], 0.0, True)
-    assert ei.value.code == _lib.ERR_UNSUPPORTED
+    assert np.isfinite(eng.point_eval(x, [(O.ACQ_EI, 0.0)], 0.0, True)[0])  # (r05: the linear basis is served, tests/test_gpu_point.py)
     assert eng.hessian(x).shape == (len(x), len(x))  # linear trend: its Hessian is zero, the SE part is served
     g2 = load_golden("G2_m32_ok_noisy")
     commit_golden(eng, g2)

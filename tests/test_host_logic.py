@@ -349,3 +349,43 @@ def test_driver_trace_fixture_replays_on_the_oracle_engine(fixture):
             np.testing.assert_array_equal(out[1], c["out"][1])
             n_top += 1
     assert n_nll >= 50 and n_top == (3 if fixture == "G28_driver_trace" else 0)
+
+
+_LOOKAHEAD_SEEN = set()
+
+
+@pytest.mark.parametrize("budget,wait_iter,random_start", [(None, 3, 6), (45, 5, 5), (90, 2, 7), (300, 1, 4), (25, 5, 3)])
+@pytest.mark.parametrize("kw", [dict(nugget=1e-6), dict(nugget=0), dict(nugget=1e-6, noise_estim=True)])
+def test_lookahead_restarts_are_the_sequential_loop_bit_for_bit(budget, wait_iter, random_start, kw):
+    """r05: `restart_lookahead` runs the NEXT restart(s) of the reference's sequential MLE loop (gpr.py:1127-1162) speculatively on further
+    engines while the current one runs.  It must be invisible: fitted parameters, likelihood, evaluation count AND the position of the global
+    np.random stream afterwards equal to the plain loop's, exactly -- also when a tight budget makes a speculative restart invalid (re-run)
+    and when the stagnation counter stops the loop with restarts in flight (cancelled, their start points un-drawn)."""
+    import bogp
+    from support.oracle_engine import OracleEngine
+
+    rng = np.random.default_rng(11)
+    d = 3
+    X = rng.uniform(-5, 5, size=(30, d))
+    y = np.sum(X**2, axis=1) + 2.0 * rng.standard_normal(30)
+    y = ((y - y.mean()) / y.std()).reshape(-1, 1)
+    out = []
+    for ahead in (0, 1, 3):
+        gp = bogp.GaussianProcess(mean=bogp.trend.constant_trend(d), corr="matern", thetaL=[1e-3] * d, thetaU=[1e2] * d, random_start=random_start,
+                                  wait_iter=wait_iter, eval_budget=budget, restart_lookahead=ahead, **kw)  # fmt: skip
+        gp._engine = OracleEngine()
+        np.random.seed(5)
+        gp.fit(X, y)
+        first = (gp.theta_.copy(), np.array(gp.sigma2, float).copy(), float(gp.log_likelihood_), int(gp.eval_count), float(np.random.uniform()))
+        gp.fit(X, y)  # a refit: warm start from the previous optimum, the stream continues
+        out.append(first + (gp.theta_.copy(), float(gp.log_likelihood_), int(gp.eval_count), float(np.random.uniform())))
+        if ahead:
+            _LOOKAHEAD_SEEN.update(k for k, v in gp.lookahead_stats.items() if v)
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_lookahead_cases_above_exercised_every_branch():
+    """(runs after the parametrised cases: speculation, a re-run under the true budget and a cancellation all occurred)"""
+    assert {"speculated", "rerun", "cancelled"} <= _LOOKAHEAD_SEEN, _LOOKAHEAD_SEEN
