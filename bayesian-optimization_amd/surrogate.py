@@ -672,35 +672,58 @@ class GaussianProcess:
                 return None
             return p_, l_, info, calls[0]
 
-        free = list(range(W))
-        inflight = {}
+        from concurrent.futures import FIRST_COMPLETED, wait
+
+        depth = max(ahead, 4)  # restarts that may be in flight or finished-and-waiting beyond the current one: an engine that finishes a short
+        #                        restart early takes the next one instead of idling behind a long restart i
+        inflight = {}  # restart index -> (future, engine index, maxfun it was given, generator state before its draw, cancel event, start point)
+        busy = [None] * W  # the future each engine is working on
         stats = dict(restarts=0, speculated=0, rerun=0, cancelled=0)  # (kept in self.lookahead_stats: tests, `verbose`)
         next_it, budget, wait_count, first, most = 0, int(eval_budget), 0, True, 0
         param_opt, llf_opt = np.array(log10param0, dtype=float), np.inf
         self.eval_count = 0
+
+        def launch_what_fits(it):
+            nonlocal next_it
+            while next_it < self.random_start and next_it <= it + depth:
+                free = [e for e in range(W) if busy[e] is None or busy[e].done()]
+                if not free:
+                    return
+                # speculate only while the budget is roomy: a restart that runs into the end of the budget it was GUESSED to have must be
+                # re-run with the real one, and near the end of the budget that is the common case (twice the largest restart so far, per
+                # restart between here and there)
+                if next_it > it and budget < 2 * max(most, 1) * (next_it - it + 1):
+                    return
+                state = np.random.get_state() if next_it != 0 else None
+                start = np.array(log10param0, dtype=float) if next_it == 0 else np.random.uniform(lo, hi)
+                e = free[0]
+                cancel = threading.Event()
+                busy[e] = pool.submit(run, engines[e], start, budget, cancel)
+                inflight[next_it] = (busy[e], e, budget, state, cancel, start)
+                stats["speculated"] += int(next_it > it)
+                next_it += 1
+
         with warnings.catch_warnings():  # (ONE context around the pool: catch_warnings is not thread-safe)
             warnings.simplefilter("ignore")
             with ThreadPoolExecutor(max_workers=W) as pool:
                 it = 0
                 while it < self.random_start:
-                    while next_it < self.random_start and next_it <= it + ahead and free:
-                        # speculate only while the budget is roomy: a restart that runs into the end of the budget it was GUESSED to have must be
-                        # re-run with the real one, and near the end of the budget that is the common case (twice the largest restart so far)
-                        if next_it > it and budget < 2 * max(most, 1) * (next_it - it + 1):
-                            break
-                        state = np.random.get_state() if next_it != 0 else None
-                        start = np.array(log10param0, dtype=float) if next_it == 0 else np.random.uniform(lo, hi)
-                        e = free.pop(0)
-                        cancel = threading.Event()
-                        inflight[next_it] = (pool.submit(run, engines[e], start, budget, cancel), e, budget, state, cancel, start)
-                        stats["speculated"] += int(next_it > it)
-                        next_it += 1
+                    launch_what_fits(it)
+                    fut = inflight[it][0]
+                    while not fut.done():  # whenever ANY restart finishes, its engine may take the next speculative one
+                        wait([f for f in busy if f is not None and not f.done()], return_when=FIRST_COMPLETED)
+                        launch_what_fits(it)
                     fut, e, spec_budget, _, _, start = inflight.pop(it)
                     p_, l_, info, calls = fut.result()
                     if spec_budget != budget and info["funcalls"] > budget:
-                        p_, l_, info, calls = run(engines[e], start, budget, None)  # it ran into a budget it did not have: the sequential call
+                        # it ran into a budget it did not have: the sequential call, on an engine that is idle NOW (its own may have moved on)
+                        idle = [k for k in range(W) if busy[k] is None or busy[k].done()]
+                        if not idle:
+                            wait([f for f in busy if f is not None], return_when=FIRST_COMPLETED)
+                            idle = [k for k in range(W) if busy[k] is None or busy[k].done()]
+                        busy[idle[0]] = pool.submit(run, engines[idle[0]], start, budget, None)
+                        p_, l_, info, calls = busy[idle[0]].result()
                         stats["rerun"] += 1
-                    free.append(e)
                     stats["restarts"] += 1
                     if first:
                         param_opt, llf_opt, first = p_, l_, False
