@@ -1493,7 +1493,8 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
   const int nblk32 = Np / 32;
   // the training set is sliced into groups of 8 x 32 rows per producer workgroup: a function of N only, so that the
   // grouping of the partial sums of mu (hence every output bit) does not depend on the chunk size
-  const int nblk_per_split = 8;
+  static const int nblk_env = [] { const char* e = getenv("BOGP_CORR_SPLIT"); return e ? std::max(2, atoi(e)) : 8; }();  // A/B switch (profiles/r05_corr_split_ab.txt)
+  const int nblk_per_split = nblk_env;
   const int S = (nblk32 + nblk_per_split - 1) / nblk_per_split;
   const int cols = contract_cols_per_group();
   const int NJ16 = Nrows / 16;
