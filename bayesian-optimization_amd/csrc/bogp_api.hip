@@ -1486,7 +1486,8 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
   if (const char* env = getenv("BOGP_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, atoi(env)) << 20;
   // trend-rows path (k_pack_Vx): the chunk carries Nt - Np extra rows (the hole up to a whole column group, then -f(x*)), the contraction
   // runs over the extended factor
-  const bool vx = h->vx_Nt > 0 && h->p >= trend_rows_min() && h->estimate_trend && need_var;
+  const bool vx_model = h->vx_Nt > 0 && h->p >= trend_rows_min() && h->estimate_trend;  // the committed model takes the trend-rows path ...
+  const bool vx = vx_model && need_var;                                                     // ... and this call needs the variance
   const int Nrows = vx ? h->vx_Nt : Np;
   int64_t Mc = (int64_t)(chunk_bytes / ((size_t)Nrows * sizeof(double)) / 64) * 64;
   Mc = std::max<int64_t>(64, std::min<int64_t>(Mc, Mpad));
@@ -1629,7 +1630,7 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
   if ((e = ensure(h, &h->dss_part, &h->ss_part_cap, (size_t)nJ * Mc))) return e;
   if (h->p > 1) {
     if (Mc > 0x7fffffff / 2) FAIL(h, BOGP_ERR_UNSUPPORTED, "chunk of %lld candidates is too large for the trend GEMM (lower BOGP_CHUNK_MB)", (long long)Mc);
-    if (!vx) {
+    if (!vx_model) {
       if ((e = ensure(h, &h->dTt, &h->Tt_cap, (size_t)Mc * ((h->p + 127) / 128 * 128)))) return e;  // whole 128-column tiles (k_mm128)
       if ((e = ensure(h, &h->dCS, &h->CS_cap, (size_t)Mc * ((h->p + 127) / 128 * 128)))) return e;
     }
@@ -1638,7 +1639,8 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
   }
   // a polynomial basis of at most 32 columns under universal kriging: T = W^T r is accumulated by the producer itself
   // (k_corr_chunk<K, PV>) and finished by ONE per-candidate launch (k_trend_small); BOGP_TREND_FUSED=0 keeps the tile products
-  const int pv = (!vx && h->p > 1 && h->estimate_trend && !(getenv("BOGP_TREND_FUSED") && atoi(getenv("BOGP_TREND_FUSED")) == 0)) ? corr_trend_columns(h->p) : 0;
+  // (a mean-only call of a trend-rows model keeps the producer the full call uses -- pv = 0 -- so that mu comes out bit-identical)
+  const int pv = (!vx_model && h->p > 1 && h->estimate_trend && !(getenv("BOGP_TREND_FUSED") && atoi(getenv("BOGP_TREND_FUSED")) == 0)) ? corr_trend_columns(h->p) : 0;
   if (pv > 0)
     for (int b = 0; b < nbuf; ++b)
       if ((e = ensure(h, &h->dtpart[b], &h->tpart_cap[b], (size_t)S * pv * Mc))) return e;
@@ -1734,7 +1736,7 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
         HIPCHK(h, launch_trend_small(h->trend, h->dXs, m0, mcount, d, Mc, h->dbetav, h->dtpart[b], S, pv, pt, h->dSinv, h->dmtrend, h->duu, st));
         aa.uu = h->duu;
       } else {
-      if (h->estimate_trend) {
+      if (h->estimate_trend && !vx_model) {
         if (tiles128)
           HIPCHK(h, launch_mm128_gen(h->drT[b], (int)Mc, h->dWpT, pp, h->dTt, (int)Mc, TI, pp / 128, Np, st));
         else
@@ -1742,7 +1744,7 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
         Tt = h->dTt;
       }
       HIPCHK(h, launch_trend_terms(h->trend, h->dXs, m0, mcount, d, Mc, h->dbetav, Tt, h->dmtrend, st));
-      if (h->estimate_trend) {
+      if (h->estimate_trend && !vx_model) {
         if (tiles128)
           HIPCHK(h, launch_mm128_gen(h->dTt, (int)Mc, h->dSinvP, pp, h->dCS, (int)Mc, TI, pp / 128, pp, st));
         else
