@@ -1995,6 +1995,12 @@ extern "C" int bogp_debug_dscal(bogp_handle* h, double* out) {
 }
 #endif
 
+#ifdef ELIM_PROFILE
+// (profiling builds only, `make EXTRA=-DELIM_PROFILE`: the wall-clock stamps the fused elimination step leaves -- tools/probes/elim_stamps.py)
+namespace bogp { hipError_t debug_elim_stamps(unsigned long long* out); }
+extern "C" int bogp_debug_elim_stamps(unsigned long long* out) { return bogp::debug_elim_stamps(out) == hipSuccess ? BOGP_OK : BOGP_ERR_HIP; }
+#endif
+
 extern "C" int bogp_selftest_gemm(bogp_handle* h, int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda,
                                   const double* B, int ldb, double beta, double* C, int ldc, int tri, int split) {
   if (!h) return BOGP_ERR_INVALID;

@@ -337,21 +337,35 @@ __device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int mask) {
 
 // ---- 4 x 4 pivot arithmetic of the in-place elimination (kernels_nllsmall.hip: k_nll_small; kernels_chol.hip: elim_diag) ----
 // sqrt(p) and 1 / sqrt(p) of a pivot 0 < p (no range scaling: pivots of a correlation matrix lie in (1e-300, 4)): the hardware's
-// reciprocal square root estimate + ONE third-order (Halley) step -- five dependent operations where sqrt() followed by a
-// division is ~45; a dependent FP64 operation costs ~26 cycles in a lone wave and this chain is on the critical path of EVERY
-// step (kernels_chol.hip: rsqrt_nr, same arithmetic)
+// reciprocal square root estimate + ONE third-order (Halley) step, y' = y + (y e)(1/2 + 3 e / 8) with e = 1 - p y^2 -- FOUR dependent
+// operations after v_rsq_f64 (t, e, {y e | 1/2 + 3 e / 8}, fma; r05: the two factors of the correction formed side by side -- the r02 form
+// y + y ((1/2 + 3 e / 8) e) had five) where sqrt() followed by a division is ~45; a dependent FP64 operation costs ~26 cycles in a lone
+// wave and this chain is on the critical path of EVERY step (kernels_chol.hip: rsqrt_nr, the r02 arithmetic, serves the opt-in chain only)
 __device__ __forceinline__ void ns_sqrt_rsqrt(double p, double& root, double& inv) {
   const double y = __builtin_amdgcn_rsq(p);
   const double t = p * y;
   const double e = __builtin_fma(-t, y, 1.0);
-  double q = __builtin_fma(0.375, e, 0.5);
-  q = q * e;
-  inv = __builtin_fma(y, q, y);
+  const double ye = y * e;
+  const double q = __builtin_fma(0.375, e, 0.5);
+  inv = __builtin_fma(ye, q, y);
   root = p * inv;
 }
 
+// acc - (a0 b0 + a1 b1 + a2 b2 + a3 b3), the rank-4 correction of one entry, as two chains of two products and a subtraction: three
+// dependent operations instead of four (the diagonal block's entry (0, 0) is the head of a step's chain)
+__device__ __forceinline__ double ns_dot4_sub(double acc, double a0, double b0, double a1, double b1, double a2, double b2, double a3, double b3) {
+  double s1 = __builtin_fma(-a0, b0, acc);
+  double s2 = a2 * b2;
+  s1 = __builtin_fma(-a1, b1, s1);
+  s2 = __builtin_fma(a3, b3, s2);
+  return s1 - s2;
+}
+
 // 4 x 4 Cholesky of the lower triangle of a: l (strict lower part) and inv[c] = 1 / l_cc -- the panel's rows are then solved by
-// substitution, o = M L^-T, column c of o as soon as pivot c is known: off the pivots' dependent chain except for one product
+// substitution, o = M L^-T, column c of o as soon as pivot c is known: off the pivots' dependent chain except for one product.
+// A pivot that is not in (0, 1e300) is reported (the first one, 1-based) and replaced by 1 as before, but the test no longer sits in
+// front of the reciprocal square root: the estimate + Halley step run on the raw pivot while the comparison is evaluated, and ONE select
+// on the result (inv = 1, l_cc = 1 for a rejected pivot -- the values the replaced pivot gave) closes the chain: a compare less per pivot.
 __device__ __forceinline__ int ns_factor4_sub(const double (&a)[4][4], double (&l)[4][4], double (&inv)[4], double& pivprod) {
   int bad = 0;
 #pragma unroll
@@ -359,12 +373,12 @@ __device__ __forceinline__ int ns_factor4_sub(const double (&a)[4][4], double (&
     double p = a[c][c];
 #pragma unroll
     for (int m = 0; m < c; ++m) p = __builtin_fma(-l[c][m], l[c][m], p);
-    if (!(p > 0.0) || !(p < 1e300)) {
-      if (!bad) bad = c + 1;
-      p = 1.0;
-    }
-    double lc;
-    ns_sqrt_rsqrt(p, lc, inv[c]);
+    const bool ok = (p > 0.0) && (p < 1e300);
+    if (!ok && !bad) bad = c + 1;
+    double lc, ic;
+    ns_sqrt_rsqrt(p, lc, ic);
+    inv[c] = ok ? ic : 1.0;
+    lc = ok ? lc : 1.0;
     l[c][c] = lc;
     pivprod *= lc;
 #pragma unroll

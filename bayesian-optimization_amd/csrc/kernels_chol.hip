@@ -305,8 +305,9 @@ __device__ __forceinline__ int diag_factor_invert(const double* cs, double* sb, 
 // 4 x 4 blocks, threads 0 .. 63 = the panel (one a ROW of a panel block: block row i = tid / 4), threads 64 .. 199 = one owner a
 // block of the lower triangle, ONE barrier a 4-column step, the panel built one step ahead on copied-out blocks.  L and W = L^-1
 // ARE the panels (L(i, kn) = P_kn[i] for i > kn; X = L^-T appears column by column: W(4 kn + c, 4 i + r) = X(i, kn)[r][c], i <= kn),
-// so an owner's work ends at step bi (no -R^-1 phase) and the panel threads store both straight to global memory: W (dense, zeros
-// above the diagonal) into its 64 x 64 column-major buffer, the lower triangle of L into the matrix at Ad (nullptr: not wanted).
+// so an owner's work ends at step bi (no -R^-1 phase) and both go straight to global memory: W (dense, zeros above the diagonal) into its
+// 64 x 64 column-major buffer -- by the last wave, out of the panel in LDS, one step behind --, the lower triangle of L into the matrix at Ad
+// by the panel threads (nullptr: not wanted).
 // ~14 us a block (16 steps of ~2100 cycles) against diag_factor_invert's 19.5.  ED_LDS doubles of LDS scratch; returns LAPACK's info (valid in thread 0),
 // *logsum (if given, thread 0) = sum(log diag L).
 constexpr int ED_PITCH = 18;
@@ -318,18 +319,26 @@ __device__ __forceinline__ void ed_tri_index(int q, int& bi, int& bj) {  // q = 
   while (bi * (bi + 1) / 2 > q) --bi;
   bj = q - bi * (bi + 1) / 2;
 }
-__device__ __forceinline__ int diag_pipe(const double* cs, double* scr, double* __restrict__ Wn, double* __restrict__ Ad, int ld, int nlive,
-                                         int tid, double* logsum) {
-  double* P = scr;                        // [2][16 * ED_PITCH], pair layout (ed_pidx)
-  double* Raw = scr + 2 * 16 * ED_PITCH;  // [2][16 * ED_PITCH], element-major
+// what no panel thread writes: zeros above the diagonal of W, the identity of the padding (W and the lower triangle of L).  Independent of the
+// factorisation: FILL = false leaves it to a caller whose other workgroups have done it (the elimination: k_elim_first fills every W_k of
+// the evaluation), so that the 16 stores a lane are off the chain of diagonal blocks
+__device__ __forceinline__ void diag_fill(double* __restrict__ Wn, double* __restrict__ Ad, int ld, int nlive, int tid) {
   const int nb = min(16, (nlive + 3) >> 2);
-  // what no panel thread writes: zeros above the diagonal of W, the identity of the padding (W and the lower triangle of L)
   for (int e = tid; e < CB * CB; e += 256) {
     const int r = e & 63, col = e >> 6;
     const bool pad = r >= 4 * nb || col >= 4 * nb;
     if (r < col || pad) Wn[col * CB + r] = r == col ? 1.0 : 0.0;
     if (Ad != nullptr && pad && r >= col) Ad[(size_t)col * ld + r] = r == col ? 1.0 : 0.0;
   }
+}
+template <bool FILL = true>
+__device__ __forceinline__ int diag_pipe(const double* cs, double* scr, double* __restrict__ Wn, double* __restrict__ Ad, int ld, int nlive,
+                                         int tid, double* logsum) {
+  double* P = scr;                        // [2][16 * ED_PITCH], pair layout (ed_pidx)
+  double* Raw = scr + 2 * 16 * ED_PITCH;  // [2][16 * ED_PITCH], element-major
+  const int nb = min(16, (nlive + 3) >> 2);
+  if (FILL) diag_fill(Wn, Ad, ld, nlive, tid);
+  gd2v* Wg = (gd2v*)Wn;  // (known to be global memory: global_store instead of flat_store)
   const int ot = tid - 64;
   int bi = 0, bj = 0;
   if (ot >= 0) ed_tri_index(ot, bi, bj);
@@ -389,12 +398,7 @@ __device__ __forceinline__ int diag_pipe(const double* cs, double* scr, double* 
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c <= r; ++c) {
-              double sacc = D[r][c];
-#pragma unroll
-              for (int m = 0; m < 4; ++m) sacc = __builtin_fma(-Q[r][m], Q[c][m], sacc);
-              D[r][c] = sacc;
-            }
+            for (int c = 0; c <= r; ++c) D[r][c] = ns_dot4_sub(D[r][c], Q[r][0], Q[c][0], Q[r][1], Q[c][1], Q[r][2], Q[c][2], Q[r][3], Q[c][3]);
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             double sacc = Mr[c];
@@ -425,7 +429,6 @@ __device__ __forceinline__ int diag_pipe(const double* cs, double* scr, double* 
           v = v * inv[c];
           T[0][c] = v;
           if (mine) pdst[ed_pidx(4 * pr + c, i)] = v;
-          if (mine && i <= kn) Wn[(4 * i + pr) * CB + 4 * kn + c] = v;  // W(4 kn + c, 4 i + pr) = X(i, kn)[pr][c]
           if (Ad != nullptr && mine && i > kn) Ad[(size_t)(4 * kn + c) * ld + 4 * i + pr] = v;  // L(4 i + pr, 4 kn + c)
           if (Ad != nullptr && mine && i == kn && c <= pr) {  // row pr of the 4 x 4 factor (selected WITHOUT a run-time register index)
             const double lv = pr == 0 ? l[0][c] : (pr == 1 ? l[1][c < 2 ? c : 1] : (pr == 2 ? l[2][c < 3 ? c : 2] : l[3][c]));
@@ -435,6 +438,20 @@ __device__ __forceinline__ int diag_pipe(const double* cs, double* scr, double* 
       }
     } else if (kn > 0) {
       const int p = kn - 1;
+      if (tid >= 192) {
+        // W(4 p + c, 4 i + pr) = X(i, p)[pr][c], i <= p, out of the panel in LDS, one step behind the panel threads and by the wave with the
+        // fewest owners: 64 lines a store instruction (W is column-major, a lane's four values are 32 contiguous bytes), which cost the
+        // panel wave -- the one every step waits for -- 1.2 us a block when it issued them itself (r05, tools/probes/run_variants.sh)
+        const int l = tid - 192, i = l >> 2, pr = l & 3;
+        if (i < nb && i <= p) {
+          const double* pp = P + (p & 1) * 16 * ED_PITCH;
+          const d2v v01 = *reinterpret_cast<const d2v*>(pp + ed_pidx(4 * pr, i));
+          const d2v v23 = *reinterpret_cast<const d2v*>(pp + ed_pidx(4 * pr + 2, i));
+          gd2v* dst = Wg + ((4 * i + pr) * CB + 4 * p) / 2;
+          dst[0] = v01;
+          dst[1] = v23;
+        }
+      }
       if (live && p < bi) {  // R phase (p < bj) or X phase (bj <= p < bi); nothing after step bi
         const double* pp = P + (p & 1) * 16 * ED_PITCH;
         double pa[4][4], pb[4][4];
@@ -1540,16 +1557,24 @@ __device__ __forceinline__ double* elim_tile(const ElimArgs& a, int bi, int bj, 
   ldt = CB;
   return a.Eb + (size_t)bj * CB * CB;
 }
-// the diagonal block of an elimination step: diag_pipe + the identity rows of block row kb in the raw panel + sum(log diag L) + info
-__device__ __forceinline__ void elim_diag2(const double* cs, double* scr, double* __restrict__ Wn, double* __restrict__ logpart,
-                                           int* __restrict__ info, int base, int reset, int nlive, double* __restrict__ Pn, int lde,
-                                           int kb, int tid) {
+// the identity rows of block row kb in a raw panel (M_kb = I: the solved block of the pivot row is W_kb^T itself)
+__device__ __forceinline__ void elim_identity_rows(double* __restrict__ Pn, int lde, int kb, int tid) {
   for (int e = tid; e < CB * CB; e += 256) {
     const int r = e & 63, col = e >> 6;
     Pn[(size_t)col * lde + (size_t)kb * CB + r] = r == col ? 1.0 : 0.0;
   }
+}
+// the diagonal block of an elimination step: diag_pipe + sum(log diag L) + info.  ALONE = true (k_elim_diag_b, the first block): also the
+// identity rows of block row kb in the raw panel; otherwise the workgroup of block (kb + 1, kb) of the same launch writes them
+// (elim_store_plain) and k_elim_first has filled the constant part of every W_k -- r05: the chain of diagonal blocks is what an
+// evaluation waits for, and these 32 stores a lane were 1.7 us of its 25 us a step (tools/probes/run_variants.sh)
+template <bool ALONE>
+__device__ __forceinline__ void elim_diag2(const double* cs, double* scr, double* __restrict__ Wn, double* __restrict__ logpart,
+                                           int* __restrict__ info, int base, int reset, int nlive, double* __restrict__ Pn, int lde,
+                                           int kb, int tid) {
+  if (ALONE) elim_identity_rows(Pn, lde, kb, tid);
   double ls = 0.0;
-  const int bad = diag_pipe(cs, scr, Wn, nullptr, 0, nlive, tid, &ls);
+  const int bad = diag_pipe<false>(cs, scr, Wn, nullptr, 0, nlive, tid, &ls);
   if (tid == 0) {
     *logpart = ls;
     if (reset) *info = bad;
@@ -1573,12 +1598,14 @@ __device__ __forceinline__ void elim_first_block(const ElimArgs& a, double* __re
       cs[r * (CB + 1) + c] = T[(size_t)c * ldt + r];
     }
     __syncthreads();
-    elim_diag2(cs, sb, W0, a.logpart, a.info, 0, 1, max(0, min(CB, a.N)), Pn, lde, 0, tid);
+    elim_diag2<true>(cs, sb, W0, a.logpart, a.info, 0, 1, max(0, min(CB, a.N)), Pn, lde, 0, tid);
   } else {
     for (int e = tid; e < CB * CB; e += 256) {
       const int r = e & 63, c = e >> 6;
       Pn[(size_t)c * lde + (size_t)bi * CB + r] = T[(size_t)c * ldt + r];
     }
+    // the constant part of W_{bi-1} (zeros above the diagonal, identity padding), for every diagonal block of this evaluation
+    diag_fill(W0 + (size_t)(bi - 1) * CB * CB, nullptr, 0, max(0, min(CB, a.N - CB * (bi - 1))), tid);
   }
 }
 __global__ __launch_bounds__(256) void k_elim_first(const ElimArgs a, double* __restrict__ W0, double* __restrict__ Pn) {
@@ -1591,6 +1618,16 @@ __global__ __launch_bounds__(256) void k_elim_first_b(const BatchSlot* __restric
   elim_first_block(sl.ea, sl.Winv, sl.panels);
 }
 
+#ifdef ELIM_PROFILE
+// (profiling builds only, `make EXTRA=-DELIM_PROFILE`: wall-clock stamps (100 MHz, common to all CUs) of the fused step's workgroups --
+// row k: [0..7] the workgroup of the next diagonal block, [8..9] entry / exit of workgroup 0, [10..11] of the last workgroup;
+// tools/probes/elim_stamps.py)
+__device__ unsigned long long g_elim_stamps[64 * 16];
+#define ESTAMP(cond_, k_, slot_)                                                                      \
+  if ((cond_) && threadIdx.x == 0) g_elim_stamps[((k_) & 63) * 16 + (slot_)] = wall_clock64();
+#else
+#define ESTAMP(cond_, k_, slot_)
+#endif
 // the updated block back into the state; the blocks of column / row k + 1 into the next raw panel; block (k + 1, k + 1) factored and
 // inverted for the next step.  Shared by the fused step (k_elim_step) and the split one (k_elim_update_b).
 __device__ __forceinline__ bool elim_store_plain(const ElimArgs& a, int k, int bi, int bj, const double (&acc)[4][4], double* __restrict__ Tb,
@@ -1612,6 +1649,7 @@ __device__ __forceinline__ bool elim_store_plain(const ElimArgs& a, int k, int b
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int t = 0; t < 4; ++t) Pnext[(size_t)(16 * mi + 4 * t + lk) * lde + i0 + 16 * w + (lane & 15)] = -acc[mi][t];
+    if (bi == kn + 1) elim_identity_rows(Pnext, lde, kn, tid);  // (for the workgroup of the diagonal block, which has the chain to carry)
   } else if (bi == kn && bj < kn) {  // row kn, transposed: raw row block bj
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -1634,10 +1672,17 @@ __device__ __forceinline__ void elim_stage_diag(const double (&acc)[4][4], doubl
 }
 __device__ __forceinline__ void elim_store_block(const ElimArgs& a, int k, int bi, int bj, double (&acc)[4][4], double* __restrict__ Tb, int ldt,
                                                  double* lds, double* sb, double* __restrict__ Pnext, double* __restrict__ Wn) {
-  if (!elim_store_plain(a, k, bi, bj, acc, Tb, ldt, Pnext)) return;
   const int kn = k + 1;
+  // the next diagonal block goes straight to its factorisation: its tile in the state is dead (step kn restarts the block from zero; only
+  // k_elim_diag_b reads it from the state, behind the super-tile update's own stores), so the 16 stores a lane are off the chain
+  if (!(kn < a.nb && bi == kn && bj == kn)) {
+    elim_store_plain(a, k, bi, bj, acc, Tb, ldt, Pnext);
+    return;
+  }
+  ESTAMP(true, k, 4)
   elim_stage_diag(acc, lds);
-  elim_diag2(lds, sb, Wn, a.logpart + kn, a.info, CB * kn, 0, max(0, min(CB, a.N - CB * kn)), Pnext, a.ld + CB, kn, threadIdx.x);
+  ESTAMP(true, k, 5)
+  elim_diag2<false>(lds, sb, Wn, a.logpart + kn, a.info, CB * kn, 0, max(0, min(CB, a.N - CB * kn)), Pnext, a.ld + CB, kn, threadIdx.x);
 }
 
 // XROW >= 0 (the group chain of a batch, k_elim_substep_b): this workgroup also leaves the solved block of block row XROW (= bi or bj) in
@@ -1653,6 +1698,12 @@ __device__ __forceinline__ void elim_step_core(const ElimArgs& a, int k, int bi,
   const int lde = a.ld + CB;
   const int i0 = CB * bi, j0 = CB * bj;
   const bool restart = bi == k || bj == k;
+  const bool dg_ = bi == k + 1 && bj == k + 1;
+  // the workgroup every other one of the NEXT step waits for: its waves issue ahead of the neighbours it shares a CU with
+  if (dg_) __builtin_amdgcn_s_setprio(3);
+  ESTAMP(dg_, k, 0)
+  ESTAMP(blockIdx.x == 0, k, 8)
+  ESTAMP(blockIdx.x == gridDim.x - 1, k, 10)
 
   stage_aside(lds, as_global(Wk), CB, tid);  // tile[kk][c] = W(c, kk)
   double bv[16], bvi[16];
@@ -1671,6 +1722,7 @@ __device__ __forceinline__ void elim_step_core(const ElimArgs& a, int k, int bi,
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[mi][t] = restart ? 0.0 : -Tb[(size_t)(16 * mi + 4 * t + lk) * ldt + 16 * w + (lane & 15)];
   __syncthreads();
+  ESTAMP(dg_, k, 1)
   mma_64(lds, bv, xj, lane);  // X_j = M_j W^T: rows 16 w .. of block row bj, element (row, col 16 mi + 4 t + lk)
   if (bi != bj) {
     mma_64(lds, bvi, xi, lane);
@@ -1709,8 +1761,13 @@ __device__ __forceinline__ void elim_step_core(const ElimArgs& a, int k, int bi,
                : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7]), "+v"(bv[8]),
                  "+v"(bv[9]), "+v"(bv[10]), "+v"(bv[11]), "+v"(bv[12]), "+v"(bv[13]), "+v"(bv[14]), "+v"(bv[15]));
   __syncthreads();
+  ESTAMP(dg_, k, 2)
   mma_64(lds, bv, acc, lane);  // -T_new = -T_old + X_i X_j^T
+  ESTAMP(dg_, k, 3)
   elim_store_block(a, k, bi, bj, acc, Tb, ldt, lds, sb, Pnext, Wn);
+  ESTAMP(dg_, k, 6)
+  ESTAMP(blockIdx.x == 0, k, 9)
+  ESTAMP(blockIdx.x == gridDim.x - 1, k, 11)
 }
 __device__ __forceinline__ void elim_step_block(const ElimArgs& a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
                                                 double* __restrict__ Pnext, double* __restrict__ Wn) {
@@ -1780,6 +1837,7 @@ __device__ __forceinline__ void elim_update_one(const BatchSlot& sl, int k, int 
   const int lk = lane >> 4;
   const size_t lde = (size_t)a.ld + CB;
   const bool restart = bi == k || bj == k;
+  if (bi == k + 1 && bj == k + 1) __builtin_amdgcn_s_setprio(3);  // (as in elim_step_core)
   const double* __restrict__ xp = sl.xpanel + (size_t)(k & 3) * ((size_t)a.nb + 1) * CB * CB;
   stage_aside(lds, as_global(xp + (size_t)bj * CB * CB), CB, tid);  // A side: tile[kk][c] = X_j(c, kk)
   double bv[16];
@@ -1866,6 +1924,7 @@ __device__ __forceinline__ void elim_group_block(const BatchSlot& sl, int k, int
   const size_t lde = (size_t)a.ld + CB;
   const size_t xsz = ((size_t)a.nb + 1) * CB * CB;
   const int klast = k + ng - 1;
+  if (bi == klast + 1 && bj == klast + 1) __builtin_amdgcn_s_setprio(3);  // (as in elim_step_core)
   // the LAST step of the group that restarts this block (its row or column index); the sub-mode launches have carried the blocks of
   // columns / rows k + 1 .. klast up to their restart, which zeroes them anyway: what such a block still needs are the steps from there on
   int first = -1;
@@ -2088,7 +2147,7 @@ __global__ __launch_bounds__(256) void k_elim_diag_b(const BatchSlot* __restrict
     cs[r * (CB + 1) + c] = T[(size_t)c * ldt + r];
   }
   __syncthreads();
-  elim_diag2(cs, sb, sl.Winv + (size_t)kn * CB * CB, a.logpart + kn, a.info, CB * kn, 0, max(0, min(CB, a.N - CB * kn)),
+  elim_diag2<true>(cs, sb, sl.Winv + (size_t)kn * CB * CB, a.logpart + kn, a.info, CB * kn, 0, max(0, min(CB, a.N - CB * kn)),
              sl.panels + ((kn & 1) ? lde * CB : 0), (int)lde, kn, tid);
 }
 
@@ -2271,4 +2330,7 @@ hipError_t launch_elim(const ElimArgs& a, const double* y, double* Winv, double*
   return hipGetLastError();
 }
 
+#ifdef ELIM_PROFILE
+hipError_t debug_elim_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_elim_stamps), sizeof(g_elim_stamps)); }
+#endif
 }  // namespace bogp

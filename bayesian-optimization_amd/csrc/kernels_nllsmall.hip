@@ -249,12 +249,7 @@ __global__ __launch_bounds__(TMAX) void k_nll_small(const NllSmallArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c <= r; ++c) {
-              double sacc = D[r][c];
-#pragma unroll
-              for (int m = 0; m < 4; ++m) sacc = __builtin_fma(-Q[r][m], Q[c][m], sacc);
-              D[r][c] = sacc;
-            }
+            for (int c = 0; c <= r; ++c) D[r][c] = ns_dot4_sub(D[r][c], Q[r][0], Q[c][0], Q[r][1], Q[c][1], Q[r][2], Q[c][2], Q[r][3], Q[c][3]);
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             double sacc = Mr[c];
