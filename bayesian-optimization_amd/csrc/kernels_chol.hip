@@ -89,6 +89,9 @@ __device__ __forceinline__ void load_bside(double (&bv)[16], const gdouble* Bs, 
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) bv[ks] = Bs[(size_t)(4 * ks + lk) * ldb + 16 * w + (lane & 15)];
 }
+// TRI = true: the staged side is a LOWER TRIANGULAR factor, tile[kk][c] = W(c, kk) = 0 for kk > c (the inverse of a diagonal block): the
+// k-steps of column tile mi stop at 4 mi + 3 -- 40 of the 64 MFMAs, and the skipped ones added exact zeros (r05).
+template <bool TRI = false>
 __device__ __forceinline__ void mma_64(const double* lds, const double (&bv)[16], double (&acc)[4][4], int lane) {
   const int aoff = (lane >> 4) * CPITCH + (lane & 15);  // MFMA-A = the LDS-staged side: lane (k, i) reads tile[k][16 mi + i]
   d4 c[4];
@@ -101,7 +104,8 @@ __device__ __forceinline__ void mma_64(const double* lds, const double (&bv)[16]
   for (int ks = 0; ks < 16; ++ks) {
     const double* trow = &lds[4 * ks * CPITCH];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) mfma16(trow[aoff + 16 * mi], bv[ks], c[mi]);
+    for (int mi = 0; mi < 4; ++mi)
+      if (!TRI || ks < 4 * (mi + 1)) mfma16(trow[aoff + 16 * mi], bv[ks], c[mi]);
   }
   // the drain names the accumulators as in/out operands so that no read of them can be scheduled above it
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
@@ -1723,9 +1727,9 @@ __device__ __forceinline__ void elim_step_core(const ElimArgs& a, int k, int bi,
     for (int t = 0; t < 4; ++t) acc[mi][t] = restart ? 0.0 : -Tb[(size_t)(16 * mi + 4 * t + lk) * ldt + 16 * w + (lane & 15)];
   __syncthreads();
   ESTAMP(dg_, k, 1)
-  mma_64(lds, bv, xj, lane);  // X_j = M_j W^T: rows 16 w .. of block row bj, element (row, col 16 mi + 4 t + lk)
+  mma_64<true>(lds, bv, xj, lane);  // X_j = M_j W^T: rows 16 w .. of block row bj, element (row, col 16 mi + 4 t + lk)
   if (bi != bj) {
-    mma_64(lds, bvi, xi, lane);
+    mma_64<true>(lds, bvi, xi, lane);
   } else {
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -1810,7 +1814,7 @@ __device__ __forceinline__ void elim_panel_row(const BatchSlot& sl, int k, int b
 #pragma unroll
     for (int t = 0; t < 4; ++t) x[mi][t] = 0.0;
   __syncthreads();
-  mma_64(lds, bv, x, lane);  // X_i = M_i W^T: rows 16 w .. of block row bi, element (row, col 16 mi + 4 t + lk)
+  mma_64<true>(lds, bv, x, lane);  // X_i = M_i W^T: rows 16 w .. of block row bi, element (row, col 16 mi + 4 t + lk)
   if (bi == a.nb && w == 0 && (lane & 15) < 2) {  // rows 0 / 1 of the solved right-hand sides: Yt, Ft of block k
     double* dst = (lane & 15) == 0 ? a.yt : a.ft;
 #pragma unroll

@@ -32,10 +32,3 @@ for N, d in ((512, 10), (1024, 20), (2048, 20)):
         print("  %2d | %5.2f %5.2f %5.2f %5.2f %5.2f %5.2f || %5.2f %5.2f | %5.2f %5.2f || %5.2f %5.2f" % (
             k, *[(r[j] - t0) / 1e3 for j in (1, 2, 3, 4, 5, 6)], (r[8] - t0) / 1e3, (r[9] - t0) / 1e3, (r[10] - t0) / 1e3, (r[11] - t0) / 1e3,
             (nxt[0] - r[6]) / 1e3 if k + 2 < nb else float("nan"), (nxt[8] - r[6]) / 1e3))
-    d = (C.c_longlong * 16)()
-    if hasattr(lib, "bogp_debug_diag_stamps") and lib.bogp_debug_diag_stamps(d) == 0:
-        v = [x / 17.0 for x in d[:]]
-        print("  diag_pipe of the last block, shader clocks per step (17 barrier steps): panel thread 0: barrier wait %.0f, read+apply %.0f, factor4 %.0f, solve+stores %.0f (sum %.0f)"
-              % (v[0], v[1], v[2], v[3], sum(v[:4])))
-        print("     owner thread 64 (block (0,0): idle after step 0): barrier %.0f update %.0f publish %.0f | owner thread 199 (last block): barrier %.0f, read+update %.0f, restart+publish %.0f"
-              % (v[4], v[5], v[6], v[8], v[9], v[10]))
