@@ -1693,9 +1693,8 @@ __device__ __forceinline__ void elim_store_block(const ElimArgs& a, int k, int b
 // `Xout` (the layout of k_elim_panel_b) and, for the right-hand sides' row, Yt / Ft of block k -- what the separate panel launch would have
 // written for that row
 __device__ __forceinline__ void elim_step_core(const ElimArgs& a, int k, int bi, int bj, const double* __restrict__ Wk, const double* __restrict__ Pcur,
-                                               double* __restrict__ Pnext, double* __restrict__ Wn, int xrow, double* __restrict__ Xout) {
-  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
-  __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
+                                               double* __restrict__ Pnext, double* __restrict__ Wn, int xrow, double* __restrict__ Xout,
+                                               double* lds, double* sb) {  // lds: CB * CPITCH doubles, sb: ED_LDS doubles of the workgroup's LDS
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lk = lane >> 4;
@@ -1776,8 +1775,10 @@ __device__ __forceinline__ void elim_step_core(const ElimArgs& a, int k, int bi,
 __device__ __forceinline__ void elim_step_block(const ElimArgs& a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
                                                 double* __restrict__ Pnext, double* __restrict__ Wn) {
   int bi, bj;
+  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
+  __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
   tri_index((int)blockIdx.x, bi, bj);  // bi <= nb (block row nb = the right-hand sides); (nb, nb) is not launched
-  elim_step_core(a, k, bi, bj, Wk, Pcur, Pnext, Wn, -1, nullptr);
+  elim_step_core(a, k, bi, bj, Wk, Pcur, Pnext, Wn, -1, nullptr, lds, sb);
 }
 __global__ __launch_bounds__(256) void k_elim_step(const ElimArgs a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
                                                    double* __restrict__ Pnext, double* __restrict__ Wn) {
@@ -1789,6 +1790,169 @@ __global__ __launch_bounds__(256) void k_elim_step_b(const BatchSlot* __restrict
   double* P0 = sl.panels;
   double* P1 = sl.panels + lde * CB;
   elim_step_block(sl.ea, k, sl.Winv + (size_t)k * CB * CB, (k & 1) ? P1 : P0, (k & 1) ? P0 : P1, sl.Winv + (size_t)(k + 1) * CB * CB);
+}
+
+// ---- the fused step on ROW PAIRS (r05: one evaluation above ~500 blocks a step, N > 1920) ------------------------------------------------
+// k_elim_step at N = 2048 is 560 workgroups on 256 CUs: two or three tenants a CU, each with three 64^3 products, and the workgroup of the
+// next diagonal block -- the one the next step waits for -- shares its CU's matrix pipe, LDS and memory queue with them: 24.7 - 29.5 us a
+// step against 19.3 at N = 1024, where every workgroup has a CU to itself (profiles/r05_elim_chain.txt).  Here a workgroup owns the two
+// blocks (r0, c), (r0 + 1, c) of a pair of block rows: the solved block of column c is formed once for both (2 or 2.5 products a block
+// instead of 3, the zero half of W skipped), every operand is requested before the first product, and the next diagonal block is left out
+// and taken by workgroup 0 ALONE on its CU through the ordinary block routine (its operands arrive in 1.4 us instead of 4 - 5).  ~290
+// workgroups at N = 2048.  Every block sees the same mma_64 calls on the same operands as in k_elim_step: the same bits.
+// (Measured first, and replaced: 2 x 2 super-tiles -- 154 workgroups of 256 threads, every product behind its own global load, 36 us a
+// step; of 512 threads in two groups, 24 us: the matrix-pipe work of a step sits on 154 of the 256 CUs.)
+// workgroup q >= 0 of the pair grid: pair BI holds the block rows r0 = 2 BI - o, r0 + 1 (o = 1 when nb is even: row 0 alone, so that the
+// last pair is (nb - 1, nb)), column c <= min(r0 + 1, nb - 1)
+__device__ __forceinline__ void elim_pair_index(int q, int o, int& BI, int& c) {
+  if (o) {
+    BI = (int)sqrt((double)q);
+    while ((BI + 1) * (BI + 1) <= q) ++BI;
+    while (BI * BI > q) --BI;
+    c = q - BI * BI;
+  } else {
+    BI = (int)((sqrt(4.0 * q + 1.0) - 1.0) * 0.5);
+    while ((BI + 1) * (BI + 2) <= q) ++BI;
+    while (BI * (BI + 1) > q) --BI;
+    c = q - BI * (BI + 1);
+  }
+}
+static int elim_pair_grid(int nb) {  // workgroups of the pair grid: sum over the pairs of min(r0 + 2, nb)
+  const int o = (nb & 1) ? 0 : 1;
+  int tot = 0;
+  for (int BI = 0; 2 * BI - o <= nb; ++BI) tot += min(2 * BI - o + 2, nb);
+  return tot;
+}
+__device__ __forceinline__ void elim_step_pair(const ElimArgs& a, int k, int q, const double* __restrict__ Wk, const double* __restrict__ Pcur,
+                                               double* __restrict__ Pnext, double* tile) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lk = lane >> 4;
+  const int lde = a.ld + CB;
+  const int o = (a.nb & 1) ? 0 : 1;
+  int BI, c;
+  elim_pair_index(q, o, BI, c);
+  const int r0 = 2 * BI - o;
+  if (c > a.nb - 1) return;  // (cannot happen inside elim_pair_grid's range)
+  // the two blocks: (r0, c) if r0 >= max(c, 0), (r0 + 1, c) if r0 + 1 <= nb -- and not the next diagonal block, which is workgroup 0's
+  bool live[2];
+  int rows[2], ldts[2];
+  double* Tbs[2];
+  double accs[2][4][4];  // negated tiles
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii) {
+    const int bi = r0 + ii;
+    rows[ii] = bi;
+    live[ii] = bi >= 0 && bi >= c && bi <= a.nb && !(bi == k + 1 && c == k + 1 && k + 1 < a.nb);
+    if (!live[ii]) rows[ii] = c;  // (a placeholder inside the arrays)
+    Tbs[ii] = elim_tile(a, rows[ii], c, ldts[ii]);
+  }
+  if (!live[0] && !live[1]) return;  // (the pair of the next diagonal block's column that holds nothing else)
+  ESTAMP(blockIdx.x == gridDim.x / 2, k, 8)
+  ESTAMP(blockIdx.x == gridDim.x - 1, k, 10)
+  // every operand requested at once: W, the raw panel blocks of column c and of both rows, both state tiles
+  stage_aside(tile, as_global(Wk), CB, tid);  // tile[kk][cc] = W(cc, kk)
+  const bool own_c = (live[0] ? rows[0] : rows[1]) != c;  // no row of the pair is block row c: X_c takes a product of its own
+  double bvc[16], bvr[2][16];
+  if (own_c) load_bside(bvc, as_global(Pcur + CB * c), lde, w, lane);
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+    if (live[ii]) load_bside(bvr[ii], as_global(Pcur + CB * rows[ii]), lde, w, lane);
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii) {
+    const bool fetch = live[ii] && !(rows[ii] == k || c == k);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) accs[ii][mi][t] = fetch ? -Tbs[ii][(size_t)(16 * mi + 4 * t + lk) * ldts[ii] + 16 * w + (lane & 15)] : 0.0;
+  }
+  double xc[4][4], xr[2][4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xc[mi][t] = xr[0][mi][t] = xr[1][mi][t] = 0.0;
+  __syncthreads();
+  ESTAMP(blockIdx.x == gridDim.x / 2, k, 12)
+  if (own_c) mma_64<true>(tile, bvc, xc, lane);  // X_c = M_c W^T
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+    if (live[ii]) mma_64<true>(tile, bvr[ii], xr[ii], lane);  // X of block row rows[ii]
+  if (!own_c) {  // block row c is the first live row of the pair
+    const int ic = live[0] ? 0 : 1;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xc[mi][t] = ic ? xr[1][mi][t] : xr[0][mi][t];
+  }
+  // rows 0 / 1 of the solved right-hand sides: Yt, Ft of block k -- by the workgroup that holds block (nb, k)
+  if (c == k && w == 0 && (lane & 15) < 2) {
+    double* dst = (lane & 15) == 0 ? a.yt : a.ft;
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+      if (live[ii] && rows[ii] == a.nb) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dst[CB * k + 16 * mi + 4 * t + lk] = xr[ii][mi][t];
+      }
+  }
+  __syncthreads();  // every wave is done with the W tile
+  ESTAMP(blockIdx.x == gridDim.x / 2, k, 13)
+  // A side of both updates: tile[kk][cc] = X_c(cc, kk)
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) tile[(16 * mi + 4 * t + lk) * CPITCH + 16 * w + (lane & 15)] = xc[mi][t];
+  __syncthreads();
+  ESTAMP(blockIdx.x == gridDim.x / 2, k, 14)
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii) {
+    if (!live[ii]) continue;
+    // B side: X_i(row 16 w + (lane & 15), kk = 4 ks + lk) is exactly xr[ks / 4][ks % 4] of this lane
+    double bv[16];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bv[4 * mi + t] = xr[ii][mi][t];
+    asm volatile("s_nop 7\n\ts_nop 7"
+                 : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7]), "+v"(bv[8]),
+                   "+v"(bv[9]), "+v"(bv[10]), "+v"(bv[11]), "+v"(bv[12]), "+v"(bv[13]), "+v"(bv[14]), "+v"(bv[15]));
+    mma_64(tile, bv, accs[ii], lane);  // -T_new = -T_old + X_i X_c^T
+    ESTAMP(blockIdx.x == gridDim.x / 2 && ii == 1, k, 15)
+    elim_store_plain(a, k, rows[ii], c, accs[ii], Tbs[ii], ldts[ii], Pnext);
+  }
+  ESTAMP(blockIdx.x == gridDim.x / 2, k, 9)
+  ESTAMP(blockIdx.x == gridDim.x - 1, k, 11)
+}
+__device__ __forceinline__ void elim_step_pair_wg(const ElimArgs& a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
+                                                  double* __restrict__ Pnext, double* __restrict__ Wn) {
+  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
+  __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
+  if (blockIdx.x == 0) {  // the chain: the next diagonal block through the ordinary block routine
+    if (k + 1 < a.nb) elim_step_core(a, k, k + 1, k + 1, Wk, Pcur, Pnext, Wn, -1, nullptr, lds, sb);
+    return;
+  }
+  elim_step_pair(a, k, (int)blockIdx.x - 1, Wk, Pcur, Pnext, lds);
+}
+__global__ __launch_bounds__(256) void k_elim_stepS(const ElimArgs a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
+                                                    double* __restrict__ Pnext, double* __restrict__ Wn) {
+  elim_step_pair_wg(a, k, Wk, Pcur, Pnext, Wn);
+}
+__global__ __launch_bounds__(256) void k_elim_stepS_b(const BatchSlot* __restrict__ slots, int k) {
+  const BatchSlot& sl = slots[blockIdx.y];
+  const size_t lde = (size_t)sl.ea.ld + CB;
+  double* P0 = sl.panels;
+  double* P1 = sl.panels + lde * CB;
+  elim_step_pair_wg(sl.ea, k, sl.Winv + (size_t)k * CB * CB, (k & 1) ? P1 : P0, (k & 1) ? P0 : P1, sl.Winv + (size_t)(k + 1) * CB * CB);
+}
+// one evaluation's fused steps on row pairs when a step has BOGP_ELIM_STEP_PAIR_MIN .. BOGP_ELIM_STEP_PAIR_MAX 64 x 64 blocks (defaults 300 .. 500:
+// nb = 23 .. 30, N = 1409 .. 1920; MIN = 0: never).  Below, every block has a CU of its own anyway (no gain measured at nb = 23); above -- nb = 31, 32:
+// 272 / 289 pair workgroups -- some CUs hold two of them, the diagonal block's among them, and a step costs 31 / 34 us where the block grid costs
+// 29.7 / 30.3 and the pair grid 23.6 at nb = 30 (profiles/r05_elim_chain.txt)
+static bool elim_step_pairs(int grid) {
+  static const int lo = [] { const char* e = getenv("BOGP_ELIM_STEP_PAIR_MIN"); return e ? atoi(e) : 300; }();
+  static const int hi = [] { const char* e = getenv("BOGP_ELIM_STEP_PAIR_MAX"); return e ? atoi(e) : 500; }();
+  return lo > 0 && grid >= lo && grid <= hi;
 }
 
 // ---- the step split in two launches (batches whose blocks outnumber the workgroup slots) --------------------------------------------
@@ -1902,8 +2066,10 @@ __global__ __launch_bounds__(256) void k_elim_substep_b(const BatchSlot* __restr
   double* P0 = sl.panels;
   double* P1 = sl.panels + lde * CB;
   double* Xout = sl.xpanel + (size_t)(k & 3) * ((size_t)a.nb + 1) * CB * CB + (size_t)t * CB * CB;
+  __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
+  __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
   elim_step_core(a, k, t <= c ? c : t, t <= c ? t : c, sl.Winv + (size_t)k * CB * CB, (k & 1) ? P1 : P0, (k & 1) ? P0 : P1,
-                 sl.Winv + (size_t)(k + 1) * CB * CB, ci == 0 ? t : -1, Xout);
+                 sl.Winv + (size_t)(k + 1) * CB * CB, ci == 0 ? t : -1, Xout, lds, sb);
 }
 
 // ---- GROUPED steps: two or four block columns per pass over the state (r04) ----------------------------------------------------------
@@ -2312,7 +2478,10 @@ hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double
       if (xcd_local) hipLaunchKernelGGL(k_elim_update_b, dim3((unsigned)(8 * (((long)grid * P + 7) / 8))), 256, 0, st, slots, k, 1, grid, P);
       else hipLaunchKernelGGL(k_elim_update_b, dim3(grid, P), 256, 0, st, slots, k, 0, grid, P);
     } else {
-      hipLaunchKernelGGL(k_elim_step_b, dim3(grid, P), 256, 0, st, slots, k);
+      if (P == 1 && elim_step_pairs(grid))
+        hipLaunchKernelGGL(k_elim_stepS_b, dim3(elim_pair_grid(nb) + 1, P), 256, 0, st, slots, k);
+      else
+        hipLaunchKernelGGL(k_elim_step_b, dim3(grid, P), 256, 0, st, slots, k);
     }
   }
   hipLaunchKernelGGL(k_elim_finish_b, dim3(nb * (nb + 1) / 2 + 1, P), 256, 0, st, slots, estimate_trend, mode, beta);
@@ -2326,9 +2495,15 @@ hipError_t launch_elim(const ElimArgs& a, const double* y, double* Winv, double*
   hipLaunchKernelGGL(k_elim_init, dim3(a.ld), 64, 0, st, a, y);
   hipLaunchKernelGGL(k_elim_first, dim3(nb + 1), 256, 0, st, a, Winv, P[0]);
   const int grid = (nb + 1) * (nb + 2) / 2 - 1;
-  for (int k = 0; k < nb; ++k)
-    hipLaunchKernelGGL(k_elim_step, dim3(grid), 256, 0, st, a, k, Winv + (size_t)k * CB * CB, P[k & 1], P[(k + 1) & 1],
-                       Winv + (size_t)(k + 1) * CB * CB);
+  const bool super_step = elim_step_pairs(grid);
+  for (int k = 0; k < nb; ++k) {
+    if (super_step)
+      hipLaunchKernelGGL(k_elim_stepS, dim3(elim_pair_grid(nb) + 1), 256, 0, st, a, k, Winv + (size_t)k * CB * CB, P[k & 1], P[(k + 1) & 1],
+                         Winv + (size_t)(k + 1) * CB * CB);
+    else
+      hipLaunchKernelGGL(k_elim_step, dim3(grid), 256, 0, st, a, k, Winv + (size_t)k * CB * CB, P[k & 1], P[(k + 1) & 1],
+                         Winv + (size_t)(k + 1) * CB * CB);
+  }
   hipLaunchKernelGGL(k_elim_finish, dim3(nb * (nb + 1) / 2 + 1), 256, 0, st, a, Rinv, ldr, gamma, scal, coefw, estimate_trend, mode, beta,
                      s2t_host);
   return hipGetLastError();

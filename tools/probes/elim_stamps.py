@@ -12,7 +12,7 @@ from bogp import _lib
 
 lib = _lib.load()
 eng = _lib.Engine(0)
-for N, d in ((512, 10), (1024, 20), (2048, 20)):
+for N, d in [(int(a), 20) for a in sys.argv[1:]] or ((512, 10), (1024, 20), (2048, 20)):
     rng = np.random.default_rng(0)
     X = rng.uniform(-5, 5, size=(N, d)); y = np.sum(X**2, axis=1); y = ((y - y.mean()) / y.std() + 0.05 * rng.standard_normal(N)).reshape(-1, 1)
     par = np.r_[np.full(d, 0.2 / d), 0.9]
@@ -32,3 +32,8 @@ for N, d in ((512, 10), (1024, 20), (2048, 20)):
         print("  %2d | %5.2f %5.2f %5.2f %5.2f %5.2f %5.2f || %5.2f %5.2f | %5.2f %5.2f || %5.2f %5.2f" % (
             k, *[(r[j] - t0) / 1e3 for j in (1, 2, 3, 4, 5, 6)], (r[8] - t0) / 1e3, (r[9] - t0) / 1e3, (r[10] - t0) / 1e3, (r[11] - t0) / 1e3,
             (nxt[0] - r[6]) / 1e3 if k + 2 < nb else float("nan"), (nxt[8] - r[6]) / 1e3))
+    if N > 1900:
+        print("  row-pair workgroup gridDim/2 (us from its entry): operands in | panel products done | tiles written | second update done | out")
+        for k in range(0, nb - 1, 5):
+            r = s[k]
+            print("  %2d | %5.2f %5.2f %5.2f %5.2f %5.2f   (entry %.2f us after the diagonal workgroup's)" % (k, *[(r[j] - r[8]) / 1e3 for j in (12, 13, 14, 15, 9)], (r[8] - r[0]) / 1e3))
