@@ -1777,7 +1777,19 @@ __device__ __forceinline__ void elim_step_block(const ElimArgs& a, int k, const 
   int bi, bj;
   __shared__ __attribute__((aligned(16))) double lds[CB * CPITCH];
   __shared__ __attribute__((aligned(16))) double sb[ED_LDS];
-  tri_index((int)blockIdx.x, bi, bj);  // bi <= nb (block row nb = the right-hand sides); (nb, nb) is not launched
+  int b = (int)blockIdx.x;
+  const int nblk = (a.nb + 1) * (a.nb + 2) / 2 - 1;
+  if ((int)gridDim.x > nblk) {
+    // launch_elim's layout for one evaluation above 256 blocks a step (gridDim.x = blocks + 2): the workgroup of the next diagonal block is
+    // dispatched FIRST and the two workgroups the dispatcher would put on its CU after it (it fills the CUs round by round: 256 and 512 land where
+    // 0 did) do nothing -- the diagonal block has its CU to itself (r05: operands in 1.4 - 2.8 us instead of 4 - 5, factorisation 12 us instead of 14 - 17)
+    const int D = (k + 1) * (k + 2) / 2 + k + 1;  // its place in the triangular order (>= nblk in the last step: no such block)
+    if (b == 256 || b == 512) return;
+    b -= (b > 256) + (b > 512);                   // 0 .. nblk - 1
+    if (b >= nblk) return;                        // (a grid below 513 holds one idle workgroup only)
+    if (D < nblk) b = b == 0 ? D : (b <= D ? b - 1 : b);
+  }
+  tri_index(b, bi, bj);  // bi <= nb (block row nb = the right-hand sides); (nb, nb) is not launched
   elim_step_core(a, k, bi, bj, Wk, Pcur, Pnext, Wn, -1, nullptr, lds, sb);
 }
 __global__ __launch_bounds__(256) void k_elim_step(const ElimArgs a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
@@ -2501,8 +2513,8 @@ hipError_t launch_elim(const ElimArgs& a, const double* y, double* Winv, double*
       hipLaunchKernelGGL(k_elim_stepS, dim3(elim_pair_grid(nb) + 1), 256, 0, st, a, k, Winv + (size_t)k * CB * CB, P[k & 1], P[(k + 1) & 1],
                          Winv + (size_t)(k + 1) * CB * CB);
     else
-      hipLaunchKernelGGL(k_elim_step, dim3(grid), 256, 0, st, a, k, Winv + (size_t)k * CB * CB, P[k & 1], P[(k + 1) & 1],
-                         Winv + (size_t)(k + 1) * CB * CB);
+      hipLaunchKernelGGL(k_elim_step, dim3(grid > 256 ? grid + 2 : grid), 256, 0, st, a, k, Winv + (size_t)k * CB * CB, P[k & 1], P[(k + 1) & 1],
+                         Winv + (size_t)(k + 1) * CB * CB);  // (+ 2: the diagonal block's CU kept free, elim_step_block)
   }
   hipLaunchKernelGGL(k_elim_finish, dim3(nb * (nb + 1) / 2 + 1), 256, 0, st, a, Rinv, ldr, gamma, scal, coefw, estimate_trend, mode, beta,
                      s2t_host);
