@@ -1780,7 +1780,7 @@ __device__ __forceinline__ void elim_step_block(const ElimArgs& a, int k, const 
   int b = (int)blockIdx.x;
   const int nblk = (a.nb + 1) * (a.nb + 2) / 2 - 1;
   if ((int)gridDim.x > nblk) {
-    // launch_elim's layout for one evaluation above 256 blocks a step (gridDim.x = blocks + 2): the workgroup of the next diagonal block is
+    // launch_elim's layout for one evaluation above 512 blocks a step -- 31 / 32 block rows (gridDim.x = blocks + 2; at 299 blocks it LOSES: 592 -> 620 us): the workgroup of the next diagonal block is
     // dispatched FIRST and the two workgroups the dispatcher would put on its CU after it (it fills the CUs round by round: 256 and 512 land where
     // 0 did) do nothing -- the diagonal block has its CU to itself (r05: operands in 1.4 - 2.8 us instead of 4 - 5, factorisation 12 us instead of 14 - 17)
     const int D = (k + 1) * (k + 2) / 2 + k + 1;  // its place in the triangular order (>= nblk in the last step: no such block)
@@ -1828,6 +1828,11 @@ __device__ __forceinline__ void elim_pair_index(int q, int o, int& BI, int& c) {
     while (BI * (BI + 1) > q) --BI;
     c = q - BI * (BI + 1);
   }
+}
+__device__ __forceinline__ int elim_pair_grid_dev(int nb) {  // = elim_pair_grid(nb) in closed form
+  const int o = (nb & 1) ? 0 : 1;
+  const int last = (nb + o) / 2;  // the last pair: (nb - 1, nb)
+  return (o ? last * last : last * (last + 1)) + nb;
 }
 static int elim_pair_grid(int nb) {  // workgroups of the pair grid: sum over the pairs of min(r0 + 2, nb)
   const int o = (nb & 1) ? 0 : 1;
@@ -1944,7 +1949,10 @@ __device__ __forceinline__ void elim_step_pair_wg(const ElimArgs& a, int k, cons
     if (k + 1 < a.nb) elim_step_core(a, k, k + 1, k + 1, Wk, Pcur, Pnext, Wn, -1, nullptr, lds, sb);
     return;
   }
-  elim_step_pair(a, k, (int)blockIdx.x - 1, Wk, Pcur, Pnext, lds);
+  if (blockIdx.x == 256) return;  // (the workgroup that would land on the diagonal block's CU: idle, as in elim_step_block)
+  const int q = (int)blockIdx.x - 1 - (blockIdx.x > 256);
+  if (q >= elim_pair_grid_dev(a.nb)) return;
+  elim_step_pair(a, k, q, Wk, Pcur, Pnext, lds);
 }
 __global__ __launch_bounds__(256) void k_elim_stepS(const ElimArgs a, int k, const double* __restrict__ Wk, const double* __restrict__ Pcur,
                                                     double* __restrict__ Pnext, double* __restrict__ Wn) {
@@ -2491,7 +2499,7 @@ hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double
       else hipLaunchKernelGGL(k_elim_update_b, dim3(grid, P), 256, 0, st, slots, k, 0, grid, P);
     } else {
       if (P == 1 && elim_step_pairs(grid))
-        hipLaunchKernelGGL(k_elim_stepS_b, dim3(elim_pair_grid(nb) + 1, P), 256, 0, st, slots, k);
+        hipLaunchKernelGGL(k_elim_stepS_b, dim3(elim_pair_grid(nb) + 2, P), 256, 0, st, slots, k);
       else
         hipLaunchKernelGGL(k_elim_step_b, dim3(grid, P), 256, 0, st, slots, k);
     }
@@ -2510,10 +2518,10 @@ hipError_t launch_elim(const ElimArgs& a, const double* y, double* Winv, double*
   const bool super_step = elim_step_pairs(grid);
   for (int k = 0; k < nb; ++k) {
     if (super_step)
-      hipLaunchKernelGGL(k_elim_stepS, dim3(elim_pair_grid(nb) + 1), 256, 0, st, a, k, Winv + (size_t)k * CB * CB, P[k & 1], P[(k + 1) & 1],
+      hipLaunchKernelGGL(k_elim_stepS, dim3(elim_pair_grid(nb) + 2), 256, 0, st, a, k, Winv + (size_t)k * CB * CB, P[k & 1], P[(k + 1) & 1],
                          Winv + (size_t)(k + 1) * CB * CB);
     else
-      hipLaunchKernelGGL(k_elim_step, dim3(grid > 256 ? grid + 2 : grid), 256, 0, st, a, k, Winv + (size_t)k * CB * CB, P[k & 1], P[(k + 1) & 1],
+      hipLaunchKernelGGL(k_elim_step, dim3(grid > 512 ? grid + 2 : grid), 256, 0, st, a, k, Winv + (size_t)k * CB * CB, P[k & 1], P[(k + 1) & 1],
                          Winv + (size_t)(k + 1) * CB * CB);  // (+ 2: the diagonal block's CU kept free, elim_step_block)
   }
   hipLaunchKernelGGL(k_elim_finish, dim3(nb * (nb + 1) / 2 + 1), 256, 0, st, a, Rinv, ldr, gamma, scal, coefw, estimate_trend, mode, beta,
