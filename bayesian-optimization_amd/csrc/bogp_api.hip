@@ -428,10 +428,11 @@ extern "C" int bogp_nll_path(int N, int d, int trend, int n_targets) {
   if (N <= 0 || d <= 0 || trend != BOGP_TREND_CONSTANT || n_targets != 1) return BOGP_NLL_PATH_GENERAL;
   if (getenv("BOGP_NLL_FUSED") && atoi(getenv("BOGP_NLL_FUSED")) == 0) return BOGP_NLL_PATH_GENERAL;
   if (nll_small_fits(N, d)) return BOGP_NLL_PATH_ONE_LAUNCH;
-  // 157 <= N <= 2048 (BOGP_NLL_ELIM_MAX; slower than the kernels it replaces from ~3000 on): factor + inverse + solves as one
+  // 157 <= N <= 3072 (BOGP_NLL_ELIM_MAX; r05: 2048 -> 3072 after the step lost a third of its time -- llf + gradient 1.73 -> 0.95 ms at N = 2112,
+  // 2.78 -> 2.28 at 3072, a slot of a batch of ten 1.61 -> 0.93 ms; it loses from ~3500 on: profiles/r05_elim_chain.txt): factor + inverse + solves as one
   // elimination at 64-block granularity (kernels_chol.hip: k_elim_step), one launch a block column; BOGP_NLL_ELIM=0 keeps the
   // Cholesky / recursive-doubling / U U^T kernels
-  static const int elim_max = [] { const char* e_ = getenv("BOGP_NLL_ELIM_MAX"); return e_ ? atoi(e_) : 2048; }();
+  static const int elim_max = [] { const char* e_ = getenv("BOGP_NLL_ELIM_MAX"); return e_ ? atoi(e_) : 3072; }();
   const int ld = ((N + 63) / 64) * 64;
   if (N <= elim_max && N <= 6080 && ld >= 192 && !(getenv("BOGP_NLL_ELIM") && atoi(getenv("BOGP_NLL_ELIM")) == 0)) return BOGP_NLL_PATH_ELIM;
   return BOGP_NLL_PATH_GENERAL;
@@ -442,7 +443,7 @@ extern "C" int bogp_nll_path(int N, int d, int trend, int n_targets) {
 struct FusedNll {
   bool want_grad = false;
   bool done = false;
-  bool mid = false;  // 157 <= N <= 2048: k_build_R + k_elim_* left R^-1, gamma, the scalars and the gradient weights; the caller's tail follows
+  bool mid = false;  // 157 <= N <= 3072: k_build_R + k_elim_* left R^-1, gamma, the scalars and the gradient weights; the caller's tail follows
   double S[64 + 3];
 };
 static int factorize(bogp_handle* h, int kernel, int mode, const double* par, int n_par, double noise_var, int trend,
@@ -485,7 +486,7 @@ static int factorize(bogp_handle* h, int kernel, int mode, const double* par, in
   hipStream_t st = h->stream;
   HIPCHK(h, hipSetDevice(h->device));
   const int path = fz ? bogp_nll_path(N, d, trend, h->n_t) : BOGP_NLL_PATH_GENERAL;
-  // 157 <= N <= 2048 (BOGP_NLL_ELIM_MAX; slower than the kernels it replaces from ~3000 on): factor + inverse + solves as one elimination at 64-block granularity (kernels_chol.hip: k_elim_step), one
+  // 157 <= N <= 3072 (BOGP_NLL_ELIM_MAX; slower than the kernels it replaces from ~3500 on): factor + inverse + solves as one elimination at 64-block granularity (kernels_chol.hip: k_elim_step), one
   // launch a block column; BOGP_NLL_ELIM=0 keeps the Cholesky / recursive-doubling / U U^T kernels
   const bool elim = path == BOGP_NLL_PATH_ELIM && (!fz->want_grad || pend);
   const bool mid = elim;

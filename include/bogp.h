@@ -121,7 +121,7 @@ int bogp_nll(bogp_handle* h, int kernel, int mode, const double* par, int n_par,
  *         and grad row s zero for a failed slot
  * Slot s returns exactly the bits the s-th of P sequential bogp_nll calls returns.  The return value is BOGP_OK when the batch ran
  * (whatever the slots' outcomes) and an error code for what stops a bogp_nll call before the device (bad ids, no training set, HIP).
- * N <= 156: one launch, one workgroup a slot; N <= 2048: the elimination kernels over P workspaces (2 ld^2 doubles a slot, groups
+ * N <= 156: one launch, one workgroup a slot; N <= 3072: the elimination kernels over P workspaces (2 ld^2 doubles a slot, groups
  * bounded by BOGP_BATCH_MAX_MB, default 8192); above, and for polynomial trends / several targets: the P sequential calls,
  * dealt over up to three handles of the library's own (the caller's + helpers with their own stream and factor buffers, one host
  * thread each; two above N = 4096; BOGP_NLL_WORKERS) so that independent evaluations interleave on the device -- C5: 15.4 -> 13.4 ms
@@ -392,7 +392,7 @@ int bogp_lbfgsb_minimize(int n, int m, double* x, const double* lo, const double
  * switches alone; gpr.py:920-1040 is the function all three evaluate):
  *   BOGP_NLL_PATH_GENERAL   the multi-kernel path (blocked Cholesky, recursive-doubling inverse, U U^T, ...)
  *   BOGP_NLL_PATH_ONE_LAUNCH  the whole evaluation in one launch of one workgroup (k_nll_small; N <= 156 if it fits one CU's LDS)
- *   BOGP_NLL_PATH_ELIM      one launch per 64 columns (k_elim_step; up to N = 2048)
+ *   BOGP_NLL_PATH_ELIM      one launch per 64 columns (k_elim_step; up to N = 3072)
  * DESIGN.md section 5.12; used by tests/test_abi.py.                                                                         */
 #define BOGP_NLL_PATH_GENERAL 0
 #define BOGP_NLL_PATH_ONE_LAUNCH 1
