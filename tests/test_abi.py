@@ -54,14 +54,14 @@ def test_abi_version_and_constants_match_header():
 def test_likelihood_path_by_size():
     """bogp_nll_path: which device path a likelihood evaluation takes is decided from the sizes alone (no handle, no device call):
     one launch of one workgroup up to N = 156 while X and the block image fit one CU's LDS, one launch per 64 columns up to
-    N = 2048, the multi-kernel path above, for polynomial bases and for several targets."""
+    N = 3072 (2048 until the end of r05), the multi-kernel path above, for polynomial bases and for several targets."""
     lib = _lib.load()
     consts = dict(re.findall(r"#define\s+(BOGP_[A-Z_0-9]+)\s+\(?(-?\d+)\)?", open(HEADER).read()))
     general, one, elim = (int(consts["BOGP_NLL_PATH_" + k]) for k in ("GENERAL", "ONE_LAUNCH", "ELIM"))
     p = lib.bogp_nll_path
     assert [p(n, 10, 0, 1) for n in (1, 16, 128, 129, 156)] == [one] * 5
-    assert [p(n, 10, 0, 1) for n in (157, 192, 256, 1024, 2048)] == [elim] * 5
-    assert p(2049, 10, 0, 1) == general and p(8192, 50, 0, 1) == general
+    assert [p(n, 10, 0, 1) for n in (157, 192, 256, 1024, 2048, 2049, 3072)] == [elim] * 7
+    assert p(3073, 10, 0, 1) == general and p(8192, 50, 0, 1) == general
     assert p(100, 64, 0, 1) == one and p(100, 65, 0, 1) == general      # theta travels as a kernel argument: d <= 64; ld = 128 < 192
     assert p(150, 40, 0, 1) == elim                                       # X + the block image exceed 160 KB of LDS: next path
     assert p(100, 5, 1, 1) == general and p(100, 5, 2, 1) == general      # linear / quadratic basis
