@@ -44,8 +44,9 @@ GRAD_KERNELS = [_lib.KERNEL_SE, _lib.KERNEL_MATERN12, _lib.KERNEL_MATERN32, _lib
 SIZES = [1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128,   # one launch (k_nll_small, 768 threads)
          129, 131, 144, 145, 153, 156,                                            # one launch (k_nll_small, 1024 threads)
          157, 177, 192, 193, 200, 240, 249, 252,                                  # k_build_R + k_elim_* + the gradient kernels
-         253, 256, 257, 320, 511, 512, 700, 1024, 1500, 2048,
-         2049]                                                                    # the general path itself
+         253, 256, 257, 320, 511, 512, 700, 1024, 1500, 1984, 2048,               # (1500: row-pair steps; 1984, 2048: the diagonal block's CU kept free)
+         2049, 2500, 3072,                                                         # the elimination's far end (N <= 3072 since the end of r05)
+         3073]                                                                    # the general path itself
 
 
 def par_of(mode, d, iso, rng):
