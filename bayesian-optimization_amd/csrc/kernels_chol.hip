@@ -1804,7 +1804,7 @@ __global__ __launch_bounds__(256) void k_elim_step_b(const BatchSlot* __restrict
   elim_step_block(sl.ea, k, sl.Winv + (size_t)k * CB * CB, (k & 1) ? P1 : P0, (k & 1) ? P0 : P1, sl.Winv + (size_t)(k + 1) * CB * CB);
 }
 
-// ---- the fused step on ROW PAIRS (r05: one evaluation above ~500 blocks a step, N > 1920) ------------------------------------------------
+// ---- the fused step on ROW PAIRS (r05: one evaluation with 14 .. 30 block rows, N = 833 .. 1920) ------------------------------------------------
 // k_elim_step at N = 2048 is 560 workgroups on 256 CUs: two or three tenants a CU, each with three 64^3 products, and the workgroup of the
 // next diagonal block -- the one the next step waits for -- shares its CU's matrix pipe, LDS and memory queue with them: 24.7 - 29.5 us a
 // step against 19.3 at N = 1024, where every workgroup has a CU to itself (profiles/r05_elim_chain.txt).  Here a workgroup owns the two
@@ -1965,12 +1965,13 @@ __global__ __launch_bounds__(256) void k_elim_stepS_b(const BatchSlot* __restric
   double* P1 = sl.panels + lde * CB;
   elim_step_pair_wg(sl.ea, k, sl.Winv + (size_t)k * CB * CB, (k & 1) ? P1 : P0, (k & 1) ? P0 : P1, sl.Winv + (size_t)(k + 1) * CB * CB);
 }
-// one evaluation's fused steps on row pairs when a step has BOGP_ELIM_STEP_PAIR_MIN .. BOGP_ELIM_STEP_PAIR_MAX 64 x 64 blocks (defaults 300 .. 500:
-// nb = 23 .. 30, N = 1409 .. 1920; MIN = 0: never).  Below, every block has a CU of its own anyway (no gain measured at nb = 23); above -- nb = 31, 32:
-// 272 / 289 pair workgroups -- some CUs hold two of them, the diagonal block's among them, and a step costs 31 / 34 us where the block grid costs
-// 29.7 / 30.3 and the pair grid 23.6 at nb = 30 (profiles/r05_elim_chain.txt)
+// one evaluation's fused steps on row pairs when a step has BOGP_ELIM_STEP_PAIR_MIN .. BOGP_ELIM_STEP_PAIR_MAX 64 x 64 blocks (defaults 110 .. 500:
+// nb = 14 .. 30, N = 833 .. 1920; MIN = 0: never).  Measured per step, blocks / pairs (us; tools/probes/time_elim_pairmin.py, time_elim_ld.py): nb = 3 34.4 / 37.1,
+// 8: 25.9 / 26.8, 10 - 12: equal, 14: 24.3 / 23.9, 16: 23.9 / 23.5, 20: 24.1 / 23.4, 22: 25.0 / 23.4, 23: 25.8 / 23.4, 24 - 30: 26.1 - 28.6 / 23.3 - 23.6.
+// Above -- nb = 31, 32: 272 / 289 pair workgroups -- some CUs hold two of them, the diagonal block's among them, and a step costs 31 / 34 us where the block
+// grid costs 29.7 / 30.3 (27.3 with the diagonal block's CU kept free) and the pair grid 23.6 at nb = 30 (profiles/r05_elim_chain.txt)
 static bool elim_step_pairs(int grid) {
-  static const int lo = [] { const char* e = getenv("BOGP_ELIM_STEP_PAIR_MIN"); return e ? atoi(e) : 300; }();
+  static const int lo = [] { const char* e = getenv("BOGP_ELIM_STEP_PAIR_MIN"); return e ? atoi(e) : 110; }();
   static const int hi = [] { const char* e = getenv("BOGP_ELIM_STEP_PAIR_MAX"); return e ? atoi(e) : 500; }();
   return lo > 0 && grid >= lo && grid <= hi;
 }

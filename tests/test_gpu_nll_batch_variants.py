@@ -40,9 +40,9 @@ def test_launch_plan_gives_the_sequential_bits(name):
     assert r.returncode == 0, "%s: %s\n%s" % (name, r.stdout[-3000:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("N", [1409, 1472, 1600, 1900, 1920])
+@pytest.mark.parametrize("N", [833, 900, 1100, 1409, 1472, 1600, 1900, 1920])
 def test_row_pair_steps_at_their_default_sizes(N):
-    """N = 1409 .. 1920 (23 .. 30 block rows): bogp_nll runs its elimination steps on row pairs by default, a batch of three on the block
+    """N = 833 .. 1920 (14 .. 30 block rows): bogp_nll runs its elimination steps on row pairs by default, a batch of three on the block
     kernels (grouped steps): slot s of the batch = the bits of the sequential call, value and gradient -- and the oracle's value."""
     import numpy as np
 
