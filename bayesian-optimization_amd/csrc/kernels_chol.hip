@@ -2502,7 +2502,7 @@ hipError_t launch_elim_batch(const BatchSlot* slots, int P, int ld, const double
       if (P == 1 && elim_step_pairs(grid))
         hipLaunchKernelGGL(k_elim_stepS_b, dim3(elim_pair_grid(nb) + 2, P), 256, 0, st, slots, k);
       else
-        hipLaunchKernelGGL(k_elim_step_b, dim3(grid, P), 256, 0, st, slots, k);
+        hipLaunchKernelGGL(k_elim_step_b, dim3(P == 1 && grid > 512 ? grid + 2 : grid, P), 256, 0, st, slots, k);  // (+ 2: launch_elim's free-CU layout, elim_step_block)
     }
   }
   hipLaunchKernelGGL(k_elim_finish_b, dim3(nb * (nb + 1) / 2 + 1, P), 256, 0, st, slots, estimate_trend, mode, beta);
