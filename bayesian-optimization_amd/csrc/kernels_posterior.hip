@@ -25,6 +25,7 @@
 // blocks of 32; 16x16 blocks above the diagonal are skipped (executed flops ~= N^2 (1 + 16/N) per candidate).
 // A 16x16 output tile is 4 instructions: instruction t pairs A row-block (b+t)%4 with B column-block b, so ONE
 // B register and four rotated A reads (LDS) feed 2048 flop.
+#include <algorithm>
 #include <cstdlib>
 
 #include "bogp_device.h"
@@ -347,16 +348,39 @@ constexpr int PITCH = 64 + 16;       // LDS row pitch in doubles: 640 B == 128 (
 // Tiling, staging, guards and the epilogue's summation order are those of kernel B.
 // ---------------------------------------------------------------------------------------------------
 typedef double d4 __attribute__((ext_vector_type(4)));
+#ifdef CONTRACT_TRACE
+// (profiling builds only, `make EXTRA=-DCONTRACT_TRACE`: shader-clock stamps of every wave of every workgroup of k_contract16<4>, parked in LDS and
+// written out at the end -- tools/contract_trace.py turns them into the MFMA-idle attribution of profiles/r06_contract_att.txt.  This image has
+// no thread-trace decoder and the driver offers no PC sampling (same file), so the kernel keeps its own time.  The MFMAs are volatile here so
+// that they stay on their side of a stamp.)
+constexpr int TR_BLK = 64;                // blocks with stamps (N <= 2048)
+constexpr int TR_NST = 8 + 8 * TR_BLK;    // words per wave: 8 header + 8 per block
+__device__ __forceinline__ unsigned long long tr_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+  return t;
+}
+#define BOGP_TR(p, i) ((p)[(i)] = tr_now())
+#define BOGP_TR_PARAM , unsigned long long* trb
+#define BOGP_TR_ARG(x) , (x)
+__device__ __forceinline__ void mfma16_acc(double a, double b, d4& c) {
+  asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+#else
+#define BOGP_TR(p, i) ((void)0)
+#define BOGP_TR_PARAM
+#define BOGP_TR_ARG(x)
 __device__ __forceinline__ void mfma16_acc(double a, double b, d4& c) {
   asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
+#endif
 // 16 passes: the result of the last MFMA must not be read by the VALU before it has left the pipe
 #define BOGP_MFMA16_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
 
-template <int NR>
-__device__ __forceinline__ void contract_block16(const bool GUARDED, const double* __restrict__ tile, const double2* __restrict__ vp,
+template <int NR, bool GUARDED>
+__device__ __forceinline__ void contract_block16(const double* __restrict__ tile, const double2* __restrict__ vp,
                                                  const size_t (&boff)[NR], const int (&jt)[NR], int aoff, int kb, int kp_last,
-                                                 double2 (&bq)[4][NR], d4 (&acc)[MR][NR]) {
+                                                 double2 (&bq)[4][NR], d4 (&acc)[MR][NR] BOGP_TR_PARAM) {
   // A fragments are read one k-step AHEAD of the MFMAs that use them (two register sets): with only four LDS reads per
   // sixteen MFMAs their latency would otherwise sit in front of every k-step
   double af[2][MR];
@@ -366,8 +390,13 @@ __device__ __forceinline__ void contract_block16(const bool GUARDED, const doubl
   for (int s = 0; s < 4; ++s) {
     const int kp = kb * 4 + s;
     const int kb16 = kp >> 1;
+    if (s > 0) BOGP_TR(trb, s);
     {  // B fragments are requested TWO k-pairs ahead (four slots = the four k-pairs of a block; clamped at the end)
+#ifdef CONTRACT_AB_FIXB  // every B fragment from the tile's first k-pair (L2 / L1-hot)
+      const int kpn = min(0, kp_last);
+#else
       const int kpn = min(kp + 2, kp_last);
+#endif
 #pragma unroll
       for (int ni = 0; ni < NR; ++ni) bq[(s + 2) & 3][ni] = vp[boff[ni] + (size_t)kpn * 64];
     }
@@ -389,6 +418,7 @@ __device__ __forceinline__ void contract_block16(const bool GUARDED, const doubl
       }
     }
   }
+  BOGP_TR(trb, 4);
 }
 
 // NCP != 0 (16 / 32 / 64): the batched one-point path (kernels_point.hip, k_point_rhs_T).  The 64 "candidates" of a workgroup are
@@ -398,13 +428,31 @@ __device__ __forceinline__ void contract_block16(const bool GUARDED, const doubl
 // differs: the first row of every NCP-row group (fragment head, register 0, lane quarter 0) is broadcast to the other quarters
 // and multiplies instead of the square; the sums land as the row-block records k_point_finish reads.
 template <int NR, int NCP = 0>
+#ifdef CONTRACT_TRACE
+__global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArgs a, unsigned long long* trace_out) {
+#else
 __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArgs a) {
+#endif
   constexpr int JT16 = NWJ * NR;
   __shared__ __attribute__((aligned(16))) double lds[2 * KB * PITCH];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CONTRACT_TRACE
+  __shared__ unsigned long long trc_all[NWJ][TR_NST];
+  unsigned long long* trc = trc_all[w];
+  {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    trc[0] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+  }
+  BOGP_TR(trc, 1);
+#define BOGP_TRB(kb_) ((kb_) < TR_BLK ? trc + 8 + 8 * (kb_) : trc + 8)
+#else
+#define BOGP_TRB(kb_) 0
+#endif
   const int nMt = a.nMt;
   // Column-group-major order, heaviest group first: concurrent workgroups then walk the SAME 256-column panel of V, which
   // stays hot in every XCD's L2 (the B fragments feed the MFMAs straight from global loads).  Measured alternative (r02,
@@ -415,7 +463,11 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
   const int64_t mc0 = (int64_t)mt * 64;
   const int NJ16 = a.NJ16, NKP = a.NKP;
   const int kmax16 = min((jg + 1) * JT16, NJ16);
+#ifdef CONTRACT_AB_NOZONE  // the 256-row diagonal zone is skipped (column group 0 then runs ONE block): what the zone costs = product - this
+  const int nkb = max(jg * (JT16 / 2), 1);
+#else
   const int nkb = kmax16 >> 1;
+#endif
   const int nkb_full = jg * (JT16 / 2);
   const int kp_last = 2 * kmax16 - 1;
 
@@ -448,7 +500,7 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
   double2 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
 #define BOGP_STAGE_LOAD(S, kb_)                                                                      \
   do {                                                                                               \
-    const double* p_ = rbase + (size_t)((kb_)*KB + srow) * Mc;                                       \
+    const double* p_ = rbase + (size_t)(BOGP_STAGE_ROW(kb_)*KB + srow) * Mc;                                       \
     S##0 = *reinterpret_cast<const double2*>(p_);                                                    \
     S##1 = *reinterpret_cast<const double2*>(p_ + 8 * Mc);                                           \
     S##2 = *reinterpret_cast<const double2*>(p_ + 16 * Mc);                                          \
@@ -463,6 +515,22 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
     *reinterpret_cast<double2*>(q_ + 24 * PITCH) = S##3;                                             \
   } while (0)
 
+// (removal experiments of r06, profiles/r06_contract_att.txt: -DCONTRACT_AB_NOBAR drops the per-block barrier, -DCONTRACT_AB_NOSTS the stage
+// stores -- both give WRONG sums and exist only to price the two phases; never defined in the product build)
+#ifdef CONTRACT_AB_NOBAR
+#define BOGP_LOOP_BARRIER() asm volatile("" ::: "memory")
+#else
+#define BOGP_LOOP_BARRIER() __syncthreads()
+#endif
+#ifdef CONTRACT_AB_NOSTS
+#undef BOGP_STAGE_STORE
+#define BOGP_STAGE_STORE(S, buf_) asm volatile("" :: "v"((S##0).x), "v"((S##1).x), "v"((S##2).x), "v"((S##3).x))
+#endif
+#ifdef CONTRACT_AB_NOSTL  // every stage load reads tile 0 (L2-hot): no HBM latency behind the stage stores
+#define BOGP_STAGE_ROW(kb_) 0
+#else
+#define BOGP_STAGE_ROW(kb_) (kb_)
+#endif
   const double2* __restrict__ vp = a.Vp + lane;
   double2 bq[4][NR];
 #pragma unroll
@@ -478,20 +546,36 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
   BOGP_STAGE_LOAD(sa, 0);
   BOGP_STAGE_STORE(sa, 0);
   BOGP_STAGE_LOAD(sa, min(1, nkb - 1));  // tile 1 -> set A (stored at the end of block 0)
+  BOGP_TR(trc, 2);
 
-  for (int kb = 0; kb < nkb; kb += 2) {
-    __syncthreads();  // tile kb is in lds[0]; every wave is done with lds[1]
-    BOGP_STAGE_LOAD(sb, min(kb + 2, nkb - 1));
-    contract_block16<NR>(kb >= nkb_full, &lds[0], vp, boff, jt, aoff, kb, kp_last, bq, acc);
-    BOGP_STAGE_STORE(sa, 1);  // tile kb + 1
-    if (kb + 1 >= nkb) break;
-    __syncthreads();  // tile kb + 1 is in lds[1]; every wave is done with lds[0]
-    BOGP_STAGE_LOAD(sa, min(kb + 3, nkb - 1));
-    contract_block16<NR>(kb + 1 >= nkb_full, &lds[KB * PITCH], vp, boff, jt, aoff, kb + 1, kp_last, bq, acc);
-    BOGP_STAGE_STORE(sb, 0);  // tile kb + 2
-  }
+  // Two loops, one body each (r06): the full blocks run WITHOUT the per-tile guards -- as one code path with a run-time guard the compiler put a
+  // compare / select / branch chain in front of every four MFMAs of the full blocks too and moved three of the four tile groups out of line
+  // (six taken branches a k-step); an if / else of the two bodies inside ONE loop made the register allocator shuffle the 128 accumulators
+  // (734 spills).  nkb_full = 8 jg is even, so the zone starts on buffer 0.
+#define BOGP_BLOCK_PAIR(G)                                                                                                    \
+  do {                                                                                                                        \
+    BOGP_LOOP_BARRIER(); /* tile kb is in lds[0]; every wave is done with lds[1] */                                           \
+    BOGP_TR(BOGP_TRB(kb), 0);                                                                                                 \
+    BOGP_STAGE_LOAD(sb, min(kb + 2, nkb - 1));                                                                                \
+    contract_block16<NR, G>(&lds[0], vp, boff, jt, aoff, kb, kp_last, bq, acc BOGP_TR_ARG(BOGP_TRB(kb)));                     \
+    BOGP_STAGE_STORE(sa, 1); /* tile kb + 1 */                                                                                \
+    BOGP_TR(BOGP_TRB(kb), 5);                                                                                                 \
+    if (kb + 1 >= nkb) break;                                                                                                 \
+    BOGP_LOOP_BARRIER(); /* tile kb + 1 is in lds[1]; every wave is done with lds[0] */                                       \
+    BOGP_TR(BOGP_TRB(kb + 1), 0);                                                                                             \
+    BOGP_STAGE_LOAD(sa, min(kb + 3, nkb - 1));                                                                                \
+    contract_block16<NR, G>(&lds[KB * PITCH], vp, boff, jt, aoff, kb + 1, kp_last, bq, acc BOGP_TR_ARG(BOGP_TRB(kb + 1)));    \
+    BOGP_STAGE_STORE(sb, 0); /* tile kb + 2 */                                                                                \
+    BOGP_TR(BOGP_TRB(kb + 1), 5);                                                                                             \
+  } while (0)
+  int kb = 0;
+  for (; kb < nkb_full; kb += 2) BOGP_BLOCK_PAIR(false);
+  for (; kb < nkb; kb += 2) BOGP_BLOCK_PAIR(true);
+#undef BOGP_BLOCK_PAIR
+  BOGP_TR(trc, 3);
 #undef BOGP_STAGE_LOAD
 #undef BOGP_STAGE_STORE
+#undef BOGP_LOOP_BARRIER
 
   // ---- epilogue: D[i][j] sits in lane 16 (i % 4) + j, register i / 4 ---------------------------------
   // (BOGP_LINT_NO_DRAIN / BOGP_LINT_NO_FENCE: negative controls of tests/test_isa_lint.py -- builds WITHOUT the drain / the fences must
@@ -508,6 +592,11 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
     for (int ni = 0; ni < NR; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
 #endif
   __syncthreads();
+  BOGP_TR(trc, 4);
+#ifdef CONTRACT_AB_NOEPI  // no reduction: one accumulator word per thread keeps the MFMAs alive
+  if (acc[0][0][0] == 12345.678) a.ss_part[tid] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];
+  return;
+#endif
   // red[slot][wave][row] with a row pitch of 65 doubles: the writes (lanes = 4 rows x 16 slots) fall on (4 slot + row)
   // mod 32 = every bank pair twice, the reads (lanes = 64 consecutive rows) are conflict free.  (The first layout,
   // [wave][row][slot], made every read a 64-way bank conflict: 13.7k cycles of epilogue per workgroup.)
@@ -545,6 +634,7 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
       }
   }
   __syncthreads();
+  BOGP_TR(trc, 5);
   {  // every thread adds the 16 slots of one (wave, row) in a fixed order, then 64 threads add the four waves
     double s = 0.0;
 #pragma unroll
@@ -563,6 +653,15 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
       if (b < a.cross_B) a.ss_part[((size_t)b * (a.nJ + 1) + 1 + jg) * (2 * NCP) + c] = tot;
     }
   }
+#ifdef CONTRACT_TRACE
+  BOGP_TR(trc, 6);
+  __syncthreads();
+  if (trace_out) {
+    unsigned long long* dst = trace_out + (size_t)blockIdx.x * (NWJ * TR_NST);
+    const unsigned long long* src = &trc_all[0][0];
+    for (int i = tid; i < NWJ * TR_NST; i += 256) dst[i] = src[i];
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -655,11 +754,43 @@ static int contract_nr() {
   return nr;
 }
 
+#ifdef CONTRACT_TRACE
+static unsigned long long* g_trace = nullptr;
+static size_t g_trace_words = 0, g_trace_used = 0;
+static int g_trace_dims[4] = {0, 0, 0, 0};
+hipError_t launch_contract(const ContractArgs& a, hipStream_t st) {
+  const size_t need = (size_t)a.nMt * a.nJ * NWJ * TR_NST;
+  if (need > g_trace_words) {
+    if (g_trace) (void)hipFree(g_trace);
+    hipError_t e = hipMalloc((void**)&g_trace, need * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    g_trace_words = need;
+  }
+  // the stamps of the LARGEST launch seen are kept (a sweep's last chunk is a short one); smaller launches run the same code without the dump
+  const bool keep = need >= g_trace_used;
+  if (keep) {
+    g_trace_used = need;
+    g_trace_dims[0] = a.nMt; g_trace_dims[1] = a.nJ; g_trace_dims[2] = a.NJ16; g_trace_dims[3] = TR_NST;
+  }
+  hipLaunchKernelGGL(k_contract16<4>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a, keep ? g_trace : (unsigned long long*)nullptr);
+  return hipGetLastError();
+}
+// the last launch's stamps: dims = {nMt, nJ, NJ16, words per wave}; out may be NULL (size query)
+hipError_t debug_contract_trace(unsigned long long* out, size_t cap_words, size_t* used_words, int* dims) {
+  if (used_words) *used_words = g_trace_used;
+  if (dims) for (int i = 0; i < 4; ++i) dims[i] = g_trace_dims[i];
+  if (!out) return hipSuccess;
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return e;
+  return hipMemcpy(out, g_trace, std::min(cap_words, g_trace_used) * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+#else
 hipError_t launch_contract(const ContractArgs& a, hipStream_t st) {
   if (contract_nr() == 4) hipLaunchKernelGGL(k_contract16<4>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
   else hipLaunchKernelGGL(k_contract16<2>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
   return hipGetLastError();
 }
+#endif
 
 int contract_cols_per_group() { return NWJ * contract_nr() * 16; }
 
@@ -667,10 +798,18 @@ int contract_cols_per_group() { return NWJ * contract_nr() * 16; }
 // 256-column workgroups (a.nJ must be ceil(Np / 256)); a.ss_part = the points' record array, a.cross_B = points
 hipError_t launch_contract_cross(const ContractArgs& a, int ncp, hipStream_t st) {
   const dim3 grid((unsigned)(a.nMt * a.nJ));
+#ifdef CONTRACT_TRACE
+  unsigned long long* none = nullptr;
+  if (ncp == 16) hipLaunchKernelGGL((k_contract16<4, 16>), grid, 256, 0, st, a, none);
+  else if (ncp == 32) hipLaunchKernelGGL((k_contract16<4, 32>), grid, 256, 0, st, a, none);
+  else if (ncp == 64) hipLaunchKernelGGL((k_contract16<4, 64>), grid, 256, 0, st, a, none);
+  else return hipErrorInvalidValue;
+#else
   if (ncp == 16) hipLaunchKernelGGL((k_contract16<4, 16>), grid, 256, 0, st, a);
   else if (ncp == 32) hipLaunchKernelGGL((k_contract16<4, 32>), grid, 256, 0, st, a);
   else if (ncp == 64) hipLaunchKernelGGL((k_contract16<4, 64>), grid, 256, 0, st, a);
   else return hipErrorInvalidValue;
+#endif
   return hipGetLastError();
 }
 
