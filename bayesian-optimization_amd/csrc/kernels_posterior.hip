@@ -665,6 +665,155 @@ __global__ __launch_bounds__(256, NR == 2 ? 3 : 2) void k_contract16(ContractArg
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Kernel B'' (r06): the same contraction with NO LDS and NO barrier in the main loop.
+//
+// profiles/r06_contract_att.txt: in k_contract16 ONE wave does not keep its SIMD's MFMA pipe full -- the A reads (LDS) end up just in
+// front of the MFMAs that use them, the B fragments (L2) retire behind the stage loads (HBM) on the in-order vmcnt, and whenever one of
+// the two resident waves waits at the per-block barrier or stores its stage registers the pipe runs at what the other wave manages
+// alone.  Here every wave fetches its own operands: the A fragment of a k-step is 4 rows x 16 candidates = four 128-byte runs of rT,
+// read as ONE global_load_dwordx4 per PAIR of fragments (lane (k, i) takes candidates 2 i and 2 i + 1 of a 32-candidate half: fragment
+// mi = 2 half + e holds candidates 32 half + 2 i + e -- any bijection of fragment rows onto candidates will do, the epilogue knows it),
+// the B fragments as before.  A and B of k-pair t + DEPTH are requested before k-pair t is multiplied (DEPTH + 1 register slots of
+// 32 VGPRs beside the 128 accumulators), the four waves of a workgroup run free of each other (the sibling waves' A requests hit
+// L1 / L2 behind the first one) and meet only in the epilogue, which is k_contract16's and adds in the same order: the sums are
+// bit-identical to k_contract16's.
+// ---------------------------------------------------------------------------------------------------
+#ifndef CONTRACT_D_DEPTH
+#define CONTRACT_D_DEPTH 2
+#endif
+constexpr int DD = CONTRACT_D_DEPTH;  // k-pairs in flight
+constexpr int DR = DD + 1;            // register slots
+
+__global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
+  constexpr int NR = 4;
+  constexpr int JT16 = NWJ * NR;
+  constexpr int RP = 65;
+  __shared__ __attribute__((aligned(16))) double lds[16 * NWJ * RP + NWJ * 64];  // the epilogue's reduction arrays only
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nMt = a.nMt;
+  const int jg = a.nJ - 1 - (int)(blockIdx.x / nMt);  // heaviest column group first (k_contract16)
+  const int mt = blockIdx.x % nMt;
+  const int64_t mc0 = (int64_t)mt * 64;
+  const int NJ16 = a.NJ16, NKP = a.NKP;
+  const int kmax16 = min((jg + 1) * JT16, NJ16);
+  const int nkp = 2 * kmax16;            // k-pairs of this workgroup
+  const int nkp_full = 2 * jg * JT16;    // ... of them without a guard
+  const int kp_last = nkp - 1;
+
+  int jt[NR];
+  bool valid[NR];
+  const char* vb[NR];
+#pragma unroll
+  for (int ni = 0; ni < NR; ++ni) {
+    const int j = jg * JT16 + ((ni & 1) ? NWJ * (ni + 1) - 1 - w : NWJ * ni + w);  // serpentine (k_contract16)
+    valid[ni] = j < NJ16;
+    jt[ni] = valid[ni] ? j : -1;
+    vb[ni] = reinterpret_cast<const char*>(a.Vp + (size_t)min(j, NJ16 - 1) * NKP * 64);
+  }
+  const size_t Mc = (size_t)a.Mc;
+  const char* ab = reinterpret_cast<const char*>(a.rT + mc0);
+  const size_t kp_stride = 8 * Mc * sizeof(double);                                                    // 8 rows a k-pair
+  const unsigned voffA0 = (unsigned)(((size_t)(lane >> 4) * Mc + 2 * (lane & 15)) * sizeof(double));   // k-step 0 of the pair
+  const unsigned voffA1 = voffA0 + (unsigned)(4 * Mc * sizeof(double));                                // k-step 1
+  const unsigned voffB = (unsigned)lane * 16u;
+
+  d4 acc[MR][NR];
+#pragma unroll
+  for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  double2 av[DR][2][2], bv[DR][NR];
+  // load g of a k-pair, in the order the groups below need them (a group waits for the loads up to its own, vmcnt retires in order):
+  // 0, 1 = the A pairs of k-step 0 (candidate halves 0 / 1), 2 .. 5 = the B fragments of tiles 0 .. 3, 6, 7 = the A pairs of k-step 1
+#define BOGP_D_LOAD1(slot, g, ap_, kpc_)                                                                              \
+  do {                                                                                                                \
+    if ((g) < 2) av[slot][0][(g) & 1] = *reinterpret_cast<const double2*>((ap_) + voffA0 + (((g) & 1) ? 256 : 0));    \
+    else if ((g) >= 6) av[slot][1][(g) & 1] = *reinterpret_cast<const double2*>((ap_) + voffA1 + (((g) & 1) ? 256 : 0)); \
+    else bv[slot][(g) - 2] = *reinterpret_cast<const double2*>(vb[(g) - 2] + (size_t)(kpc_) * 1024 + voffB);          \
+  } while (0)
+  // one k-pair: 8 groups of 4 MFMAs (k-step h = g / 4, tile ni = g % 4); load g of k-pair kp_ + DD goes out in front of group g, so
+  // that the requests ride in the shadow of the MFMAs instead of in a block between two k-pairs (the sched_barriers pin that order)
+#define BOGP_D_KPAIR(G, u, kp_)                                                                                       \
+  do {                                                                                                                \
+    const int kpc_ = min((kp_) + DD, kp_last);                                                                        \
+    const char* ap_ = ab + (size_t)kpc_ * kp_stride;                                                                  \
+    const int k16_ = (kp_) >> 1;                                                                                      \
+    _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                                                   \
+      BOGP_D_LOAD1(((u) + DD) % DR, g, ap_, kpc_);                                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                              \
+      if (!(G) || k16_ <= jt[g & 3]) {                                                                                \
+        const double b_ = (g >> 2) == 0 ? bv[u][g & 3].x : bv[u][g & 3].y;                                            \
+        _Pragma("unroll") for (int mi = 0; mi < MR; ++mi)                                                             \
+          mfma16_acc((mi & 1) ? av[u][g >> 2][mi >> 1].y : av[u][g >> 2][mi >> 1].x, b_, acc[mi][g & 3]);             \
+      }                                                                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                              \
+    }                                                                                                                 \
+  } while (0)
+
+#pragma unroll
+  for (int t = 0; t < DD; ++t) {
+    const int kpc = min(t, kp_last);
+    const char* ap = ab + (size_t)kpc * kp_stride;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) BOGP_D_LOAD1(t, g, ap, kpc);
+  }
+
+  int kp = 0;
+  // full k-pairs, DR at a time (static register slots); what is left of them goes through the guarded loop (its guards hold there)
+  for (; kp + DR <= nkp_full; kp += DR) {
+#pragma unroll
+    for (int u = 0; u < DR; ++u) BOGP_D_KPAIR(false, u, kp + u);
+  }
+  for (; kp < nkp; kp += DR) {
+#pragma unroll
+    for (int u = 0; u < DR; ++u)
+      if (kp + u < nkp) BOGP_D_KPAIR(true, u, kp + u);
+  }
+#undef BOGP_D_KPAIR
+#undef BOGP_D_LOAD1
+
+  // ---- epilogue (k_contract16's): D[i][j] sits in lane 16 (i % 4) + j, register i / 4; row i of fragment mi = candidate
+  // 32 (mi / 2) + 2 i + (mi % 2)
+  BOGP_MFMA16_DRAIN();
+#pragma unroll
+  for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NR; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
+  double* red = lds;                    // [16 slots][NWJ][RP]
+  double* red2 = lds + 16 * NWJ * RP;   // [NWJ][64]: per-wave partial sums
+  const int q = lane >> 4, jc = lane & 15;
+#pragma unroll
+  for (int mi = 0; mi < MR; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double s = 0.0;
+#pragma unroll
+      for (int ni = 0; ni < NR; ++ni)
+        if (valid[ni]) s = __builtin_fma(acc[mi][ni][r], acc[mi][ni][r], s);
+      red[(jc * NWJ + w) * RP + 32 * (mi >> 1) + 2 * (4 * r + q) + (mi & 1)] = s;  // slot = column inside the 16-tile
+    }
+  // the wave's own slots: no workgroup barrier needed between its writes and its reads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  {
+    double s = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) s += red[(sl * NWJ + w) * RP + lane];
+    red2[w * 64 + lane] = s;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const double tot = ((red2[tid] + red2[64 + tid]) + red2[128 + tid]) + red2[192 + tid];
+    a.ss_part[(size_t)jg * a.Mc + mc0 + tid] = tot;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------------
 // BOGP_CORR_MFMA=0: every kernel through kernel A (the r04 producer); the A/B switch of profiles/r05_corr_mfma_ab.txt
@@ -785,8 +934,18 @@ hipError_t debug_contract_trace(unsigned long long* out, size_t cap_words, size_
   return hipMemcpy(out, g_trace, std::min(cap_words, g_trace_used) * sizeof(unsigned long long), hipMemcpyDeviceToHost);
 }
 #else
+// BOGP_CONTRACT_DIRECT=0: the LDS-staged kernel (k_contract16<4>); the A/B switch of profiles/r06_contract_direct_ab.txt
+static bool contract_direct() {
+  static const bool on = [] {
+    const char* e = getenv("BOGP_CONTRACT_DIRECT");
+    return !(e && atoi(e) == 0);
+  }();
+  return on;
+}
+
 hipError_t launch_contract(const ContractArgs& a, hipStream_t st) {
-  if (contract_nr() == 4) hipLaunchKernelGGL(k_contract16<4>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
+  if (contract_nr() == 4 && contract_direct()) hipLaunchKernelGGL(k_contract16d, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
+  else if (contract_nr() == 4) hipLaunchKernelGGL(k_contract16<4>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
   else hipLaunchKernelGGL(k_contract16<2>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
   return hipGetLastError();
 }
