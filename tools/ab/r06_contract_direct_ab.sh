@@ -1,13 +1,14 @@
-# r06: k_contract16d (no LDS, no barrier) against k_contract16<4> (BOGP_CONTRACT_DIRECT=0) on the workloads in $WL (default C3 C5 C2b);
+# r06: k_contract16p (persistent waves) / k_contract16d (no LDS, no barrier; BOGP_CONTRACT_PERSIST=0) against k_contract16<4> (BOGP_CONTRACT_DIRECT=0) on the workloads in $WL (default C3 C5 C2b);
 # gpurun -- 'bash tools/ab/r06_contract_direct_ab.sh'.  Also checks that the two kernels give bit-identical sweep results.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r06_direct_ab
 mkdir -p $OUT
 cd $ROOT
 for WLK in ${WL:-C3 C5}; do
-  for DIRECT in 1 0 1 0; do
-    echo "== $WLK BOGP_CONTRACT_DIRECT=$DIRECT" | tee -a $OUT/times.txt
-    BOGP_CONTRACT_DIRECT=$DIRECT python - $WLK <<'PY' 2>&1 | grep -v amdgpu.ids | tee -a $OUT/times.txt
+  for MODE in ${MODES:-1_1 1_0 0_0 1_1 1_0 0_0}; do
+    set -- ${MODE/_/ }
+    echo "== $WLK BOGP_CONTRACT_DIRECT=$1 BOGP_CONTRACT_PERSIST=$2" | tee -a $OUT/times.txt
+    BOGP_CONTRACT_DIRECT=$1 BOGP_CONTRACT_PERSIST=$2 python - $WLK <<'PY' 2>&1 | grep -v amdgpu.ids | tee -a $OUT/times.txt
 import os, sys, hashlib
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.getcwd()))
 import numpy as np, torch, bench
