@@ -1628,7 +1628,7 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     if ((e = ensure(h, &h->dmu_part[b], &h->mu_part_cap[b], (size_t)S * Mc))) return e;
     if ((e = ensure(h, &h->dw_part[b], &h->w_part_cap[b], (size_t)S * Mc))) return e;
   }
-  if ((e = ensure(h, &h->dss_part, &h->ss_part_cap, (size_t)4 * nJ * Mc))) return e;  // (four rows a group: k_contract16p)
+  if ((e = ensure(h, &h->dss_part, &h->ss_part_cap, (size_t)nJ * Mc))) return e;
   if (h->p > 1) {
     if (Mc > 0x7fffffff / 2) FAIL(h, BOGP_ERR_UNSUPPORTED, "chunk of %lld candidates is too large for the trend GEMM (lower BOGP_CHUNK_MB)", (long long)Mc);
     if (!vx_model) {
@@ -1688,7 +1688,6 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     ContractArgs ka;
     ka.rT = h->drT[b]; ka.Vp = vx ? h->dVpx : h->dVp; ka.ss_part = h->dss_part; ka.Mc = Mc; ka.nMt = (int)(Mc_eff / 64); ka.nJ = nJ;
     ka.NJ16 = NJ16; ka.NKP = Nrows / 8;
-    ka.n_cu = h->n_cu; ka.quads = need_var ? contract_quads(ka.nMt, nJ, h->n_cu) : 0;
     // producer: may reuse buffer b only after chunk c-2 (its previous user) is completely done
     if (overlap && c >= 2) HIPCHK(h, hipStreamWaitEvent(stP, h->ev[(size_t)((c - 2) * EPC + 4)], 0));
     if (h->hXs_lazy) {  // lazily uploaded candidates: this chunk's rows must have arrived (chunk 0: copied here; later ones: below)
@@ -1715,7 +1714,6 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     memset(&aa, 0, sizeof(aa));
     aa.mu_part = h->dmu_part[b]; aa.w_part = h->dw_part[b]; aa.ss_part = h->dss_part; aa.S = S; aa.nJ = need_var ? nJ_main : 0; aa.Mc = Mc;
     aa.nJ_plus = vx ? nJ - nJ_main : 0;
-    aa.ss_quads = ka.quads;
     aa.mcount = mcount; aa.m0 = m0; aa.beta = h->beta; aa.G = h->G; aa.estimate_trend = h->estimate_trend;
     aa.sigma2 = h->sigma2; aa.mu_out = want_out ? h->dmu_out : nullptr; aa.mse_out = want_out ? h->dmse_out : nullptr;
     aa.q = q;

@@ -42,8 +42,6 @@ struct ContractArgs {
   int NJ16;  // Np / 16
   int NKP;   // Np / 8
   int64_t cross_B;  // launch_contract_cross: points (ss_part is then their record array, see k_contract16<NR, NCP>)
-  int quads = 0;    // contract_quads(): k_contract16p -- ss_part is then [4 nJ][Mc], one row per column QUARTER of a group
-  int n_cu = 256;
 };
 
 struct AcqArgs {
@@ -51,7 +49,6 @@ struct AcqArgs {
   const double* w_part;   // [S][Mc]
   const double* ss_part;  // [nJ][Mc]
   int S, nJ;
-  int ss_quads = 0;       // ss_part holds four rows per column group (ContractArgs::quads), added ((q0 + q1) + q2) + q3
   int nJ_plus = 0;        // trend-rows path (k_pack_Vx): column groups nJ .. nJ + nJ_plus - 1 of ss_part hold |u|^2 and are ADDED
   int64_t Mc;      // chunk stride of the partial arrays
   int64_t mcount;  // valid candidates in this chunk
@@ -112,7 +109,6 @@ hipError_t launch_sweep_small(int kernel, const SmallArgs& a, int n_cu, hipStrea
 
 hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipStream_t st);
 hipError_t launch_contract(const ContractArgs& a, hipStream_t st);
-int contract_quads(int nMt, int nJ, int n_cu);
 hipError_t launch_contract_cross(const ContractArgs& a, int ncp, hipStream_t st);
 int contract_cols_per_group();
 hipError_t launch_acquisition(const AcqArgs& a, hipStream_t st);

@@ -27,21 +27,11 @@ __global__ __launch_bounds__(256) void k_acquisition(AcqArgs a) {
       mu += a.mu_part[(size_t)s * a.Mc + i];
       wd += a.w_part[(size_t)s * a.Mc + i];
     }
-    if (a.ss_quads) {  // k_contract16p: the four column quarters of a group, added as k_contract16's epilogue adds its four waves
-      for (int j = 0; j < a.nJ; ++j) {
-        const double* p = a.ss_part + (size_t)(4 * j) * a.Mc + i;
-        ss += ((p[0] + p[a.Mc]) + p[2 * a.Mc]) + p[3 * a.Mc];
-      }
-    } else {
-      for (int j = 0; j < a.nJ; ++j) ss += a.ss_part[(size_t)j * a.Mc + i];
-    }
+    for (int j = 0; j < a.nJ; ++j) ss += a.ss_part[(size_t)j * a.Mc + i];
     mu = (a.mtrend ? a.mtrend[i] : a.beta) + mu;
     double u2 = 0.0;
     if (a.nJ_plus > 0) {
-      for (int j = a.nJ; j < a.nJ + a.nJ_plus; ++j) {
-        const double* p = a.ss_part + (size_t)(a.ss_quads ? 4 * j : j) * a.Mc + i;
-        u2 += a.ss_quads ? ((p[0] + p[a.Mc]) + p[2 * a.Mc]) + p[3 * a.Mc] : p[0];
-      }
+      for (int j = a.nJ; j < a.nJ + a.nJ_plus; ++j) u2 += a.ss_part[(size_t)j * a.Mc + i];
     } else if (a.uu) {
       u2 = a.uu[i];
     } else if (a.estimate_trend) {

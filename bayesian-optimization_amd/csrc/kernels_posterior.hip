@@ -763,7 +763,6 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
     const int kpc_ = min((kp_) + DD, kp_last);                                                                        \
     const char* ap_ = ab + (size_t)BOGP_D_AROW(kpc_) * kp_stride;                                                     \
     const int k16_ = (kp_) >> 1;                                                                                      \
-    BOGP_D_PREFETCH(kp_);                                                                                             \
     _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                                                   \
       BOGP_D_LOAD1(((u) + DD) % DR, g, ap_, kpc_);                                                                    \
       __builtin_amdgcn_sched_barrier(0);                                                                              \
@@ -776,27 +775,6 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
     }                                                                                                                 \
   } while (0)
 
-  // L2 prefetch over the SCALAR path (profiles/r06_contract_cache.txt): the L1 (TCP) returns data in request order, for all waves of the CU,
-  // and the A rows come from HBM -- the head of its queue waits out an HBM round trip per k-pair while the B fragments (L2 hits) queue
-  // behind it (TCP_PENDING_STALL_CYCLES: 66 % of the launch).  Scalar loads take another road to the L2 (the scalar data cache), so each
-  // wave touches two of the eight rows of the k-pair CONTRACT_D_PF k-pairs beyond the one the vector loads are fetching (one dword per
-  // 64 bytes); the vector loads then find their lines in the L2.  The values are never used: an empty asm one k-pair later retires them.
-#ifdef CONTRACT_D_PF
-  typedef const int __attribute__((address_space(4))) cint_k;
-  int pfv[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) pfv[i] = 0;
-#define BOGP_D_PREFETCH(kp_)                                                                                          \
-  do {                                                                                                                \
-    _Pragma("unroll") for (int i = 0; i < 16; ++i) asm volatile("" ::"s"(pfv[i]));                                    \
-    const int kpf_ = min((kp_) + DD + CONTRACT_D_PF, kp_last);                                                        \
-    const char* pr_ = ab + ((size_t)kpf_ * 8 + 2 * w) * (Mc * sizeof(double));                                        \
-    _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                                    \
-      pfv[i] = *reinterpret_cast<cint_k*>(reinterpret_cast<uintptr_t>(pr_ + (i >> 3) * (Mc * sizeof(double)) + (i & 7) * 64)); \
-  } while (0)
-#else
-#define BOGP_D_PREFETCH(kp_) ((void)0)
-#endif
 #ifdef CONTRACT_AB_FIXB  // (removal experiment, wrong sums: every B fragment from the tile's first k-pair)
 #define BOGP_D_BROW(k_) 0
 #else
@@ -868,180 +846,6 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
     const double tot = ((red2[tid] + red2[64 + tid]) + red2[128 + tid]) + red2[192 + tid];
     a.ss_part[(size_t)jg * a.Mc + mc0 + tid] = tot;
   }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Kernel B-persistent (r06): k_contract16d as PERSISTENT, fully independent waves.
-//
-// One workgroup of EIGHT waves per CU (2 per SIMD, 256 VGPRs each: the CU is full) walks a static list of DOUBLE tiles -- 128 candidates
-// x one 256-column group; wave w works on candidate half w / 4 and column quarter w % 4 (the serpentine tiles of k_contract16).  Why:
-//   * waves w and w + 4 sit on the same SIMD, read the SAME B fragments and alternate on its MFMA pipe, so every B line is fetched from
-//     L2 once per CU and k-pair instead of twice (profiles/r06_contract_cache.txt: 27.5 GB of L1 fills per launch for 38.6 GB requested,
-//     the B half of it never shared between the two independent workgroups of a CU);
-//   * no workgroup ever starts or ends inside the launch: the requests of the NEXT double tile's first k-pairs go out in the current
-//     one's last k-pairs (one flat stream of k-pairs through the DD + 1 register slots) and are in flight during the epilogue -- no
-//     dispatch gap (10 k cycles), no cold prologue (9 k cycles);
-//   * no workgroup barrier anywhere: a wave reduces its 64 x 64 block over its own columns (wave-private LDS transposition, the
-//     summation order of k_contract16) and writes ONE partial row, ss_part[(4 jg + quarter)][candidate]; k_acquisition adds the four
-//     quarters of a group as k_contract16's last step did -- ((q0 + q1) + q2) + q3 -- so the sums stay bit-identical.
-// A tile's k-pairs are padded to a multiple of DD + 1 (the padding multiplies nothing) so that register slots stay static.
-// ---------------------------------------------------------------------------------------------------
-struct PTile {
-  const char* ab;      // rT + first candidate of this wave's 64
-  const char* vb[4];   // packed V, tile ni
-  int jt[4];           // 16-column tile index (-1: past the last one)
-  int nkp, nkp_full, nkp3, jg;
-  int64_t mc0;
-  bool store;
-};
-
-__global__ __launch_bounds__(512, 1) void k_contract16p(ContractArgs a) {
-  constexpr int NR = 4;
-  constexpr int JT16 = NWJ * NR;
-  constexpr int RP = 65;
-  __shared__ __attribute__((aligned(16))) double lds[8 * 16 * RP];  // wave-private transposition arrays
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = w >> 2, quarter = w & 3;
-  const int nMt = a.nMt, nMt2 = (nMt + 1) >> 1;
-  const int nItems = a.nJ * nMt2;
-  const int NJ16 = a.NJ16, NKP = a.NKP;
-  const size_t Mc = (size_t)a.Mc;
-  const size_t kp_stride = 8 * Mc * sizeof(double);
-  const unsigned voffA0 = (unsigned)(((size_t)(lane >> 4) * Mc + 2 * (lane & 15)) * sizeof(double));
-  const unsigned voffA1 = voffA0 + (unsigned)(4 * Mc * sizeof(double));
-  const unsigned voffB = (unsigned)lane * 16u;
-
-  auto setup = [&](int item, PTile& t) {
-    const int jg = a.nJ - 1 - item / nMt2;  // heaviest column group first
-    const int mt_want = 2 * (item % nMt2) + half;
-    const int mt = min(mt_want, nMt - 1);   // (odd tile count: the spare half repeats the last tile and does not store)
-    t.store = mt_want < nMt;
-    t.jg = jg;
-    t.mc0 = (int64_t)mt * 64;
-    t.ab = reinterpret_cast<const char*>(a.rT + t.mc0);
-    const int kmax16 = min((jg + 1) * JT16, NJ16);
-    t.nkp = 2 * kmax16;
-    t.nkp_full = 2 * jg * JT16;
-    t.nkp3 = (t.nkp + DR - 1) / DR * DR;
-#pragma unroll
-    for (int ni = 0; ni < NR; ++ni) {
-      const int j = jg * JT16 + ((ni & 1) ? NWJ * (ni + 1) - 1 - quarter : NWJ * ni + quarter);
-      t.jt[ni] = j < NJ16 ? j : -1;
-      t.vb[ni] = reinterpret_cast<const char*>(a.Vp + (size_t)min(j, NJ16 - 1) * NKP * 64);
-    }
-  };
-
-  // Static schedule, dealt like cards in a serpentine: round r hands items r G .. r G + G - 1 (heaviest first) to the workgroups in
-  // forward order when r is even and in reverse order when r is odd, so that a workgroup that drew the heavier end of one round draws the
-  // lighter end of the next (plain striding left whole column groups of difference between workgroups: C5 +5 %).
-  const int G = (int)gridDim.x;
-  auto item_of = [&](int r) { return r * G + ((r & 1) ? G - 1 - (int)blockIdx.x : (int)blockIdx.x); };
-  int round = 0;
-  int item = item_of(0);
-  if (item >= nItems) return;
-  PTile cur, nxt;
-  setup(item, cur);
-
-  d4 acc[MR][NR];
-  double2 av[DR][2][2], bv[DR][NR];
-#define BOGP_P_LOAD1(slot, g, ab_, vb_, k_)                                                            \
-  do {                                                                                                 \
-    const char* ap_ = (ab_) + (size_t)(k_) * kp_stride;                                                \
-    if ((g) < 2) av[slot][0][(g) & 1] = ld2_plain(ap_ + voffA0 + (((g) & 1) ? 256 : 0));               \
-    else if ((g) >= 6) av[slot][1][(g) & 1] = ld2_plain(ap_ + voffA1 + (((g) & 1) ? 256 : 0));         \
-    else bv[slot][(g) - 2] = ld2_plain((vb_)[(g) - 2] + (size_t)(k_) * 1024 + voffB);                  \
-  } while (0)
-  // k-pair kp_ of the current tile (register slot u); its loads serve position kp_ + DD of the flat stream: this tile's k-pair, padding
-  // (the tile's last k-pair once more: L1 hits, multiplied by nothing) or the NEXT tile's first k-pairs.  G = false: a full k-pair
-  // whose target is known to lie inside this tile.
-#define BOGP_P_KPAIR(G, u, kp_)                                                                        \
-  do {                                                                                                 \
-    const int tg_ = (kp_) + DD;                                                                        \
-    const bool own_ = !(G) || tg_ < cur.nkp3;                                                          \
-    const char* lab_ = own_ ? cur.ab : nxt.ab;                                                         \
-    const char* lvb_[4] = {own_ ? cur.vb[0] : nxt.vb[0], own_ ? cur.vb[1] : nxt.vb[1],                 \
-                           own_ ? cur.vb[2] : nxt.vb[2], own_ ? cur.vb[3] : nxt.vb[3]};                \
-    const int lk_ = !(G) ? tg_ : (tg_ < cur.nkp ? tg_ : (own_ ? cur.nkp - 1 : tg_ - cur.nkp3));        \
-    const int k16_ = (kp_) >> 1;                                                                       \
-    _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                                    \
-      BOGP_P_LOAD1(((u) + DD) % DR, g, lab_, lvb_, lk_);                                               \
-      __builtin_amdgcn_sched_barrier(0);                                                               \
-      if (!(G) || k16_ <= cur.jt[g & 3]) {                                                             \
-        const double b_ = (g >> 2) == 0 ? bv[u][g & 3].x : bv[u][g & 3].y;                             \
-        _Pragma("unroll") for (int mi = 0; mi < MR; ++mi)                                              \
-          mfma16_acc((mi & 1) ? av[u][g >> 2][mi >> 1].y : av[u][g >> 2][mi >> 1].x, b_, acc[mi][g & 3]); \
-      }                                                                                                \
-      __builtin_amdgcn_sched_barrier(0);                                                               \
-    }                                                                                                  \
-  } while (0)
-
-#pragma unroll
-  for (int t = 0; t < DD; ++t) {  // (every tile has at least two k-pairs)
-#pragma unroll
-    for (int g = 0; g < 8; ++g) BOGP_P_LOAD1(t, g, cur.ab, cur.vb, t);
-  }
-
-  double* red = lds + w * (16 * RP);  // [16 slots][RP]
-  const int q = lane >> 4, jc = lane & 15;
-  for (;;) {
-    // (an odd last round may leave a hole at this workgroup's place: the rounds end there for it -- the items behind the hole belong to others)
-    const int item_n = item_of(round + 1);
-    const bool more = item_n < nItems;
-    setup(more ? item_n : item, nxt);  // (last tile: its own first k-pairs once more, never multiplied)
-
-#pragma unroll
-    for (int mi = 0; mi < MR; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NR; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
-
-    int kp = 0;
-    for (; kp + DR <= cur.nkp_full; kp += DR) {
-#pragma unroll
-      for (int u = 0; u < DR; ++u) BOGP_P_KPAIR(false, u, kp + u);
-    }
-    for (; kp < cur.nkp3; kp += DR) {
-#pragma unroll
-      for (int u = 0; u < DR; ++u) BOGP_P_KPAIR(true, u, kp + u);
-    }
-
-    // ---- epilogue: k_contract16's, per wave.  D[i][j] sits in lane 16 (i % 4) + j, register i / 4; row i of fragment mi = candidate
-    // 32 (mi / 2) + 2 i + (mi % 2)
-    BOGP_MFMA16_DRAIN();
-#pragma unroll
-    for (int mi = 0; mi < MR; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NR; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
-#pragma unroll
-    for (int mi = 0; mi < MR; ++mi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double s = 0.0;
-#pragma unroll
-        for (int ni = 0; ni < NR; ++ni)
-          if (cur.jt[ni] >= 0) s = __builtin_fma(acc[mi][ni][r], acc[mi][ni][r], s);
-        red[jc * RP + 32 * (mi >> 1) + 2 * (4 * r + q) + (mi & 1)] = s;  // slot = column inside the 16-tile
-      }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    {
-      double s = 0.0;
-#pragma unroll
-      for (int sl = 0; sl < 16; ++sl) s += red[sl * RP + lane];
-      if (cur.store) a.ss_part[(size_t)(4 * cur.jg + quarter) * a.Mc + cur.mc0 + lane] = s;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (!more) break;
-    item = item_n;
-    ++round;
-    cur = nxt;
-  }
-#undef BOGP_P_KPAIR
-#undef BOGP_P_LOAD1
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1174,22 +978,8 @@ static bool contract_direct() {
   return on;
 }
 
-// BOGP_CONTRACT_PERSIST=0: never the persistent kernel.  It takes launches of at least four double tiles per CU: below that the
-// 256-thread workgroups of k_contract16d spread a small launch over twice as many units.
-int contract_quads(int nMt, int nJ, int n_cu) {
-  static const bool on = [] {
-    const char* e = getenv("BOGP_CONTRACT_PERSIST");
-    return !(e && atoi(e) == 0);
-  }();
-  if (!on || contract_nr() != 4 || !contract_direct()) return 0;
-  return (int64_t)nJ * ((nMt + 1) / 2) >= 4 * (int64_t)n_cu ? 1 : 0;
-}
-
 hipError_t launch_contract(const ContractArgs& a, hipStream_t st) {
-  if (a.quads) {
-    const int64_t items = (int64_t)a.nJ * ((a.nMt + 1) / 2);
-    hipLaunchKernelGGL(k_contract16p, dim3((unsigned)std::min<int64_t>(items, a.n_cu)), 512, 0, st, a);
-  } else if (contract_nr() == 4 && contract_direct()) hipLaunchKernelGGL(k_contract16d, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
+  if (contract_nr() == 4 && contract_direct()) hipLaunchKernelGGL(k_contract16d, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
   else if (contract_nr() == 4) hipLaunchKernelGGL(k_contract16<4>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
   else hipLaunchKernelGGL(k_contract16<2>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
   return hipGetLastError();
