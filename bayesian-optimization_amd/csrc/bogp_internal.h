@@ -102,7 +102,6 @@ struct SmallArgs {
   int64_t m_begin;           // first candidate of THIS launch (set by launch_sweep_small: bulk launch 0, tail launch after it)
   int64_t blk_begin;         // first partial-argmax slot of this launch
   int final_launch;          // the launch whose last workgroup reduces the partial winners
-  int64_t ntiles;            // k_sweep_small_df: 64-candidate tiles of this launch (its workgroups deal them out among themselves)
 };
 bool sweep_small_supported(int Np, int d, int kernel);
 int64_t sweep_small_blocks(int64_t M, int n_cu);

@@ -53,8 +53,7 @@ __device__ __forceinline__ void mfma16s(double a, double b, d4s& c) {
 template <int SM_MR, int SM_NR, int RING, int PH>
 __device__ __forceinline__ void small_block16(const bool GUARDED, const double* __restrict__ tile, const double2* __restrict__ vp,
                                               const size_t (&boff)[SM_NR], const int (&jt)[SM_NR], const int (&aoffm)[SM_MR],
-                                              int kb, int kp_clamp, double2 (&bq)[RING][SM_NR], d4s (&acc)[SM_MR][SM_NR],
-                                              int kp_wrap = 0x7fffffff) {  // (k_sweep_small_df: fragment requests past this k-pair wrap to the next tile's first ones)
+                                              int kb, int kp_clamp, double2 (&bq)[RING][SM_NR], d4s (&acc)[SM_MR][SM_NR]) {
   double af[2][SM_MR];
 #pragma unroll
   for (int mi = 0; mi < SM_MR; ++mi) af[0][mi] = tile[aoffm[mi]];
@@ -64,9 +63,7 @@ __device__ __forceinline__ void small_block16(const bool GUARDED, const double* 
     const int kb16 = kp >> 1;
     constexpr int AHEAD = RING - 2;
     {
-      int kpn = kp + AHEAD;
-      if (kpn >= kp_wrap) kpn -= kp_wrap;
-      kpn = min(kpn, kp_clamp);
+      const int kpn = min(kp + AHEAD, kp_clamp);
 #pragma unroll
       for (int ni = 0; ni < SM_NR; ++ni) bq[(4 * PH + s + AHEAD) & (RING - 1)][ni] = vp[boff[ni] + (size_t)kpn * 64];
     }
@@ -435,388 +432,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep_small(const double* __rest
   if (tid == 0) *a.counter = 0u;  // ready for the next launch on this stream
 }
 
-// ---------------------------------------------------------------------------------------------------
-// k_sweep_small_df (r06): the same sweep as a DATAFLOW of persistent waves -- no workgroup barrier after the prologue.
-//
-// Why (tools/small_stamps.py, N = 512, d = 10, 1e5 candidates: per wave and 64-candidate tile 38 k cycles producing, 171 k contracting,
-// 16 k waiting at the four panel barriers, 6 k in the epilogue, ~16 k between workgroups): with one 8-wave workgroup on the CU nothing
-// runs beside a phase -- while the panel is produced the matrix cores idle, at every barrier the pipe drains, and between two workgroups
-// the CU is empty.  Here ONE workgroup per CU walks its share of the candidate tiles and every wave follows its own program:
-//   * the resident panel becomes a RING of eight 32-row blocks (the same 128 KB); block b of a tile is produced by wave b % 8 -- the
-//     wave that produces those rows in k_sweep_small, so the per-wave sums r.gamma / r.w group the same rows in the same order --
-//     LEAD block positions before it is contracted, straight behind the wave's own MFMA work: the two waves of a SIMD are in different
-//     phases most of the time and the FP64 pipe has VALU and MFMA work queued side by side;
-//   * two LDS counters per ring slot replace the barriers: ready[slot] (the block number it holds; a consumer spins on it -- in
-//     practice never) and done[slot] (waves finished with its occupants; the producer of the next occupant waits for all eight);
-//   * the ring runs across tile boundaries: the first blocks of the NEXT tile are produced while the last ones of this tile are
-//     contracted (its candidate tile is staged into the second xs buffer two positions earlier), the B-fragment ring wraps into the next
-//     tile's first k-pairs, and the wave that finishes a tile's partial sums LAST (LDS ticket) does its posterior / criteria / argmax
-//     while the others are already in the next tile.
-// Tiles, k order, the producer's operations and every summation order are k_sweep_small's: the outputs are the SAME BITS
-// (test_fused_small_sweep_dataflow_is_bit_identical).  Np in (256, 512], four tiles per wave, two candidate tiles of 64 d doubles in LDS:
-// d <= DF_MAX_D; launch_sweep_small routes everything else (and the ragged tail of a sweep) to k_sweep_small.
-// ---------------------------------------------------------------------------------------------------
-namespace {
-#ifndef DF_LEAD_BLOCKS
-#define DF_LEAD_BLOCKS 4
-#endif
-constexpr int DF_LEAD = DF_LEAD_BLOCKS;        // a block is produced this many positions before its consumers reach it
-constexpr int DF_SCR = 1536;      // bytes of private LDS per wave: [3][64] partial sums; the [8 slots][16 candidates] transposition array lies over the last two
-constexpr int DF_MAX_D = 18;      // 128 KB ring + 8 x DF_SCR + 2 candidate tiles of 64 x roundup(d, 2) doubles + the counters <= 160 KB
-struct DfSync {
-  unsigned ready[8], done[8], xs_ready[2], xs_done[2], epi_count, fin_gen;
-};
-__device__ __forceinline__ void df_wait_ge(unsigned* p, unsigned target) {
-  while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
-    __builtin_amdgcn_s_sleep(1);
-}
-__device__ __forceinline__ void df_signal(unsigned* p, int lane) {  // after this wave's LDS writes (release), one increment
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-}  // namespace
-
-template <int KERNEL>
-__global__ __launch_bounds__(512, 2) void k_sweep_small_df(const double* __restrict__ Xs, const double* __restrict__ sqrt_theta,
-                                                           const double* __restrict__ XthT, const double* __restrict__ gamma,
-                                                           const double* __restrict__ wvec, const double2* __restrict__ Vp,
-                                                           SmallArgs a) {
-  constexpr int SM_MR = 4, SM_NR = 4, NW = 8, NT = 512, HW = 16, RING = 4;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int d = a.d, Np = a.Np, NJ16 = a.NJ16, NKP = a.NKP;
-  const int d2 = (d + 1) & ~1;
-  double* rs = smem;                                   // [8 slots][32][64] ring of r blocks, swizzled as k_sweep_small's panel
-  double* xsb = smem + 8 * 32 * SM_MT;                 // [2][d2][64] candidate tiles
-  char* scr_all = reinterpret_cast<char*>(xsb + 2 * d2 * SM_MT);
-  DfSync* sy = reinterpret_cast<DfSync*>(scr_all + 8 * DF_SCR);
-  __shared__ int s_last;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  double* part = reinterpret_cast<double*>(scr_all + w * DF_SCR);  // [3][64] this wave's ss / r.gamma / r.w of the tile
-  double* tr = part + 64;                                          // [8][16] transposition (before r.gamma / r.w are parked there)
-  const double pexp = kernel_exponent<KERNEL>(sqrt_theta, d);
-  const int G = (int)gridDim.x;
-  const int ntiles = (int)a.ntiles;
-  const int niter = (ntiles - (int)blockIdx.x + G - 1) / G;  // tiles of this workgroup: blockIdx.x, + G, ...
-  const int NB = Np / 32;                                    // blocks per tile (9 .. 16)
-
-  auto stage_xs = [&](int it, int first, int step) {  // this caller's share of tile `it`'s candidate tile -> xs buffer it & 1
-    double* xs = xsb + (it & 1) * d2 * SM_MT;
-    const int64_t mg0 = a.m_begin + ((int64_t)blockIdx.x + (int64_t)it * G) * SM_MT;
-    for (int idx = first; idx < SM_MT * d; idx += step) {
-      const int row = idx / d, k = idx - row * d;
-      const int64_t gm = mg0 + row;
-      xs[k * SM_MT + row] = (gm < a.M ? Xs[gm * d + k] : 0.0) * sqrt_theta[k];
-    }
-    for (int idx = first; idx < SM_MT * (d2 - d); idx += step) xs[d * SM_MT + idx] = 0.0;
-  };
-  if (tid < (int)(sizeof(DfSync) / sizeof(unsigned))) reinterpret_cast<unsigned*>(sy)[tid] = 0u;
-  stage_xs(0, tid, NT);
-  __syncthreads();  // the only workgroup barrier before the final reduce
-  if (lane == 0 && w == 0) sy->xs_ready[0] = 8u;
-
-  int jt[SM_NR];
-  size_t boff[SM_NR];
-  bool valid[SM_NR];
-#pragma unroll
-  for (int ni = 0; ni < SM_NR; ++ni) {
-    const int j = (ni >> 1) * HW + ((ni & 1) ? HW - 1 - w : w);
-    valid[ni] = j < NJ16;
-    jt[ni] = valid[ni] ? j : -1;
-    boff[ni] = (size_t)min(j, NJ16 - 1) * NKP * 64;
-  }
-  d4s acc[SM_MR][SM_NR];
-#pragma unroll
-  for (int mi = 0; mi < SM_MR; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < SM_NR; ++ni) acc[mi][ni] = (d4s){0.0, 0.0, 0.0, 0.0};
-  int aoffm[SM_MR];
-  {
-    const int lk = lane >> 4, li = lane & 15, par = lk & 1;
-#pragma unroll
-    for (int mi = 0; mi < SM_MR; ++mi) aoffm[mi] = lk * 64 + ((16 * mi + li) ^ (par << 4));
-  }
-  const double2* __restrict__ vp = Vp + lane;
-  const int kp_clamp = NKP - 1;
-  int jmax = -1;
-#pragma unroll
-  for (int ni = 0; ni < SM_NR; ++ni) jmax = max(jmax, jt[ni]);
-  const int nkb_w = a.need_var ? min(NB, (jmax >> 1) + 1) : 0;  // blocks this wave's tiles need
-  const int kp_wrap = 4 * max(nkb_w, 1);                         // the B ring wraps into the next tile's first k-pairs
-  const int b_last = w + 8 < NB ? w + 8 : w;                     // this wave's last block of a tile (NB >= 9: every wave has one)
-  const int e_pos = max(max(nkb_w - 1, b_last - DF_LEAD), 0);    // position behind which the wave's sums of a tile are complete
-  const int xs_pos = NB - DF_LEAD - 2;                           // position at which the next tile's candidates are staged
-  double2 bq[RING][SM_NR];
-#pragma unroll
-  for (int kp0 = 0; kp0 < RING - 2; ++kp0)
-#pragma unroll
-    for (int ni = 0; ni < SM_NR; ++ni) bq[kp0][ni] = vp[boff[ni] + (size_t)min(kp0, kp_clamp) * 64];
-
-  double mu = 0.0, wd = 0.0, mu_n = 0.0, wd_n = 0.0;  // r.gamma, r.w over the rows this wave produced: of the tile being contracted / of the next one
-  // ---- one 32-row block: rows 32 bp .. of tile itp into ring slot gp & 7 (k_sweep_small's producer, stage by stage) ----
-  auto produce = [&](int itp, int bp, unsigned gp, bool next_tile) {
-    const int slot = (int)(gp & 7u);
-    if (gp >= 8u) df_wait_ge(&sy->done[slot], 8u * (gp >> 3));               // all eight waves are done with the slot's previous occupants
-    df_wait_ge(&sy->xs_ready[itp & 1], 8u * ((unsigned)(itp >> 1) + 1u));  // the tile's candidates are staged
-    const double* xs = xsb + (itp & 1) * d2 * SM_MT;
-    double* blk = rs + slot * 32 * 64;
-#ifdef DF_PRIO_PRODUCE
-    __builtin_amdgcn_s_setprio(DF_PRIO_PRODUCE);
-#endif
-    double pm = next_tile ? mu_n : mu, pw = next_tile ? wd_n : wd;  // the running sums go on in row order, as in k_sweep_small
-#pragma unroll 1
-    for (int st = 0; st < 4; ++st) {
-      const int n0 = bp * 32 + st * 8;
-      double ac[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) ac[i] = dist_init<KERNEL>();
-      const double* __restrict__ xp = XthT + n0;
-      double c0[8], c1[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        c0[i] = xp[i];
-        c1[i] = xp[(size_t)Np + i];
-      }
-      double xa0 = xs[lane], xa1 = xs[SM_MT + lane];
-#pragma unroll 1
-      for (int k = 0; k < d2; k += 2) {
-        const int kn = k + 2 < d2 ? k + 2 : k;
-        const double* __restrict__ y0 = xp + (size_t)kn * Np;
-        const double* __restrict__ y1 = y0 + Np;
-        double e0[8], e1[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          e0[i] = y0[i];
-          e1[i] = y1[i];
-        }
-        const double xb0 = xs[kn * SM_MT + lane], xb1 = xs[(kn + 1) * SM_MT + lane];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ac[i] = dist_accumulate<KERNEL>(xa0 - c0[i], ac[i], pexp);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ac[i] = dist_accumulate<KERNEL>(xa1 - c1[i], ac[i], pexp);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          c0[i] = e0[i];
-          c1[i] = e1[i];
-        }
-        xa0 = xb0;
-        xa1 = xb1;
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const double r = corr_profile<KERNEL>(ac[i]);
-        const int nl = st * 8 + i;
-        blk[nl * 64 + (lane ^ ((nl & 1) << 4))] = r;
-        pm = __builtin_fma(r, gamma[n0 + i], pm);
-        pw = __builtin_fma(r, wvec[n0 + i], pw);
-      }
-    }
-    if (next_tile) {
-      mu_n = pm;
-      wd_n = pw;
-    } else {
-      mu = pm;
-      wd = pw;
-    }
-#ifdef DF_PRIO_PRODUCE
-    __builtin_amdgcn_s_setprio(0);
-#endif
-    df_signal(&sy->ready[slot], lane);  // ready[slot] counts the blocks it has held: block gp is there at gp / 8 + 1
-    if (bp == b_last) df_signal(&sy->xs_done[itp & 1], lane);
-  };
-
-  // ---- the wave's program: position g = it NB + b (it = tile of this workgroup, b = block).  At every position: produce the block
-  // LEAD positions ahead if it is this wave's, [stage the next tile's candidates], contract block b if the wave's tiles reach it,
-  // release the slot, [finish the tile's sums].
-  const unsigned P = (unsigned)niter * (unsigned)NB;
-  int it = 0, b = -DF_LEAD;          // (negative positions: the ring is filled LEAD blocks deep before the first contraction)
-  int itp = 0, bp = 0;               // tile / block of position g + LEAD
-  int cur = 0;                       // tile whose sums `mu`, `wd` and `acc` carry
-  for (unsigned gl = 0; gl < P + DF_LEAD; ++gl) {  // gl = g + LEAD
-    if (gl < P && (bp & 7) == w) produce(itp, bp, gl, itp != cur);
-    if (b >= 0) {
-      const unsigned g = gl - DF_LEAD;
-      const int slot = (int)(g & 7u);
-      if (b == xs_pos && it + 1 < niter) {
-        if (it + 1 >= 2) df_wait_ge(&sy->xs_done[(it + 1) & 1], 8u * (unsigned)((it + 1) >> 1));
-        stage_xs(it + 1, w * 64 + lane, NT);
-        df_signal(&sy->xs_ready[(it + 1) & 1], lane);
-      }
-      if (b < nkb_w) {
-        df_wait_ge(&sy->ready[slot], (g >> 3) + 1u);
-        bool full = true;
-#pragma unroll
-        for (int ni = 0; ni < SM_NR; ++ni) full = full && (jt[ni] >= 2 * b + 1);
-        small_block16<SM_MR, SM_NR, RING, 0>(!full, rs + slot * 32 * 64, vp, boff, jt, aoffm, b, kp_clamp, bq, acc, kp_wrap);
-      }
-      df_signal(&sy->done[slot], lane);
-      if (b == e_pos) {
-        // ---- the tile's sums of this wave (k_sweep_small's epilogue up to red2) ----
-        BOGP_SM_DRAIN();
-#pragma unroll
-        for (int mi = 0; mi < SM_MR; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < SM_NR; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
-        if (it >= 1) df_wait_ge(&sy->fin_gen, (unsigned)it);  // the previous tile's finisher has read this wave's partial sums
-        const int qd = lane >> 4, jc = lane & 15;
-#pragma unroll
-        for (int mi = 0; mi < SM_MR; ++mi) {
-          double sq[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            double s = 0.0;
-#pragma unroll
-            for (int ni = 0; ni < SM_NR; ++ni)
-              if (valid[ni]) s = __builtin_fma(acc[mi][ni][r], acc[mi][ni][r], s);
-            sq[r] = s;
-          }
-          // the 16 column slots of the fragment's 16 candidates, eight at a time through [8][16] doubles, added in slot order
-          double tot = 0.0;
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            if ((jc >> 3) == hf) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) tr[(jc & 7) * 16 + 4 * r + qd] = sq[r];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (lane < 16) {
-#pragma unroll
-              for (int sl = 0; sl < 8; ++sl) tot += tr[sl * 16 + lane];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-          }
-          if (lane < 16) part[16 * mi + lane] = tot;
-        }
-        part[64 + lane] = mu;
-        part[128 + lane] = wd;
-#pragma unroll
-        for (int mi = 0; mi < SM_MR; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < SM_NR; ++ni) acc[mi][ni] = (d4s){0.0, 0.0, 0.0, 0.0};
-        mu = mu_n;
-        wd = wd_n;
-        mu_n = 0.0;
-        wd_n = 0.0;
-        cur = it + 1;
-        // ---- the LAST wave to get here finishes the tile: the eight waves' sums in wave order, posterior, criteria, block argmax ----
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        unsigned tk = 0u;
-        if (lane == 0) tk = __hip_atomic_fetch_add(&sy->epi_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        tk = (unsigned)__builtin_amdgcn_readfirstlane((int)tk);
-        if (tk == 8u * (unsigned)it + 7u) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          double ss = 0.0, rg = 0.0, wr = 0.0;
-#pragma unroll
-          for (int ww = 0; ww < 8; ++ww) {
-            const double* pp = reinterpret_cast<const double*>(scr_all + ww * DF_SCR);
-            ss += pp[lane];
-            rg += pp[64 + lane];
-            wr += pp[128 + lane];
-          }
-          const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * G;
-          const int64_t gm = a.m_begin + tile * SM_MT + lane;
-          const bool ok = gm < a.M;
-          double pm, pv;
-          posterior_of_sums(rg, wr, a.need_var ? ss : 0.0, a.beta, a.G, a.estimate_trend, a.sigma2, pm, pv);
-          if (ok && a.mu_out) a.mu_out[gm] = pm;
-          if (ok && a.mse_out) a.mse_out[gm] = pv;
-          const double y_hat = a.minimize ? pm : -1 * pm;
-          const double sd = sqrt(pv);
-          for (int c = 0; c < a.q; ++c) {
-            double v = -INFINITY;
-            int64_t idx = INT64_MAX;
-            if (ok) {
-              v = acq_value(a.acq_id[c], a.acq_par[c], y_hat, sd, a.plugin, a.sigma2);
-              idx = gm;
-              if (a.acq_out) a.acq_out[(size_t)c * a.M + gm] = v;
-            }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-              const double ov = shfl_xor_f64(v, off);
-              const int64_t oi = shfl_xor_i64(idx, off);
-              if (better(ov, oi, v, idx)) {
-                v = ov;
-                idx = oi;
-              }
-            }
-            if (lane == 0) {
-              a.blk_val[(size_t)c * a.nblk + a.blk_begin + tile] = v;
-              a.blk_idx[(size_t)c * a.nblk + a.blk_begin + tile] = idx;
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the block winners are out before this workgroup can take its ticket below
-          if (lane == 0) __hip_atomic_store(&sy->fin_gen, (unsigned)it + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
-    }
-    if (++b == NB) {
-      b = 0;
-      ++it;
-    }
-    if (++bp == NB) {
-      bp = 0;
-      ++itp;
-    }
-  }
-  __syncthreads();
-  if (a.q <= 0 || !a.final_launch) return;
-  // ---- the last workgroup to arrive reduces the per-tile winners (k_sweep_small's final reduce over blk_begin + ntiles slots) ----
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned int ticket = atomicAdd(a.counter, 1u);
-    s_last = ticket == gridDim.x - 1;
-    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __shared__ double fv[NW];
-  __shared__ int64_t fi[NW];
-  const int64_t nslots = a.blk_begin + ntiles;
-  for (int c = 0; c < a.q; ++c) {
-    double v = -INFINITY;
-    int64_t idx = INT64_MAX;
-    for (int64_t k = tid; k < nslots; k += NT) {
-      const double ov = __builtin_nontemporal_load(&a.blk_val[(size_t)c * a.nblk + k]);
-      const int64_t oi = __builtin_nontemporal_load(&a.blk_idx[(size_t)c * a.nblk + k]);
-      if (better(ov, oi, v, idx)) {
-        v = ov;
-        idx = oi;
-      }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double ov = shfl_xor_f64(v, off);
-      const int64_t oi = shfl_xor_i64(idx, off);
-      if (better(ov, oi, v, idx)) {
-        v = ov;
-        idx = oi;
-      }
-    }
-    if (lane == 0) {
-      fv[w] = v;
-      fi[w] = idx;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      for (int k = 1; k < NW; ++k)
-        if (better(fv[k], fi[k], v, idx)) {
-          v = fv[k];
-          idx = fi[k];
-        }
-      a.best_val[c] = v;
-      a.best_idx[c] = idx;
-    }
-    __syncthreads();
-  }
-  if (tid == 0) *a.counter = 0u;
-}
-
 bool sweep_small_supported(int Np, int d, int kernel) {
   // generalized_exponential calls pow() per pair and dimension: inlined 16 times per producer trip it spills > 1000 VGPRs
   // next to the resident accumulators -- that kernel (values only, never fitted) keeps the chunked schedule
@@ -902,39 +517,6 @@ static hipError_t launch_small_nr(int kernel, const SmallArgs& a, unsigned nwg, 
   return launch_small_mr<MR, 4, 8>(kernel, a, nwg, st);
 }
 
-// The dataflow kernel takes the bulk of a sweep when the training set needs four tiles per wave (Np > 256), two candidate tiles fit beside
-// the ring (d <= DF_MAX_D) and every CU gets at least two tiles to pipeline; BOGP_SMALL_DF=0 keeps k_sweep_small (A/B runs and the
-// bit-identity test); the phase stamps (BOGP_SMALL_STAMPS) are k_sweep_small's.
-static bool small_dataflow(const SmallArgs& a, int64_t bulk, int n_cu) {
-  const char* e = getenv("BOGP_SMALL_DF");
-  if (e && atoi(e) == 0) return false;
-  return a.Np > 256 && a.d <= DF_MAX_D && !a.stamps && bulk >= 2 * (int64_t)n_cu;
-}
-static hipError_t launch_small_df(int kernel, SmallArgs a, int64_t ntiles, int n_cu, hipStream_t st) {
-  const int d2 = (a.d + 1) & ~1;
-  const size_t shm = (size_t)8 * 32 * SM_MT * sizeof(double) + (size_t)2 * d2 * SM_MT * sizeof(double) + 8 * DF_SCR + sizeof(DfSync);
-  a.ntiles = ntiles;
-  const unsigned nwg = (unsigned)std::min<int64_t>(ntiles, n_cu);
-#define BOGP_LAUNCH_DF(K)                                                                                                \
-  do {                                                                                                                   \
-    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_small_df<K>),                             \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                           \
-    if (e_ != hipSuccess) return e_;                                                                                     \
-    hipLaunchKernelGGL((k_sweep_small_df<K>), dim3(nwg), 512, shm, st, a.Xs, a.sqrt_theta, a.XthT, a.gamma, a.wvec, a.Vp, a); \
-  } while (0)
-  switch (kernel) {
-    case BOGP_KERNEL_SE: BOGP_LAUNCH_DF(BOGP_KERNEL_SE); break;
-    case BOGP_KERNEL_MATERN12: BOGP_LAUNCH_DF(BOGP_KERNEL_MATERN12); break;
-    case BOGP_KERNEL_MATERN32: BOGP_LAUNCH_DF(BOGP_KERNEL_MATERN32); break;
-    case BOGP_KERNEL_ABSEXP: BOGP_LAUNCH_DF(BOGP_KERNEL_ABSEXP); break;
-    case BOGP_KERNEL_CUBIC: BOGP_LAUNCH_DF(BOGP_KERNEL_CUBIC); break;
-    case BOGP_KERNEL_GENEXP: return hipErrorInvalidValue;
-    default: BOGP_LAUNCH_DF(BOGP_KERNEL_MATERN52); break;
-  }
-#undef BOGP_LAUNCH_DF
-  return hipGetLastError();
-}
-
 // `a` describes the whole sweep (M candidates, a.nblk = sweep_small_blocks(M, n_cu) partial-argmax slots)
 hipError_t launch_sweep_small(int kernel, const SmallArgs& a0, int n_cu, hipStream_t st) {
   int64_t bulk, tail_wg;
@@ -960,9 +542,7 @@ hipError_t launch_sweep_small(int kernel, const SmallArgs& a0, int n_cu, hipStre
     }
   }
   a.final_launch = tail_wg == 0;
-  hipError_t e;
-  if (small_dataflow(a0, bulk, n_cu)) e = launch_small_df(kernel, a, bulk, n_cu, st);
-  else e = launch_small_nr<4>(kernel, a, (unsigned)bulk, st);
+  hipError_t e = launch_small_nr<4>(kernel, a, (unsigned)bulk, st);
   if (e != hipSuccess || tail_wg == 0) return e;
   a.m_begin = bulk * SM_MT;
   a.blk_begin = bulk;

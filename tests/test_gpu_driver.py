@@ -341,43 +341,6 @@ def test_fused_small_sweep_tiles_per_wave_variants_are_bit_identical(N, d):
     eng.close()
 
 
-@pytest.mark.parametrize("N,d,kernel", [(512, 10, "SE"), (500, 7, "M52"), (300, 3, "M32"), (289, 18, "SE"), (448, 1, "M52")])
-def test_fused_small_sweep_dataflow_is_bit_identical(N, d, kernel):
-    """r06: k_sweep_small_df (persistent waves, ring of r blocks, LDS counters instead of barriers) takes the whole rounds of a sweep at
-    256 < Np <= 512, d <= 18.  Same producer operations, same tiles and k order, same summation orders: mu, MSE, criteria values and the
-    argmax must be the SAME BITS as k_sweep_small's (BOGP_SMALL_DF=0), with and without the variance, at tile counts that are and are not
-    a multiple of the workgroup count, with a ragged last tile, and for repeated calls (the counters start from zero every launch)."""
-    import os
-
-    rng = np.random.default_rng(7000 + 10 * N + d)
-    X = rng.uniform(-5, 5, size=(N, d))
-    y = np.sum(np.cos(X), axis=1)
-    y = ((y - y.mean()) / y.std() + 0.05 * rng.standard_normal(N)).reshape(-1, 1)
-    par = np.r_[np.full(d, 0.3 / d), 0.9]
-    kid = {"SE": O.KERNEL_SE, "M52": O.KERNEL_MATERN52, "M32": O.KERNEL_MATERN32}[kernel]
-    eng = _lib.Engine(0)
-    eng.set_train(X, y)
-    eng.commit(kid, O.MODE_NOISY, par, 1e-6, True, 0.0)
-    acq = [(_lib.ACQ_EI, 0.0), (_lib.ACQ_MGFI, 2.0)]
-    for M in (2 * 256 * 64, 3 * 256 * 64 + 64 * 17 + 5, 100_000):
-        eng.upload_candidates(rng.uniform(-5, 5, size=(M, d)))
-        out = []
-        for env in ({}, {"BOGP_SMALL_DF": "0"}, {}):
-            os.environ.update(env)
-            try:
-                mu, mse = eng.predict()
-                mu_only, _ = eng.predict(eval_MSE=False)
-                best, idx, vals = eng.sweep(acq, float(y.min()), True, return_values=True)
-            finally:
-                for k in env:
-                    os.environ.pop(k, None)
-            out.append((mu, mse, mu_only, best, idx, vals))
-        for other in out[1:]:
-            for a, b in zip(out[0], other):
-                np.testing.assert_array_equal(a, b)
-    eng.close()
-
-
 def test_mle_restarts_on_several_streams_of_one_gpu():
     """GaussianProcess(restart_streams=T): the restarts of the MLE (gpr.py:1127-1162) run on T engines (= HIP streams) of the same GPU
     at once, every worker with 1 / T of the budget, all starting points from the global np.random stream in the sequential order
