@@ -1690,6 +1690,9 @@ static int run_sweep(bogp_handle* h, bool want_out, int q, const int* acq_id, co
     ka.NJ16 = NJ16; ka.NKP = Nrows / 8;
     // producer: may reuse buffer b only after chunk c-2 (its previous user) is completely done
     if (overlap && c >= 2) HIPCHK(h, hipStreamWaitEvent(stP, h->ev[(size_t)((c - 2) * EPC + 4)], 0));
+    // trend-rows models: k_trend_rows (below, on the producer stream) writes h->dmtrend, which is NOT double buffered -- chunk c - 1's
+    // k_acquisition on the main stream must have read it first (without this wait chunk c - 1 could get chunk c's means)
+    if (overlap && vx && c >= 1) HIPCHK(h, hipStreamWaitEvent(stP, h->ev[(size_t)((c - 1) * EPC + 4)], 0));
     if (h->hXs_lazy) {  // lazily uploaded candidates: this chunk's rows must have arrived (chunk 0: copied here; later ones: below)
       int el = lazy_copy_to(h, m0 + mcount);
       if (el) return el;

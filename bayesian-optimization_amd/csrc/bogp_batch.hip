@@ -304,6 +304,7 @@ std::vector<bogp_handle*> nll_team(bogp_handle* h, int P) {
   if (workers > 1 && N >= 192 && !h->h_X.empty()) {
     for (int w = 1; w < workers; ++w) {
       if ((int)h->aux.size() < w) {
+        if (h->aux_fail_valid && h->aux_fail_gen == h->train_gen) break;  // a helper could not be loaded with THIS training set: not tried again
         bogp_handle* a = nullptr;
         if (bogp_create(h->device, &a) != BOGP_OK) break;  // (no helper: fewer handles do it all)
         h->aux.push_back(a);
@@ -311,7 +312,16 @@ std::vector<bogp_handle*> nll_team(bogp_handle* h, int P) {
       }
       bogp_handle* a = h->aux[(size_t)w - 1];
       if (h->aux_gen[(size_t)w - 1] != h->train_gen) {
-        if (bogp_set_train(a, h->h_X.data(), h->h_y.data(), N, d, h->n_t) != BOGP_OK) break;
+        if (bogp_set_train(a, h->h_X.data(), h->h_y.data(), N, d, h->n_t) != BOGP_OK) {
+          // (device memory, most likely: a helper that stopped halfway through its N^2 buffers keeps none of them -- the primary handle may
+          // need the room -- and the same allocation is not retried on every later batch call)
+          for (size_t k = (size_t)w - 1; k < h->aux.size(); ++k) bogp_destroy(h->aux[k]);
+          h->aux.resize((size_t)w - 1);
+          h->aux_gen.resize((size_t)w - 1);
+          h->aux_fail_valid = true;
+          h->aux_fail_gen = h->train_gen;
+          break;
+        }
         h->aux_gen[(size_t)w - 1] = h->train_gen;
       }
       a->h_beta_fixed = h->h_beta_fixed;  // fixed coefficients of a polynomial basis, if any
@@ -377,11 +387,20 @@ extern "C" int bogp_nll_batch(bogp_handle* h, int kernel, int mode, int P, const
     }
     std::vector<int> rcs((size_t)W, BOGP_OK);
     std::vector<std::thread> threads;
-    for (int w = 1; w < W; ++w)
-      threads.emplace_back([&, w] {
-        for (int s = w; s < P && !fatal(rcs[(size_t)w]); s += W) rcs[(size_t)w] = run_slot(team[(size_t)w], s);
-      });
+    int started = 1;  // workers that have a thread (this thread is worker 0)
+    try {  // (nothing may leave an extern "C" function as an exception, least of all with joinable threads behind it)
+      threads.reserve((size_t)W - 1);
+      for (int w = 1; w < W; ++w) {
+        threads.emplace_back([&, w] {
+          for (int s = w; s < P && !fatal(rcs[(size_t)w]); s += W) rcs[(size_t)w] = run_slot(team[(size_t)w], s);
+        });
+        ++started;
+      }
+    } catch (...) {
+    }
     for (int s = 0; s < P && !fatal(rcs[0]); s += W) rcs[0] = run_slot(h, s);
+    for (int w = started; w < W; ++w)  // a worker without a thread: its slots on the caller's handle, here
+      for (int s = w; s < P && !fatal(rcs[(size_t)w]); s += W) rcs[(size_t)w] = run_slot(h, s);
     for (auto& t : threads) t.join();
     if (fatal(rcs[0])) return rcs[0];
     for (int w = 1; w < W; ++w)

@@ -122,6 +122,8 @@ struct bogp_handle {
   unsigned long train_gen = 0;
   std::vector<bogp_handle*> aux;       // helper handles (up to 2)
   std::vector<unsigned long> aux_gen;  // the train_gen each was last fed at
+  bool aux_fail_valid = false;         // a helper could not be loaded (device memory) at train_gen == aux_fail_gen: not retried until the training set changes
+  unsigned long aux_fail_gen = 0;
   std::vector<double> h_betav, h_Sinv;     // committed beta (p) and (Ft^T Ft)^-1 (p x p, column-major) for bogp_gradient
   double *dF = nullptr, *dFt = nullptr, *dQ1 = nullptr, *dQ = nullptr;  // N x p, column-major, ld = N
   double* dWp = nullptr;                                                // Np x p: L^-T Ft, zero-padded rows

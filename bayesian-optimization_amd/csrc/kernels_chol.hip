@@ -17,6 +17,7 @@
 //                     others:       A_ij -= X_i X_j^T (64x64 tiles, K = 64), same MFMA micro-kernel
 // Measured alternatives for the diagonal block (tools/probes/ubench_potf2.hip, profiles/r01_ubench_potf2.txt): one wave with
 // a row per lane and v_readlane / ds_bpermute / LDS broadcasts needs 50-300 us per block (SGPR pressure and spills).
+#include <atomic>
 #include "bogp_device.h"
 #include "bogp_internal.h"
 
@@ -1275,14 +1276,27 @@ static bool big_chol(int ld) {
   return big_path(ld) && e && atoi(e) != 0;
 }
 
+// k_mm128's 73.7 KB of dynamic LDS must be granted once PER DEVICE (hipFuncSetAttribute acts on the current device's copy of the function),
+// and bogp_nll runs on several host threads (the helper handles of bogp_nll_batch, the look-ahead of surrogate.py): one bit per device
+// ordinal in an atomic word (r05 had a plain static bool: a second handle on another device would have launched without the grant).
+static hipError_t mm128_grant_lds(int shm) {
+  static std::atomic<unsigned long long> granted{0ull};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = (dev >= 0 && dev < 64) ? 1ull << dev : 0ull;  // (ordinals past 63: the attribute is set on every launch)
+  if (bit && (granted.load(std::memory_order_acquire) & bit)) return hipSuccess;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm128), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+  if (e != hipSuccess) return e;
+  if (bit) granted.fetch_or(bit, std::memory_order_release);
+  return hipSuccess;
+}
+
 static hipError_t launch_mm128(MmArgs a, int mode, int TI, int TJ, int ny, int nz, hipStream_t st) {
   constexpr int shm = 2 * 2 * MKB * MPT * (int)sizeof(double);  // 73.7 KB: two stages of (row tile + column tile)
-  auto kern = &k_mm128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+  {
+    hipError_t e = mm128_grant_lds(shm);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   a.TI = TI;
   a.TJ = TJ;
@@ -1303,12 +1317,12 @@ static hipError_t launch_mm128(MmArgs a, int mode, int TI, int TJ, int ny, int n
                            : (unsigned)((nb2 - a.nl) * a.fp * nb2 + a.nl * (a.fp + (a.nl > 0 ? 1 : 0)) * nb2);
     }
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3(count, 1, 1), 256, shm, st, a, mode);
+    hipLaunchKernelGGL(k_mm128, dim3(count, 1, 1), 256, shm, st, a, mode);
     return hipGetLastError();
   }
   a.order = 0;
   const int nsuper = ((TI + 7) / 8) * ((TJ + 7) / 8);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(nsuper * 64), ny, nz), 256, shm, st, a, mode);
+  hipLaunchKernelGGL(k_mm128, dim3((unsigned)(nsuper * 64), ny, nz), 256, shm, st, a, mode);
   return hipGetLastError();
 }
 
@@ -1316,11 +1330,9 @@ hipError_t launch_mm128_gen(const double* Rs, int ldr, const double* Cs, int ldc
                             hipStream_t st) {
   if (TI <= 0 || TJ <= 0) return hipSuccess;
   constexpr int shm = 2 * 2 * MKB * MPT * (int)sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm128), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+  {
+    hipError_t e = mm128_grant_lds(shm);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   MmArgs a{};
   a.gR = Rs; a.gC = Cs; a.gO = out;

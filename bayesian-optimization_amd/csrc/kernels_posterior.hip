@@ -720,7 +720,9 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
 #ifdef CONTRACT_AB_NOZONE  // (removal experiment, wrong sums: the diagonal zone is skipped -- what it costs = product - this)
   const int nkp = max(nkp_full, 2);
 #else
-  const int nkp = 2 * kmax16;            // k-pairs of this workgroup
+  // k-pairs of this WAVE: its last tile (15 - w of the group, serpentine below) ends 2 w k-pairs before the group does -- the waves do not
+  // wait for each other before the epilogue, so a wave that has nothing left to multiply stops requesting operands too
+  const int nkp = min(2 * kmax16, max(2 * ((jg + 1) * JT16 - w), 2));
 #endif
   const int kp_last = nkp - 1;
 
@@ -750,11 +752,11 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
   double2 av[DR][2][2], bv[DR][NR];
   // load g of a k-pair, in the order the groups below need them (a group waits for the loads up to its own, vmcnt retires in order):
   // 0, 1 = the A pairs of k-step 0 (candidate halves 0 / 1), 2 .. 5 = the B fragments of tiles 0 .. 3, 6, 7 = the A pairs of k-step 1
-#define BOGP_D_LOAD1(slot, g, ap_, kpc_)                                                                              \
+#define BOGP_D_LOAD1(slot, g, ap_, kpc_, vb_)                                                                         \
   do {                                                                                                                \
     if ((g) < 2) av[slot][0][(g) & 1] = BOGP_D_LDA((ap_) + voffA0 + (((g) & 1) ? 256 : 0));                           \
     else if ((g) >= 6) av[slot][1][(g) & 1] = BOGP_D_LDA((ap_) + voffA1 + (((g) & 1) ? 256 : 0));                     \
-    else bv[slot][(g) - 2] = BOGP_D_LDB(vb[(g) - 2] + (size_t)BOGP_D_BROW(kpc_) * 1024 + voffB);                      \
+    else bv[slot][(g) - 2] = BOGP_D_LDB((vb_)[(g) - 2] + (size_t)BOGP_D_BROW(kpc_) * 1024 + voffB);                   \
   } while (0)
   // one k-pair: 8 groups of 4 MFMAs (k-step h = g / 4, tile ni = g % 4); load g of k-pair kp_ + DD goes out in front of group g, so
   // that the requests ride in the shadow of the MFMAs instead of in a block between two k-pairs (the sched_barriers pin that order)
@@ -763,8 +765,12 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
     const int kpc_ = min((kp_) + DD, kp_last);                                                                        \
     const char* ap_ = ab + (size_t)BOGP_D_AROW(kpc_) * kp_stride;                                                     \
     const int k16_ = (kp_) >> 1;                                                                                      \
+    /* diagonal zone: a tile that is past its diagonal at k-pair kpc_ needs no fragment -- its request goes to the address */ \
+    /* of the wave's last tile instead (an L1 hit on a line that is on its way anyway, no second L2 request)            */ \
+    const char* vbe_[NR];                                                                                             \
+    _Pragma("unroll") for (int ni = 0; ni < NR; ++ni) vbe_[ni] = (!(G) || ((kpc_ >> 1) <= jt[ni])) ? vb[ni] : vb[NR - 1]; \
     _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                                                   \
-      BOGP_D_LOAD1(((u) + DD) % DR, g, ap_, kpc_);                                                                    \
+      BOGP_D_LOAD1(((u) + DD) % DR, g, ap_, kpc_, vbe_);                                                              \
       __builtin_amdgcn_sched_barrier(0);                                                                              \
       if (!(G) || k16_ <= jt[g & 3]) {                                                                                \
         const double b_ = (g >> 2) == 0 ? bv[u][g & 3].x : bv[u][g & 3].y;                                            \
@@ -790,7 +796,7 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
     const int kpc = min(t, kp_last);
     const char* ap = ab + (size_t)kpc * kp_stride;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) BOGP_D_LOAD1(t, g, ap, kpc);
+    for (int g = 0; g < 8; ++g) BOGP_D_LOAD1(t, g, ap, kpc, vb);
   }
 
   int kp = 0;

@@ -505,8 +505,12 @@ class GaussianProcess:
         if ahead < 0:
             ahead = 2 if len(self.X) >= 1500 else 1
         ahead = min(ahead, self.random_start - 1, 3)
+        looked = None
         if ahead > 0 and dist is None and not restricted:
-            param_opt, llf_opt = self._restarts_with_lookahead(ahead, log10param, log10bounds, eval_budget)
+            # (None: the worker engines could not be set up -- device memory -- and nothing was drawn or evaluated: the plain loop below runs)
+            looked = self._restarts_with_lookahead(ahead, log10param, log10bounds, eval_budget)
+        if looked is not None:
+            param_opt, llf_opt = looked
             optimal_param = 10.0**param_opt
             env = {}
             optimal_llf_value = llf_fun(optimal_param, env, _adopt=True)
@@ -637,13 +641,42 @@ class GaussianProcess:
         from concurrent.futures import ThreadPoolExecutor
 
         lo, hi = log10bounds[:, 0], log10bounds[:, 1]
-        W = ahead + 1
         make = type(self.engine)  # (the oracle-backed stand-in of the CPU tests speculates on stand-ins)
-        while len(self._worker_engines) < ahead:
-            self._worker_engines.append(make(self.device))
-        engines = [self.engine] + self._worker_engines[:ahead]
-        for eng in engines[1:]:
-            eng.set_train(self.X, self.y)
+        # A worker engine holds its own factor buffers (4 to 6 N^2 doubles).  If one cannot be created or loaded -- another process on the
+        # GPU, a very large N -- the fit must not fail where the sequential loop would have run: the workers that did come up are kept, the
+        # broken one is destroyed, and with none at all the caller runs the plain loop (nothing has been drawn or evaluated yet).
+        ready = []
+        for k in range(ahead):
+            eng = None
+            try:
+                if k < len(self._worker_engines):
+                    eng = self._worker_engines[k]
+                else:
+                    eng = make(self.device)
+                eng.set_train(self.X, self.y)
+                ready.append(eng)
+            except Exception as exc:  # noqa: BLE001 -- HIP out-of-memory surfaces as the library's RuntimeError
+                if eng is not None:
+                    try:
+                        eng.close()
+                    except Exception:  # noqa: BLE001
+                        pass
+                if self.verbose:
+                    print("MLE look-ahead: worker engine %d unavailable (%s); %d in use" % (k + 1, exc, len(ready)))
+                break
+        for eng in self._worker_engines:
+            if not any(eng is r for r in ready):
+                try:
+                    eng.close()
+                except Exception:  # noqa: BLE001
+                    pass
+        self._worker_engines = list(ready)
+        if not ready:
+            self.lookahead_stats = dict(restarts=0, speculated=0, rerun=0, cancelled=0, fallback=1)
+            return None
+        ahead = len(ready)
+        W = ahead + 1
+        engines = [self.engine] + ready
         tid, est, beta = self._trend_args()
         mode, nv, kid = self._MODE[self.estimation_mode], self._nv(), self.kernel_id
 
@@ -706,7 +739,8 @@ class GaussianProcess:
         with warnings.catch_warnings():  # (ONE context around the pool: catch_warnings is not thread-safe)
             warnings.simplefilter("ignore")
             with ThreadPoolExecutor(max_workers=W) as pool:
-                it = 0
+              it = 0
+              try:
                 while it < self.random_start:
                     launch_what_fits(it)
                     fut = inflight[it][0]
@@ -740,17 +774,31 @@ class GaussianProcess:
                     it += 1
                     if budget <= 0 or wait_count >= self.wait_iter:
                         break
-                # restarts launched beyond the loop's end never happened: stop them, and un-draw their start points
+              finally:
+                # restarts launched beyond the loop's end -- or beyond an exception of the current one (a HIP error, an unsupported
+                # configuration) -- never happened: stop them, wait for their threads, and un-draw their start points, so that the global
+                # generator is where the sequential loop would have left it on this path too
                 rest = sorted(inflight)
                 for j in rest:
                     inflight[j][4].set()
                 for j in rest:
-                    inflight[j][0].result()
-                if rest:
-                    np.random.set_state(inflight[rest[0]][3])
+                    try:
+                        inflight[j][0].result()
+                    except Exception:  # noqa: BLE001 -- a speculative restart's own failure dies with it
+                        pass
+                states = [inflight[j][3] for j in rest if inflight[j][3] is not None]
+                if states:
+                    np.random.set_state(states[0])
                 stats["cancelled"] = len(rest)
         self.lookahead_stats = stats
         self._committed_par = None
+        if len(self.X) >= 4096:  # the workers' factor buffers (>= 0.5 GB each from here on) go back to the device between fits
+            for eng in self._worker_engines:
+                try:
+                    eng.close()
+                except Exception:  # noqa: BLE001
+                    pass
+            self._worker_engines = []
         return np.asarray(param_opt, dtype=float), float(llf_opt)
 
     def _restarts_on_streams(self, streams, log10param0, log10bounds, eval_budget):

@@ -386,6 +386,99 @@ def test_lookahead_restarts_are_the_sequential_loop_bit_for_bit(budget, wait_ite
             np.testing.assert_array_equal(a, b)
 
 
+def _lookahead_problem():
+    rng = np.random.default_rng(11)
+    d = 3
+    X = rng.uniform(-5, 5, size=(30, d))
+    y = np.sum(X**2, axis=1) + 2.0 * rng.standard_normal(30)
+    return d, X, ((y - y.mean()) / y.std()).reshape(-1, 1)
+
+
+@pytest.mark.parametrize("fail_at", ["create", "set_train_first", "set_train_second"])
+def test_lookahead_falls_back_when_a_worker_engine_cannot_be_set_up(fail_at):
+    """a worker engine of the look-ahead holds its own N^2 factor buffers; if it cannot be created or loaded (device memory) the
+    fit must run where the sequential loop would have -- with the workers that did come up, or as the plain loop -- and give the same
+    numbers and the same np.random position.  The broken worker is closed, not kept."""
+    import bogp
+    from support.oracle_engine import OracleEngine
+
+    d, X, y = _lookahead_problem()
+    closed = []
+
+    class Flaky(OracleEngine):
+        made = 0
+
+        def __init__(self, *a, **k):
+            Flaky.made += 1
+            self.serial = Flaky.made
+            if fail_at == "create" and self.serial >= 2:
+                raise RuntimeError("hipMalloc: out of memory (test)")
+            super().__init__(*a, **k)
+
+        def set_train(self, *a, **k):
+            if fail_at == "set_train_first" and self.serial == 2:
+                raise RuntimeError("hipMalloc: out of memory (test)")
+            if fail_at == "set_train_second" and self.serial == 3:
+                raise RuntimeError("hipMalloc: out of memory (test)")
+            return super().set_train(*a, **k)
+
+        def close(self):
+            closed.append(self.serial)
+
+    out = []
+    for ahead, make in ((0, OracleEngine), (2, Flaky)):
+        gp = bogp.GaussianProcess(mean=bogp.trend.constant_trend(d), corr="matern", thetaL=[1e-3] * d, thetaU=[1e2] * d, random_start=5,
+                                  wait_iter=3, eval_budget=None, restart_lookahead=ahead, nugget=1e-6)  # fmt: skip
+        Flaky.made = 0
+        gp._engine = make()
+        np.random.seed(5)
+        gp.fit(X, y)
+        out.append((gp.theta_.copy(), float(gp.log_likelihood_), int(gp.eval_count), float(np.random.uniform())))
+        if ahead:
+            stats = gp.lookahead_stats
+            if fail_at == "set_train_second":
+                assert len(gp._worker_engines) == 1 and stats.get("speculated", 0) > 0 and closed == [3]
+            else:
+                assert gp._worker_engines == [] and stats.get("fallback") == 1
+                assert closed == ([2] if fail_at == "set_train_first" else [])
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_lookahead_error_path_cancels_the_speculation_and_restores_the_generator():
+    """when the CURRENT restart raises (a HIP error, an unsupported configuration), the speculative restarts are cancelled and
+    waited for, and np.random is put back to where the sequential loop leaves it on the same error: behind the draws of the restarts that
+    did run, before those that were only speculated."""
+    import bogp
+    from support.oracle_engine import OracleEngine
+
+    d, X, y = _lookahead_problem()
+
+    class Boom(OracleEngine):
+        calls = 0
+
+        def nll(self, *a, **k):
+            Boom.calls += 1
+            if Boom.calls == Boom.limit:
+                raise RuntimeError("device lost (test)")
+            return super().nll(*a, **k)
+
+    after = []
+    for ahead in (0, 2):
+        gp = bogp.GaussianProcess(mean=bogp.trend.constant_trend(d), corr="matern", thetaL=[1e-3] * d, thetaU=[1e2] * d, random_start=6,
+                                  wait_iter=6, eval_budget=None, restart_lookahead=ahead, nugget=1e-6)  # fmt: skip
+        # the FIRST restart fails on its third likelihood evaluation: nothing but the speculative draws has touched the generator
+        Boom.calls, Boom.limit = 0, 3
+        gp._engine = Boom()
+        if ahead:
+            gp._worker_engines = [OracleEngine() for _ in range(ahead)]  # (the workers are healthy: they run restarts 2 and 3 meanwhile)
+        np.random.seed(5)
+        with pytest.raises(RuntimeError, match="device lost"):
+            gp.fit(X, y)
+        after.append(float(np.random.uniform()))
+    assert after[0] == after[1]
+
+
 def test_lookahead_cases_above_exercised_every_branch():
     """(runs after the parametrised cases: speculation, a re-run under the true budget and a cancellation all occurred)"""
     assert {"speculated", "rerun", "cancelled"} <= _LOOKAHEAD_SEEN, _LOOKAHEAD_SEEN
