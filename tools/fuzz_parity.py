@@ -25,6 +25,15 @@ NO_GRAD = (O.KERNEL_CUBIC, O.KERNEL_GENEXP, O.KERNEL_MATERN_NU)
 EDGE_N = [2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 640, 1023, 1025]
 
 
+# Every place a comparison is made at something wider than the bare 1e-6 rtol is COUNTED (README, "Tolerance ledger"): the summary line at the end
+# says how many problems took each carve-out, so that a creeping tolerance shows up as a count going up between rounds.
+CARVE = {}
+
+
+def carve(name, n=1):
+    CARVE[name] = CARVE.get(name, 0) + n
+
+
 def close(a, b, rtol=1e-6, atol=0.0):
     return np.allclose(np.asarray(a, float), np.asarray(b, float), rtol=rtol, atol=atol, equal_nan=True)
 
@@ -95,7 +104,12 @@ def one(seed, eng, orc):
     compare = cond <= 1e12
     tol = max(1e-8, 100.0 * cond * 2.2e-16)  # likelihood tolerance: both sides carry cond(R) eps
     ptol = max(1e-6, 100.0 * cond * 2.2e-16)  # posterior / criterion tolerance
+    if compare and ptol > 1e-6:
+        carve("T5 posterior / criteria at 100 cond(R) eps instead of 1e-6 (cond > 4.5e7)")
+    if compare and tol > 1e-8:
+        carve("T6 likelihood at 100 cond(R) eps instead of 1e-8 (cond > 4.5e5)")
     if kernel == O.KERNEL_MATERN_NU and compare and cond > 1e4:
+        carve("T7 general-nu oracle given the accurate K_nu (cond > 1e4)")
         # r05: the device's K_nu is within 4 eps of the TRUE value (tests/test_gpu_special.py), but scipy.special.kv -- the oracle's, the reference's --
         # is up to hundreds of eps off (tests/golden/G36_kv_table.npz): the reference's R is a perturbed matrix and cond(R) amplifies the
         # perturbation (seed 960921: cond 8e9, the two means 1e-4 apart).  On ill-conditioned problems of this kernel the oracle therefore gets an
@@ -120,6 +134,7 @@ def one(seed, eng, orc):
         got, got_err = None, type(e).__name__
     if (ref_err is None) != (got_err is None):
         # a likelihood at the edge of positive definiteness may fail on one side only; count, do not fail
+        carve("T8 likelihood failed on one side only (edge of positive definiteness): counted, not compared")
         return [], tag + " -- one-sided failure (%s / %s)" % (ref_err, got_err)
     if ref is None:
         return [], None
@@ -130,6 +145,7 @@ def one(seed, eng, orc):
             eng.sweep([(0, 0.0)], float(y.min()), True)
         except _lib.BogpError:
             pass
+        carve("T9 cond(R) > 1e12: ran for crashes, not compared")
         return [], tag + " -- ill-conditioned (cond %.1e > 1e12): ran, not compared" % cond
     if grad:
         if not close(got[0], ref[0], tol, tol):
@@ -242,6 +258,8 @@ def one(seed, eng, orc):
                         fails.append("point batch B=%d row %d: gradient max diff %g / %g" % (B, bb, np.abs(pdm[bb] - np.ravel(rm)).max(), np.abs(pds[bb] - np.ravel(rv_)).max()))
                 _, _, sv = eng.sweep(pacq, float(y.min()), True, return_values=True)
                 solid = np.ravel(rs2) > 1e-9 * s2
+                if not np.all(solid):
+                    carve("T3 criteria rows with MSE <= 1e-9 sigma2 (noise rows) left out of the point-batch / sweep comparison", int(np.sum(~solid)))
                 if not close(pv[solid], sv.T[solid], 1e-6, 1e-300):
                     fails.append("point batch B=%d: criteria differ from the sweep's by %g" % (B, np.nanmax(np.abs(pv[solid] - sv.T[solid]))))
                 if not np.all(np.isfinite(pdv[solid])):
@@ -278,12 +296,15 @@ def one(seed, eng, orc):
         if int(i[c]) != int(ri[c]):
             # a different index is a failure only if the oracle's values separate the two candidates
             v = rv[c]
-            if not (np.isnan(v[int(i[c])]) or abs(v[int(i[c])] - v[int(ri[c])]) <= max(1e-9, 1e-3 * ptol) * (abs(v[int(ri[c])]) + 1e-300)):
+            if np.isnan(v[int(i[c])]) or abs(v[int(i[c])] - v[int(ri[c])]) <= max(1e-9, 1e-3 * ptol) * (abs(v[int(ri[c])]) + 1e-300):
+                carve("T10 argmax index differs where the oracle's two values are a tie (<= 1e-9 relative)")
+            else:
                 fails.append("argmax[%d] %d vs %d (values %r / %r)" % (c, i[c], ri[c], v[int(i[c])], v[int(ri[c])]))
         elif ((abs(rb[c]) > 1e10 and abs(b[c]) > 1e10) or (0.0 < abs(rb[c]) < 1e-10 and 0.0 < abs(b[c]) < 1e-10)) and np.sign(b[c]) == np.sign(rb[c]):
             # MGFI far out on its exponential (exp of tens to hundreds) -- or, r05, EI / PI / MGFI far DOWN their Gaussian tail (seed 3060382: a best value of
             # 1.0467e-109, z ~ -22, 3e-5 from the oracle's on the builds before AND after the r05 fit work): a relative error e in the exponent is
             # e |exponent| in the value, so the exponents are what can be compared at the posterior's tolerance
+            carve("T4 criterion value beyond 1e+-10: exponents compared")
             if not close(np.log(abs(b[c])), np.log(abs(rb[c])), ptol, 0.0):
                 fails.append("best[%d] %r vs %r (exponents differ)" % (c, b[c], rb[c]))
         elif not close(b[c], rb[c], 10 * ptol if ptol > 1e-6 else 1e-6, 1e-300):
@@ -315,6 +336,11 @@ def main():
         n += 1
         seed += 1
     print("fuzz: %d problems in %.0f s, %d with failures, %d notes (next seed %d)" % (n, time.time() - t0, nfail, nskip, seed))
+    print("carve-outs taken (problems, or rows where it says rows), of %d problems:" % n)
+    for k in sorted(CARVE):
+        print("   %6d  %s" % (CARVE[k], k))
+    if not CARVE:
+        print("   none")
     sys.exit(1 if nfail else 0)
 
 
