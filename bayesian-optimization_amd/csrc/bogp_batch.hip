@@ -354,9 +354,7 @@ extern "C" int bogp_nll_batch(bogp_handle* h, int kernel, int mode, int P, const
   }
   HIPCHK(h, hipSetDevice(h->device));
   const int path = bogp_nll_path(N, d, trend, h->n_t);
-  // (the elimination path of ONE evaluation is taken with the gradient queued behind it -- BOGP_NLL_TWO_SYNCS=1 switches that off)
-  const bool two_syncs = getenv("BOGP_NLL_TWO_SYNCS") && atoi(getenv("BOGP_NLL_TWO_SYNCS")) != 0;
-  if (path == BOGP_NLL_PATH_GENERAL || (path == BOGP_NLL_PATH_ELIM && grad && two_syncs)) {
+  if (path == BOGP_NLL_PATH_GENERAL) {
     // evaluations above N = 2048, with a polynomial trend or with several targets: the sequential call, slot by slot -- on SEVERAL handles at
     // once when there are at least two slots (r05): an evaluation is a chain of small launches between larger ones, and independent chains
     // interleave on the device (C5: 15.4 -> 13.5 ms per evaluation, N = 4096: 4.4 -> 3.2, N = 3000: 2.7 -> 1.8; linear trend at N = 2048:

@@ -24,4 +24,13 @@ int factorize_finish(bogp_handle* h, const FitPending& fp, int info, const doubl
 // d llf / d par from the d + 1 contractions S[0 .. d], trace(R^-1) S[d + 1] and gamma.gamma S[d + 2] (gpr.py:1001-1038)
 void nll_gradient_from_sums(int mode, bool iso, int d, const double* par, int n_par, int n_t, const double* S, double s2t, double* grad);
 
+// helpers shared by the three parts of the C ABI (bogp_api.hip defines them)
+void select_target(bogp_handle* h, int t);
+int ensure_gsplit(bogp_handle* h);
+int trend_solve(bogp_handle* h, int trend, int estimate_trend);
+// polynomial bases with p > 32 columns take the trend-rows path (r05; against the r02-r04 tile products: profiles/r05_trend_timing.txt);
+// p <= 32 stays fused into kernel A
+inline bool trend_rows_enabled() { return true; }
+inline int trend_rows_min() { return 33; }
+
 }  // namespace bogp

@@ -28,7 +28,7 @@ struct bogp_handle {
   hipStream_t stream = nullptr;
   unsigned int* dchain_flags = nullptr;  // 2 * (cap_ld / 64) words: hand-over flags of the resident diagonal chain (k_chol_chain)
   hipEvent_t ev_chol[2] = {nullptr, nullptr};  // look-ahead of the large-matrix Cholesky (second stream)
-  hipStream_t stream_upd = nullptr;  // BOGP_CHOL_RESERVE_CU=n: a stream whose CU mask leaves n CUs to the factorisation's chain (two-level Cholesky)
+  hipStream_t stream_upd = nullptr;  // (r04 experiment, always null since r06: a CU-masked stream for the look-ahead update of the two-level Cholesky)
   hipStream_t stream2 = nullptr;  // producer stream: k_corr_chunk of chunk c+1 runs beside k_contract of chunk c
   std::string err;
 

@@ -185,9 +185,8 @@ static int point_eval_chunk(bogp_handle* h, const double* Xb, int B, int q, cons
   }
   // One point (the BFGS loop's call): completion is read off a sequence word the finishing workgroup stores behind the record
   // (pinned memory, system-scope release) -- polling it costs less than a stream synchronisation (profiles/r03_point_call_latency.txt);
-  // bounded: after ~2 ms of polling the ordinary synchronisation takes over.  BOGP_POINT_POLL=0 disables.
-  static const bool poll = [] { const char* e_ = getenv("BOGP_POINT_POLL"); return !(e_ && atoi(e_) == 0); }();
-  if (B == 1 && poll) {
+  // bounded: after ~2 ms of polling the ordinary synchronisation takes over.
+  if (B == 1) {
     volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->hpin + nrec);
     const unsigned long long seq = ++h->pt_seq;
     unsigned long long* dflag = reinterpret_cast<unsigned long long*>(h->hpin_dev + nrec);

@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void k_grad_contract_b(const double* __restric
 // Tile side: 64 x 64 pairs (16 a thread) from N = 1025 on; 32 x 32 (4 a thread) below, 16 x 16 (one a thread) up to N = 256: a likelihood gradient of a few hundred
 // points is ten-odd workgroups either way, and a thread's 16 exp / sqrt chains were 25 us of a 175-us evaluation at N = 200
 static int grad_contract_q(int N) {
-  static const int q1max = [] { const char* e_ = getenv("BOGP_GRADC_Q1_MAX"); return e_ ? atoi(e_) : 256; }();
+  constexpr int q1max = 256;
   return N <= q1max ? 1 : (N <= 1024 ? 2 : 4);
 }
 int grad_contract_blocks(int N) {

@@ -695,12 +695,7 @@ __global__ __launch_bounds__(64) void k_polish_step(PolishArgs a) {
 }  // namespace
 
 int point_columns_per_pass(int d) {
-  static const int forced = [] {
-    const char* e = getenv("BOGP_POINT_NC");  // A/B switch (profiles/r03_point_tri_ab.txt)
-    return e ? atoi(e) : 0;
-  }();
-  if (forced == 12 || forced == 22) return forced;
-  return d + 1 <= 12 ? 12 : 22;
+  return d + 1 <= 12 ? 12 : 22;  // (12 / 22 forced either way: profiles/r03_point_tri_ab.txt)
 }
 int point_passes(int d) {
   const int nc = point_columns_per_pass(d);
@@ -731,12 +726,10 @@ void point_tri_geometry(int N, int d, int B, int* rb, int* nsplit) {
   const int npass = point_passes(d);
   // rows of V per lane: 2 halves the scalar rhs traffic per FMA -- measured NEUTRAL (524 vs 525 us at B = 128): what bounds the
   // batched rate is the V stream from L2 (8 bytes per 22 FMAs, ~4 TB/s at B = 128), not the rhs (profiles/r03_point_tri_ab.txt)
-  int rows = 1;
-  if (const char* e = getenv("BOGP_POINT_ROWS")) rows = atoi(e) == 2 ? 2 : 1;  // A/B switch
+  constexpr int rows = 1;
   const int r = 64 * rows;
   const long long wgs = (long long)((N + r - 1) / r + 1) * npass * B;
   int s = wgs < 128 ? 16 : (wgs < 512 ? 8 : 4);
-  if (const char* e = getenv("BOGP_POINT_SPLIT")) s = std::max(1, atoi(e));  // A/B switch
   s = std::max(1, std::min(s, (N + 15) / 16));  // at least ~4 columns per wave and split
   *rb = r;
   *nsplit = s;

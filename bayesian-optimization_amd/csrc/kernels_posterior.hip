@@ -815,11 +815,16 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
 
   // ---- epilogue (k_contract16's): D[i][j] sits in lane 16 (i % 4) + j, register i / 4; row i of fragment mi = candidate
   // 32 (mi / 2) + 2 i + (mi % 2)
+  // (BOGP_LINT_NO_DRAIN / BOGP_LINT_NO_FENCE: the negative controls of tests/test_isa_lint.py, as in k_contract16)
+#ifndef BOGP_LINT_NO_DRAIN
   BOGP_MFMA16_DRAIN();
+#endif
+#ifndef BOGP_LINT_NO_FENCE
 #pragma unroll
   for (int mi = 0; mi < MR; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NR; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
+#endif
 #ifdef CONTRACT_AB_NOEPI  // (removal experiment: no reduction; one accumulator word per thread keeps the MFMAs alive)
   if (acc[0][0][0] == 12345.678) a.ss_part[tid] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];
   return;
@@ -857,14 +862,8 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
 // ---------------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------------
-// BOGP_CORR_MFMA=0: every kernel through kernel A (the r04 producer); the A/B switch of profiles/r05_corr_mfma_ab.txt
-static bool corr_mfma_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("BOGP_CORR_MFMA");
-    return !(e && atoi(e) == 0);
-  }();
-  return on;
-}
+// (kernel A' for the squared-distance kernels without a fused trend; against kernel A everywhere: profiles/r05_corr_mfma_ab.txt)
+static bool corr_mfma_enabled() { return true; }
 
 hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipStream_t st) {
   dim3 grid((unsigned)nMt, (unsigned)S);
@@ -936,13 +935,9 @@ hipError_t launch_corr_chunk(int kernel, const CorrArgs& a, int nMt, int S, hipS
 // profiles/r04_trend_timing.txt)
 int corr_trend_columns(int p) { return p <= 1 ? 0 : (p <= 16 ? 16 : (p <= 32 ? 32 : 0)); }
 
-static int contract_nr() {
-  static int nr = [] {
-    const char* e = getenv("BOGP_CONTRACT_NR");
-    return (e && atoi(e) == 2) ? 2 : 4;
-  }();
-  return nr;
-}
+// four 16-column fragments per wave = 256-column groups (the NR = 2 instantiation of k_contract16 -- 128-column groups, three workgroups
+// per CU -- lost in r01 and was never the default; removed with its switch in r06)
+static constexpr int contract_nr() { return 4; }
 
 #ifdef CONTRACT_TRACE
 static unsigned long long* g_trace = nullptr;
@@ -985,9 +980,8 @@ static bool contract_direct() {
 }
 
 hipError_t launch_contract(const ContractArgs& a, hipStream_t st) {
-  if (contract_nr() == 4 && contract_direct()) hipLaunchKernelGGL(k_contract16d, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
-  else if (contract_nr() == 4) hipLaunchKernelGGL(k_contract16<4>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
-  else hipLaunchKernelGGL(k_contract16<2>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
+  if (contract_direct()) hipLaunchKernelGGL(k_contract16d, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
+  else hipLaunchKernelGGL(k_contract16<4>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
   return hipGetLastError();
 }
 #endif

@@ -532,15 +532,6 @@ hipError_t launch_sweep_small(int kernel, const SmallArgs& a0, int n_cu, hipStre
     a.final_launch = 1;
     return launch_small_mr<4, 4, 4>(kernel, a, (unsigned)g64, st);
   }
-  if (const char* f = getenv("BOGP_SMALL_FORCE_MR")) {  // measurement aid: every workgroup with 16 * MR candidates
-    const int mr = atoi(f);
-    if (mr >= 2 && mr <= 3) {  // (MR = 1 is gone: one accumulator per tile, every MFMA waiting for its predecessor, 21 spilled VGPRs)
-      const unsigned nwg = (unsigned)((a0.M + 16 * mr - 1) / (16 * mr));
-      a.final_launch = 1;
-      if ((int64_t)nwg > a0.nblk) return hipErrorInvalidValue;
-      return mr == 2 ? launch_small_nr<2>(kernel, a, nwg, st) : launch_small_nr<3>(kernel, a, nwg, st);
-    }
-  }
   a.final_launch = tail_wg == 0;
   hipError_t e = launch_small_nr<4>(kernel, a, (unsigned)bulk, st);
   if (e != hipSuccess || tail_wg == 0) return e;

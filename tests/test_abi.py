@@ -189,3 +189,25 @@ def test_c_reduce_rules_equal_the_python_ones():
                     np.testing.assert_array_equal(x[c, j], xs[pr[j], c, ps[j]])
                 elif d:
                     assert np.all(np.isnan(x[c, j]))
+
+
+def test_switch_table_is_complete():
+    """every BOGP_* variable the native library reads is in the table of tools/README.md ("Switches") with its default and the
+    test that runs its non-default setting -- at most 20 of them -- and that test's source does mention the variable."""
+    import glob
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    read = set()
+    for f in glob.glob(os.path.join(root, "bayesian-optimization_amd", "csrc", "*.h*")):
+        read |= set(re.findall(r'getenv\("(BOGP_[A-Z0-9_]+)"\)', open(f).read()))
+    table = {}
+    for line in open(os.path.join(root, "tools", "README.md")):
+        m = re.match(r"\| `(BOGP_[A-Z0-9_]+)` \|", line)
+        if m:
+            table[m.group(1)] = re.findall(r"`(tests/[a-z_0-9]+\.py)", line)
+    assert read == set(table), "library reads %s, table lists %s" % (sorted(read - set(table)), sorted(set(table) - read))
+    assert len(read) <= 20, sorted(read)
+    for var, files in table.items():
+        assert files, var
+        assert any(var in open(os.path.join(root, f)).read() for f in files), "%s: none of %s mentions it" % (var, files)

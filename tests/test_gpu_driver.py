@@ -380,44 +380,6 @@ def test_mle_restarts_on_several_streams_of_one_gpu():
     np.testing.assert_allclose(mse, omse, rtol=1e-6, atol=1e-12 * float(st.sigma2[0]))
 
 
-@pytest.mark.parametrize("N,d", [(130, 3), (700, 6), (2048, 20), (2500, 4)])
-def test_resident_diagonal_chain_against_the_default_schedule(N, d):
-    """BOGP_CHOL_CHAIN=1: the diagonal chain of the fused block columns runs in ONE resident workgroup beside the block-column kernels
-    (flag hand-overs, bounded waits; kernels_chol.hip k_chol_chain) -- an experiment kept off by default because it measured no
-    faster.  Likelihood, gradient and committed factor: reproducible to the bit, and equal to the default schedule's to rounding
-    (sizes: two block columns; all fused; exactly 32 fused columns; unfused columns first, then the chain)."""
-    import os
-
-    rng = np.random.default_rng(7 * N + d)
-    X = rng.uniform(-5, 5, size=(N, d))
-    y = np.sum(np.sin(X), axis=1)
-    y = ((y - y.mean()) / y.std() + 0.5 * rng.standard_normal(N)).reshape(-1, 1)  # (noisy: a dense smooth sample has llf > 0, which is rejected)
-    par = np.r_[np.full(d, 0.4 / d), 0.9]
-    out = []
-    for flag in ("0", "1", "1"):
-        os.environ["BOGP_CHOL_CHAIN"] = flag
-        try:
-            eng = _lib.Engine(0)
-            eng.set_train(X, y)
-            llf, grad = eng.nll(O.KERNEL_MATERN32, O.MODE_NOISY, par, 1e-2, True, 0.0, eval_grad=True)
-            eng.commit(O.KERNEL_MATERN32, O.MODE_NOISY, par, 1e-2, True, 0.0)
-            st = eng.get_state()
-            eng.close()
-        finally:
-            del os.environ["BOGP_CHOL_CHAIN"]
-        out.append((llf, grad, st["C"], st["gamma"]))
-    # the two chained runs: the same bits; against the default schedule: to rounding -- its diagonal blocks have been factored by the
-    # pipelined 4 x 4 routine (diag_pipe) since r03, the chain's still by diag_factor_invert (same quantities, another order of operations)
-    assert out[2][0] == out[1][0]
-    np.testing.assert_array_equal(out[2][1], out[1][1])
-    np.testing.assert_array_equal(np.tril(out[2][2]), np.tril(out[1][2]))
-    np.testing.assert_array_equal(out[2][3], out[1][3])
-    assert out[1][0] == pytest.approx(out[0][0], rel=1e-12)
-    np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-9, atol=1e-9 * np.abs(out[0][1]).max())
-    np.testing.assert_allclose(np.tril(out[1][2]), np.tril(out[0][2]), rtol=0, atol=1e-12)
-    np.testing.assert_allclose(out[1][3], out[0][3], rtol=0, atol=1e-9 * np.abs(out[0][3]).max())
-
-
 @pytest.mark.parametrize("N", [6144, 6200, 7000])
 def test_large_fit_path_equals_the_64_block_path(N):
     """From ld = 6144 on the inverse and R^-1 = U U^T run on 128 x 128 tiles (k_mm128, kernels_chol.hip; with

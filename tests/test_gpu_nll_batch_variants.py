@@ -26,8 +26,8 @@ VARIANTS = {
     "super-no-xcd": {"BOGP_ELIM_SPLIT_BLOCKS": "1", "BOGP_ELIM_SUPER": "1", "BOGP_ELIM_XCD": "0"},
     # r05: ONE evaluation's fused steps on row pairs (k_elim_stepS: two blocks a workgroup, the next diagonal block alone in workgroup 0) at every
     # size of the elimination path, even and odd numbers of block rows -- against batches on the block kernels
-    "row-pair-steps": {"BOGP_ELIM_STEP_PAIR_MIN": "1", "BOGP_ELIM_STEP_PAIR_MAX": "1000000"},
-    "block-steps-only": {"BOGP_ELIM_STEP_PAIR_MIN": "0"},
+    "row-pair-steps": {"BOGP_ELIM_STEP_PAIRS": "1"},
+    "block-steps-only": {"BOGP_ELIM_STEP_PAIRS": "0"},
 }
 
 
