@@ -860,178 +860,6 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Kernel B-ring (r06, experiment behind BOGP_CONTRACT_RING=1): k_contract16d with the A operand through an LDS RING filled by
-// global_load_lds_dwordx4 -- ONE request per workgroup and r row instead of one per wave (profiles/r06_contract_cache.txt: the L1's
-// in-order return is what bounds k_contract16d, and three of its four A requests are duplicates).  The ring holds 16 k-pairs
-// (16 x [8 rows][64 candidates] = 64 KB); wave w fetches rows 2 w, 2 w + 1 of every k-pair (lanes 0-31 / 32-63: one 512-byte row each,
-// landing back to back); the workgroup meets at ONE barrier per EIGHT k-pairs (half a ring), by when the half it is about to read was
-// requested at least four k-pairs earlier.  The DMA is inline asm (with the builtin hipcc 7.2 waits vmcnt(0) at every later use of an
-// ordinary load), so the compiler's vmcnt counts know nothing of it: its waits for the B fragments can only come out stricter, never
-// laxer (extra entries in an in-order queue), and the wait in front of the barrier is placed by hand.  Same tiles, same k order, same
-// epilogue as k_contract16d: the same bits.
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void glds16(const char* g, unsigned lds_byte) {
-  // (one wait state between the write of M0 and the LDS-DMA that reads it)
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte), "v"(g) : "memory");
-}
-
-__global__ __launch_bounds__(256, 2) void k_contract16r(ContractArgs a) {
-  constexpr int NR = 4;
-  constexpr int JT16 = NWJ * NR;
-  constexpr int RP = 65;
-  constexpr int RH = 8;                        // k-pairs per half ring
-  constexpr int SLOT = 8 * 64;                 // doubles per ring slot: [8 rows][64 candidates]
-  static_assert(2 * RH * SLOT >= 16 * NWJ * RP + NWJ * 64, "the epilogue's reduction arrays overlay the ring");
-  __shared__ __attribute__((aligned(16))) double lds[2 * RH * SLOT];  // 64 KB
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nMt = a.nMt;
-  const int jg = a.nJ - 1 - (int)(blockIdx.x / nMt);
-  const int mt = blockIdx.x % nMt;
-  const int64_t mc0 = (int64_t)mt * 64;
-  const int NJ16 = a.NJ16, NKP = a.NKP;
-  const int kmax16 = min((jg + 1) * JT16, NJ16);
-  const int nkp_full = 2 * jg * JT16;  // k-pairs without a guard (a multiple of 32)
-  const int nkp = 2 * kmax16;          // k-pairs of the WORKGROUP (every wave fetches and meets the barriers to the end)
-  const int kp_last = nkp - 1;
-  const int nhalf = (nkp + RH - 1) / RH;
-
-  int jt[NR];
-  bool valid[NR];
-  const char* vb[NR];
-#pragma unroll
-  for (int ni = 0; ni < NR; ++ni) {
-    const int j = jg * JT16 + ((ni & 1) ? NWJ * (ni + 1) - 1 - w : NWJ * ni + w);
-    valid[ni] = j < NJ16;
-    jt[ni] = valid[ni] ? j : -1;
-    vb[ni] = reinterpret_cast<const char*>(a.Vp + (size_t)min(j, NJ16 - 1) * NKP * 64);
-  }
-  const size_t Mc = (size_t)a.Mc;
-  const char* ab = reinterpret_cast<const char*>(a.rT + mc0);
-  const size_t row_stride = Mc * sizeof(double);
-  const unsigned voffB = (unsigned)lane * 16u;
-  // this lane's share of a k-pair's tile: row 2 w + lane / 32, 16-byte chunk lane % 32
-  const char* dma_src = ab + (size_t)(2 * w + (lane >> 5)) * row_stride + (size_t)(lane & 31) * 16;
-  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) double*)lds);
-  const unsigned dma_dst = lds0 + (unsigned)w * 1024u;  // + slot * 4096 (+ lane * 16 by the hardware)
-  // A pair of fragments of k-step h: row 4 h + lane / 16, candidates 32 j + 2 (lane % 16), + 1
-  const int aoff = (lane >> 4) * 64 + 2 * (lane & 15);
-
-  d4 acc[MR][NR];
-#pragma unroll
-  for (int mi = 0; mi < MR; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NR; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
-  double2 bv[4][NR];
-  double2 af[2][2];
-
-#define BOGP_R_DMA(kp_, slot_)                                                                       \
-  glds16(dma_src + (size_t)min((kp_), kp_last) * 8 * row_stride, dma_dst + (unsigned)(slot_) * 4096u)
-#define BOGP_R_BLOAD(slot_, kp_)                                                                     \
-  do {                                                                                               \
-    const int kpc_ = min((kp_), kp_last);                                                            \
-    _Pragma("unroll") for (int ni = 0; ni < NR; ++ni)                                                \
-      bv[slot_][ni] = ld2_plain(vb[ni] + (size_t)kpc_ * 1024 + voffB);                               \
-  } while (0)
-#define BOGP_R_AREAD(dst_, slot_, h_)                                                                \
-  do {                                                                                               \
-    const double* t_ = lds + (slot_)*SLOT + (h_)*256 + aoff;                                         \
-    (dst_)[0] = *reinterpret_cast<const double2*>(t_);                                               \
-    (dst_)[1] = *reinterpret_cast<const double2*>(t_ + 32);                                          \
-  } while (0)
-
-  // prologue: the first half ring, the first two k-pairs of B fragments; the eight B requests behind the eight DMAs make vmcnt(8) the DMAs' wait
-#pragma unroll
-  for (int u = 0; u < RH; ++u) BOGP_R_DMA(u, u);
-  BOGP_R_BLOAD(0, 0);
-  BOGP_R_BLOAD(1, 1);
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-#define BOGP_R_HALF(GUARDED_)                                                                     \
-  do {                                                                                               \
-    const int sb = (hb & 1) * RH; \
-    const int sn = RH - sb; \
-    BOGP_R_AREAD(af[0], sb, 0); \
-_Pragma("unroll") \
-    for (int u = 0; u < RH; ++u) { \
-      const int kp = hb * RH + u; \
-      if (u < RH / 2) { \
-        BOGP_R_DMA((hb + 1) * RH + 2 * u, sn + 2 * u); \
-        BOGP_R_DMA((hb + 1) * RH + 2 * u + 1, sn + 2 * u + 1); \
-      } \
-      BOGP_R_BLOAD((u + 2) & 3, kp + 2); \
-      const int k16 = kp >> 1; \
-_Pragma("unroll") \
-      for (int h = 0; h < 2; ++h) { \
-        if (h == 0) BOGP_R_AREAD(af[1], sb + u, 1); \
-        else if (u + 1 < RH) BOGP_R_AREAD(af[0], sb + u + 1, 0); \
-        __builtin_amdgcn_sched_barrier(0); \
-_Pragma("unroll") \
-        for (int ni = 0; ni < NR; ++ni) { \
-          if (!(GUARDED_) || k16 <= jt[ni]) { \
-            const double b_ = h == 0 ? bv[u & 3][ni].x : bv[u & 3][ni].y; \
-_Pragma("unroll") \
-            for (int mi = 0; mi < MR; ++mi) mfma16_acc((mi & 1) ? af[h][mi >> 1].y : af[h][mi >> 1].x, b_, acc[mi][ni]); \
-          } \
-        } \
-        __builtin_amdgcn_sched_barrier(0); \
-      } \
-    } \
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); \
-    __builtin_amdgcn_s_barrier(); \
-  } while (0)
-  // (two loops, one body each: with a run-time guard flag the full halves carry a compare / branch chain in front of every four MFMAs)
-  const int nhalf_full = nkp_full / RH;
-  int hb = 0;
-  for (; hb < nhalf_full; ++hb) BOGP_R_HALF(false);
-  for (; hb < nhalf; ++hb) BOGP_R_HALF(true);
-#undef BOGP_R_HALF
-#undef BOGP_R_DMA
-#undef BOGP_R_BLOAD
-#undef BOGP_R_AREAD
-
-  // ---- epilogue (k_contract16d's) ----
-  BOGP_MFMA16_DRAIN();
-#pragma unroll
-  for (int mi = 0; mi < MR; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NR; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the clamped DMAs of the last half must have landed before the ring is reused)
-  __syncthreads();
-  double* red = lds;                    // [16 slots][NWJ][RP]
-  double* red2 = lds + 16 * NWJ * RP;   // [NWJ][64]
-  const int q = lane >> 4, jc = lane & 15;
-#pragma unroll
-  for (int mi = 0; mi < MR; ++mi)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double s = 0.0;
-#pragma unroll
-      for (int ni = 0; ni < NR; ++ni)
-        if (valid[ni]) s = __builtin_fma(acc[mi][ni][r], acc[mi][ni][r], s);
-      red[(jc * NWJ + w) * RP + 32 * (mi >> 1) + 2 * (4 * r + q) + (mi & 1)] = s;
-    }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  {
-    double s = 0.0;
-#pragma unroll
-    for (int sl = 0; sl < 16; ++sl) s += red[(sl * NWJ + w) * RP + lane];
-    red2[w * 64 + lane] = s;
-  }
-  __syncthreads();
-  if (tid < 64) {
-    const double tot = ((red2[tid] + red2[64 + tid]) + red2[128 + tid]) + red2[192 + tid];
-    a.ss_part[(size_t)jg * a.Mc + mc0 + tid] = tot;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------------
 // (kernel A' for the squared-distance kernels without a fused trend; against kernel A everywhere: profiles/r05_corr_mfma_ab.txt)
@@ -1152,11 +980,6 @@ static bool contract_direct() {
 }
 
 hipError_t launch_contract(const ContractArgs& a, hipStream_t st) {
-  static const bool ring = [] { const char* e = getenv("BOGP_CONTRACT_RING"); return e && atoi(e) != 0; }();
-  if (ring) {
-    hipLaunchKernelGGL(k_contract16r, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
-    return hipGetLastError();
-  }
   if (contract_direct()) hipLaunchKernelGGL(k_contract16d, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
   else hipLaunchKernelGGL(k_contract16<4>, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a);
   return hipGetLastError();
