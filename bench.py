@@ -415,7 +415,7 @@ def main():
             kernel_label = ("k_sweep_small (N <= 512: correlation producer + v_mfma_f64_16x16x4_f64 contraction + acquisition + "
                             "argmax in ONE kernel; `achieved` counts the contraction's flops over the whole kernel's time)")
         else:
-            kernel_label = "k_contract16 (v_mfma_f64_16x16x4_f64, VGPR accumulators)"
+            kernel_label = "k_contract16d (v_mfma_f64_16x16x4_f64, VGPR accumulators, operands straight from global memory: no LDS, no barrier in the main loop)"
         res = {
             "metric": "candidates/sec (GP posterior+EI) at N=2048,d=20 and ask() wall-time, 1/2/4/8 GPU",
             "value": value,
