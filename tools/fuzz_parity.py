@@ -304,6 +304,12 @@ def one(seed, eng, orc):
             # MGFI far out on its exponential (exp of tens to hundreds) -- or, r05, EI / PI / MGFI far DOWN their Gaussian tail (seed 3060382: a best value of
             # 1.0467e-109, z ~ -22, 3e-5 from the oracle's on the builds before AND after the r05 fit work): a relative error e in the exponent is
             # e |exponent| in the value, so the exponents are what can be compared at the posterior's tolerance
+            if abs(b[c]) < 2.3e-308 and abs(rb[c]) < 2.3e-308:
+                # r06 (seeds 1150105, 1151224: 5e-324 vs 2.3e-321, 1.5e-314 vs 2.1e-311, the same index on both sides): SUBNORMAL on both sides.  A subnormal
+                # double carries 52 - (1022 + log2 value) bits (5e-324: one), and EI / PI down there are differences of products that have themselves
+                # underflowed: neither side's value means anything beyond "zero".  The index was compared above.
+                carve("T11 best criterion value subnormal (< 2.2e-308) on both sides: index compared, value not")
+                continue
             carve("T4 criterion value beyond 1e+-10: exponents compared")
             if not close(np.log(abs(b[c])), np.log(abs(rb[c])), ptol, 0.0):
                 fails.append("best[%d] %r vs %r (exponents differ)" % (c, b[c], rb[c]))
