@@ -736,13 +736,8 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
     jt[ni] = valid[ni] ? j : -1;
     vb[ni] = reinterpret_cast<const char*>(a.Vp + (size_t)min(j, NJ16 - 1) * NKP * 64);
   }
-#ifdef CONTRACT_AB_TILED  // (experiment, wrong sums: the A rows of a candidate tile read as if rT were laid out [tile][row][64] -- one contiguous stream per workgroup)
-  const size_t Mc = 64;
-  const char* ab = reinterpret_cast<const char*>(a.rT + (size_t)mt * 64 * ((size_t)NKP * 8));
-#else
   const size_t Mc = (size_t)a.Mc;
   const char* ab = reinterpret_cast<const char*>(a.rT + mc0);
-#endif
   const size_t kp_stride = 8 * Mc * sizeof(double);                                                    // 8 rows a k-pair
   const unsigned voffA0 = (unsigned)(((size_t)(lane >> 4) * Mc + 2 * (lane & 15)) * sizeof(double));   // k-step 0 of the pair
   const unsigned voffA1 = voffA0 + (unsigned)(4 * Mc * sizeof(double));                                // k-step 1
