@@ -866,8 +866,8 @@ namespace bogp { hipError_t debug_elim_stamps(unsigned long long* out); }
 extern "C" int bogp_debug_elim_stamps(unsigned long long* out) { return bogp::debug_elim_stamps(out) == hipSuccess ? BOGP_OK : BOGP_ERR_HIP; }
 #endif
 
-#ifdef CONTRACT_TRACE
-// (profiling builds only, `make EXTRA=-DCONTRACT_TRACE`: the stamps the last k_contract16<4> launch left -- tools/contract_trace.py)
+#if defined(CONTRACT_TRACE) || defined(CONTRACT_D_TRACE)
+// (profiling builds only, `make EXTRA=-DCONTRACT_TRACE` / -DCONTRACT_D_TRACE: the stamps the last k_contract16<4> launch left -- tools/contract_trace.py)
 namespace bogp { hipError_t debug_contract_trace(unsigned long long* out, size_t cap_words, size_t* used_words, int* dims); }
 extern "C" int bogp_debug_contract_trace(unsigned long long* out, size_t cap_words, size_t* used_words, int* dims) {
   return bogp::debug_contract_trace(out, cap_words, used_words, dims) == hipSuccess ? BOGP_OK : BOGP_ERR_HIP;

@@ -701,7 +701,30 @@ __device__ __forceinline__ double2 ld2_nt(const char* p) {
 constexpr int DD = CONTRACT_D_DEPTH;  // k-pairs in flight
 constexpr int DR = DD + 1;            // register slots
 
+#ifdef CONTRACT_D_TRACE
+// (profiling builds only, -DCONTRACT_D_TRACE: shader-clock stamps of every wave -- entry, loop start, the start of EVERY k-pair, loop end, drain, reduction, exit --
+// parked in LDS and written out at the end; tools/contract_d_trace.py -> profiles/r06_contract_d_trace.txt.  A k-pair's stamp is requested in front of its first load
+// and waited for / stored behind its first four MFMAs, so that the scalar-memory round trip of s_memtime hides under matrix work.)
+constexpr int DT_NST = 8 + 264;  // words per wave: 8 header + one per k-pair (N <= 2112)
+#define BOGP_DT_NOW(idx_)                                                            \
+  do {                                                                               \
+    unsigned long long t_;                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_));                 \
+    dtr[(idx_)] = t_;                                                                \
+  } while (0)
+#define BOGP_DT_ISSUE() asm volatile("s_memtime %0" : "=s"(dt_pending))
+#define BOGP_DT_STORE(idx_)                                                          \
+  do {                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dt_pending));                         \
+    if ((idx_) < DT_NST) dtr[(idx_)] = dt_pending;                                   \
+  } while (0)
+__global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a, unsigned long long* trace_out) {
+#else
+#define BOGP_DT_NOW(idx_) ((void)0)
+#define BOGP_DT_ISSUE() ((void)0)
+#define BOGP_DT_STORE(idx_) ((void)0)
 __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
+#endif
   constexpr int NR = 4;
   constexpr int JT16 = NWJ * NR;
   constexpr int RP = 65;
@@ -710,6 +733,18 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CONTRACT_D_TRACE
+  __shared__ unsigned long long dtr_all[NWJ][DT_NST];
+  unsigned long long* dtr = dtr_all[w];
+  unsigned long long dt_pending = 0;
+  {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    dtr[0] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+  }
+  BOGP_DT_NOW(1);
+#endif
   const int nMt = a.nMt;
   const int jg = a.nJ - 1 - (int)(blockIdx.x / nMt);  // heaviest column group first (k_contract16)
   const int mt = blockIdx.x % nMt;
@@ -739,9 +774,9 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
   const size_t Mc = (size_t)a.Mc;
   const char* ab = reinterpret_cast<const char*>(a.rT + mc0);
   const size_t kp_stride = 8 * Mc * sizeof(double);                                                    // 8 rows a k-pair
-  const unsigned voffA0 = (unsigned)(((size_t)(lane >> 4) * Mc + 2 * (lane & 15)) * sizeof(double));   // k-step 0 of the pair
-  const unsigned voffA1 = voffA0 + (unsigned)(4 * Mc * sizeof(double));                                // k-step 1
-  const unsigned voffB = (unsigned)lane * 16u;
+  unsigned voffA0 = (unsigned)(((size_t)(lane >> 4) * Mc + 2 * (lane & 15)) * sizeof(double));   // k-step 0 of the pair
+  unsigned voffA1 = voffA0 + (unsigned)(4 * Mc * sizeof(double));                                // k-step 1
+  unsigned voffB = (unsigned)lane * 16u;
 
   d4 acc[MR][NR];
 #pragma unroll
@@ -758,6 +793,28 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
     else if ((g) >= 6) av[slot][1][(g) & 1] = BOGP_D_LDA((ap_) + voffA1 + (((g) & 1) ? 256 : 0));                     \
     else bv[slot][(g) - 2] = BOGP_D_LDB((vb_)[(g) - 2] + (size_t)BOGP_D_BROW(kpc_) * 1024 + voffB);                   \
   } while (0)
+  // The k-pair's eight loads go out as ONE block in front of its 32 MFMAs (CONTRACT_D_LBLOCK = 8; 1 / 2 / 4 = one load in front of every group / every second /
+  // every fourth: the first version of this kernel).  The phase trace (profiles/r06_contract_d_trace.txt) showed a FULL k-pair taking 4284 cycles where the two waves
+  // of a SIMD need 4096: every hand-over of the issue port between them costs a few cycles, and a load between two groups of MFMAs is a hand-over.  58.4 -> 58.0 ms.
+  // NO VALU IN THE LOOP: the address of every load is a scalar base (advanced by scalar arithmetic) + the lane's constant 32-bit offset, the `v_offset, s[base]`
+  // form of global_load.  hipcc only selects that form when it sees the zero-extension of the offset next to the load; hoisted out of the loop (it is loop
+  // invariant) the offset is a 64-bit register pair and every load gets a v_lshl_add_u64 -- a 64-bit VALU operation, i.e. one that runs on the SAME FP64 pipe as
+  // the MFMAs: eight of them per k-pair and wave.  Passing the three offsets through an empty asm inside the loop keeps the zero-extension where the load is.
+  // 58.0 -> 55.9 ms a step at C3 (0.917 -> 0.956 of peak), 454.9 -> 439.1 ms at C5.  (-DCONTRACT_D_NO_SADDR: the A/B switch of profiles/r06_contract_d_trace.txt.)
+#ifndef CONTRACT_D_NO_SADDR
+#define BOGP_D_OPAQUE_OFFSETS() asm volatile("" : "+v"(voffA0), "+v"(voffA1), "+v"(voffB))
+#else
+#define BOGP_D_OPAQUE_OFFSETS() ((void)0)
+#endif
+#ifndef CONTRACT_D_LBLOCK
+#define CONTRACT_D_LBLOCK 8
+#endif
+#define BOGP_D_LOADS_AT(g, slot, ap_, kpc_, vb_)                                                                      \
+  do {                                                                                                                \
+    if ((g) % CONTRACT_D_LBLOCK == 0) {                                                                               \
+      _Pragma("unroll") for (int l_ = 0; l_ < CONTRACT_D_LBLOCK; ++l_) BOGP_D_LOAD1(slot, (g) + l_, ap_, kpc_, vb_);  \
+    }                                                                                                                 \
+  } while (0)
   // one k-pair: 8 groups of 4 MFMAs (k-step h = g / 4, tile ni = g % 4); load g of k-pair kp_ + DD goes out in front of group g, so
   // that the requests ride in the shadow of the MFMAs instead of in a block between two k-pairs (the sched_barriers pin that order)
 #define BOGP_D_KPAIR(G, u, kp_)                                                                                       \
@@ -765,12 +822,15 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
     const int kpc_ = min((kp_) + DD, kp_last);                                                                        \
     const char* ap_ = ab + (size_t)BOGP_D_AROW(kpc_) * kp_stride;                                                     \
     const int k16_ = (kp_) >> 1;                                                                                      \
+    BOGP_D_OPAQUE_OFFSETS();                                                                                          \
     /* diagonal zone: a tile that is past its diagonal at k-pair kpc_ needs no fragment -- its request goes to the address */ \
     /* of the wave's last tile instead (an L1 hit on a line that is on its way anyway, no second L2 request)            */ \
     const char* vbe_[NR];                                                                                             \
     _Pragma("unroll") for (int ni = 0; ni < NR; ++ni) vbe_[ni] = (!(G) || ((kpc_ >> 1) <= jt[ni])) ? vb[ni] : vb[NR - 1]; \
+    BOGP_DT_ISSUE();                                                                                                  \
     _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                                                   \
-      BOGP_D_LOAD1(((u) + DD) % DR, g, ap_, kpc_, vbe_);                                                              \
+      if (g == 1) BOGP_DT_STORE(8 + (kp_));                                                                           \
+      BOGP_D_LOADS_AT(g, ((u) + DD) % DR, ap_, kpc_, vbe_);                                                           \
       __builtin_amdgcn_sched_barrier(0);                                                                              \
       if (!(G) || k16_ <= jt[g & 3]) {                                                                                \
         const double b_ = (g >> 2) == 0 ? bv[u][g & 3].x : bv[u][g & 3].y;                                            \
@@ -799,6 +859,7 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
     for (int g = 0; g < 8; ++g) BOGP_D_LOAD1(t, g, ap, kpc, vb);
   }
 
+  BOGP_DT_NOW(2);
   int kp = 0;
   // full k-pairs, DR at a time (static register slots); what is left of them goes through the guarded loop (its guards hold there)
   for (; kp + DR <= nkp_full; kp += DR) {
@@ -812,6 +873,7 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
   }
 #undef BOGP_D_KPAIR
 #undef BOGP_D_LOAD1
+  BOGP_DT_NOW(3);
 
   // ---- epilogue (k_contract16's): D[i][j] sits in lane 16 (i % 4) + j, register i / 4; row i of fragment mi = candidate
   // 32 (mi / 2) + 2 i + (mi % 2)
@@ -829,6 +891,7 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
   if (acc[0][0][0] == 12345.678) a.ss_part[tid] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];
   return;
 #endif
+  BOGP_DT_NOW(4);
   double* red = lds;                    // [16 slots][NWJ][RP]
   double* red2 = lds + 16 * NWJ * RP;   // [NWJ][64]: per-wave partial sums
   const int q = lane >> 4, jc = lane & 15;
@@ -852,12 +915,26 @@ __global__ __launch_bounds__(256, 2) void k_contract16d(ContractArgs a) {
     for (int sl = 0; sl < 16; ++sl) s += red[(sl * NWJ + w) * RP + lane];
     red2[w * 64 + lane] = s;
   }
+  BOGP_DT_NOW(5);
   __syncthreads();
   if (tid < 64) {
     const double tot = ((red2[tid] + red2[64 + tid]) + red2[128 + tid]) + red2[192 + tid];
     a.ss_part[(size_t)jg * a.Mc + mc0 + tid] = tot;
   }
+#ifdef CONTRACT_D_TRACE
+  BOGP_DT_NOW(6);
+  dtr[7] = (unsigned long long)nkp | ((unsigned long long)nkp_full << 32);
+  __syncthreads();
+  if (trace_out) {
+    unsigned long long* dst = trace_out + (size_t)blockIdx.x * (NWJ * DT_NST);
+    const unsigned long long* src = &dtr_all[0][0];
+    for (int i = tid; i < NWJ * DT_NST; i += 256) dst[i] = src[i];
+  }
+#endif
 }
+#undef BOGP_DT_NOW
+#undef BOGP_DT_ISSUE
+#undef BOGP_DT_STORE
 
 // ---------------------------------------------------------------------------------------------------
 // host-side launchers
@@ -961,6 +1038,34 @@ hipError_t launch_contract(const ContractArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 // the last launch's stamps: dims = {nMt, nJ, NJ16, words per wave}; out may be NULL (size query)
+hipError_t debug_contract_trace(unsigned long long* out, size_t cap_words, size_t* used_words, int* dims) {
+  if (used_words) *used_words = g_trace_used;
+  if (dims) for (int i = 0; i < 4; ++i) dims[i] = g_trace_dims[i];
+  if (!out) return hipSuccess;
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return e;
+  return hipMemcpy(out, g_trace, std::min(cap_words, g_trace_used) * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+#elif defined(CONTRACT_D_TRACE)
+static unsigned long long* g_trace = nullptr;
+static size_t g_trace_words = 0, g_trace_used = 0;
+static int g_trace_dims[4] = {0, 0, 0, 0};
+hipError_t launch_contract(const ContractArgs& a, hipStream_t st) {
+  const size_t need = (size_t)a.nMt * a.nJ * NWJ * DT_NST;
+  if (need > g_trace_words) {
+    if (g_trace) (void)hipFree(g_trace);
+    hipError_t e = hipMalloc((void**)&g_trace, need * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    g_trace_words = need;
+  }
+  const bool keep = need >= g_trace_used;  // the stamps of the LARGEST launch seen are kept
+  if (keep) {
+    g_trace_used = need;
+    g_trace_dims[0] = a.nMt; g_trace_dims[1] = a.nJ; g_trace_dims[2] = a.NJ16; g_trace_dims[3] = DT_NST;
+  }
+  hipLaunchKernelGGL(k_contract16d, dim3((unsigned)(a.nMt * a.nJ)), 256, 0, st, a, keep ? g_trace : (unsigned long long*)nullptr);
+  return hipGetLastError();
+}
 hipError_t debug_contract_trace(unsigned long long* out, size_t cap_words, size_t* used_words, int* dims) {
   if (used_words) *used_words = g_trace_used;
   if (dims) for (int i = 0; i < 4; ++i) dims[i] = g_trace_dims[i];
