@@ -51,8 +51,8 @@ __device__ __forceinline__ void mfma16s(double a, double b, d4s& c) {
 // to L2 (+7 % at N = 256; profiles/r03_sweep_scaling.txt).  PH = this block's position inside the RING / 4 blocks the caller
 // unrolls, so that every slot index is a compile-time constant.
 template <int SM_MR, int SM_NR, int RING, int PH>
-__device__ __forceinline__ void small_block16(const bool GUARDED, const double* __restrict__ tile, const double2* __restrict__ vp,
-                                              const size_t (&boff)[SM_NR], const int (&jt)[SM_NR], const int (&aoffm)[SM_MR],
+__device__ __forceinline__ void small_block16(const bool GUARDED, const double* __restrict__ tile, const char* const (&vbase)[SM_NR],
+                                              unsigned& voffB, const int (&jt)[SM_NR], const int (&aoffm)[SM_MR],
                                               int kb, int kp_clamp, double2 (&bq)[RING][SM_NR], d4s (&acc)[SM_MR][SM_NR]) {
   double af[2][SM_MR];
 #pragma unroll
@@ -64,8 +64,12 @@ __device__ __forceinline__ void small_block16(const bool GUARDED, const double* 
     constexpr int AHEAD = RING - 2;
     {
       const int kpn = min(kp + AHEAD, kp_clamp);
+      // (r06, from k_contract16d: scalar base + the lane's constant 32-bit offset, kept opaque here so that hipcc selects the `v_offset, s[base]` form -- with the
+      // offset's zero-extension hoisted out of the loop every load cost a v_lshl_add_u64, a 64-bit VALU operation on the FP64 pipe the MFMAs use)
+      asm volatile("" : "+v"(voffB));
 #pragma unroll
-      for (int ni = 0; ni < SM_NR; ++ni) bq[(4 * PH + s + AHEAD) & (RING - 1)][ni] = vp[boff[ni] + (size_t)kpn * 64];
+      for (int ni = 0; ni < SM_NR; ++ni)
+        bq[(4 * PH + s + AHEAD) & (RING - 1)][ni] = *reinterpret_cast<const double2*>(vbase[ni] + (size_t)kpn * 1024 + voffB);
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -133,14 +137,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep_small(const double* __rest
   // column tiles of this wave: serpentine over the (up to) 32 tiles, so that in every panel every wave carries the same
   // number of sixteen-row groups: tiles {w, 15 - w} end inside panel 0, {16 + w, 31 - w} inside panel 1
   int jt[SM_NR];
-  size_t boff[SM_NR];
+  const char* vbase[SM_NR];  // packed V of tile ni (wave-uniform)
   bool valid[SM_NR];
 #pragma unroll
   for (int ni = 0; ni < SM_NR; ++ni) {
     const int j = (ni >> 1) * HW + ((ni & 1) ? HW - 1 - w : w);
     valid[ni] = j < NJ16;
     jt[ni] = valid[ni] ? j : -1;
-    boff[ni] = (size_t)min(j, NJ16 - 1) * NKP * 64;
+    vbase[ni] = reinterpret_cast<const char*>(Vp + (size_t)min(j, NJ16 - 1) * NKP * 64);
   }
   d4s acc[SM_MR][SM_NR];
 #pragma unroll
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep_small(const double* __rest
 #pragma unroll
     for (int mi = 0; mi < SM_MR; ++mi) aoffm[mi] = lk * 64 + ((16 * mi + li) ^ (par << 4));
   }
-  const double2* __restrict__ vp = Vp + lane;
+  unsigned voffB = (unsigned)lane * 16u;
   const int kp_clamp = NKP - 1;
 
   // optional phase timing (BOGP_SMALL_STAMPS=1): wave-cycles spent producing / contracting / in the epilogue, summed
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep_small(const double* __rest
 #pragma unroll
   for (int kp0 = 0; kp0 < RING - 2; ++kp0)  // in flight while the first panel is produced
 #pragma unroll
-    for (int ni = 0; ni < SM_NR; ++ni) bq[kp0][ni] = vp[boff[ni] + (size_t)min(kp0, kp_clamp) * 64];
+    for (int ni = 0; ni < SM_NR; ++ni) bq[kp0][ni] = *reinterpret_cast<const double2*>(vbase[ni] + (size_t)min(kp0, kp_clamp) * 1024 + voffB);
   // ONE loop over the 32-row blocks; at every panel boundary all waves meet, produce the next 256 rows of r into LDS and
   // meet again.  Between two boundaries a wave runs its blocks with no barrier; a wave whose tiles are finished idles at
   // the next boundary only (every wave carries the same MFMA count per panel, so they arrive together).
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep_small(const double* __rest
       bool full = true;                                                                                                \
       _Pragma("unroll") for (int ni = 0; ni < SM_NR; ++ni) full = full && (jt[ni] >= 2 * (kb + PH_) + 1);               \
       const double* tile = rs + ((kb + PH_) & (PANEL / 32 - 1)) * 32 * 64;                                          \
-      small_block16<SM_MR, SM_NR, RING, (PH_ < UNR ? PH_ : 0)>(!full, tile, vp, boff, jt, aoffm, kb + PH_, kp_clamp, bq, acc); \
+      small_block16<SM_MR, SM_NR, RING, (PH_ < UNR ? PH_ : 0)>(!full, tile, vbase, voffB, jt, aoffm, kb + PH_, kp_clamp, bq, acc); \
     }
     BOGP_SMALL_BLOCK(0)
     BOGP_SMALL_BLOCK(1)
