@@ -208,11 +208,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int nb1 = min(a.Np, nb0 + a.nblk_per_split * 32);
   typedef double d4t __attribute__((ext_vector_type(4)));
   double mu[4] = {0.0, 0.0, 0.0, 0.0}, wd[4] = {0.0, 0.0, 0.0, 0.0};
+  // (r06, from k_contract16d: every global address of the loop is a wave-uniform base + a lane-constant 32-bit offset, kept opaque inside the loop so that
+  // hipcc selects the `v_offset, s[base]` form -- hoisted, each access cost a v_lshl_add_u64 on the FP64 pipe that the MFMAs and the profile's arithmetic share)
+  unsigned offA = (unsigned)(((size_t)lk * a.Np + li) * sizeof(double));   // XthT: row lk of a k-step, training point li of the block
+  unsigned offN = (unsigned)(lk * sizeof(double));                          // xnorm / gamma / w: training point 4 c + lk
+  unsigned offR = (unsigned)(((size_t)lk * a.Mc + li) * sizeof(double));   // rT: row 4 c + lk of the block, candidate 16 t + li
+  const char* const xthB = reinterpret_cast<const char*>(XthT);
+  const char* const xnB = reinterpret_cast<const char*>(xnorm);
+  const char* const gaB = reinterpret_cast<const char*>(gamma);
+  const char* const wvB = reinterpret_cast<const char*>(wvec);
+  char* const rtB = reinterpret_cast<char*>(rT + mc0);
   for (int n0 = nb0 + 16 * g; n0 < nb1; n0 += 64) {
+#define BOGP_OPQ(o_) asm("" : "+v"(o_))  /* (beside EVERY access: the zero-extension must sit in the access's own basic block to be matched) */
     d4t acc[4];
     // a_m . b_n over the dimensions, four at a time
     {
-      const double* __restrict__ ap = XthT + (size_t)lk * a.Np + n0 + li;
+      const char* __restrict__ apb = xthB + (size_t)n0 * sizeof(double);
       const double* bp = xs + lk * 64 + li;
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = (d4t){0.0, 0.0, 0.0, 0.0};
@@ -220,7 +231,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       for (int ks0 = 0; ks0 < KS; ks0 += KB) {
         double av[KB];
 #pragma unroll
-        for (int u = 0; u < KB; ++u) av[u] = (4 * (ks0 + u) + lk) < d ? ap[(size_t)4 * (ks0 + u) * a.Np] : 0.0;
+        for (int u = 0; u < KB; ++u)
+        {
+          BOGP_OPQ(offA);
+          av[u] = (4 * (ks0 + u) + lk) < d ? *reinterpret_cast<const double*>(apb + (size_t)4 * (ks0 + u) * a.Np * sizeof(double) + offA) : 0.0;
+        }
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
           if (ks0 + u < KS) {
@@ -237,7 +252,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // this lane's four training rows n0 + 4 c + lk: norm, gamma, w (the loads fly while the matrix pipe drains)
     double nbv[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) nbv[c] = xnorm[n0 + 4 * c + lk];
+    for (int c = 0; c < 4; ++c) {
+      BOGP_OPQ(offN);
+      nbv[c] = *reinterpret_cast<const double*>(xnB + (size_t)(n0 + 4 * c) * sizeof(double) + offN);
+    }
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 #pragma unroll
     for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(acc[t]));
@@ -289,12 +307,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      double* __restrict__ rrow = rT + (size_t)(n0 + 4 * c + lk) * a.Mc + mc0 + li;
-      const double gv = gamma[n0 + 4 * c + lk], wv = wvec[n0 + 4 * c + lk];
+      char* __restrict__ rrow = rtB + (size_t)(n0 + 4 * c) * a.Mc * sizeof(double);
+      BOGP_OPQ(offN);
+      const double gv = *reinterpret_cast<const double*>(gaB + (size_t)(n0 + 4 * c) * sizeof(double) + offN);
+      const double wv = *reinterpret_cast<const double*>(wvB + (size_t)(n0 + 4 * c) * sizeof(double) + offN);
+      BOGP_OPQ(offR);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const double r = corr_profile<KERNEL>(s2[t][c], pexp);
-        rrow[16 * t] = r;
+        *reinterpret_cast<double*>(rrow + 16 * t * sizeof(double) + offR) = r;
         mu[t] = __builtin_fma(r, gv, mu[t]);
         wd[t] = __builtin_fma(r, wv, wd[t]);
       }
@@ -321,6 +342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
+#undef BOGP_OPQ
 // ---------------------------------------------------------------------------------------------------
 // Kernel B: triangular contraction  ss_part[jg][m] = sum_{j in group jg} (sum_{n<=j} V[j][n] r[m][n])^2
 // ---------------------------------------------------------------------------------------------------
