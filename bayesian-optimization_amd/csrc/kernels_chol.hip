@@ -542,22 +542,27 @@ __device__ __forceinline__ void mm128_tile(const MmTile& t, double* lds) {
   }
   const int nkb = (t.k1 - t.k0) / MKB;
   if (nkb > 0) {
-    const int srow = tid >> 6, scol = (tid & 63) * 2;
-    const double* __restrict__ rbase = t.Rs + (size_t)t.k0 * t.ldr + scol;
-    const double* __restrict__ cbase = t.Cs + (size_t)t.k0 * t.ldc + scol;
+    const int srow = w, scol = (tid & 63) * 2;  // (the staged row of a thread is its wave's index: wave-uniform)
+    // (r06, from k_contract16d: wave-uniform base + the lane's constant 32-bit offset, kept opaque beside the loads so that hipcc selects the `v_offset, s[base]`
+    // form -- a hoisted zero-extension costs a v_lshl_add_u64 per load, a 64-bit VALU operation on the FP64 pipe the MFMAs use)
+    const char* const rbase = reinterpret_cast<const char*>(t.Rs + (size_t)t.k0 * t.ldr);
+    const char* const cbase = reinterpret_cast<const char*>(t.Cs + (size_t)t.k0 * t.ldc);
+    unsigned loff = (unsigned)scol * (unsigned)sizeof(double);
     double2 r0, r1, r2, r3, c0, c1, c2, c3;
 #define BOGP_MM_LOAD(kb_)                                                                 \
   do {                                                                                    \
-    const double* pr_ = rbase + (size_t)((kb_)*MKB + srow) * t.ldr;                       \
-    const double* pc_ = cbase + (size_t)((kb_)*MKB + srow) * t.ldc;                       \
-    r0 = *reinterpret_cast<const double2*>(pr_);                                          \
-    r1 = *reinterpret_cast<const double2*>(pr_ + (size_t)4 * t.ldr);                      \
-    r2 = *reinterpret_cast<const double2*>(pr_ + (size_t)8 * t.ldr);                      \
-    r3 = *reinterpret_cast<const double2*>(pr_ + (size_t)12 * t.ldr);                     \
-    c0 = *reinterpret_cast<const double2*>(pc_);                                          \
-    c1 = *reinterpret_cast<const double2*>(pc_ + (size_t)4 * t.ldc);                      \
-    c2 = *reinterpret_cast<const double2*>(pc_ + (size_t)8 * t.ldc);                      \
-    c3 = *reinterpret_cast<const double2*>(pc_ + (size_t)12 * t.ldc);                     \
+    const char* pr_ = rbase + (size_t)((kb_)*MKB + srow) * t.ldr * sizeof(double);        \
+    const char* pc_ = cbase + (size_t)((kb_)*MKB + srow) * t.ldc * sizeof(double);        \
+    const size_t sr_ = (size_t)4 * t.ldr * sizeof(double), sc_ = (size_t)4 * t.ldc * sizeof(double); \
+    asm volatile("" : "+v"(loff));                                                        \
+    r0 = *reinterpret_cast<const double2*>(pr_ + loff);                                   \
+    r1 = *reinterpret_cast<const double2*>(pr_ + sr_ + loff);                             \
+    r2 = *reinterpret_cast<const double2*>(pr_ + 2 * sr_ + loff);                         \
+    r3 = *reinterpret_cast<const double2*>(pr_ + 3 * sr_ + loff);                         \
+    c0 = *reinterpret_cast<const double2*>(pc_ + loff);                                   \
+    c1 = *reinterpret_cast<const double2*>(pc_ + sc_ + loff);                             \
+    c2 = *reinterpret_cast<const double2*>(pc_ + 2 * sc_ + loff);                         \
+    c3 = *reinterpret_cast<const double2*>(pc_ + 3 * sc_ + loff);                         \
   } while (0)
 #define BOGP_MM_STORE(buf_)                                                               \
   do {                                                                                    \
