@@ -50,10 +50,49 @@ __device__ __forceinline__ void mfma16s(double a, double b, d4s& c) {
 // absent tiles would have taken carry an 8-slot ring instead: the wave has half the MFMAs per k-pair to cover each round trip
 // to L2 (+7 % at N = 256; profiles/r03_sweep_scaling.txt).  PH = this block's position inside the RING / 4 blocks the caller
 // unrolls, so that every slot index is a compile-time constant.
-template <int SM_MR, int SM_NR, int RING, int PH>
+template <int SM_MR, int SM_NR, int RING, int PH, bool KPB>
 __device__ __forceinline__ void small_block16(const bool GUARDED, const double* __restrict__ tile, const char* const (&vbase)[SM_NR],
                                               unsigned& voffB, const int (&jt)[SM_NR], const int (&aoffm)[SM_MR],
                                               int kb, int kp_clamp, double2 (&bq)[RING][SM_NR], d4s (&acc)[SM_MR][SM_NR]) {
+  if constexpr (KPB) {
+  // (r06, default: the k-pair's four B requests AND the eight A reads of its two k-steps in ONE block in front of its MFMAs -- one hand-over of the issue port a
+  // k-pair instead of three; the LDS round trip is then exposed once a k-pair and left to the SIMD's other wave.  KPB = the eight-wave workgroups with four tiles a
+  // wave (256 < Np <= 512): -1.7 % at N = 512, -3.5 % at 384; the schedules of Np <= 256 (two workgroups a CU, or two tiles a wave) lose 2-6 % with it and keep the
+  // r02-r05 order below: A reads one k-step ahead of the MFMAs that use them)
+  double af[2][SM_MR];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int kp = kb * 4 + s;
+    const int kb16 = kp >> 1;
+    constexpr int AHEAD = RING - 2;
+    {
+      const int kpn = min(kp + AHEAD, kp_clamp);
+      asm volatile("" : "+v"(voffB));
+#pragma unroll
+      for (int ni = 0; ni < SM_NR; ++ni)
+        bq[(4 * PH + s + AHEAD) & (RING - 1)][ni] = *reinterpret_cast<const double2*>(vbase[ni] + (size_t)kpn * 1024 + voffB);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const double* trow = tile + (4 * (2 * s + h)) * 64;
+#pragma unroll
+      for (int mi = 0; mi < SM_MR; ++mi) af[h][mi] = trow[aoffm[mi]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int ni = 0; ni < SM_NR; ++ni) {
+        if (!GUARDED || kb16 <= jt[ni]) {
+          const double bv = h == 0 ? bq[(4 * PH + s) & (RING - 1)][ni].x : bq[(4 * PH + s) & (RING - 1)][ni].y;
+#pragma unroll
+          for (int mi = 0; mi < SM_MR; ++mi) mfma16s(af[h][mi], bv, acc[mi][ni]);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  } else {
   double af[2][SM_MR];
 #pragma unroll
   for (int mi = 0; mi < SM_MR; ++mi) af[0][mi] = tile[aoffm[mi]];
@@ -64,9 +103,8 @@ __device__ __forceinline__ void small_block16(const bool GUARDED, const double* 
     constexpr int AHEAD = RING - 2;
     {
       const int kpn = min(kp + AHEAD, kp_clamp);
-      // (r06, from k_contract16d: scalar base + the lane's constant 32-bit offset, kept opaque here so that hipcc selects the `v_offset, s[base]` form -- with the
-      // offset's zero-extension hoisted out of the loop every load cost a v_lshl_add_u64, a 64-bit VALU operation on the FP64 pipe the MFMAs use)
-      asm volatile("" : "+v"(voffB));
+      // (the schedules of Np <= 256 keep the 64-bit address adds: with the scalar-base form they measured 2-4 % SLOWER -- N = 128 0.990 -> 1.012 ms, N = 256
+      // 2.193 -> 2.280 ms per 1e6 candidates; the offset is therefore not made opaque here and hipcc hoists its zero-extension as before)
 #pragma unroll
       for (int ni = 0; ni < SM_NR; ++ni)
         bq[(4 * PH + s + AHEAD) & (RING - 1)][ni] = *reinterpret_cast<const double2*>(vbase[ni] + (size_t)kpn * 1024 + voffB);
@@ -88,6 +126,7 @@ __device__ __forceinline__ void small_block16(const bool GUARDED, const double* 
         }
       }
     }
+  }
   }
 }
 }  // namespace
@@ -264,7 +303,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sweep_small(const double* __rest
       bool full = true;                                                                                                \
       _Pragma("unroll") for (int ni = 0; ni < SM_NR; ++ni) full = full && (jt[ni] >= 2 * (kb + PH_) + 1);               \
       const double* tile = rs + ((kb + PH_) & (PANEL / 32 - 1)) * 32 * 64;                                          \
-      small_block16<SM_MR, SM_NR, RING, (PH_ < UNR ? PH_ : 0)>(!full, tile, vbase, voffB, jt, aoffm, kb + PH_, kp_clamp, bq, acc); \
+      small_block16<SM_MR, SM_NR, RING, (PH_ < UNR ? PH_ : 0), (NW == 8 && SM_NR == 4)>(!full, tile, vbase, voffB, jt, aoffm, kb + PH_, kp_clamp, bq, acc); \
     }
     BOGP_SMALL_BLOCK(0)
     BOGP_SMALL_BLOCK(1)
