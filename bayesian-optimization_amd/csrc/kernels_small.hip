@@ -63,7 +63,10 @@ __device__ __forceinline__ void small_block16(const bool GUARDED, const double* 
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int kp = kb * 4 + s;
-    const int kb16 = kp >> 1;
+    int kb16 = kp >> 1;
+    // (opaque per k-pair: shared between the two k-pairs of a sixteen-row group, hipcc parks each tile's test in a VGPR -- v_cndmask + v_cmp per tile and k-pair,
+    // VALU instructions between the MFMA bursts -- instead of repeating a scalar compare)
+    asm volatile("" : "+s"(kb16));
     constexpr int AHEAD = RING - 2;
     {
       const int kpn = min(kp + AHEAD, kp_clamp);
@@ -79,11 +82,12 @@ __device__ __forceinline__ void small_block16(const bool GUARDED, const double* 
       for (int mi = 0; mi < SM_MR; ++mi) af[h][mi] = trow[aoffm[mi]];
     }
     __builtin_amdgcn_sched_barrier(0);
+    // tile by tile, both k-steps of a tile behind ONE test: bursts of eight MFMAs, four tests a k-pair (every accumulator still sees k-step 0 before k-step 1)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int ni = 0; ni < SM_NR; ++ni) {
+      if (!GUARDED || kb16 <= jt[ni]) {
 #pragma unroll
-      for (int ni = 0; ni < SM_NR; ++ni) {
-        if (!GUARDED || kb16 <= jt[ni]) {
+        for (int h = 0; h < 2; ++h) {
           const double bv = h == 0 ? bq[(4 * PH + s) & (RING - 1)][ni].x : bq[(4 * PH + s) & (RING - 1)][ni].y;
 #pragma unroll
           for (int mi = 0; mi < SM_MR; ++mi) mfma16s(af[h][mi], bv, acc[mi][ni]);
