@@ -82,6 +82,7 @@ SIGNATURES = {
     "bogp_last_timing": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip]),
     "bogp_flops_per_candidate": (C.c_double, [C.c_void_p]),
     "bogp_nll_path": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "bogp_chol_wide_panels": (C.c_int, [C.c_int, _ip, C.c_int]),
     "bogp_selftest_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, _dp, C.c_int64, _dp]),
     "bogp_selftest_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _dp, C.c_int, C.c_double, _dp, C.c_int, C.c_int, C.c_int]),
 }

@@ -59,6 +59,12 @@ static int fit_readback(bogp_handle* h, const double* dS, int nS, double* blk /*
 // pend == nullptr: queue the device work, read info + scalars back, finish (ONE host synchronisation).
 // pend != nullptr: queue only -- the caller appends its own device work (the likelihood gradient), reads everything back in ONE
 // synchronisation and calls factorize_finish itself.
+extern "C" int bogp_chol_wide_panels(int N, int* widths, int cap) {
+  if (N <= 0) return 0;
+  const int ld = N > 6080 ? ((N + 127) / 128) * 128 : ((N + 63) / 64) * 64;  // bogp_set_train's leading dimension
+  return chol_wide_panels(ld, widths, cap < 0 ? 0 : cap);
+}
+
 extern "C" int bogp_nll_path(int N, int d, int trend, int n_targets) {
   if (N <= 0 || d <= 0 || trend != BOGP_TREND_CONSTANT || n_targets != 1) return BOGP_NLL_PATH_GENERAL;
   if (getenv("BOGP_NLL_FUSED") && atoi(getenv("BOGP_NLL_FUSED")) == 0) return BOGP_NLL_PATH_GENERAL;

@@ -173,6 +173,7 @@ hipError_t launch_pad_identity(double* A, int N, int ld, hipStream_t st);
 // st2 + ev[2] (optional): a second stream and two events for the look-ahead of the large-matrix path; N (optional): the
 // data columns -- [N, ld) is identity padding whose diagonal-block steps are skipped; chain_flags (optional, with st2 and ev):
 // 2 * (ld / 64) words for the resident diagonal chain of the fused block columns (k_chol_chain)
+int chol_wide_panels(int ld, int* widths, int cap);  // wide first panels launch_chol_lower takes at this leading dimension (host only)
 hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStream_t st, hipStream_t st2 = nullptr,
                              hipEvent_t* ev = nullptr, double* scratch = nullptr, int N = 0, unsigned int* chain_flags = nullptr);
 hipError_t launch_tri_inverse(const double* L, const double* Winv, double* V, double* U, double* T, int ld, hipStream_t st);

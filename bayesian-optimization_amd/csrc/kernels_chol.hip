@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256, 2) void k_mm128(MmArgs a, int mode0) {
     mm128_tile(g, mm_lds);
     return;
   }
-  if (a.order && mode != MM_SYRK) {
+  if (a.order) {
     // Longest K first, only tiles that exist: the dispatcher hands out workgroups in index order as slots free up, and
     // consecutive indices go to different XCDs -- every XCD sees the same mix of long and short tiles.  (The products are not
     // bound by operand traffic -- identical times with every k-row at one address -- so the XCD-local super tiles of
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(256, 2) void k_mm128(MmArgs a, int mode0) {
     // steer the real ones onto a subset of the CUs (measured at N = 6144), hence the compaction over the partial last pair:
     // fp full pairs, and nl < nb2 live tile rows / columns of block 22 in one more pair.
     const int q = (int)blockIdx.x, nb2 = a.nb2, fp = a.fp, nl = a.nl;
-    if (mode == MM_UUT) {  // row ti has ti + 1 tiles, K shrinks with ti
+    if (mode == MM_UUT || mode == MM_SYRK) {  // row ti has ti + 1 tiles (MM_UUT: K shrinks with ti)
       ti = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
       while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
       while (ti * (ti + 1) / 2 > q) --ti;
@@ -798,13 +798,27 @@ static bool big_path(int ld) {
   return ld >= BIG_LD && ld % MB == 0 && !(e && atoi(e) != 0);
 }
 
-// The two-level factorisation is kept behind BOGP_BIG_CHOL=1: its panel chain (a k_chol_panel + k_chol_update pair per block
-// column, ~33 us each, bound by the 64-pivot diagonal block) runs beside the trailing update in the one-level variant
-// (workgroup 0 of k_chol_update) but ahead of it here, and the look-ahead on a second stream does not hide it (the small
-// chain kernels queue behind the update's workgroups): 9.5 ms against 8.9 ms at N = 8192.  The inverse and R^-1 do win.
-static bool big_chol(int ld) {
+// Wide first panels of the large-N Cholesky (r06, launch_chol_lower): block columns per wide panel, in order; the block columns behind them run
+// the one-level chain.  BOGP_BIG_CHOL = "0": none; a comma list ("32", "16,16", ...): that schedule (A/B runs, tools/ab/ab_big_chol.sh); unset: by size.
+static int wide_panels(int ld, int* widths, int cap) {
+  if (!big_path(ld)) return 0;
   const char* e = getenv("BOGP_BIG_CHOL");
-  return big_path(ld) && e && atoi(e) != 0;
+  int n = 0;
+  if (e) {
+    while (*e && n < cap) {
+      const int v = atoi(e);
+      if (v > 0) widths[n++] = v;
+      while (*e && *e != ',') ++e;
+      if (*e == ',') ++e;
+    }
+    return n;
+  }
+  // by size: panels of 24 block columns while at least 72 block columns (4608 rows) stay behind them -- N = 6144 ... 7552: one, 7680 ... 9088: two, ...
+  // (measured, profiles/r06_wide_panels_ab.txt: 16 ... 32 columns a panel and one panel more or less are within 0.1 ms of each other at every size;
+  // behind 72 block columns the one-level chain's updates are within a third of the diagonal chain's floor and a wide panel buys nothing)
+  const int nb = ld / CB;
+  for (int k = 0; n < cap && nb - (k + 24) >= 72; k += 24) widths[n++] = 24;
+  return n;
 }
 
 // k_mm128's 73.7 KB of dynamic LDS must be granted once PER DEVICE (hipFuncSetAttribute acts on the current device's copy of the function),
@@ -834,9 +848,9 @@ static hipError_t launch_mm128(MmArgs a, int mode, int TI, int TJ, int ny, int n
   constexpr int order = 1;  // (the tile orders that lost: tools/ab/ab_mm128_order.sh, EXPERIMENTS.md)
   a.fixed = 0;
   a.order = order;
-  if (order && mode != MM_SYRK && nz == 1) {
+  if (order && nz == 1 && (mode != MM_SYRK || (a.cj0 == 0 && a.cj1 >= TI && TI == TJ))) {
     unsigned count;
-    if (mode == MM_UUT) {
+    if (mode == MM_UUT || mode == MM_SYRK) {  // (SYRK: every live tile has the same K -- the compact triangular grid only drops the workgroups that would exit)
       count = (unsigned)(TI * (TI + 1) / 2);
     } else {  // ny pairs of diagonal blocks of nb2 tiles each; block 22 of the last pair may be cut by the matrix edge
       const int nb2 = a.nb2;
@@ -869,64 +883,6 @@ hipError_t launch_mm128_gen(const double* Rs, int ldr, const double* Cs, int ldc
   a.gldr = ldr; a.gldc = ldc; a.gldo = ldo; a.gK = K;
   a.TI = TI; a.TJ = TJ;
   hipLaunchKernelGGL(k_mm128, dim3((unsigned)(TI * TJ), 1, 1), 256, shm, st, a, (int)MM_GEN);
-  return hipGetLastError();
-}
-
-// two-level right-looking Cholesky: panels of 4 block columns (256); inside a panel the 64-block kernels with their updates
-// confined to the panel; then one rank-256 update of the trailing matrix and the factorisation of its first block.
-// With a second stream (st2 + two events) the update is split with LOOK-AHEAD: the two column tiles that form the NEXT
-// panel are updated on the main stream, which then goes on factoring that panel (a serial chain of ~33 us per block
-// column: 64 pivots each), while the rest of the trailing matrix is updated on st2 beside it.
-static hipError_t launch_chol_lower_big(double* A, int ld, double* Winv, int* info, hipStream_t st, hipStream_t st2,
-                                        hipEvent_t* ev) {
-  const int nb = ld / CB;
-  const bool ahead = st2 != nullptr && ev != nullptr;
-  bool rest_pending = false;
-  hipLaunchKernelGGL(k_chol_first, dim3(1), 256, 0, st, A, ld, Winv, info, 0, 1);
-  static const int PWB = [] {  // block columns per panel (8 = 512 wide: measured 18.3 ms per llf+gradient at N = 8192 against 18.8 with 4 and 20.0 with 2)
-    return 8;
-  }();
-  for (int kbeg = 0; kbeg < nb; kbeg += PWB) {
-    const int kend = min(nb, kbeg + PWB);
-    for (int k = kbeg; k < kend; ++k) {
-      const int m = nb - k - 1, k0 = k * CB;
-      if (m == 0) break;
-      hipLaunchKernelGGL(k_chol_panel, dim3(m), 256, 0, st, Winv + (size_t)k * CB * CB, A + (size_t)k0 * ld + k0 + CB, ld);
-      const int nc = kend - 1 - k;  // block columns of this panel still to the right of k
-      if (nc > 0)
-        hipLaunchKernelGGL(k_chol_update, dim3(m * nc), 256, 0, st, A, ld, k0, 1, k0 + CB, m, nc,
-                           Winv + (size_t)(k + 1) * CB * CB, info, (double*)nullptr, 0, CB);
-    }
-    if (kend < nb) {
-      MmArgs a{};
-      a.A = A; a.ld = ld; a.nt = ld / MB;
-      a.t0 = kend / 2; a.kp0 = kbeg * CB; a.kp1 = kend * CB;
-      const int TT = a.nt - a.t0;
-      hipError_t e;
-      if (!ahead || TT <= PWB / 2) {
-        a.cj0 = 0; a.cj1 = TT;
-        if ((e = launch_mm128(a, MM_SYRK, TT, TT, 1, 1, st)) != hipSuccess) return e;
-      } else {
-        // the previous panel's remainder update (st2) writes the same trailing columns: it has to be through first
-        if (rest_pending && (e = hipStreamWaitEvent(st, ev[1], 0)) != hipSuccess) return e;
-        const int nstrip = min(TT, PWB / 2);
-        a.cj0 = 0; a.cj1 = nstrip;  // the next panel's column tiles
-        if ((e = launch_mm128(a, MM_SYRK, TT, nstrip, 1, 1, st)) != hipSuccess) return e;
-        if ((e = hipEventRecord(ev[0], st)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(st2, ev[0], 0)) != hipSuccess) return e;
-        a.cj0 = nstrip; a.cj1 = TT;
-        if ((e = launch_mm128(a, MM_SYRK, TT, TT, 1, 1, st2)) != hipSuccess) return e;
-        if ((e = hipEventRecord(ev[1], st2)) != hipSuccess) return e;
-        rest_pending = true;
-      }
-      hipLaunchKernelGGL(k_chol_first, dim3(1), 256, 0, st, A + (size_t)kend * CB * (ld + 1), ld, Winv + (size_t)kend * CB * CB, info,
-                         kend * CB, 0);
-    }
-  }
-  if (rest_pending) {
-    hipError_t e = hipStreamWaitEvent(st, ev[1], 0);
-    if (e != hipSuccess) return e;
-  }
   return hipGetLastError();
 }
 
@@ -975,6 +931,20 @@ hipError_t launch_uut(const double* U, double* Rinv, int ld, hipStream_t st, int
   return hipGetLastError();
 }
 
+// the schedule launch_chol_lower takes for a matrix of leading dimension ld (bogp_chol_wide_panels; no device call)
+int chol_wide_panels(int ld, int* widths, int cap) {
+  int w[16];
+  const int n = wide_panels(ld, w, 16), nb = ld / CB;
+  int kept = 0, kend = 0;
+  for (int p = 0; p < n; ++p) {  // launch_chol_lower's own conditions
+    kend += w[p];
+    if ((kend & 1) || nb - kend - 1 <= 32 + 1) break;
+    if (kept < cap && widths) widths[kept] = w[p];
+    ++kept;
+  }
+  return kept;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // identity padding of an ld x ld column-major matrix outside its leading N x N block
 // ---------------------------------------------------------------------------------------------------------------
@@ -999,7 +969,6 @@ hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStre
   if (N <= 0 || N > ld) N = ld;
   auto live = [&](int col0) { return max(0, min(CB, N - col0)); };  // data columns of the 64-block that starts at col0
   const int nb = ld / CB;
-  if (big_chol(ld)) return launch_chol_lower_big(A, ld, Winv, info, st, st2, ev);
   hipLaunchKernelGGL(k_chol_first, dim3(1), 256, 0, st, A, ld, Winv, info, 0, 1, live(0));
   // BOGP_CHOL_GROUP=G > 1 (experiment, default 1): block columns in groups of G -- inside a group the update after panel k
   // touches only block column k + 1 (with all the group's panels so far), the group's LAST panel triggers ONE rank-64 G
@@ -1033,7 +1002,42 @@ hipError_t launch_chol_lower(double* A, int ld, double* Winv, int* info, hipStre
   const bool chain = chain_on && chain_flags != nullptr && st2 != nullptr && ev != nullptr && can_fuse && tri && kf + 1 < nb;
   unsigned int* flagW = chain ? chain_flags : nullptr;
   unsigned int* flagT = chain ? chain_flags + nb : nullptr;
-  for (int kbeg = 0; kbeg + 1 < nb; kbeg += G) {
+  // Wide first panels (r06).  The one-level chain reads and writes the whole trailing triangle once per block column: 537 MB at the first column of
+  // N = 8192, 143 us = 3.75 TB/s -- its early block columns are HBM bound (profiles/r05_big_chol_trace.txt).  Inside a wide panel of w block columns
+  // the rank-64 updates are confined to the panel's own columns (the strip: ld x 64 w doubles, it fits the Infinity Cache), and ONE rank-64 w product
+  // on 128 x 128 tiles (k_mm128, compute bound at K >= 1024) brings the rest of the trailing matrix up to date; the diagonal chain of the panel runs
+  // beside the strip updates (workgroup 0 of k_chol_update) as everywhere else.  Only the FIRST columns are worth it -- later the trailing triangle is
+  // small enough for the one-level chain to be bound by its diagonal blocks -- so the schedule is a short list of widths, not a uniform panel size
+  // (the uniform two-level variant of r02-r05, 8 block columns a panel with a look-ahead stream, lost to the one-level chain and is gone).
+  int kstart = 0;
+  {
+    int widths[16];
+    const int nw = wide_panels(ld, widths, 16);
+    for (int p = 0; p < nw; ++p) {
+      const int kbeg = kstart, kend = kbeg + widths[p];
+      // k_mm128 works on 128-tiles; the chain behind the last wide panel must start with an unfused step (a fused one reads the copy of the unsolved
+      // panel that the step before it leaves)
+      if ((kend & 1) || nb - kend - 1 <= fuse_max + 1 || kend * CB >= N) break;
+      for (int k = kbeg; k < kend; ++k) {
+        const int m = nb - k - 1, k0 = k * CB, nc = kend - 1 - k;
+        hipLaunchKernelGGL(k_chol_panel, dim3(m), 256, 0, st, Winv + (size_t)k * CB * CB, A + (size_t)k0 * ld + k0 + CB, ld);
+        if (nc > 0)
+          hipLaunchKernelGGL(k_chol_update, dim3(m * nc), 256, 0, st, A, ld, k0, 1, k0 + CB, m, nc, Winv + (size_t)(k + 1) * CB * CB, info,
+                             (double*)nullptr, 0, live(k0 + CB));
+      }
+      MmArgs a{};
+      a.A = A; a.ld = ld; a.nt = ld / MB;
+      a.t0 = kend / 2; a.kp0 = kbeg * CB; a.kp1 = kend * CB;
+      const int TT = a.nt - a.t0;
+      a.cj0 = 0; a.cj1 = TT;
+      hipError_t e = launch_mm128(a, MM_SYRK, TT, TT, 1, 1, st);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k_chol_first, dim3(1), 256, 0, st, A + (size_t)kend * CB * (ld + 1), ld, Winv + (size_t)kend * CB * CB, info, kend * CB, 0,
+                         live(kend * CB));
+      kstart = kend;
+    }
+  }
+  for (int kbeg = kstart; kbeg + 1 < nb; kbeg += G) {
     for (int k = kbeg; k < kbeg + G && k + 1 < nb; ++k) {
       const int k0 = k * CB;
       const int m = nb - k - 1;

@@ -79,6 +79,37 @@ def test_likelihood_path_by_size():
         del os.environ["BOGP_NLL_ELIM"]
 
 
+def test_wide_panel_schedule_of_the_large_cholesky_by_size():
+    """bogp_chol_wide_panels: the first block columns of the general path's Cholesky (gpr.py:795) run as wide panels from ld = 6144 on -- 24 block
+    columns a panel while 72 stay behind them -- decided from the size and BOGP_BIG_CHOL alone (no handle, no device call); a list in the switch is
+    taken as given as far as launch_chol_lower's own conditions allow (even column count, an unfused chain behind the last panel)."""
+    import ctypes as C
+
+    lib = _lib.load()
+
+    def sched(N):
+        w = (C.c_int * 16)()
+        n = lib.bogp_chol_wide_panels(N, w, 16)
+        return [int(w[i]) for i in range(n)]
+
+    assert [sched(N) for N in (0, 100, 3073, 4096, 6080)] == [[]] * 5   # 64-block path: no wide panels
+    assert sched(6081) == sched(6144) == sched(7000) == sched(7552) == [24]
+    assert sched(7553) == sched(8192) == sched(9088) == [24, 24]
+    assert sched(10240) == [24, 24, 24] and sched(16384) == [24] * 7
+    assert lib.bogp_chol_wide_panels(8192, None, 0) == 2                # count only
+    for value, expect in (("0", []), ("32", [32]), ("16,10,6", [16, 10, 6]), ("15,16", []), ("16,15", [16]), ("64,40", [64])):
+        os.environ["BOGP_BIG_CHOL"] = value
+        try:
+            assert sched(8192) == expect, value
+        finally:
+            del os.environ["BOGP_BIG_CHOL"]
+    os.environ["BOGP_NO_BIG_FIT"] = "1"
+    try:
+        assert sched(8192) == []
+    finally:
+        del os.environ["BOGP_NO_BIG_FIT"]
+
+
 def test_oracle_ids_match_library_ids():
     from oracle import gp_oracle as O
 

@@ -382,10 +382,12 @@ def test_mle_restarts_on_several_streams_of_one_gpu():
 
 @pytest.mark.parametrize("N", [6144, 6200, 7000])
 def test_large_fit_path_equals_the_64_block_path(N):
-    """From ld = 6144 on the inverse and R^-1 = U U^T run on 128 x 128 tiles (k_mm128, kernels_chol.hip; with
-    BOGP_BIG_CHOL=1 also a two-level Cholesky with rank-512 trailing updates).  Same mathematics, other summation order:
-    likelihood, gradient, committed state and posterior against the 64-block path (BOGP_NO_BIG_FIT=1), incl. sizes whose
-    tile count is not a power of two, and the -inf convention on an indefinite matrix."""
+    """From ld = 6144 on the inverse and R^-1 = U U^T run on 128 x 128 tiles (k_mm128, kernels_chol.hip), and the Cholesky's first block
+    columns as WIDE PANELS (r06: rank-64 updates confined to the panel, one rank-64 w k_mm128 update of the rest; by default 24 block columns a
+    panel while 72 stay behind; BOGP_BIG_CHOL=0: none, a list: that schedule).  Same mathematics, other summation order than the 64-block path: likelihood, gradient,
+    committed state and posterior against the 64-block path (BOGP_NO_BIG_FIT=1), incl. sizes whose tile count is not a power of two, schedules
+    with panels of unequal width, and the -inf convention on an indefinite matrix.  Among themselves the schedules are BIT-identical."""
+    import ctypes
     import os
 
     d = 6
@@ -396,9 +398,12 @@ def test_large_fit_path_equals_the_64_block_path(N):
     par = np.r_[np.full(d, 0.2) * rng.uniform(0.8, 1.2, size=d), 0.9]
     Xs = rng.uniform(-5, 5, size=(300, d))
     out = {}
-    for tag, flag in (("big", "0"), ("small", "1"), ("bigchol", "0")):
-        os.environ["BOGP_NO_BIG_FIT"] = flag
-        os.environ["BOGP_BIG_CHOL"] = "1" if tag == "bigchol" else "0"
+    variants = {"default": (None, None), "small": ("1", None), "one-level": (None, "0"), "one panel": (None, "32"), "three panels": (None, "16,10,6")}
+    for tag, (no_big, sched) in variants.items():
+        for k, v in (("BOGP_NO_BIG_FIT", no_big), ("BOGP_BIG_CHOL", sched)):
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
         try:
             eng = _lib.Engine(0)
             eng.set_train(X, y)
@@ -408,14 +413,25 @@ def test_large_fit_path_equals_the_64_block_path(N):
             eng.upload_candidates(Xs)
             mu, mse = eng.predict()
             out[tag] = (llf, grad, llf_c, st, mu, mse)
-            if tag in ("big", "bigchol"):  # an indefinite matrix (negative nugget: diagonal below the off-diagonal mass) is reported as LAPACK would
+            if tag != "small":  # an indefinite matrix (negative nugget: diagonal below the off-diagonal mass) is reported as LAPACK would
                 with pytest.raises(_lib.NotPositiveDefinite):
                     eng.commit(_lib.KERNEL_SE, _lib.MODE_NOISY, np.r_[np.full(d, 1e-4), 0.9], -0.6)
             eng.close()
         finally:
-            del os.environ["BOGP_NO_BIG_FIT"], os.environ["BOGP_BIG_CHOL"]
-    for variant in ("big", "bigchol"):
-        _compare_fit_outputs(out[variant], out["small"])
+            os.environ.pop("BOGP_NO_BIG_FIT", None)
+            os.environ.pop("BOGP_BIG_CHOL", None)
+    for variant in variants:
+        if variant != "small":
+            _compare_fit_outputs(out[variant], out["small"])
+    # every schedule is the one-level chain's arithmetic in another order of LAUNCHES, not of operations: a wide panel's rank-64 w product starts from
+    # the tile it updates and runs over k in the order of the w rank-64 updates it replaces -- the factor, and everything computed from it, is the same bits
+    w = (ctypes.c_int * 16)()
+    assert _lib.load().bogp_chol_wide_panels(N, w, 16) == 1 and w[0] == 24  # (the default does take a wide panel at these sizes)
+    for variant in ("default", "one panel", "three panels"):
+        np.testing.assert_array_equal(out[variant][3]["C"], out["one-level"][3]["C"])
+        assert out[variant][0] == out["one-level"][0] and out[variant][2] == out["one-level"][2]
+        np.testing.assert_array_equal(out[variant][1], out["one-level"][1])
+        np.testing.assert_array_equal(out[variant][5], out["one-level"][5])
 
 
 def _compare_fit_outputs(b, s):
