@@ -171,8 +171,8 @@ extern "C" int bogp_set_train(bogp_handle* h, const double* X, const double* y, 
     h->M = 0;
     h->last_q = h->last_topk_q = h->last_topk_k = 0;
   }
-  // leading dimension: N rounded up to 64; to 128 from 6144 on, where the inverse and R^-1 work on 128 x 128 tiles
-  const int ld_need = N > 6080 ? ((N + 127) / 128) * 128 : ((N + 63) / 64) * 64;
+  // leading dimension: N rounded up to 64; to 128 above N = 3072 (r06; 6080 before), where the inverse, R^-1 and the Cholesky's wide panels work on 128 x 128 tiles
+  const int ld_need = N > 3072 ? ((N + 127) / 128) * 128 : ((N + 63) / 64) * 64;  // (above the elimination's limit the fit runs on 128 x 128 tiles: kernels_chol.hip, BIG_LD)
   const bool fits = h->dX && h->dtheta && ld_need <= h->cap_ld && d <= h->cap_d && n_targets <= h->cap_nt;
   if (fits) {
     free_trend(h);  // N x p buffers of a polynomial basis: rebuilt on demand

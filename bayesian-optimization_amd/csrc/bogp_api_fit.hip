@@ -61,7 +61,7 @@ static int fit_readback(bogp_handle* h, const double* dS, int nS, double* blk /*
 // synchronisation and calls factorize_finish itself.
 extern "C" int bogp_chol_wide_panels(int N, int* widths, int cap) {
   if (N <= 0) return 0;
-  const int ld = N > 6080 ? ((N + 127) / 128) * 128 : ((N + 63) / 64) * 64;  // bogp_set_train's leading dimension
+  const int ld = N > 3072 ? ((N + 127) / 128) * 128 : ((N + 63) / 64) * 64;  // bogp_set_train's leading dimension
   return chol_wide_panels(ld, widths, cap < 0 ? 0 : cap);
 }
 

@@ -504,7 +504,10 @@ namespace {
 constexpr int MB = 128;        // tile edge
 constexpr int MKB = 16;        // k rows per LDS stage
 constexpr int MPT = MB + 16;   // LDS pitch in doubles
-constexpr int BIG_LD = 6144;  // measured cross-over (tools/time_fit_big.py): 4096 5.1 vs 4.8 ms, 6144 9.9 vs 10.2, 8192 17.6 vs 20.2
+// r02-r05: 6144 (the staged tile core: 4096 5.1 vs 4.8 ms, 6144 9.9 vs 10.2, 8192 17.6 vs 20.2).  With the LDS-free core (mm128_tile_direct) the 128-tile products win wherever
+// the general path runs at all (profiles/r06_mm128_direct_ab.txt: llf + gradient 3.52 -> 3.40 ms at N = 3584, 4.51 -> 4.00 at 4096, 6.86 -> 5.83 at 5120, 9.07 -> 7.64 at 6016), so
+// every training set above the elimination's limit (N > 3072: bogp_set_train rounds the leading dimension to 128 there) takes them.
+constexpr int BIG_LD = 3200;
 
 struct MmTile {
   const double* Rs;  // row-side operand: element (row, k) at Rs[row + k * ldr]
@@ -516,7 +519,7 @@ struct MmTile {
   int beta;          // 1: out += alpha * product
 };
 
-__device__ __forceinline__ void mm128_tile(const MmTile& t, double* lds) {
+__device__ __forceinline__ __attribute__((unused)) void mm128_tile_lds(const MmTile& t, double* lds) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w & 1, wn = w >> 1;  // this wave: rows 64 wm .., columns 64 wn ..
@@ -631,6 +634,121 @@ __device__ __forceinline__ void mm128_tile(const MmTile& t, double* lds) {
       for (int rj = 0; rj < 4; ++rj) o[16 * rj] = t.alpha * acc[ci][rj][r];
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same tile with NO LDS and NO barrier (r06, last session; the default -- `make EXTRA=-DMM128_LDS` builds the staged core above
+// for A/B runs): what k_contract16d did for the sweep (kernels_posterior.hip, DESIGN 5.2'').  Both operands are k-major with the
+// non-contracted index contiguous, so a wave fetches its own fragments straight from global memory: lane (k, i) takes the PAIR of
+// rows 2 i, 2 i + 1 of a 32-row half with one global_load_dwordx4 (four 256-byte runs an instruction) -- fragment f = 2 half + e
+// stands for rows 32 half + 2 i + e, on both sides, and the epilogue stores pairs accordingly (256-byte runs, half as many store
+// instructions).  A k-pair (8 k values) is 8 loads, issued as ONE block in front of its 32 MFMAs, two k-pairs in flight through three
+// register slots; every address is a scalar base + the lane's constant 32-bit offset (kept opaque in the loop: no 64-bit VALU adds on
+// the MFMAs' pipe).  The two waves that share a row (column) half of the tile meet in L1.  Per output element the products run over
+// k in the same order from the same starting value as in the staged core: the SAME BITS (profiles/r06_mm128_direct_ab.txt).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mm128_tile_direct(const MmTile& t) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w & 1, wn = w >> 1;  // this wave: rows 64 wm .., columns 64 wn ..
+  const int lk = lane >> 4, li = lane & 15;
+  d4 acc[4][4];  // [column fragment][row fragment]; fragment f = 2 half + e <-> index 32 half + 2 i + e of the wave's 64
+  // D[i][j] of (ci, rj): lane 16 (i % 4) + j, register i / 4 -> column 64 wn + 32 (ci >> 1) + 2 (4 r + lk) + (ci & 1), rows 64 wm + 32 (rj >> 1) + 2 li + (rj & 1)
+  if (t.beta) {
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double* __restrict__ o = t.out + (size_t)(64 * wn + 32 * (ci >> 1) + 2 * (4 * r + lk) + (ci & 1)) * t.ldo + 64 * wm + 2 * li;
+#pragma unroll
+        for (int hr = 0; hr < 2; ++hr) {
+          const double2 v = *reinterpret_cast<const double2*>(o + 32 * hr);
+          acc[ci][2 * hr][r] = t.alpha * v.x;
+          acc[ci][2 * hr + 1][r] = t.alpha * v.y;
+        }
+      }
+  } else {
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int rj = 0; rj < 4; ++rj) acc[ci][rj] = (d4){0.0, 0.0, 0.0, 0.0};
+  }
+  const int nkp = (t.k1 - t.k0) / 8;  // k-pairs (K ranges are multiples of MKB = 16)
+  if (nkp > 0) {
+    constexpr int DD = 2, DR = DD + 1;  // k-pairs in flight, register slots
+    const int kp_last = nkp - 1;
+    const char* const rbase = reinterpret_cast<const char*>(t.Rs + (size_t)t.k0 * t.ldr + 64 * wm);
+    const char* const cbase = reinterpret_cast<const char*>(t.Cs + (size_t)t.k0 * t.ldc + 64 * wn);
+    const size_t rstride = (size_t)8 * t.ldr * sizeof(double), cstride = (size_t)8 * t.ldc * sizeof(double);  // a k-pair
+    unsigned voffR0 = (unsigned)(((size_t)lk * t.ldr + 2 * li) * sizeof(double));  // k-step 0 of the pair
+    unsigned voffR1 = voffR0 + (unsigned)(4 * (size_t)t.ldr * sizeof(double));   // k-step 1
+    unsigned voffC0 = (unsigned)(((size_t)lk * t.ldc + 2 * li) * sizeof(double));
+    unsigned voffC1 = voffC0 + (unsigned)(4 * (size_t)t.ldc * sizeof(double));
+    double2 rv[DR][2][2], cv[DR][2][2];  // [slot][k-step][half]
+#define BOGP_MMD_LOADS(slot, kpc_)                                                        \
+  do {                                                                                    \
+    const char* pr_ = rbase + (size_t)(kpc_) * rstride;                                   \
+    const char* pc_ = cbase + (size_t)(kpc_) * cstride;                                   \
+    asm volatile("" : "+v"(voffR0), "+v"(voffR1), "+v"(voffC0), "+v"(voffC1));            \
+    cv[slot][0][0] = *reinterpret_cast<const double2*>(pc_ + voffC0);                     \
+    cv[slot][0][1] = *reinterpret_cast<const double2*>(pc_ + voffC0 + 256);               \
+    rv[slot][0][0] = *reinterpret_cast<const double2*>(pr_ + voffR0);                     \
+    rv[slot][0][1] = *reinterpret_cast<const double2*>(pr_ + voffR0 + 256);               \
+    cv[slot][1][0] = *reinterpret_cast<const double2*>(pc_ + voffC1);                     \
+    cv[slot][1][1] = *reinterpret_cast<const double2*>(pc_ + voffC1 + 256);               \
+    rv[slot][1][0] = *reinterpret_cast<const double2*>(pr_ + voffR1);                     \
+    rv[slot][1][1] = *reinterpret_cast<const double2*>(pr_ + voffR1 + 256);               \
+  } while (0)
+#define BOGP_MMD_KPAIR(u, kp_)                                                            \
+  do {                                                                                    \
+    BOGP_MMD_LOADS(((u) + DD) % DR, min((kp_) + DD, kp_last));                            \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h)                                         \
+      _Pragma("unroll") for (int ci = 0; ci < 4; ++ci) {                                  \
+        const double c_ = (ci & 1) ? cv[u][h][ci >> 1].y : cv[u][h][ci >> 1].x;           \
+        _Pragma("unroll") for (int rj = 0; rj < 4; ++rj)                                  \
+          mfma16(c_, (rj & 1) ? rv[u][h][rj >> 1].y : rv[u][h][rj >> 1].x, acc[ci][rj]);  \
+      }                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  } while (0)
+#pragma unroll
+    for (int tt = 0; tt < DD; ++tt) BOGP_MMD_LOADS(tt, min(tt, kp_last));
+    int kp = 0;
+    for (; kp + DR <= nkp; kp += DR) {
+#pragma unroll
+      for (int u = 0; u < DR; ++u) BOGP_MMD_KPAIR(u, kp + u);
+    }
+    for (; kp < nkp; kp += DR) {
+#pragma unroll
+      for (int u = 0; u < DR; ++u)
+        if (kp + u < nkp) BOGP_MMD_KPAIR(u, kp + u);
+    }
+#undef BOGP_MMD_KPAIR
+#undef BOGP_MMD_LOADS
+    BOGP_CHOL_DRAIN();
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int rj = 0; rj < 4; ++rj) asm volatile("" : "+v"(acc[ci][rj]));  // the stores' reads of the accumulators stay behind the drain
+  }
+  // (out = alpha * acc: with beta the accumulators started from alpha * out, and alpha^2 = 1)
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double* __restrict__ o = t.out + (size_t)(64 * wn + 32 * (ci >> 1) + 2 * (4 * r + lk) + (ci & 1)) * t.ldo + 64 * wm + 2 * li;
+#pragma unroll
+      for (int hr = 0; hr < 2; ++hr)
+        *reinterpret_cast<double2*>(o + 32 * hr) = make_double2(t.alpha * acc[ci][2 * hr][r], t.alpha * acc[ci][2 * hr + 1][r]);
+    }
+}
+
+#ifdef MM128_LDS
+constexpr int MM_SHM = 2 * 2 * MKB * MPT * (int)sizeof(double);  // 73.7 KB: two stages of (row tile + column tile)
+__device__ __forceinline__ void mm128_tile(const MmTile& t, double* lds) { mm128_tile_lds(t, lds); }
+#else
+constexpr int MM_SHM = 0;
+__device__ __forceinline__ void mm128_tile(const MmTile& t, double*) { mm128_tile_direct(t); }
+#endif
 
 enum { MM_UUT = 0, MM_T = 1, MM_V = 2, MM_U = 3, MM_SYRK = 4, MM_GEN = 5 };
 struct MmArgs {
@@ -838,8 +956,8 @@ static hipError_t mm128_grant_lds(int shm) {
 }
 
 static hipError_t launch_mm128(MmArgs a, int mode, int TI, int TJ, int ny, int nz, hipStream_t st) {
-  constexpr int shm = 2 * 2 * MKB * MPT * (int)sizeof(double);  // 73.7 KB: two stages of (row tile + column tile)
-  {
+  constexpr int shm = MM_SHM;
+  if (shm > 0) {
     hipError_t e = mm128_grant_lds(shm);
     if (e != hipSuccess) return e;
   }
@@ -873,8 +991,8 @@ static hipError_t launch_mm128(MmArgs a, int mode, int TI, int TJ, int ny, int n
 hipError_t launch_mm128_gen(const double* Rs, int ldr, const double* Cs, int ldc, double* out, int ldo, int TI, int TJ, int K,
                             hipStream_t st) {
   if (TI <= 0 || TJ <= 0) return hipSuccess;
-  constexpr int shm = 2 * 2 * MKB * MPT * (int)sizeof(double);
-  {
+  constexpr int shm = MM_SHM;
+  if (shm > 0) {
     hipError_t e = mm128_grant_lds(shm);
     if (e != hipSuccess) return e;
   }

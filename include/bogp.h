@@ -400,7 +400,7 @@ int bogp_lbfgsb_minimize(int n, int m, double* x, const double* lo, const double
 int bogp_nll_path(int N, int d, int trend, int n_targets);
 
 /* The schedule of WIDE FIRST PANELS the blocked Cholesky of the general path (gpr.py:795, `cholesky(R, lower=True)`) takes for N training
- * points -- no handle, no device call.  Returns the number of wide panels (0 below N = 6081 and with BOGP_BIG_CHOL=0) and writes up to `cap`
+ * points -- no handle, no device call.  Returns the number of wide panels (0 below N = 6017 and with BOGP_BIG_CHOL=0) and writes up to `cap`
  * widths (64-column blocks per panel) to `widths` (may be NULL).  Inside a wide panel the rank-64 updates touch the panel's own columns
  * only and ONE rank-64w product on 128 x 128 tiles updates the rest of the trailing matrix; every schedule yields the SAME BITS as the
  * one-level chain (the products run over k in the same order from the same starting value).  DESIGN.md section 5.9; tests/test_abi.py,

@@ -80,7 +80,7 @@ def test_likelihood_path_by_size():
 
 
 def test_wide_panel_schedule_of_the_large_cholesky_by_size():
-    """bogp_chol_wide_panels: the first block columns of the general path's Cholesky (gpr.py:795) run as wide panels from ld = 6144 on -- 24 block
+    """bogp_chol_wide_panels: the first block columns of the general path's Cholesky (gpr.py:795) run as wide panels from ld = 6144 (N = 6017) on -- 24 block
     columns a panel while 72 stay behind them -- decided from the size and BOGP_BIG_CHOL alone (no handle, no device call); a list in the switch is
     taken as given as far as launch_chol_lower's own conditions allow (even column count, an unfused chain behind the last panel)."""
     import ctypes as C
@@ -92,8 +92,8 @@ def test_wide_panel_schedule_of_the_large_cholesky_by_size():
         n = lib.bogp_chol_wide_panels(N, w, 16)
         return [int(w[i]) for i in range(n)]
 
-    assert [sched(N) for N in (0, 100, 3073, 4096, 6080)] == [[]] * 5   # 64-block path: no wide panels
-    assert sched(6081) == sched(6144) == sched(7000) == sched(7552) == [24]
+    assert [sched(N) for N in (0, 100, 3073, 4096, 6016)] == [[]] * 5   # fewer than 96 block columns: no wide panels
+    assert sched(6017) == sched(6144) == sched(7000) == sched(7552) == [24]  # (the leading dimension is N rounded up to 128 above N = 3072)
     assert sched(7553) == sched(8192) == sched(9088) == [24, 24]
     assert sched(10240) == [24, 24, 24] and sched(16384) == [24] * 7
     assert lib.bogp_chol_wide_panels(8192, None, 0) == 2                # count only

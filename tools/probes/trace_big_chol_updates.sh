@@ -13,7 +13,7 @@ rng = np.random.default_rng(0)
 X = rng.uniform(-5, 5, size=(N, d)); y = np.sum(X**2, axis=1); y = ((y - y.mean()) / y.std()).reshape(-1, 1)
 par = np.r_[np.full(d, 0.004), 0.9]
 eng = _lib.Engine(0); eng.set_train(X, y)
-for _ in range(3): eng.nll(0, 1, par, 1e-6, False, 0.0, eval_grad=False)
+for _ in range(3): eng.nll(0, 1, par, 1e-6, False, 0.0, eval_grad=bool(int(os.environ.get("GRAD", "0"))))
 PY
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/tr -o t -- env BOGP_BIG_CHOL=${BIG:-0} python /tmp/big1.py > $O/run.log 2>&1
 python - <<'PY'

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bogp import _lib
 BIG_ONLY = "--big-only" in sys.argv
+SHA = "--sha" in sys.argv  # + sha1 of (llf, gradient, committed factor): bit-identity of library variants
 for N in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or (4096, 8192):
     d = 50
     rng = np.random.default_rng(0)
@@ -26,5 +27,14 @@ for N in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or (4096, 8192
             res.append((time.perf_counter() - t0) / 5 * 1e3)
         if not eg or not isinstance(out, tuple): out = (out, np.zeros(1))
         t0 = time.perf_counter(); call(lambda: eng.commit(0, 1, par, 1e-6, False, 0.0)); tc = (time.perf_counter() - t0) * 1e3
-        print("N=%d %-9s llf %.2f ms  llf+grad %.2f ms  commit %.2f ms  (llf %.6f, |grad| %.6e)" % (N, tag, res[0], res[1], tc, out[0], np.abs(out[1]).sum()))
+        sha = ""
+        if SHA:
+            import hashlib
+            hsh = hashlib.sha1(np.float64(out[0]).tobytes() + np.ascontiguousarray(out[1]).tobytes())
+            try:
+                hsh.update(np.ascontiguousarray(eng.get_state()["C"]).tobytes())
+            except _lib.BogpError:
+                pass
+            sha = "  sha1 " + hsh.hexdigest()[:16]
+        print("N=%d %-9s llf %.2f ms  llf+grad %.2f ms  commit %.2f ms  (llf %.6f, |grad| %.6e)%s" % (N, tag, res[0], res[1], tc, out[0], np.abs(out[1]).sum(), sha))
         eng.close()
