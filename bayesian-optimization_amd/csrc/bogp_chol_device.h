@@ -103,37 +103,6 @@ __device__ __forceinline__ void mma_64(const double* lds, const double (&bv)[16]
     for (int t = 0; t < 4; ++t) acc[mi][t] = c[mi][t];
 }
 
-// mma_64 for two block rows against ONE staged tile, the accumulators held as MFMA operands throughout (k_elim_updateS_b keeps four tiles
-// live and has no registers to spare for repacking): every A fragment read from LDS feeds both rows' MFMAs (half the LDS reads), the fragments of
-// step ks + 1 are fetched while the eight MFMAs of step ks issue, and the scheduling fences keep the compiler from hoisting all 64
-// fragment reads (128 VGPRs) above the chain.  Per output element the same sixteen accumulations in the same order as mma_64.
-__device__ __forceinline__ void mma_64v2(const double* lds, const double (&bv0)[16], const double (&bv1)[16], d4 (&c0)[4], d4 (&c1)[4], int lane) {
-  const int aoff = (lane >> 4) * CPITCH + (lane & 15);
-  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]));
-  double an[4];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) an[mi] = lds[aoff + 16 * mi];
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    double ac[4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) ac[mi] = an[mi];
-    if (ks + 1 < 16) {
-      const double* trow = &lds[4 * (ks + 1) * CPITCH];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) an[mi] = trow[aoff + 16 * mi];
-    }
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      mfma16(ac[mi], bv0[ks], c0[mi]);
-      mfma16(ac[mi], bv1[ks], c1[mi]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
-               : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]));
-}
-
 // ---- diagonal block: Cholesky factor and its inverse, blocked by 4 columns -----------------------------------------
 // Thread (tr, tc) = (tid >> 4, tid & 15) owns ONE 4x4 register tile z of the symmetric block (rows 4 tr.., columns
 // 4 tc..; both triangles are kept).  With M = (4x4 diagonal factor)^-1 of block step jb, the block row

@@ -631,10 +631,10 @@ __global__ __launch_bounds__(256) void k_elim_updateG_b(const BatchSlot* __restr
 // ---- the grouped update on 128 x 128 SUPER-TILES (r04) --------------------------------------------------------------------------------
 // k_elim_updateG_b fetches two 32-KB solved tiles per 64^3 product: with P matrices in flight the solved panels of a slot (4 MB at
 // N = 2048) do not stay in an XCD's 4-MB L2 next to the streaming state, and the kernel sits at ~47 % of the matrix peak on those
-// fetches (profiles/r04_nll_batch_group.txt).  Here a workgroup owns the 2 x 2 blocks (2 BI + a, 2 BJ + b): per step it stages the TWO
-// A-side tiles X_{2BJ}, X_{2BJ+1} and loads the TWO B-side fragments X_{2BI}, X_{2BI+1} for FOUR products -- half the fetches per
+// fetches (profiles/r04_nll_batch_group.txt).  Here a workgroup owns the 2 x 2 blocks (2 BI + a, 2 BJ + b): per step it fetches the TWO
+// A-side tiles X_{2BJ}, X_{2BJ+1} and the TWO B-side fragments X_{2BI}, X_{2BI+1} for FOUR products -- half the fetches per
 // flop.  Every block still sees the accumulations of k_elim_updateG_b on the same operands in the same order (its own first step ..
-// klast; mma_64v2 issues mma_64's instructions for two block rows at once), then elim_store_block's stores: the same bits.  Blocks above
+// klast), then elim_store_block's stores: the same bits.  Blocks above
 // the diagonal or outside the nb + 1 block rows / nb block columns are computed and discarded, a block that restarts inside the group is
 // zeroed when the loop reaches its step (no per-block control flow around the MFMA chains: see the kernel).  The next diagonal block is
 // factored by k_elim_diag_b.
@@ -658,22 +658,15 @@ template <int AUX = 0>
 __device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t r, unsigned voff_doubles, unsigned soff_doubles) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, 8 * voff_doubles, 8 * soff_doubles, AUX);
 }
-__device__ __forceinline__ void stage_aside_b(double* lds, __amdgpu_buffer_rsrc_t r, int tid) {  // stage_aside for a 64 x 64 tile, lda = 64
-  const unsigned srow = tid >> 5, scol = (tid & 31) * 2;
-  const unsigned voff = 8 * (srow * CB + scol);
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 8 * (p * 8 * CB), 0);
-    *reinterpret_cast<v4u*>(&lds[(srow + 8 * p) * CPITCH + scol]) = v;
-  }
-}
-__device__ __forceinline__ void load_bside_b(double (&bv)[16], __amdgpu_buffer_rsrc_t r, int w, int lane) {  // load_bside, ldb = 64
-  const unsigned voff = (unsigned)(lane >> 4) * CB + 16 * w + (lane & 15);
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) bv[ks] = buf_load(r, voff, ks * 4 * CB);
-}
+// r06, last session: NO LDS and NO barrier (what k_contract16d did for the sweep and mm128_tile_direct for the tile products).  The A side -- the two
+// solved tiles X_{2BJ}, X_{2BJ+1}, k-major with the row index contiguous -- comes straight from global memory as row PAIRS per lane (lane (k, i) takes
+// rows 2 i, 2 i + 1 of a 32-row half with one 128-bit buffer load: fragment mi = 2 half + e stands for rows 32 half + 2 i + e of the tile, i.e. for the
+// COLUMNS 32 (mi >> 1) + 8 t + 2 lk + (mi & 1) of the output block in register t of lane group lk), the B side one value a k-step as before; a k-pair's
+// twelve loads go out as ONE block in front of the 32 MFMAs of the k-pair before it (two register slots), across step boundaries too.  A block that
+// restarts at a step is zeroed between that step's first load block and its first MFMA, behind a drain.  Per output element the same accumulations in
+// the same order as k_elim_updateG_b and as the staged version of r04-r06 (two LDS tiles + two barriers a step; git de191e8): the same bits
+// (tests/test_gpu_nll_batch_variants.py).  A slot of a batch of 16 at N = 2048: 334 -> 321 us, of 8 at N = 3072: 947 -> 899 us (profiles/r06_elim_super_direct_ab.txt).
 __global__ __launch_bounds__(256, 2) void k_elim_updateS_b(const BatchSlot* __restrict__ slots, int k, int ng, int xcd, int G, int P) {
-  __shared__ __attribute__((aligned(16))) double lds[2][CB * CPITCH];
   int slot = (int)blockIdx.y, blk = (int)blockIdx.x;
   if (xcd) {
     const long U = (long)G * P, L = (long)blockIdx.x;
@@ -688,18 +681,14 @@ __global__ __launch_bounds__(256, 2) void k_elim_updateS_b(const BatchSlot* __re
   const ElimArgs& a = sl.ea;
   int BI, BJ;
   tri_index(blk, BI, BJ);
-  BI = __builtin_amdgcn_readfirstlane(BI);  // (tri_index goes through the vector ALU: tell the compiler the result is uniform, or every
-  BJ = __builtin_amdgcn_readfirstlane(BJ);  //  buffer descriptor below gets a waterfall loop)
+  BI = __builtin_amdgcn_readfirstlane(BI);
+  BJ = __builtin_amdgcn_readfirstlane(BJ);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lk = lane >> 4;
+  const int lk = lane >> 4, li = lane & 15;
   const unsigned lde = (unsigned)a.ld + CB;
   const size_t xsz = ((size_t)a.nb + 1) * CB * CB;
   const int klast = k + ng - 1;
-  // per block: is it there, and the first step of the group it still needs (k_elim_updateG_b's rule).  The step loop itself has NO per-block
-  // control flow -- all four products every step: a block that restarts at step f > k is simply zeroed when the loop gets there (what it
-  // gathered before is discarded, as are the blocks above the diagonal / past the edge), so that the four accumulator tiles live in fixed
-  // registers.  (With a branch per block the compiler keeps copies of the tiles across the variants and spills.)
   bool valid[2][2];
   int first[2][2];
   bool any = false;
@@ -716,7 +705,9 @@ __global__ __launch_bounds__(256, 2) void k_elim_updateS_b(const BatchSlot* __re
       any = any || valid[ia][ib];
     }
   if (!any) return;  // nothing of this super-tile is there
-  d4 acc[2][2][4];  // negated tiles, as MFMA accumulators: [mi] component t
+  // output block element (row 16 w + li, column colmap(mi, t) + 2 lk): accumulator [mi] component t
+#define BOGP_ES_COL(mi, t) (32 * ((mi) >> 1) + 8 * (t) + ((mi) & 1))
+  d4 acc[2][2][4];
 #pragma unroll
   for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
@@ -724,39 +715,87 @@ __global__ __launch_bounds__(256, 2) void k_elim_updateS_b(const BatchSlot* __re
       if (valid[ia][ib] && first[ia][ib] < 0) {
         int ldt;
         const __amdgpu_buffer_rsrc_t Tb = tile_rsrc(elim_tile(a, 2 * BI + ia, 2 * BJ + ib, ldt));
-        const unsigned voff = (unsigned)lk * ldt + 16 * w + (lane & 15);
+        const unsigned voff = (unsigned)(2 * lk) * ldt + 16 * w + li;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[ia][ib][mi][t] = -buf_load<BOGP_STATE_AUX>(Tb, voff, (unsigned)(16 * mi + 4 * t) * ldt);
+          for (int t = 0; t < 4; ++t) acc[ia][ib][mi][t] = -buf_load<BOGP_STATE_AUX>(Tb, voff, (unsigned)BOGP_ES_COL(mi, t) * ldt);
       } else {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) acc[ia][ib][mi] = (d4){0.0, 0.0, 0.0, 0.0};
       }
     }
   const int tj1 = 2 * BJ + (2 * BJ + 1 <= a.nb ? 1 : 0), ti1 = 2 * BI + (2 * BI + 1 <= a.nb ? 1 : 0);  // (past the edge: the tile before, discarded)
+  const unsigned voffA = 8u * ((unsigned)lk * CB + 2 * li);        // bytes: row pair 2 li of half 0 at k = lk of the k-step; half 1: + 256 bytes
+  const unsigned voffB = (unsigned)lk * CB + 16 * w + li;          // doubles: row 16 w + li at k = lk of the k-step
+  v4u av[2][2][2][2];  // [slot][tile ib][k-step][half]: two doubles (rows 2 i, 2 i + 1)
+  double bv[2][2][2];  // [slot][tile ia][k-step]
+  // the twelve loads of k-pair kp_ (0 .. 7) of step st_: tiles of the solved panel of that step
+#define BOGP_ES_LOADS(sl_, st_, kp_)                                                                                   \
+  do {                                                                                                                 \
+    const double* xs_ = sl.xpanel + (size_t)((st_) & 3) * xsz;                                                          \
+    const __amdgpu_buffer_rsrc_t a0_ = tile_rsrc(xs_ + (size_t)(2 * BJ) * CB * CB), a1_ = tile_rsrc(xs_ + (size_t)tj1 * CB * CB); \
+    const __amdgpu_buffer_rsrc_t b0_ = tile_rsrc(xs_ + (size_t)(2 * BI) * CB * CB), b1_ = tile_rsrc(xs_ + (size_t)ti1 * CB * CB); \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                                 \
+      const unsigned so_ = (unsigned)(8 * (kp_) + 4 * h_) * CB;  /* doubles */                                          \
+      av[sl_][0][h_][0] = __builtin_amdgcn_raw_buffer_load_b128(a0_, voffA, 8 * so_, 0);                               \
+      av[sl_][0][h_][1] = __builtin_amdgcn_raw_buffer_load_b128(a0_, voffA + 256, 8 * so_, 0);                         \
+      av[sl_][1][h_][0] = __builtin_amdgcn_raw_buffer_load_b128(a1_, voffA, 8 * so_, 0);                               \
+      av[sl_][1][h_][1] = __builtin_amdgcn_raw_buffer_load_b128(a1_, voffA + 256, 8 * so_, 0);                         \
+      bv[sl_][0][h_] = buf_load(b0_, voffB, so_);                                                                      \
+      bv[sl_][1][h_] = buf_load(b1_, voffB, so_);                                                                      \
+    }                                                                                                                  \
+  } while (0)
+#define BOGP_ES_AVAL(sl_, ib_, h_, mi_) __builtin_bit_cast(double, (v2u){av[sl_][ib_][h_][(mi_) >> 1][2 * ((mi_) & 1)], av[sl_][ib_][h_][(mi_) >> 1][2 * ((mi_) & 1) + 1]})
+#define BOGP_ES_MFMAS(sl_)                                                                                             \
+  do {                                                                                                                 \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                                   \
+      _Pragma("unroll") for (int ib_ = 0; ib_ < 2; ++ib_)                                                              \
+        _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_) {                                                          \
+          const double a_ = BOGP_ES_AVAL(sl_, ib_, h_, mi_);                                                           \
+          mfma16(a_, bv[sl_][0][h_], acc[0][ib_][mi_]);                                                                \
+          mfma16(a_, bv[sl_][1][h_], acc[1][ib_][mi_]);                                                                \
+        }                                                                                                              \
+  } while (0)
+#define BOGP_ES_ALL_ACC                                                                                                                    \
+  "+v"(acc[0][0][0]), "+v"(acc[0][0][1]), "+v"(acc[0][0][2]), "+v"(acc[0][0][3]), "+v"(acc[0][1][0]), "+v"(acc[0][1][1]), "+v"(acc[0][1][2]), \
+      "+v"(acc[0][1][3]), "+v"(acc[1][0][0]), "+v"(acc[1][0][1]), "+v"(acc[1][0][2]), "+v"(acc[1][0][3]), "+v"(acc[1][1][0]), "+v"(acc[1][1][1]), \
+      "+v"(acc[1][1][2]), "+v"(acc[1][1][3])
+  BOGP_ES_LOADS(0, k, 0);
+  // the VALU moves that built the accumulators must retire before the first MFMA reads them as SrcC (inline-asm MFMAs: wait states by hand)
+  asm volatile("s_nop 7\n\ts_nop 7" : BOGP_ES_ALL_ACC);
   for (int sidx = k; sidx <= klast; ++sidx) {
-    const double* xs = sl.xpanel + (size_t)(sidx & 3) * xsz;
-    double bv0[16], bv1[16];
-    if (sidx > k) __syncthreads();  // every wave is done with the previous step's tiles
-    stage_aside_b(lds[0], tile_rsrc(xs + (size_t)(2 * BJ) * CB * CB), tid);
-    stage_aside_b(lds[1], tile_rsrc(xs + (size_t)tj1 * CB * CB), tid);
-    __builtin_amdgcn_sched_barrier(0);  // the staging registers are dead before the B-side fragments go live: 2 workgroups a CU (<= 256 VGPRs)
-    load_bside_b(bv0, tile_rsrc(xs + (size_t)(2 * BI) * CB * CB), w, lane);
-    load_bside_b(bv1, tile_rsrc(xs + (size_t)ti1 * CB * CB), w, lane);
+    bool restart = false;
 #pragma unroll
     for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-        if (sidx == first[ia][ib]) {  // the restart: T <- 0 - X_i X_j^T from this step on
+      for (int ib = 0; ib < 2; ++ib) restart = restart || sidx == first[ia][ib];
+    if (restart) {  // (uniform) T <- 0 - X_i X_j^T from this step on: behind the drain of what the block gathered so far, in front of the step's first MFMA
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : BOGP_ES_ALL_ACC);
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi) acc[ia][ib][mi] = (d4){0.0, 0.0, 0.0, 0.0};
-        }
-    __syncthreads();
-    // step sidx:  -T <- -T + X_i X_j^T
-    mma_64v2(lds[0], bv0, bv1, acc[0][0], acc[1][0], lane);
-    mma_64v2(lds[1], bv0, bv1, acc[0][1], acc[1][1], lane);
+      for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+          if (sidx == first[ia][ib]) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) acc[ia][ib][mi] = (d4){0.0, 0.0, 0.0, 0.0};
+          }
+      asm volatile("s_nop 7\n\ts_nop 7" : BOGP_ES_ALL_ACC);
+    }
+    const int snext = min(sidx + 1, klast);
+#pragma unroll
+    for (int kp = 0; kp < 8; ++kp) {
+      if (kp < 7) BOGP_ES_LOADS((kp + 1) & 1, sidx, kp + 1);
+      else BOGP_ES_LOADS(0, snext, 0);  // (the last step asks for its own first k-pair again: nothing uses it)
+      __builtin_amdgcn_sched_barrier(0);
+      BOGP_ES_MFMAS(kp & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : BOGP_ES_ALL_ACC);
+#undef BOGP_ES_LOADS
+#undef BOGP_ES_MFMAS
+#undef BOGP_ES_AVAL
   // elim_store_block's stores: the block back into the state; column kn as it is / row kn transposed into the next raw panel (the next
   // diagonal block is factored by k_elim_diag_b)
   const __amdgpu_buffer_rsrc_t Pnext = tile_rsrc(sl.panels + ((klast & 1) ? 0 : (size_t)lde * CB));
@@ -769,26 +808,28 @@ __global__ __launch_bounds__(256, 2) void k_elim_updateS_b(const BatchSlot* __re
       const int bi = 2 * BI + ia, bj = 2 * BJ + ib;
       int ldt;
       const __amdgpu_buffer_rsrc_t Tb = tile_rsrc(elim_tile(a, bi, bj, ldt));
-      const unsigned voff = (unsigned)lk * ldt + 16 * w + (lane & 15);
+      const unsigned voff = (unsigned)(2 * lk) * ldt + 16 * w + li;
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) buf_store<BOGP_STATE_AUX>(-acc[ia][ib][mi][t], Tb, voff, (unsigned)(16 * mi + 4 * t) * ldt);
+        for (int t = 0; t < 4; ++t) buf_store<BOGP_STATE_AUX>(-acc[ia][ib][mi][t], Tb, voff, (unsigned)BOGP_ES_COL(mi, t) * ldt);
       if (kn >= a.nb) continue;
       if (bj == kn && bi > kn) {
-        const unsigned vo = (unsigned)lk * lde + 16 * w + (lane & 15);
+        const unsigned vo = (unsigned)(2 * lk) * lde + 16 * w + li;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) buf_store(-acc[ia][ib][mi][t], Pnext, vo, (unsigned)(16 * mi + 4 * t) * lde + (unsigned)(CB * bi));
+          for (int t = 0; t < 4; ++t) buf_store(-acc[ia][ib][mi][t], Pnext, vo, (unsigned)BOGP_ES_COL(mi, t) * lde + (unsigned)(CB * bi));
       } else if (bi == kn && bj < kn) {
-        const unsigned vo = (unsigned)(16 * w + (lane & 15)) * lde + lk;
+        const unsigned vo = (unsigned)(16 * w + li) * lde + 2 * lk;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) buf_store(-acc[ia][ib][mi][t], Pnext, vo, (unsigned)(CB * bj + 16 * mi + 4 * t));
+          for (int t = 0; t < 4; ++t) buf_store(-acc[ia][ib][mi][t], Pnext, vo, (unsigned)(CB * bj + BOGP_ES_COL(mi, t)));
       }
     }
+#undef BOGP_ES_ALL_ACC
+#undef BOGP_ES_COL
 }
 
 // the next diagonal block after a super-tile update: factored and inverted from the state by a workgroup of its own launch (inlined
