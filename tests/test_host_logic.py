@@ -1,5 +1,6 @@
 """Host-side logic of the drop-in layer that needs no GPU: protocol surface, validation, argmax reduction rules."""
 import functools
+import os
 import pickle
 
 import numpy as np
@@ -481,4 +482,6 @@ def test_lookahead_error_path_cancels_the_speculation_and_restores_the_generator
 
 def test_lookahead_cases_above_exercised_every_branch():
     """(runs after the parametrised cases: speculation, a re-run under the true budget and a cancellation all occurred)"""
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        pytest.skip("a statement about the cases above having run in THIS process: under pytest-xdist they are dealt to other workers")
     assert {"speculated", "rerun", "cancelled"} <= _LOOKAHEAD_SEEN, _LOOKAHEAD_SEEN
