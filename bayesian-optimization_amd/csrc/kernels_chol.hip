@@ -17,7 +17,6 @@
 //                     others:       A_ij -= X_i X_j^T (64x64 tiles, K = 64), same MFMA micro-kernel
 // Measured alternatives for the diagonal block (tools/probes/ubench_potf2.hip, profiles/r01_ubench_potf2.txt): one wave with
 // a row per lane and v_readlane / ds_bpermute / LDS broadcasts needs 50-300 us per block (SGPR pressure and spills).
-#include <atomic>
 #include "bogp_device.h"
 #include "bogp_internal.h"
 
@@ -484,26 +483,23 @@ __global__ __launch_bounds__(256) void k_tri_base(const double* __restrict__ Win
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Large matrices (ld >= 4096): the same products on 128 x 128 tiles.
+// Large matrices (ld >= BIG_LD = 3200, i.e. every N > 3072): the same products on 128 x 128 tiles.
 //
 // The 64 x 64 tile product above moves 64 KB of operands per 0.5 MFLOP (8 flop/B) and, at N = 8192, none of the 512 MB
 // matrices stays in a cache: the inverse ran at 39 TF/s and the rank-64 trailing updates of the factorisation at
 // 22 TF/s (profiles/r01_nll_n8192_kernel_stats.csv).  k_mm128 forms out(128 x 128) = alpha * Rside Cside^T (+ out):
-//   * BOTH operands go through LDS (k-major tiles of 16 x 128, pitch 144 doubles: the four k-rows of a fragment read fall
-//     into different 128-byte bank groups), register-staged global -> LDS one k-block ahead, two LDS buffers, one barrier
-//     per k-block; 4 waves x (64 x 64) outputs = 16 d4 accumulators per wave, two workgroups per CU;
+//   * 4 waves x (64 x 64) outputs = 16 d4 accumulators per wave, two workgroups per CU; the operands come straight from global
+//     memory (mm128_tile_direct below; through two LDS stages with a barrier per 16 k until r06);
 //   * the MFMA's A operand is the COLUMN side, so that D's lane index (lane & 15) runs along the rows of the column-major
-//     output: every store instruction writes 128-byte row segments;
-//   * workgroups are dealt to tiles XCD-aware (mm_tile_of): inside every 8 x 8 super tile each XCD owns a 2 x 4 block, so
-//     its workgroups share operand panels through that XCD's L2 and all XCDs carry the same mix of long and short K;
+//     output: every store instruction writes whole row segments;
+//   * workgroups walk the live tiles of a triangular product in order of decreasing K (or are dealt XCD-aware, mm_tile_of, where the
+//     tiles are equally long);
 //   * structure is exploited at tile level: tiles above the diagonal leave at once, K ranges follow the triangles.
-// Two-level Cholesky: 256-wide panels are factored by the 64-block kernels above (updates confined to the panel), the
-// trailing matrix then receives ONE rank-256 update from k_mm128 instead of four rank-64 ones.
+// Wide first panels of the Cholesky (launch_chol_lower): the panel's block columns are factored by the 64-block kernels above with their
+// updates confined to the panel, the trailing matrix then receives ONE rank-64 w update from k_mm128 (MM_SYRK) instead of w rank-64 ones.
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int MB = 128;        // tile edge
-constexpr int MKB = 16;        // k rows per LDS stage
-constexpr int MPT = MB + 16;   // LDS pitch in doubles
 // r02-r05: 6144 (the staged tile core: 4096 5.1 vs 4.8 ms, 6144 9.9 vs 10.2, 8192 17.6 vs 20.2).  With the LDS-free core (mm128_tile_direct) the 128-tile products win wherever
 // the general path runs at all (profiles/r06_mm128_direct_ab.txt: llf + gradient 3.52 -> 3.40 ms at N = 3584, 4.51 -> 4.00 at 4096, 6.86 -> 5.83 at 5120, 9.07 -> 7.64 at 6016), so
 // every training set above the elimination's limit (N > 3072: bogp_set_train rounds the leading dimension to 128 there) takes them.
@@ -514,137 +510,22 @@ struct MmTile {
   const double* Cs;  // column-side operand: element (col, k) at Cs[col + k * ldc]
   double* out;       // out(row, col) at out[row + col * ldo]
   int ldr, ldc, ldo;
-  int k0, k1;        // K range, multiples of MKB
+  int k0, k1;        // K range, multiples of 16
   double alpha;
   int beta;          // 1: out += alpha * product
 };
 
-__device__ __forceinline__ __attribute__((unused)) void mm128_tile_lds(const MmTile& t, double* lds) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w & 1, wn = w >> 1;  // this wave: rows 64 wm .., columns 64 wn ..
-  const int lk = lane >> 4, li = lane & 15;
-  d4 acc[4][4];  // [column fragment][row fragment]
-  if (t.beta) {
-    // out += alpha * product with alpha = +-1: start from alpha * out (exact) and scale by alpha at the end.  All 64 loads
-    // of the tile are issued before anything waits on them (a read-modify-write in the epilogue serialises 64 round trips
-    // per thread: measured 100 us per workgroup)
-#pragma unroll
-    for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double* __restrict__ o = t.out + (size_t)(64 * wn + 16 * ci + 4 * r + lk) * t.ldo + 64 * wm + li;
-#pragma unroll
-        for (int rj = 0; rj < 4; ++rj) acc[ci][rj][r] = t.alpha * o[16 * rj];
-      }
-  } else {
-#pragma unroll
-    for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-      for (int rj = 0; rj < 4; ++rj) acc[ci][rj] = (d4){0.0, 0.0, 0.0, 0.0};
-  }
-  const int nkb = (t.k1 - t.k0) / MKB;
-  if (nkb > 0) {
-    const int srow = w, scol = (tid & 63) * 2;  // (the staged row of a thread is its wave's index: wave-uniform)
-    // (r06, from k_contract16d: wave-uniform base + the lane's constant 32-bit offset, kept opaque beside the loads so that hipcc selects the `v_offset, s[base]`
-    // form -- a hoisted zero-extension costs a v_lshl_add_u64 per load, a 64-bit VALU operation on the FP64 pipe the MFMAs use)
-    const char* const rbase = reinterpret_cast<const char*>(t.Rs + (size_t)t.k0 * t.ldr);
-    const char* const cbase = reinterpret_cast<const char*>(t.Cs + (size_t)t.k0 * t.ldc);
-    unsigned loff = (unsigned)scol * (unsigned)sizeof(double);
-    double2 r0, r1, r2, r3, c0, c1, c2, c3;
-#define BOGP_MM_LOAD(kb_)                                                                 \
-  do {                                                                                    \
-    const char* pr_ = rbase + (size_t)((kb_)*MKB + srow) * t.ldr * sizeof(double);        \
-    const char* pc_ = cbase + (size_t)((kb_)*MKB + srow) * t.ldc * sizeof(double);        \
-    const size_t sr_ = (size_t)4 * t.ldr * sizeof(double), sc_ = (size_t)4 * t.ldc * sizeof(double); \
-    asm volatile("" : "+v"(loff));                                                        \
-    r0 = *reinterpret_cast<const double2*>(pr_ + loff);                                   \
-    r1 = *reinterpret_cast<const double2*>(pr_ + sr_ + loff);                             \
-    r2 = *reinterpret_cast<const double2*>(pr_ + 2 * sr_ + loff);                         \
-    r3 = *reinterpret_cast<const double2*>(pr_ + 3 * sr_ + loff);                         \
-    c0 = *reinterpret_cast<const double2*>(pc_ + loff);                                   \
-    c1 = *reinterpret_cast<const double2*>(pc_ + sc_ + loff);                             \
-    c2 = *reinterpret_cast<const double2*>(pc_ + 2 * sc_ + loff);                         \
-    c3 = *reinterpret_cast<const double2*>(pc_ + 3 * sc_ + loff);                         \
-  } while (0)
-#define BOGP_MM_STORE(buf_)                                                               \
-  do {                                                                                    \
-    double* qr_ = lds + (buf_)*2 * MKB * MPT + srow * MPT + scol;                         \
-    double* qc_ = qr_ + MKB * MPT;                                                        \
-    *reinterpret_cast<double2*>(qr_) = r0;                                                \
-    *reinterpret_cast<double2*>(qr_ + 4 * MPT) = r1;                                      \
-    *reinterpret_cast<double2*>(qr_ + 8 * MPT) = r2;                                      \
-    *reinterpret_cast<double2*>(qr_ + 12 * MPT) = r3;                                     \
-    *reinterpret_cast<double2*>(qc_) = c0;                                                \
-    *reinterpret_cast<double2*>(qc_ + 4 * MPT) = c1;                                      \
-    *reinterpret_cast<double2*>(qc_ + 8 * MPT) = c2;                                      \
-    *reinterpret_cast<double2*>(qc_ + 12 * MPT) = c3;                                     \
-  } while (0)
-    const int roff = lk * MPT + 64 * wm + li, coff = MKB * MPT + lk * MPT + 64 * wn + li;
-    BOGP_MM_LOAD(0);
-    BOGP_MM_STORE(0);
-    for (int kb = 0; kb < nkb; ++kb) {
-      __syncthreads();  // block kb is in buffer kb & 1; every wave is done with the other buffer
-      BOGP_MM_LOAD(min(kb + 1, nkb - 1));
-      // keep the loads HERE: left alone, the scheduler sinks them below the MFMAs, next to the LDS stores that consume them
-      // (fewer live registers), and every k-block then waits out the full global latency (measured: 20 TF/s)
-      __builtin_amdgcn_sched_barrier(0);
-      const double* tb = lds + (kb & 1) * 2 * MKB * MPT;
-      double rf[2][4], cf[2][4];
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        rf[0][f] = tb[roff + 16 * f];
-        cf[0][f] = tb[coff + 16 * f];
-      }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < 3) {
-#pragma unroll
-          for (int f = 0; f < 4; ++f) {
-            rf[(ks + 1) & 1][f] = tb[roff + 4 * (ks + 1) * MPT + 16 * f];
-            cf[(ks + 1) & 1][f] = tb[coff + 4 * (ks + 1) * MPT + 16 * f];
-          }
-          // (pinning these reads ahead of the MFMAs of k-step ks with sched_barrier / sched_group_barrier measured -1 %:
-          // the second wave of the SIMD already covers the LDS round trips -- profiles/r03_mm128_order_ab.txt)
-        }
-#pragma unroll
-        for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-          for (int rj = 0; rj < 4; ++rj) mfma16(cf[ks & 1][ci], rf[ks & 1][rj], acc[ci][rj]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      BOGP_MM_STORE((kb + 1) & 1);
-    }
-#undef BOGP_MM_LOAD
-#undef BOGP_MM_STORE
-    BOGP_CHOL_DRAIN();
-#pragma unroll
-    for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-      for (int rj = 0; rj < 4; ++rj) asm volatile("" : "+v"(acc[ci][rj]));  // the stores' reads of the accumulators stay behind the drain
-  }
-  // D[i][j]: i = column (MFMA A side), j = row; lane 16 (i % 4) + j, register i / 4
-  // (out = alpha * acc: with beta the accumulators started from alpha * out, and alpha^2 = 1)
-#pragma unroll
-  for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double* __restrict__ o = t.out + (size_t)(64 * wn + 16 * ci + 4 * r + lk) * t.ldo + 64 * wm + li;
-#pragma unroll
-      for (int rj = 0; rj < 4; ++rj) o[16 * rj] = t.alpha * acc[ci][rj][r];
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// The same tile with NO LDS and NO barrier (r06, last session; the default -- `make EXTRA=-DMM128_LDS` builds the staged core above
-// for A/B runs): what k_contract16d did for the sweep (kernels_posterior.hip, DESIGN 5.2'').  Both operands are k-major with the
-// non-contracted index contiguous, so a wave fetches its own fragments straight from global memory: lane (k, i) takes the PAIR of
-// rows 2 i, 2 i + 1 of a 32-row half with one global_load_dwordx4 (four 256-byte runs an instruction) -- fragment f = 2 half + e
-// stands for rows 32 half + 2 i + e, on both sides, and the epilogue stores pairs accordingly (256-byte runs, half as many store
-// instructions).  A k-pair (8 k values) is 8 loads, issued as ONE block in front of its 32 MFMAs, two k-pairs in flight through three
-// register slots; every address is a scalar base + the lane's constant 32-bit offset (kept opaque in the loop: no 64-bit VALU adds on
-// the MFMAs' pipe).  The two waves that share a row (column) half of the tile meet in L1.  Per output element the products run over
-// k in the same order from the same starting value as in the staged core: the SAME BITS (profiles/r06_mm128_direct_ab.txt).
+// The tile core: NO LDS and NO barrier (r06, last session) -- what k_contract16d did for the sweep (kernels_posterior.hip, DESIGN 5.2'').
+// Both operands are k-major with the non-contracted index contiguous, so a wave fetches its own fragments straight from global memory:
+// lane (k, i) takes the PAIR of rows 2 i, 2 i + 1 of a 32-row half with one global_load_dwordx4 (four 256-byte runs an instruction) --
+// fragment f = 2 half + e stands for rows 32 half + 2 i + e, on both sides, and the epilogue stores pairs accordingly (256-byte runs,
+// half as many store instructions).  A k-pair (8 k values) is 8 loads, issued as ONE block in front of its 32 MFMAs, two k-pairs in
+// flight through three register slots; every address is a scalar base + the lane's constant 32-bit offset (kept opaque in the loop: no
+// 64-bit VALU adds on the MFMAs' pipe).  The two waves that share a row (column) half of the tile meet in L1.  231 VGPRs, no spills,
+// two workgroups a CU.  (The staged core of r02-r06 -- both operands through two LDS stages of 16 x 128, one barrier a k-block -- is in git
+// de191e8 behind -DMM128_LDS; the two give the SAME BITS, per output element the products run over k in the same order from the same
+// starting value, and this one is 7-20 % faster per launch: profiles/r06_mm128_direct_ab.txt.)
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void mm128_tile_direct(const MmTile& t) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -672,7 +553,7 @@ __device__ __forceinline__ void mm128_tile_direct(const MmTile& t) {
 #pragma unroll
       for (int rj = 0; rj < 4; ++rj) acc[ci][rj] = (d4){0.0, 0.0, 0.0, 0.0};
   }
-  const int nkp = (t.k1 - t.k0) / 8;  // k-pairs (K ranges are multiples of MKB = 16)
+  const int nkp = (t.k1 - t.k0) / 8;  // k-pairs (K ranges are multiples of 16)
   if (nkp > 0) {
     constexpr int DD = 2, DR = DD + 1;  // k-pairs in flight, register slots
     const int kp_last = nkp - 1;
@@ -742,13 +623,6 @@ __device__ __forceinline__ void mm128_tile_direct(const MmTile& t) {
     }
 }
 
-#ifdef MM128_LDS
-constexpr int MM_SHM = 2 * 2 * MKB * MPT * (int)sizeof(double);  // 73.7 KB: two stages of (row tile + column tile)
-__device__ __forceinline__ void mm128_tile(const MmTile& t, double* lds) { mm128_tile_lds(t, lds); }
-#else
-constexpr int MM_SHM = 0;
-__device__ __forceinline__ void mm128_tile(const MmTile& t, double*) { mm128_tile_direct(t); }
-#endif
 
 enum { MM_UUT = 0, MM_T = 1, MM_V = 2, MM_U = 3, MM_SYRK = 4, MM_GEN = 5 };
 struct MmArgs {
@@ -792,7 +666,6 @@ __device__ __forceinline__ bool mm_tile_of(int TI, int TJ, int& ti, int& tj) {
 }  // namespace
 
 __global__ __launch_bounds__(256, 2) void k_mm128(MmArgs a, int mode0) {
-  extern __shared__ __attribute__((aligned(16))) double mm_lds[];
   const int mode = mode0 + (int)blockIdx.z;
   int ti, tj, pair = (int)blockIdx.y;
   if (mode == MM_GEN) {  // every tile is live and equally long; consecutive workgroups share the row panel
@@ -805,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void k_mm128(MmArgs a, int mode0) {
     g.ldr = a.gldr; g.ldc = a.gldc; g.ldo = a.gldo;
     g.k0 = 0; g.k1 = a.gK;
     g.alpha = 1.0; g.beta = 0;
-    mm128_tile(g, mm_lds);
+    mm128_tile_direct(g);
     return;
   }
   if (a.order) {
@@ -894,7 +767,7 @@ __global__ __launch_bounds__(256, 2) void k_mm128(MmArgs a, int mode0) {
     }
   }
   if (a.fixed) t.ldr = t.ldc = 0;  // experiment: every k-row of the operands at one address (no L2 / HBM traffic)
-  mm128_tile(t, mm_lds);
+  mm128_tile_direct(t);
 }
 
 // U12 = V21^T for every pair of a level (the third product of the recursive doubling is a transposition of the second):
@@ -939,28 +812,8 @@ static int wide_panels(int ld, int* widths, int cap) {
   return n;
 }
 
-// k_mm128's 73.7 KB of dynamic LDS must be granted once PER DEVICE (hipFuncSetAttribute acts on the current device's copy of the function),
-// and bogp_nll runs on several host threads (the helper handles of bogp_nll_batch, the look-ahead of surrogate.py): one bit per device
-// ordinal in an atomic word (r05 had a plain static bool: a second handle on another device would have launched without the grant).
-static hipError_t mm128_grant_lds(int shm) {
-  static std::atomic<unsigned long long> granted{0ull};
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  const unsigned long long bit = (dev >= 0 && dev < 64) ? 1ull << dev : 0ull;  // (ordinals past 63: the attribute is set on every launch)
-  if (bit && (granted.load(std::memory_order_acquire) & bit)) return hipSuccess;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm128), hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-  if (e != hipSuccess) return e;
-  if (bit) granted.fetch_or(bit, std::memory_order_release);
-  return hipSuccess;
-}
-
+// (until r06 k_mm128 needed 73.7 KB of dynamic LDS, granted once per device through an atomic mask -- ADVICE r05; the tile core takes no LDS any more)
 static hipError_t launch_mm128(MmArgs a, int mode, int TI, int TJ, int ny, int nz, hipStream_t st) {
-  constexpr int shm = MM_SHM;
-  if (shm > 0) {
-    hipError_t e = mm128_grant_lds(shm);
-    if (e != hipSuccess) return e;
-  }
   a.TI = TI;
   a.TJ = TJ;
   constexpr int order = 1;  // (the tile orders that lost: tools/ab/ab_mm128_order.sh, EXPERIMENTS.md)
@@ -979,28 +832,23 @@ static hipError_t launch_mm128(MmArgs a, int mode, int TI, int TJ, int ny, int n
                            : (unsigned)((nb2 - a.nl) * a.fp * nb2 + a.nl * (a.fp + (a.nl > 0 ? 1 : 0)) * nb2);
     }
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_mm128, dim3(count, 1, 1), 256, shm, st, a, mode);
+    hipLaunchKernelGGL(k_mm128, dim3(count, 1, 1), 256, 0, st, a, mode);
     return hipGetLastError();
   }
   a.order = 0;
   const int nsuper = ((TI + 7) / 8) * ((TJ + 7) / 8);
-  hipLaunchKernelGGL(k_mm128, dim3((unsigned)(nsuper * 64), ny, nz), 256, shm, st, a, mode);
+  hipLaunchKernelGGL(k_mm128, dim3((unsigned)(nsuper * 64), ny, nz), 256, 0, st, a, mode);
   return hipGetLastError();
 }
 
 hipError_t launch_mm128_gen(const double* Rs, int ldr, const double* Cs, int ldc, double* out, int ldo, int TI, int TJ, int K,
                             hipStream_t st) {
   if (TI <= 0 || TJ <= 0) return hipSuccess;
-  constexpr int shm = MM_SHM;
-  if (shm > 0) {
-    hipError_t e = mm128_grant_lds(shm);
-    if (e != hipSuccess) return e;
-  }
   MmArgs a{};
   a.gR = Rs; a.gC = Cs; a.gO = out;
   a.gldr = ldr; a.gldc = ldc; a.gldo = ldo; a.gK = K;
   a.TI = TI; a.TJ = TJ;
-  hipLaunchKernelGGL(k_mm128, dim3((unsigned)(TI * TJ), 1, 1), 256, shm, st, a, (int)MM_GEN);
+  hipLaunchKernelGGL(k_mm128, dim3((unsigned)(TI * TJ), 1, 1), 256, 0, st, a, (int)MM_GEN);
   return hipGetLastError();
 }
 
