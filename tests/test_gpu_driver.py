@@ -437,6 +437,50 @@ def test_large_fit_path_equals_the_64_block_path(N):
         np.testing.assert_array_equal(out[variant][5], out["one-level"][5])
 
 
+@pytest.mark.parametrize("N,d,trend", [(3300, 3, 1), (3585, 2, 2)])
+def test_large_fit_path_with_a_polynomial_trend_and_the_restricted_likelihood(N, d, trend):
+    """The 128-tile path (every N > 3072 since r06) under a linear / quadratic basis (trend.py:94-142) and for the restricted likelihood
+    (gpr.py:813-918): against the 64-block kernels (BOGP_NO_BIG_FIT=1; the factor, and with it llf / REML / mu, are the same bits) and
+    against the oracle, incl. the posterior of a trend sweep (k_mm128's chunk products)."""
+    import os
+
+    rng = np.random.default_rng(N)
+    X = rng.uniform(-5, 5, size=(N, d))
+    y = np.sum(X**2, axis=1) + X[:, 0]
+    y = ((y - y.mean()) / y.std() + 0.2 * rng.standard_normal(N)).reshape(-1, 1)
+    par = np.r_[np.full(d, 0.3), 0.8]
+    Xs = rng.uniform(-5, 5, size=(777, d))
+    out = {}
+    for tag, flag in (("big", None), ("small", "1")):
+        os.environ.pop("BOGP_NO_BIG_FIT", None)
+        if flag:
+            os.environ["BOGP_NO_BIG_FIT"] = flag
+        try:
+            eng = _lib.Engine(0)
+            eng.set_train(X, y)
+            llf, grad = eng.nll(_lib.KERNEL_MATERN32, _lib.MODE_NOISY, par, 1e-6, True, 0.0, eval_grad=True, trend=trend)
+            rl, rg = eng.nll_restricted(_lib.KERNEL_MATERN32, _lib.MODE_NOISY, par, 1e-6, True, 0.0, eval_grad=True, trend=trend)
+            eng.commit(_lib.KERNEL_MATERN32, _lib.MODE_NOISY, par, 1e-6, True, 0.0, trend=trend)
+            eng.upload_candidates(Xs)
+            mu, mse = eng.predict()
+            out[tag] = (llf, grad, rl, rg, mu, mse)
+            eng.close()
+        finally:
+            os.environ.pop("BOGP_NO_BIG_FIT", None)
+    b, s = out["big"], out["small"]
+    assert b[0] == s[0] and b[2] == s[2]
+    np.testing.assert_array_equal(b[4], s[4])
+    np.testing.assert_allclose(b[1], s[1], rtol=1e-8, atol=1e-9 * np.abs(s[1]).max())
+    np.testing.assert_allclose(b[3], s[3], rtol=1e-8, atol=1e-9 * np.abs(s[3]).max())
+    ollf = float(O.log_likelihood_concentrated(par, X, y, O.KERNEL_MATERN32, O.MODE_NOISY, 1e-6, trend=trend, estimate_trend=True))
+    orl = float(O.log_likelihood_restricted(par, X, y, O.KERNEL_MATERN32, O.MODE_NOISY, 1e-6, trend=trend, estimate_trend=True))
+    np.testing.assert_allclose([b[0], b[2]], [ollf, orl], rtol=1e-9)
+    st = O.make_state(par, X, y, O.KERNEL_MATERN32, O.MODE_NOISY, 1e-6, trend=trend, estimate_trend=True)
+    omu, omse = (np.asarray(v).ravel() for v in O.predict(st, Xs))
+    np.testing.assert_allclose(b[4], omu, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(b[5], omse, rtol=1e-6, atol=1e-12 * float(st.sigma2[0]))
+
+
 def _compare_fit_outputs(b, s):
     np.testing.assert_allclose(b[0], s[0], rtol=1e-11)
     np.testing.assert_allclose(b[2], s[2], rtol=1e-11)
